@@ -1,0 +1,45 @@
+"""Stand-in for the part of ``anemoi.models.data_indices.IndexCollection`` the forward path reads.
+
+The model root only touches ``data_indices.internal_model.{input,output}`` for
+``len()``, ``.prognostic``, ``.full``, ``.diagnostic`` and ``.name_to_index``
+(reference models/encoder_processor_decoder.py:103,108-125).  A real
+``IndexCollection`` can be passed instead; this class exists so tests and
+``bench.py`` need no dataset configuration.
+
+Variable layout: input = [prognostic..., forcing...], output = [prognostic..., diagnostic...].
+"""
+
+from __future__ import annotations
+
+import torch
+
+
+class _ModelIndex:
+    def __init__(self, names, prognostic, diagnostic=(), forcing=()):
+        self.name_to_index = {n: i for i, n in enumerate(names)}
+        self.full = torch.arange(len(names), dtype=torch.int64)
+        self.prognostic = torch.as_tensor(list(prognostic), dtype=torch.int64)
+        self.diagnostic = torch.as_tensor(list(diagnostic), dtype=torch.int64)
+        self.forcing = torch.as_tensor(list(forcing), dtype=torch.int64)
+
+    def __len__(self) -> int:
+        return len(self.name_to_index)
+
+
+class _Internal:
+    def __init__(self, inp, out):
+        self.input = inp
+        self.output = out
+
+
+class SimpleDataIndices:
+    def __init__(self, n_prognostic: int, n_forcing: int = 0, n_diagnostic: int = 0) -> None:
+        prog = [f"prog_{i}" for i in range(n_prognostic)]
+        forc = [f"forc_{i}" for i in range(n_forcing)]
+        diag = [f"diag_{i}" for i in range(n_diagnostic)]
+        inp = _ModelIndex(prog + forc, range(n_prognostic), forcing=range(n_prognostic, n_prognostic + n_forcing))
+        out = _ModelIndex(prog + diag, range(n_prognostic),
+                          diagnostic=range(n_prognostic, n_prognostic + n_diagnostic))
+        self.internal_model = _Internal(inp, out)
+        self.num_input = len(inp)
+        self.num_output = len(out)

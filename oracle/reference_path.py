@@ -1,0 +1,401 @@
+"""Plain-PyTorch CPU restatement of the reference encoder-processor-decoder forward.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Every function follows one reference function (cited as ``file:line`` relative
+to ``/root/reference/src/anemoi/models``) and operates on a reference
+``state_dict`` (same key names) plus plain tensors, so "identical random
+weights" means literally the same dictionary.  No torch_geometric, hydra or
+anemoi.utils imports: their arithmetic is restated in :mod:`oracle.pyg_semantics`.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Mapping, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from .pyg_semantics import bipartite_dst_mask
+from .pyg_semantics import k_hop_edge_mask_directed
+from .pyg_semantics import scatter_sum
+from .pyg_semantics import segment_softmax
+
+SD = Mapping[str, Tensor]
+
+_ACT = {
+    "GELU": lambda t: F.gelu(t),  # nn.GELU() default: exact erf form
+    "SiLU": F.silu,
+    "ReLU": F.relu,
+    "Tanh": torch.tanh,
+    "Sigmoid": torch.sigmoid,
+    "Identity": lambda t: t,
+}
+
+
+def _act(name: str):
+    if name not in _ACT:
+        raise RuntimeError(f"activation {name} not supported by the oracle")
+    return _ACT[name]
+
+
+def _lin(sd: SD, p: str, x: Tensor) -> Tensor:
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def _ln(sd: SD, p: str, x: Tensor) -> Tensor:
+    w = sd[p + ".weight"]
+    return F.layer_norm(x, (w.shape[0],), w, sd[p + ".bias"], 1e-5)
+
+
+# --------------------------------------------------------------------------
+# integer / index helpers (bit-exact)
+# --------------------------------------------------------------------------
+
+
+def expand_edges(edge_index: Tensor, edge_inc: Tensor, batch_size: int) -> Tensor:
+    """layers/mapper.py:150-171 ``GraphEdgeMixin._expand_edges``."""
+    return torch.cat([edge_index + i * edge_inc for i in range(batch_size)], dim=1)
+
+
+def trainable_tensor(x: Tensor, trainable: Optional[Tensor], batch_size: int) -> Tensor:
+    """layers/graph.py:37-44 ``TrainableTensor.forward`` (einops.repeat == Tensor.repeat on dim 0)."""
+    latent = [x.repeat(batch_size, 1)]
+    if trainable is not None:
+        latent.append(trainable.repeat(batch_size, 1))
+    return torch.cat(latent, dim=-1)
+
+
+def get_shape_shards(t: Tensor, dim: int, comm_size: int = 1) -> list:
+    """distributed/shapes.py:19-24."""
+    return [list(x.shape) for x in torch.tensor_split(t, comm_size, dim=dim)]
+
+
+def sort_edges_1hop_chunks(num_nodes, edge_attr: Tensor, edge_index: Tensor, num_chunks: int):
+    """distributed/khop_edges.py:88-130: stable partition of edges by contiguous dst ranges."""
+    n_dst = num_nodes if isinstance(num_nodes, int) else num_nodes[1]
+    node_chunks = torch.arange(n_dst, device=edge_index.device).tensor_split(num_chunks)
+    edge_attr_list, edge_index_list = [], []
+    for chunk in node_chunks:
+        if isinstance(num_nodes, int):
+            mask = k_hop_edge_mask_directed(chunk, edge_index, n_dst)
+        else:
+            mask = bipartite_dst_mask(chunk, edge_index, n_dst)
+        edge_index_list.append(edge_index[:, mask])
+        edge_attr_list.append(edge_attr[mask])
+    return edge_attr_list, edge_index_list
+
+
+# --------------------------------------------------------------------------
+# GraphTransformer conv / blocks
+# --------------------------------------------------------------------------
+
+
+def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index: Tensor, n_dst: int) -> Tensor:
+    """layers/conv.py:98-142 ``GraphTransformerConv`` (+ PyG propagate, flow source_to_target).
+
+    query [N_dst,H,D], key/value [N_src,H,D], edges [E,H,D], edge_index int64 [2,E]
+    (row 0 = src ``j``, row 1 = dst ``i``).
+    """
+    src, dst = edge_index[0], edge_index[1]
+    d = query.shape[-1]
+    query_i = query.index_select(0, dst)
+    key_j = key.index_select(0, src) + edges  # conv.py:134-135
+    value_j = value.index_select(0, src)
+    alpha = (query_i * key_j).sum(dim=-1) / d**0.5  # conv.py:137
+    alpha = segment_softmax(alpha, dst, n_dst)  # conv.py:139
+    msg = (value_j + edges) * alpha.unsqueeze(-1)  # conv.py:142 (dropout p=0)
+    return scatter_sum(msg, dst, n_dst)  # aggr="add", conv.py:92
+
+
+def _gt_tail(sd: SD, p: str, out: Tensor, x_r: Tensor, x_skip: Tensor, act: str, num_chunks: int = 1) -> Tensor:
+    """projection(out + x_r) + skip; node_dst_mlp(.) + .  (block.py:530-538 / :630-633)."""
+    a = _act(act)
+    out = torch.cat([_lin(sd, p + ".projection", c) for c in torch.tensor_split(out + x_r, num_chunks, dim=0)], dim=0)
+    out = out + x_skip
+    res = []
+    for c in out.tensor_split(num_chunks, dim=0):
+        h = _ln(sd, p + ".node_dst_mlp.0", c)
+        h = a(_lin(sd, p + ".node_dst_mlp.1", h))
+        res.append(_lin(sd, p + ".node_dst_mlp.3", h) + c)
+    return torch.cat(res, dim=0)
+
+
+def gt_processor_block(
+    sd: SD, p: str, x: Tensor, edge_attr: Tensor, edge_index: Tensor, num_heads: int, act: str = "GELU"
+) -> Tensor:
+    """layers/block.py:602-635 ``GraphTransformerProcessorBlock.forward`` (no comm group)."""
+    n, c = x.shape
+    d = sd[p + ".lin_query.weight"].shape[0] // num_heads
+    x_skip = x
+    xh = _ln(sd, p + ".layer_norm1", x)
+    x_r = _lin(sd, p + ".lin_self", xh)
+    q = _lin(sd, p + ".lin_query", xh).view(n, num_heads, d)
+    k = _lin(sd, p + ".lin_key", xh).view(n, num_heads, d)
+    v = _lin(sd, p + ".lin_value", xh).view(n, num_heads, d)
+    e = _lin(sd, p + ".lin_edge", edge_attr).view(-1, num_heads, d)
+    out = gt_conv(q, k, v, e, edge_index, n).reshape(n, num_heads * d)
+    return _gt_tail(sd, p, out, x_r, x_skip, act)
+
+
+def gt_mapper_block(
+    sd: SD,
+    p: str,
+    x_src: Tensor,
+    x_dst: Tensor,
+    edge_attr: Tensor,
+    edge_index: Tensor,
+    num_heads: int,
+    act: str = "GELU",
+    num_chunks: int = 1,
+) -> Tensor:
+    """layers/block.py:479-550 ``GraphTransformerMapperBlock.forward`` (update_src_nodes=False).
+
+    ``num_chunks`` > 1 follows the inference chunking branch (block.py:508-524):
+    edges partitioned by contiguous dst ranges, conv per chunk, results summed.
+    Returns the new dst nodes (src nodes are returned unchanged by the reference).
+    """
+    n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+    d = sd[p + ".lin_query.weight"].shape[0] // num_heads
+    xs = _ln(sd, p + ".layer_norm1", x_src)
+    xd = _ln(sd, p + ".layer_norm2", x_dst)
+    x_r = _lin(sd, p + ".lin_self", xd)
+    q = _lin(sd, p + ".lin_query", xd).view(n_dst, num_heads, d)
+    k = _lin(sd, p + ".lin_key", xs).view(n_src, num_heads, d)
+    v = _lin(sd, p + ".lin_value", xs).view(n_src, num_heads, d)
+    e = _lin(sd, p + ".lin_edge", edge_attr).view(-1, num_heads, d)
+    if num_chunks > 1:
+        ea_list, ei_list = sort_edges_1hop_chunks((n_src, n_dst), e, edge_index, num_chunks)
+        out = torch.zeros((n_dst, num_heads, d))
+        for ea, ei in zip(ea_list, ei_list):
+            out += gt_conv(q, k, v, ea, ei, n_dst)
+    else:
+        out = gt_conv(q, k, v, e, edge_index, n_dst)
+    out = out.reshape(n_dst, num_heads * d)
+    return _gt_tail(sd, p, out, x_r, x_dst, act, num_chunks)
+
+
+def gt_forward_mapper(
+    sd: SD, p: str, x_src: Tensor, x_dst: Tensor, edge_attr_buf: Tensor, edge_index_base: Tensor,
+    batch_size: int, num_heads: int, act: str = "GELU", num_chunks: int = 1,
+):
+    """layers/mapper.py:275-345 + :245-272 + :108-116 ``GraphTransformerForwardMapper.forward``."""
+    edge_attr = trainable_tensor(edge_attr_buf, sd.get(p + ".trainable.trainable"), batch_size)
+    edge_index = expand_edges(edge_index_base, sd[p + ".edge_inc"], batch_size)
+    xs = _lin(sd, p + ".emb_nodes_src", x_src)
+    xd = _lin(sd, p + ".emb_nodes_dst", x_dst)
+    out = gt_mapper_block(sd, p + ".proc", xs, xd, edge_attr, edge_index, num_heads, act, num_chunks)
+    return x_src, out  # mapper.py:344-345: raw src tensor is handed back
+
+
+def gt_backward_mapper(
+    sd: SD, p: str, x_src: Tensor, x_dst: Tensor, edge_attr_buf: Tensor, edge_index_base: Tensor,
+    batch_size: int, num_heads: int, act: str = "GELU", num_chunks: int = 1,
+) -> Tensor:
+    """layers/mapper.py:348-418 + :96-102 ``GraphTransformerBackwardMapper.forward``."""
+    edge_attr = trainable_tensor(edge_attr_buf, sd.get(p + ".trainable.trainable"), batch_size)
+    edge_index = expand_edges(edge_index_base, sd[p + ".edge_inc"], batch_size)
+    xd = _lin(sd, p + ".emb_nodes_dst", x_dst)  # mapper.py:412-418: only dst is embedded
+    out = gt_mapper_block(sd, p + ".proc", x_src, xd, edge_attr, edge_index, num_heads, act, num_chunks)
+    out = _ln(sd, p + ".node_data_extractor.0", out)
+    return _lin(sd, p + ".node_data_extractor.1", out)
+
+
+def gt_processor(
+    sd: SD, p: str, x: Tensor, edge_attr_buf: Tensor, edge_index_base: Tensor, batch_size: int,
+    num_layers: int, num_chunks: int, num_heads: int, act: str = "GELU", return_all: bool = False,
+):
+    """layers/processor.py:317-343 + layers/chunk.py:225-238 ``GraphTransformerProcessor.forward``."""
+    edge_attr = trainable_tensor(edge_attr_buf, sd.get(p + ".trainable.trainable"), batch_size)
+    edge_index = expand_edges(edge_index_base, sd[p + ".edge_inc"], batch_size)
+    per_chunk = num_layers // num_chunks
+    outs = []
+    for c in range(num_chunks):
+        for b in range(per_chunk):
+            x = gt_processor_block(sd, f"{p}.proc.{c}.blocks.{b}", x, edge_attr, edge_index, num_heads, act)
+            outs.append(x)
+    return (x, outs) if return_all else x
+
+
+# --------------------------------------------------------------------------
+# GNN (edge-MLP message passing) path
+# --------------------------------------------------------------------------
+
+
+def mlp(sd: SD, p: str, x: Tensor, act: str = "SiLU", n_extra_layers: int = 0, layer_norm: bool = True,
+        final_activation: bool = False) -> Tensor:
+    """layers/mlp.py:74-89 ``MLP``: Linear,act,(Linear,act)x(extra+1),Linear,[act],[LayerNorm]."""
+    a = _act(act)
+    idx = 0
+    x = a(_lin(sd, f"{p}.model.{idx}", x))
+    idx += 2
+    for _ in range(n_extra_layers + 1):
+        x = a(_lin(sd, f"{p}.model.{idx}", x))
+        idx += 2
+    x = _lin(sd, f"{p}.model.{idx}", x)
+    idx += 1
+    if final_activation:
+        x = a(x)
+        idx += 1
+    if layer_norm:
+        x = _ln(sd, f"{p}.model.{idx}", x)
+    return x
+
+
+def gnn_conv(sd: SD, p: str, x_src: Tensor, x_dst: Tensor, edge_attr: Tensor, edge_index: Tensor,
+             act: str = "SiLU", n_extra_layers: int = 0):
+    """layers/conv.py:61-76 ``GraphConv``: e' = MLP(cat[x_i, x_j, e]) + e ; out = scatter_sum_dst(e')."""
+    x_i = x_dst.index_select(0, edge_index[1])
+    x_j = x_src.index_select(0, edge_index[0])
+    edges_new = mlp(sd, p + ".edge_mlp", torch.cat([x_i, x_j, edge_attr], dim=1), act, n_extra_layers) + edge_attr
+    return scatter_sum(edges_new, edge_index[1], x_dst.shape[0]), edges_new
+
+
+def gnn_processor_block(sd: SD, p: str, x: Tensor, edge_attr: Tensor, edge_index: Tensor, act: str = "SiLU",
+                        n_extra_layers: int = 0):
+    """layers/block.py:193-223 ``GraphConvProcessorBlock.forward`` (num_chunks=1, no comm group)."""
+    out, edges_new = gnn_conv(sd, p + ".conv", x, x, edge_attr, edge_index, act, n_extra_layers)
+    nodes_new = mlp(sd, p + ".node_mlp", torch.cat([x, out], dim=1), act, n_extra_layers) + x
+    return nodes_new, edges_new
+
+
+def gnn_processor(sd: SD, p: str, x: Tensor, edge_attr_buf: Tensor, edge_index_base: Tensor, batch_size: int,
+                  num_layers: int, num_chunks: int, act: str = "SiLU", n_extra_layers: int = 0) -> Tensor:
+    """layers/processor.py:228-250 + layers/chunk.py:165-181 ``GNNProcessor.forward``."""
+    edge_attr = trainable_tensor(edge_attr_buf, sd.get(p + ".trainable.trainable"), batch_size)
+    edge_index = expand_edges(edge_index_base, sd[p + ".edge_inc"], batch_size)
+    per_chunk = num_layers // num_chunks
+    for c in range(num_chunks):
+        x = x * 1.0
+        if c == 0:
+            edge_attr = mlp(sd, f"{p}.proc.0.emb_edges", edge_attr, act, n_extra_layers)
+        for b in range(per_chunk):
+            x, edge_attr = gnn_processor_block(sd, f"{p}.proc.{c}.blocks.{b}", x, edge_attr, edge_index, act,
+                                               n_extra_layers)
+    return x
+
+
+# --------------------------------------------------------------------------
+# Transformer (MHSA) path
+# --------------------------------------------------------------------------
+
+
+def mhsa(sd: SD, p: str, x: Tensor, batch_size: int, num_heads: int, window_size: Optional[int] = None) -> Tensor:
+    """layers/attention.py:67-112 ``MultiHeadSelfAttention.forward``.
+
+    ``window_size=None`` is the reference's SDPA fallback (global attention, the
+    window is ignored there, attention.py:99-105).  With an integer window this
+    follows flash-attn's ``window_size=(w, w)`` semantics (attention.py:96):
+    key ``j`` is visible from query ``i`` iff ``|i - j| <= w``.
+    """
+    c = x.shape[1]
+    d = c // num_heads
+    qkv = _lin(sd, p + ".lin_qkv", x)
+    q, k, v = qkv.chunk(3, -1)
+    g = x.shape[0] // batch_size
+
+    def heads(t):
+        return t.reshape(batch_size, g, num_heads, d).permute(0, 2, 1, 3)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
+    if window_size is not None:
+        i = torch.arange(g)
+        mask = (i[:, None] - i[None, :]).abs() <= window_size
+        s = s.masked_fill(~mask, float("-inf"))
+    out = torch.matmul(torch.softmax(s, dim=-1), v)
+    out = out.permute(0, 2, 1, 3).reshape(batch_size * g, c)
+    return _lin(sd, p + ".projection", out)
+
+
+def transformer_block(sd: SD, p: str, x: Tensor, batch_size: int, num_heads: int, act: str = "GELU",
+                      window_size: Optional[int] = None) -> Tensor:
+    """layers/block.py:99-105 ``TransformerProcessorBlock.forward``."""
+    x = x + mhsa(sd, p + ".attention", _ln(sd, p + ".layer_norm1", x), batch_size, num_heads, window_size)
+    h = _act(act)(_lin(sd, p + ".mlp.0", _ln(sd, p + ".layer_norm2", x)))
+    return x + _lin(sd, p + ".mlp.2", h)
+
+
+def transformer_processor(sd: SD, p: str, x: Tensor, batch_size: int, num_layers: int, num_chunks: int,
+                          num_heads: int, act: str = "GELU", window_size: Optional[int] = None) -> Tensor:
+    """layers/processor.py:145-162 + layers/chunk.py:108-114 ``TransformerProcessor.forward``."""
+    per_chunk = num_layers // num_chunks
+    for c in range(num_chunks):
+        for b in range(per_chunk):
+            x = transformer_block(sd, f"{p}.proc.{c}.blocks.{b}", x, batch_size, num_heads, act, window_size)
+    return x
+
+
+# --------------------------------------------------------------------------
+# Model root
+# --------------------------------------------------------------------------
+
+
+def node_attributes(sd: SD, name: str, batch_size: int) -> Tensor:
+    """layers/graph.py:107-113 ``NamedNodesAttributes.forward``."""
+    return trainable_tensor(
+        sd[f"node_attributes.latlons_{name}"],
+        sd.get(f"node_attributes.trainable_tensors.{name}.trainable"),
+        batch_size,
+    )
+
+
+def model_forward(
+    sd: SD,
+    graph: Mapping[str, Tensor],
+    x: Tensor,
+    *,
+    num_heads: int,
+    num_layers: int,
+    num_chunks: int,
+    prognostic_in: Sequence[int],
+    prognostic_out: Sequence[int],
+    processor: str = "GraphTransformer",
+    act: str = "GELU",
+    mapper_chunks: int = 1,
+    data: str = "data",
+    hidden: str = "hidden",
+    gnn_act: str = "SiLU",
+    window_size: Optional[int] = None,
+    return_stages: bool = False,
+):
+    """models/encoder_processor_decoder.py:168-233 ``AnemoiModelEncProcDec.forward`` (no boundings).
+
+    ``graph`` holds ``enc_edge_index``/``enc_edge_attr`` (data->hidden),
+    ``proc_edge_index``/``proc_edge_attr`` (hidden->hidden) and
+    ``dec_edge_index``/``dec_edge_attr`` (hidden->data): the non-persistent
+    buffers ``edge_index_base`` / ``edge_attr`` of layers/mapper.py:141-148.
+    """
+    b, t, ens, g, v = x.shape
+    x_data = torch.cat(
+        (x.permute(0, 2, 3, 1, 4).reshape(b * ens * g, t * v), node_attributes(sd, data, b)), dim=-1
+    )  # :173-179
+    x_hidden = node_attributes(sd, hidden, b)  # :181
+
+    x_data_latent, x_latent = gt_forward_mapper(
+        sd, "encoder", x_data, x_hidden, graph["enc_edge_attr"], graph["enc_edge_index"], b, num_heads, act,
+        mapper_chunks,
+    )  # :188-194
+    if processor == "GraphTransformer":
+        x_proc = gt_processor(sd, "processor", x_latent, graph["proc_edge_attr"], graph["proc_edge_index"], b,
+                              num_layers, num_chunks, num_heads, act)
+    elif processor == "GNN":
+        x_proc = gnn_processor(sd, "processor", x_latent, graph["proc_edge_attr"], graph["proc_edge_index"], b,
+                               num_layers, num_chunks, gnn_act)
+    elif processor == "Transformer":
+        x_proc = transformer_processor(sd, "processor", x_latent, b, num_layers, num_chunks, num_heads, act,
+                                       window_size)
+    else:
+        raise ValueError(processor)
+    x_latent_proc = x_proc + x_latent  # :204
+    x_out = gt_backward_mapper(
+        sd, "decoder", x_latent_proc, x_data_latent, graph["dec_edge_attr"], graph["dec_edge_index"], b, num_heads,
+        act, mapper_chunks,
+    )  # :207-213
+    x_out = x_out.reshape(b, ens, g, -1).to(x.dtype).clone()  # :215-224
+    x_out[..., list(prognostic_out)] += x[:, -1, :, :, list(prognostic_in)]  # :227
+    if return_stages:
+        return x_out, {"x_latent": x_latent, "x_proc": x_proc}
+    return x_out

@@ -1,0 +1,249 @@
+"""Generate the golden vectors under ``tests/golden/`` from the REAL reference sources.
+
+Run in the build container only (needs ``/root/reference``)::
+
+    python tests/golden/make_golden.py
+
+It imports ``/root/reference/src/anemoi/models`` unchanged through the stand-ins of
+``_ref_stubs.py`` (torch_geometric / hydra / anemoi.utils are not installed here),
+runs the reference modules on seeded inputs in fp32 on CPU and stores inputs,
+weights (the reference ``state_dict``) and outputs as ``.npz`` fixtures.  Only
+data is written: no reference source text ends up in this repository.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_stubs  # noqa: E402
+
+_ref_stubs.install("/root/reference/src")
+
+from anemoi.models.distributed.khop_edges import sort_edges_1hop_chunks  # noqa: E402
+from anemoi.models.layers.attention import MultiHeadSelfAttention  # noqa: E402
+from anemoi.models.layers.block import GraphConvProcessorBlock  # noqa: E402
+from anemoi.models.layers.block import GraphTransformerMapperBlock  # noqa: E402
+from anemoi.models.layers.block import GraphTransformerProcessorBlock  # noqa: E402
+from anemoi.models.layers.block import TransformerProcessorBlock  # noqa: E402
+from anemoi.models.layers.mapper import GraphEdgeMixin  # noqa: E402
+from anemoi.models.models.encoder_processor_decoder import AnemoiModelEncProcDec  # noqa: E402
+
+from anemoi_models_amd.graphs.synthetic import build_graph  # noqa: E402
+from anemoi_models_amd.utils.indices import SimpleDataIndices  # noqa: E402
+
+EDGE_ATTRS = ["edge_length", "edge_dirs"]
+
+
+def randomise(module: torch.nn.Module, seed: int) -> None:
+    """Non-default LN affine and non-zero trainable tensors so that every term of the path is exercised."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name.endswith("trainable"):
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.1)
+        for m in module.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+
+
+def to_ref_graph(g):
+    ref = _ref_stubs.HeteroData()
+    for name, store in g.node_items():
+        ref[name].x = store.x
+    for key, store in g.edge_items():
+        for k, v in store.items():
+            ref[key][k] = v
+    return ref
+
+
+def model_config(processor: str, channels: int, layers: int, heads: int):
+    common = {"sub_graph_edge_attributes": EDGE_ATTRS, "trainable_size": 8}
+    mapper = {"activation": "GELU", "num_chunks": 1, "mlp_hidden_ratio": 4, "num_heads": heads, **common}
+    procs = {
+        "GraphTransformer": {
+            "_target_": "anemoi.models.layers.processor.GraphTransformerProcessor",
+            "activation": "GELU", "num_layers": layers, "num_chunks": 2, "mlp_hidden_ratio": 4,
+            "num_heads": heads, **common,
+        },
+        "GNN": {
+            "_target_": "anemoi.models.layers.processor.GNNProcessor",
+            "activation": "SiLU", "num_layers": layers, "num_chunks": 2, "mlp_extra_layers": 0, **common,
+        },
+        "Transformer": {
+            "_target_": "anemoi.models.layers.processor.TransformerProcessor",
+            "activation": "GELU", "num_layers": layers, "num_chunks": 2, "mlp_hidden_ratio": 4,
+            "num_heads": heads, "window_size": 512, "dropout_p": 0.0,
+        },
+    }
+    return _ref_stubs.DotDict(
+        {
+            "graph": {"data": "data", "hidden": "hidden"},
+            "training": {"multistep_input": 2},
+            "model": {
+                "num_channels": channels,
+                "trainable_parameters": {"data": 8, "hidden": 8},
+                "encoder": {"_target_": "anemoi.models.layers.mapper.GraphTransformerForwardMapper", **mapper},
+                "processor": procs[processor],
+                "decoder": {"_target_": "anemoi.models.layers.mapper.GraphTransformerBackwardMapper", **mapper},
+            },
+        }
+    )
+
+
+def golden_model(processor: str, fname: str, graph_name: str = "o32_ico2", channels: int = 64, layers: int = 4,
+                 heads: int = 16, n_prog: int = 10, n_forc: int = 2, n_diag: int = 1) -> dict:
+    g = build_graph(graph_name)
+    idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
+    torch.manual_seed(1234)
+    model = AnemoiModelEncProcDec(model_config=model_config(processor, channels, layers, heads), data_indices=idx,
+                                  graph_data=to_ref_graph(g))
+    randomise(model, 4321)
+    model.eval()
+    n_grid = g["data"].num_nodes
+    x = torch.randn((1, 2, 1, n_grid, idx.num_input), generator=torch.Generator().manual_seed(7))
+
+    stages = {}
+
+    def hook(name):
+        def fn(_m, _inp, out):
+            stages[name] = (out[1] if name == "encoder" else out[0] if isinstance(out, tuple) else out).detach().clone()
+        return fn
+
+    handles = [model.encoder.register_forward_hook(hook("encoder"))]
+    nb = 0
+    for c, chunk in enumerate(model.processor.proc):
+        for b, blk in enumerate(chunk.blocks):
+            handles.append(blk.register_forward_hook(hook(f"block{nb}")))
+            nb += 1
+    handles.append(model.processor.register_forward_hook(hook("processor")))
+    with torch.no_grad():
+        y = model(x)
+    for h in handles:
+        h.remove()
+
+    sd = model.state_dict()
+    out = {"x": x.numpy(), "y": y.numpy()}
+    out.update({f"stage.{k}": v.numpy() for k, v in stages.items()})
+    out.update({f"sd.{k}": v.numpy() for k, v in sd.items()})
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "params", sum(p.numel() for p in model.parameters()), "y", tuple(y.shape), "|y|max", float(y.abs().max()))
+    return {k: list(v.shape) for k, v in sd.items()}
+
+
+def golden_blocks() -> None:
+    gen = torch.Generator().manual_seed(99)
+    out = {}
+
+    def rnd(*shape):
+        return torch.randn(shape, generator=gen)
+
+    # --- GraphTransformerProcessorBlock: 150 nodes, 700 edges, C=128, H=16 (D=8), edge_dim 11
+    n, e, c, h = 150, 700, 128, 16
+    torch.manual_seed(11)
+    blk = GraphTransformerProcessorBlock(c, 4 * c, c, edge_dim=11, num_heads=h, activation="GELU")
+    randomise(blk, 12)
+    blk.eval()
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[1, :40] = 3  # one destination with in-degree >= 40
+    ei[1][ei[1] == 7] = 8  # node 7 is an isolated destination
+    x, ea = rnd(n, c), rnd(e, 11)
+    with torch.no_grad():
+        y, _ = blk(x, ea, ei, (None, None, None), 1, size=None)
+    out.update({"gtp.x": x, "gtp.edge_attr": ea, "gtp.edge_index": ei, "gtp.y": y})
+    out.update({f"gtp.sd.{k}": v for k, v in blk.state_dict().items()})
+
+    # --- GraphTransformerMapperBlock: N_src 180 != N_dst 90, C=64, H=16 (D=4), edge_dim 11, chunked == unchunked
+    ns, nd, e, c, h = 180, 90, 500, 64, 16
+    torch.manual_seed(13)
+    mb = GraphTransformerMapperBlock(c, 4 * c, c, edge_dim=11, num_heads=h, activation="GELU")
+    randomise(mb, 14)
+    mb.eval()
+    ei = torch.stack([torch.randint(0, ns, (e,), generator=gen), torch.randint(0, nd, (e,), generator=gen)])
+    ei[1, :35] = 5
+    ei[1][ei[1] == 11] = 12  # isolated destination
+    xs, xd, ea = rnd(ns, c), rnd(nd, c), rnd(e, 11)
+    with torch.no_grad():
+        (ys, yd), _ = mb((xs, xd), ea, ei, (None, None, None), 1, size=(ns, nd))
+    assert torch.equal(ys, xs)
+    out.update({"gtm.x_src": xs, "gtm.x_dst": xd, "gtm.edge_attr": ea, "gtm.edge_index": ei, "gtm.y_dst": yd})
+    out.update({f"gtm.sd.{k}": v for k, v in mb.state_dict().items()})
+
+    # --- GraphConvProcessorBlock (GNN): 120 nodes, 400 edges, C=64
+    n, e, c = 120, 400, 64
+    torch.manual_seed(15)
+    gb = GraphConvProcessorBlock(c, c, mlp_extra_layers=0, activation="SiLU")
+    randomise(gb, 16)
+    gb.eval()
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    x, ea = rnd(n, c), rnd(e, c)
+    with torch.no_grad():
+        y, e_new = gb(x, ea, ei, (None, None), None, size=None)
+    out.update({"gnn.x": x, "gnn.edge_attr": ea, "gnn.edge_index": ei, "gnn.y": y, "gnn.edges_new": e_new})
+    out.update({f"gnn.sd.{k}": v for k, v in gb.state_dict().items()})
+
+    # --- TransformerProcessorBlock / MHSA (SDPA fallback = global attention): 2 x 96 tokens, C=64, H=8
+    bsz, g, c, h = 2, 96, 64, 8
+    torch.manual_seed(17)
+    tb = TransformerProcessorBlock(c, 4 * c, h, "GELU", window_size=16, dropout_p=0.0)
+    randomise(tb, 18)
+    tb.eval()
+    x = rnd(bsz * g, c)
+    with torch.no_grad():
+        y = tb(x, [[bsz * g, c]], bsz)
+        att = tb.attention(x, [[bsz * g, c]], bsz)
+    assert isinstance(tb.attention, MultiHeadSelfAttention)
+    out.update({"tfm.x": x, "tfm.y": y, "tfm.att": att})
+    out.update({f"tfm.sd.{k}": v for k, v in tb.state_dict().items()})
+
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **{k: v.numpy() for k, v in out.items()})
+    print("blocks.npz", len(out), "arrays")
+
+
+def golden_index_ops() -> None:
+    gen = torch.Generator().manual_seed(5)
+    out = {}
+    # homogeneous graph (int num_nodes -> k_hop_subgraph branch), 5 chunks of 53 nodes (uneven tensor_split)
+    n, e = 53, 400
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ea = torch.randn((e, 3), generator=gen)
+    attr_l, idx_l = sort_edges_1hop_chunks(n, ea, ei, 5)
+    out.update({"homo.edge_index": ei, "homo.edge_attr": ea})
+    for i, (a, b) in enumerate(zip(attr_l, idx_l)):
+        out[f"homo.attr{i}"], out[f"homo.index{i}"] = a, b
+    # bipartite graph (tuple num_nodes -> bipartite_subgraph branch), 4 chunks
+    ns, nd, e = 70, 31, 300
+    ei = torch.stack([torch.randint(0, ns, (e,), generator=gen), torch.randint(0, nd, (e,), generator=gen)])
+    ea = torch.randn((e, 2), generator=gen)
+    attr_l, idx_l = sort_edges_1hop_chunks((ns, nd), ea, ei, 4)
+    out.update({"bip.edge_index": ei, "bip.edge_attr": ea})
+    for i, (a, b) in enumerate(zip(attr_l, idx_l)):
+        out[f"bip.attr{i}"], out[f"bip.index{i}"] = a, b
+    # _expand_edges for batch 3
+    inc = torch.tensor([[ns], [nd]], dtype=torch.int64)
+    out["expand.edge_index"] = ei
+    out["expand.out"] = GraphEdgeMixin()._expand_edges(ei, inc, 3)
+    np.savez_compressed(os.path.join(HERE, "index_ops.npz"), **{k: v.numpy() for k, v in out.items()})
+    print("index_ops.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    keys = {
+        "GraphTransformer": golden_model("GraphTransformer", "cfg1_gt.npz"),
+        "GNN": golden_model("GNN", "cfg1_gnn.npz"),
+        "Transformer": golden_model("Transformer", "cfg1_tfm.npz"),
+    }
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    golden_blocks()
+    golden_index_ops()
