@@ -1,0 +1,81 @@
+"""Build ``libanemoi_amd.so`` (the C-ABI kernel library) for gfx950 with hipcc, in-tree.
+
+``hipcc`` cross-compiles without a GPU, so this runs in the build container; the resulting
+``anemoi_models_amd/lib/libanemoi_amd.so`` travels with the tree to the GPU box.
+"""
+
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libanemoi_amd.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build the gfx950 kernel library")
+    return exe
+
+
+def sources() -> list:
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _deps() -> list:
+    return sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(
+        os.path.join(os.path.dirname(PKG_DIR), "include", "*.h")
+    )
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(f) > t for f in _deps())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every ``csrc/*.hip`` for gfx950 and link the shared library.  Returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(os.path.join(LIB_DIR, "obj"), exist_ok=True)
+    hipcc = _hipcc()
+    hdr_time = max(os.path.getmtime(f) for f in _deps() if not f.endswith(".hip"))
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(LIB_DIR, "obj", os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
+            return obj
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr}")
+        if verbose and res.stderr.strip():
+            print(res.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(sources()) or 1)) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc link failed:\n{res.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    import sys
+
+    print(build(force="--force" in sys.argv, verbose=True))

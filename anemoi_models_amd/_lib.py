@@ -1,0 +1,98 @@
+"""ctypes binding of ``libanemoi_amd.so`` -- the C ABI declared in ``include/anemoi_amd.h``.
+
+There is no CPU fallback: if the library is missing or a kernel call fails the caller gets an
+exception.  The product path never routes through ``oracle/``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p
+from ctypes import c_float
+from ctypes import c_int
+from ctypes import c_int64
+from ctypes import c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libanemoi_amd.so")
+
+ANEMOI_OK = 0
+ANEMOI_ERR_INVALID = 1
+ANEMOI_ERR_UNSUPPORTED = 2
+ANEMOI_ERR_LAUNCH = 3
+
+F32 = 0
+BF16 = 1
+
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
+ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
+
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    "anemoi_abi_version": (c_int, []),
+    "anemoi_last_error": (c_char_p, []),
+    "anemoi_layer_norm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                  c_float, c_void_p]),
+    "anemoi_linear": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                              c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "anemoi_edge_attr_csr": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int64,
+                                     c_void_p]),
+    "anemoi_gt_edge_attention": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int64, c_int64, c_int, c_int, c_void_p]),
+    "anemoi_assemble_nodes": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_int,
+                                      c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "anemoi_prognostic_residual": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,
+                                           c_void_p, c_int, c_void_p]),
+    "anemoi_convert_pad": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "anemoi_add": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class KernelLibraryMissing(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = False) -> ctypes.CDLL:
+    """Load the kernel library (once).  Raises :class:`KernelLibraryMissing` if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from ._build import build
+
+            build()
+        else:
+            raise KernelLibraryMissing(
+                f"{LIB_PATH} not found: the HIP kernel library has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch between header and library
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.anemoi_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libanemoi_amd.so ABI version {got} != expected {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    """Map a C status code to the exception type the reference raises in the same situation."""
+    if status == ANEMOI_OK:
+        return
+    msg = load().anemoi_last_error()
+    msg = msg.decode() if msg else what
+    if status == ANEMOI_ERR_INVALID:
+        raise ValueError(msg)
+    if status == ANEMOI_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,163 @@
+// Shared device/host helpers for the gfx950 forward-path kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/anemoi_amd.h"
+
+namespace anemoi {
+
+// ---------------------------------------------------------------- error reporting
+inline char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ANEMOI_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return ANEMOI_OK;
+}
+
+#define ANEMOI_REQUIRE(cond, code, ...) \
+  do {                                  \
+    if (!(cond)) return ::anemoi::fail(code, __VA_ARGS__); \
+  } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> f32
+typedef uint16_t bf16_t;  // raw storage
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16 cast)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16_t> {
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// Vector load/store of VEC consecutive elements as f32 registers (VEC*sizeof(T) <= 16 bytes, aligned).
+template <typename T, int VEC>
+struct VecIO;
+
+template <int VEC>
+struct VecIO<float, VEC> {
+  static __device__ __forceinline__ void load(const float* p, float (&r)[VEC]) {
+    if constexpr (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(p);
+      r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    } else if constexpr (VEC == 2) {
+      float2 t = *reinterpret_cast<const float2*>(p);
+      r[0] = t.x; r[1] = t.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = p[i];
+    }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&r)[VEC]) {
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    } else if constexpr (VEC == 2) {
+      *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) p[i] = r[i];
+    }
+  }
+};
+
+template <int VEC>
+struct VecIO<bf16_t, VEC> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&r)[VEC]) {
+    if constexpr (VEC == 8) {
+      uint4 t = *reinterpret_cast<const uint4*>(p);
+      uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        r[2 * i] = __uint_as_float(w[i] << 16);
+        r[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+      }
+    } else if constexpr (VEC == 4) {
+      uint2 t = *reinterpret_cast<const uint2*>(p);
+      r[0] = __uint_as_float(t.x << 16); r[1] = __uint_as_float(t.x & 0xffff0000u);
+      r[2] = __uint_as_float(t.y << 16); r[3] = __uint_as_float(t.y & 0xffff0000u);
+    } else if constexpr (VEC == 2) {
+      uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+      r[0] = __uint_as_float(t << 16); r[1] = __uint_as_float(t & 0xffff0000u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = bf16_to_f32(p[i]);
+    }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&r)[VEC]) {
+    if constexpr (VEC == 8) {
+      *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]),
+                                                pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7]));
+    } else if constexpr (VEC == 4) {
+      *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]));
+    } else if constexpr (VEC == 2) {
+      *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(r[0], r[1]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) p[i] = f32_to_bf16(r[i]);
+    }
+  }
+};
+
+// ---------------------------------------------------------------- wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// sum over aligned groups of `width` consecutive lanes (width = power of two <= 64)
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case ANEMOI_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case ANEMOI_ACT_SILU: return x / (1.0f + __expf(-x));
+    case ANEMOI_ACT_RELU: return x > 0.f ? x : 0.f;
+    default: return x;
+  }
+}
+
+inline hipStream_t as_stream(anemoi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace anemoi

@@ -1,0 +1,328 @@
+// HBM-bound row kernels of the forward path: LayerNorm, input assembly, edge-attribute CSR gather,
+// dtype conversion / K-padding, elementwise add and the prognostic residual.
+//
+// All of them are streaming kernels: one pass over the data, 16-byte accesses per lane where the
+// layout allows, one wave64 per row (LayerNorm) or a flat grid-stride mapping.
+#include "common.hpp"
+
+namespace anemoi {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row cached in registers (ITEMS x VEC values per lane).
+// Two-pass statistics in f32 (mean, then centred sum of squares) -- same formula as ATen's CPU
+// kernel up to summation order.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, int ITEMS>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         int64_t ldy, int64_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float v[ITEMS][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int c = (i * 64 + lane) * VEC;
+    if (c < C) {
+      VecIO<T, VEC>::load(xr + c, v[i]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s += v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int c = (i * 64 + lane) * VEC;
+    if (c < C) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  T* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int c = (i * 64 + lane) * VEC;
+    if (c < C) {
+      float g[VEC], b[VEC], o[VEC];
+      VecIO<float, VEC>::load(gamma + c, g);
+      VecIO<float, VEC>::load(beta + c, b);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      VecIO<T, VEC>::store(yr + c, o);
+    }
+  }
+}
+
+// Fallback for very wide or oddly aligned rows: three passes over the (cache-resident) row.
+template <typename T>
+__global__ __launch_bounds__(256) void layer_norm_generic_kernel(const T* __restrict__ x, int64_t ldx,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 T* __restrict__ y, int64_t ldy, int64_t rows,
+                                                                 int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += Elem<T>::load(xr + c);
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = Elem<T>::load(xr + c) - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  T* yr = y + row * ldy;
+  for (int c = lane; c < C; c += 64) Elem<T>::store(yr + c, (Elem<T>::load(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+}
+
+template <typename T>
+static int layer_norm_launch(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                             int64_t rows, int C, float eps, hipStream_t st) {
+  constexpr int VMAX = 16 / sizeof(T);
+  const T* xp = static_cast<const T*>(x);
+  T* yp = static_cast<T*>(y);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const bool aligned = (C % VMAX == 0) && (ldx % VMAX == 0) && (ldy % VMAX == 0) &&
+                       ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+                       ((uintptr_t)beta % 16 == 0);
+  const int per_pass = 64 * VMAX;
+  const int items = (C + per_pass - 1) / per_pass;
+#define LN_CASE(I)                                                                                       \
+  case I:                                                                                                \
+    hipLaunchKernelGGL((layer_norm_kernel<T, VMAX, I>), grid, block, 0, st, xp, ldx, gamma, beta, yp, ldy, \
+                       rows, C, eps);                                                                    \
+    break;
+  if (aligned && items <= 8) {
+    switch (items) {
+      LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+    }
+  } else {
+    hipLaunchKernelGGL((layer_norm_generic_kernel<T>), grid, block, 0, st, xp, ldx, gamma, beta, yp, ldy, rows, C,
+                       eps);
+  }
+#undef LN_CASE
+  return check_launch("anemoi_layer_norm");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Input assembly: out[(b,ens,g), :] = [x[b,:,ens,g,:] (time-major) | latlons[g] | trainable[g] | 0]
+// One thread per output element; consecutive threads write consecutive columns (coalesced store),
+// reads of x are contiguous runs of V floats.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_nodes_kernel(const float* __restrict__ x, int B, int T_, int Ens,
+                                                             int64_t G, int V, const float* __restrict__ latlons,
+                                                             int n_ll, const float* __restrict__ trainable, int n_tr,
+                                                             T* __restrict__ out, int64_t ldo) {
+  const int64_t total = (int64_t)B * Ens * G * ldo;
+  const int tv = T_ * V;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / ldo;
+    const int c = (int)(idx - row * ldo);
+    const int64_t g = row % G;
+    float val = 0.f;
+    if (c < tv) {
+      const int64_t be = row / G;
+      const int e = (int)(be % Ens);
+      const int64_t b = be / Ens;
+      const int t = c / V, v = c - t * V;
+      val = x[((((b * T_ + t) * Ens + e) * G) + g) * V + v];
+    } else if (c < tv + n_ll) {
+      val = latlons[g * n_ll + (c - tv)];
+    } else if (c < tv + n_ll + n_tr) {
+      val = trainable[g * n_tr + (c - tv - n_ll)];
+    }
+    Elem<T>::store(out + idx, val);
+  }
+}
+
+// out[e, :] = [a0[perm[e] % rows0] | a1[perm[e] % rows0] | 0]
+__global__ __launch_bounds__(256) void edge_attr_csr_kernel(const float* __restrict__ a0, int d0,
+                                                            const float* __restrict__ a1, int d1, int64_t rows0,
+                                                            const int32_t* __restrict__ perm, float* __restrict__ out,
+                                                            int ld, int64_t n_edges) {
+  const int64_t total = n_edges * ld;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / ld;
+    const int c = (int)(idx - e * ld);
+    const int64_t src = (int64_t)perm[e] % rows0;
+    float val = 0.f;
+    if (c < d0) val = a0[src * d0 + c];
+    else if (c < d0 + d1) val = a1[src * d1 + (c - d0)];
+    out[idx] = val;
+  }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_pad_kernel(const S* __restrict__ src, int64_t ld_src,
+                                                          D* __restrict__ dst, int64_t ld_dst, int64_t rows,
+                                                          int cols) {
+  const int64_t total = rows * ld_dst;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / ld_dst;
+    const int c = (int)(idx - r * ld_dst);
+    const float val = c < cols ? Elem<S>::load(src + r * ld_src + c) : 0.f;
+    Elem<D>::store(dst + idx, val);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b,
+                                                  int64_t ldb, T* __restrict__ y, int64_t ldy, int64_t rows,
+                                                  int cols) {
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    Elem<T>::store(y + r * ldy + c, Elem<T>::load(a + r * lda + c) + Elem<T>::load(b + r * ldb + c));
+  }
+}
+
+__global__ __launch_bounds__(256) void prognostic_residual_kernel(float* __restrict__ y, int V_out,
+                                                                  const float* __restrict__ x, int B, int T_,
+                                                                  int Ens, int64_t G, int V_in,
+                                                                  const int32_t* __restrict__ out_idx,
+                                                                  const int32_t* __restrict__ in_idx, int n_prog) {
+  const int64_t total = (int64_t)B * Ens * G * n_prog;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / n_prog;  // (b, ens, g)
+    const int p = (int)(idx - row * n_prog);
+    const int64_t g = row % G;
+    const int64_t be = row / G;
+    const int e = (int)(be % Ens);
+    const int64_t b = be / Ens;
+    y[row * V_out + out_idx[p]] += x[((((b * T_ + (T_ - 1)) * Ens + e) * G) + g) * V_in + in_idx[p]];
+  }
+}
+
+static inline unsigned flat_grid(int64_t total) {
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace anemoi
+
+using namespace anemoi;
+
+extern "C" {
+
+int anemoi_layer_norm(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                      int64_t ldy, int64_t rows, int C, float eps, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && y && gamma && beta, ANEMOI_ERR_INVALID, "anemoi_layer_norm: null pointer");
+  ANEMOI_REQUIRE(C > 0 && rows >= 0 && ldx >= C && ldy >= C, ANEMOI_ERR_INVALID,
+                 "anemoi_layer_norm: bad shape rows=%lld C=%d ldx=%lld ldy=%lld", (long long)rows, C, (long long)ldx,
+                 (long long)ldy);
+  if (rows == 0) return ANEMOI_OK;
+  if (dtype == ANEMOI_F32) return layer_norm_launch<float>(x, ldx, gamma, beta, y, ldy, rows, C, eps, as_stream(stream));
+  if (dtype == ANEMOI_BF16) return layer_norm_launch<bf16_t>(x, ldx, gamma, beta, y, ldy, rows, C, eps, as_stream(stream));
+  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm: dtype %d", dtype);
+}
+
+int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
+                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo,
+                          anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(out && B > 0 && Ens > 0 && G >= 0 && T >= 0 && V >= 0 && n_ll >= 0 && n_tr >= 0, ANEMOI_ERR_INVALID,
+                 "anemoi_assemble_nodes: bad argument");
+  ANEMOI_REQUIRE((x != nullptr) || T * V == 0, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: x is null");
+  ANEMOI_REQUIRE((latlons != nullptr) || n_ll == 0, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: latlons is null");
+  ANEMOI_REQUIRE((trainable != nullptr) || n_tr == 0, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: trainable is null");
+  ANEMOI_REQUIRE(ldo >= (int64_t)T * V + n_ll + n_tr, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: ldo too small");
+  const int64_t total = (int64_t)B * Ens * G * ldo;
+  if (total == 0) return ANEMOI_OK;
+  hipStream_t st = as_stream(stream);
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((assemble_nodes_kernel<float>), dim3(flat_grid(total)), dim3(256), 0, st, x, B, T, Ens, G, V,
+                       latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((assemble_nodes_kernel<bf16_t>), dim3(flat_grid(total)), dim3(256), 0, st, x, B, T, Ens, G, V,
+                       latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_assemble_nodes: dtype %d", dtype);
+  return check_launch("anemoi_assemble_nodes");
+}
+
+int anemoi_edge_attr_csr(const float* a0, int d0, const float* a1, int d1, int64_t rows0, const int32_t* perm,
+                         float* out, int ld_out, int64_t n_edges, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(a0 && perm && out && d0 > 0 && d1 >= 0 && rows0 > 0 && n_edges >= 0, ANEMOI_ERR_INVALID,
+                 "anemoi_edge_attr_csr: bad argument");
+  ANEMOI_REQUIRE((a1 != nullptr) || d1 == 0, ANEMOI_ERR_INVALID, "anemoi_edge_attr_csr: a1 is null but d1 > 0");
+  ANEMOI_REQUIRE(ld_out >= d0 + d1, ANEMOI_ERR_INVALID, "anemoi_edge_attr_csr: ld_out %d < %d", ld_out, d0 + d1);
+  if (n_edges == 0) return ANEMOI_OK;
+  hipLaunchKernelGGL(edge_attr_csr_kernel, dim3(flat_grid(n_edges * ld_out)), dim3(256), 0, as_stream(stream), a0, d0,
+                     a1, d1, rows0, perm, out, ld_out, n_edges);
+  return check_launch("anemoi_edge_attr_csr");
+}
+
+int anemoi_convert_pad(int src_dtype, const void* src, int64_t ld_src, int dst_dtype, void* dst, int64_t ld_dst,
+                       int64_t rows, int cols, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(src && dst && rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols, ANEMOI_ERR_INVALID,
+                 "anemoi_convert_pad: bad argument");
+  if (rows == 0 || ld_dst == 0) return ANEMOI_OK;
+  hipStream_t st = as_stream(stream);
+  dim3 grid(flat_grid(rows * ld_dst)), block(256);
+#define CP(S, D)                                                                                           \
+  hipLaunchKernelGGL((convert_pad_kernel<S, D>), grid, block, 0, st, static_cast<const S*>(src), ld_src, \
+                     static_cast<D*>(dst), ld_dst, rows, cols)
+  if (src_dtype == ANEMOI_F32 && dst_dtype == ANEMOI_F32) CP(float, float);
+  else if (src_dtype == ANEMOI_F32 && dst_dtype == ANEMOI_BF16) CP(float, bf16_t);
+  else if (src_dtype == ANEMOI_BF16 && dst_dtype == ANEMOI_F32) CP(bf16_t, float);
+  else if (src_dtype == ANEMOI_BF16 && dst_dtype == ANEMOI_BF16) CP(bf16_t, bf16_t);
+  else return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_convert_pad: dtypes %d -> %d", src_dtype, dst_dtype);
+#undef CP
+  return check_launch("anemoi_convert_pad");
+}
+
+int anemoi_add(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
+               int cols, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(a && b && y && rows >= 0 && cols >= 0, ANEMOI_ERR_INVALID, "anemoi_add: bad argument");
+  if (rows * cols == 0) return ANEMOI_OK;
+  hipStream_t st = as_stream(stream);
+  dim3 grid(flat_grid(rows * cols)), block(256);
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((add_kernel<float>), grid, block, 0, st, static_cast<const float*>(a), lda,
+                       static_cast<const float*>(b), ldb, static_cast<float*>(y), ldy, rows, cols);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((add_kernel<bf16_t>), grid, block, 0, st, static_cast<const bf16_t*>(a), lda,
+                       static_cast<const bf16_t*>(b), ldb, static_cast<bf16_t*>(y), ldy, rows, cols);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_add: dtype %d", dtype);
+  return check_launch("anemoi_add");
+}
+
+int anemoi_prognostic_residual(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
+                               const int32_t* out_idx, const int32_t* in_idx, int n_prog, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(y && x && B > 0 && T > 0 && Ens > 0 && G >= 0 && n_prog >= 0, ANEMOI_ERR_INVALID,
+                 "anemoi_prognostic_residual: bad argument");
+  ANEMOI_REQUIRE(n_prog == 0 || (out_idx && in_idx), ANEMOI_ERR_INVALID, "anemoi_prognostic_residual: null index");
+  const int64_t total = (int64_t)B * Ens * G * n_prog;
+  if (total == 0) return ANEMOI_OK;
+  hipLaunchKernelGGL(prognostic_residual_kernel, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), y, V_out, x,
+                     B, T, Ens, G, V_in, out_idx, in_idx, n_prog);
+  return check_launch("anemoi_prognostic_residual");
+}
+
+int anemoi_abi_version(void) { return 1; }
+
+const char* anemoi_last_error(void) { return err_buf(); }
+
+}  // extern "C"

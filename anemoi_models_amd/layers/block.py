@@ -1,0 +1,315 @@
+"""Per-layer blocks mirroring reference layers/block.py, executed by the gfx950 kernels.
+
+Class names, constructor kwargs, sub-module names (``state_dict`` keys) and forward signatures follow the
+reference; the forward bodies are launch sequences over ``libanemoi_amd.so``:
+
+GraphTransformerProcessorBlock (reference layers/block.py:602-635), per call
+    LayerNorm -> ONE GEMM for lin_self|lin_query|lin_key|lin_value -> fused edge attention (+ x_r)
+    -> projection GEMM (+ x skip in the epilogue) -> LayerNorm -> GEMM+GELU -> GEMM (+ residual).
+GraphTransformerMapperBlock (reference layers/block.py:479-550)
+    same with separate source / destination node sets (k|v from the sources, self|q from the destinations).
+"""
+
+from __future__ import annotations
+
+import os
+from abc import ABC
+from abc import abstractmethod
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch import nn
+
+from .. import ops
+from .. import runtime
+from ..runtime import EdgePlan
+from .conv import GraphConv
+from .conv import GraphTransformerConv
+from .mlp import MLP
+from .mlp import NativeSequential
+from .mlp import activation_class
+
+
+def inference_num_chunks() -> int:
+    """``ANEMOI_INFERENCE_NUM_CHUNKS`` (reference layers/block.py:38-39), read at call time."""
+    return int(os.environ.get("ANEMOI_INFERENCE_NUM_CHUNKS", "1"))
+
+
+def _group_size(group) -> int:
+    return 1 if group is None else group.size()
+
+
+def _as_compute(x: Tensor, dtype: torch.dtype) -> Tensor:
+    x = x if x.dtype == dtype else x.to(dtype)
+    return x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
+
+
+class BaseBlock(nn.Module, ABC):
+    """Base class for network blocks."""
+
+    @abstractmethod
+    def forward(self, x, edge_attr, edge_index, shapes, batch_size, size=None, model_comm_group=None): ...
+
+
+# =============================================================================================
+# Graph transformer blocks
+# =============================================================================================
+class GraphTransformerBaseBlock(BaseBlock, ABC):
+    """Parameters of one graph-transformer layer (reference layers/block.py:289-364)."""
+
+    def __init__(
+        self,
+        in_channels: int,
+        hidden_dim: int,
+        out_channels: int,
+        edge_dim: int,
+        num_heads: int = 16,
+        bias: bool = True,
+        activation: str = "GELU",
+        num_chunks: int = 1,
+        update_src_nodes: bool = False,
+        **kwargs,
+    ) -> None:
+        super().__init__(**kwargs)
+        self.update_src_nodes = update_src_nodes
+        self.out_channels_conv = out_channels // num_heads
+        self.num_heads = num_heads
+        self.num_chunks = num_chunks
+        self.activation = activation
+        self.edge_dim = edge_dim
+        width = num_heads * self.out_channels_conv
+
+        self.lin_key = nn.Linear(in_channels, width)
+        self.lin_query = nn.Linear(in_channels, width)
+        self.lin_value = nn.Linear(in_channels, width)
+        self.lin_self = nn.Linear(in_channels, width, bias=bias)
+        self.lin_edge = nn.Linear(edge_dim, width)
+        self.conv = GraphTransformerConv(out_channels=self.out_channels_conv)
+        self.projection = nn.Linear(out_channels, out_channels)
+
+        act = activation_class(activation)
+        self.node_dst_mlp = nn.Sequential(
+            nn.LayerNorm(out_channels), nn.Linear(out_channels, hidden_dim), act(), nn.Linear(hidden_dim, out_channels)
+        )
+        self.layer_norm1 = nn.LayerNorm(in_channels)
+        if self.update_src_nodes:
+            self.node_src_mlp = nn.Sequential(
+                nn.LayerNorm(out_channels), nn.Linear(out_channels, hidden_dim), act(),
+                nn.Linear(hidden_dim, out_channels),
+            )
+        self._packed = runtime.PackedWeights()
+        self._plans = runtime.PlanCache()
+        self._dst_mlp: Optional[NativeSequential] = None
+        self._src_mlp: Optional[NativeSequential] = None
+
+    # ---- packed parameters -------------------------------------------------------------------
+    def _cat_linear(self, tag: str, layers, dtype):
+        w = self._packed.get((tag, "w", dtype), [l.weight for l in layers],
+                             lambda: runtime.pack_weight([l.weight for l in layers], dtype))
+        b = self._packed.get((tag, "b"), [l.bias for l in layers],
+                             lambda: runtime.pack_bias([l.bias for l in layers], [l.out_features for l in layers],
+                                                       layers[0].weight.device))
+        return w, b
+
+    def _edge_params(self):
+        return runtime.f32c(self.lin_edge.weight), runtime.f32c(self.lin_edge.bias)
+
+    def _node_mlp(self, y: Tensor, which: str, num_chunks: int) -> Tensor:
+        """``mlp(y) + y`` with mlp = LayerNorm, Linear, act, Linear; optionally in row chunks (bounded hidden buffer)."""
+        if which == "dst":
+            if self._dst_mlp is None:
+                self._dst_mlp = NativeSequential(self.node_dst_mlp)
+            run = self._dst_mlp
+        else:
+            if self._src_mlp is None:
+                self._src_mlp = NativeSequential(self.node_src_mlp)
+            run = self._src_mlp
+        if num_chunks <= 1:
+            return run(y, residual=y)
+        return torch.cat([run(c, residual=c) for c in y.tensor_split(num_chunks, dim=0) if c.shape[0] > 0], dim=0)
+
+    def _check_channels(self, dtype) -> None:
+        mult = ops.k_multiple(dtype)
+        width = self.num_heads * self.out_channels_conv
+        if width % mult != 0:
+            raise NotImplementedError(
+                f"hidden width {width} must be a multiple of {mult} for {dtype} on the MI355X path"
+            )
+
+    def _edge_inputs(self, edge_attr: Tensor, edge_index: Tensor, n_src: int, n_dst: int):
+        if edge_attr.shape[1] != self.edge_dim:
+            raise ValueError(f"edge_attr has {edge_attr.shape[1]} features, lin_edge expects {self.edge_dim}")
+        if edge_attr.shape[0] != edge_index.shape[1]:
+            raise ValueError(f"edge_attr has {edge_attr.shape[0]} rows for {edge_index.shape[1]} edges")
+        plan = self._plans.get(edge_index, n_src, n_dst)
+        return plan, ops.edge_attr_csr(edge_attr, None, plan.perm)
+
+    @abstractmethod
+    def forward(self, x, edge_attr, edge_index, shapes, batch_size, model_comm_group=None, size=None): ...
+
+
+class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
+    """Graph transformer layer on one node set (reference layers/block.py:553-635)."""
+
+    def native(self, x: Tensor, edge_attr_csr: Tensor, plan: EdgePlan) -> Tensor:
+        """x ``[N, C]`` in the compute dtype, edge attributes already in CSR order.  Returns the new nodes."""
+        dtype = x.dtype
+        self._check_channels(dtype)
+        c = self.num_heads * self.out_channels_conv
+        w4, b4 = self._cat_linear("sqkv", [self.lin_self, self.lin_query, self.lin_key, self.lin_value], dtype)
+        wp, bp = self._cat_linear("proj", [self.projection], dtype)
+        we, be = self._edge_params()
+        xh = ops.layer_norm(x, runtime.f32c(self.layer_norm1.weight), runtime.f32c(self.layer_norm1.bias),
+                            self.layer_norm1.eps)
+        sqkv = ops.linear(xh, w4, b4)  # [N, 4C] = x_r | q | k | v
+        att = self.conv.fused(sqkv[:, c:2 * c], sqkv[:, 2 * c:3 * c], sqkv[:, 3 * c:], sqkv[:, :c], edge_attr_csr,
+                              self.edge_dim, we, be, plan, self.num_heads)
+        y = ops.linear(att, wp, bp, residual=x)  # projection(out + x_r) + x_skip
+        return self._node_mlp(y, "dst", 1)
+
+    def forward(
+        self,
+        x: Tensor,
+        edge_attr: Tensor,
+        edge_index: Tensor,
+        shapes: tuple,
+        batch_size: int,
+        model_comm_group=None,
+        size=None,
+    ):
+        if _group_size(model_comm_group) > 1:
+            assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+        runtime.require_inference(self)
+        dtype = runtime.compute_dtype(x)
+        n = x.shape[0]
+        if size is not None and tuple(size) != (n, n):
+            raise ValueError(f"Encountered tensor with size {n} in dimension 0, but expected size {tuple(size)}")
+        plan, ea = self._edge_inputs(edge_attr, edge_index, n, n)
+        return self.native(_as_compute(x, dtype), ea, plan), edge_attr
+
+
+class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
+    """Graph transformer layer between two node sets (reference layers/block.py:429-550)."""
+
+    def __init__(
+        self,
+        in_channels: int,
+        hidden_dim: int,
+        out_channels: int,
+        edge_dim: int,
+        num_heads: int = 16,
+        bias: bool = True,
+        activation: str = "GELU",
+        num_chunks: int = 1,
+        update_src_nodes: bool = False,
+        **kwargs,
+    ) -> None:
+        super().__init__(
+            in_channels=in_channels, hidden_dim=hidden_dim, out_channels=out_channels, edge_dim=edge_dim,
+            num_heads=num_heads, bias=bias, activation=activation, num_chunks=num_chunks,
+            update_src_nodes=update_src_nodes, **kwargs,
+        )
+        self.layer_norm2 = nn.LayerNorm(in_channels)
+
+    def native(self, x_src: Tensor, x_dst: Tensor, edge_attr_csr: Tensor, plan: EdgePlan, num_chunks: int = 1):
+        dtype = x_dst.dtype
+        self._check_channels(dtype)
+        c = self.num_heads * self.out_channels_conv
+        w_sq, b_sq = self._cat_linear("sq", [self.lin_self, self.lin_query], dtype)
+        w_kv, b_kv = self._cat_linear("kv", [self.lin_key, self.lin_value], dtype)
+        wp, bp = self._cat_linear("proj", [self.projection], dtype)
+        we, be = self._edge_params()
+        ln1, ln2 = self.layer_norm1, self.layer_norm2
+        xs = ops.layer_norm(x_src, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
+        kv = ops.linear(xs, w_kv, b_kv)  # [N_src, 2C] = k | v
+        del xs
+        xd = ops.layer_norm(x_dst, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
+        sq = ops.linear(xd, w_sq, b_sq)  # [N_dst, 2C] = x_r | q
+        del xd
+        att = self.conv.fused(sq[:, c:], kv[:, :c], kv[:, c:], sq[:, :c], edge_attr_csr, self.edge_dim, we, be, plan,
+                              self.num_heads)
+        del sq, kv
+        y = ops.linear(att, wp, bp, residual=x_dst)
+        del att
+        new_dst = self._node_mlp(y, "dst", num_chunks)
+        new_src = self._node_mlp(x_src, "src", num_chunks) if self.update_src_nodes else x_src
+        return new_src, new_dst
+
+    def forward(
+        self,
+        x,
+        edge_attr: Tensor,
+        edge_index: Tensor,
+        shapes: tuple,
+        batch_size: int,
+        model_comm_group=None,
+        size=None,
+    ):
+        if _group_size(model_comm_group) > 1:
+            assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+        runtime.require_inference(self)
+        x_src, x_dst = x
+        dtype = runtime.compute_dtype(x_dst)
+        n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+        if size is not None and tuple(size) != (n_src, n_dst):
+            raise ValueError(f"Encountered tensors with sizes {(n_src, n_dst)}, but expected size {tuple(size)}")
+        plan, ea = self._edge_inputs(edge_attr, edge_index, n_src, n_dst)
+        num_chunks = self.num_chunks if self.training else inference_num_chunks()
+        new_src, new_dst = self.native(_as_compute(x_src, dtype), _as_compute(x_dst, dtype), ea, plan, num_chunks)
+        return (new_src if self.update_src_nodes else x[0], new_dst), edge_attr
+
+
+# =============================================================================================
+# GNN (edge-MLP message passing) blocks -- parameters mirror reference layers/block.py:108-286
+# =============================================================================================
+class GraphConvBaseBlock(BaseBlock, ABC):
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        mlp_extra_layers: int = 0,
+        activation: str = "SiLU",
+        update_src_nodes: bool = True,
+        num_chunks: int = 1,
+        **kwargs,
+    ) -> None:
+        super().__init__(**kwargs)
+        self.update_src_nodes = update_src_nodes
+        self.num_chunks = num_chunks
+        self.node_mlp = MLP(2 * in_channels, out_channels, out_channels, n_extra_layers=mlp_extra_layers,
+                            activation=activation)
+        self.conv = GraphConv(in_channels=in_channels, out_channels=out_channels, mlp_extra_layers=mlp_extra_layers,
+                              activation=activation)
+
+
+class GraphConvProcessorBlock(GraphConvBaseBlock):
+    def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
+        raise NotImplementedError("GNN processor block: MI355X kernels not available in this build")
+
+
+class GraphConvMapperBlock(GraphConvBaseBlock):
+    def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
+        raise NotImplementedError("GNN mapper block: MI355X kernels not available in this build")
+
+
+# =============================================================================================
+# Transformer block (mesh-node multi-head self attention) -- reference layers/block.py:61-105
+# =============================================================================================
+class TransformerProcessorBlock(BaseBlock):
+    def __init__(self, num_channels: int, hidden_dim: int, num_heads: int, activation: str, window_size: int,
+                 dropout_p: float = 0.0):
+        super().__init__()
+        from .attention import MultiHeadSelfAttention
+
+        act = activation_class(activation)
+        self.layer_norm1 = nn.LayerNorm(num_channels)
+        self.attention = MultiHeadSelfAttention(num_heads=num_heads, embed_dim=num_channels, window_size=window_size,
+                                                bias=False, is_causal=False, dropout_p=dropout_p)
+        self.mlp = nn.Sequential(nn.Linear(num_channels, hidden_dim), act(), nn.Linear(hidden_dim, num_channels))
+        self.layer_norm2 = nn.LayerNorm(num_channels)
+
+    def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None) -> Tensor:
+        raise NotImplementedError("Transformer processor block: MI355X kernels not available in this build")

@@ -1,0 +1,236 @@
+"""Grid <-> mesh mappers mirroring reference layers/mapper.py.
+
+``GraphTransformerForwardMapper`` (data -> hidden) and ``GraphTransformerBackwardMapper`` (hidden -> data):
+node embeddings on the fused GEMM, one :class:`GraphTransformerMapperBlock` on the bipartite CSR plan, and for
+the backward mapper the LayerNorm + Linear extractor.  Sub-module / buffer names match the reference, so a
+reference ``state_dict`` loads unchanged (``edge_inc`` persistent; ``edge_attr`` / ``edge_index_base`` not).
+"""
+
+from __future__ import annotations
+
+from abc import ABC
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch import nn
+
+from .. import ops
+from .. import runtime
+from .block import GraphConvMapperBlock
+from .block import GraphTransformerMapperBlock
+from .block import inference_num_chunks
+from .graph import TrainableTensor
+from .mlp import MLP
+from .mlp import linear_native
+
+
+class BaseMapper(nn.Module, ABC):
+    def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
+                 out_channels_dst: Optional[int] = None, cpu_offload: bool = False, activation: str = "SiLU",
+                 **kwargs) -> None:
+        super().__init__()
+        self.in_channels_src = in_channels_src
+        self.in_channels_dst = in_channels_dst
+        self.hidden_dim = hidden_dim
+        self.out_channels_dst = out_channels_dst
+        self.activation = activation
+        self.proc = NotImplemented
+        self.offload_layers(cpu_offload)
+
+    def offload_layers(self, cpu_offload: bool) -> None:
+        if cpu_offload:
+            raise NotImplementedError("cpu_offload is not supported on the MI355X path (288 GB HBM per GPU)")
+
+
+class GraphEdgeMixin:
+    """Edge buffers of a sub-graph (reference layers/mapper.py:119-171)."""
+
+    def _register_edges(self, sub_graph, edge_attributes, src_size: int, dst_size: int, trainable_size: int) -> None:
+        assert sub_graph, f"{self.__class__.__name__} needs a valid sub_graph to register edges."
+        assert edge_attributes is not None, "Edge attributes must be provided"
+        attr = torch.cat([sub_graph[name] for name in edge_attributes], dim=1)
+        self.edge_dim = attr.shape[1] + trainable_size
+        self.register_buffer("edge_attr", attr, persistent=False)
+        self.register_buffer("edge_index_base", sub_graph.edge_index, persistent=False)
+        self.register_buffer("edge_inc", torch.from_numpy(np.asarray([[src_size], [dst_size]], dtype=np.int64)),
+                             persistent=True)
+
+    def _expand_edges(self, edge_index: Tensor, edge_inc: Tensor, batch_size: int) -> Tensor:
+        return runtime.expand_edges(edge_index, edge_inc, batch_size)
+
+
+class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
+    def __init__(
+        self,
+        in_channels_src: int = 0,
+        in_channels_dst: int = 0,
+        hidden_dim: int = 128,
+        trainable_size: int = 8,
+        out_channels_dst: Optional[int] = None,
+        num_chunks: int = 1,
+        cpu_offload: bool = False,
+        activation: str = "GELU",
+        num_heads: int = 16,
+        mlp_hidden_ratio: int = 4,
+        sub_graph=None,
+        sub_graph_edge_attributes: Optional[list] = None,
+        src_grid_size: int = 0,
+        dst_grid_size: int = 0,
+    ) -> None:
+        super().__init__(in_channels_src, in_channels_dst, hidden_dim, out_channels_dst=out_channels_dst,
+                         num_chunks=num_chunks, cpu_offload=cpu_offload, activation=activation)
+        self._register_edges(sub_graph, sub_graph_edge_attributes, src_grid_size, dst_grid_size, trainable_size)
+        self.trainable = TrainableTensor(trainable_size=trainable_size, tensor_size=self.edge_attr.shape[0])
+        self.proc = GraphTransformerMapperBlock(
+            hidden_dim, mlp_hidden_ratio * hidden_dim, hidden_dim, num_heads=num_heads, edge_dim=self.edge_dim,
+            activation=activation, num_chunks=num_chunks,
+        )
+        self.offload_layers(cpu_offload)
+        self.emb_nodes_dst = nn.Linear(self.in_channels_dst, self.hidden_dim)
+        self._packed = runtime.PackedWeights()
+        self._plans = runtime.PlanCache()
+
+    # ---- hooks specialised by the forward / backward mapper ------------------------------------
+    def _embed(self, x_src: Tensor, x_dst: Tensor):
+        raise NotImplementedError
+
+    def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
+        return x_dst
+
+    def native(self, x_src: Tensor, x_dst: Tensor, batch_size: int, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+        """Inputs in the compute dtype (optionally K padded).  Returns the mapped destination nodes."""
+        n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+        plan = self._plans.get(self.edge_index_base, n_src, n_dst, batch_size, self.edge_inc)
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)
+        h_src, h_dst = self._embed(x_src, x_dst)
+        num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
+        _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks)
+        return self._extract(h_dst, out_dtype)
+
+    def _run(self, x, batch_size: int, shard_shapes, model_comm_group) -> Tensor:
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
+        runtime.require_inference(self)
+        x_src, x_dst = x
+        size = (sum(s[0] for s in shard_shapes[0]), sum(s[0] for s in shard_shapes[1]))
+        if size != (x_src.shape[0], x_dst.shape[0]):
+            raise ValueError(f"shard_shapes describe {size} nodes, inputs have {(x_src.shape[0], x_dst.shape[0])}")
+        dtype = runtime.compute_dtype(x_dst)
+
+        def prep(t):
+            t = t if t.dtype == dtype else t.to(dtype)
+            return t if t.stride(-1) == 1 else t.contiguous()
+
+        return self.native(prep(x_src), prep(x_dst), batch_size)
+
+
+class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
+    """data -> hidden (reference layers/mapper.py:275-345): both node sets are embedded."""
+
+    def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
+                 trainable_size: int = 8, out_channels_dst: Optional[int] = None, num_chunks: int = 1,
+                 cpu_offload: bool = False, activation: str = "GELU", num_heads: int = 16, mlp_hidden_ratio: int = 4,
+                 sub_graph=None, sub_graph_edge_attributes: Optional[list] = None, src_grid_size: int = 0,
+                 dst_grid_size: int = 0) -> None:
+        super().__init__(in_channels_src, in_channels_dst, hidden_dim, trainable_size,
+                         out_channels_dst=out_channels_dst, num_chunks=num_chunks, cpu_offload=cpu_offload,
+                         activation=activation, num_heads=num_heads, mlp_hidden_ratio=mlp_hidden_ratio,
+                         sub_graph=sub_graph, sub_graph_edge_attributes=sub_graph_edge_attributes,
+                         src_grid_size=src_grid_size, dst_grid_size=dst_grid_size)
+        self.emb_nodes_src = nn.Linear(self.in_channels_src, self.hidden_dim)
+
+    def _embed(self, x_src: Tensor, x_dst: Tensor):
+        return (linear_native(self._packed, "emb_nodes_src", self.emb_nodes_src, x_src),
+                linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst))
+
+    def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None):
+        x_dst = self._run(x, batch_size, shard_shapes, model_comm_group)
+        return x[0], x_dst  # the RAW source tensor is handed back (reference layers/mapper.py:344-345)
+
+
+class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
+    """hidden -> data (reference layers/mapper.py:348-418): only the destination is embedded, then extracted."""
+
+    def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
+                 trainable_size: int = 8, out_channels_dst: Optional[int] = None, num_chunks: int = 1,
+                 cpu_offload: bool = False, activation: str = "GELU", num_heads: int = 16, mlp_hidden_ratio: int = 4,
+                 sub_graph=None, sub_graph_edge_attributes: Optional[list] = None, src_grid_size: int = 0,
+                 dst_grid_size: int = 0) -> None:
+        super().__init__(in_channels_src, in_channels_dst, hidden_dim, trainable_size,
+                         out_channels_dst=out_channels_dst, num_chunks=num_chunks, cpu_offload=cpu_offload,
+                         activation=activation, num_heads=num_heads, mlp_hidden_ratio=mlp_hidden_ratio,
+                         sub_graph=sub_graph, sub_graph_edge_attributes=sub_graph_edge_attributes,
+                         src_grid_size=src_grid_size, dst_grid_size=dst_grid_size)
+        self.node_data_extractor = nn.Sequential(nn.LayerNorm(self.hidden_dim),
+                                                 nn.Linear(self.hidden_dim, self.out_channels_dst))
+
+    def _embed(self, x_src: Tensor, x_dst: Tensor):
+        return x_src, linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst)
+
+    def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
+        ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]
+        h = ops.layer_norm(x_dst, runtime.f32c(ln.weight), runtime.f32c(ln.bias), ln.eps)
+        return linear_native(self._packed, "extract", lin, h, out_dtype=out_dtype)
+
+    def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
+        return self._run(x, batch_size, shard_shapes, model_comm_group)
+
+
+# ---------------------------------------------------------------------------------------------
+# GNN mappers: parameter layout mirrors reference layers/mapper.py:421-705
+# ---------------------------------------------------------------------------------------------
+class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
+    def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
+                 trainable_size: int = 8, out_channels_dst: Optional[int] = None, num_chunks: int = 1,
+                 cpu_offload: bool = False, activation: str = "SiLU", mlp_extra_layers: int = 0, sub_graph=None,
+                 sub_graph_edge_attributes: Optional[list] = None, src_grid_size: int = 0,
+                 dst_grid_size: int = 0) -> None:
+        super().__init__(in_channels_src, in_channels_dst, hidden_dim, out_channels_dst=out_channels_dst,
+                         num_chunks=num_chunks, cpu_offload=cpu_offload, activation=activation)
+        self._register_edges(sub_graph, sub_graph_edge_attributes, src_grid_size, dst_grid_size, trainable_size)
+        self.emb_edges = MLP(in_features=self.edge_dim, hidden_dim=hidden_dim, out_features=hidden_dim,
+                             n_extra_layers=mlp_extra_layers, activation=activation)
+        self.trainable = TrainableTensor(trainable_size=trainable_size, tensor_size=self.edge_attr.shape[0])
+
+    def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None):
+        raise NotImplementedError("GNN mappers: MI355X kernels not available in this build")
+
+
+class GNNForwardMapper(GNNBaseMapper):
+    def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
+                 trainable_size: int = 8, out_channels_dst: Optional[int] = None, num_chunks: int = 1,
+                 cpu_offload: bool = False, activation: str = "SiLU", mlp_extra_layers: int = 0, sub_graph=None,
+                 sub_graph_edge_attributes: Optional[list] = None, src_grid_size: int = 0,
+                 dst_grid_size: int = 0) -> None:
+        super().__init__(in_channels_src, in_channels_dst, hidden_dim, trainable_size, out_channels_dst, num_chunks,
+                         cpu_offload, activation, mlp_extra_layers, sub_graph=sub_graph,
+                         sub_graph_edge_attributes=sub_graph_edge_attributes, src_grid_size=src_grid_size,
+                         dst_grid_size=dst_grid_size)
+        self.proc = GraphConvMapperBlock(hidden_dim, hidden_dim, mlp_extra_layers=mlp_extra_layers,
+                                         activation=activation, update_src_nodes=True, num_chunks=num_chunks)
+        self.offload_layers(cpu_offload)
+        self.emb_nodes_src = MLP(in_features=in_channels_src, hidden_dim=hidden_dim, out_features=hidden_dim,
+                                 n_extra_layers=mlp_extra_layers, activation=activation)
+        self.emb_nodes_dst = MLP(in_features=in_channels_dst, hidden_dim=hidden_dim, out_features=hidden_dim,
+                                 n_extra_layers=mlp_extra_layers, activation=activation)
+
+
+class GNNBackwardMapper(GNNBaseMapper):
+    def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
+                 trainable_size: int = 8, out_channels_dst: Optional[int] = None, num_chunks: int = 1,
+                 cpu_offload: bool = False, activation: str = "SiLU", mlp_extra_layers: int = 0, sub_graph=None,
+                 sub_graph_edge_attributes: Optional[list] = None, src_grid_size: int = 0,
+                 dst_grid_size: int = 0) -> None:
+        super().__init__(in_channels_src, in_channels_dst, hidden_dim, trainable_size,
+                         out_channels_dst=out_channels_dst, num_chunks=num_chunks, cpu_offload=cpu_offload,
+                         activation=activation, mlp_extra_layers=mlp_extra_layers, sub_graph=sub_graph,
+                         sub_graph_edge_attributes=sub_graph_edge_attributes, src_grid_size=src_grid_size,
+                         dst_grid_size=dst_grid_size)
+        self.proc = GraphConvMapperBlock(hidden_dim, hidden_dim, mlp_extra_layers=mlp_extra_layers,
+                                         activation=activation, update_src_nodes=False, num_chunks=num_chunks)
+        self.offload_layers(cpu_offload)
+        self.node_data_extractor = MLP(in_features=self.hidden_dim, hidden_dim=self.hidden_dim,
+                                       out_features=self.out_channels_dst, n_extra_layers=mlp_extra_layers,
+                                       activation=self.activation, layer_norm=False, final_activation=False)

@@ -1,0 +1,133 @@
+"""MLP mirror (reference layers/mlp.py:22-89) executed with the fused Linear(+activation) and LayerNorm kernels.
+
+``state_dict`` keys are those of the reference: ``model.<i>.{weight,bias}`` for the Linear layers at the
+even positions of the ``nn.Sequential`` and the trailing ``AutocastLayerNorm``.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch import nn
+
+from .. import ops
+from .. import runtime
+from .utils import AutocastLayerNorm
+from .utils import CheckpointWrapper
+
+LOGGER = logging.getLogger(__name__)
+
+
+def activation_class(name: str):
+    """``getattr(nn, name)`` with the reference's error behaviour (layers/mlp.py:66-72, layers/block.py:75-79)."""
+    try:
+        return getattr(nn, name)
+    except AttributeError as ae:
+        LOGGER.error("Activation function %s not supported", name)
+        raise RuntimeError from ae
+
+
+class NativeSequential:
+    """Runs an ``nn.Sequential`` of Linear / activation / LayerNorm modules on the HIP kernels.
+
+    Each ``Linear`` is fused with the activation that follows it; weights are packed (cast + K padded)
+    once per dtype and cached.  ``residual`` is added by the epilogue of the last Linear when the
+    sequence does not end in a LayerNorm, otherwise by a separate add.
+    """
+
+    def __init__(self, seq: nn.Sequential) -> None:
+        self.seq = seq
+        self.cache = runtime.PackedWeights()
+        self.steps = []
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                act = "Identity"
+                if i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm)):
+                    act = type(mods[i + 1]).__name__
+                    i += 1
+                self.steps.append(("linear", m, act))
+            elif isinstance(m, nn.LayerNorm):
+                self.steps.append(("ln", m, None))
+            else:
+                raise NotImplementedError(f"module {type(m).__name__} cannot be fused into the native MLP")
+            i += 1
+
+    def __call__(self, x: Tensor, residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+        dtype = x.dtype
+        last_linear = max(i for i, s in enumerate(self.steps) if s[0] == "linear")
+        ends_with_ln = self.steps[-1][0] == "ln"
+        for i, (kind, m, act) in enumerate(self.steps):
+            if kind == "linear":
+                w = self.cache.get(("w", i, dtype), [m.weight], lambda m=m: runtime.pack_weight([m.weight], dtype))
+                b = None if m.bias is None else runtime.f32c(m.bias)
+                if x.shape[1] != w.shape[1]:
+                    x = ops.convert_pad(x, dtype, w.shape[1])
+                fuse_res = residual is not None and i == last_linear and not ends_with_ln
+                last = i == len(self.steps) - 1
+                x = ops.linear(x, w, b, act=act, residual=residual if fuse_res else None,
+                               out_dtype=out_dtype if last else None)
+            else:
+                x = ops.layer_norm(x, runtime.f32c(m.weight), runtime.f32c(m.bias), m.eps)
+        if residual is not None and ends_with_ln:
+            x = ops.add(x, residual)
+        return x
+
+
+class MLP(nn.Module):
+    """Linear, act, (Linear, act) x (n_extra_layers + 1), Linear, [act], [LayerNorm]."""
+
+    def __init__(
+        self,
+        in_features: int,
+        hidden_dim: int,
+        out_features: int,
+        n_extra_layers: int = 0,
+        activation: str = "SiLU",
+        final_activation: bool = False,
+        layer_norm: bool = True,
+        checkpoints: bool = False,
+    ) -> None:
+        super().__init__()
+        act = activation_class(activation)
+        layers = [nn.Linear(in_features, hidden_dim), act()]
+        for _ in range(n_extra_layers + 1):
+            layers += [nn.Linear(hidden_dim, hidden_dim), act()]
+        layers.append(nn.Linear(hidden_dim, out_features))
+        if final_activation:
+            layers.append(act())
+        if layer_norm:
+            layers.append(AutocastLayerNorm(out_features))
+        seq = nn.Sequential(*layers)
+        self.model = CheckpointWrapper(seq) if checkpoints else seq
+        self._native: Optional[NativeSequential] = None
+
+    def native(self) -> NativeSequential:
+        if self._native is None:
+            seq = self.model.module if isinstance(self.model, CheckpointWrapper) else self.model
+            self._native = NativeSequential(seq)
+        return self._native
+
+    def forward(self, x: Tensor) -> Tensor:
+        runtime.require_inference(self)
+        dtype = runtime.compute_dtype(x)
+        xin = x if x.dtype == dtype else x.to(dtype)
+        return self.native()(xin.contiguous() if xin.stride(-1) != 1 else xin)
+
+
+def linear_native(cache: runtime.PackedWeights, tag: str, lin: nn.Linear, x: Tensor, act: str = "Identity",
+                  residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """One ``nn.Linear`` on the fused GEMM kernel; ``x`` may carry zero K-padding or none (it is padded here)."""
+    dtype = x.dtype
+    w = cache.get((tag, "w", dtype), [lin.weight], lambda: runtime.pack_weight([lin.weight], dtype))
+    b = None if lin.bias is None else runtime.f32c(lin.bias)
+    if x.shape[1] != w.shape[1]:
+        if x.shape[1] != lin.in_features:
+            raise ValueError(f"{tag}: input has {x.shape[1]} features, expected {lin.in_features}")
+        x = ops.convert_pad(x, dtype, w.shape[1])
+    return ops.linear(x, w, b, act=act, residual=residual, out_dtype=out_dtype)

@@ -1,0 +1,127 @@
+"""Processors mirroring reference layers/processor.py: a stack of ``num_layers`` blocks in ``num_chunks`` chunks.
+
+A processor owns the mesh edge set (non-persistent buffers ``edge_attr`` / ``edge_index_base``, persistent
+``edge_inc``) and the per-edge trainable tensor; once per forward it builds / reuses the destination-sorted CSR
+plan and gathers ``[edge_attr | trainable]`` into CSR order, then every block runs on that shared edge input.
+"""
+
+from __future__ import annotations
+
+from abc import ABC
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch import nn
+
+from .. import ops
+from .. import runtime
+from .chunk import GNNProcessorChunk
+from .chunk import GraphTransformerProcessorChunk
+from .chunk import TransformerProcessorChunk
+from .graph import TrainableTensor
+from .mapper import GraphEdgeMixin
+
+
+class BaseProcessor(nn.Module, ABC):
+    def __init__(self, num_layers: int, *args, num_channels: int = 128, num_chunks: int = 2,
+                 activation: str = "GELU", cpu_offload: bool = False, **kwargs) -> None:
+        super().__init__()
+        self.num_chunks = num_chunks
+        self.num_channels = num_channels
+        self.chunk_size = num_layers // num_chunks
+        assert (
+            num_layers % num_chunks == 0
+        ), f"Number of processor layers ({num_layers}) has to be divisible by the number of processor chunks ({num_chunks})."
+
+    def offload_layers(self, cpu_offload: bool) -> None:
+        if cpu_offload:
+            raise NotImplementedError("cpu_offload is not supported on the MI355X path (288 GB HBM per GPU)")
+
+    def build_layers(self, processor_chunk_class, *args, **kwargs) -> None:
+        self.proc = nn.ModuleList([processor_chunk_class(*args, **kwargs) for _ in range(self.num_chunks)])
+
+    def run_layers(self, data: tuple, *args, **kwargs):
+        for layer in self.proc:
+            data = layer(*data, *args, **kwargs)
+        return data
+
+    def forward(self, x: Tensor, *args, **kwargs) -> Tensor:
+        return self.run_layers((x,), *args, **kwargs)
+
+
+class TransformerProcessor(BaseProcessor):
+    def __init__(self, num_layers: int, *args, window_size: Optional[int] = None, num_channels: int = 128,
+                 num_chunks: int = 2, activation: str = "GELU", cpu_offload: bool = False, num_heads: int = 16,
+                 mlp_hidden_ratio: int = 4, dropout_p: float = 0.1, **kwargs) -> None:
+        super().__init__(num_channels=num_channels, num_layers=num_layers, num_chunks=num_chunks,
+                         activation=activation, cpu_offload=cpu_offload)
+        self.build_layers(
+            TransformerProcessorChunk, num_channels=num_channels, mlp_hidden_ratio=mlp_hidden_ratio,
+            num_heads=num_heads, num_layers=self.chunk_size, window_size=window_size, activation=activation,
+            dropout_p=dropout_p,
+        )
+        self.offload_layers(cpu_offload)
+
+    def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None, *args, **kwargs) -> Tensor:
+        if model_comm_group is not None:
+            assert (
+                model_comm_group.size() == 1 or batch_size == 1
+            ), "Only batch size of 1 is supported when model is sharded accross GPUs"
+        (x,) = self.run_layers((x,), shard_shapes, batch_size, model_comm_group)
+        return x
+
+
+class GNNProcessor(GraphEdgeMixin, BaseProcessor):
+    def __init__(self, num_layers: int, *args, trainable_size: int = 8, num_channels: int = 128, num_chunks: int = 2,
+                 mlp_extra_layers: int = 0, activation: str = "SiLU", cpu_offload: bool = False, sub_graph=None,
+                 sub_graph_edge_attributes: Optional[list] = None, src_grid_size: int = 0, dst_grid_size: int = 0,
+                 **kwargs) -> None:
+        super().__init__(num_channels=num_channels, num_layers=num_layers, num_chunks=num_chunks,
+                         activation=activation, cpu_offload=cpu_offload)
+        self._register_edges(sub_graph, sub_graph_edge_attributes, src_grid_size, dst_grid_size, trainable_size)
+        self.trainable = TrainableTensor(trainable_size=trainable_size, tensor_size=self.edge_attr.shape[0])
+        kw = {"num_layers": self.chunk_size, "mlp_extra_layers": mlp_extra_layers, "activation": activation,
+              "edge_dim": None}
+        self.build_layers(GNNProcessorChunk, num_channels, **kw)
+        kw["edge_dim"] = self.edge_dim  # only the first chunk embeds the raw edge attributes
+        self.proc[0] = GNNProcessorChunk(num_channels, **kw)
+        self.offload_layers(cpu_offload)
+
+    def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
+        raise NotImplementedError("GNNProcessor: MI355X kernels not available in this build")
+
+
+class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
+    def __init__(self, num_layers: int, trainable_size: int = 8, num_channels: int = 128, num_chunks: int = 2,
+                 num_heads: int = 16, mlp_hidden_ratio: int = 4, activation: str = "GELU", cpu_offload: bool = False,
+                 sub_graph=None, sub_graph_edge_attributes: Optional[list] = None, src_grid_size: int = 0,
+                 dst_grid_size: int = 0, **kwargs) -> None:
+        super().__init__(num_layers=num_layers, num_channels=num_channels, num_chunks=num_chunks,
+                         activation=activation, cpu_offload=cpu_offload)
+        self._register_edges(sub_graph, sub_graph_edge_attributes, src_grid_size, dst_grid_size, trainable_size)
+        self.trainable = TrainableTensor(trainable_size=trainable_size, tensor_size=self.edge_attr.shape[0])
+        self.build_layers(
+            GraphTransformerProcessorChunk, num_channels=num_channels, num_layers=self.chunk_size,
+            num_heads=num_heads, mlp_hidden_ratio=mlp_hidden_ratio, activation=activation, edge_dim=self.edge_dim,
+        )
+        self.offload_layers(cpu_offload)
+        self._plans = runtime.PlanCache()
+
+    def native(self, x: Tensor, batch_size: int) -> Tensor:
+        """x ``[B * N, C]`` in the compute dtype -> processed nodes (same dtype)."""
+        n = x.shape[0]
+        plan = self._plans.get(self.edge_index_base, n, n, batch_size, self.edge_inc)
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)
+        for chunk in self.proc:
+            x = chunk.native(x, ea, plan)
+        return x
+
+    def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None, *args, **kwargs) -> Tensor:
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+            raise NotImplementedError("processor-level model sharding: use the node-partitioned model forward")
+        runtime.require_inference(self)
+        dtype = runtime.compute_dtype(x)
+        xin = x if x.dtype == dtype else x.to(dtype)
+        return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)

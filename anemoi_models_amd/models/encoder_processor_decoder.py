@@ -1,0 +1,152 @@
+"""Model root mirroring reference models/encoder_processor_decoder.py:30-233.
+
+Same constructor (``model_config``, ``data_indices``, ``graph_data``), same sub-module names (``node_attributes``,
+``encoder``, ``processor``, ``decoder``, ``boundings``) and therefore the same ``state_dict``; ``forward(x,
+model_comm_group=None)`` maps ``[B, T, Ens, G, V_in]`` to ``[B, Ens, G, V_out]``.
+
+The forward is one stream of HIP launches: input assembly -> encoder -> processor (+ skip) -> decoder (f32
+output from the last GEMM epilogue) -> prognostic residual -> boundings.  Activation checkpointing of the
+reference (``_run_mapper``) has no forward-pass effect and is not needed here.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch import nn
+
+from .. import ops
+from .. import runtime
+from ..layers.graph import NamedNodesAttributes
+
+try:  # real hydra when available, otherwise the local minimal implementation
+    from hydra.utils import instantiate as _hydra_instantiate  # type: ignore
+except ImportError:  # pragma: no cover - hydra is not in the build image
+    _hydra_instantiate = None
+
+from ..utils.config import instantiate as _local_instantiate
+from ..utils.config import REFERENCE_PREFIX
+
+LOGGER = logging.getLogger(__name__)
+
+
+def instantiate(cfg, **kwargs):
+    target = cfg.get("_target_", "") if hasattr(cfg, "get") else ""
+    if _hydra_instantiate is not None and not target.startswith(REFERENCE_PREFIX):
+        return _hydra_instantiate(cfg, **kwargs)
+    return _local_instantiate(cfg, **kwargs)
+
+
+class AnemoiModelEncProcDec(nn.Module):
+    """Encoder - processor - decoder graph network on MI355X kernels."""
+
+    def __init__(self, *, model_config, data_indices, graph_data) -> None:
+        super().__init__()
+        self._graph_data = graph_data
+        self._graph_name_data = model_config.graph.data
+        self._graph_name_hidden = model_config.graph.hidden
+
+        self._calculate_shapes_and_indices(data_indices)
+        self._assert_matching_indices(data_indices)
+        self.data_indices = data_indices
+
+        self.multi_step = model_config.training.multistep_input
+        self.num_channels = model_config.model.num_channels
+
+        self.node_attributes = NamedNodesAttributes(model_config.model.trainable_parameters.hidden, self._graph_data)
+        data, hidden = self._graph_name_data, self._graph_name_hidden
+        input_dim = self.multi_step * self.num_input_channels + self.node_attributes.attr_ndims[data]
+
+        self.encoder = instantiate(
+            model_config.model.encoder,
+            in_channels_src=input_dim,
+            in_channels_dst=self.node_attributes.attr_ndims[hidden],
+            hidden_dim=self.num_channels,
+            sub_graph=self._graph_data[(data, "to", hidden)],
+            src_grid_size=self.node_attributes.num_nodes[data],
+            dst_grid_size=self.node_attributes.num_nodes[hidden],
+        )
+        self.processor = instantiate(
+            model_config.model.processor,
+            num_channels=self.num_channels,
+            sub_graph=self._graph_data[(hidden, "to", hidden)],
+            src_grid_size=self.node_attributes.num_nodes[hidden],
+            dst_grid_size=self.node_attributes.num_nodes[hidden],
+        )
+        self.decoder = instantiate(
+            model_config.model.decoder,
+            in_channels_src=self.num_channels,
+            in_channels_dst=input_dim,
+            hidden_dim=self.num_channels,
+            out_channels_dst=self.num_output_channels,
+            sub_graph=self._graph_data[(hidden, "to", data)],
+            src_grid_size=self.node_attributes.num_nodes[hidden],
+            dst_grid_size=self.node_attributes.num_nodes[data],
+        )
+        self.boundings = nn.ModuleList(
+            [
+                instantiate(cfg, name_to_index=self.data_indices.internal_model.output.name_to_index)
+                for cfg in getattr(model_config.model, "bounding", [])
+            ]
+        )
+        self._idx_cache: dict = {}
+
+    def _calculate_shapes_and_indices(self, data_indices) -> None:
+        self.num_input_channels = len(data_indices.internal_model.input)
+        self.num_output_channels = len(data_indices.internal_model.output)
+        self._internal_input_idx = data_indices.internal_model.input.prognostic
+        self._internal_output_idx = data_indices.internal_model.output.prognostic
+
+    def _assert_matching_indices(self, data_indices) -> None:
+        n_full = len(data_indices.internal_model.output.full)
+        n_diag = len(data_indices.internal_model.output.diagnostic)
+        assert len(self._internal_output_idx) == n_full - n_diag, (
+            f"Mismatch between the internal data indices ({len(self._internal_output_idx)}) and "
+            f"the internal output indices excluding diagnostic variables ({n_full - n_diag})"
+        )
+        assert len(self._internal_input_idx) == len(
+            self._internal_output_idx
+        ), f"Internal model indices must match {self._internal_input_idx} != {self._internal_output_idx}"
+
+    def _prognostic_indices(self, device):
+        key = str(device)
+        if key not in self._idx_cache:
+            as_i32 = lambda t: torch.as_tensor(t).to(device=device, dtype=torch.int32).contiguous()  # noqa: E731
+            self._idx_cache[key] = (as_i32(self._internal_output_idx), as_i32(self._internal_input_idx))
+        return self._idx_cache[key]
+
+    def forward(self, x: Tensor, model_comm_group=None) -> Tensor:
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            from ..distributed.partition import sharded_forward
+
+            return sharded_forward(self, x, model_comm_group)
+        runtime.require_inference(self)
+        batch_size, _, ensemble_size, grid, _ = x.shape
+        dtype = runtime.compute_dtype(x)
+        kmult = ops.k_multiple(dtype)
+        data, hidden = self._graph_name_data, self._graph_name_hidden
+        na = self.node_attributes
+
+        # [x (time-major) | sin/cos latlon | trainable | 0-pad]: written once, straight into the GEMM input layout
+        width = self.multi_step * self.num_input_channels + na.attr_ndims[data]
+        x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, batch_size, dtype,
+                                    ld_out=ops.round_up(width, kmult))
+        x_hidden = ops.assemble_nodes(None, na.latlons(hidden), na.trainable_tensors[hidden].trainable, batch_size,
+                                      dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
+
+        x_latent = self.encoder.native(x_data, x_hidden, batch_size)
+        x_proc = self.processor.native(x_latent, batch_size)
+        x_latent_proc = ops.add(x_proc, x_latent)
+        y = self.decoder.native(x_latent_proc, x_data, batch_size, out_dtype=torch.float32)
+
+        y = y.view(batch_size, ensemble_size, grid, self.num_output_channels)
+        out_idx, in_idx = self._prognostic_indices(y.device)
+        ops.prognostic_residual(y, x, out_idx, in_idx)
+        if y.dtype != x.dtype:
+            y = y.to(x.dtype)
+        for bounding in self.boundings:
+            y = bounding(y)
+        return y

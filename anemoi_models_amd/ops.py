@@ -1,0 +1,196 @@
+"""Tensor-level wrappers over the C ABI (``include/anemoi_amd.h``).
+
+Every function takes torch tensors that live on an MI355X, passes raw device pointers, sizes and the
+current HIP stream to ``libanemoi_amd.so`` and returns torch tensors.  PyTorch is used for device
+memory and streams only.  There is deliberately no CPU implementation behind these names: calling
+them with CPU tensors raises.  (CPU tests of the host logic substitute this module's functions from
+``tests/``; the package itself never does.)
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise NotImplementedError(f"compute dtype {dtype} is not supported (float32 or bfloat16)") from None
+
+
+def k_multiple(dtype: torch.dtype) -> int:
+    """The K dimension of a Linear must be a multiple of this many elements (128-byte K-slabs)."""
+    return 128 // torch.empty((), dtype=dtype).element_size()
+
+
+def round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def _dev(*tensors: Optional[Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "anemoi_models_amd kernels run on an MI355X only: got a CPU tensor (there is no CPU fallback)"
+            )
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t: Tensor) -> Tensor:
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"expected a row-major 2-D tensor (unit inner stride), got shape {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:
+    _dev(x, weight, bias, out)
+    _rows(x)
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    st = _lib.load().anemoi_layer_norm(dtype_code(x.dtype), x.data_ptr(), _ld(x), weight.data_ptr(), bias.data_ptr(),
+                                       out.data_ptr(), _ld(_rows(out)), x.shape[0], x.shape[1], eps, _stream())
+    _lib.check(st, "anemoi_layer_norm")
+    return out
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "Identity",
+           residual: Optional[Tensor] = None, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+           n_out: Optional[int] = None) -> Tensor:
+    """``act(x @ w.T + bias) + residual``; ``w`` is ``[N, K]`` in x's dtype with K already padded like x."""
+    _dev(x, w, bias, residual, out)
+    _rows(x)
+    if w.dtype != x.dtype or not w.is_contiguous():
+        raise ValueError("linear: weight must be contiguous and in the activation dtype")
+    n = w.shape[0] if n_out is None else n_out
+    k = w.shape[1]
+    if x.shape[1] != k:
+        raise ValueError(f"linear: x has {x.shape[1]} columns, weight expects {k}")
+    if out is None:
+        out = torch.empty((x.shape[0], n), dtype=out_dtype or x.dtype, device=x.device)
+    if act not in _lib.ACT_CODES:
+        raise RuntimeError(f"activation {act} is not supported by the fused Linear kernel")
+    st = _lib.load().anemoi_linear(
+        dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias), _ptr(residual),
+        0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)), x.shape[0], n, k,
+        _lib.ACT_CODES[act], _stream())
+    _lib.check(st, "anemoi_linear")
+    return out
+
+
+def edge_attr_csr(a0: Tensor, a1: Optional[Tensor], perm: Tensor, ld_out: Optional[int] = None) -> Tensor:
+    """Edge attributes ``[a0 | a1]`` gathered into CSR order (rows ``perm[e] % a0.shape[0]``), f32, zero padded."""
+    _dev(a0, a1, perm)
+    d0 = a0.shape[1]
+    d1 = 0 if a1 is None else a1.shape[1]
+    ld = round_up(d0 + d1, 4) if ld_out is None else ld_out
+    a0 = a0.contiguous().float()
+    a1 = None if a1 is None else a1.contiguous().float()
+    out = torch.empty((perm.shape[0], ld), dtype=torch.float32, device=a0.device)
+    st = _lib.load().anemoi_edge_attr_csr(a0.data_ptr(), d0, _ptr(a1), d1, a0.shape[0], perm.data_ptr(),
+                                          out.data_ptr(), ld, perm.shape[0], _stream())
+    _lib.check(st, "anemoi_edge_attr_csr")
+    return out
+
+
+def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], edge_attr: Tensor, edge_dim: int,
+                      w_edge: Tensor, b_edge: Tensor, rowptr: Tensor, col: Tensor, num_heads: int,
+                      out: Optional[Tensor] = None) -> Tensor:
+    """Fused gather -> lin_edge -> score -> segment softmax -> weighted scatter-sum (+ x_r) over a dst-CSR graph."""
+    _dev(q, k, v, x_r, edge_attr, w_edge, b_edge, rowptr, col, out)
+    n_dst, c = _rows(q).shape
+    if _ld(_rows(k)) != _ld(_rows(v)):
+        raise ValueError("gt_edge_attention: k and v must share their leading dimension")
+    if out is None:
+        out = torch.empty((n_dst, c), dtype=q.dtype, device=q.device)
+    if rowptr.dtype != torch.int32 or col.dtype != torch.int32 or rowptr.shape[0] != n_dst + 1:
+        raise ValueError("gt_edge_attention: rowptr/col must be int32 with rowptr of length n_dst + 1")
+    st = _lib.load().anemoi_gt_edge_attention(
+        dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(k), _ptr(x_r),
+        0 if x_r is None else _ld(_rows(x_r)), edge_attr.data_ptr(), edge_attr.stride(0) if edge_attr.shape[0] > 1
+        else edge_attr.shape[1], edge_dim, w_edge.data_ptr(), b_edge.data_ptr(), rowptr.data_ptr(), col.data_ptr(),
+        out.data_ptr(), _ld(_rows(out)), n_dst, c, num_heads, _stream())
+    _lib.check(st, "anemoi_gt_edge_attention")
+    return out
+
+
+def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Tensor], batch_size: int,
+                   dtype: torch.dtype, ld_out: Optional[int] = None, ensemble: int = 1) -> Tensor:
+    """Rows ``(b, ens, g)`` of ``[x (time-major) | latlons | trainable | 0-pad]`` in ``dtype``."""
+    _dev(x, latlons, trainable)
+    g = latlons.shape[0]
+    n_ll = latlons.shape[1]
+    n_tr = 0 if trainable is None else trainable.shape[1]
+    if x is not None:
+        b, t, ens, gx, v = x.shape
+        if gx != g or b != batch_size:
+            raise ValueError(f"assemble_nodes: x has shape {tuple(x.shape)} but the graph has {g} nodes")
+        x = x.contiguous().float()
+    else:
+        b, t, ens, v = batch_size, 0, ensemble, 0
+    width = t * v + n_ll + n_tr
+    ld = width if ld_out is None else ld_out
+    out = torch.empty((b * ens * g, ld), dtype=dtype, device=latlons.device)
+    latlons = latlons.contiguous().float()
+    trainable = None if trainable is None else trainable.contiguous().float()
+    st = _lib.load().anemoi_assemble_nodes(dtype_code(dtype), _ptr(x), b, t, ens, g, v, latlons.data_ptr(), n_ll,
+                                           _ptr(trainable), n_tr, out.data_ptr(), ld, _stream())
+    _lib.check(st, "anemoi_assemble_nodes")
+    return out
+
+
+def prognostic_residual(y: Tensor, x: Tensor, out_idx: Tensor, in_idx: Tensor) -> Tensor:
+    """In place: ``y[..., out_idx] += x[:, -1, :, :, in_idx]`` (y f32 ``[B, Ens, G, V_out]`` contiguous)."""
+    _dev(y, x, out_idx, in_idx)
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise ValueError("prognostic_residual: y must be contiguous float32")
+    b, t, ens, g, v_in = x.shape
+    x = x.contiguous().float()
+    st = _lib.load().anemoi_prognostic_residual(y.data_ptr(), y.shape[-1], x.data_ptr(), b, t, ens, g, v_in,
+                                                out_idx.data_ptr(), in_idx.data_ptr(), out_idx.shape[0], _stream())
+    _lib.check(st, "anemoi_prognostic_residual")
+    return y
+
+
+def convert_pad(src: Tensor, dtype: torch.dtype, ld_out: Optional[int] = None) -> Tensor:
+    """Copy ``src`` ([rows, cols]) into a ``dtype`` buffer whose rows are zero padded to ``ld_out`` columns."""
+    _dev(src)
+    _rows(src)
+    rows, cols = src.shape
+    ld = cols if ld_out is None else ld_out
+    out = torch.empty((rows, ld), dtype=dtype, device=src.device)
+    st = _lib.load().anemoi_convert_pad(dtype_code(src.dtype), src.data_ptr(), _ld(src), dtype_code(dtype),
+                                        out.data_ptr(), ld, rows, cols, _stream())
+    _lib.check(st, "anemoi_convert_pad")
+    return out
+
+
+def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    _dev(a, b, out)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("add: shape / dtype mismatch")
+    if out is None:
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    st = _lib.load().anemoi_add(dtype_code(a.dtype), a.data_ptr(), _ld(_rows(a)), b.data_ptr(), _ld(_rows(b)),
+                                out.data_ptr(), _ld(_rows(out)), a.shape[0], a.shape[1], _stream())
+    _lib.check(st, "anemoi_add")
+    return out

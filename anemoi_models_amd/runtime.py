@@ -1,0 +1,161 @@
+"""Host-side runtime state shared by the layer mirrors: compute dtype policy, dst-sorted CSR plans
+of the edge sets, and packed (concatenated / cast / K-padded) weights.
+
+Plans and packed weights are plumbing built with torch ops on the tensors' own device and cached;
+they are recomputed when the underlying tensor is replaced or modified in place (``_version``).
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Callable, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+_FORCED_DTYPE = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                 "bfloat16": torch.bfloat16}
+
+
+def compute_dtype(x: Tensor) -> torch.dtype:
+    """Storage type of activations / GEMM weights for this call.
+
+    ``ANEMOI_AMD_DTYPE=fp32|bf16`` forces it; otherwise an active CUDA autocast context selects its
+    dtype (what anemoi-training's ``precision: 16-mixed / bf16-mixed`` does to the reference) and
+    without autocast the input dtype is kept (f32 in -> exact-f32 kernels).
+    """
+    forced = os.environ.get("ANEMOI_AMD_DTYPE")
+    if forced:
+        return _FORCED_DTYPE[forced.lower()]
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_gpu_dtype()
+        if dt not in (torch.bfloat16, torch.float32):
+            raise NotImplementedError(f"autocast dtype {dt} is not supported on the MI355X path (use bfloat16)")
+        return dt
+    return torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+
+
+def require_inference(*modules: torch.nn.Module) -> None:
+    """The HIP path is forward-only in this release: refuse to run where autograd would need a backward."""
+    if torch.is_grad_enabled() and any(p.requires_grad for m in modules for p in m.parameters()):
+        raise NotImplementedError(
+            "anemoi_models_amd: the MI355X kernels implement the forward pass only; run under torch.no_grad() / "
+            "torch.inference_mode() (backward is listed as the next step in DESIGN.md)"
+        )
+
+
+# ------------------------------------------------------------------------------------------ CSR plans
+@dataclass
+class EdgePlan:
+    """Destination-sorted CSR view of an ``int64 [2, E]`` edge index (row 0 = src, row 1 = dst).
+
+    ``perm[e]`` = original edge id at CSR slot ``e``.  The sort is stable, so the edges of one
+    destination keep their original relative order (= the summation order of the reference's
+    ``scatter_add_``).
+    """
+
+    rowptr: Tensor  # int32 [n_dst + 1]
+    col: Tensor  # int32 [E]  source node of CSR slot e
+    perm: Tensor  # int32 [E]
+    n_src: int
+    n_dst: int
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.col.shape[0])
+
+
+def build_edge_plan(edge_index: Tensor, n_src: int, n_dst: int) -> EdgePlan:
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+    e = edge_index.shape[1]
+    if e >= 2**31 or n_src >= 2**31 or n_dst >= 2**31:
+        raise NotImplementedError("edge / node counts beyond int32 are not supported")
+    src, dst = edge_index[0], edge_index[1]
+    if e > 0:
+        smin, smax = int(src.min()), int(src.max())
+        dmin, dmax = int(dst.min()), int(dst.max())
+        if smin < 0 or smax >= n_src or dmin < 0 or dmax >= n_dst:
+            raise ValueError(
+                f"edge_index out of range: src in [{smin}, {smax}] for {n_src} source nodes, "
+                f"dst in [{dmin}, {dmax}] for {n_dst} destination nodes"
+            )
+    perm = torch.argsort(dst, stable=True)
+    counts = torch.bincount(dst, minlength=n_dst)
+    rowptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=edge_index.device)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    return EdgePlan(rowptr.to(torch.int32), src[perm].to(torch.int32).contiguous(), perm.to(torch.int32), n_src,
+                    n_dst)
+
+
+class PlanCache:
+    """Edge plans keyed by the identity + version of the edge-index tensor they were built from."""
+
+    def __init__(self) -> None:
+        self._plans: dict = {}
+
+    def get(self, edge_index: Tensor, n_src: int, n_dst: int, batch_size: int = 1,
+            edge_inc: Optional[Tensor] = None) -> EdgePlan:
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(edge_index.device), n_src,
+               n_dst, batch_size)
+        plan = self._plans.get(key)
+        if plan is None:
+            ei = edge_index
+            if batch_size > 1:
+                ei = expand_edges(edge_index, edge_inc, batch_size)
+            plan = build_edge_plan(ei, n_src, n_dst)
+            if len(self._plans) > 16:
+                self._plans.clear()
+            self._plans[key] = plan
+        return plan
+
+
+def expand_edges(edge_index: Tensor, edge_inc: Tensor, batch_size: int) -> Tensor:
+    """Batched edge index: block ``i`` is ``edge_index + i * edge_inc`` (reference layers/mapper.py:150-171)."""
+    return torch.cat([edge_index + i * edge_inc for i in range(batch_size)], dim=1)
+
+
+# ------------------------------------------------------------------------------------------ packed weights
+class PackedWeights:
+    """Cache of derived weight tensors (concatenated, cast to the compute dtype, K padded)."""
+
+    def __init__(self) -> None:
+        self._store: dict = {}
+
+    def get(self, key, params: Sequence[Optional[Tensor]], build: Callable[[], Tensor]) -> Tensor:
+        ver = tuple((p.data_ptr(), p._version, p.device) for p in params if p is not None)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            val = build()
+        self._store[key] = (ver, val)
+        return val
+
+    def clear(self) -> None:
+        self._store.clear()
+
+
+def pack_weight(weights: Sequence[Tensor], dtype: torch.dtype) -> Tensor:
+    """``cat(weights, 0)`` as ``[N, K_pad]`` in ``dtype`` with K zero padded to the kernel's K-slab multiple."""
+    w = torch.cat([t.detach() for t in weights], dim=0) if len(weights) > 1 else weights[0].detach()
+    k = w.shape[1]
+    kp = ops.round_up(k, ops.k_multiple(dtype))
+    out = torch.zeros((w.shape[0], kp), dtype=dtype, device=w.device)
+    out[:, :k] = w.to(dtype)
+    return out
+
+
+def pack_bias(biases: Sequence[Optional[Tensor]], sizes: Sequence[int], device) -> Tensor:
+    parts = [b.detach().float() if b is not None else torch.zeros(n, dtype=torch.float32, device=device)
+             for b, n in zip(biases, sizes)]
+    return torch.cat(parts, 0).contiguous() if len(parts) > 1 else parts[0].contiguous()
+
+
+def f32c(t: Tensor) -> Tensor:
+    """f32 contiguous view of a parameter (no copy for the usual f32 parameter)."""
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()

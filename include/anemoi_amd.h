@@ -1,0 +1,131 @@
+/*
+ * anemoi_amd.h -- C ABI of the MI355X (gfx950) forward-path kernels.
+ *
+ * Drop-in boundary for the encoder -> processor -> decoder forward path of
+ * ecmwf/anemoi-models.  The reference has no FFI of its own: the boundary there
+ * is the set of nn.Module.forward methods in anemoi/models/layers (SURVEY.md
+ * section 8b).  Each entry point below replaces the ATen / torch_geometric op
+ * sequence of one such method; the citation names the reference lines it
+ * replaces (paths relative to /root/reference/src/anemoi/models).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     stated otherwise; `stream` is a hipStream_t passed as void*.
+ *   - node / edge feature matrices are row-major with an explicit leading
+ *     dimension (in elements), so slices of wider buffers can be passed.
+ *   - `dtype` selects the storage type of activations and GEMM weights:
+ *     ANEMOI_F32 (exact f32 MFMA / f32 math) or ANEMOI_BF16 (bf16 storage,
+ *     f32 accumulate).  Biases, LayerNorm affine parameters, edge attributes and
+ *     the lin_edge weights are always f32.
+ *   - every function returns ANEMOI_OK (0) or an error code; the message of the
+ *     last error on the calling thread is available from anemoi_last_error().
+ *     Nothing is allocated, no global state is kept, all launches go to `stream`.
+ */
+#ifndef ANEMOI_AMD_H
+#define ANEMOI_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANEMOI_OK 0
+#define ANEMOI_ERR_INVALID 1     /* bad argument; Python shim raises ValueError        */
+#define ANEMOI_ERR_UNSUPPORTED 2 /* unsupported shape/dtype; shim raises NotImplementedError */
+#define ANEMOI_ERR_LAUNCH 3      /* HIP launch failure; shim raises RuntimeError          */
+
+#define ANEMOI_F32 0
+#define ANEMOI_BF16 1
+
+#define ANEMOI_ACT_NONE 0
+#define ANEMOI_ACT_GELU 1 /* exact erf form, nn.GELU() default */
+#define ANEMOI_ACT_SILU 2
+#define ANEMOI_ACT_RELU 3
+
+typedef void* anemoi_stream_t; /* hipStream_t */
+
+/* ABI version (bumped on any signature change) and last error text of this thread. */
+int anemoi_abi_version(void);
+const char* anemoi_last_error(void);
+
+/*
+ * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean_r) * rstd_r * gamma + beta.
+ * Replaces nn.LayerNorm calls layers/block.py:614 (layer_norm1), :491-494 (layer_norm1/2 of the
+ * mapper block), node_dst_mlp[0] :349-351, node_data_extractor[0] layers/mapper.py:408-410.
+ * Statistics in f32 (two-pass, biased variance, eps inside the sqrt) as ATen does.
+ */
+int anemoi_layer_norm(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                      int64_t ldy, int64_t rows, int C, float eps, anemoi_stream_t stream);
+
+/*
+ * Fused Linear: y = act(x @ W^T + bias) + residual, on MFMA.
+ *   x [M, K] (ldx), W [N, K] row-major contiguous in `dtype` (nn.Linear layout), bias [N] f32 or NULL,
+ *   residual [M, N] (ldr) in `dtype` or NULL, y [M, N] (ldy) in `out_dtype`.
+ * K must be a multiple of 32 (the host pads the K dimension of x and W with zeros).
+ * Replaces the nn.Linear calls layers/block.py:615-618 (lin_self/query/key/value as ONE GEMM over the
+ * concatenated weight), :630 (projection, + x_skip :632 as residual), node_dst_mlp[1..3] :633
+ * (GELU and the "+ out" residual fused), layers/mapper.py:112-113,416 (emb_nodes_*), :100
+ * (node_data_extractor[1]), layers/attention.py:68,110 and the MLPs of layers/mlp.py:74-84.
+ */
+int anemoi_linear(int dtype, int out_dtype, const void* x, int64_t ldx, const void* w, const float* bias,
+                  const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
+                  anemoi_stream_t stream);
+
+/*
+ * Edge attributes in CSR (destination-sorted) order:
+ *   out[e, :] = [ a0[perm[e] % rows0, 0:d0] | a1[perm[e] % rows0, 0:d1] | 0 ... ]   (row stride ld_out)
+ * `perm[e]` is the original (batched) edge id of CSR slot e.  Replaces TrainableTensor.forward
+ * (layers/graph.py:37-44: repeat over the batch + concat of the trainable tensor) composed with the edge
+ * gather that torch_geometric's propagate performs per block.  a1 may be NULL (d1 = 0).
+ */
+int anemoi_edge_attr_csr(const float* a0, int d0, const float* a1, int d1, int64_t rows0, const int32_t* perm,
+                         float* out, int ld_out, int64_t n_edges, anemoi_stream_t stream);
+
+/*
+ * Fused GraphTransformer edge phase for all destinations (K1 + K2 of SURVEY.md section 2a):
+ *   e_ij   = W_e a_ij + b_e                                        (lin_edge, layers/block.py:499,620)
+ *   s_ij,h = q_i,h . (k_j,h + e_ij,h) / sqrt(D)                    (layers/conv.py:134-137)
+ *   alpha  = exp(s - max_i) / (sum_i exp(s - max_i) + 1e-16)       (PyG softmax, layers/conv.py:139)
+ *   out_i  = sum_j alpha_ij,h (v_j,h + e_ij,h)  [+ x_r_i]          (layers/conv.py:142 + scatter-sum;
+ *                                                                   "+ x_r" of layers/block.py:531,630)
+ * Graph given as CSR by destination: rowptr [n_dst+1], col [E] (source index), edge_attr [E, ea_ld] f32 in
+ * CSR order.  Edges of one destination are accumulated in CSR order (= original edge order when the CSR is a
+ * stable sort), destinations without edges give out_i = 0 (+ x_r_i).  One pass, no atomics, no [E, C]
+ * temporaries.  q/k/v/x_r/out are [*, C] slices with leading dimensions; H heads of D = C/H channels.
+ */
+int anemoi_gt_edge_attention(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                             const void* x_r, int64_t ldr, const float* edge_attr, int ea_ld, int edge_dim,
+                             const float* w_edge, const float* b_edge, const int32_t* rowptr, const int32_t* col,
+                             void* out, int64_t ldo, int64_t n_dst, int C, int H, anemoi_stream_t stream);
+
+/*
+ * Input assembly (I/O glue K9): rows (b, ens, g) of
+ *   out = [ x[b, 0..T-1, ens, g, 0..V-1] (time-major) | latlons[g, 0:n_ll] | trainable[g, 0:n_tr] | 0-pad ]
+ * x is f32 [B, T, Ens, G, V] contiguous; out is `dtype` with leading dimension ldo >= T*V + n_ll + n_tr.
+ * Replaces einops.rearrange + NamedNodesAttributes + torch.cat, models/encoder_processor_decoder.py:173-181.
+ * With x == NULL (T = 0) it produces the hidden-node attribute matrix of line :181.
+ */
+int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
+                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo,
+                          anemoi_stream_t stream);
+
+/*
+ * Prognostic residual (models/encoder_processor_decoder.py:227), in place on the f32 output:
+ *   y[b, ens, g, out_idx[p]] += x[b, T-1, ens, g, in_idx[p]]   for p < n_prog.
+ */
+int anemoi_prognostic_residual(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
+                               const int32_t* out_idx, const int32_t* in_idx, int n_prog, anemoi_stream_t stream);
+
+/* dtype conversion / K-padding copy: dst[r, 0:cols] = src[r, 0:cols], dst[r, cols:ld_dst] = 0. */
+int anemoi_convert_pad(int src_dtype, const void* src, int64_t ld_src, int dst_dtype, void* dst, int64_t ld_dst,
+                       int64_t rows, int cols, anemoi_stream_t stream);
+
+/* y = a + b elementwise over [rows, cols] slices (processor skip, models/encoder_processor_decoder.py:204). */
+int anemoi_add(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
+               int cols, anemoi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANEMOI_AMD_H */

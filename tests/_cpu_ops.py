@@ -1,0 +1,90 @@
+"""CPU stand-ins for ``anemoi_models_amd.ops`` used ONLY by tests of the host logic.
+
+They are built on plain torch + the oracle and are substituted from the tests (monkeypatch); the package never
+imports this file.  Purpose: check, without a GPU, that the launch sequences written in the layer mirrors
+(weight packing, concatenated GEMMs, CSR plans, K padding, residual placement) compute the reference function.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from oracle.pyg_semantics import scatter_sum
+from oracle.pyg_semantics import segment_softmax
+
+_ACT = {"Identity": lambda t: t, "GELU": F.gelu, "SiLU": F.silu, "ReLU": F.relu}
+
+
+def layer_norm(x, weight, bias, eps=1e-5, out=None):
+    return F.layer_norm(x.float(), (x.shape[1],), weight, bias, eps).to(x.dtype)
+
+
+def linear(x, w, bias=None, *, act="Identity", residual=None, out=None, out_dtype=None, n_out=None):
+    assert x.shape[1] == w.shape[1] and w.shape[1] % (128 // x.element_size()) == 0, "K must be slab padded"
+    y = _ACT[act](F.linear(x.float(), w.float(), bias))
+    if residual is not None:
+        y = y + residual.float()
+    return y.to(out_dtype or x.dtype)
+
+
+def edge_attr_csr(a0, a1, perm, ld_out=None):
+    rows = perm.long() % a0.shape[0]
+    parts = [a0[rows].float()] + ([] if a1 is None else [a1[rows].float()])
+    out = torch.cat(parts, dim=1)
+    ld = (out.shape[1] + 3) // 4 * 4 if ld_out is None else ld_out
+    return F.pad(out, (0, ld - out.shape[1]))
+
+
+def gt_edge_attention(q, k, v, x_r, edge_attr, edge_dim, w_edge, b_edge, rowptr, col, num_heads, out=None):
+    n_dst, c = q.shape
+    d = c // num_heads
+    dst = torch.repeat_interleave(torch.arange(n_dst), (rowptr[1:] - rowptr[:-1]).long())
+    src = col.long()
+    e = F.linear(edge_attr[:, :edge_dim], w_edge, b_edge).view(-1, num_heads, d)
+    qi = q.float().view(n_dst, num_heads, d)[dst]
+    kj = k.float().reshape(-1, num_heads, d)[src] + e
+    vj = v.float().reshape(-1, num_heads, d)[src] + e
+    alpha = segment_softmax((qi * kj).sum(-1) / d**0.5, dst, n_dst)
+    res = scatter_sum(vj * alpha.unsqueeze(-1), dst, n_dst).reshape(n_dst, c)
+    if x_r is not None:
+        res = res + x_r.float()
+    return res.to(q.dtype)
+
+
+def assemble_nodes(x, latlons, trainable, batch_size, dtype, ld_out=None, ensemble=1):
+    parts = []
+    if x is not None:
+        b, t, ens, g, v = x.shape
+        parts.append(x.permute(0, 2, 3, 1, 4).reshape(b * ens * g, t * v))
+        rep = b
+    else:
+        rep = batch_size
+    parts.append(latlons.repeat(rep, 1))
+    if trainable is not None:
+        parts.append(trainable.detach().repeat(rep, 1))
+    out = torch.cat(parts, dim=1)
+    ld = out.shape[1] if ld_out is None else ld_out
+    return F.pad(out, (0, ld - out.shape[1])).to(dtype)
+
+
+def prognostic_residual(y, x, out_idx, in_idx):
+    y[..., out_idx.long()] += x[:, -1, :, :, in_idx.long()]
+    return y
+
+
+def convert_pad(src, dtype, ld_out=None):
+    ld = src.shape[1] if ld_out is None else ld_out
+    return F.pad(src, (0, ld - src.shape[1])).to(dtype)
+
+
+def add(a, b, out=None):
+    return a + b
+
+
+def install(monkeypatch):
+    import anemoi_models_amd.ops as ops
+
+    for name in ("layer_norm", "linear", "edge_attr_csr", "gt_edge_attention", "assemble_nodes",
+                 "prognostic_residual", "convert_pad", "add"):
+        monkeypatch.setattr(ops, name, globals()[name])

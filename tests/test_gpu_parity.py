@@ -1,0 +1,232 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): HIP kernels through the C ABI vs the CPU oracle.
+
+Tolerances: f32 path <= 1e-3 relative (north star), in practice ~1e-5; bf16 path is reported against the f32
+oracle with a bf16-appropriate bound.  Index outputs are bit exact.
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import split_prefix
+from oracle import reference_path as ref
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from anemoi_models_amd import _lib
+
+    _lib.load()  # the native library must be present: no fallback
+    assert torch.cuda.is_available()
+
+
+# ------------------------------------------------------------------------------------------- ops
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,c", [(1, 64), (257, 512), (1000, 1024), (33, 2048), (5, 100), (7, 4096)])
+def test_layer_norm(dtype, rows, c):
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(rows * 7 + c)
+    x = (torch.randn(rows, c, generator=g) * 2 + 0.5).to(dtype)
+    w, b = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    want = F.layer_norm(x.float(), (c,), w, b, 1e-5)
+    got = ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert got.dtype == dtype
+    assert rel_err(got, want) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,n,k,act,res", [
+    (128, 128, 64, "Identity", False), (1, 64, 64, "Identity", False), (300, 256, 128, "GELU", True),
+    (129, 80, 192, "Identity", False), (1000, 11, 64, "SiLU", True), (513, 1024, 1024, "GELU", False),
+    (2050, 384, 256, "ReLU", True), (77, 2048, 512, "Identity", True),
+])
+def test_linear(dtype, m, n, k, act, res):
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(m + n + k)
+    # asymmetric, non-identity operands: catches transposed fragments / swapped row<->col epilogues
+    x = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) / k**0.5).to(dtype)
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g).to(dtype) if res else None
+    acts = {"Identity": lambda t: t, "GELU": F.gelu, "SiLU": F.silu, "ReLU": F.relu}
+    want = acts[act](F.linear(x.double(), w.double(), b.double()))
+    if res:
+        want = want + r.double()
+    got = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=act, residual=None if r is None else r.to(DEV))
+    assert got.shape == (m, n) and got.dtype == dtype
+    assert rel_err(got, want) < (2e-6 if dtype == torch.float32 else 1e-2)
+
+
+def test_linear_f32_is_exact_fma_chain_and_bf16_to_f32_out():
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(200, 128, generator=g).bfloat16()
+    w = torch.randn(96, 128, generator=g).bfloat16()
+    got = ops.linear(x.to(DEV), w.to(DEV), None, out_dtype=torch.float32)
+    assert got.dtype == torch.float32
+    assert rel_err(got, F.linear(x.double(), w.double())) < 1e-5  # bf16 products are exact in f32, f32 accumulate
+    with pytest.raises(ValueError):
+        ops.linear(torch.zeros(4, 48, device=DEV), torch.zeros(8, 48, device=DEV))  # K not slab padded
+
+
+def _edge_case(n_src, n_dst, e, c, h, edge_dim, seed):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, n_dst, (e,), generator=g)])
+    if n_dst > 4:
+        ei[1, : min(e, 40)] = 2  # a high in-degree destination
+        ei[1][ei[1] == 3] = 4  # destination 3 isolated
+    q, k, v = (torch.randn(n, c, generator=g) for n in (n_dst, n_src, n_src))
+    xr = torch.randn(n_dst, c, generator=g)
+    ea = torch.randn(e, edge_dim, generator=g)
+    we, be = torch.randn(c, edge_dim, generator=g) * 0.3, torch.randn(c, generator=g) * 0.1
+    return ei, q, k, v, xr, ea, we, be
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_src,n_dst,e,c,h,edge_dim", [
+    (180, 90, 500, 64, 16, 11),     # cfg1 shape class: D=4
+    (150, 150, 700, 128, 16, 11),   # D=8
+    (300, 200, 2000, 512, 16, 11),  # cfg2: D=32
+    (120, 100, 900, 1024, 16, 11),  # cfg3: D=64
+    (64, 50, 300, 256, 16, 13),     # reference test shape: D=16, edge_dim 3+4+6
+    (40, 30, 100, 96, 8, 5),        # D=12: generic path
+    (20, 10, 0, 64, 16, 11),        # no edges at all
+    (30, 1, 64, 128, 4, 20),        # single destination, wide edge_dim (generic path)
+])
+def test_gt_edge_attention(dtype, n_src, n_dst, e, c, h, edge_dim):
+    from anemoi_models_amd import ops, runtime
+
+    ei, q, k, v, xr, ea, we, be = _edge_case(n_src, n_dst, e, c, h, edge_dim, seed=c + e)
+    q, k, v, xr = (t.to(dtype) for t in (q, k, v, xr))
+    d = c // h
+    edges = F.linear(ea, we, be).view(-1, h, d)
+    want = ref.gt_conv(q.float().view(n_dst, h, d), k.float().view(n_src, h, d), v.float().view(n_src, h, d), edges,
+                       ei, n_dst).reshape(n_dst, c) + xr.float()
+    plan = runtime.build_edge_plan(ei.to(DEV), n_src, n_dst)
+    ea_csr = ops.edge_attr_csr(ea.to(DEV), None, plan.perm)
+    got = ops.gt_edge_attention(q.to(DEV), k.to(DEV), v.to(DEV), xr.to(DEV), ea_csr, edge_dim, we.to(DEV),
+                                be.to(DEV), plan.rowptr, plan.col, h)
+    assert rel_err(got, want) < (2e-5 if dtype == torch.float32 else 2e-2)
+    if e > 0 and n_dst > 4:  # isolated destination: exactly x_r
+        assert torch.equal(got[3].cpu(), xr[3])
+
+
+def test_edge_plan_on_device_is_bit_exact_with_cpu():
+    from anemoi_models_amd import runtime
+
+    g = torch.Generator().manual_seed(1)
+    ei = torch.stack([torch.randint(0, 500, (5000,), generator=g), torch.randint(0, 300, (5000,), generator=g)])
+    a, b = runtime.build_edge_plan(ei, 500, 300), runtime.build_edge_plan(ei.to(DEV), 500, 300)
+    for f in ("rowptr", "col", "perm"):
+        assert torch.equal(getattr(a, f), getattr(b, f).cpu())
+
+
+def test_glue_kernels():
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 1, 50, 7, generator=g)
+    ll, tr = torch.randn(50, 4, generator=g), torch.randn(50, 8, generator=g)
+    for dtype in (torch.float32, torch.bfloat16):
+        got = ops.assemble_nodes(x.to(DEV), ll.to(DEV), tr.to(DEV), 2, dtype, ld_out=64).cpu()
+        want = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(100, 21), ll.repeat(2, 1), tr.repeat(2, 1)], 1)
+        assert torch.equal(got[:, :33], want.to(dtype)) and torch.all(got[:, 33:] == 0)
+    hid = ops.assemble_nodes(None, ll.to(DEV), tr.to(DEV), 2, torch.float32, ld_out=32).cpu()
+    assert torch.equal(hid[:, :12], torch.cat([ll, tr], 1).repeat(2, 1)) and torch.all(hid[:, 12:] == 0)
+    y = torch.randn(2, 1, 50, 6, generator=g)
+    oi, ii = torch.tensor([0, 2, 5], dtype=torch.int32), torch.tensor([1, 3, 6], dtype=torch.int32)
+    want = y.clone()
+    want[..., oi.long()] += x[:, -1, :, :, ii.long()]
+    got = ops.prognostic_residual(y.to(DEV), x.to(DEV), oi.to(DEV), ii.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    a, b = torch.randn(33, 64, generator=g), torch.randn(33, 64, generator=g)
+    assert torch.equal(ops.add(a.to(DEV), b.to(DEV)).cpu(), a + b)
+
+
+# ------------------------------------------------------------------------------------------- blocks + model
+def test_gt_blocks_vs_golden(golden_blocks):
+    from anemoi_models_amd.layers.block import GraphTransformerMapperBlock, GraphTransformerProcessorBlock
+
+    b = golden_blocks
+    blk = GraphTransformerProcessorBlock(128, 512, 128, edge_dim=11, num_heads=16, activation="GELU")
+    blk.load_state_dict(split_prefix(b, "gtp.sd."))
+    blk = blk.to(DEV).eval()
+    with torch.no_grad():
+        y, _ = blk(b["gtp.x"].to(DEV), b["gtp.edge_attr"].to(DEV), b["gtp.edge_index"].to(DEV), (None,) * 3, 1)
+    assert rel_err(y, b["gtp.y"]) < 1e-4
+    mb = GraphTransformerMapperBlock(64, 256, 64, edge_dim=11, num_heads=16, activation="GELU")
+    mb.load_state_dict(split_prefix(b, "gtm.sd."))
+    mb = mb.to(DEV).eval()
+    with torch.no_grad():
+        (_, yd), _ = mb((b["gtm.x_src"].to(DEV), b["gtm.x_dst"].to(DEV)), b["gtm.edge_attr"].to(DEV),
+                        b["gtm.edge_index"].to(DEV), (None,) * 3, 1, size=(180, 90))
+    assert rel_err(yd, b["gtm.y_dst"]) < 1e-4
+
+
+def _build(graph, channels, layers, heads=16, processor="GraphTransformer", n_prog=10, n_forc=2, n_diag=1):
+    from anemoi_models_amd.models import AnemoiModelEncProcDec
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
+    return AnemoiModelEncProcDec(model_config=model_config(processor, channels, layers, heads), data_indices=idx,
+                                 graph_data=graph), idx
+
+
+def test_model_cfg1_vs_golden_f32(graph_o32, golden_cfg1_gt):
+    gold = golden_cfg1_gt
+    model, _ = _build(graph_o32, 64, 4)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        y = model(gold["x"].to(DEV))
+    assert y.dtype == torch.float32 and y.shape == gold["y"].shape
+    assert rel_err(y, gold["y"]) < 1e-3  # north-star tolerance
+    assert rel_err(y, gold["y"]) < 1e-4  # what f32 MFMA + f32 edge math actually deliver
+
+
+def test_model_cfg1_bf16_report(graph_o32, golden_cfg1_gt, monkeypatch):
+    gold = golden_cfg1_gt
+    model, _ = _build(graph_o32, 64, 4)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    with torch.no_grad():
+        y = model(gold["x"].to(DEV))
+    err = rel_err(y, gold["y"])
+    print(f"bf16 storage / f32 accumulate vs f32 reference, cfg1: max rel err {err:.3e}")
+    assert err < 5e-2
+
+
+def test_model_o96_ico5_512ch_vs_oracle_f32():
+    """BASELINE config 2 shape (O96 -> ico-5, 512 ch, 16 heads) with 4 processor blocks to keep the CPU oracle fast."""
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from test_oracle_golden import graph_tensors
+
+    graph = build_graph("o96_ico5")
+    torch.manual_seed(1234)
+    model, idx = _build(graph, 512, 4, n_prog=20, n_forc=4, n_diag=2)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    model.eval()
+    x = torch.randn(1, 2, 1, graph["data"].num_nodes, idx.num_input, generator=torch.Generator().manual_seed(7))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = ref.model_forward(sd, graph_tensors(graph), x, num_heads=16, num_layers=4, num_chunks=2,
+                                 prognostic_in=range(20), prognostic_out=range(20))
+        got = model.to(DEV)(x.to(DEV))
+    assert rel_err(got, want) < 1e-3

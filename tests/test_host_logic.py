@@ -1,0 +1,128 @@
+"""CPU tests of the host side: state_dict layout, config instantiation, CSR plans, launch-sequence wiring.
+
+The kernels themselves are GPU-only; here ``anemoi_models_amd.ops`` is replaced by oracle-backed torch functions
+(tests/_cpu_ops.py) so that the orchestration in the layer mirrors can be compared with the golden vectors.
+"""
+
+import json
+import os
+
+import pytest
+import torch
+
+import _cpu_ops
+from conftest import GOLDEN
+from conftest import split_prefix
+from anemoi_models_amd import runtime
+from anemoi_models_amd.models import AnemoiModelEncProcDec
+from anemoi_models_amd.utils.indices import SimpleDataIndices
+from anemoi_models_amd.utils.presets import model_config
+
+
+def build_model(graph, processor="GraphTransformer"):
+    idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+    return AnemoiModelEncProcDec(model_config=model_config(processor, 64, 4, 16), data_indices=idx, graph_data=graph)
+
+
+@pytest.mark.parametrize("processor", ["GraphTransformer", "GNN", "Transformer"])
+def test_state_dict_layout_matches_reference(graph_o32, processor):
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        ref = json.load(f)[processor]
+    sd = build_model(graph_o32, processor).state_dict()
+    assert list(sd.keys()) == list(ref.keys()) or set(sd.keys()) == set(ref.keys())
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
+def test_same_seed_same_initial_weights_as_reference(graph_o32, golden_cfg1_gt):
+    """Parameters are created in the reference's order, so a seeded construction gives the reference's init."""
+    torch.manual_seed(1234)
+    sd = build_model(graph_o32).state_dict()
+    gold = split_prefix(golden_cfg1_gt, "sd.")
+    for k in ("encoder.emb_nodes_src.weight", "processor.proc.1.blocks.1.lin_value.weight",
+              "decoder.node_data_extractor.1.weight", "decoder.proc.node_dst_mlp.3.bias"):
+        assert torch.equal(sd[k], gold[k]), k
+
+
+def test_edge_plan_is_stable_dst_sort():
+    g = torch.Generator().manual_seed(0)
+    ei = torch.stack([torch.randint(0, 50, (400,), generator=g), torch.randint(0, 30, (400,), generator=g)])
+    plan = runtime.build_edge_plan(ei, 50, 30)
+    assert plan.rowptr.dtype == torch.int32 and plan.col.dtype == torch.int32
+    assert plan.rowptr[0] == 0 and plan.rowptr[-1] == 400
+    dst_sorted = ei[1][plan.perm.long()]
+    assert torch.all(dst_sorted[1:] >= dst_sorted[:-1])
+    for d in range(30):
+        seg = plan.perm[plan.rowptr[d]:plan.rowptr[d + 1]].long()
+        assert torch.all(ei[1][seg] == d)
+        assert torch.all(seg[1:] > seg[:-1])  # stable: original edge order inside a destination
+        assert torch.equal(plan.col[plan.rowptr[d]:plan.rowptr[d + 1]].long(), ei[0][seg])
+    with pytest.raises(ValueError):
+        runtime.build_edge_plan(ei, 50, 29)
+
+
+def test_expand_edges_bit_exact(golden_index_ops):
+    z = golden_index_ops
+    inc = torch.tensor([[70], [31]], dtype=torch.int64)
+    assert torch.equal(runtime.expand_edges(z["expand.edge_index"], inc, 3), z["expand.out"])
+
+
+def test_forward_requires_no_grad(graph_o32, monkeypatch):
+    _cpu_ops.install(monkeypatch)
+    model = build_model(graph_o32)
+    with pytest.raises(NotImplementedError):
+        model(torch.zeros(1, 2, 1, graph_o32["data"].num_nodes, 12))
+
+
+def test_kernels_refuse_cpu_tensors():
+    from anemoi_models_amd import ops
+
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_gt_model_wiring_matches_golden(graph_o32, golden_cfg1_gt, monkeypatch):
+    _cpu_ops.install(monkeypatch)
+    gold = golden_cfg1_gt
+    model = build_model(graph_o32)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model.eval()
+    with torch.no_grad():
+        y = model(gold["x"])
+    torch.testing.assert_close(y, gold["y"], atol=1e-4, rtol=1e-4)
+
+
+def test_gt_blocks_wiring_matches_golden(golden_blocks, monkeypatch):
+    from anemoi_models_amd.layers.block import GraphTransformerMapperBlock
+    from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
+
+    _cpu_ops.install(monkeypatch)
+    b = golden_blocks
+    blk = GraphTransformerProcessorBlock(128, 512, 128, edge_dim=11, num_heads=16, activation="GELU")
+    blk.load_state_dict(split_prefix(b, "gtp.sd."))
+    with torch.no_grad():
+        y, ea = blk(b["gtp.x"], b["gtp.edge_attr"], b["gtp.edge_index"], (None, None, None), 1)
+    torch.testing.assert_close(y, b["gtp.y"], atol=2e-5, rtol=2e-5)
+    assert ea is b["gtp.edge_attr"]
+
+    mb = GraphTransformerMapperBlock(64, 256, 64, edge_dim=11, num_heads=16, activation="GELU").eval()
+    mb.load_state_dict(split_prefix(b, "gtm.sd."))
+    with torch.no_grad():
+        (ys, yd), _ = mb((b["gtm.x_src"], b["gtm.x_dst"]), b["gtm.edge_attr"], b["gtm.edge_index"],
+                         (None, None, None), 1, size=(180, 90))
+        assert ys is b["gtm.x_src"]
+        torch.testing.assert_close(yd, b["gtm.y_dst"], atol=2e-5, rtol=2e-5)
+        # reference test_GraphTransformerMapperBlock_chunking: chunked == unchunked
+        monkeypatch.setenv("ANEMOI_INFERENCE_NUM_CHUNKS", "5")
+        (_, yc), _ = mb((b["gtm.x_src"], b["gtm.x_dst"]), b["gtm.edge_attr"], b["gtm.edge_index"],
+                        (None, None, None), 1, size=(180, 90))
+        assert torch.allclose(yd, yc, atol=1e-4)
+        with pytest.raises(ValueError):
+            mb((b["gtm.x_src"], b["gtm.x_dst"]), b["gtm.edge_attr"], b["gtm.edge_index"], (None,) * 3, 1,
+               size=(180, 91))
+
+
+def test_bad_activation_raises_runtime_error():
+    from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
+
+    with pytest.raises(RuntimeError):
+        GraphTransformerProcessorBlock(64, 256, 64, edge_dim=11, num_heads=16, activation="NoSuchAct")
