@@ -14,6 +14,9 @@ from ctypes import c_int
 from ctypes import c_int64
 from ctypes import c_void_p
 
+import torch  # noqa: F401  -- FIRST: puts torch's bundled HIP runtime (libamdhip64.so.7) in the process so that
+#                        this library binds to the same runtime instance that owns torch's device memory
+
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libanemoi_amd.so")
 

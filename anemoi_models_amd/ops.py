@@ -106,6 +106,8 @@ def edge_attr_csr(a0: Tensor, a1: Optional[Tensor], perm: Tensor, ld_out: Option
     a0 = a0.contiguous().float()
     a1 = None if a1 is None else a1.contiguous().float()
     out = torch.empty((perm.shape[0], ld), dtype=torch.float32, device=a0.device)
+    if perm.shape[0] == 0:
+        return out
     st = _lib.load().anemoi_edge_attr_csr(a0.data_ptr(), d0, _ptr(a1), d1, a0.shape[0], perm.data_ptr(),
                                           out.data_ptr(), ld, perm.shape[0], _stream())
     _lib.check(st, "anemoi_edge_attr_csr")
