@@ -126,6 +126,9 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], ed
         out = torch.empty((n_dst, c), dtype=q.dtype, device=q.device)
     if rowptr.dtype != torch.int32 or col.dtype != torch.int32 or rowptr.shape[0] != n_dst + 1:
         raise ValueError("gt_edge_attention: rowptr/col must be int32 with rowptr of length n_dst + 1")
+    if col.shape[0] == 0:  # graph without edges: the C ABI still wants valid (never dereferenced) pointers
+        col = torch.zeros(1, dtype=torch.int32, device=q.device)
+        edge_attr = torch.zeros((1, max(4, round_up(edge_dim, 4))), dtype=torch.float32, device=q.device)
     st = _lib.load().anemoi_gt_edge_attention(
         dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(k), _ptr(x_r),
         0 if x_r is None else _ld(_rows(x_r)), edge_attr.data_ptr(), edge_attr.stride(0) if edge_attr.shape[0] > 1
