@@ -18,6 +18,31 @@ from . import _lib
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
+# Optional per-launch timing used by bench.py's roofline leg (never active inside a timed region):
+# when PROFILE is a list, every wrapper appends (kernel name, start event, end event, work dict) with the
+# events recorded on the stream the kernel is launched on.
+PROFILE: Optional[list] = None
+
+
+class _Timed:
+    __slots__ = ("name", "work", "start")
+
+    def __init__(self, name: str, **work) -> None:
+        self.name, self.work, self.start = name, work, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream())
+            PROFILE.append((self.name, self.start, end, self.work))
+        return False
+
 
 def dtype_code(dtype: torch.dtype) -> int:
     try:
@@ -67,8 +92,10 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, out: 
     _rows(x)
     if out is None:
         out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
-    st = _lib.load().anemoi_layer_norm(dtype_code(x.dtype), x.data_ptr(), _ld(x), weight.data_ptr(), bias.data_ptr(),
-                                       out.data_ptr(), _ld(_rows(out)), x.shape[0], x.shape[1], eps, _stream())
+    with _Timed("layer_norm", bytes=2 * x.shape[0] * x.shape[1] * x.element_size()):
+        st = _lib.load().anemoi_layer_norm(dtype_code(x.dtype), x.data_ptr(), _ld(x), weight.data_ptr(),
+                                           bias.data_ptr(), out.data_ptr(), _ld(_rows(out)), x.shape[0], x.shape[1],
+                                           eps, _stream())
     _lib.check(st, "anemoi_layer_norm")
     return out
 
@@ -89,10 +116,11 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
         out = torch.empty((x.shape[0], n), dtype=out_dtype or x.dtype, device=x.device)
     if act not in _lib.ACT_CODES:
         raise RuntimeError(f"activation {act} is not supported by the fused Linear kernel")
-    st = _lib.load().anemoi_linear(
-        dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias), _ptr(residual),
-        0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)), x.shape[0], n, k,
-        _lib.ACT_CODES[act], _stream())
+    with _Timed("linear", flops=2 * x.shape[0] * n * k, m=x.shape[0], n=n, k=k):
+        st = _lib.load().anemoi_linear(
+            dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
+            _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)),
+            x.shape[0], n, k, _lib.ACT_CODES[act], _stream())
     _lib.check(st, "anemoi_linear")
     return out
 
@@ -129,11 +157,16 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], ed
     if col.shape[0] == 0:  # graph without edges: the C ABI still wants valid (never dereferenced) pointers
         col = torch.zeros(1, dtype=torch.int32, device=q.device)
         edge_attr = torch.zeros((1, max(4, round_up(edge_dim, 4))), dtype=torch.float32, device=q.device)
-    st = _lib.load().anemoi_gt_edge_attention(
-        dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(k), _ptr(x_r),
-        0 if x_r is None else _ld(_rows(x_r)), edge_attr.data_ptr(), edge_attr.stride(0) if edge_attr.shape[0] > 1
-        else edge_attr.shape[1], edge_dim, w_edge.data_ptr(), b_edge.data_ptr(), rowptr.data_ptr(), col.data_ptr(),
-        out.data_ptr(), _ld(_rows(out)), n_dst, c, num_heads, _stream())
+    # algorithmic bytes per SURVEY.md section 8d: q + out over the destinations, k + v over the sources (each once),
+    # 48 B of raw attributes + 4 B column index per edge, the row pointers
+    alg_bytes = (2 * n_dst + 2 * k.shape[0]) * c * q.element_size() + col.shape[0] * 52 + (n_dst + 1) * 4
+    with _Timed("gt_edge_attention", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
+        st = _lib.load().anemoi_gt_edge_attention(
+            dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(k), _ptr(x_r),
+            0 if x_r is None else _ld(_rows(x_r)), edge_attr.data_ptr(),
+            edge_attr.stride(0) if edge_attr.shape[0] > 1 else edge_attr.shape[1], edge_dim, w_edge.data_ptr(),
+            b_edge.data_ptr(), rowptr.data_ptr(), col.data_ptr(), out.data_ptr(), _ld(_rows(out)), n_dst, c,
+            num_heads, _stream())
     _lib.check(st, "anemoi_gt_edge_attention")
     return out
 

@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Headline benchmark: mesh-node updates/sec of one full encoder -> processor -> decoder forward step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json / SURVEY.md section 8d): ``N_mesh x num_processor_blocks / t_fwd`` with ``t_fwd`` the wall time
+of one ``AnemoiModelEncProcDec.forward`` (batch 1, eval, no grad), inputs resident in HBM.  Default workload: BASELINE
+config 3 (N320 -> ico-6, 16 GraphTransformer blocks, 1024 channels, 2 x 90 input variables) on synthetic graph /
+state / weights, bf16 storage with f32 accumulation.  One process per GPU; with N > 1 the mesh is node-partitioned
+over the ranks of one model group (strong scaling: the same single forward step is shared by all ranks).
+
+The JSON line also carries
+  roofline      the dominant kernel (fused Linear, MFMA bound): algorithmic flops / measured kernel time, live,
+                from HIP events on the launch stream in a separate instrumented pass (not inside the timed region);
+  roofline_edge the fused gather/scatter edge kernel against the HBM roofline (algorithmic bytes of section 8d);
+  cpu_baseline  the CPU oracle (plain PyTorch, same algorithm as the reference) timed on this host's cores on a
+                bounded sample of the same workload.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks (bf16 / exact-f32 MFMA)
+
+WORKLOADS = {
+    # name: (graph, channels, processor blocks, heads, description)
+    "cfg1": ("o32_ico2", 64, 4, 16, "O32->ico-2, 4 GT blocks, 64 ch"),
+    "cfg2": ("o96_ico5", 512, 16, 16, "O96->ico-5, 16 GT blocks, 512 ch"),
+    "cfg3": ("n320_ico6", 1024, 16, 16, "N320->ico-6, 16 GT blocks, 1024 ch"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-blocks", type=int, default=2, help="processor blocks in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def build(workload: str, device):
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.models import AnemoiModelEncProcDec
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    graph_name, channels, layers, heads, _ = WORKLOADS[workload]
+    graph = build_graph(graph_name)
+    idx = SimpleDataIndices(n_prognostic=80, n_forcing=10, n_diagnostic=0)
+    torch.manual_seed(1234)
+    with torch.device(device):  # random-init the weights directly in HBM
+        model = AnemoiModelEncProcDec(model_config=model_config("GraphTransformer", channels, layers, heads),
+                                      data_indices=idx, graph_data=graph.to(device))
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    model = model.to(device).eval()
+    x = torch.randn((1, 2, 1, graph["data"].num_nodes, idx.num_input), generator=torch.Generator().manual_seed(7))
+    return model, graph, x.to(device), idx
+
+
+def profile_pass(model, x, group, dtype_name: str):
+    """One instrumented forward: HIP events around every kernel launch, on the launch stream."""
+    from anemoi_models_amd import ops
+
+    ops.PROFILE = []
+    with torch.no_grad():
+        model(x, group) if group is not None else model(x)
+    torch.cuda.synchronize()
+    records, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for name, start, end, work in records:
+        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        a["launches"] += 1
+        a["ms"] += start.elapsed_time(end)
+        a["flops"] += work.get("flops", 0)
+        a["bytes"] += work.get("bytes", 0)
+    out = {}
+    if "linear" in agg and agg["linear"]["ms"] > 0:
+        a = agg["linear"]
+        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[dtype_name]
+        out["roofline"] = {
+            "kernel": "anemoi::linear_kernel (fused Linear, MFMA)", "bound": "mfma", "achieved": round(achieved, 2),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "launches": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+            "flops_per_launch": a["flops"] / a["launches"], "share_of_step": None,
+        }
+    if "gt_edge_attention" in agg and agg["gt_edge_attention"]["ms"] > 0:
+        a = agg["gt_edge_attention"]
+        achieved = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+        out["roofline_edge"] = {
+            "kernel": "anemoi::gt_edge_attention_kernel (fused gather/lin_edge/softmax/scatter)", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
+            "avg_launch_ms": round(a["ms"] / a["launches"], 4), "bytes_per_launch": a["bytes"] / a["launches"],
+        }
+    total_ms = sum(a["ms"] for a in agg.values())
+    out["kernel_time_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    if "roofline" in out and total_ms > 0:
+        out["roofline"]["share_of_step"] = round(agg["linear"]["ms"] / total_ms, 3)
+    return out
+
+
+def cpu_baseline(model, graph, n_blocks: int):
+    """CPU oracle (plain PyTorch restatement of the reference algorithm) on a bounded sample of the workload.
+
+    Sample: the first ``n_blocks`` GraphTransformer processor blocks at the full mesh size / channel width, f32, all
+    host cores PyTorch uses.  The unit is the metric's: mesh-node updates per second over those blocks.
+    """
+    from oracle import reference_path as ref  # checker / baseline only
+
+    p = model.processor
+    sd = {"processor." + k: v.detach().float().cpu() for k, v in p.state_dict().items()}
+    edge_attr = ref.trainable_tensor(p.edge_attr.cpu(), sd["processor.trainable.trainable"], 1)
+    edge_index = p.edge_index_base.cpu()
+    n_mesh, c = graph["hidden"].num_nodes, model.num_channels
+    heads = p.proc[0].blocks[0].num_heads
+    xm = torch.randn(n_mesh, c, generator=torch.Generator().manual_seed(3))
+    blocks = [f"processor.proc.{ci}.blocks.{bi}" for ci in range(len(p.proc)) for bi in range(len(p.proc[ci].blocks))]
+    blocks = blocks[:n_blocks]
+    with torch.no_grad():
+        ref.gt_processor_block(sd, blocks[0], xm[:256], edge_attr[:8], edge_index[:, :8] % 256, heads)  # warm-up
+        t0 = time.perf_counter()
+        for name in blocks:
+            xm = ref.gt_processor_block(sd, name, xm, edge_attr, edge_index, heads)
+        dt = time.perf_counter() - t0
+    return {
+        "value": round(n_mesh * len(blocks) / dt, 1), "unit": "mesh-node updates/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{len(blocks)} of {len(p.proc) * len(p.proc[0].blocks)} GraphTransformer processor blocks at full "
+                  f"size ({n_mesh} mesh nodes, {c} ch, f32, CPU oracle = plain PyTorch), {dt:.1f} s; mappers excluded",
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    from anemoi_models_amd import _lib
+
+    _lib.load()  # fail loudly if the HIP library is missing
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        group = dist.group.WORLD
+
+    os.environ["ANEMOI_AMD_DTYPE"] = args.dtype
+    model, graph, x, _ = build(args.workload, device)
+    n_mesh = graph["hidden"].num_nodes
+    layers = WORKLOADS[args.workload][2]
+
+    def step():
+        with torch.no_grad():
+            return model(x, group) if group is not None else model(x)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if group is not None:
+            import torch.distributed as dist
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_mesh * layers / (elapsed / args.steps)
+    extra = profile_pass(model, x, group, args.dtype)
+
+    if rank == 0:
+        line = {
+            "metric": "mesh-node updates/sec (fwd step)", "value": round(value, 1), "unit": "mesh-node updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {
+                "workload": WORKLOADS[args.workload][4] + ", batch 1, 2 x 90 input vars -> 80 output vars, "
+                                                          "full encoder+processor+decoder forward",
+                "mesh_nodes": n_mesh, "grid_nodes": graph["data"].num_nodes, "processor_blocks": layers,
+                "parallelism": "single GPU" if world == 1 else f"mesh node-partitioned over {world} GPUs, halo all-to-all-v",
+                "device": torch.cuda.get_device_name(local_rank),
+            },
+        }
+        line.update(extra)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(model, graph, args.cpu_blocks)
+        print(json.dumps(line), flush=True)
+    if group is not None:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
