@@ -57,110 +57,210 @@ __device__ __forceinline__ void unpack(const typename RawVec<T, VEC>::type& raw,
 
 // ---------------------------------------------------------------------------------------------
 // Fast path: compile-time VEC (channels per lane), LPH (lanes per head) and EDP (edge_dim padded to 4).
+//
+// lin_edge is linear, so it is never evaluated per edge.  With a_ij the raw attributes (+ a constant 1
+// for the bias) and W_h the rows of W_e that belong to head h:
+//     q_i,h . (k_j,h + e_ij,h)      = q_i,h . k_j,h + (W_h^T q_i,h) . a_ij         -> u_i,h = W_h^T q_i,h  per node
+//     sum_j p_ij (v_j,h + e_ij,h)   = sum_j p_ij v_j,h + W_h (sum_j p_ij a_ij)     -> t_i,h = sum_j p_ij a_ij
+// Per edge that leaves VEC FMAs for q.k, EDP FMAs for u.a, VEC FMAs for p*v and EDP FMAs for t; W_e is
+// touched twice per destination node (u in the prologue, W t in the epilogue) and lives in LDS in a
+// lane-major layout so that each access is one conflict-free ds_read_b128 per 4 channels.
 // ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+struct QK;  // dot product of the lane's q and k slices
+
+template <int VEC>
+struct QK<float, VEC> {
+  using Raw = typename RawVec<float, VEC>::type;
+  float q[VEC];
+  __device__ __forceinline__ void set(const float (&qf)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) q[i] = qf[i];
+  }
+  __device__ __forceinline__ float dot(const Raw& kr) const {
+    float kk[VEC];
+    unpack<float, VEC>(kr, kk);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s = fmaf(q[i], kk[i], s);
+    return s;
+  }
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+template <int VEC>
+struct QK<bf16_t, VEC> {
+  using Raw = typename RawVec<bf16_t, VEC>::type;
+  static_assert(VEC % 2 == 0, "bf16 fast path packs channel pairs");
+  uint32_t q[VEC / 2];  // q stays packed: v_dot2c_f32_bf16 multiplies bf16 pairs exactly and accumulates in f32
+  __device__ __forceinline__ void set(const float (&qf)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) q[i] = pack_bf16x2(qf[2 * i], qf[2 * i + 1]);
+  }
+  __device__ __forceinline__ float dot(const Raw& kr) const {
+    const uint32_t* kw = reinterpret_cast<const uint32_t*>(&kr);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) {
+      uint32_t a = q[i], b = kw[i];
+      s = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf16x2_t*>(&a), *reinterpret_cast<bf16x2_t*>(&b), s,
+                                          false);
+    }
+    return s;
+  }
+};
+
 template <typename T, int VEC, int LPH, int EDP>
 __global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnParams p) {
-  constexpr int U = 4;  // edges in flight per wave: 2*U independent 16-byte gathers per lane
+  constexpr int U = 4;          // edges in flight per wave: 2*U independent 16-byte gathers per lane
+  constexpr int NQ = (VEC + 3) / 4;  // 16-byte LDS reads per lane per attribute row
+  constexpr int QW = VEC < 4 ? VEC : 4;
   using Raw = typename RawVec<T, VEC>::type;
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];  // [(EDP + 1) * NQ][C / VEC][QW]; row EDP = bias
+
+  const int lanes_total = p.C / VEC;
+  for (int idx = threadIdx.x; idx < (EDP + 1) * p.C; idx += blockDim.x) {
+    const int i = idx % QW;
+    const int gl = (idx / QW) % lanes_total;
+    const int ah = idx / (QW * lanes_total);
+    const int a = ah / NQ, h = ah % NQ;
+    const int c = gl * VEC + h * QW + i;
+    float val = 0.f;
+    if (a < p.edge_dim) val = p.w[(int64_t)c * p.edge_dim + a];
+    else if (a == EDP) val = p.b[c];
+    w_lds[idx] = val;
+  }
+  __syncthreads();
+
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wpb = (int)(blockDim.x >> 6);
   const int xcd = blockIdx.x & 7;
-  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
-  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * wpb + wib;
+  const int waves_per_xcd = (int)(gridDim.x >> 3) * wpb;
   const int slice = wave_in_xcd % p.n_slices;
   const int64_t node_first = wave_in_xcd / p.n_slices;
   const int64_t node_stride = waves_per_xcd / p.n_slices;
   const int64_t n0 = p.n_dst * xcd / 8, n1 = p.n_dst * (xcd + 1) / 8;
 
-  const int c0 = (slice * 64 + lane) * VEC;
-  const bool active = c0 < p.C;
-  const int cs = active ? c0 : 0;  // inactive lanes shadow channel 0 (never stored)
+  const int gl = slice * 64 + lane;  // global lane index = channel group
+  const bool active = gl < lanes_total;
+  const int gls = active ? gl : 0;  // inactive lanes shadow group 0 (never stored)
+  const int c0 = gls * VEC;
 
-  float w[VEC][EDP];
-  float bias[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    bias[i] = p.b[cs + i];
-#pragma unroll
-    for (int a = 0; a < EDP; ++a) w[i][a] = a < p.edge_dim ? p.w[(int64_t)(cs + i) * p.edge_dim + a] : 0.f;
-  }
-
-  const T* qb = static_cast<const T*>(p.q) + cs;
-  const T* kb = static_cast<const T*>(p.k) + cs;
-  const T* vb = static_cast<const T*>(p.v) + cs;
+  const T* qb = static_cast<const T*>(p.q) + c0;
+  const T* kb = static_cast<const T*>(p.k) + c0;
+  const T* vb = static_cast<const T*>(p.v) + c0;
 
   for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
-    float q[VEC];
-    VecIO<T, VEC>::load(qb + node * p.ldq, q);
     const int e_begin = p.rowptr[node], e_end = p.rowptr[node + 1];
+    QK<T, VEC> qk;
+    float u[EDP + 1];
+    // The LDS image of W_e is loop invariant; without these opaque offsets the compiler hoists all
+    // (EDP + 1) * VEC weight reads out of the node loop (and keeps them live across the edge loop),
+    // i.e. rebuilds the register-resident W_e that costs the kernel its occupancy.
+    int wofs = gls * QW;
+    asm volatile("" : "+v"(wofs));
+    {
+      float qf[VEC];
+      VecIO<T, VEC>::load(qb + node * p.ldq, qf);
+      qk.set(qf);
+      // u[a] = sum over the head's channels of W_e[c][a] * q[c]   (a = EDP: bias row)
+#pragma unroll
+      for (int a = 0; a <= EDP; ++a) {
+        float part = 0.f;
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+          float wv[QW];
+          VecIO<float, QW>::load(&w_lds[(a * NQ + h) * lanes_total * QW + wofs], wv);
+#pragma unroll
+          for (int i = 0; i < QW; ++i) part = fmaf(wv[i], qf[h * QW + i], part);
+        }
+        u[a] = group_sum<LPH>(part);
+      }
+    }
     float m = -INFINITY, l = 0.f;
-    float acc[VEC];
+    float acc[VEC], tacc[EDP];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int a = 0; a < EDP; ++a) tacc[a] = 0.f;
 
     for (int e = e_begin; e < e_end; e += U) {
       Raw kr[U], vr[U];
-      float ee[U][VEC];
       float s[U];
-      // ---- issue all gathers of this batch first
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (e + u < e_end) {
-          const int64_t j = p.col[e + u];
-          kr[u] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
-          vr[u] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          const int64_t j = p.col[e + uu];
+          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
+          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
         }
       }
-      // ---- lin_edge (scalar attribute loads, VGPR-resident weights) and scores
       float mb = m;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        s[u] = -INFINITY;
-        if (e + u < e_end) {
-          const float* at = p.attr + (int64_t)(e + u) * p.ea_ld;
+      for (int uu = 0; uu < U; ++uu) {
+        s[uu] = -INFINITY;
+        if (e + uu < e_end) {
+          const float* at = p.attr + (int64_t)(e + uu) * p.ea_ld;
+          float t = u[EDP];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) ee[u][i] = bias[i];
-#pragma unroll
-          for (int a = 0; a < EDP; ++a) {
-            const float av = at[a];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) ee[u][i] = fmaf(w[i][a], av, ee[u][i]);
-          }
-          float kk[VEC];
-          unpack<T, VEC>(kr[u], kk);
-          float part = 0.f;
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) part = fmaf(q[i], kk[i] + ee[u][i], part);
-          s[u] = group_sum<LPH>(part) * p.scale;
-          mb = fmaxf(mb, s[u]);
+          for (int a = 0; a < EDP; ++a) t = fmaf(u[a], at[a], t);
+          s[uu] = (group_sum<LPH>(qk.dot(kr[uu])) + t) * p.scale;
+          mb = fmaxf(mb, s[uu]);
         }
       }
-      // ---- online softmax update (one rescale per batch)
       const float corr = __expf(m - mb);
       l *= corr;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] *= corr;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (e + u < e_end) {
-          const float pe = __expf(s[u] - mb);
+      for (int a = 0; a < EDP; ++a) tacc[a] *= corr;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          const float* at = p.attr + (int64_t)(e + uu) * p.ea_ld;
+          const float pe = __expf(s[uu] - mb);
           l += pe;
           float vv[VEC];
-          unpack<T, VEC>(vr[u], vv);
+          unpack<T, VEC>(vr[uu], vv);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i] + ee[u][i], acc[i]);
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i], acc[i]);
+#pragma unroll
+          for (int a = 0; a < EDP; ++a) tacc[a] = fmaf(pe, at[a], tacc[a]);
         }
       }
       m = mb;
     }
 
+    // epilogue: out = (acc + W_h t + b * l) / (l + 1e-16) (+ x_r)
     const float inv = 1.0f / (l + 1e-16f);
     float o[VEC];
+    int wofs2 = gls * QW;
+    asm volatile("" : "+v"(wofs2));
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = acc[i] * inv;
+    for (int h = 0; h < NQ; ++h) {
+      float bv[QW];
+      VecIO<float, QW>::load(&w_lds[(EDP * NQ + h) * lanes_total * QW + wofs2], bv);
+#pragma unroll
+      for (int i = 0; i < QW; ++i) o[h * QW + i] = fmaf(bv[i], l, acc[h * QW + i]);
+    }
+#pragma unroll
+    for (int a = 0; a < EDP; ++a) {
+#pragma unroll
+      for (int h = 0; h < NQ; ++h) {
+        float wv[QW];
+        VecIO<float, QW>::load(&w_lds[(a * NQ + h) * lanes_total * QW + wofs2], wv);
+#pragma unroll
+        for (int i = 0; i < QW; ++i) o[h * QW + i] = fmaf(wv[i], tacc[a], o[h * QW + i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] *= inv;
     if (p.xr != nullptr) {
       float r[VEC];
-      VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + cs + node * p.ldr, r);
+      VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] += r[i];
     }
@@ -224,24 +324,41 @@ __global__ __launch_bounds__(256) void gt_edge_attention_generic_kernel(const Ed
 }
 
 template <typename T, int VEC, int LPH, int EDP>
-static void launch_fast(const EdgeAttnParams& p, hipStream_t st) {
+static bool launch_fast(const EdgeAttnParams& p, hipStream_t st) {
+  // W_e (+ bias row) in LDS: (EDP + 1) * C floats per workgroup of 4 waves
+  const size_t lds = (size_t)(EDP + 1) * p.C * sizeof(float);
+  if (lds > 160 * 1024 || p.C % VEC != 0) return false;
+  auto kern = gt_edge_attention_kernel<T, VEC, LPH, EDP>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // per instantiation
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return false;
+      raised = true;
+    }
+  }
   // persistent-style grid: 8 XCDs x blocks_per_xcd, 4 waves per block, waves_per_xcd % n_slices == 0
+  constexpr int WPB = 4;
   const int64_t units_per_xcd = ((p.n_dst + 7) / 8) * p.n_slices;
-  int64_t bpx = (units_per_xcd + 3) / 4;
-  if (bpx > 96) bpx = 96;
+  int64_t bpx = (units_per_xcd + WPB - 1) / WPB;
+  const int64_t resident = 160 * 1024 / (lds > 0 ? lds : 1);  // workgroups per CU that fit in LDS
+  int64_t cap = 32 * (resident > 4 ? 4 : (resident < 1 ? 1 : resident));  // 32 CUs per XCD
+  if (bpx > cap) bpx = cap;
   if (bpx < 1) bpx = 1;
-  bpx = (bpx + p.n_slices - 1) / p.n_slices * p.n_slices;
-  hipLaunchKernelGGL((gt_edge_attention_kernel<T, VEC, LPH, EDP>), dim3((unsigned)(8 * bpx)), dim3(256), 0, st, p);
+  while ((bpx * WPB) % p.n_slices != 0) ++bpx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * bpx)), dim3(64 * WPB), lds, st, p);
+  return true;
 }
 
 template <typename T, int VEC, int LPH>
 static bool dispatch_edp(const EdgeAttnParams& p, hipStream_t st) {
   const int edp = (p.edge_dim + 3) / 4 * 4;
   switch (edp) {
-    case 4: launch_fast<T, VEC, LPH, 4>(p, st); return true;
-    case 8: launch_fast<T, VEC, LPH, 8>(p, st); return true;
-    case 12: launch_fast<T, VEC, LPH, 12>(p, st); return true;
-    case 16: launch_fast<T, VEC, LPH, 16>(p, st); return true;
+    case 4: return launch_fast<T, VEC, LPH, 4>(p, st);
+    case 8: return launch_fast<T, VEC, LPH, 8>(p, st);
+    case 12: return launch_fast<T, VEC, LPH, 12>(p, st);
+    case 16: return launch_fast<T, VEC, LPH, 16>(p, st);
     default: return false;
   }
 }

@@ -217,6 +217,188 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, in
   }
 }
 
+// =============================================================================================
+// bf16 256 x 256 tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), K-slab 64, two LDS
+// stages of 64 KiB.  Twice the arithmetic intensity per L2/LDS byte of the 128 x 128 kernel (which is
+// L2-bandwidth bound on this chip beyond ~900 TFLOP/s).  Tiles are mapped XCD-aware: the 8 XCDs each walk
+// a contiguous range of the (mt, nt) tile list with nt fastest, so the tiles that share an x row panel
+// run on the same XCD (private L2) back to back.  The epilogue goes through LDS so that every output /
+// residual access is a full 128-byte row segment (16 bytes per lane).
+// =============================================================================================
+constexpr int BIG_M = 256, BIG_N = 256;
+constexpr int BIG_STAGE = (BIG_M + BIG_N) * ROW_BYTES;  // 64 KiB
+constexpr int BIG_LDS = 2 * BIG_STAGE;                  // 128 KiB
+
+__device__ __forceinline__ uint32_t bf16x2_add(uint32_t a, uint32_t b) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  return pack_bf16x2(lo, hi);
+}
+
+__global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+                                                              const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              const bf16_t* __restrict__ R, int64_t ldr,
+                                                              bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
+                                                              int K, int act, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // ---- XCD-aware, bijective tile mapping (cdna_hip_programming.md T1)
+  const int nt_count = (N + BIG_N - 1) / BIG_N;
+  const int64_t tiles = (int64_t)gridDim.x;
+  const int64_t q8 = tiles / 8, r8 = tiles % 8;
+  const int64_t xcd = blockIdx.x % 8;
+  const int64_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+  const int nt = (int)(tile % nt_count);
+  const int64_t mt = tile / nt_count;
+  const int64_t m0 = mt * BIG_M;
+  const int n0 = nt * BIG_N;
+  const int nk = K / 64;
+
+  // ---- staging: 32 row groups (8 rows x 128 B) per operand, 4 of each per wave
+  const int srow = lane >> 3, scp = lane & 7;
+  const char* xg[4];
+  const char* wg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    const int c = swz(r, scp);
+    int64_t gm = m0 + r;
+    if (gm > M - 1) gm = M - 1;
+    int gn = n0 + r;
+    if (gn > N - 1) gn = N - 1;
+    xg[i] = reinterpret_cast<const char*>(X + gm * ldx) + c * 16;
+    wg[i] = reinterpret_cast<const char*>(W + (int64_t)gn * K) + c * 16;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* xs = smem + buf * BIG_STAGE + wid * 4096;
+    char* ws = xs + BIG_M * ROW_BYTES;
+    const int64_t koff = (int64_t)kt * ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(xg[i] + koff, xs + i * 1024);
+      glds16(wg[i] + koff, ws + i * 1024);
+    }
+  };
+
+  const int wm = wid >> 2, wn = wid & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* xs = smem + (kt & 1) * BIG_STAGE;
+    const char* ws = xs + BIG_M * ROW_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wn * 64 + i * 16 + fr;
+        a[i] = *reinterpret_cast<const bf16x8_t*>(ws + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
+      }
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        bf16x8_t b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wm * 128 + (jh * 4 + j) * 16 + fr;
+          b[j] = *reinterpret_cast<const bf16x8_t*>(xs + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh * 4 + j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue through LDS: each wave owns a [128 rows][64 cols] bf16 image (16 KiB), 8-byte units XOR-swizzled
+  __syncthreads();  // every wave has finished reading the last K-slab
+  char* region = smem + wid * 16384;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nloc = i * 16 + fq * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+      const int n = n0 + wn * 64 + nloc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (n + r < N) ? bias[n + r] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = j * 16 + fr;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[r], act);
+      const int unit = (i * 4 + fq) ^ (row & 15);
+      *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) = make_uint2(pack_bf16x2(o[0], o[1]),
+                                                                            pack_bf16x2(o[2], o[3]));
+    }
+  }
+  // rows are read back as whole 128-byte lines: 8 lanes per row, 8 rows per pass
+  const int rc = lane & 7, rr = lane >> 3;
+#pragma unroll 4
+  for (int t = 0; t < 16; ++t) {
+    const int row = t * 8 + rr;
+    const int sft = row & 15;
+    const int base_unit = ((2 * rc) ^ sft) & ~1;
+    uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + base_unit * 8);
+    if (sft & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+    const int64_t m = m0 + wm * 128 + row;
+    const int n = n0 + wn * 64 + rc * 8;
+    if (m < M && n < N) {
+      if (vec_ok && n + 8 <= N) {
+        if (R != nullptr) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
+          v = make_uint4(bf16x2_add(v.x, rv.x), bf16x2_add(v.y, rv.y), bf16x2_add(v.z, rv.z), bf16x2_add(v.w, rv.w));
+        }
+        *reinterpret_cast<uint4*>(Y + m * ldy + n) = v;
+      } else {
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (n + c < N) {
+            float o = __uint_as_float((c & 1) ? (wv[c >> 1] & 0xffff0000u) : (wv[c >> 1] << 16));
+            if (R != nullptr) o += bf16_to_f32(R[m * ldr + n + c]);
+            Y[m * ldy + n + c] = f32_to_bf16(o);
+          }
+        }
+      }
+    }
+  }
+}
+
+static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
+                                  int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
+                                  hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess)
+      return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", BIG_LDS);
+    raised = true;
+  }
+  const int64_t mt = (M + BIG_M - 1) / BIG_M;
+  const int64_t nt = (N + BIG_N - 1) / BIG_N;
+  ANEMOI_REQUIRE(mt * nt < (int64_t)1 << 31, ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: grid too large");
+  const bool vec_ok = (N % 8 == 0) && (ldy % 8 == 0) && ((uintptr_t)y % 16 == 0) &&
+                      (residual == nullptr || (ldr % 8 == 0 && (uintptr_t)residual % 16 == 0));
+  hipLaunchKernelGGL(linear_bf16_256_kernel, dim3((unsigned)(mt * nt)), dim3(512), BIG_LDS, st,
+                     static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
+                     static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,
+                     vec_ok ? 1 : 0);
+  return check_launch("anemoi_linear(256x256)");
+}
+
 template <typename T, typename TO>
 static int linear_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                          int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st) {
@@ -254,6 +436,8 @@ extern "C" int anemoi_linear(int dtype, int out_dtype, const void* x, int64_t ld
   hipStream_t st = as_stream(stream);
   if (dtype == ANEMOI_F32 && out_dtype == ANEMOI_F32)
     return linear_launch<float, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
+  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16 && M >= 1024 && N >= 256)
+    return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16)
     return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_F32)

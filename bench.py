@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2, help="processor blocks in the CPU-baseline sample")
+    ap.add_argument("--detail", action="store_true", help="print a per-shape kernel table to stderr")
     return ap.parse_args()
 
 
@@ -78,7 +79,25 @@ def build(workload: str, device):
     return model, graph, x.to(device), idx
 
 
-def profile_pass(model, x, group, dtype_name: str):
+def detail_table(records, dtype_name: str) -> None:
+    from collections import defaultdict
+
+    agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    for name, start, end, work in records:
+        key = (name,) + tuple(sorted((k, v) for k, v in work.items() if k not in ("flops", "bytes")))
+        a = agg[key]
+        a[0] += 1
+        a[1] += start.elapsed_time(end)
+        a[2] += work.get("flops", 0)
+        a[3] += work.get("bytes", 0)
+    print(f"{'kernel / shape':70s} {'n':>4s} {'avg_ms':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
+    for key, (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        label = key[0] + " " + " ".join(f"{k}={v}" for k, v in key[1:])
+        print(f"{label:70s} {n:4d} {ms / n:9.4f} {fl / ms / 1e9 if fl else 0:9.1f} {by / ms / 1e6 if by else 0:9.1f}",
+              file=sys.stderr)
+
+
+def profile_pass(model, x, group, dtype_name: str, detail: bool = False):
     """One instrumented forward: HIP events around every kernel launch, on the launch stream."""
     from anemoi_models_amd import ops
 
@@ -87,6 +106,8 @@ def profile_pass(model, x, group, dtype_name: str):
         model(x, group) if group is not None else model(x)
     torch.cuda.synchronize()
     records, ops.PROFILE = ops.PROFILE, None
+    if detail:
+        detail_table(records, dtype_name)
     agg = {}
     for name, start, end, work in records:
         a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
@@ -208,7 +229,7 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_mesh * layers / (elapsed / args.steps)
-    extra = profile_pass(model, x, group, args.dtype)
+    extra = profile_pass(model, x, group, args.dtype, args.detail and rank == 0)
 
     if rank == 0:
         line = {
