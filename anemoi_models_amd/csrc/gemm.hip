@@ -15,6 +15,9 @@
 // one barrier per K-slab.  The LDS image is lane-linear (8 rows x 128 B per wave instruction), so the
 // bank swizzle is applied to the per-lane SOURCE address and undone on the fragment read
 // (chunk' = chunk ^ ((row >> 1) & 7)): conflict-free for both fragment shapes.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace anemoi {
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, in
 // =============================================================================================
 constexpr int BIG_M = 256, BIG_N = 256;
 constexpr int BIG_STAGE = (BIG_M + BIG_N) * ROW_BYTES;  // 64 KiB
-constexpr int BIG_LDS = 2 * BIG_STAGE;                  // 128 KiB
+constexpr int BIG_EPI = 8 * 4096;                       // 4 KiB epilogue scratch per wave
+constexpr int BIG_LDS = 2 * BIG_STAGE + BIG_EPI;        // 160 KiB: the whole LDS of a CU, one workgroup per CU
 
 __device__ __forceinline__ uint32_t bf16x2_add(uint32_t a, uint32_t b) {
   const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
@@ -235,42 +239,63 @@ __device__ __forceinline__ uint32_t bf16x2_add(uint32_t a, uint32_t b) {
   return pack_bf16x2(lo, hi);
 }
 
+// unaligned / ragged-N tail of one 8-column output segment (cold path, kept out of line)
+__device__ __noinline__ void store_row_tail(uint4 v, const bf16_t* __restrict__ R, int64_t ldr, bf16_t* __restrict__ Y,
+                                            int64_t ldy, int64_t m, int n, int N) {
+  const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (n + c < N) {
+      float o = __uint_as_float((c & 1) ? (wv[c >> 1] & 0xffff0000u) : (wv[c >> 1] << 16));
+      if (R != nullptr) o += bf16_to_f32(R[m * ldr + n + c]);
+      Y[m * ldy + n + c] = f32_to_bf16(o);
+    }
+  }
+}
+
+// Persistent: gridDim.x = 8 * blocks_per_xcd workgroups (one per CU); the tile list (nt fastest) is cut into 8
+// contiguous per-XCD chunks and workgroup (xcd, i) takes tiles i, i + blocks_per_xcd, ... of its chunk, so at any
+// time the CUs of one XCD work on neighbouring tiles (shared x row panels / W column panels in that XCD's L2).
+// The K-slabs of consecutive tiles form ONE double-buffered stream: slab 0 of the next tile is already in flight
+// while the current tile's epilogue runs out of a separate 32 KiB LDS scratch.
 __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                               const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias,
                                                               const bf16_t* __restrict__ R, int64_t ldr,
                                                               bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
-                                                              int K, int act, int vec_ok) {
+                                                              int K, int act, int vec_ok, int64_t n_tiles,
+                                                              int nt_count, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // ---- XCD-aware, bijective tile mapping (cdna_hip_programming.md T1)
-  const int nt_count = (N + BIG_N - 1) / BIG_N;
-  const int64_t tiles = (int64_t)gridDim.x;
-  const int64_t q8 = tiles / 8, r8 = tiles % 8;
-  const int64_t xcd = blockIdx.x % 8;
-  const int64_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
-  const int nt = (int)(tile % nt_count);
-  const int64_t mt = tile / nt_count;
-  const int64_t m0 = mt * BIG_M;
-  const int n0 = nt * BIG_N;
+  const int64_t xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int64_t q8 = n_tiles / 8, r8 = n_tiles % 8;
+  const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int64_t chunk_len = q8 + (xcd < r8 ? 1 : 0);
+  if (bix >= chunk_len) return;
   const int nk = K / 64;
 
-  // ---- staging: 32 row groups (8 rows x 128 B) per operand, 4 of each per wave
+  // staging addresses of the tile whose K-slabs are currently being issued (one set: the next tile's
+  // addresses replace them right after the current tile's last slab has been issued)
   const int srow = lane >> 3, scp = lane & 7;
+  const int r_first = wid * 32 + srow;  // row of this lane in row group i = 0; group i adds 8 * i
   const char* xg[4];
   const char* wg[4];
+  auto setup = [&](int64_t tile) {
+    const int64_t m0 = (tile / nt_count) * BIG_M;
+    const int n0 = (int)(tile % nt_count) * BIG_N;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wid * 4 + i) * 8 + srow;
-    const int c = swz(r, scp);
-    int64_t gm = m0 + r;
-    if (gm > M - 1) gm = M - 1;
-    int gn = n0 + r;
-    if (gn > N - 1) gn = N - 1;
-    xg[i] = reinterpret_cast<const char*>(X + gm * ldx) + c * 16;
-    wg[i] = reinterpret_cast<const char*>(W + (int64_t)gn * K) + c * 16;
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int r = r_first + 8 * i;
+      const int c = swz(r, scp);
+      int64_t gm = m0 + r;
+      if (gm > M - 1) gm = M - 1;
+      int gn = n0 + r;
+      if (gn > N - 1) gn = N - 1;
+      xg[i] = reinterpret_cast<const char*>(X + gm * ldx) + c * 16;
+      wg[i] = reinterpret_cast<const char*>(W + (int64_t)gn * K) + c * 16;
+    }
+  };
   auto stage = [&](int kt, int buf) {
     char* xs = smem + buf * BIG_STAGE + wid * 4096;
     char* ws = xs + BIG_M * ROW_BYTES;
@@ -284,96 +309,119 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
 
   const int wm = wid >> 2, wn = wid & 3;
   const int fr = lane & 15, fq = lane >> 4;
-  f32x4_t acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* xs = smem + (kt & 1) * BIG_STAGE;
-    const char* ws = xs + BIG_M * ROW_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t a[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wn * 64 + i * 16 + fr;
-        a[i] = *reinterpret_cast<const bf16x8_t*>(ws + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
-      }
-#pragma unroll
-      for (int jh = 0; jh < 2; ++jh) {
-        bf16x8_t b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = wm * 128 + (jh * 4 + j) * 16 + fr;
-          b[j] = *reinterpret_cast<const bf16x8_t*>(xs + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh * 4 + j], 0, 0, 0);
-      }
-    }
-  }
-
-  // ---- epilogue through LDS: each wave owns a [128 rows][64 cols] bf16 image (16 KiB), 8-byte units XOR-swizzled
-  __syncthreads();  // every wave has finished reading the last K-slab
-  char* region = smem + wid * 16384;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int nloc = i * 16 + fq * 4;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias != nullptr) {
-      const int n = n0 + wn * 64 + nloc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = (n + r < N) ? bias[n + r] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int row = j * 16 + fr;
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[r], act);
-      const int unit = (i * 4 + fq) ^ (row & 15);
-      *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) = make_uint2(pack_bf16x2(o[0], o[1]),
-                                                                            pack_bf16x2(o[2], o[3]));
-    }
-  }
-  // rows are read back as whole 128-byte lines: 8 lanes per row, 8 rows per pass
+  char* region = smem + 2 * BIG_STAGE + wid * 4096;
   const int rc = lane & 7, rr = lane >> 3;
-#pragma unroll 4
-  for (int t = 0; t < 16; ++t) {
-    const int row = t * 8 + rr;
-    const int sft = row & 15;
-    const int base_unit = ((2 * rc) ^ sft) & ~1;
-    uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + base_unit * 8);
-    if (sft & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-    const int64_t m = m0 + wm * 128 + row;
-    const int n = n0 + wn * 64 + rc * 8;
-    if (m < M && n < N) {
-      if (vec_ok && n + 8 <= N) {
-        if (R != nullptr) {
-          const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
-          v = make_uint4(bf16x2_add(v.x, rv.x), bf16x2_add(v.y, rv.y), bf16x2_add(v.z, rv.z), bf16x2_add(v.w, rv.w));
-        }
-        *reinterpret_cast<uint4*>(Y + m * ldy + n) = v;
-      } else {
-        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+
+  setup(chunk_start + bix);
+  stage(0, 0);
+  int g = 0;  // running K-slab counter over all tiles of this workgroup: LDS stage = g & 1
+  for (int64_t li = bix; li < chunk_len; li += bpx) {
+    const int64_t tile = chunk_start + li;
+    const bool has_next = li + bpx < chunk_len;
+    const int64_t m0 = (tile / nt_count) * BIG_M;
+    const int n0 = (int)(tile % nt_count) * BIG_N;
+
+    f32x4_t acc[4][8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (n + c < N) {
-            float o = __uint_as_float((c & 1) ? (wv[c >> 1] & 0xffff0000u) : (wv[c >> 1] << 16));
-            if (R != nullptr) o += bf16_to_f32(R[m * ldr + n + c]);
-            Y[m * ldy + n + c] = f32_to_bf16(o);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      __syncthreads();  // slab g landed for every wave; everyone is done reading the other stage
+      if (kt + 1 < nk) {
+        stage(kt + 1, (g + 1) & 1);
+      } else if (has_next) {
+        setup(tile + bpx);
+        stage(0, (g + 1) & 1);
+      }
+      const char* xs = smem + (g & 1) * BIG_STAGE;
+      const char* ws = xs + BIG_M * ROW_BYTES;
+      if (dbg & 2) continue;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wn * 64 + i * 16 + fr;
+          a[i] = *reinterpret_cast<const bf16x8_t*>(ws + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
+        }
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+          bf16x8_t b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = wm * 128 + (jh * 4 + j) * 16 + fr;
+            b[j] = *reinterpret_cast<const bf16x8_t*>(xs + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][jh * 4 + j] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh * 4 + j], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue: 4 passes of 32 rows through this wave's private 4 KiB scratch ([32 rows][64 cols] bf16, 8-byte
+    //      units XOR-swizzled), read back as whole 128-byte output rows (16 B per lane); the next tile's first
+    //      K-slab is in flight meanwhile.
+    float bv[4][4];  // bias of this lane's 4 x 4 output columns: one 16-byte load each, once per tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nb = n0 + wn * 64 + i * 16 + fq * 4;
+      if (bias != nullptr && vec_ok && nb + 4 <= N) {
+        VecIO<float, 4>::load(bias + nb, bv[i]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = (bias != nullptr && nb + r < N) ? bias[nb + r] : 0.f;
+      }
+    }
+    auto epilogue_pass = [&](auto ps_tag) {
+      constexpr int ps = decltype(ps_tag)::value;  // compile-time: acc[][] must be indexed statically (registers)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        constexpr int jbase = ps * 2;
+        const int j = jbase + jj;
+        const int row = jj * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[i][r], act);
+          const int unit = (i * 4 + fq) ^ (row & 15);
+          *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) =
+              make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 8 + rr;
+        const int sft = row & 15;
+        const int base_unit = ((2 * rc) ^ sft) & ~1;
+        uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + base_unit * 8);
+        if (sft & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+        const int64_t m = m0 + wm * 128 + ps * 32 + row;
+        const int n = n0 + wn * 64 + rc * 8;
+        if (m < M && n < N && !(dbg & 1)) {
+          if (vec_ok && n + 8 <= N) {
+            if (R != nullptr) {
+              const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
+              v = make_uint4(bf16x2_add(v.x, rv.x), bf16x2_add(v.y, rv.y), bf16x2_add(v.z, rv.z),
+                             bf16x2_add(v.w, rv.w));
+            }
+            *reinterpret_cast<uint4*>(Y + m * ldy + n) = v;
+          } else {
+            store_row_tail(v, R, ldr, Y, ldy, m, n, N);
           }
         }
       }
-    }
+    };
+    epilogue_pass(std::integral_constant<int, 0>{});
+    epilogue_pass(std::integral_constant<int, 1>{});
+    epilogue_pass(std::integral_constant<int, 2>{});
+    epilogue_pass(std::integral_constant<int, 3>{});
   }
 }
 
@@ -391,11 +439,18 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   const int64_t nt = (N + BIG_N - 1) / BIG_N;
   ANEMOI_REQUIRE(mt * nt < (int64_t)1 << 31, ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: grid too large");
   const bool vec_ok = (N % 8 == 0) && (ldy % 8 == 0) && ((uintptr_t)y % 16 == 0) &&
-                      (residual == nullptr || (ldr % 8 == 0 && (uintptr_t)residual % 16 == 0));
-  hipLaunchKernelGGL(linear_bf16_256_kernel, dim3((unsigned)(mt * nt)), dim3(512), BIG_LDS, st,
+                      (bias == nullptr || (uintptr_t)bias % 16 == 0) && (residual == nullptr || (ldr % 8 == 0 && (uintptr_t)residual % 16 == 0));
+  int64_t blocks = mt * nt;
+  static const int64_t max_blocks = [] {  // ANEMOI_AMD_GEMM_BLOCKS: tuning knob (default: one persistent WG per CU)
+    const char* e = getenv("ANEMOI_AMD_GEMM_BLOCKS");
+    return e ? (int64_t)atoll(e) : (int64_t)256;
+  }();
+  if (blocks > max_blocks) blocks = max_blocks;
+  blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
+  hipLaunchKernelGGL(linear_bf16_256_kernel, dim3((unsigned)blocks), dim3(512), BIG_LDS, st,
                      static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
                      static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,
-                     vec_ok ? 1 : 0);
+                     vec_ok ? 1 : 0, mt * nt, (int)nt, getenv("ANEMOI_AMD_GEMM_DEBUG") ? atoi(getenv("ANEMOI_AMD_GEMM_DEBUG")) : 0);
   return check_launch("anemoi_linear(256x256)");
 }
 
