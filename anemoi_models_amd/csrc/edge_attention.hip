@@ -269,6 +269,205 @@ __global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnPa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Folded path: lin_edge never appears in the kernel.  The two places where W_e acts are linear maps of
+// node-level quantities, so they are folded into the GEMMs on either side of the edge phase:
+//     u_i,h = W_h'^T q_i,h      comes out of the q/k/v projection GEMM as H*UP extra output columns
+//                               (weight rows  W_u[(h,a), :] = sum_{c in h} W_e'[c,a] * W_q[c, :]),
+//     W_h' t_i,h                goes into the output projection GEMM as H*UP extra input columns
+//                               (weight cols  W_t[:, (h,a)] = sum_{c in h} W_p[:, c] * W_e'[c,a]),
+// with W_e' = [W_e | b_e] and the edge attributes carrying a constant 1 in column edge_dim (so the bias and
+// the softmax normaliser ride along for free).  The kernel is then a pure gather / dot / online softmax /
+// weighted sum: no LDS, ~half the registers, 2x the resident waves.
+//   inputs : q, u per destination; k, v per source; attr [E, UP] (CSR order, attr[edge_dim] = 1)
+//   outputs: out[:, 0:C]        = sum_j alpha_ij v_j (+ x_r)
+//            out[:, C:C+H*UP]   = t~_i,h = sum_j alpha_ij a_ij        (alpha includes the 1e-16 normaliser)
+// ---------------------------------------------------------------------------------------------
+struct EdgeFoldParams {
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* xr;
+  const void* u;
+  void* out;
+  int64_t ldq, ldkv, ldr, ldu, ldo;
+  const float* attr;
+  const int32_t* rowptr;
+  const int32_t* col;
+  int64_t n_dst;
+  int C, D, n_slices;
+  float scale;
+};
+
+template <typename T, int VEC, int LPH, int UP>
+__global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const EdgeFoldParams p) {
+  constexpr int U = 4;
+  using Raw = typename RawVec<T, VEC>::type;
+  constexpr int UV = 16 / sizeof(T);  // elements per 16-byte load of u
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
+  const int slice = wave_in_xcd % p.n_slices;
+  const int64_t node_first = wave_in_xcd / p.n_slices;
+  const int64_t node_stride = waves_per_xcd / p.n_slices;
+  const int64_t n0 = p.n_dst * xcd / 8, n1 = p.n_dst * (xcd + 1) / 8;
+
+  const int lanes_total = p.C / VEC;
+  const int gl = slice * 64 + lane;
+  const bool active = gl < lanes_total;
+  const int gls = active ? gl : 0;
+  const int c0 = gls * VEC;
+  const int head = gls / LPH;
+  const bool head_lead = active && (gls % LPH == 0);
+
+  const T* qb = static_cast<const T*>(p.q) + c0;
+  const T* kb = static_cast<const T*>(p.k) + c0;
+  const T* vb = static_cast<const T*>(p.v) + c0;
+  const T* ub = static_cast<const T*>(p.u) + head * UP;
+
+  for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
+    const int e_begin = p.rowptr[node], e_end = p.rowptr[node + 1];
+    QK<T, VEC> qk;
+    float u[UP];
+    {
+      float qf[VEC];
+      VecIO<T, VEC>::load(qb + node * p.ldq, qf);
+      qk.set(qf);
+      const T* un = ub + node * p.ldu;
+      if constexpr (UP % UV == 0) {
+#pragma unroll
+        for (int a = 0; a < UP; a += UV) {
+          float t[UV];
+          VecIO<T, UV>::load(un + a, t);
+#pragma unroll
+          for (int i = 0; i < UV; ++i) u[a + i] = t[i];
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < UP; a += 4) {
+          float t[4];
+          VecIO<T, 4>::load(un + a, t);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) u[a + i] = t[i];
+        }
+      }
+    }
+    float m = -INFINITY, l = 0.f;
+    float acc[VEC], tacc[UP];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int a = 0; a < UP; ++a) tacc[a] = 0.f;
+
+    for (int e = e_begin; e < e_end; e += U) {
+      Raw kr[U], vr[U];
+      float s[U];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          const int64_t j = p.col[e + uu];
+          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
+          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
+        }
+      }
+      float mb = m;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        s[uu] = -INFINITY;
+        if (e + uu < e_end) {
+          const float* at = p.attr + (int64_t)(e + uu) * UP;
+          float t = 0.f;
+#pragma unroll
+          for (int a = 0; a < UP; ++a) t = fmaf(u[a], at[a], t);
+          s[uu] = (group_sum<LPH>(qk.dot(kr[uu])) + t) * p.scale;
+          mb = fmaxf(mb, s[uu]);
+        }
+      }
+      const float corr = __expf(m - mb);
+      l *= corr;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] *= corr;
+#pragma unroll
+      for (int a = 0; a < UP; ++a) tacc[a] *= corr;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          const float* at = p.attr + (int64_t)(e + uu) * UP;
+          const float pe = __expf(s[uu] - mb);
+          l += pe;
+          float vv[VEC];
+          unpack<T, VEC>(vr[uu], vv);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i], acc[i]);
+#pragma unroll
+          for (int a = 0; a < UP; ++a) tacc[a] = fmaf(pe, at[a], tacc[a]);
+        }
+      }
+      m = mb;
+    }
+
+    const float inv = 1.0f / (l + 1e-16f);
+    float o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = acc[i] * inv;
+    if (p.xr != nullptr) {
+      float r[VEC];
+      VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] += r[i];
+    }
+    T* on = static_cast<T*>(p.out) + node * p.ldo;
+    if (active) VecIO<T, VEC>::store(on + c0, o);
+    if (head_lead) {
+      T* tn = on + p.C + head * UP;
+#pragma unroll
+      for (int a = 0; a < UP; a += 4) {
+        const float t4[4] = {tacc[a] * inv, tacc[a + 1] * inv, tacc[a + 2] * inv, tacc[a + 3] * inv};
+        VecIO<T, 4>::store(tn + a, t4);
+      }
+    }
+  }
+}
+
+template <typename T, int VEC, int LPH, int UP>
+static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
+  constexpr int WPB = 4;
+  const int64_t units_per_xcd = ((p.n_dst + 7) / 8) * p.n_slices;
+  int64_t bpx = (units_per_xcd + WPB - 1) / WPB;
+  if (bpx > 32 * 5) bpx = 32 * 5;  // up to 5 resident workgroups (20 waves) per CU, 32 CUs per XCD
+  if (bpx < 1) bpx = 1;
+  while ((bpx * WPB) % p.n_slices != 0) ++bpx;
+  hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP>), dim3((unsigned)(8 * bpx)), dim3(64 * WPB),
+                     0, st, p);
+}
+
+template <typename T, int VEC, int LPH>
+static bool dispatch_folded_up(const EdgeFoldParams& p, int up, hipStream_t st) {
+  switch (up) {
+    case 4: launch_folded<T, VEC, LPH, 4>(p, st); return true;
+    case 8: launch_folded<T, VEC, LPH, 8>(p, st); return true;
+    case 12: launch_folded<T, VEC, LPH, 12>(p, st); return true;
+    case 16: launch_folded<T, VEC, LPH, 16>(p, st); return true;
+    default: return false;
+  }
+}
+
+template <typename T>
+static bool dispatch_folded(const EdgeFoldParams& p, int up, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (p.D % VEC != 0 || p.C % VEC != 0) return false;
+  switch (p.D / VEC) {
+    case 1: return dispatch_folded_up<T, VEC, 1>(p, up, st);
+    case 2: return dispatch_folded_up<T, VEC, 2>(p, up, st);
+    case 4: return dispatch_folded_up<T, VEC, 4>(p, up, st);
+    case 8: return dispatch_folded_up<T, VEC, 8>(p, up, st);
+    case 16: return dispatch_folded_up<T, VEC, 16>(p, up, st);
+    default: return false;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic path: one channel per lane, run-time lanes-per-head and edge_dim, W_e read through the
 // cache per edge.  Covers every shape the fast path does not (odd head sizes, edge_dim > 16, ...).
 // Requires D to be a power of two <= 64 or, failing that, uses a shuffle-free LDS reduction? -- no:
@@ -427,4 +626,45 @@ extern "C" int anemoi_gt_edge_attention(int dtype, const void* q, int64_t ldq, c
   if (dtype == ANEMOI_F32) return edge_attention_launch<float>(p, as_stream(stream));
   if (dtype == ANEMOI_BF16) return edge_attention_launch<bf16_t>(p, as_stream(stream));
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention: dtype %d", dtype);
+}
+
+extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                                               int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
+                                               const float* edge_attr, int up, const int32_t* rowptr,
+                                               const int32_t* col, void* out, int64_t ldo, int64_t n_dst, int C, int H,
+                                               anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(q && k && v && u && out && rowptr, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_edge_attention_folded: null pointer");
+  ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_edge_attention_folded: C=%d not divisible by H=%d", C, H);
+  ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
+                     (x_r == nullptr || ldr >= C),
+                 ANEMOI_ERR_INVALID, "anemoi_gt_edge_attention_folded: leading dimension too small");
+  ANEMOI_REQUIRE(n_dst >= 0, ANEMOI_ERR_INVALID, "anemoi_gt_edge_attention_folded: n_dst < 0");
+  if (n_dst == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(col != nullptr && edge_attr != nullptr, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_edge_attention_folded: null edge arrays");
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4;
+  const int vec = 16 / esz;
+  const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                       ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                       (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % vec == 0)) && ldq % vec == 0 &&
+                       ldkv % vec == 0 && ldu % vec == 0 && ldo % vec == 0 && ((uintptr_t)edge_attr % 16 == 0) &&
+                       ((int64_t)up * esz) % 8 == 0 && ((int64_t)C * esz) % 16 == 0;
+  ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_folded: operands must be 16-byte aligned");
+  EdgeFoldParams p;
+  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
+  p.attr = edge_attr; p.rowptr = rowptr; p.col = col;
+  p.n_dst = n_dst; p.C = C; p.D = C / H;
+  p.n_slices = (C + 64 * vec - 1) / (64 * vec);
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  bool ok = false;
+  if (dtype == ANEMOI_F32) ok = dispatch_folded<float>(p, up, as_stream(stream));
+  else if (dtype == ANEMOI_BF16) ok = dispatch_folded<bf16_t>(p, up, as_stream(stream));
+  else return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_folded: dtype %d", dtype);
+  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED,
+                 "anemoi_gt_edge_attention_folded: unsupported shape (D=%d, UP=%d); use anemoi_gt_edge_attention", C / H,
+                 up);
+  return check_launch("anemoi_gt_edge_attention_folded");
 }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(const float* __rest
 __global__ __launch_bounds__(256) void edge_attr_csr_kernel(const float* __restrict__ a0, int d0,
                                                             const float* __restrict__ a1, int d1, int64_t rows0,
                                                             const int32_t* __restrict__ perm, float* __restrict__ out,
-                                                            int ld, int64_t n_edges) {
+                                                            int ld, int one_col, int64_t n_edges) {
   const int64_t total = n_edges * ld;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void edge_attr_csr_kernel(const float* __restr
     float val = 0.f;
     if (c < d0) val = a0[src * d0 + c];
     else if (c < d0 + d1) val = a1[src * d1 + (c - d0)];
+    else if (c == one_col) val = 1.0f;
     out[idx] = val;
   }
 }
@@ -262,14 +263,16 @@ int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int6
 }
 
 int anemoi_edge_attr_csr(const float* a0, int d0, const float* a1, int d1, int64_t rows0, const int32_t* perm,
-                         float* out, int ld_out, int64_t n_edges, anemoi_stream_t stream) {
+                         float* out, int ld_out, int one_col, int64_t n_edges, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(a0 && perm && out && d0 > 0 && d1 >= 0 && rows0 > 0 && n_edges >= 0, ANEMOI_ERR_INVALID,
                  "anemoi_edge_attr_csr: bad argument");
   ANEMOI_REQUIRE((a1 != nullptr) || d1 == 0, ANEMOI_ERR_INVALID, "anemoi_edge_attr_csr: a1 is null but d1 > 0");
   ANEMOI_REQUIRE(ld_out >= d0 + d1, ANEMOI_ERR_INVALID, "anemoi_edge_attr_csr: ld_out %d < %d", ld_out, d0 + d1);
+  ANEMOI_REQUIRE(one_col < ld_out && (one_col < 0 || one_col >= d0 + d1), ANEMOI_ERR_INVALID,
+                 "anemoi_edge_attr_csr: one_col %d must be a padding column", one_col);
   if (n_edges == 0) return ANEMOI_OK;
   hipLaunchKernelGGL(edge_attr_csr_kernel, dim3(flat_grid(n_edges * ld_out)), dim3(256), 0, as_stream(stream), a0, d0,
-                     a1, d1, rows0, perm, out, ld_out, n_edges);
+                     a1, d1, rows0, perm, out, ld_out, one_col, n_edges);
   return check_launch("anemoi_edge_attr_csr");
 }
 
@@ -321,7 +324,7 @@ int anemoi_prognostic_residual(float* y, int V_out, const float* x, int B, int T
   return check_launch("anemoi_prognostic_residual");
 }
 
-int anemoi_abi_version(void) { return 1; }
+int anemoi_abi_version(void) { return 2; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

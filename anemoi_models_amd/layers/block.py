@@ -115,6 +115,67 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
     def _edge_params(self):
         return runtime.f32c(self.lin_edge.weight), runtime.f32c(self.lin_edge.bias)
 
+    # ---- lin_edge folded into the neighbouring GEMMs (see include/anemoi_amd.h: anemoi_gt_edge_attention_folded)
+    def fold_width(self, dtype) -> Optional[int]:
+        """Per-head width ``up`` of the folded edge representation (``edge_dim`` attributes + the constant 1,
+        rounded up to 4), or ``None`` when this shape has to use the unfolded kernel."""
+        if os.environ.get("ANEMOI_AMD_EDGE_FOLD", "1") == "0":
+            return None
+        vec = 16 // torch.empty((), dtype=dtype).element_size()
+        d, h = self.out_channels_conv, self.num_heads
+        if d % vec != 0 or (d // vec) not in (1, 2, 4, 8, 16):
+            return None
+        up = ops.round_up(self.edge_dim + 1, 4)
+        if up > 16 or (h * up) % vec != 0 or self.lin_self.in_features % vec != 0:
+            return None
+        return up
+
+    def edge_layout(self, dtype):
+        """(row width, index of the constant-1 column or -1) of the CSR edge-attribute matrix this block consumes."""
+        up = self.fold_width(dtype)
+        return (ops.round_up(self.edge_dim, 4), -1) if up is None else (up, self.edge_dim)
+
+    def _edge_fold(self, up: int) -> Tensor:
+        """``W_e' = [W_e | b_e | 0]`` as ``[H, D, up]`` in f32."""
+        h, d = self.num_heads, self.out_channels_conv
+        we = torch.zeros((h * d, up), dtype=torch.float32, device=self.lin_edge.weight.device)
+        we[:, : self.edge_dim] = self.lin_edge.weight.detach().float()
+        we[:, self.edge_dim] = self.lin_edge.bias.detach().float()
+        return we.view(h, d, up)
+
+    def _query_fold(self, up: int):
+        """Rows / bias that make the q GEMM also emit ``u[n, h, a] = sum_{c in h} W_e'[c, a] q[n, c]``."""
+        h, d = self.num_heads, self.out_channels_conv
+        weh = self._edge_fold(up)
+        wq = self.lin_query.weight.detach().float().view(h, d, -1)
+        wu = torch.einsum("hda,hdc->hac", weh, wq).reshape(h * up, -1)
+        bu = torch.einsum("hda,hd->ha", weh, self.lin_query.bias.detach().float().view(h, d)).reshape(h * up)
+        return wu, bu
+
+    def _projection_fold(self, up: int) -> Tensor:
+        """Columns that make ``projection`` absorb ``W_e' t``: ``W_t[o, (h, a)] = sum_{c in h} W_p[o, c] W_e'[c, a]``."""
+        h, d = self.num_heads, self.out_channels_conv
+        wp = self.projection.weight.detach().float()
+        return torch.einsum("ohd,hda->oha", wp.view(wp.shape[0], h, d), self._edge_fold(up)).reshape(wp.shape[0],
+                                                                                                       h * up)
+
+    def _folded_linears(self, tag: str, lead_layers, dtype, up: int):
+        """Packed ``[lead_layers..., W_u]`` (q/k/v side) and ``[W_p | W_t]`` (projection side) weights + biases."""
+        edge_q = [self.lin_edge.weight, self.lin_edge.bias, self.lin_query.weight, self.lin_query.bias]
+        w_in = self._packed.get((tag, "w", dtype, up), [l.weight for l in lead_layers] + edge_q,
+                                lambda: runtime.pack_weight([l.weight for l in lead_layers] + [self._query_fold(up)[0]],
+                                                            dtype))
+        b_in = self._packed.get((tag, "b", up), [l.bias for l in lead_layers] + edge_q,
+                                lambda: torch.cat([runtime.pack_bias([l.bias for l in lead_layers],
+                                                                     [l.out_features for l in lead_layers],
+                                                                     self.lin_edge.weight.device),
+                                                   self._query_fold(up)[1]]).contiguous())
+        edge_p = [self.lin_edge.weight, self.lin_edge.bias, self.projection.weight]
+        w_out = self._packed.get(("projf", "w", dtype, up), edge_p,
+                                 lambda: runtime.pack_weight_cols([self.projection.weight.detach().float(),
+                                                                   self._projection_fold(up)], dtype))
+        return w_in, b_in, w_out, runtime.f32c(self.projection.bias)
+
     def _node_mlp(self, y: Tensor, which: str, num_chunks: int) -> Tensor:
         """``mlp(y) + y`` with mlp = LayerNorm, Linear, act, Linear; optionally in row chunks (bounded hidden buffer)."""
         if which == "dst":
@@ -137,13 +198,13 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
                 f"hidden width {width} must be a multiple of {mult} for {dtype} on the MI355X path"
             )
 
-    def _edge_inputs(self, edge_attr: Tensor, edge_index: Tensor, n_src: int, n_dst: int):
+    def _edge_inputs(self, edge_attr: Tensor, edge_index: Tensor, n_src: int, n_dst: int, dtype):
         if edge_attr.shape[1] != self.edge_dim:
             raise ValueError(f"edge_attr has {edge_attr.shape[1]} features, lin_edge expects {self.edge_dim}")
         if edge_attr.shape[0] != edge_index.shape[1]:
             raise ValueError(f"edge_attr has {edge_attr.shape[0]} rows for {edge_index.shape[1]} edges")
         plan = self._plans.get(edge_index, n_src, n_dst)
-        return plan, ops.edge_attr_csr(edge_attr, None, plan.perm)
+        return plan, ops.edge_attr_csr(edge_attr, None, plan.perm, *self.edge_layout(dtype))
 
     @abstractmethod
     def forward(self, x, edge_attr, edge_index, shapes, batch_size, model_comm_group=None, size=None): ...
@@ -157,11 +218,21 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         dtype = x.dtype
         self._check_channels(dtype)
         c = self.num_heads * self.out_channels_conv
+        xh = ops.layer_norm(x, runtime.f32c(self.layer_norm1.weight), runtime.f32c(self.layer_norm1.bias),
+                            self.layer_norm1.eps)
+        up = self.fold_width(dtype)
+        if up is not None:
+            w5, b5, wpf, bp = self._folded_linears(
+                "sqkvu", [self.lin_self, self.lin_query, self.lin_key, self.lin_value], dtype, up)
+            sq = ops.linear(xh, w5, b5)  # [N, 4C + H*up] = x_r | q | k | v | u
+            att = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c],
+                                               sq[:, 4 * c:], edge_attr_csr, plan.rowptr, plan.col, self.num_heads,
+                                               up, ld_out=wpf.shape[1])
+            y = ops.linear(att, wpf, bp, residual=x)  # projection(out + x_r) + x_skip, lin_edge part via W_t
+            return self._node_mlp(y, "dst", 1)
         w4, b4 = self._cat_linear("sqkv", [self.lin_self, self.lin_query, self.lin_key, self.lin_value], dtype)
         wp, bp = self._cat_linear("proj", [self.projection], dtype)
         we, be = self._edge_params()
-        xh = ops.layer_norm(x, runtime.f32c(self.layer_norm1.weight), runtime.f32c(self.layer_norm1.bias),
-                            self.layer_norm1.eps)
         sqkv = ops.linear(xh, w4, b4)  # [N, 4C] = x_r | q | k | v
         att = self.conv.fused(sqkv[:, c:2 * c], sqkv[:, 2 * c:3 * c], sqkv[:, 3 * c:], sqkv[:, :c], edge_attr_csr,
                               self.edge_dim, we, be, plan, self.num_heads)
@@ -186,7 +257,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         n = x.shape[0]
         if size is not None and tuple(size) != (n, n):
             raise ValueError(f"Encountered tensor with size {n} in dimension 0, but expected size {tuple(size)}")
-        plan, ea = self._edge_inputs(edge_attr, edge_index, n, n)
+        plan, ea = self._edge_inputs(edge_attr, edge_index, n, n, dtype)
         return self.native(_as_compute(x, dtype), ea, plan), edge_attr
 
 
@@ -217,19 +288,28 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         dtype = x_dst.dtype
         self._check_channels(dtype)
         c = self.num_heads * self.out_channels_conv
-        w_sq, b_sq = self._cat_linear("sq", [self.lin_self, self.lin_query], dtype)
         w_kv, b_kv = self._cat_linear("kv", [self.lin_key, self.lin_value], dtype)
-        wp, bp = self._cat_linear("proj", [self.projection], dtype)
-        we, be = self._edge_params()
         ln1, ln2 = self.layer_norm1, self.layer_norm2
         xs = ops.layer_norm(x_src, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
         kv = ops.linear(xs, w_kv, b_kv)  # [N_src, 2C] = k | v
         del xs
         xd = ops.layer_norm(x_dst, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
-        sq = ops.linear(xd, w_sq, b_sq)  # [N_dst, 2C] = x_r | q
-        del xd
-        att = self.conv.fused(sq[:, c:], kv[:, :c], kv[:, c:], sq[:, :c], edge_attr_csr, self.edge_dim, we, be, plan,
-                              self.num_heads)
+        up = self.fold_width(dtype)
+        if up is not None:
+            w_squ, b_squ, wp, bp = self._folded_linears("squ", [self.lin_self, self.lin_query], dtype, up)
+            sq = ops.linear(xd, w_squ, b_squ)  # [N_dst, 2C + H*up] = x_r | q | u
+            del xd
+            att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
+                                               edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
+                                               ld_out=wp.shape[1])
+        else:
+            w_sq, b_sq = self._cat_linear("sq", [self.lin_self, self.lin_query], dtype)
+            wp, bp = self._cat_linear("proj", [self.projection], dtype)
+            we, be = self._edge_params()
+            sq = ops.linear(xd, w_sq, b_sq)  # [N_dst, 2C] = x_r | q
+            del xd
+            att = self.conv.fused(sq[:, c:], kv[:, :c], kv[:, c:], sq[:, :c], edge_attr_csr, self.edge_dim, we, be,
+                                  plan, self.num_heads)
         del sq, kv
         y = ops.linear(att, wp, bp, residual=x_dst)
         del att
@@ -256,7 +336,7 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         n_src, n_dst = x_src.shape[0], x_dst.shape[0]
         if size is not None and tuple(size) != (n_src, n_dst):
             raise ValueError(f"Encountered tensors with sizes {(n_src, n_dst)}, but expected size {tuple(size)}")
-        plan, ea = self._edge_inputs(edge_attr, edge_index, n_src, n_dst)
+        plan, ea = self._edge_inputs(edge_attr, edge_index, n_src, n_dst, dtype)
         num_chunks = self.num_chunks if self.training else inference_num_chunks()
         new_src, new_dst = self.native(_as_compute(x_src, dtype), _as_compute(x_dst, dtype), ea, plan, num_chunks)
         return (new_src if self.update_src_nodes else x[0], new_dst), edge_attr

@@ -103,7 +103,7 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         """Inputs in the compute dtype (optionally K padded).  Returns the mapped destination nodes."""
         n_src, n_dst = x_src.shape[0], x_dst.shape[0]
         plan = self._plans.get(self.edge_index_base, n_src, n_dst, batch_size, self.edge_inc)
-        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
         h_src, h_dst = self._embed(x_src, x_dst)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
         _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks)

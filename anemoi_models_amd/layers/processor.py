@@ -112,7 +112,8 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
         """x ``[B * N, C]`` in the compute dtype -> processed nodes (same dtype)."""
         n = x.shape[0]
         plan = self._plans.get(self.edge_index_base, n, n, batch_size, self.edge_inc)
-        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm,
+                               *self.proc[0].blocks[0].edge_layout(x.dtype))
         for chunk in self.proc:
             x = chunk.native(x, ea, plan)
         return x

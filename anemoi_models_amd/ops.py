@@ -125,8 +125,12 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
     return out
 
 
-def edge_attr_csr(a0: Tensor, a1: Optional[Tensor], perm: Tensor, ld_out: Optional[int] = None) -> Tensor:
-    """Edge attributes ``[a0 | a1]`` gathered into CSR order (rows ``perm[e] % a0.shape[0]``), f32, zero padded."""
+def edge_attr_csr(a0: Tensor, a1: Optional[Tensor], perm: Tensor, ld_out: Optional[int] = None,
+                  one_col: int = -1) -> Tensor:
+    """Edge attributes ``[a0 | a1]`` gathered into CSR order (rows ``perm[e] % a0.shape[0]``), f32, zero padded.
+
+    ``one_col >= 0`` writes a constant 1 into that (padding) column: the bias carrier of the folded edge kernel.
+    """
     _dev(a0, a1, perm)
     d0 = a0.shape[1]
     d1 = 0 if a1 is None else a1.shape[1]
@@ -137,7 +141,7 @@ def edge_attr_csr(a0: Tensor, a1: Optional[Tensor], perm: Tensor, ld_out: Option
     if perm.shape[0] == 0:
         return out
     st = _lib.load().anemoi_edge_attr_csr(a0.data_ptr(), d0, _ptr(a1), d1, a0.shape[0], perm.data_ptr(),
-                                          out.data_ptr(), ld, perm.shape[0], _stream())
+                                          out.data_ptr(), ld, one_col, perm.shape[0], _stream())
     _lib.check(st, "anemoi_edge_attr_csr")
     return out
 
@@ -168,6 +172,40 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], ed
             b_edge.data_ptr(), rowptr.data_ptr(), col.data_ptr(), out.data_ptr(), _ld(_rows(out)), n_dst, c,
             num_heads, _stream())
     _lib.check(st, "anemoi_gt_edge_attention")
+    return out
+
+
+def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
+                             rowptr: Tensor, col: Tensor, num_heads: int, up: int, out: Optional[Tensor] = None,
+                             ld_out: Optional[int] = None) -> Tensor:
+    """Edge phase with lin_edge folded away: returns ``[n_dst, ld_out]`` = ``[sum alpha v (+ x_r) | t (H*up) | 0-pad]``.
+
+    ``u`` is ``[n_dst, H*up]`` (extra columns of the q/k/v GEMM), ``edge_attr`` ``[E, up]`` f32 in CSR order with the
+    constant-1 column.  Columns beyond ``C + H*up`` (K padding for the projection GEMM) are zero filled.
+    """
+    _dev(q, k, v, x_r, u, edge_attr, rowptr, col, out)
+    n_dst, c = _rows(q).shape
+    width = c + num_heads * up
+    ld = width if ld_out is None else ld_out
+    if out is None:
+        out = torch.empty((n_dst, ld), dtype=q.dtype, device=q.device)
+        if ld > width:
+            out[:, width:].zero_()
+    if rowptr.dtype != torch.int32 or col.dtype != torch.int32 or rowptr.shape[0] != n_dst + 1:
+        raise ValueError("gt_edge_attention_folded: rowptr/col must be int32 with rowptr of length n_dst + 1")
+    if edge_attr.shape[0] != col.shape[0] or (col.shape[0] > 0 and (edge_attr.shape[1] != up or
+                                                                      not edge_attr.is_contiguous())):
+        raise ValueError("gt_edge_attention_folded: edge_attr must be contiguous [E, up]")
+    if col.shape[0] == 0:
+        col = torch.zeros(1, dtype=torch.int32, device=q.device)
+        edge_attr = torch.zeros((1, up), dtype=torch.float32, device=q.device)
+    alg_bytes = (2 * n_dst + 2 * k.shape[0]) * c * q.element_size() + col.shape[0] * 52 + (n_dst + 1) * 4
+    with _Timed("gt_edge_attention", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
+        st = _lib.load().anemoi_gt_edge_attention_folded(
+            dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
+            0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
+            rowptr.data_ptr(), col.data_ptr(), out.data_ptr(), _ld(_rows(out)), n_dst, c, num_heads, _stream())
+    _lib.check(st, "anemoi_gt_edge_attention_folded")
     return out
 
 

@@ -149,6 +149,16 @@ def pack_weight(weights: Sequence[Tensor], dtype: torch.dtype) -> Tensor:
     return out
 
 
+def pack_weight_cols(parts: Sequence[Tensor], dtype: torch.dtype) -> Tensor:
+    """``cat(parts, 1)`` (extra INPUT columns) as ``[N, K_pad]`` in ``dtype``, K zero padded to the K-slab multiple."""
+    w = torch.cat([t.detach() for t in parts], dim=1)
+    k = w.shape[1]
+    kp = ops.round_up(k, ops.k_multiple(dtype))
+    out = torch.zeros((w.shape[0], kp), dtype=dtype, device=w.device)
+    out[:, :k] = w.to(dtype)
+    return out
+
+
 def pack_bias(biases: Sequence[Optional[Tensor]], sizes: Sequence[int], device) -> Tensor:
     parts = [b.detach().float() if b is not None else torch.zeros(n, dtype=torch.float32, device=device)
              for b, n in zip(biases, sizes)]

@@ -75,12 +75,13 @@ int anemoi_linear(int dtype, int out_dtype, const void* x, int64_t ldx, const vo
 /*
  * Edge attributes in CSR (destination-sorted) order:
  *   out[e, :] = [ a0[perm[e] % rows0, 0:d0] | a1[perm[e] % rows0, 0:d1] | 0 ... ]   (row stride ld_out)
- * `perm[e]` is the original (batched) edge id of CSR slot e.  Replaces TrainableTensor.forward
+ * and, when one_col >= 0, out[e, one_col] = 1 (the constant attribute that carries the lin_edge bias through the
+ * folded kernel below).  `perm[e]` is the original (batched) edge id of CSR slot e.  Replaces TrainableTensor.forward
  * (layers/graph.py:37-44: repeat over the batch + concat of the trainable tensor) composed with the edge
  * gather that torch_geometric's propagate performs per block.  a1 may be NULL (d1 = 0).
  */
 int anemoi_edge_attr_csr(const float* a0, int d0, const float* a1, int d1, int64_t rows0, const int32_t* perm,
-                         float* out, int ld_out, int64_t n_edges, anemoi_stream_t stream);
+                         float* out, int ld_out, int one_col, int64_t n_edges, anemoi_stream_t stream);
 
 /*
  * Fused GraphTransformer edge phase for all destinations (K1 + K2 of SURVEY.md section 2a):
@@ -98,6 +99,21 @@ int anemoi_gt_edge_attention(int dtype, const void* q, int64_t ldq, const void* 
                              const void* x_r, int64_t ldr, const float* edge_attr, int ea_ld, int edge_dim,
                              const float* w_edge, const float* b_edge, const int32_t* rowptr, const int32_t* col,
                              void* out, int64_t ldo, int64_t n_dst, int C, int H, anemoi_stream_t stream);
+
+/*
+ * The same edge phase with lin_edge folded into the neighbouring GEMMs (the fast path used by the block mirrors).
+ * lin_edge is linear, so with W_e' = [W_e | b_e], a'_ij = [a_ij | 1] and per head h:
+ *   q_i,h . e_ij,h       = u_i,h . a'_ij      with u_i,h = W_h'^T q_i,h  -> H*up extra OUTPUT columns of the q/k/v GEMM
+ *   sum_j alpha e_ij,h   = W_h' t_i,h         with t_i,h = sum_j alpha a'_ij -> H*up extra INPUT columns of `projection`
+ * The kernel therefore never touches W_e:  u [n_dst, H, up] (ldu) is read next to q, edge_attr is [E, up] f32 in CSR
+ * order with a constant 1 in column edge_dim, and out (ldo >= C + H*up) receives
+ *   out[:, 0:C] = sum_j alpha_ij v_j (+ x_r)      out[:, C:C+H*up] = t_i,h      (alpha as defined above, incl. 1e-16).
+ * up is 4, 8, 12 or 16; D = C/H must be a multiple of the 16-byte vector width with D/vec a power of two <= 16.
+ */
+int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                    const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
+                                    int up, const int32_t* rowptr, const int32_t* col, void* out, int64_t ldo,
+                                    int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
  * Input assembly (I/O glue K9): rows (b, ens, g) of

@@ -123,6 +123,52 @@ def test_gt_edge_attention(dtype, n_src, n_dst, e, c, h, edge_dim):
         assert torch.equal(got[3].cpu(), xr[3])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_src,n_dst,e,c,h,edge_dim", [
+    (150, 150, 700, 128, 16, 11), (300, 200, 2000, 512, 16, 11), (120, 100, 900, 1024, 16, 11),
+    (64, 50, 300, 256, 16, 13), (30, 20, 0, 512, 16, 11), (180, 90, 500, 64, 4, 3),
+])
+def test_gt_edge_attention_folded(dtype, n_src, n_dst, e, c, h, edge_dim):
+    """Folded kernel (u in, t out) against the oracle conv evaluated with explicit lin_edge."""
+    from anemoi_models_amd import ops, runtime
+
+    d = c // h
+    if d % (16 // torch.empty((), dtype=dtype).element_size()) != 0:
+        pytest.skip("head size below the 16-byte vector width: unfolded kernel covers it")
+    up = (edge_dim + 1 + 3) // 4 * 4
+    ei, q, k, v, xr, ea, we, be = _edge_case(n_src, n_dst, e, c, h, edge_dim, seed=c + e + 1)
+    q, k, v, xr = (t.to(dtype) for t in (q, k, v, xr))
+    wef = torch.zeros(c, up)
+    wef[:, :edge_dim], wef[:, edge_dim] = we, be
+    weh = wef.view(h, d, up)
+    u = torch.einsum("hda,nhd->nha", weh, q.float().view(n_dst, h, d)).reshape(n_dst, h * up).to(dtype)
+    edges = F.linear(ea, we, be).view(-1, h, d)
+    # oracle: scores use the (dtype-rounded) u the kernel sees; values use the exact lin_edge output
+    a1 = torch.cat([ea, torch.ones(e, 1), torch.zeros(e, up - edge_dim - 1)], 1)
+    src, dst = ei[0], ei[1]
+    score = ((q.float().view(n_dst, h, d)[dst] * k.float().view(n_src, h, d)[src]).sum(-1)
+             + (u.float().view(n_dst, h, up)[dst] * a1.unsqueeze(1)).sum(-1)) / d**0.5
+    from oracle.pyg_semantics import scatter_sum, segment_softmax
+
+    alpha = segment_softmax(score, dst, n_dst)
+    want_v = scatter_sum(v.float().view(n_src, h, d)[src] * alpha.unsqueeze(-1), dst, n_dst).reshape(n_dst, c)
+    want_t = scatter_sum(a1.unsqueeze(1) * alpha.unsqueeze(-1), dst, n_dst).reshape(n_dst, h * up)
+    want_full = want_v + torch.einsum("hda,nha->nhd", weh, want_t.view(n_dst, h, up)).reshape(n_dst, c)
+    ref_full = ref.gt_conv(q.float().view(n_dst, h, d), k.float().view(n_src, h, d), v.float().view(n_src, h, d),
+                           edges, ei, n_dst).reshape(n_dst, c)
+    if dtype == torch.float32:  # the fold is exact algebra: it reproduces the reference conv
+        torch.testing.assert_close(want_full, ref_full, atol=2e-4, rtol=2e-4)
+    plan = runtime.build_edge_plan(ei.to(DEV), n_src, n_dst)
+    ea_csr = ops.edge_attr_csr(ea.to(DEV), None, plan.perm, up, edge_dim)
+    ld = ops.round_up(c + h * up, ops.k_multiple(dtype))
+    got = ops.gt_edge_attention_folded(q.to(DEV), k.to(DEV), v.to(DEV), xr.to(DEV), u.to(DEV), ea_csr, plan.rowptr,
+                                       plan.col, h, up, ld_out=ld).cpu().float()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(got[:, :c], want_v + xr.float()) < tol
+    assert rel_err(got[:, c:c + h * up], want_t) < tol if e > 0 else torch.all(got[:, c:c + h * up] == 0)
+    assert torch.all(got[:, c + h * up:] == 0)
+
+
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
     from anemoi_models_amd import runtime
 
