@@ -141,11 +141,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// sum over aligned groups of `width` consecutive lanes (width = power of two <= 64)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over aligned groups of `width` consecutive lanes (width = power of two <= 64); every lane of the group
+// receives the total.  Up to 16 lanes this is pure DPP (quad_perm swaps, row_half_mirror, row_mirror: one VALU
+// op per step, no LDS crossbar); wider groups finish with ds_bpermute-based shuffles.
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if constexpr (WIDTH >= 2) v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  if constexpr (WIDTH >= 4) v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  if constexpr (WIDTH >= 8) v += dpp_f32<0x141>(v);  // row_half_mirror: the other quad of the 8-lane half row
+  if constexpr (WIDTH >= 16) v += dpp_f32<0x140>(v); // row_mirror: the other half of the 16-lane row
+  if constexpr (WIDTH >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 

@@ -99,10 +99,14 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
     def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
         return x_dst
 
-    def native(self, x_src: Tensor, x_dst: Tensor, batch_size: int, out_dtype: Optional[torch.dtype] = None) -> Tensor:
-        """Inputs in the compute dtype (optionally K padded).  Returns the mapped destination nodes."""
+    def native(self, x_src: Tensor, x_dst: Tensor, batch_size: int, out_dtype: Optional[torch.dtype] = None,
+               src_map: Optional[Tensor] = None, dst_map: Optional[Tensor] = None) -> Tensor:
+        """Inputs in the compute dtype (optionally K padded).  Returns the mapped destination nodes.
+
+        ``src_map`` / ``dst_map``: optional external-id -> row relabelling when the caller keeps a node set in an
+        internal order (the model root does this for the mesh)."""
         n_src, n_dst = x_src.shape[0], x_dst.shape[0]
-        plan = self._plans.get(self.edge_index_base, n_src, n_dst, batch_size, self.edge_inc)
+        plan = self._plans.get(self.edge_index_base, n_src, n_dst, batch_size, self.edge_inc, src_map, dst_map)
         ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
         h_src, h_dst = self._embed(x_src, x_dst)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()

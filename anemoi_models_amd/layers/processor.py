@@ -108,10 +108,12 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
         self.offload_layers(cpu_offload)
         self._plans = runtime.PlanCache()
 
-    def native(self, x: Tensor, batch_size: int) -> Tensor:
-        """x ``[B * N, C]`` in the compute dtype -> processed nodes (same dtype)."""
+    def native(self, x: Tensor, batch_size: int, node_map: Optional[Tensor] = None) -> Tensor:
+        """x ``[B * N, C]`` in the compute dtype -> processed nodes (same dtype).
+
+        ``node_map``: optional external-id -> row relabelling when ``x`` is kept in an internal node order."""
         n = x.shape[0]
-        plan = self._plans.get(self.edge_index_base, n, n, batch_size, self.edge_inc)
+        plan = self._plans.get(self.edge_index_base, n, n, batch_size, self.edge_inc, node_map, node_map)
         ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm,
                                *self.proc[0].blocks[0].edge_layout(x.dtype))
         for chunk in self.proc:

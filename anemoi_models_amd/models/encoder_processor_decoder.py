@@ -12,6 +12,7 @@ reference (``_run_mapper``) has no forward-pass effect and is not needed here.
 from __future__ import annotations
 
 import logging
+import os
 from typing import Optional
 
 import torch
@@ -118,6 +119,18 @@ class AnemoiModelEncProcDec(nn.Module):
             self._idx_cache[key] = (as_i32(self._internal_output_idx), as_i32(self._internal_input_idx))
         return self._idx_cache[key]
 
+    def _mesh_order(self, device):
+        """(order, inverse) of the internal, locality-preserving mesh row order (cached per device)."""
+        key = ("mesh_order", str(device))
+        if key not in self._idx_cache:
+            latlons = self.node_attributes.latlons(self._graph_name_hidden)
+            if os.environ.get("ANEMOI_AMD_MESH_REORDER", "1") == "0":
+                order = torch.arange(latlons.shape[0], device=device)
+            else:
+                order = runtime.locality_order(latlons).to(device)
+            self._idx_cache[key] = (order, runtime.inverse_permutation(order))
+        return self._idx_cache[key]
+
     def forward(self, x: Tensor, model_comm_group=None) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             from ..distributed.partition import sharded_forward
@@ -134,13 +147,17 @@ class AnemoiModelEncProcDec(nn.Module):
         width = self.multi_step * self.num_input_channels + na.attr_ndims[data]
         x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, batch_size, dtype,
                                     ld_out=ops.round_up(width, kmult))
-        x_hidden = ops.assemble_nodes(None, na.latlons(hidden), na.trainable_tensors[hidden].trainable, batch_size,
-                                      dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
+        # mesh rows live in an internal Morton order (gather locality of the edge kernels); only the tiny
+        # per-node attribute tables are permuted, the mesh never leaves the model
+        order, inv = self._mesh_order(x.device)
+        tr_hidden = na.trainable_tensors[hidden].trainable
+        x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[order], None if tr_hidden is None else tr_hidden[order],
+                                      batch_size, dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
 
-        x_latent = self.encoder.native(x_data, x_hidden, batch_size)
-        x_proc = self.processor.native(x_latent, batch_size)
+        x_latent = self.encoder.native(x_data, x_hidden, batch_size, dst_map=inv)
+        x_proc = self.processor.native(x_latent, batch_size, node_map=inv)
         x_latent_proc = ops.add(x_proc, x_latent)
-        y = self.decoder.native(x_latent_proc, x_data, batch_size, out_dtype=torch.float32)
+        y = self.decoder.native(x_latent_proc, x_data, batch_size, out_dtype=torch.float32, src_map=inv)
 
         y = y.view(batch_size, ensemble_size, grid, self.num_output_channels)
         out_idx, in_idx = self._prognostic_indices(y.device)

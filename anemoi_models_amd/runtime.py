@@ -98,19 +98,52 @@ class PlanCache:
         self._plans: dict = {}
 
     def get(self, edge_index: Tensor, n_src: int, n_dst: int, batch_size: int = 1,
-            edge_inc: Optional[Tensor] = None) -> EdgePlan:
+            edge_inc: Optional[Tensor] = None, src_map: Optional[Tensor] = None,
+            dst_map: Optional[Tensor] = None) -> EdgePlan:
+        """``src_map`` / ``dst_map`` (int64, external node id -> internal row) relabel the node sets, e.g. to the
+        locality-preserving internal mesh order of :func:`locality_order`; they cover one batch block."""
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(edge_index.device), n_src,
-               n_dst, batch_size)
+               n_dst, batch_size, None if src_map is None else src_map.data_ptr(),
+               None if dst_map is None else dst_map.data_ptr())
         plan = self._plans.get(key)
         if plan is None:
             ei = edge_index
+            if src_map is not None or dst_map is not None:
+                src = ei[0] if src_map is None else src_map[ei[0]]
+                dst = ei[1] if dst_map is None else dst_map[ei[1]]
+                ei = torch.stack([src, dst])
             if batch_size > 1:
-                ei = expand_edges(edge_index, edge_inc, batch_size)
+                ei = expand_edges(ei, edge_inc, batch_size)
             plan = build_edge_plan(ei, n_src, n_dst)
             if len(self._plans) > 16:
                 self._plans.clear()
             self._plans[key] = plan
         return plan
+
+
+def locality_order(sincos_latlon: Tensor) -> Tensor:
+    """Permutation (internal row -> external node id) that sorts nodes along a 3-D Morton curve of their positions.
+
+    ``sincos_latlon`` is the ``[N, 4]`` buffer ``[sin lat, sin lon, cos lat, cos lon]`` the model keeps for every
+    node set (reference layers/graph.py:90-93).  Refined icosahedral meshes number their nodes level by level, so
+    graph neighbours are far apart in memory; along the Morton curve the in-neighbours of consecutive destination
+    rows fall into a compact window, which is what lets the edge kernel's k/v gathers hit in the XCD-local L2.
+    Purely internal: the mesh never appears in the model's inputs or outputs.
+    """
+    s_lat, s_lon, c_lat, c_lon = sincos_latlon.detach().double().unbind(dim=1)
+    xyz = torch.stack([c_lat * c_lon, c_lat * s_lon, s_lat], dim=1)
+    q = ((xyz + 1.0) * 0.5 * 1023.0).round().clamp_(0, 1023).to(torch.int64)
+    code = torch.zeros(q.shape[0], dtype=torch.int64, device=q.device)
+    for bit in range(10):
+        for axis in range(3):
+            code |= ((q[:, axis] >> bit) & 1) << (3 * bit + axis)
+    return torch.argsort(code, stable=True)
+
+
+def inverse_permutation(order: Tensor) -> Tensor:
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.shape[0], device=order.device, dtype=order.dtype)
+    return inv
 
 
 def expand_edges(edge_index: Tensor, edge_inc: Tensor, batch_size: int) -> Tensor:
