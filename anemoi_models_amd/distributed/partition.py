@@ -1,0 +1,234 @@
+"""Node-partitioned forward of ``AnemoiModelEncProcDec`` over one model communication group.
+
+Partition (built once per (graph, world size, rank) and cached on the model):
+
+* mesh nodes, in the internal Morton order, are cut into ``P`` contiguous ranges (``tensor_split`` sizes); rank ``r``
+  owns range ``r`` -- i.e. a spatially compact patch of the sphere;
+* processor: rank ``r`` owns the edges whose destination it owns (exactly the dst-partition of the reference's
+  ``sort_edges_1hop_chunks``, reference distributed/khop_edges.py:88-130); sources outside the range are its HALO.
+  Per block one all-to-all-v moves the k|v rows of halo nodes from their owners (2C values per halo node);
+* encoder: every rank receives the full input (contract), so it embeds and projects exactly the grid rows that feed
+  its mesh nodes -- no communication at all;
+* decoder: grid node ``g`` belongs to the rank that owns its first (nearest) mesh source, so decoder edges are mostly
+  local; one all-to-all-v of mesh k|v halo rows; the ``[rows, V_out]`` results are all-gathered (padded) and put back
+  in grid order on every rank.
+
+No all-reduce anywhere in the forward.  All index plumbing is torch; the arithmetic goes through ``ops`` as on one GPU.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .. import ops
+from .. import runtime
+from ..runtime import EdgePlan
+from .shapes import split_bounds
+
+
+def _alltoallv(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int], group) -> None:
+    """Row-wise all-to-all-v.  RCCL path: one ``all_to_all_single``; other backends (gloo in CPU tests): P2P pairs."""
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+        return
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    outs = list(out.split(out_splits, dim=0))
+    ins = list(inp.split(in_splits, dim=0))
+    outs[rank].copy_(ins[rank])
+    reqs = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        g_peer = dist.get_global_rank(group, peer) if group is not dist.group.WORLD else peer
+        if in_splits[peer] > 0:
+            reqs.append(dist.isend(ins[peer].contiguous(), g_peer, group=group))
+        if out_splits[peer] > 0:
+            reqs.append(dist.irecv(outs[peer], g_peer, group=group))
+    for r in reqs:
+        r.wait()
+
+
+@dataclass
+class HaloExchange:
+    """Send / receive lists of one all-to-all-v of boundary rows (indices local to the owner's row range)."""
+
+    send_idx: Tensor  # int64 [n_send]  own-row indices, grouped by destination rank (ascending)
+    send_splits: List[int]
+    recv_splits: List[int]
+    group: object
+
+    @property
+    def n_recv(self) -> int:
+        return sum(self.recv_splits)
+
+    def exchange(self, rows: Tensor, n_own: int) -> None:
+        """``rows[n_own : n_own + n_recv] <-`` the rows this rank's halo needs; ``rows[:n_own]`` are its own rows."""
+        send = rows[:n_own].index_select(0, self.send_idx)
+        _alltoallv(rows[n_own:n_own + self.n_recv], send, self.recv_splits, self.send_splits, self.group)
+
+
+@dataclass
+class LocalGraph:
+    plan: EdgePlan  # CSR over LOCAL indices; plan.perm holds ORIGINAL edge ids (for the attribute gather)
+    n_own_src: int  # leading source rows that are this rank's own (the rest is halo)
+    halo: Optional[HaloExchange]
+
+
+def _owner(ids: Tensor, bounds: Tensor) -> Tensor:
+    return torch.bucketize(ids, bounds[1:], right=True)
+
+
+def _local_graph(src: Tensor, dst_local: Tensor, e_ids: Tensor, n_src: int, n_dst: int) -> EdgePlan:
+    plan = runtime.build_edge_plan(torch.stack([src, dst_local]), n_src, n_dst)
+    plan.perm = e_ids[plan.perm.long()].to(torch.int32)
+    return plan
+
+
+def _halo_lists(src_int: Tensor, dst_owner_mask_fn, bounds: List[int], rank: int, world: int, group) -> tuple:
+    """For mesh-source edge sets: (halo ids of `rank`, HaloExchange).  ``dst_owner_mask_fn(p)`` -> edge mask of rank p."""
+    dev = src_int.device
+    b = torch.tensor(bounds, device=dev)
+    need = []  # need[p] = sorted unique mesh ids (internal) that rank p reads but does not own
+    for p in range(world):
+        s = src_int[dst_owner_mask_fn(p)]
+        s = torch.unique(s[(s < bounds[p]) | (s >= bounds[p + 1])])
+        need.append(s)
+    mine = need[rank]
+    recv_splits = [int(((mine >= bounds[p]) & (mine < bounds[p + 1])).sum()) for p in range(world)]
+    send_parts, send_splits = [], []
+    for p in range(world):
+        s = need[p]
+        s = s[(s >= bounds[rank]) & (s < bounds[rank + 1])] - bounds[rank]
+        send_parts.append(s)
+        send_splits.append(int(s.numel()))
+    _ = b
+    return mine, HaloExchange(torch.cat(send_parts), send_splits, recv_splits, group)
+
+
+@dataclass
+class ShardPlan:
+    rank: int
+    world: int
+    lo: int
+    hi: int
+    enc_src_ids: Tensor  # grid ids (ascending) whose embeddings this rank needs
+    enc: LocalGraph
+    proc: LocalGraph
+    dec_dst_ids: Tensor  # grid ids (ascending) this rank produces
+    dec: LocalGraph
+    dec_counts: List[int]  # rows produced by every rank
+    dec_all_ids: Tensor  # concatenation of every rank's dec_dst_ids (rank order)
+
+
+def build_shard_plan(model, group, device) -> ShardPlan:
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    order, inv = model._mesh_order(device)
+    n_mesh = order.shape[0]
+    bounds = split_bounds(n_mesh, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n_own = hi - lo
+    bt = torch.tensor(bounds, device=device)
+
+    # ---- encoder: grid -> mesh, destinations = own mesh rows, sources gathered locally
+    ei = model.encoder.edge_index_base
+    dst_int = inv[ei[1]]
+    e_ids = torch.nonzero((dst_int >= lo) & (dst_int < hi)).flatten()
+    src = ei[0][e_ids]
+    enc_src_ids = torch.unique(src)
+    enc = LocalGraph(_local_graph(torch.searchsorted(enc_src_ids, src), dst_int[e_ids] - lo, e_ids,
+                                  int(enc_src_ids.numel()), n_own), int(enc_src_ids.numel()), None)
+
+    # ---- processor: mesh -> mesh
+    ei = model.processor.edge_index_base
+    src_int, dst_int = inv[ei[0]], inv[ei[1]]
+    dst_owner = _owner(dst_int, bt)
+    halo_ids, halo = _halo_lists(src_int, lambda p: dst_owner == p, bounds, rank, world, group)
+    e_ids = torch.nonzero(dst_owner == rank).flatten()
+    s = src_int[e_ids]
+    own = (s >= lo) & (s < hi)
+    s_local = torch.where(own, s - lo, n_own + torch.searchsorted(halo_ids, s))
+    proc = LocalGraph(_local_graph(s_local, dst_int[e_ids] - lo, e_ids, n_own + int(halo_ids.numel()), n_own), n_own,
+                      halo)
+
+    # ---- decoder: mesh -> grid; a grid node goes to the owner of its first mesh source
+    ei = model.decoder.edge_index_base
+    n_grid = int(model.node_attributes.num_nodes[model._graph_name_data])
+    src_int, dst = inv[ei[0]], ei[1]
+    full = runtime.build_edge_plan(torch.stack([src_int, dst]), n_mesh, n_grid)  # stable: first CSR slot = first edge
+    has_edge = full.rowptr[1:] > full.rowptr[:-1]
+    first_slot = full.rowptr[:-1].long().clamp_max(max(ei.shape[1] - 1, 0))
+    first_src = torch.where(has_edge, full.col.long()[first_slot] if ei.shape[1] > 0 else first_slot,
+                            torch.full_like(first_slot, -1))
+    g_owner = torch.where(first_src >= 0, _owner(first_src.clamp_min(0), bt),
+                          torch.arange(n_grid, device=device) % world)
+    e_owner = g_owner[dst]
+    halo_ids, halo = _halo_lists(src_int, lambda p: e_owner == p, bounds, rank, world, group)
+    dec_dst_ids = torch.nonzero(g_owner == rank).flatten()
+    e_ids = torch.nonzero(e_owner == rank).flatten()
+    s = src_int[e_ids]
+    own = (s >= lo) & (s < hi)
+    s_local = torch.where(own, s - lo, n_own + torch.searchsorted(halo_ids, s))
+    dec = LocalGraph(_local_graph(s_local, torch.searchsorted(dec_dst_ids, dst[e_ids]), e_ids,
+                                  n_own + int(halo_ids.numel()), int(dec_dst_ids.numel())), n_own, halo)
+    counts = torch.bincount(g_owner, minlength=world).tolist()
+    all_ids = torch.argsort(g_owner, stable=True)  # rank-major, ascending grid id inside a rank
+    return ShardPlan(rank, world, lo, hi, enc_src_ids, enc, proc, dec_dst_ids, dec, counts, all_ids)
+
+
+def sharded_forward(model, x: Tensor, group) -> Tensor:
+    """Full-input / full-output forward with the mesh partitioned over ``group`` (batch size 1, as in the reference)."""
+    runtime.require_inference(model)
+    batch_size, _, ensemble_size, grid, _ = x.shape
+    assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+    dtype = runtime.compute_dtype(x)
+    if model.encoder.proc.fold_width(dtype) is None:
+        raise NotImplementedError("the node-partitioned forward needs the folded edge kernel for this shape / dtype")
+    kmult = ops.k_multiple(dtype)
+    key = ("shard_plan", str(x.device), dist.get_world_size(group), dist.get_rank(group))
+    if key not in model._idx_cache:
+        model._idx_cache[key] = build_shard_plan(model, group, x.device)
+    sp: ShardPlan = model._idx_cache[key]
+    data, hidden = model._graph_name_data, model._graph_name_hidden
+    na = model.node_attributes
+    order, _ = model._mesh_order(x.device)
+    own_ids = order[sp.lo:sp.hi]
+
+    width = model.multi_step * model.num_input_channels + na.attr_ndims[data]
+    x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, 1, dtype,
+                                ld_out=ops.round_up(width, kmult))
+    tr_hidden = na.trainable_tensors[hidden].trainable
+    x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[own_ids], None if tr_hidden is None else tr_hidden[own_ids],
+                                  1, dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
+
+    x_latent = model.encoder.native_local(x_data.index_select(0, sp.enc_src_ids), x_hidden, sp.enc)
+    x_proc = model.processor.native_local(x_latent, sp.proc)
+    x_latent_proc = ops.add(x_proc, x_latent)
+    y_local = model.decoder.native_local(x_latent_proc, x_data.index_select(0, sp.dec_dst_ids), sp.dec,
+                                         out_dtype=torch.float32)
+
+    # ---- all-gather (padded to the largest shard) and put the rows back into grid order
+    v_out = model.num_output_channels
+    max_rows = max(sp.dec_counts)
+    send = torch.zeros((max_rows, v_out), dtype=torch.float32, device=x.device)
+    send[: y_local.shape[0]] = y_local
+    gathered = torch.empty((sp.world, max_rows, v_out), dtype=torch.float32, device=x.device)
+    dist.all_gather_into_tensor(gathered.view(-1, v_out), send, group=group)
+    rows = torch.cat([gathered[r, :c] for r, c in enumerate(sp.dec_counts)], dim=0)
+    y = torch.empty((grid, v_out), dtype=torch.float32, device=x.device)
+    y[sp.dec_all_ids] = rows
+    y = y.view(1, ensemble_size, grid, v_out)
+
+    out_idx, in_idx = model._prognostic_indices(y.device)
+    ops.prognostic_residual(y, x, out_idx, in_idx)
+    if y.dtype != x.dtype:
+        y = y.to(x.dtype)
+    for bounding in model.boundings:
+        y = bounding(y)
+    return y

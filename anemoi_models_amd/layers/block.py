@@ -213,14 +213,33 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
 class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
     """Graph transformer layer on one node set (reference layers/block.py:553-635)."""
 
-    def native(self, x: Tensor, edge_attr_csr: Tensor, plan: EdgePlan) -> Tensor:
-        """x ``[N, C]`` in the compute dtype, edge attributes already in CSR order.  Returns the new nodes."""
+    def native(self, x: Tensor, edge_attr_csr: Tensor, plan: EdgePlan, halo=None) -> Tensor:
+        """x ``[N, C]`` in the compute dtype, edge attributes already in CSR order.  Returns the new nodes.
+
+        With ``halo`` (node-partitioned run) ``x`` holds this rank's rows only; the k|v rows of the halo sources are
+        fetched from their owners by one all-to-all-v and appended behind the own rows (the plan's source index space).
+        """
         dtype = x.dtype
         self._check_channels(dtype)
         c = self.num_heads * self.out_channels_conv
         xh = ops.layer_norm(x, runtime.f32c(self.layer_norm1.weight), runtime.f32c(self.layer_norm1.bias),
                             self.layer_norm1.eps)
         up = self.fold_width(dtype)
+        if halo is not None:
+            if up is None:
+                raise NotImplementedError("node-partitioned blocks need the folded edge kernel")
+            n_own = x.shape[0]
+            w_kv, b_kv = self._cat_linear("kv", [self.lin_key, self.lin_value], dtype)
+            kv = torch.empty((n_own + halo.n_recv, 2 * c), dtype=dtype, device=x.device)
+            ops.linear(xh, w_kv, b_kv, out=kv[:n_own])
+            halo.exchange(kv, n_own)
+            w_squ, b_squ, wpf, bp = self._folded_linears("squ", [self.lin_self, self.lin_query], dtype, up)
+            sq = ops.linear(xh, w_squ, b_squ)  # [n_own, 2C + H*up] = x_r | q | u
+            att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
+                                               edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
+                                               ld_out=wpf.shape[1])
+            y = ops.linear(att, wpf, bp, residual=x)
+            return self._node_mlp(y, "dst", 1)
         if up is not None:
             w5, b5, wpf, bp = self._folded_linears(
                 "sqkvu", [self.lin_self, self.lin_query, self.lin_key, self.lin_value], dtype, up)
@@ -284,14 +303,23 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         )
         self.layer_norm2 = nn.LayerNorm(in_channels)
 
-    def native(self, x_src: Tensor, x_dst: Tensor, edge_attr_csr: Tensor, plan: EdgePlan, num_chunks: int = 1):
+    def native(self, x_src: Tensor, x_dst: Tensor, edge_attr_csr: Tensor, plan: EdgePlan, num_chunks: int = 1,
+               halo=None):
+        """``halo``: node-partitioned run -- ``x_src`` holds this rank's source rows, the k|v rows of the other
+        sources of the plan are appended by one all-to-all-v."""
         dtype = x_dst.dtype
         self._check_channels(dtype)
         c = self.num_heads * self.out_channels_conv
         w_kv, b_kv = self._cat_linear("kv", [self.lin_key, self.lin_value], dtype)
         ln1, ln2 = self.layer_norm1, self.layer_norm2
         xs = ops.layer_norm(x_src, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
-        kv = ops.linear(xs, w_kv, b_kv)  # [N_src, 2C] = k | v
+        if halo is None:
+            kv = ops.linear(xs, w_kv, b_kv)  # [N_src, 2C] = k | v
+        else:
+            n_own = x_src.shape[0]
+            kv = torch.empty((n_own + halo.n_recv, 2 * c), dtype=dtype, device=x_src.device)
+            ops.linear(xs, w_kv, b_kv, out=kv[:n_own])
+            halo.exchange(kv, n_own)
         del xs
         xd = ops.layer_norm(x_dst, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
         up = self.fold_width(dtype)

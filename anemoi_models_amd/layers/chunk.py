@@ -77,9 +77,9 @@ class GraphTransformerProcessorChunk(BaseProcessorChunk):
             out_channels=num_channels, num_heads=num_heads, edge_dim=edge_dim, activation=activation,
         )
 
-    def native(self, x: Tensor, edge_attr_csr: Tensor, plan: EdgePlan) -> Tensor:
+    def native(self, x: Tensor, edge_attr_csr: Tensor, plan: EdgePlan, halo=None) -> Tensor:
         for blk in self.blocks:
-            x = blk.native(x, edge_attr_csr, plan)
+            x = blk.native(x, edge_attr_csr, plan, halo)
         return x
 
     def forward(self, x, edge_attr, edge_index, shapes, batch_size, model_comm_group=None, size=None):

@@ -113,6 +113,16 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks)
         return self._extract(h_dst, out_dtype)
 
+    def native_local(self, x_src: Tensor, x_dst: Tensor, local_graph, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+        """Node-partitioned run (``distributed/partition.py``): local source / destination rows and a local CSR plan
+        whose ``perm`` holds original edge ids; halo source rows (decoder) arrive by all-to-all-v inside the block."""
+        plan = local_graph.plan
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
+        h_src, h_dst = self._embed(x_src, x_dst)
+        num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
+        _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, local_graph.halo)
+        return self._extract(h_dst, out_dtype)
+
     def _run(self, x, batch_size: int, shard_shapes, model_comm_group) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")

@@ -120,6 +120,15 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
             x = chunk.native(x, ea, plan)
         return x
 
+    def native_local(self, x_own: Tensor, local_graph) -> Tensor:
+        """Node-partitioned run (``distributed/partition.py``): this rank's mesh rows in, same rows out."""
+        plan = local_graph.plan
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm,
+                               *self.proc[0].blocks[0].edge_layout(x_own.dtype))
+        for chunk in self.proc:
+            x_own = chunk.native(x_own, ea, plan, local_graph.halo)
+        return x_own
+
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None, *args, **kwargs) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"

@@ -25,7 +25,11 @@ def linear(x, w, bias=None, *, act="Identity", residual=None, out=None, out_dtyp
     y = _ACT[act](F.linear(x.float(), w.float(), bias))
     if residual is not None:
         y = y + residual.float()
-    return y.to(out_dtype or x.dtype)
+    y = y.to(out_dtype or x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def edge_attr_csr(a0, a1, perm, ld_out=None, one_col=-1):

@@ -276,3 +276,31 @@ def test_model_o96_ico5_512ch_vs_oracle_f32():
                                  prognostic_in=range(20), prognostic_out=range(20))
         got = model.to(DEV)(x.to(DEV))
     assert rel_err(got, want) < 1e-3
+
+
+def test_node_partitioned_forward_world1_rccl(graph_o32, golden_cfg1_gt):
+    """The partitioned code path (local CSR plans, all-to-all-v, padded all-gather) through RCCL on one GPU."""
+    import os
+
+    import torch.distributed as dist
+
+    from anemoi_models_amd.distributed.partition import sharded_forward
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        gold = golden_cfg1_gt
+        model, _ = _build(graph_o32, 64, 4)
+        model.load_state_dict(split_prefix(gold, "sd."))
+        model = model.to(DEV).eval()
+        with torch.no_grad():
+            y1 = model(gold["x"].to(DEV))
+            y2 = sharded_forward(model, gold["x"].to(DEV), dist.group.WORLD)
+        assert rel_err(y2, gold["y"]) < 1e-4
+        assert rel_err(y2, y1) < 1e-5
+    finally:
+        if created:
+            dist.destroy_process_group()
