@@ -425,16 +425,201 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
   }
 }
 
+// =============================================================================================
+// Same tile and epilogue, deeper software pipeline: four 32 KiB LDS stages of K = 32 (64-byte rows), three
+// half-slabs of LDS-DMA always in flight, COUNTED s_waitcnt vmcnt(8|4|0) (never a drain in steady state) and raw
+// s_barrier -- the __syncthreads() of the two-stage kernel drains vmcnt(0) every slab, which exposes the ~1.5 us
+// load latency against 0.85 us of MFMA work (measured: that kernel is latency-, not bandwidth-bound).
+// vmcnt counts stores too; the counted wait stays correct because loads complete in order among loads: with N
+// younger loads outstanding, "at most N operations outstanding" can only hold once every older load has landed.
+// 64-byte rows need their own bank swizzle: chunk' = chunk ^ ((-(row >> 2)) & 3) (conflict-free for the
+// 16x16x32 fragment read pattern, derived per ds_read_b128 lane group as in MI355X_MICROARCH.md section LDS).
+// =============================================================================================
+constexpr int Q_STAGE = (BIG_M + BIG_N) * 64;            // 32 KiB
+constexpr int Q_LDS = 4 * Q_STAGE + BIG_EPI;             // 160 KiB
+
+__global__ __launch_bounds__(512) void linear_bf16_256x4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+                                                                const bf16_t* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                const bf16_t* __restrict__ R, int64_t ldr,
+                                                                bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
+                                                                int K, int act, int vec_ok, int64_t n_tiles,
+                                                                int nt_count) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int64_t q8 = n_tiles / 8, r8 = n_tiles % 8;
+  const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int64_t chunk_len = q8 + (xcd < r8 ? 1 : 0);
+  if (bix >= chunk_len) return;
+  const int nh = K / 32;  // half-slabs per tile
+
+  // ---- issue side of the stream: (issue_li, issue_h) runs up to three half-slabs ahead of the compute side
+  const int srow = lane >> 2;                                 // row inside a 16-row group
+  const int schunk = (lane & 3) ^ ((-(lane >> 4)) & 3);       // source chunk landing at LDS position lane & 3
+  const char* xg[2];
+  const char* wg[2];
+  int64_t issue_li = bix;
+  int issue_h = 0;
+  int issued = 0;  // half-slabs issued so far (stage = issued & 3)
+  auto setup = [&](int64_t tile) {
+    const int64_t m0 = (tile / nt_count) * BIG_M;
+    const int n0 = (int)(tile % nt_count) * BIG_N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wid * 2 + i) * 16 + srow;
+      int64_t gm = m0 + r;
+      if (gm > M - 1) gm = M - 1;
+      int gn = n0 + r;
+      if (gn > N - 1) gn = N - 1;
+      xg[i] = reinterpret_cast<const char*>(X + gm * ldx) + schunk * 16;
+      wg[i] = reinterpret_cast<const char*>(W + (int64_t)gn * K) + schunk * 16;
+    }
+  };
+  auto issue_next = [&]() {
+    if (issue_li >= chunk_len) return;
+    char* xs = smem + (issued & 3) * Q_STAGE + wid * 2048;
+    char* ws = xs + BIG_M * 64;
+    const int64_t koff = (int64_t)issue_h * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(xg[i] + koff, xs + i * 1024);
+      glds16(wg[i] + koff, ws + i * 1024);
+    }
+    ++issued;
+    if (++issue_h == nh) {
+      issue_h = 0;
+      issue_li += bpx;
+      if (issue_li < chunk_len) setup(chunk_start + issue_li);
+    }
+  };
+
+  const int wm = wid >> 2, wn = wid & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int frag_off = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);  // lane part of every fragment address
+  char* region = smem + 4 * Q_STAGE + wid * 4096;
+  const int rc = lane & 7, rr = lane >> 3;
+
+  setup(chunk_start + bix);
+  issue_next();
+  issue_next();
+  issue_next();
+  int g = 0;  // half-slabs consumed so far
+  for (int64_t li = bix; li < chunk_len; li += bpx) {
+    const int64_t tile = chunk_start + li;
+    const int64_t m0 = (tile / nt_count) * BIG_M;
+    const int n0 = (int)(tile % nt_count) * BIG_N;
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int h = 0; h < nh; ++h, ++g) {
+      // my loads of half-slab g have landed once at most (younger half-slabs) * 4 operations are outstanding
+      const int ahead = issued - g - 1;
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone's part of g landed; everyone is done reading stage (g + 3) & 3
+      asm volatile("" ::: "memory");
+      issue_next();
+      const char* xs = smem + (g & 3) * Q_STAGE + wm * (128 * 64) + frag_off;
+      const char* ws = smem + (g & 3) * Q_STAGE + BIG_M * 64 + wn * (64 * 64) + frag_off;
+      bf16x8_t a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ws + i * (16 * 64));
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        bf16x8_t b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(xs + (jh * 4 + j) * (16 * 64));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh * 4 + j], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue (as in the two-stage kernel): private 4 KiB scratch, whole 128-byte output rows
+    float bv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nb = n0 + wn * 64 + i * 16 + fq * 4;
+      if (bias != nullptr && vec_ok && nb + 4 <= N) {
+        VecIO<float, 4>::load(bias + nb, bv[i]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = (bias != nullptr && nb + r < N) ? bias[nb + r] : 0.f;
+      }
+    }
+    auto epilogue_pass = [&](auto ps_tag) {
+      constexpr int ps = decltype(ps_tag)::value;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        constexpr int jbase = ps * 2;
+        const int j = jbase + jj;
+        const int row = jj * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[i][r], act);
+          const int unit = (i * 4 + fq) ^ (row & 15);
+          *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) =
+              make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 8 + rr;
+        const int sft = row & 15;
+        const int base_unit = ((2 * rc) ^ sft) & ~1;
+        uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + base_unit * 8);
+        if (sft & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+        const int64_t m = m0 + wm * 128 + ps * 32 + row;
+        const int n = n0 + wn * 64 + rc * 8;
+        if (m < M && n < N) {
+          if (vec_ok && n + 8 <= N) {
+            if (R != nullptr) {
+              const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
+              v = make_uint4(bf16x2_add(v.x, rv.x), bf16x2_add(v.y, rv.y), bf16x2_add(v.z, rv.z),
+                             bf16x2_add(v.w, rv.w));
+            }
+            *reinterpret_cast<uint4*>(Y + m * ldy + n) = v;
+          } else {
+            store_row_tail(v, R, ldr, Y, ldy, m, n, N);
+          }
+        }
+      }
+    };
+    epilogue_pass(std::integral_constant<int, 0>{});
+    epilogue_pass(std::integral_constant<int, 1>{});
+    epilogue_pass(std::integral_constant<int, 2>{});
+    epilogue_pass(std::integral_constant<int, 3>{});
+  }
+}
+
 static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                                   int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
                                   hipStream_t st) {
   static bool raised = false;
   if (!raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256x4_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS) != hipSuccess)
       return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", BIG_LDS);
     raised = true;
   }
+  static const int variant = [] {  // ANEMOI_AMD_GEMM_VARIANT: 2 = two-stage (default), 4 = four-stage counted-vmcnt pipeline.  Measured equal
+  // within 3 %: the main loop is bound by the ~45 GB/s/CU global->LDS DMA rate, not by its latency
+    const char* e = getenv("ANEMOI_AMD_GEMM_VARIANT");
+    return e ? atoi(e) : 2;
+  }();
   const int64_t mt = (M + BIG_M - 1) / BIG_M;
   const int64_t nt = (N + BIG_N - 1) / BIG_N;
   ANEMOI_REQUIRE(mt * nt < (int64_t)1 << 31, ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: grid too large");
@@ -447,11 +632,65 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   }();
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
+  if (variant == 4) {
+    hipLaunchKernelGGL(linear_bf16_256x4_kernel, dim3((unsigned)blocks), dim3(512), Q_LDS, st,
+                       static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
+                       static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,
+                       vec_ok ? 1 : 0, mt * nt, (int)nt);
+    return check_launch("anemoi_linear(256x256, 4-stage)");
+  }
   hipLaunchKernelGGL(linear_bf16_256_kernel, dim3((unsigned)blocks), dim3(512), BIG_LDS, st,
                      static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
                      static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,
                      vec_ok ? 1 : 0, mt * nt, (int)nt, getenv("ANEMOI_AMD_GEMM_DEBUG") ? atoi(getenv("ANEMOI_AMD_GEMM_DEBUG")) : 0);
   return check_launch("anemoi_linear(256x256)");
+}
+
+// =============================================================================================
+// Skinny rows (M <= 8): one wave per output column, K swept with 16-byte loads, f32 accumulation, wave reduction.
+// Used for the ragged last rows of a tall GEMM (M % 256 in 1..8) so that they do not cost a full tile round.
+// =============================================================================================
+template <int ROWS>
+__global__ __launch_bounds__(256) void linear_bf16_skinny_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+                                                                 const bf16_t* __restrict__ W,
+                                                                 const float* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ R, int64_t ldr,
+                                                                 bf16_t* __restrict__ Y, int64_t ldy, int M, int N,
+                                                                 int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  const bf16_t* wrow = W + (int64_t)n * K;
+  for (int k = lane * 8; k < K; k += 512) {
+    float wv[8];
+    VecIO<bf16_t, 8>::load(wrow + k, wv);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (r < M) {
+        float xv[8];
+        VecIO<bf16_t, 8>::load(X + r * ldx + k, xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r] = fmaf(xv[i], wv[i], acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
+    const float b = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (r < M) {
+        float o = act_apply(acc[r] + b, act);
+        o = bf16_to_f32(f32_to_bf16(o));  // same double rounding as the tiled kernel (bf16 result, then + residual)
+        if (R != nullptr) o += bf16_to_f32(R[r * ldr + n]);
+        Y[r * ldy + n] = f32_to_bf16(o);
+      }
+    }
+  }
 }
 
 template <typename T, typename TO>
@@ -491,8 +730,23 @@ extern "C" int anemoi_linear(int dtype, int out_dtype, const void* x, int64_t ld
   hipStream_t st = as_stream(stream);
   if (dtype == ANEMOI_F32 && out_dtype == ANEMOI_F32)
     return linear_launch<float, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
-  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16 && M >= 1024 && N >= 256)
-    return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
+  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16 && M >= 1024 && N >= 256) {
+    // A ragged last row tile would cost every CU of one XCD a full extra round (161 vs 160 row tiles at M = 40 962:
+    // +10 %): the 256-row multiple goes to the persistent kernel, the few remaining rows to the 128 x 128 kernel.
+    const int64_t m_main = M / BIG_M * BIG_M, m_tail = M - m_main;
+    if (m_tail == 0) return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
+    const int rc = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, m_main, N, K, act, st);
+    if (rc != ANEMOI_OK) return rc;
+    const bf16_t* xt = static_cast<const bf16_t*>(x) + m_main * ldx;
+    const bf16_t* rt = residual ? static_cast<const bf16_t*>(residual) + m_main * ldr : nullptr;
+    bf16_t* yt = static_cast<bf16_t*>(y) + m_main * ldy;
+    if (m_tail <= 8 && K % 8 == 0) {
+      hipLaunchKernelGGL((linear_bf16_skinny_kernel<8>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, xt, ldx,
+                         static_cast<const bf16_t*>(w), bias, rt, ldr, yt, ldy, (int)m_tail, N, K, act);
+      return check_launch("anemoi_linear(skinny tail)");
+    }
+    return linear_launch<bf16_t, bf16_t>(xt, ldx, w, bias, rt, ldr, yt, ldy, m_tail, N, K, act, st);
+  }
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16)
     return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_F32)
