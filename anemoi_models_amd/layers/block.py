@@ -391,11 +391,52 @@ class GraphConvBaseBlock(BaseBlock, ABC):
                             activation=activation)
         self.conv = GraphConv(in_channels=in_channels, out_channels=out_channels, mlp_extra_layers=mlp_extra_layers,
                               activation=activation)
+        self._packed = runtime.PackedWeights()
+        self._plans = runtime.PlanCache()
 
 
 class GraphConvProcessorBlock(GraphConvBaseBlock):
+    """Edge-MLP message passing on one node set (reference layers/block.py:170-223, layers/conv.py:27-76)."""
+
+    def native(self, x: Tensor, e_csr: Tensor, plan: EdgePlan):
+        """x ``[N, C]``, edge state ``[E, C]`` in CSR (destination-sorted) order -> (new nodes, new edge state)."""
+        dtype = x.dtype
+        c = x.shape[1]
+        edge_mlp, node_mlp = self.conv.edge_mlp.native(), self.node_mlp.native()
+        lin1 = edge_mlp.steps[0][1]
+        act1 = edge_mlp.steps[0][2]
+        if lin1.in_features != 3 * c or e_csr.shape[1] != c:
+            raise ValueError(f"GNN block expects node / edge width {lin1.in_features // 3}, got {c} / {e_csr.shape[1]}")
+        # W1 [x_i | x_j | e] = (W1a x)_i + (W1b x)_j + W1c e : node part as ONE [N, 2C] GEMM, edge part as [E, C] GEMM
+        w_nodes = self._packed.get(("w1_nodes", dtype), [lin1.weight],
+                                   lambda: runtime.pack_weight([lin1.weight[:, :c], lin1.weight[:, c:2 * c]], dtype))
+        w_edges = self._packed.get(("w1_edges", dtype), [lin1.weight],
+                                   lambda: runtime.pack_weight([lin1.weight[:, 2 * c:]], dtype))
+        p = ops.linear(x, w_nodes, None)  # [N, 2C] = W1a x | W1b x
+        t = ops.linear(e_csr, w_edges, None if lin1.bias is None else runtime.f32c(lin1.bias))
+        h = ops.gather_add_act(t, p[:, :c], p[:, c:], plan.dst, plan.col, act=act1, out=t)
+        e_new = edge_mlp(h, residual=e_csr, start=1)  # remaining Linear/act pairs, LayerNorm, "+ e"
+        del h, t, p
+        xcat = torch.empty((x.shape[0], 2 * c), dtype=dtype, device=x.device)
+        xcat[:, :c].copy_(x)
+        ops.segment_sum(e_new, plan.rowptr, out=xcat[:, c:])  # scatter-sum over destinations
+        return node_mlp(xcat, residual=x), e_new
+
     def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
-        raise NotImplementedError("GNN processor block: MI355X kernels not available in this build")
+        if _group_size(model_comm_group) > 1:
+            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+        runtime.require_inference(self)
+        if self.num_chunks > 1 and self.training:
+            pass  # edge chunking only bounds the reference's temporaries; the fused path has none
+        dtype = runtime.compute_dtype(x)
+        n = x.shape[0]
+        plan = self._plans.get(edge_index, n, n)
+        perm = plan.perm.long()
+        e_csr = _as_compute(edge_attr, dtype).index_select(0, perm)
+        x_new, e_new = self.native(_as_compute(x, dtype), e_csr, plan)
+        edges_new = torch.empty_like(e_new)
+        edges_new[perm] = e_new  # back to the caller's edge order
+        return x_new, edges_new
 
 
 class GraphConvMapperBlock(GraphConvBaseBlock):

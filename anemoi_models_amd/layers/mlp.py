@@ -58,11 +58,15 @@ class NativeSequential:
                 raise NotImplementedError(f"module {type(m).__name__} cannot be fused into the native MLP")
             i += 1
 
-    def __call__(self, x: Tensor, residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    def __call__(self, x: Tensor, residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                 start: int = 0) -> Tensor:
+        """Run steps ``start..`` (``start`` > 0: the caller has already produced the output of the earlier steps)."""
         dtype = x.dtype
         last_linear = max(i for i, s in enumerate(self.steps) if s[0] == "linear")
         ends_with_ln = self.steps[-1][0] == "ln"
         for i, (kind, m, act) in enumerate(self.steps):
+            if i < start:
+                continue
             if kind == "linear":
                 w = self.cache.get(("w", i, dtype), [m.weight], lambda m=m: runtime.pack_weight([m.weight], dtype))
                 b = None if m.bias is None else runtime.f32c(m.bias)

@@ -88,8 +88,25 @@ class GNNProcessor(GraphEdgeMixin, BaseProcessor):
         self.proc[0] = GNNProcessorChunk(num_channels, **kw)
         self.offload_layers(cpu_offload)
 
+        self._plans = runtime.PlanCache()
+
+    def native(self, x: Tensor, batch_size: int, node_map: Optional[Tensor] = None) -> Tensor:
+        """x ``[B * N, C]`` in the compute dtype -> processed nodes.  The edge state lives in CSR order throughout."""
+        n = x.shape[0]
+        plan = self._plans.get(self.edge_index_base, n, n, batch_size, self.edge_inc, node_map, node_map)
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)  # [E, pad4(edge_dim)] f32
+        e = ops.convert_pad(ea[:, : self.edge_dim], x.dtype, ops.round_up(self.edge_dim, ops.k_multiple(x.dtype)))
+        for chunk in self.proc:
+            x, e = chunk.native(x, e, plan)
+        return x
+
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
-        raise NotImplementedError("GNNProcessor: MI355X kernels not available in this build")
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            raise NotImplementedError("GNN processor: node-partitioned execution is not implemented yet")
+        runtime.require_inference(self)
+        dtype = runtime.compute_dtype(x)
+        xin = x if x.dtype == dtype else x.to(dtype)
+        return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)
 
 
 class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):

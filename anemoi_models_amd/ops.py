@@ -209,6 +209,42 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     return out
 
 
+def gather_add_act(t: Tensor, p_dst: Tensor, p_src: Tensor, dst: Tensor, src: Tensor, act: str = "Identity",
+                   out: Optional[Tensor] = None) -> Tensor:
+    """``act(t[e] + p_dst[dst[e]] + p_src[src[e]])`` per edge row (first edge-MLP layer of the GNN block)."""
+    _dev(t, p_dst, p_src, dst, src, out)
+    e, c = _rows(t).shape
+    if out is None:
+        out = torch.empty((e, c), dtype=t.dtype, device=t.device)
+    if e == 0:
+        return out
+    if dst.dtype != torch.int32 or src.dtype != torch.int32 or dst.shape[0] != e or src.shape[0] != e:
+        raise ValueError("gather_add_act: dst / src must be int32 [E]")
+    with _Timed("gather_add_act", bytes=4 * e * c * t.element_size()):
+        st = _lib.load().anemoi_gather_add_act(dtype_code(t.dtype), t.data_ptr(), _ld(t), p_dst.data_ptr(),
+                                               _ld(_rows(p_dst)), p_src.data_ptr(), _ld(_rows(p_src)), dst.data_ptr(),
+                                               src.data_ptr(), out.data_ptr(), _ld(_rows(out)), e, c,
+                                               _lib.ACT_CODES[act], _stream())
+    _lib.check(st, "anemoi_gather_add_act")
+    return out
+
+
+def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """Sum of the rows of every CSR segment: ``out[i] = v[rowptr[i]:rowptr[i+1]].sum(0)`` (scatter-sum over dst)."""
+    _dev(v, rowptr, out)
+    n_dst = rowptr.shape[0] - 1
+    c = _rows(v).shape[1]
+    if out is None:
+        out = torch.empty((n_dst, c), dtype=v.dtype, device=v.device)
+    if v.shape[0] == 0:
+        return out.zero_()
+    with _Timed("segment_sum", bytes=(v.shape[0] + n_dst) * c * v.element_size()):
+        st = _lib.load().anemoi_segment_sum(dtype_code(v.dtype), v.data_ptr(), _ld(v), rowptr.data_ptr(),
+                                            out.data_ptr(), _ld(_rows(out)), n_dst, c, _stream())
+    _lib.check(st, "anemoi_segment_sum")
+    return out
+
+
 def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Tensor], batch_size: int,
                    dtype: torch.dtype, ld_out: Optional[int] = None, ensemble: int = 1) -> Tensor:
     """Rows ``(b, ens, g)`` of ``[x (time-major) | latlons | trainable | 0-pad]`` in ``dtype``."""

@@ -67,6 +67,16 @@ class EdgePlan:
     def num_edges(self) -> int:
         return int(self.col.shape[0])
 
+    @property
+    def dst(self) -> Tensor:
+        """int32 [E]: destination node of every CSR slot (row index expanded; built on first use)."""
+        d = getattr(self, "_dst", None)
+        if d is None:
+            counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            d = torch.repeat_interleave(torch.arange(self.n_dst, device=self.rowptr.device), counts).to(torch.int32)
+            self._dst = d
+        return d
+
 
 def build_edge_plan(edge_index: Tensor, n_src: int, n_dst: int) -> EdgePlan:
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:

@@ -51,13 +51,15 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--processor", default="GraphTransformer", choices=["GraphTransformer", "GNN", "Transformer"],
+                    help="processor family (BASELINE config 5 = --workload cfg2 --processor GNN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2, help="processor blocks in the CPU-baseline sample")
     ap.add_argument("--detail", action="store_true", help="print a per-shape kernel table to stderr")
     return ap.parse_args()
 
 
-def build(workload: str, device):
+def build(workload: str, device, processor: str = "GraphTransformer"):
     from anemoi_models_amd.graphs.synthetic import build_graph
     from anemoi_models_amd.models import AnemoiModelEncProcDec
     from anemoi_models_amd.utils.indices import SimpleDataIndices
@@ -68,7 +70,7 @@ def build(workload: str, device):
     idx = SimpleDataIndices(n_prognostic=80, n_forcing=10, n_diagnostic=0)
     torch.manual_seed(1234)
     with torch.device(device):  # random-init the weights directly in HBM
-        model = AnemoiModelEncProcDec(model_config=model_config("GraphTransformer", channels, layers, heads),
+        model = AnemoiModelEncProcDec(model_config=model_config(processor, channels, layers, heads),
                                       data_indices=idx, graph_data=graph.to(device))
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -195,7 +197,7 @@ def main():
         group = dist.group.WORLD
 
     os.environ["ANEMOI_AMD_DTYPE"] = args.dtype
-    model, graph, x, _ = build(args.workload, device)
+    model, graph, x, _ = build(args.workload, device, args.processor)
     n_mesh = graph["hidden"].num_nodes
     layers = WORKLOADS[args.workload][2]
 
@@ -246,7 +248,9 @@ def main():
             },
         }
         line.update(extra)
-        if not args.no_cpu_baseline and world == 1:
+        if args.processor != "GraphTransformer":
+            line["config"]["workload"] = line["config"]["workload"].replace("GT blocks", f"{args.processor} blocks")
+        if not args.no_cpu_baseline and world == 1 and args.processor == "GraphTransformer":
             line["cpu_baseline"] = cpu_baseline(model, graph, args.cpu_blocks)
         print(json.dumps(line), flush=True)
     if group is not None:

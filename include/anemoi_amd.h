@@ -141,6 +141,23 @@ int anemoi_convert_pad(int src_dtype, const void* src, int64_t ld_src, int dst_d
 int anemoi_add(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
                int cols, anemoi_stream_t stream);
 
+/*
+ * GNN edge phase, part 1 (K5): out[e, :] = act(t[e, :] + p_dst[dst[e], :] + p_src[src[e], :]).
+ * With t = e W1c^T + b1, p_dst = x W1a^T, p_src = x W1b^T this is the first Linear + activation of the edge MLP applied
+ * to cat[x_i, x_j, e] (layers/conv.py:68-69, layers/mlp.py:74) without materialising the [E, 3C] concatenation.
+ * dst / src: int32 [E] node index per edge (CSR order: dst ascending).
+ */
+int anemoi_gather_add_act(int dtype, const void* t, int64_t ldt, const void* p_dst, int64_t ldpd, const void* p_src,
+                          int64_t ldps, const int32_t* dst, const int32_t* src, void* out, int64_t ldo,
+                          int64_t n_edges, int C, int act, anemoi_stream_t stream);
+
+/*
+ * GNN edge phase, part 2: out[i, :] = sum of v[e, :] over the CSR row i (edges sorted by destination), f32 accumulation
+ * in CSR order.  Replaces torch_geometric scatter(reduce="sum") at layers/conv.py:73-76.
+ */
+int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* rowptr, void* out, int64_t ldo,
+                       int64_t n_dst, int C, anemoi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

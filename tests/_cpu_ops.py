@@ -80,6 +80,24 @@ def gt_edge_attention(q, k, v, x_r, edge_attr, edge_dim, w_edge, b_edge, rowptr,
     return res.to(q.dtype)
 
 
+def gather_add_act(t, p_dst, p_src, dst, src, act="Identity", out=None):
+    y = _ACT[act](t.float() + p_dst.float()[dst.long()] + p_src.float()[src.long()]).to(t.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def segment_sum(v, rowptr, out=None):
+    n = rowptr.shape[0] - 1
+    dst = torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).long())
+    y = scatter_sum(v.float(), dst, n).to(v.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def assemble_nodes(x, latlons, trainable, batch_size, dtype, ld_out=None, ensemble=1):
     parts = []
     if x is not None:
@@ -114,6 +132,6 @@ def install(monkeypatch):
     import anemoi_models_amd.ops as ops
 
     for name in ("layer_norm", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
-                 "assemble_nodes",
+                 "gather_add_act", "segment_sum", "assemble_nodes",
                  "prognostic_residual", "convert_pad", "add"):
         monkeypatch.setattr(ops, name, globals()[name])

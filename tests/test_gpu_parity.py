@@ -304,3 +304,42 @@ def test_node_partitioned_forward_world1_rccl(graph_o32, golden_cfg1_gt):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------- GNN path
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gnn_edge_ops(dtype):
+    from anemoi_models_amd import ops, runtime
+
+    g = torch.Generator().manual_seed(11)
+    n, e, c = 300, 2500, 192
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n - 1, (e,), generator=g)])
+    plan = runtime.build_edge_plan(ei.to(DEV), n, n)
+    t, pd, ps = (torch.randn(s, c, generator=g).to(dtype) for s in (e, n, n))
+    want = F.silu(t.float() + pd.float()[plan.dst.long().cpu()] + ps.float()[plan.col.long().cpu()])
+    got = ops.gather_add_act(t.to(DEV), pd.to(DEV), ps.to(DEV), plan.dst, plan.col, act="SiLU")
+    assert rel_err(got, want) < (1e-6 if dtype == torch.float32 else 1e-2)
+    v = torch.randn(e, c, generator=g).to(dtype)
+    want = torch.zeros(n, c).index_add_(0, plan.dst.long().cpu(), v.float())
+    got = ops.segment_sum(v.to(DEV), plan.rowptr)
+    assert rel_err(got, want) < (1e-6 if dtype == torch.float32 else 1e-2)
+    assert torch.all(got[n - 1] == 0)  # destination without edges
+
+
+def test_gnn_block_and_model_vs_golden(graph_o32, golden_blocks, golden_cfg1_gnn):
+    from anemoi_models_amd.layers.block import GraphConvProcessorBlock
+
+    b = golden_blocks
+    blk = GraphConvProcessorBlock(64, 64, mlp_extra_layers=0, activation="SiLU")
+    blk.load_state_dict(split_prefix(b, "gnn.sd."))
+    blk = blk.to(DEV).eval()
+    with torch.no_grad():
+        y, e_new = blk(b["gnn.x"].to(DEV), b["gnn.edge_attr"].to(DEV), b["gnn.edge_index"].to(DEV), (None, None), None)
+    assert rel_err(y, b["gnn.y"]) < 1e-4 and rel_err(e_new, b["gnn.edges_new"]) < 1e-4
+    gold = golden_cfg1_gnn
+    model, _ = _build(graph_o32, 64, 4, processor="GNN")
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(gold["x"].to(DEV))
+    assert rel_err(out, gold["y"]) < 1e-4

@@ -126,3 +126,24 @@ def test_bad_activation_raises_runtime_error():
 
     with pytest.raises(RuntimeError):
         GraphTransformerProcessorBlock(64, 256, 64, edge_dim=11, num_heads=16, activation="NoSuchAct")
+
+
+def test_gnn_model_and_block_wiring_match_golden(graph_o32, golden_cfg1_gnn, golden_blocks, monkeypatch):
+    from anemoi_models_amd.layers.block import GraphConvProcessorBlock
+
+    _cpu_ops.install(monkeypatch)
+    b = golden_blocks
+    blk = GraphConvProcessorBlock(64, 64, mlp_extra_layers=0, activation="SiLU").eval()
+    blk.load_state_dict(split_prefix(b, "gnn.sd."))
+    with torch.no_grad():
+        y, e_new = blk(b["gnn.x"], b["gnn.edge_attr"], b["gnn.edge_index"], (None, None), None)
+    torch.testing.assert_close(y, b["gnn.y"], atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(e_new, b["gnn.edges_new"], atol=2e-5, rtol=2e-5)  # returned in the caller's edge order
+
+    gold = golden_cfg1_gnn
+    model = build_model(graph_o32, "GNN")
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model.eval()
+    with torch.no_grad():
+        out = model(gold["x"])
+    torch.testing.assert_close(out, gold["y"], atol=1e-4, rtol=1e-4)
