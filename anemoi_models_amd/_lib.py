@@ -52,6 +52,9 @@ SIGNATURES = {
     "anemoi_gather_add_act": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "anemoi_segment_sum": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "anemoi_mhsa_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "anemoi_mhsa": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                            c_void_p]),
     "anemoi_assemble_nodes": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "anemoi_prognostic_residual": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,

@@ -1,0 +1,320 @@
+// Mesh-node multi-head self attention (K7 of SURVEY.md section 2a): softmax(Q K^T / sqrt(D)) V per (batch, head),
+// flash style (no S x S matrix in memory), directly on the fused lin_qkv output  qkv [B*S, 3C] = q | k | v.
+//
+// bf16, D = 64: matrix cores.  One wave owns 32 query rows; the scores are produced TRANSPOSED,
+//     S^T[key][query] = K Q^T      via v_mfma_f32_32x32x16_bf16 with A = K rows, B = Q^T,
+// so that each lane holds 16 scores of ONE query: the online-softmax row max / row sum are in-lane reductions plus a
+// single cross-half exchange.  The K rows are assigned to MFMA rows with index bits 2 and 3 swapped; with the
+// accumulator map  row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)  this makes registers 0..7 / 8..15 of a lane hold 8
+// CONTIGUOUS keys each, i.e. exactly the B-operand fragment of the second product
+//     O^T[d][query] += V^T[d][key] P^T[key][query]
+// without any cross-lane movement of P.  V is transposed once per call into [B, H, D, S_pad] so that the V^T
+// fragments are plain 16-byte LDS reads.  K and V^T tiles (64 keys) are staged with global_load_lds into a
+// double-buffered LDS image using the GEMM kernel's 128-byte-row XOR swizzle.
+//
+// f32 (parity path) and other head sizes: a VALU kernel, one wave per (query, head), keys strided over the lanes.
+//
+// `window` >= 0 applies flash-attn's sliding window (key j visible from query i iff |i - j| <= window);
+// window < 0 = global attention (the reference's SDPA fallback, layers/attention.py:99-105).
+#include "common.hpp"
+
+namespace anemoi {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float af32x16_t;
+
+__device__ __forceinline__ void aglds16(const void* gptr, void* lptr) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
+}
+__device__ __forceinline__ int aswz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// ---------------------------------------------------------------------------------------------
+// vt[b, h, d, s] = qkv[b*S + s, 2C + h*D + d]   (zero padded to S_pad keys)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int S, int S_pad,
+                                                          int H, int D, int C, bf16_t* __restrict__ vt) {
+  __shared__ bf16_t tile[64][66];
+  const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  for (int d0 = 0; d0 < D; d0 += 64) {
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      const int s = s0 + r, d = d0 + c;
+      tile[r][c] = (s < S && d < D) ? qkv[((int64_t)b * S + s) * ld + 2 * C + h * D + d] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+      const int d = idx >> 6, r = idx & 63;
+      if (d0 + d < D && s0 + r < S_pad) vt[(((int64_t)b * H + h) * D + d0 + d) * S_pad + s0 + r] = tile[r][d];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 / D = 64 MFMA kernel: 4 waves x 32 queries per workgroup, 64-key tiles
+// ---------------------------------------------------------------------------------------------
+constexpr int ATT_D = 64, ATT_KV = 64, ATT_TILE = ATT_KV * 128;  // 8 KiB per operand per stage
+
+__global__ __launch_bounds__(256) void mhsa_bf16_d64_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                            const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+                                                            int64_t ldo, int S, int S_pad, int H, int C, int window,
+                                                            float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];  // 2 stages x (K tile + V^T tile)
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int half = lane >> 5, ql = lane & 31;
+  const int q = q0 + ql;                     // this lane's query (may be >= S in the last block)
+  const int qc = q < S ? q : S - 1;
+
+  // ---- Q^T fragments (B operand): Q[q][ks*16 + half*8 .. +8]
+  abf16x8_t qf[4];
+  {
+    const bf16_t* qp = qkv + ((int64_t)b * S + qc) * ld + h * ATT_D + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
+  }
+
+  // ---- key range of this workgroup (sliding window: only tiles that intersect any of its 128 queries)
+  int kt_begin = 0, kt_end = (S + ATT_KV - 1) / ATT_KV;
+  if (window >= 0) {
+    const int lo = (int)blockIdx.x * 128 - window, hi = (int)blockIdx.x * 128 + 127 + window;
+    kt_begin = lo > 0 ? lo / ATT_KV : 0;
+    const int e = hi / ATT_KV + 1;
+    kt_end = e < kt_end ? e : kt_end;
+  }
+
+  // ---- staging: K tile rows = keys, V^T tile rows = d; 8 row groups (8 rows x 128 B) each, 2 + 2 per wave
+  const int srow = lane >> 3, scp = lane & 7;
+  const bf16_t* kbase = qkv + (int64_t)b * S * ld + C + h * ATT_D;
+  const bf16_t* vbase = vt + ((int64_t)b * H + h) * ATT_D * S_pad;
+  auto stage = [&](int kt, int buf) {
+    char* ks_ = smem + buf * 2 * ATT_TILE;
+    char* vs_ = ks_ + ATT_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wid * 2 + i) * 8 + srow;
+      const int c = aswz(r, scp);
+      int key = kt * ATT_KV + r;
+      if (key > S - 1) key = S - 1;
+      aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + c * 16, ks_ + (wid * 2 + i) * 1024);
+      aglds16(reinterpret_cast<const char*>(vbase + (int64_t)r * S_pad + kt * ATT_KV) + c * 16,
+              vs_ + (wid * 2 + i) * 1024);
+    }
+  };
+
+  af32x16_t o_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // K row of MFMA row i: index bits 2 and 3 swapped
+  const int kperm = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+
+  if (kt_begin < kt_end) stage(kt_begin, 0);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    __syncthreads();
+    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
+    const char* ks_ = smem + buf * 2 * ATT_TILE;
+    const char* vs_ = ks_ + ATT_TILE;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      // ---- S^T block: 32 keys x 32 queries
+      af32x16_t s_acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+      const int krow = kb * 32 + kperm;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const abf16x8_t kf =
+            *reinterpret_cast<const abf16x8_t*>(ks_ + krow * 128 + (aswz(krow, ks * 2 + half) << 4));
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc, 0, 0, 0);
+      }
+      // ---- online softmax in the log2 domain; register r <-> key kbase_ + (r & 7) + 16 (r >> 3)
+      const int key0 = kt * ATT_KV + kb * 32 + 8 * half;
+      float t[16];
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + (r & 7) + 16 * (r >> 3);
+        bool ok = key < S;
+        if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
+        t[r] = ok ? s_acc[r] * scale_log2e : -INFINITY;
+        mloc = fmaxf(mloc, t[r]);
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;  // fully masked so far: exp2(-inf - 0) = 0
+      const float corr = exp2f(m_run - m_use);               // m_run = -inf -> 0
+      l_run *= corr;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[dt][r] *= corr;
+      float p[16];
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = exp2f(t[r] - m_use);
+        psum += p[r];
+      }
+      l_run += psum;
+      m_run = m_new;
+      // ---- P^T fragments: registers 0..7 / 8..15 are 8 contiguous keys each
+      abf16x8_t pb[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(p[kk * 8 + 2 * i], p[kk * 8 + 2 * i + 1]);
+        pb[kk] = *reinterpret_cast<abf16x8_t*>(w);
+      }
+      // ---- O^T += V^T P^T
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int vrow = dt * 32 + ql;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const abf16x8_t vf = *reinterpret_cast<const abf16x8_t*>(
+              vs_ + vrow * 128 + (aswz(vrow, kb * 4 + kk * 2 + half) << 4));
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kk], o_acc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q][dt*32 + (r & 3) + 8 (r >> 2) + 4 half]
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q < S) {
+    bf16_t* op = out + ((int64_t)b * S + q) * ldo + h * ATT_D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v4[4] = {o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv, o_acc[dt][4 * g + 2] * inv,
+                             o_acc[dt][4 * g + 3] * inv};
+        VecIO<bf16_t, 4>::store(op + dt * 32 + 8 * g + 4 * half, v4);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel (f32 or bf16 storage, any D <= 128): one wave per (query, head); lane l takes keys l, l+64, ...
+// with its own running (max, sum, acc[D]); the 64 partial states are merged at the end.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__ qkv, int64_t ld, T* __restrict__ out,
+                                                           int64_t ldo, int S, int H, int D, int C, int window,
+                                                           float scale, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
+  if (unit >= total) return;
+  const int h = (int)(unit % H);
+  const int64_t bq = unit / H;
+  const int q = (int)(bq % S);
+  const int64_t b = bq / S;
+  const T* qp = qkv + bq * ld + h * D;
+  float qv[DMAX], acc[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    qv[d] = d < D ? Elem<T>::load(qp + d) * scale : 0.f;
+    acc[d] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  int k_lo = 0, k_hi = S;
+  if (window >= 0) {
+    k_lo = q - window > 0 ? q - window : 0;
+    k_hi = q + window + 1 < S ? q + window + 1 : S;
+  }
+  for (int key = k_lo + lane; key < k_hi; key += 64) {
+    const T* kp = qkv + (b * S + key) * ld + C + h * D;
+    const T* vp = kp + C;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D) s = fmaf(qv[d], Elem<T>::load(kp + d), s);
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), pe = __expf(s - mn);
+    l = l * corr + pe;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D) acc[d] = acc[d] * corr + pe * Elem<T>::load(vp + d);
+    m = mn;
+  }
+  // merge the 64 lane states
+  float mt = m;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mt = fmaxf(mt, __shfl_xor(mt, off, 64));
+  const float w = m == -INFINITY ? 0.f : __expf(m - mt);
+  const float lt = wave_sum(l * w);
+  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  T* op = out + bq * ldo + h * D;
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    if (d < D) {
+      const float o = wave_sum(acc[d] * w) * inv;
+      if (lane == 0) Elem<T>::store(op + d, o);
+    }
+  }
+}
+
+}  // namespace anemoi
+
+using namespace anemoi;
+
+extern "C" {
+
+int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
+  if (dtype == ANEMOI_BF16 && D == ATT_D) return (int64_t)B * H * D * ((S + 63) / 64 * 64) * 2;
+  return 0;
+}
+
+int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, int B, int S, int H,
+                int D, int window, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(qkv && out, ANEMOI_ERR_INVALID, "anemoi_mhsa: null pointer");
+  ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa: bad shape");
+  const int C = H * D;
+  ANEMOI_REQUIRE(ld >= 3 * (int64_t)C && ldo >= C, ANEMOI_ERR_INVALID, "anemoi_mhsa: leading dimension too small");
+  hipStream_t st = as_stream(stream);
+  const float scale = 1.0f / sqrtf((float)D);
+  if (dtype == ANEMOI_BF16 && D == ATT_D && (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 && (uintptr_t)out % 8 == 0 &&
+      ldo % 4 == 0) {
+    ANEMOI_REQUIRE(workspace != nullptr, ANEMOI_ERR_INVALID, "anemoi_mhsa: workspace of %lld bytes required",
+                   (long long)anemoi_mhsa_workspace_bytes(dtype, B, S, H, D));
+    const int S_pad = (S + 63) / 64 * 64;
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(qkv), ld, S, S_pad, H, D, C, static_cast<bf16_t*>(workspace));
+    hipLaunchKernelGGL(mhsa_bf16_d64_kernel, dim3((S + 127) / 128, H, B), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(qkv), ld, static_cast<const bf16_t*>(workspace),
+                       static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window, scale * 1.44269504088896340736f);
+    return check_launch("anemoi_mhsa(bf16, D=64)");
+  }
+  ANEMOI_REQUIRE(D <= 128, ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa: head size %d > 128", D);
+  const int64_t units = (int64_t)B * S * H;
+  ANEMOI_REQUIRE((units + 3) / 4 < ((int64_t)1 << 31), ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa: grid too large");
+  dim3 grid((unsigned)((units + 3) / 4)), block(256);
+#define GEN(T, DM)                                                                                               \
+  hipLaunchKernelGGL((mhsa_generic_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,           \
+                     static_cast<T*>(out), ldo, S, H, D, C, window, scale, units)
+  if (dtype == ANEMOI_F32) {
+    if (D <= 32) GEN(float, 32);
+    else if (D <= 64) GEN(float, 64);
+    else GEN(float, 128);
+  } else if (dtype == ANEMOI_BF16) {
+    if (D <= 32) GEN(bf16_t, 32);
+    else if (D <= 64) GEN(bf16_t, 64);
+    else GEN(bf16_t, 128);
+  } else {
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa: dtype %d", dtype);
+  }
+#undef GEN
+  return check_launch("anemoi_mhsa(generic)");
+}
+
+}  // extern "C"

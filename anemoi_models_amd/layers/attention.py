@@ -5,10 +5,16 @@ Parameters: ``lin_qkv`` (no bias by default) and ``projection`` (bias) -- identi
 
 from __future__ import annotations
 
+import os
 from typing import Optional
 
+import torch
 from torch import Tensor
 from torch import nn
+
+from .. import ops
+from .. import runtime
+from .mlp import linear_native
 
 
 class MultiHeadSelfAttention(nn.Module):
@@ -27,5 +33,28 @@ class MultiHeadSelfAttention(nn.Module):
         self.lin_qkv = nn.Linear(embed_dim, 3 * embed_dim, bias=bias)
         self.projection = nn.Linear(embed_dim, embed_dim, bias=True)
 
+        self._packed = runtime.PackedWeights()
+
+    def attention_window(self) -> int:
+        """-1 (global) by default = the reference's scaled_dot_product_attention fallback, which ignores the window
+        (reference layers/attention.py:99-105); ``ANEMOI_AMD_FLASH_WINDOW=1`` applies flash-attn's
+        ``window_size=(w, w)`` semantics of the reference's GPU path (layers/attention.py:96)."""
+        if os.environ.get("ANEMOI_AMD_FLASH_WINDOW", "0") == "1" and self.window_size[0] is not None:
+            return int(self.window_size[0])
+        return -1
+
+    def native(self, x: Tensor, batch_size: int) -> Tensor:
+        if self.training and self.dropout_p > 0.0:
+            raise NotImplementedError("attention dropout > 0 is not implemented on the MI355X path")
+        qkv = linear_native(self._packed, "lin_qkv", self.lin_qkv, x)  # [B*S, 3C] = q | k | v
+        att = ops.mhsa(qkv, batch_size, self.num_heads, self.attention_window())
+        return linear_native(self._packed, "projection", self.projection, att)
+
     def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None) -> Tensor:
-        raise NotImplementedError("MultiHeadSelfAttention: MI355X kernel not available in this build")
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            assert batch_size == 1, "Only batch size of 1 is supported when model is sharded accross GPUs"
+            raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
+        runtime.require_inference(self)
+        dtype = runtime.compute_dtype(x)
+        xin = x if x.dtype == dtype else x.to(dtype)
+        return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)

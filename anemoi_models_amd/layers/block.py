@@ -29,6 +29,7 @@ from .conv import GraphTransformerConv
 from .mlp import MLP
 from .mlp import NativeSequential
 from .mlp import activation_class
+from .mlp import linear_native
 
 
 def inference_num_chunks() -> int:
@@ -460,5 +461,24 @@ class TransformerProcessorBlock(BaseBlock):
         self.mlp = nn.Sequential(nn.Linear(num_channels, hidden_dim), act(), nn.Linear(hidden_dim, num_channels))
         self.layer_norm2 = nn.LayerNorm(num_channels)
 
+        self._mlp: Optional[NativeSequential] = None
+
+    def native(self, x: Tensor, batch_size: int) -> Tensor:
+        """Pre-LN attention residual + pre-LN MLP residual (reference layers/block.py:99-105)."""
+        ln1, ln2 = self.layer_norm1, self.layer_norm2
+        h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
+        att = self.attention
+        qkv = linear_native(att._packed, "lin_qkv", att.lin_qkv, h)
+        a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window())
+        x = linear_native(att._packed, "projection", att.projection, a, residual=x)  # x + attention(...)
+        if self._mlp is None:
+            self._mlp = NativeSequential(self.mlp)
+        h = ops.layer_norm(x, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
+        return self._mlp(h, residual=x)
+
     def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None) -> Tensor:
-        raise NotImplementedError("Transformer processor block: MI355X kernels not available in this build")
+        if _group_size(model_comm_group) > 1:
+            raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
+        runtime.require_inference(self)
+        dtype = runtime.compute_dtype(x)
+        return self.native(_as_compute(x, dtype), batch_size)

@@ -42,6 +42,11 @@ class TransformerProcessorChunk(BaseProcessorChunk):
             num_heads=num_heads, activation=activation, window_size=window_size, dropout_p=dropout_p,
         )
 
+    def native(self, x: Tensor, batch_size: int) -> Tensor:
+        for blk in self.blocks:
+            x = blk.native(x, batch_size)
+        return x
+
     def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None):
         for blk in self.blocks:
             x = blk(x, shapes, batch_size, model_comm_group=model_comm_group)

@@ -63,13 +63,33 @@ class TransformerProcessor(BaseProcessor):
         )
         self.offload_layers(cpu_offload)
 
+    def native(self, x: Tensor, batch_size: int, node_map: Optional[Tensor] = None) -> Tensor:
+        """x ``[B * N, C]`` in the compute dtype.  Global attention is permutation-equivariant, so an internal node
+        order needs no special handling; a sliding window acts on the EXTERNAL order, hence the un/re-permutation."""
+        windowed = self.proc[0].blocks[0].attention.attention_window() >= 0
+        if node_map is not None and windowed:
+            n = node_map.shape[0]
+            ext = torch.cat([node_map + b * n for b in range(batch_size)])  # external row -> internal row
+            x = x.index_select(0, ext)
+        for chunk in self.proc:
+            x = chunk.native(x, batch_size)
+        if node_map is not None and windowed:
+            back = torch.empty_like(x)
+            back[ext] = x
+            x = back
+        return x
+
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None, *args, **kwargs) -> Tensor:
         if model_comm_group is not None:
             assert (
                 model_comm_group.size() == 1 or batch_size == 1
             ), "Only batch size of 1 is supported when model is sharded accross GPUs"
-        (x,) = self.run_layers((x,), shard_shapes, batch_size, model_comm_group)
-        return x
+            if model_comm_group.size() > 1:
+                raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
+        runtime.require_inference(self)
+        dtype = runtime.compute_dtype(x)
+        xin = x if x.dtype == dtype else x.to(dtype)
+        return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)
 
 
 class GNNProcessor(GraphEdgeMixin, BaseProcessor):

@@ -245,6 +245,26 @@ def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None) -> Tens
     return out
 
 
+def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Optional[Tensor] = None) -> Tensor:
+    """Multi-head self attention on the fused ``lin_qkv`` output ``[B*S, 3C]`` -> ``[B*S, C]`` (heads concatenated)."""
+    _dev(qkv, out)
+    rows, c3 = _rows(qkv).shape
+    c = c3 // 3
+    s_len = rows // batch_size
+    d = c // num_heads
+    if out is None:
+        out = torch.empty((rows, c), dtype=qkv.dtype, device=qkv.device)
+    lib = _lib.load()
+    code = dtype_code(qkv.dtype)
+    ws_bytes = lib.anemoi_mhsa_workspace_bytes(code, batch_size, s_len, num_heads, d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 else None
+    with _Timed("mhsa", flops=4 * batch_size * num_heads * s_len * s_len * d, s=s_len, h=num_heads, d=d):
+        st = lib.anemoi_mhsa(code, qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)), _ptr(ws), batch_size,
+                             s_len, num_heads, d, window, _stream())
+    _lib.check(st, "anemoi_mhsa")
+    return out
+
+
 def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Tensor], batch_size: int,
                    dtype: torch.dtype, ld_out: Optional[int] = None, ensemble: int = 1) -> Tensor:
     """Rows ``(b, ens, g)`` of ``[x (time-major) | latlons | trainable | 0-pad]`` in ``dtype``."""

@@ -158,6 +158,18 @@ int anemoi_gather_add_act(int dtype, const void* t, int64_t ldt, const void* p_d
 int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* rowptr, void* out, int64_t ldo,
                        int64_t n_dst, int C, anemoi_stream_t stream);
 
+/*
+ * Mesh-node multi-head self attention (K7): out[b*S + i, h*D:(h+1)*D] = softmax_j(q_i . k_j / sqrt(D)) v_j per head,
+ * flash style, on the fused lin_qkv output qkv [B*S, 3C] = q | k | v (leading dimension ld), C = H*D.
+ * Replaces the rearranges + flash_attn_func / scaled_dot_product_attention of layers/attention.py:76-108.
+ * window < 0: global attention (the reference's SDPA fallback); window >= 0: flash-attn sliding window |i - j| <= window.
+ * bf16 with D = 64 runs on MFMA and needs `workspace` of anemoi_mhsa_workspace_bytes() bytes (V transposed);
+ * other cases use a VALU kernel (workspace may be NULL).
+ */
+int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D);
+int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, int B, int S, int H,
+                int D, int window, anemoi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,19 @@ def segment_sum(v, rowptr, out=None):
     return y
 
 
+def mhsa(qkv, batch_size, num_heads, window=-1, out=None):
+    rows, c3 = qkv.shape
+    c = c3 // 3
+    s_len, d = rows // batch_size, c // num_heads
+    q, k, v = (t.float().reshape(batch_size, s_len, num_heads, d).permute(0, 2, 1, 3) for t in qkv.split(c, dim=1))
+    sc = q @ k.transpose(-1, -2) / d**0.5
+    if window >= 0:
+        i = torch.arange(s_len)
+        sc = sc.masked_fill((i[:, None] - i[None, :]).abs() > window, float("-inf"))
+    o = torch.softmax(sc, -1) @ v
+    return o.permute(0, 2, 1, 3).reshape(rows, c).to(qkv.dtype)
+
+
 def assemble_nodes(x, latlons, trainable, batch_size, dtype, ld_out=None, ensemble=1):
     parts = []
     if x is not None:
@@ -132,6 +145,6 @@ def install(monkeypatch):
     import anemoi_models_amd.ops as ops
 
     for name in ("layer_norm", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
-                 "gather_add_act", "segment_sum", "assemble_nodes",
+                 "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                  "prognostic_residual", "convert_pad", "add"):
         monkeypatch.setattr(ops, name, globals()[name])

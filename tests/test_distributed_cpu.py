@@ -32,7 +32,7 @@ def _worker(rank, world, port, result_file):
         from anemoi_models_amd.utils.presets import model_config
 
         for name in ("layer_norm", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
-                     "gather_add_act", "segment_sum", "assemble_nodes", "prognostic_residual", "convert_pad", "add"):
+                     "gather_add_act", "segment_sum", "mhsa", "assemble_nodes", "prognostic_residual", "convert_pad", "add"):
             setattr(ops, name, getattr(_cpu_ops, name))
         with np.load(os.path.join(GOLDEN, "cfg1_gt.npz")) as z:
             gold = {k: torch.from_numpy(z[k]) for k in z.files}

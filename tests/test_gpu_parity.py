@@ -343,3 +343,57 @@ def test_gnn_block_and_model_vs_golden(graph_o32, golden_blocks, golden_cfg1_gnn
     with torch.no_grad():
         out = model(gold["x"].to(DEV))
     assert rel_err(out, gold["y"]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- MHSA / Transformer path
+def _sdpa(qkv, b, h, window):
+    rows, c3 = qkv.shape
+    c, s = c3 // 3, rows // b
+    d = c // h
+    q, k, v = (t.double().reshape(b, s, h, d).permute(0, 2, 1, 3) for t in qkv.split(c, dim=1))
+    sc = q @ k.transpose(-1, -2) / d**0.5
+    if window >= 0:
+        i = torch.arange(s)
+        sc = sc.masked_fill((i[:, None] - i[None, :]).abs() > window, float("-inf"))
+    return (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(rows, c)
+
+
+@pytest.mark.parametrize("dtype,b,s,h,d,window", [
+    (torch.bfloat16, 1, 300, 4, 64, -1),      # MFMA kernel, ragged S (not a multiple of 64 / 128)
+    (torch.bfloat16, 2, 1000, 16, 64, -1),    # MFMA kernel, batch 2, config-3 head layout
+    (torch.bfloat16, 1, 777, 2, 64, 40),      # MFMA kernel + sliding window
+    (torch.bfloat16, 1, 200, 8, 32, -1),      # generic kernel, bf16 storage
+    (torch.float32, 2, 96, 8, 8, -1),         # generic kernel, the golden block shape
+    (torch.float32, 1, 500, 4, 64, -1),
+    (torch.float32, 1, 260, 2, 100, 25),      # odd head size + window
+])
+def test_mhsa(dtype, b, s, h, d, window):
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(s + d)
+    qkv = torch.randn(b * s, 3 * h * d, generator=g).to(dtype)
+    # forces the online-softmax rescale: one key with a much larger score for a few queries late in the sequence
+    qkv[s // 2, h * d: h * d + d] *= 6.0
+    want = _sdpa(qkv, b, h, window)
+    got = ops.mhsa(qkv.to(DEV), b, h, window)
+    assert got.shape == (b * s, h * d) and got.dtype == dtype
+    assert rel_err(got, want) < (2e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_transformer_block_and_model_vs_golden(graph_o32, golden_blocks, golden_cfg1_tfm):
+    from anemoi_models_amd.layers.block import TransformerProcessorBlock
+
+    b = golden_blocks
+    blk = TransformerProcessorBlock(64, 256, 8, "GELU", window_size=16, dropout_p=0.0)
+    blk.load_state_dict(split_prefix(b, "tfm.sd."))
+    blk = blk.to(DEV).eval()
+    with torch.no_grad():
+        y = blk(b["tfm.x"].to(DEV), [[192, 64]], 2)
+    assert rel_err(y, b["tfm.y"]) < 1e-4
+    gold = golden_cfg1_tfm
+    model, _ = _build(graph_o32, 64, 4, processor="Transformer")
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(gold["x"].to(DEV))
+    assert rel_err(out, gold["y"]) < 1e-4

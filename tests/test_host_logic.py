@@ -147,3 +147,25 @@ def test_gnn_model_and_block_wiring_match_golden(graph_o32, golden_cfg1_gnn, gol
     with torch.no_grad():
         out = model(gold["x"])
     torch.testing.assert_close(out, gold["y"], atol=1e-4, rtol=1e-4)
+
+
+def test_transformer_model_and_block_wiring_match_golden(graph_o32, golden_cfg1_tfm, golden_blocks, monkeypatch):
+    from anemoi_models_amd.layers.block import TransformerProcessorBlock
+
+    _cpu_ops.install(monkeypatch)
+    b = golden_blocks
+    blk = TransformerProcessorBlock(64, 256, 8, "GELU", window_size=16, dropout_p=0.0).eval()
+    blk.load_state_dict(split_prefix(b, "tfm.sd."))
+    with torch.no_grad():
+        y = blk(b["tfm.x"], [[192, 64]], 2)
+        att = blk.attention(b["tfm.x"], [[192, 64]], 2)
+    torch.testing.assert_close(att, b["tfm.att"], atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(y, b["tfm.y"], atol=2e-5, rtol=2e-5)
+
+    gold = golden_cfg1_tfm
+    model = build_model(graph_o32, "Transformer")
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model.eval()
+    with torch.no_grad():
+        out = model(gold["x"])
+    torch.testing.assert_close(out, gold["y"], atol=1e-4, rtol=1e-4)
