@@ -300,12 +300,11 @@ struct EdgeFoldParams {
   float scale;
 };
 
-template <typename T, int VEC, int LPH, int UP>
+template <typename T, int VEC, int LPH, int UP, int U = 4>
 __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const EdgeFoldParams p,
                                                                    const float* __restrict__ attr_,
                                                                    const int32_t* __restrict__ rowptr_,
                                                                    const int32_t* __restrict__ col_) {
-  constexpr int U = 4;
   using Raw = typename RawVec<T, VEC>::type;
   constexpr int UV = 16 / sizeof(T);  // elements per 16-byte load of u
   const int lane = threadIdx.x & 63;
@@ -637,9 +636,17 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_pipe_kernel(cons
 template <typename T, int VEC, int LPH, int UP>
 static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   constexpr int WPB = 4;
+  static const int edges_in_flight = [] {  // tuning knobs (A/B): ANEMOI_AMD_EDGE_U in {2,4,8}, ANEMOI_AMD_EDGE_WGS per CU
+    const char* e = getenv("ANEMOI_AMD_EDGE_U");
+    return e ? atoi(e) : 4;
+  }();
+  static const int wgs_per_cu = [] {
+    const char* e = getenv("ANEMOI_AMD_EDGE_WGS");
+    return e ? atoi(e) : 5;
+  }();
   const int64_t units_per_xcd = ((p.n_dst + 7) / 8) * p.n_slices;
   int64_t bpx = (units_per_xcd + WPB - 1) / WPB;
-  if (bpx > 32 * 5) bpx = 32 * 5;  // up to 5 resident workgroups (20 waves) per CU, 32 CUs per XCD
+  if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;  // resident workgroups per CU x 32 CUs per XCD
   if (bpx < 1) bpx = 1;
   while ((bpx * WPB) % p.n_slices != 0) ++bpx;
   // A/B switch: ANEMOI_AMD_EDGE_PIPE=1 selects the software-pipelined variant.  Measured on MI355X (N320/ico-6,
@@ -652,8 +659,14 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   if (pipelined)
     hipLaunchKernelGGL((gt_edge_attention_folded_pipe_kernel<T, VEC, LPH, UP>), dim3((unsigned)(8 * bpx)),
                        dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
+  else if (edges_in_flight == 8)
+    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 8>), dim3((unsigned)(8 * bpx)),
+                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
+  else if (edges_in_flight == 2)
+    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 2>), dim3((unsigned)(8 * bpx)),
+                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
   else
-    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP>), dim3((unsigned)(8 * bpx)),
+    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 4>), dim3((unsigned)(8 * bpx)),
                        dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
 }
 

@@ -239,6 +239,25 @@ __device__ __forceinline__ uint32_t bf16x2_add(uint32_t a, uint32_t b) {
   return pack_bf16x2(lo, hi);
 }
 
+// Tile order inside an XCD chunk: column groups of SUPER_N tile columns, row-major inside a group, so that the 32
+// tiles an XCD works on concurrently form a 4 x 8 patch of the output (4 x panels + 8 W panels shared in that XCD's
+// L2: 12 unique operand panels for 32 tiles) instead of 2 x 16 (18 panels).  Measured L2 read-miss rate 31 % -> see
+// DESIGN.md; the global->LDS stream runs at ~48 GB/s/CU out of the Infinity Cache but ~83 GB/s/CU out of L2.
+constexpr int SUPER_N = 8;
+__device__ __forceinline__ void tile_coords(int64_t t, int nt_count, int64_t mt_count, int64_t& mt, int& nt) {
+  const int full = nt_count / SUPER_N, rem = nt_count % SUPER_N;
+  const int64_t per_group = mt_count * SUPER_N;
+  if (t < full * per_group) {
+    const int64_t cg = t / per_group, r = t % per_group;
+    mt = r / SUPER_N;
+    nt = (int)(cg * SUPER_N + r % SUPER_N);
+  } else {
+    const int64_t r = t - full * per_group;
+    mt = r / rem;
+    nt = (int)(full * SUPER_N + r % rem);
+  }
+}
+
 // unaligned / ragged-N tail of one 8-column output segment (cold path, kept out of line)
 __device__ __noinline__ void store_row_tail(uint4 v, const bf16_t* __restrict__ R, int64_t ldr, bf16_t* __restrict__ Y,
                                             int64_t ldy, int64_t m, int n, int N) {
@@ -282,8 +301,11 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
   const char* xg[4];
   const char* wg[4];
   auto setup = [&](int64_t tile) {
-    const int64_t m0 = (tile / nt_count) * BIG_M;
-    const int n0 = (int)(tile % nt_count) * BIG_N;
+    int64_t mt_;
+    int nt_;
+    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+    const int64_t m0 = mt_ * BIG_M;
+    const int n0 = nt_ * BIG_N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = r_first + 8 * i;
@@ -318,8 +340,11 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
   for (int64_t li = bix; li < chunk_len; li += bpx) {
     const int64_t tile = chunk_start + li;
     const bool has_next = li + bpx < chunk_len;
-    const int64_t m0 = (tile / nt_count) * BIG_M;
-    const int n0 = (int)(tile % nt_count) * BIG_N;
+    int64_t mt_;
+    int nt_;
+    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+    const int64_t m0 = mt_ * BIG_M;
+    const int n0 = nt_ * BIG_N;
 
     f32x4_t acc[4][8];
 #pragma unroll
@@ -464,8 +489,11 @@ __global__ __launch_bounds__(512) void linear_bf16_256x4_kernel(const bf16_t* __
   int issue_h = 0;
   int issued = 0;  // half-slabs issued so far (stage = issued & 3)
   auto setup = [&](int64_t tile) {
-    const int64_t m0 = (tile / nt_count) * BIG_M;
-    const int n0 = (int)(tile % nt_count) * BIG_N;
+    int64_t mt_;
+    int nt_;
+    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+    const int64_t m0 = mt_ * BIG_M;
+    const int n0 = nt_ * BIG_N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = (wid * 2 + i) * 16 + srow;
@@ -508,8 +536,11 @@ __global__ __launch_bounds__(512) void linear_bf16_256x4_kernel(const bf16_t* __
   int g = 0;  // half-slabs consumed so far
   for (int64_t li = bix; li < chunk_len; li += bpx) {
     const int64_t tile = chunk_start + li;
-    const int64_t m0 = (tile / nt_count) * BIG_M;
-    const int n0 = (int)(tile % nt_count) * BIG_N;
+    int64_t mt_;
+    int nt_;
+    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+    const int64_t m0 = mt_ * BIG_M;
+    const int n0 = nt_ * BIG_N;
 
     f32x4_t acc[4][8];
 #pragma unroll

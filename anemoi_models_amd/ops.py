@@ -116,7 +116,9 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
         out = torch.empty((x.shape[0], n), dtype=out_dtype or x.dtype, device=x.device)
     if act not in _lib.ACT_CODES:
         raise RuntimeError(f"activation {act} is not supported by the fused Linear kernel")
-    with _Timed("linear", flops=2 * x.shape[0] * n * k, m=x.shape[0], n=n, k=k):
+    alg = (x.shape[0] * k + n * k) * x.element_size() + x.shape[0] * n * (out.element_size() + (
+        0 if residual is None else residual.element_size()))
+    with _Timed("linear", flops=2 * x.shape[0] * n * k, bytes=alg, m=x.shape[0], n=n, k=k):
         st = _lib.load().anemoi_linear(
             dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
             _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)),

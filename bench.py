@@ -126,7 +126,8 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False):
             "kernel": "anemoi::linear_kernel (fused Linear, MFMA)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
             "launches": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
-            "flops_per_launch": a["flops"] / a["launches"], "share_of_step": None,
+            "flops_per_launch": a["flops"] / a["launches"], "bytes_per_launch": a["bytes"] / a["launches"],
+            "share_of_step": None,
         }
     if "gt_edge_attention" in agg and agg["gt_edge_attention"]["ms"] > 0:
         a = agg["gt_edge_attention"]
@@ -137,6 +138,19 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "bytes_per_launch": a["bytes"] / a["launches"],
         }
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (PMC counters cannot be
+    # collected from inside the process; see profiles/r01_traffic.json for the command and the gfx950 corrections)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic = json.load(f)["kernels"]
+        if "roofline" in out and dtype_name == "bf16":
+            out["roofline"]["traffic"] = traffic["linear"]["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        if "roofline_edge" in out and dtype_name == "bf16":
+            out["roofline_edge"]["traffic"] = traffic["gt_edge_attention"]["traffic_bytes_per_launch"]
+            out["roofline_edge"]["traffic_source"] = "profiles/r01_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
     total_ms = sum(a["ms"] for a in agg.values())
     out["kernel_time_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     if "roofline" in out and total_ms > 0:
