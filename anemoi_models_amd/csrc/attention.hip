@@ -135,43 +135,52 @@ __global__ __launch_bounds__(256) void mhsa_bf16_d64_kernel(const bf16_t* __rest
             *reinterpret_cast<const abf16x8_t*>(ks_ + krow * 128 + (aswz(krow, ks * 2 + half) << 4));
         s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc, 0, 0, 0);
       }
-      // ---- online softmax in the log2 domain; register r <-> key kbase_ + (r & 7) + 16 (r >> 3)
+      // ---- online softmax in the log2 domain; register r <-> key key0 + (r & 7) + 16 (r >> 3).
+      //      VALU budget per element: max, fma, exp2, add (the scale rides in the fma); masking only on tiles that
+      //      touch the sequence end / window edge (wave-uniform test); O is rescaled only when the max grew.
       const int key0 = kt * ATT_KV + kb * 32 + 8 * half;
-      float t[16];
-      float mloc = -INFINITY;
+      const int blk0 = kt * ATT_KV + kb * 32;  // first key of this 32-key block
+      bool need_mask = blk0 + 32 > S;
+      if (window >= 0) need_mask = need_mask || (blk0 + 31 - q0 > window) || (q0 + 31 - blk0 > window);
+      if (need_mask) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key0 + (r & 7) + 16 * (r >> 3);
-        bool ok = key < S;
-        if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
-        t[r] = ok ? s_acc[r] * scale_log2e : -INFINITY;
-        mloc = fmaxf(mloc, t[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + (r & 7) + 16 * (r >> 3);
+          bool ok = key < S;
+          if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
+          s_acc[r] = ok ? s_acc[r] : -INFINITY;
+        }
       }
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float m_new = fmaxf(m_run, mloc);
-      const float m_use = m_new == -INFINITY ? 0.f : m_new;  // fully masked so far: exp2(-inf - 0) = 0
-      const float corr = exp2f(m_run - m_use);               // m_run = -inf -> 0
-      l_run *= corr;
+      float mloc = s_acc[0];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s_acc[r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
+      if (mloc > m_run) {  // (lane-divergent only in the rescale; -inf > -inf is false)
+        const float corr = __builtin_amdgcn_exp2f(m_run - mloc);  // m_run = -inf -> 0
+        l_run *= corr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[dt][r] *= corr;
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o_acc[dt][r] *= corr;
+        m_run = mloc;
+      }
+      const float m_neg = m_run == -INFINITY ? 0.f : -m_run;  // fully masked so far: exp2(-inf) = 0 below
       float p[16];
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = exp2f(t[r] - m_use);
+        p[r] = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, m_neg));  // bare v_exp_f32: argument <= 0
         psum += p[r];
       }
       l_run += psum;
-      m_run = m_new;
-      // ---- P^T fragments: registers 0..7 / 8..15 are 8 contiguous keys each
+      // ---- P^T fragments: registers 0..7 / 8..15 are 8 contiguous keys each (v_cvt_pk_bf16_f32: 2 values / instr)
       abf16x8_t pb[2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(p[kk * 8 + 2 * i], p[kk * 8 + 2 * i + 1]);
+        for (int i = 0; i < 4; ++i)
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
         pb[kk] = *reinterpret_cast<abf16x8_t*>(w);
       }
       // ---- O^T += V^T P^T

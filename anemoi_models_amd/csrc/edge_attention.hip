@@ -114,7 +114,10 @@ struct QK<bf16_t, VEC> {
 };
 
 template <typename T, int VEC, int LPH, int EDP>
-__global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnParams p) {
+__global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnParams p,
+                                                                const float* __restrict__ attr_,
+                                                                const int32_t* __restrict__ rowptr_,
+                                                                const int32_t* __restrict__ col_) {
   constexpr int U = 4;          // edges in flight per wave: 2*U independent 16-byte gathers per lane
   constexpr int NQ = (VEC + 3) / 4;  // 16-byte LDS reads per lane per attribute row
   constexpr int QW = VEC < 4 ? VEC : 4;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnPa
   const T* vb = static_cast<const T*>(p.v) + c0;
 
   for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
-    const int e_begin = p.rowptr[node], e_end = p.rowptr[node + 1];
+    const int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
     QK<T, VEC> qk;
     float u[EDP + 1];
     // The LDS image of W_e is loop invariant; without these opaque offsets the compiler hoists all
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnPa
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
         if (e + uu < e_end) {
-          const int64_t j = p.col[e + uu];
+          const int64_t j = col_[e + uu];
           kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
           vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
         }
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnPa
       for (int uu = 0; uu < U; ++uu) {
         s[uu] = -INFINITY;
         if (e + uu < e_end) {
-          const float* at = p.attr + (int64_t)(e + uu) * p.ea_ld;
+          const float* at = attr_ + (int64_t)(e + uu) * p.ea_ld;
           float t = u[EDP];
 #pragma unroll
           for (int a = 0; a < EDP; ++a) t = fmaf(u[a], at[a], t);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnPa
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
         if (e + uu < e_end) {
-          const float* at = p.attr + (int64_t)(e + uu) * p.ea_ld;
+          const float* at = attr_ + (int64_t)(e + uu) * p.ea_ld;
           const float pe = __expf(s[uu] - mb);
           l += pe;
           float vv[VEC];
@@ -774,7 +777,7 @@ static bool launch_fast(const EdgeAttnParams& p, hipStream_t st) {
   if (bpx > cap) bpx = cap;
   if (bpx < 1) bpx = 1;
   while ((bpx * WPB) % p.n_slices != 0) ++bpx;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * bpx)), dim3(64 * WPB), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * bpx)), dim3(64 * WPB), lds, st, p, p.attr, p.rowptr, p.col);
   return true;
 }
 
