@@ -239,11 +239,11 @@ __device__ __forceinline__ uint32_t bf16x2_add(uint32_t a, uint32_t b) {
   return pack_bf16x2(lo, hi);
 }
 
-// Tile order inside an XCD chunk: column groups of SUPER_N tile columns, row-major inside a group, so that the 32
-// tiles an XCD works on concurrently form a 4 x 8 patch of the output (4 x panels + 8 W panels shared in that XCD's
-// L2: 12 unique operand panels for 32 tiles) instead of 2 x 16 (18 panels).  Measured L2 read-miss rate 31 % -> see
-// DESIGN.md; the global->LDS stream runs at ~48 GB/s/CU out of the Infinity Cache but ~83 GB/s/CU out of L2.
-constexpr int SUPER_N = 8;
+// Tile order inside an XCD chunk: column groups of SUPER_N tile columns, row-major inside a group.  SUPER_N = 8 would
+// make the 32 tiles an XCD works on concurrently a 4 x 8 patch of the output (12 unique operand panels in that XCD's
+// L2 instead of 18 for 2 x 16).  Measured on MI355X: no gain (-3 %) over the plain row-major order, so the group
+// width is "unbounded" (= plain order); kept as a documented experiment.
+constexpr int SUPER_N = 1 << 20;
 __device__ __forceinline__ void tile_coords(int64_t t, int nt_count, int64_t mt_count, int64_t& mt, int& nt) {
   const int full = nt_count / SUPER_N, rem = nt_count % SUPER_N;
   const int64_t per_group = mt_count * SUPER_N;
