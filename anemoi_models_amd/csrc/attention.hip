@@ -55,8 +55,13 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 // bf16 / D = 64 MFMA kernel: 4 waves x 32 queries per workgroup, 64-key tiles
 // ---------------------------------------------------------------------------------------------
 constexpr int ATT_D = 64, ATT_KV = 64, ATT_TILE = ATT_KV * 128;  // 8 KiB per operand per stage
+constexpr int ATT_WAVES = 8, ATT_QPW = 64, ATT_QBLK = ATT_WAVES * ATT_QPW;  // 512 queries per workgroup
 
-__global__ __launch_bounds__(256) void mhsa_bf16_d64_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+// Every workgroup streams ALL keys / values of its (batch, head) through LDS, so the L2 -> LDS traffic of a layer is
+// (S / ATT_QBLK) * H * S * 256 bytes: with 128 queries per workgroup that was 54 GB per layer at S = 40 962 (the kernel
+// ran at the L2 rate, not the MFMA rate); 512 queries per workgroup and two 32-query blocks per wave (K / V^T
+// fragments read from LDS once, used by two MFMAs) cut it 4x and halve the LDS -> register traffic per MFMA.
+__global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                             const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                             int64_t ldo, int S, int S_pad, int H, int C, int window,
                                                             float scale_log2e) {
@@ -64,53 +69,53 @@ __global__ __launch_bounds__(256) void mhsa_bf16_d64_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int qw0 = blockIdx.x * ATT_QBLK + wid * ATT_QPW;  // first query of this wave
   const int half = lane >> 5, ql = lane & 31;
-  const int q = q0 + ql;                     // this lane's query (may be >= S in the last block)
-  const int qc = q < S ? q : S - 1;
 
-  // ---- Q^T fragments (B operand): Q[q][ks*16 + half*8 .. +8]
-  abf16x8_t qf[4];
-  {
+  // ---- Q^T fragments (B operand) of the wave's two 32-query blocks: Q[q][ks*16 + half*8 .. +8]
+  abf16x8_t qf[2][4];
+  int qn[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qn[qb] = qw0 + qb * 32 + ql;
+    const int qc = qn[qb] < S ? qn[qb] : S - 1;
     const bf16_t* qp = qkv + ((int64_t)b * S + qc) * ld + h * ATT_D + half * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
   }
 
-  // ---- key range of this workgroup (sliding window: only tiles that intersect any of its 128 queries)
+  // ---- key range of this workgroup (sliding window: only tiles that intersect any of its queries)
   int kt_begin = 0, kt_end = (S + ATT_KV - 1) / ATT_KV;
   if (window >= 0) {
-    const int lo = (int)blockIdx.x * 128 - window, hi = (int)blockIdx.x * 128 + 127 + window;
+    const int lo = (int)blockIdx.x * ATT_QBLK - window, hi = (int)blockIdx.x * ATT_QBLK + ATT_QBLK - 1 + window;
     kt_begin = lo > 0 ? lo / ATT_KV : 0;
     const int e = hi / ATT_KV + 1;
     kt_end = e < kt_end ? e : kt_end;
   }
 
-  // ---- staging: K tile rows = keys, V^T tile rows = d; 8 row groups (8 rows x 128 B) each, 2 + 2 per wave
+  // ---- staging: K tile rows = keys, V^T tile rows = d; 8 row groups (8 rows x 128 B) each: wave w moves group w
   const int srow = lane >> 3, scp = lane & 7;
   const bf16_t* kbase = qkv + (int64_t)b * S * ld + C + h * ATT_D;
   const bf16_t* vbase = vt + ((int64_t)b * H + h) * ATT_D * S_pad;
+  const int sr = wid * 8 + srow;          // tile row staged by this lane
+  const int sc = aswz(sr, scp);           // source chunk landing at LDS position scp
   auto stage = [&](int kt, int buf) {
     char* ks_ = smem + buf * 2 * ATT_TILE;
     char* vs_ = ks_ + ATT_TILE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wid * 2 + i) * 8 + srow;
-      const int c = aswz(r, scp);
-      int key = kt * ATT_KV + r;
-      if (key > S - 1) key = S - 1;
-      aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + c * 16, ks_ + (wid * 2 + i) * 1024);
-      aglds16(reinterpret_cast<const char*>(vbase + (int64_t)r * S_pad + kt * ATT_KV) + c * 16,
-              vs_ + (wid * 2 + i) * 1024);
-    }
+    int key = kt * ATT_KV + sr;
+    if (key > S - 1) key = S - 1;
+    aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + sc * 16, ks_ + wid * 1024);
+    aglds16(reinterpret_cast<const char*>(vbase + (int64_t)sr * S_pad + kt * ATT_KV) + sc * 16, vs_ + wid * 1024);
   };
 
-  af32x16_t o_acc[2];
+  af32x16_t o_acc[2][2];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qb][dt][r] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
   // K row of MFMA row i: index bits 2 and 3 swapped
   const int kperm = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
@@ -124,66 +129,72 @@ __global__ __launch_bounds__(256) void mhsa_bf16_d64_kernel(const bf16_t* __rest
     const char* vs_ = ks_ + ATT_TILE;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      // ---- S^T block: 32 keys x 32 queries
-      af32x16_t s_acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+      // ---- K fragments of this 32-key block, shared by both query blocks
       const int krow = kb * 32 + kperm;
+      abf16x8_t kf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const abf16x8_t kf =
-            *reinterpret_cast<const abf16x8_t*>(ks_ + krow * 128 + (aswz(krow, ks * 2 + half) << 4));
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc, 0, 0, 0);
-      }
-      // ---- online softmax in the log2 domain; register r <-> key key0 + (r & 7) + 16 (r >> 3).
-      //      VALU budget per element: max, fma, exp2, add (the scale rides in the fma); masking only on tiles that
-      //      touch the sequence end / window edge (wave-uniform test); O is rescaled only when the max grew.
+      for (int ks = 0; ks < 4; ++ks)
+        kf[ks] = *reinterpret_cast<const abf16x8_t*>(ks_ + krow * 128 + (aswz(krow, ks * 2 + half) << 4));
       const int key0 = kt * ATT_KV + kb * 32 + 8 * half;
       const int blk0 = kt * ATT_KV + kb * 32;  // first key of this 32-key block
-      bool need_mask = blk0 + 32 > S;
-      if (window >= 0) need_mask = need_mask || (blk0 + 31 - q0 > window) || (q0 + 31 - blk0 > window);
-      if (need_mask) {
+      abf16x8_t pb[2][2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        // ---- S^T block: 32 keys x 32 queries (interleaving the two blocks' MFMA chains was measured 4 % slower)
+        af32x16_t s_acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[qb][ks], s_acc, 0, 0, 0);
+        // ---- online softmax in the log2 domain; register r <-> key key0 + (r & 7) + 16 (r >> 3).
+        //      VALU budget per element: max, fma, exp2, add (the scale rides in the fma); masking only on tiles that
+        //      touch the sequence end / window edge (wave-uniform test); O is rescaled only when the max grew.
+        const int qfirst = qw0 + qb * 32;
+        bool need_mask = blk0 + 32 > S;
+        if (window >= 0) need_mask = need_mask || (blk0 + 31 - qfirst > window) || (qfirst + 31 - blk0 > window);
+        if (need_mask) {
+          const int q = qn[qb];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 7) + 16 * (r >> 3);
+            bool ok = key < S;
+            if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
+            s_acc[r] = ok ? s_acc[r] : -INFINITY;
+          }
+        }
+        float mloc = s_acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s_acc[r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
+        if (mloc > m_run[qb]) {  // (-inf > -inf is false)
+          const float corr = __builtin_amdgcn_exp2f(m_run[qb] - mloc);  // m_run = -inf -> 0
+          l_run[qb] *= corr;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[qb][dt][r] *= corr;
+          m_run[qb] = mloc;
+        }
+        const float m_neg = m_run[qb] == -INFINITY ? 0.f : -m_run[qb];  // fully masked so far: exp2(-inf) = 0 below
+        float p[16];
+        float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = key0 + (r & 7) + 16 * (r >> 3);
-          bool ok = key < S;
-          if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
-          s_acc[r] = ok ? s_acc[r] : -INFINITY;
+          p[r] = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, m_neg));  // bare v_exp_f32: argument <= 0
+          psum += p[r];
+        }
+        l_run[qb] += psum;
+        // ---- P^T fragments: registers 0..7 / 8..15 are 8 contiguous keys each (v_cvt_pk_bf16_f32: 2 values / instr)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          uint32_t w[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
+          pb[qb][kk] = *reinterpret_cast<abf16x8_t*>(w);
         }
       }
-      float mloc = s_acc[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s_acc[r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
-      if (mloc > m_run) {  // (lane-divergent only in the rescale; -inf > -inf is false)
-        const float corr = __builtin_amdgcn_exp2f(m_run - mloc);  // m_run = -inf -> 0
-        l_run *= corr;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o_acc[dt][r] *= corr;
-        m_run = mloc;
-      }
-      const float m_neg = m_run == -INFINITY ? 0.f : -m_run;  // fully masked so far: exp2(-inf) = 0 below
-      float p[16];
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, m_neg));  // bare v_exp_f32: argument <= 0
-        psum += p[r];
-      }
-      l_run += psum;
-      // ---- P^T fragments: registers 0..7 / 8..15 are 8 contiguous keys each (v_cvt_pk_bf16_f32: 2 values / instr)
-      abf16x8_t pb[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
-        pb[kk] = *reinterpret_cast<abf16x8_t*>(w);
-      }
-      // ---- O^T += V^T P^T
+      // ---- O^T += V^T P^T : each V^T fragment feeds both query blocks
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const int vrow = dt * 32 + ql;
@@ -191,25 +202,30 @@ __global__ __launch_bounds__(256) void mhsa_bf16_d64_kernel(const bf16_t* __rest
         for (int kk = 0; kk < 2; ++kk) {
           const abf16x8_t vf = *reinterpret_cast<const abf16x8_t*>(
               vs_ + vrow * 128 + (aswz(vrow, kb * 4 + kk * 2 + half) << 4));
-          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kk], o_acc[dt], 0, 0, 0);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            o_acc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[qb][kk], o_acc[qb][dt], 0, 0, 0);
         }
       }
     }
   }
 
   // ---- normalise and store: lane holds O[q][dt*32 + (r & 3) + 8 (r >> 2) + 4 half]
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q < S) {
-    bf16_t* op = out + ((int64_t)b * S + q) * ldo + h * ATT_D;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qn[qb] < S) {
+      bf16_t* op = out + ((int64_t)b * S + qn[qb]) * ldo + h * ATT_D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float v4[4] = {o_acc[dt][4 * g] * inv, o_acc[dt][4 * g + 1] * inv, o_acc[dt][4 * g + 2] * inv,
-                             o_acc[dt][4 * g + 3] * inv};
-        VecIO<bf16_t, 4>::store(op + dt * 32 + 8 * g + 4 * half, v4);
-      }
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v4[4] = {o_acc[qb][dt][4 * g] * inv, o_acc[qb][dt][4 * g + 1] * inv,
+                               o_acc[qb][dt][4 * g + 2] * inv, o_acc[qb][dt][4 * g + 3] * inv};
+          VecIO<bf16_t, 4>::store(op + dt * 32 + 8 * g + 4 * half, v4);
+        }
+    }
   }
 }
 
@@ -299,7 +315,7 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
     const int S_pad = (S + 63) / 64 * 64;
     hipLaunchKernelGGL(transpose_v_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, st,
                        static_cast<const bf16_t*>(qkv), ld, S, S_pad, H, D, C, static_cast<bf16_t*>(workspace));
-    hipLaunchKernelGGL(mhsa_bf16_d64_kernel, dim3((S + 127) / 128, H, B), dim3(256), 0, st,
+    hipLaunchKernelGGL(mhsa_bf16_d64_kernel, dim3((S + ATT_QBLK - 1) / ATT_QBLK, H, B), dim3(64 * ATT_WAVES), 0, st,
                        static_cast<const bf16_t*>(qkv), ld, static_cast<const bf16_t*>(workspace),
                        static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window, scale * 1.44269504088896340736f);
     return check_launch("anemoi_mhsa(bf16, D=64)");
