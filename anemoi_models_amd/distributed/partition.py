@@ -31,12 +31,12 @@ from ..runtime import EdgePlan
 from .shapes import split_bounds
 
 
-def _alltoallv(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int], group) -> None:
-    """Row-wise all-to-all-v.  RCCL path: one ``all_to_all_single``; other backends (gloo in CPU tests): P2P pairs."""
+def _alltoallv(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int], group, async_op: bool = False):
+    """Row-wise all-to-all-v.  RCCL path: one ``all_to_all_single`` (optionally asynchronous: it runs on RCCL's stream
+    and the returned work handle is waited for right before the consumer); other backends (gloo in CPU tests): P2P."""
     backend = dist.get_backend(group)
     if backend == "nccl":
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
-        return
+        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     outs = list(out.split(out_splits, dim=0))
@@ -68,10 +68,24 @@ class HaloExchange:
     def n_recv(self) -> int:
         return sum(self.recv_splits)
 
-    def exchange(self, rows: Tensor, n_own: int) -> None:
-        """``rows[n_own : n_own + n_recv] <-`` the rows this rank's halo needs; ``rows[:n_own]`` are its own rows."""
+    def start(self, rows: Tensor, n_own: int):
+        """Begin ``rows[n_own : n_own + n_recv] <-`` the rows this rank's halo needs (``rows[:n_own]`` are its own).
+
+        Returns a handle for :meth:`finish`; between the two the caller may launch work that does not touch the halo
+        rows (the x_r | q | u GEMM), which overlaps with the xGMI transfer."""
         send = rows[:n_own].index_select(0, self.send_idx)
-        _alltoallv(rows[n_own:n_own + self.n_recv], send, self.recv_splits, self.send_splits, self.group)
+        work = _alltoallv(rows[n_own:n_own + self.n_recv], send, self.recv_splits, self.send_splits, self.group,
+                          async_op=True)
+        return (work, send)  # keep the send buffer alive until the transfer has been waited for
+
+    @staticmethod
+    def finish(handle) -> None:
+        work = handle[0]
+        if work is not None:
+            work.wait()  # the current stream waits for RCCL's stream; the host does not block
+
+    def exchange(self, rows: Tensor, n_own: int) -> None:
+        self.finish(self.start(rows, n_own))
 
 
 @dataclass

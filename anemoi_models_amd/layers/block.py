@@ -233,9 +233,10 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             w_kv, b_kv = self._cat_linear("kv", [self.lin_key, self.lin_value], dtype)
             kv = torch.empty((n_own + halo.n_recv, 2 * c), dtype=dtype, device=x.device)
             ops.linear(xh, w_kv, b_kv, out=kv[:n_own])
-            halo.exchange(kv, n_own)
+            pending = halo.start(kv, n_own)  # xGMI transfer of the halo k|v rows ...
             w_squ, b_squ, wpf, bp = self._folded_linears("squ", [self.lin_self, self.lin_query], dtype, up)
-            sq = ops.linear(xh, w_squ, b_squ)  # [n_own, 2C + H*up] = x_r | q | u
+            sq = ops.linear(xh, w_squ, b_squ)  # ... overlapped with the x_r | q | u GEMM
+            halo.finish(pending)
             att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
                                                edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
                                                ld_out=wpf.shape[1])
@@ -320,7 +321,7 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
             n_own = x_src.shape[0]
             kv = torch.empty((n_own + halo.n_recv, 2 * c), dtype=dtype, device=x_src.device)
             ops.linear(xs, w_kv, b_kv, out=kv[:n_own])
-            halo.exchange(kv, n_own)
+            pending = halo.start(kv, n_own)  # overlapped with the destination-side LayerNorm + GEMM below
         del xs
         xd = ops.layer_norm(x_dst, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
         up = self.fold_width(dtype)
@@ -328,10 +329,14 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
             w_squ, b_squ, wp, bp = self._folded_linears("squ", [self.lin_self, self.lin_query], dtype, up)
             sq = ops.linear(xd, w_squ, b_squ)  # [N_dst, 2C + H*up] = x_r | q | u
             del xd
+            if halo is not None:
+                halo.finish(pending)
             att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
                                                edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
                                                ld_out=wp.shape[1])
         else:
+            if halo is not None:
+                raise NotImplementedError("node-partitioned blocks need the folded edge kernel")
             w_sq, b_sq = self._cat_linear("sq", [self.lin_self, self.lin_query], dtype)
             wp, bp = self._cat_linear("proj", [self.projection], dtype)
             we, be = self._edge_params()
