@@ -89,10 +89,58 @@ class HaloExchange:
 
 
 @dataclass
+class HeadExchange:
+    """rows <-> heads all-to-all around global attention (the reference's Ulysses scheme, distributed/transformer.py):
+    rank ``r`` owns ``rows[r]`` mesh rows everywhere else and heads ``tensor_split(H, P)[r]`` inside the attention."""
+
+    rows: List[int]  # mesh rows owned by every rank
+    rank: int
+    group: object
+
+    def _head_bounds(self, num_heads: int) -> List[int]:
+        return split_bounds(num_heads, len(self.rows))
+
+    def local_heads(self, num_heads: int) -> int:
+        b = self._head_bounds(num_heads)
+        return b[self.rank + 1] - b[self.rank]
+
+    def rows_to_heads(self, qkv: Tensor, num_heads: int) -> Tensor:
+        """``[n_own, 3C]`` (q|k|v, all heads) -> ``[S, 3 * C_local]`` (q|k|v of this rank's heads, all rows)."""
+        n_own, c3 = qkv.shape
+        d = c3 // 3 // num_heads
+        hb = self._head_bounds(num_heads)
+        h_loc = hb[self.rank + 1] - hb[self.rank]
+        if h_loc == 0:
+            raise NotImplementedError("more ranks than attention heads")
+        q4 = qkv.view(n_own, 3, num_heads, d)
+        send = torch.cat([q4[:, :, hb[p]:hb[p + 1], :].reshape(-1) for p in range(len(self.rows))])
+        in_splits = [n_own * 3 * (hb[p + 1] - hb[p]) * d for p in range(len(self.rows))]
+        out_splits = [r * 3 * h_loc * d for r in self.rows]
+        recv = torch.empty(sum(out_splits), dtype=qkv.dtype, device=qkv.device)
+        _alltoallv(recv, send, out_splits, in_splits, self.group)
+        return recv.view(sum(self.rows), 3 * h_loc * d)  # rows of all ranks in rank order, each [3, h_loc, d]
+
+    def heads_to_rows(self, att: Tensor, num_heads: int) -> Tensor:
+        """``[S, C_local]`` -> ``[n_own, C]``."""
+        s_len, c_loc = att.shape
+        hb = self._head_bounds(num_heads)
+        h_loc = hb[self.rank + 1] - hb[self.rank]
+        d = c_loc // h_loc
+        n_own = self.rows[self.rank]
+        in_splits = [r * c_loc for r in self.rows]
+        out_splits = [n_own * (hb[p + 1] - hb[p]) * d for p in range(len(self.rows))]
+        recv = torch.empty(sum(out_splits), dtype=att.dtype, device=att.device)
+        _alltoallv(recv, att.reshape(-1), out_splits, in_splits, self.group)
+        parts = [blk.view(n_own, hb[p + 1] - hb[p], d) for p, blk in enumerate(recv.split(out_splits))]
+        return torch.cat(parts, dim=1).reshape(n_own, num_heads * d)
+
+
+@dataclass
 class LocalGraph:
     plan: EdgePlan  # CSR over LOCAL indices; plan.perm holds ORIGINAL edge ids (for the attribute gather)
     n_own_src: int  # leading source rows that are this rank's own (the rest is halo)
     halo: Optional[HaloExchange]
+    heads: Optional[HeadExchange] = None
 
 
 def _owner(ids: Tensor, bounds: Tensor) -> Tensor:
@@ -159,8 +207,13 @@ def build_shard_plan(model, group, device) -> ShardPlan:
     enc = LocalGraph(_local_graph(torch.searchsorted(enc_src_ids, src), dst_int[e_ids] - lo, e_ids,
                                   int(enc_src_ids.numel()), n_own), int(enc_src_ids.numel()), None)
 
-    # ---- processor: mesh -> mesh
-    ei = model.processor.edge_index_base
+    # ---- processor: mesh -> mesh (the Transformer processor has no edges: rows <-> heads exchange instead)
+    heads = HeadExchange([bounds[p + 1] - bounds[p] for p in range(world)], rank, group)
+    if not hasattr(model.processor, "edge_index_base"):
+        proc = LocalGraph(None, n_own, None, heads)
+    ei = getattr(model.processor, "edge_index_base", None)
+    if ei is None:
+        ei = torch.zeros((2, 0), dtype=torch.int64, device=device)
     src_int, dst_int = inv[ei[0]], inv[ei[1]]
     dst_owner = _owner(dst_int, bt)
     halo_ids, halo = _halo_lists(src_int, lambda p: dst_owner == p, bounds, rank, world, group)
@@ -168,8 +221,9 @@ def build_shard_plan(model, group, device) -> ShardPlan:
     s = src_int[e_ids]
     own = (s >= lo) & (s < hi)
     s_local = torch.where(own, s - lo, n_own + torch.searchsorted(halo_ids, s))
-    proc = LocalGraph(_local_graph(s_local, dst_int[e_ids] - lo, e_ids, n_own + int(halo_ids.numel()), n_own), n_own,
-                      halo)
+    if hasattr(model.processor, "edge_index_base"):
+        proc = LocalGraph(_local_graph(s_local, dst_int[e_ids] - lo, e_ids, n_own + int(halo_ids.numel()), n_own),
+                          n_own, halo, heads)
 
     # ---- decoder: mesh -> grid; a grid node goes to the owner of its first mesh source
     ei = model.decoder.edge_index_base

@@ -404,8 +404,11 @@ class GraphConvBaseBlock(BaseBlock, ABC):
 class GraphConvProcessorBlock(GraphConvBaseBlock):
     """Edge-MLP message passing on one node set (reference layers/block.py:170-223, layers/conv.py:27-76)."""
 
-    def native(self, x: Tensor, e_csr: Tensor, plan: EdgePlan):
-        """x ``[N, C]``, edge state ``[E, C]`` in CSR (destination-sorted) order -> (new nodes, new edge state)."""
+    def native(self, x: Tensor, e_csr: Tensor, plan: EdgePlan, halo=None):
+        """x ``[N, C]``, edge state ``[E, C]`` in CSR (destination-sorted) order -> (new nodes, new edge state).
+
+        ``halo`` (node-partitioned run): ``x`` holds this rank's rows; the ``W1b x`` rows of halo sources are fetched
+        from their owners by one all-to-all-v (C values per halo node) while the edge-side GEMM runs."""
         dtype = x.dtype
         c = x.shape[1]
         edge_mlp, node_mlp = self.conv.edge_mlp.native(), self.node_mlp.native()
@@ -418,11 +421,23 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
                                    lambda: runtime.pack_weight([lin1.weight[:, :c], lin1.weight[:, c:2 * c]], dtype))
         w_edges = self._packed.get(("w1_edges", dtype), [lin1.weight],
                                    lambda: runtime.pack_weight([lin1.weight[:, 2 * c:]], dtype))
-        p = ops.linear(x, w_nodes, None)  # [N, 2C] = W1a x | W1b x
-        t = ops.linear(e_csr, w_edges, None if lin1.bias is None else runtime.f32c(lin1.bias))
-        h = ops.gather_add_act(t, p[:, :c], p[:, c:], plan.dst, plan.col, act=act1, out=t)
+        b1 = None if lin1.bias is None else runtime.f32c(lin1.bias)
+        if halo is None:
+            p = ops.linear(x, w_nodes, None)  # [N, 2C] = W1a x | W1b x
+            p_dst, p_src = p[:, :c], p[:, c:]
+            t = ops.linear(e_csr, w_edges, b1)
+        else:
+            n_own = x.shape[0]
+            p_src = torch.empty((n_own + halo.n_recv, c), dtype=dtype, device=x.device)
+            ops.linear(x, w_nodes[c:], None, out=p_src[:n_own])  # W1b x of the own rows, halo rows appended below
+            pending = halo.start(p_src, n_own)
+            p_dst = ops.linear(x, w_nodes[:c], None)
+            t = ops.linear(e_csr, w_edges, b1)
+            halo.finish(pending)
+            p = None
+        h = ops.gather_add_act(t, p_dst, p_src, plan.dst, plan.col, act=act1, out=t)
         e_new = edge_mlp(h, residual=e_csr, start=1)  # remaining Linear/act pairs, LayerNorm, "+ e"
-        del h, t, p
+        del h, t, p, p_dst, p_src
         xcat = torch.empty((x.shape[0], 2 * c), dtype=dtype, device=x.device)
         xcat[:, :c].copy_(x)
         ops.segment_sum(e_new, plan.rowptr, out=xcat[:, c:])  # scatter-sum over destinations
@@ -468,13 +483,22 @@ class TransformerProcessorBlock(BaseBlock):
 
         self._mlp: Optional[NativeSequential] = None
 
-    def native(self, x: Tensor, batch_size: int) -> Tensor:
-        """Pre-LN attention residual + pre-LN MLP residual (reference layers/block.py:99-105)."""
+    def native(self, x: Tensor, batch_size: int, head_exchange=None) -> Tensor:
+        """Pre-LN attention residual + pre-LN MLP residual (reference layers/block.py:99-105).
+
+        ``head_exchange`` (node-partitioned run): q|k|v of the own rows go through an all-to-all so that this rank holds
+        ALL rows of its share of the heads, attention runs on those heads, and a second all-to-all brings the own rows
+        of all heads back."""
         ln1, ln2 = self.layer_norm1, self.layer_norm2
         h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
         att = self.attention
         qkv = linear_native(att._packed, "lin_qkv", att.lin_qkv, h)
-        a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window())
+        if head_exchange is not None:
+            qkv_heads = head_exchange.rows_to_heads(qkv, att.num_heads)  # [S, 3 * C_local]
+            a_heads = ops.mhsa(qkv_heads, batch_size, head_exchange.local_heads(att.num_heads), -1)
+            a = head_exchange.heads_to_rows(a_heads, att.num_heads)  # [n_own, C]
+        else:
+            a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window())
         x = linear_native(att._packed, "projection", att.projection, a, residual=x)  # x + attention(...)
         if self._mlp is None:
             self._mlp = NativeSequential(self.mlp)

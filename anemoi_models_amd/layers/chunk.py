@@ -65,12 +65,12 @@ class GNNProcessorChunk(BaseProcessorChunk):
         self.build_blocks(GraphConvProcessorBlock, num_channels, num_channels, mlp_extra_layers=mlp_extra_layers,
                           activation=activation)
 
-    def native(self, x: Tensor, e_csr: Tensor, plan: EdgePlan):
+    def native(self, x: Tensor, e_csr: Tensor, plan: EdgePlan, halo=None):
         """``e_csr``: raw (first chunk) or embedded edge state in CSR order, compute dtype."""
         if self.emb_edges is not None:
             e_csr = self.emb_edges.native()(e_csr)
         for blk in self.blocks:
-            x, e_csr = blk.native(x, e_csr, plan)
+            x, e_csr = blk.native(x, e_csr, plan, halo)
         return x, e_csr
 
     def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):

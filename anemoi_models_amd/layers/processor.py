@@ -79,6 +79,16 @@ class TransformerProcessor(BaseProcessor):
             x = back
         return x
 
+    def native_local(self, x_own: Tensor, local_graph) -> Tensor:
+        """Node-partitioned run: rows stay sharded for LayerNorm / Linear / MLP; around the attention the heads <-> rows
+        all-to-all of the reference (distributed/transformer.py:85-130) gives every rank all rows of H / P heads."""
+        if self.proc[0].blocks[0].attention.attention_window() >= 0:
+            raise NotImplementedError("sliding-window attention is not available in the node-partitioned forward")
+        for chunk in self.proc:
+            for blk in chunk.blocks:
+                x_own = blk.native(x_own, 1, head_exchange=local_graph.heads)
+        return x_own
+
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None, *args, **kwargs) -> Tensor:
         if model_comm_group is not None:
             assert (
@@ -120,9 +130,19 @@ class GNNProcessor(GraphEdgeMixin, BaseProcessor):
             x, e = chunk.native(x, e, plan)
         return x
 
+    def native_local(self, x_own: Tensor, local_graph) -> Tensor:
+        """Node-partitioned run: this rank's mesh rows in / out; the edge state of the edges it owns stays local."""
+        plan = local_graph.plan
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)
+        e = ops.convert_pad(ea[:, : self.edge_dim], x_own.dtype,
+                            ops.round_up(self.edge_dim, ops.k_multiple(x_own.dtype)))
+        for chunk in self.proc:
+            x_own, e = chunk.native(x_own, e, plan, local_graph.halo)
+        return x_own
+
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("GNN processor: node-partitioned execution is not implemented yet")
+            raise NotImplementedError("processor-level model sharding: use the node-partitioned model forward")
         runtime.require_inference(self)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 from conftest import GOLDEN, ROOT
 
 
-def _worker(rank, world, port, result_file):
+def _worker(rank, world, port, result_file, processor="GraphTransformer"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,11 +34,12 @@ def _worker(rank, world, port, result_file):
         for name in ("layer_norm", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
                      "gather_add_act", "segment_sum", "mhsa", "assemble_nodes", "prognostic_residual", "convert_pad", "add"):
             setattr(ops, name, getattr(_cpu_ops, name))
-        with np.load(os.path.join(GOLDEN, "cfg1_gt.npz")) as z:
+        fname = {"GraphTransformer": "cfg1_gt.npz", "GNN": "cfg1_gnn.npz", "Transformer": "cfg1_tfm.npz"}[processor]
+        with np.load(os.path.join(GOLDEN, fname)) as z:
             gold = {k: torch.from_numpy(z[k]) for k in z.files}
         graph = build_graph("o32_ico2")
         idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
-        model = AnemoiModelEncProcDec(model_config=model_config("GraphTransformer", 64, 4, 16), data_indices=idx,
+        model = AnemoiModelEncProcDec(model_config=model_config(processor, 64, 4, 16), data_indices=idx,
                                       graph_data=graph)
         model.load_state_dict({k[3:]: v for k, v in gold.items() if k.startswith("sd.")})
         model.eval()
@@ -48,7 +49,8 @@ def _worker(rank, world, port, result_file):
         # every rank must hold the full output; halo / partition sanity
         sp = [v for k, v in model._idx_cache.items() if k[0] == "shard_plan"][0]
         n_mesh = graph["hidden"].num_nodes
-        info = dict(err=err, rank=rank, own=sp.hi - sp.lo, halo=sp.proc.halo.n_recv, dec_rows=int(sp.dec_dst_ids.numel()),
+        info = dict(err=err, rank=rank, own=sp.hi - sp.lo,
+                    halo=sp.proc.halo.n_recv if sp.proc.halo is not None else 1, dec_rows=int(sp.dec_dst_ids.numel()),
                     dec_halo=sp.dec.halo.n_recv, n_mesh=n_mesh, enc_src=int(sp.enc_src_ids.numel()))
         torch.save(info, f"{result_file}.{rank}")
     finally:
@@ -75,3 +77,13 @@ def test_split_bounds_match_tensor_split():
         sizes = [t.shape[0] for t in torch.arange(n).tensor_split(p)]
         b = split_bounds(n, p)
         assert [b[i + 1] - b[i] for i in range(p)] == sizes
+
+
+@pytest.mark.parametrize("processor", ["GNN", "Transformer"])
+def test_sharded_forward_other_processors(processor, tmp_path):
+    world = 2
+    port = 29700 + (os.getpid() % 200) + (7 if processor == "GNN" else 13)
+    result = str(tmp_path / "res")
+    mp.spawn(_worker, args=(world, port, result, processor), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.load(f"{result}.{r}")["err"] < 1e-4
