@@ -256,6 +256,8 @@ def sharded_forward(model, x: Tensor, group) -> Tensor:
     batch_size, _, ensemble_size, grid, _ = x.shape
     assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
     dtype = runtime.compute_dtype(x)
+    if not hasattr(model.encoder, "native_local") or not hasattr(model.decoder, "native_local"):
+        raise NotImplementedError("the node-partitioned forward supports the GraphTransformer mappers only")
     if model.encoder.proc.fold_width(dtype) is None:
         raise NotImplementedError("the node-partitioned forward needs the folded edge kernel for this shape / dtype")
     kmult = ops.k_multiple(dtype)

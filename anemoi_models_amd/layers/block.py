@@ -461,8 +461,54 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
 
 
 class GraphConvMapperBlock(GraphConvBaseBlock):
+    """Edge-MLP message passing between two node sets (reference layers/block.py:226-286)."""
+
+    def native(self, x_src: Tensor, x_dst: Tensor, e_csr: Tensor, plan: EdgePlan):
+        dtype = x_dst.dtype
+        c = x_dst.shape[1]
+        edge_mlp, node_mlp = self.conv.edge_mlp.native(), self.node_mlp.native()
+        lin1, act1 = edge_mlp.steps[0][1], edge_mlp.steps[0][2]
+        w_dst = self._packed.get(("w1_dst", dtype), [lin1.weight], lambda: runtime.pack_weight([lin1.weight[:, :c]], dtype))
+        w_src = self._packed.get(("w1_src", dtype), [lin1.weight],
+                                 lambda: runtime.pack_weight([lin1.weight[:, c:2 * c]], dtype))
+        w_edges = self._packed.get(("w1_edges", dtype), [lin1.weight],
+                                   lambda: runtime.pack_weight([lin1.weight[:, 2 * c:]], dtype))
+        p_dst = ops.linear(x_dst, w_dst, None)
+        p_src = ops.linear(x_src, w_src, None)
+        t = ops.linear(e_csr, w_edges, None if lin1.bias is None else runtime.f32c(lin1.bias))
+        h = ops.gather_add_act(t, p_dst, p_src, plan.dst, plan.col, act=act1, out=t)
+        e_new = edge_mlp(h, residual=e_csr, start=1)
+        del h, t, p_dst, p_src
+
+        def update(x, agg):  # node_mlp(cat[x, agg]) + x
+            xcat = torch.empty((x.shape[0], 2 * c), dtype=dtype, device=x.device)
+            xcat[:, :c].copy_(x)
+            if agg is None:
+                xcat[:, c:].copy_(x)
+            else:
+                ops.segment_sum(agg, plan.rowptr, out=xcat[:, c:])
+            return node_mlp(xcat, residual=x)
+
+        new_dst = update(x_dst, e_new)
+        new_src = update(x_src, None) if self.update_src_nodes else x_src  # reference block.py:282
+        return (new_src, new_dst), e_new
+
     def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
-        raise NotImplementedError("GNN mapper block: MI355X kernels not available in this build")
+        if _group_size(model_comm_group) > 1:
+            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+        runtime.require_inference(self)
+        x_src, x_dst = x
+        dtype = runtime.compute_dtype(x_dst)
+        n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+        if size is not None and tuple(size) != (n_src, n_dst):
+            raise ValueError(f"Encountered tensors with sizes {(n_src, n_dst)}, but expected size {tuple(size)}")
+        plan = self._plans.get(edge_index, n_src, n_dst)
+        perm = plan.perm.long()
+        e_csr = _as_compute(edge_attr, dtype).index_select(0, perm)
+        nodes, e_new = self.native(_as_compute(x_src, dtype), _as_compute(x_dst, dtype), e_csr, plan)
+        edges_new = torch.empty_like(e_new)
+        edges_new[perm] = e_new
+        return nodes, edges_new
 
 
 # =============================================================================================

@@ -207,9 +207,43 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
         self.emb_edges = MLP(in_features=self.edge_dim, hidden_dim=hidden_dim, out_features=hidden_dim,
                              n_extra_layers=mlp_extra_layers, activation=activation)
         self.trainable = TrainableTensor(trainable_size=trainable_size, tensor_size=self.edge_attr.shape[0])
+        self._plans = runtime.PlanCache()
+
+    # hooks: the forward mapper embeds both node sets, the backward mapper extracts the output variables
+    def _embed(self, x_src: Tensor, x_dst: Tensor):
+        return x_src, x_dst
+
+    def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
+        return x_dst
+
+    def native(self, x_src: Tensor, x_dst: Tensor, batch_size: int, out_dtype: Optional[torch.dtype] = None,
+               src_map: Optional[Tensor] = None, dst_map: Optional[Tensor] = None):
+        """Reference layers/mapper.py:485-522: embed edges, embed nodes, one GraphConvMapperBlock, post-process."""
+        n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+        plan = self._plans.get(self.edge_index_base, n_src, n_dst, batch_size, self.edge_inc, src_map, dst_map)
+        dtype = x_dst.dtype
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)
+        e = ops.convert_pad(ea[:, : self.edge_dim], dtype, ops.round_up(self.edge_dim, ops.k_multiple(dtype)))
+        e = self.emb_edges.native()(e)
+        h_src, h_dst = self._embed(x_src, x_dst)
+        (h_src, h_dst), _ = self.proc.native(h_src, h_dst, e, plan)
+        return h_src, self._extract(h_dst, out_dtype)
+
+    def _run(self, x, batch_size: int, shard_shapes, model_comm_group):
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            raise NotImplementedError("GNN mappers: node-partitioned execution is not implemented yet")
+        runtime.require_inference(self)
+        x_src, x_dst = x
+        dtype = runtime.compute_dtype(x_dst)
+
+        def prep(t):
+            t = t if t.dtype == dtype else t.to(dtype)
+            return t if t.stride(-1) == 1 else t.contiguous()
+
+        return self.native(prep(x_src), prep(x_dst), batch_size)
 
     def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None):
-        raise NotImplementedError("GNN mappers: MI355X kernels not available in this build")
+        return self._run(x, batch_size, shard_shapes, model_comm_group)
 
 
 class GNNForwardMapper(GNNBaseMapper):
@@ -230,6 +264,9 @@ class GNNForwardMapper(GNNBaseMapper):
         self.emb_nodes_dst = MLP(in_features=in_channels_dst, hidden_dim=hidden_dim, out_features=hidden_dim,
                                  n_extra_layers=mlp_extra_layers, activation=activation)
 
+    def _embed(self, x_src: Tensor, x_dst: Tensor):
+        return self.emb_nodes_src.native()(x_src), self.emb_nodes_dst.native()(x_dst)
+
 
 class GNNBackwardMapper(GNNBaseMapper):
     def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
@@ -248,3 +285,9 @@ class GNNBackwardMapper(GNNBaseMapper):
         self.node_data_extractor = MLP(in_features=self.hidden_dim, hidden_dim=self.hidden_dim,
                                        out_features=self.out_channels_dst, n_extra_layers=mlp_extra_layers,
                                        activation=self.activation, layer_norm=False, final_activation=False)
+
+    def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
+        return self.node_data_extractor.native()(x_dst, out_dtype=out_dtype)
+
+    def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
+        return self._run(x, batch_size, shard_shapes, model_comm_group)[1]

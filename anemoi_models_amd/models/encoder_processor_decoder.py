@@ -154,10 +154,15 @@ class AnemoiModelEncProcDec(nn.Module):
         x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[order], None if tr_hidden is None else tr_hidden[order],
                                       batch_size, dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
 
-        x_latent = self.encoder.native(x_data, x_hidden, batch_size, dst_map=inv)
+        enc = self.encoder.native(x_data, x_hidden, batch_size, dst_map=inv)
+        # GraphTransformer forward mapper hands the RAW data input on to the decoder (reference layers/mapper.py:345);
+        # the GNN forward mapper hands on its UPDATED source embedding (reference layers/mapper.py:522)
+        x_data_latent, x_latent = (x_data, enc) if not isinstance(enc, tuple) else enc
         x_proc = self.processor.native(x_latent, batch_size, node_map=inv)
         x_latent_proc = ops.add(x_proc, x_latent)
-        y = self.decoder.native(x_latent_proc, x_data, batch_size, out_dtype=torch.float32, src_map=inv)
+        y = self.decoder.native(x_latent_proc, x_data_latent, batch_size, out_dtype=torch.float32, src_map=inv)
+        if isinstance(y, tuple):
+            y = y[1]
 
         y = y.view(batch_size, ensemble_size, grid, self.num_output_channels)
         out_idx, in_idx = self._prognostic_indices(y.device)

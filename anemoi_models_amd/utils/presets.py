@@ -19,7 +19,8 @@ BASELINE_CONFIGS = {
 
 
 def model_config(processor: str = "GraphTransformer", channels: int = 64, layers: int = 4, heads: int = 16,
-                 multistep: int = 2, trainable: int = 8, proc_chunks: int = 2, window_size: int = 512) -> DotDict:
+                 multistep: int = 2, trainable: int = 8, proc_chunks: int = 2, window_size: int = 512,
+                 mappers: str = "GraphTransformer") -> DotDict:
     common = {"sub_graph_edge_attributes": EDGE_ATTRS, "trainable_size": trainable}
     mapper = {"activation": "GELU", "num_chunks": 1, "mlp_hidden_ratio": 4, "num_heads": heads, **common}
     procs = {
@@ -37,6 +38,12 @@ def model_config(processor: str = "GraphTransformer", channels: int = 64, layers
             "window_size": window_size, "dropout_p": 0.0,
         },
     }
+    enc = {"_target_": "anemoi.models.layers.mapper.GraphTransformerForwardMapper", **mapper}
+    dec = {"_target_": "anemoi.models.layers.mapper.GraphTransformerBackwardMapper", **mapper}
+    if mappers == "GNN":
+        gm = {"activation": "SiLU", "num_chunks": 1, "mlp_extra_layers": 0, **common}
+        enc = {"_target_": "anemoi.models.layers.mapper.GNNForwardMapper", **gm}
+        dec = {"_target_": "anemoi.models.layers.mapper.GNNBackwardMapper", **gm}
     return DotDict(
         {
             "graph": {"data": "data", "hidden": "hidden"},
@@ -44,9 +51,9 @@ def model_config(processor: str = "GraphTransformer", channels: int = 64, layers
             "model": {
                 "num_channels": channels,
                 "trainable_parameters": {"data": trainable, "hidden": trainable},
-                "encoder": {"_target_": "anemoi.models.layers.mapper.GraphTransformerForwardMapper", **mapper},
+                "encoder": enc,
                 "processor": procs[processor],
-                "decoder": {"_target_": "anemoi.models.layers.mapper.GraphTransformerBackwardMapper", **mapper},
+                "decoder": dec,
             },
         }
     )

@@ -277,6 +277,39 @@ def gnn_processor(sd: SD, p: str, x: Tensor, edge_attr_buf: Tensor, edge_index_b
     return x
 
 
+def gnn_mapper_block(sd: SD, p: str, x_src: Tensor, x_dst: Tensor, edge_attr: Tensor, edge_index: Tensor,
+                     update_src_nodes: bool, act: str = "SiLU", n_extra_layers: int = 0):
+    """layers/block.py:249-286 ``GraphConvMapperBlock.forward`` (num_chunks=1, no comm group)."""
+    out, edges_new = gnn_conv(sd, p + ".conv", x_src, x_dst, edge_attr, edge_index, act, n_extra_layers)
+    new_dst = mlp(sd, p + ".node_mlp", torch.cat([x_dst, out], dim=1), act, n_extra_layers) + x_dst
+    new_src = x_src
+    if update_src_nodes:  # block.py:282: the source update sees cat[x_src, x_src]
+        new_src = mlp(sd, p + ".node_mlp", torch.cat([x_src, x_src], dim=1), act, n_extra_layers) + x_src
+    return (new_src, new_dst), edges_new
+
+
+def gnn_forward_mapper(sd: SD, p: str, x_src: Tensor, x_dst: Tensor, edge_attr_buf: Tensor, edge_index_base: Tensor,
+                       batch_size: int, act: str = "SiLU", n_extra_layers: int = 0):
+    """layers/mapper.py:525-608 + :485-522 + :108-116 ``GNNForwardMapper.forward``: returns (x_src_new, x_dst_new)."""
+    edge_attr = trainable_tensor(edge_attr_buf, sd.get(p + ".trainable.trainable"), batch_size)
+    edge_index = expand_edges(edge_index_base, sd[p + ".edge_inc"], batch_size)
+    edge_attr = mlp(sd, p + ".emb_edges", edge_attr, act, n_extra_layers)
+    xs = mlp(sd, p + ".emb_nodes_src", x_src, act, n_extra_layers)
+    xd = mlp(sd, p + ".emb_nodes_dst", x_dst, act, n_extra_layers)
+    (xs, xd), _ = gnn_mapper_block(sd, p + ".proc", xs, xd, edge_attr, edge_index, True, act, n_extra_layers)
+    return xs, xd
+
+
+def gnn_backward_mapper(sd: SD, p: str, x_src: Tensor, x_dst: Tensor, edge_attr_buf: Tensor, edge_index_base: Tensor,
+                        batch_size: int, act: str = "SiLU", n_extra_layers: int = 0) -> Tensor:
+    """layers/mapper.py:611-705 + :96-102 ``GNNBackwardMapper.forward``: no node embedding, MLP extractor without LN."""
+    edge_attr = trainable_tensor(edge_attr_buf, sd.get(p + ".trainable.trainable"), batch_size)
+    edge_index = expand_edges(edge_index_base, sd[p + ".edge_inc"], batch_size)
+    edge_attr = mlp(sd, p + ".emb_edges", edge_attr, act, n_extra_layers)
+    (_, xd), _ = gnn_mapper_block(sd, p + ".proc", x_src, x_dst, edge_attr, edge_index, False, act, n_extra_layers)
+    return mlp(sd, p + ".node_data_extractor", xd, act, n_extra_layers, layer_norm=False)
+
+
 # --------------------------------------------------------------------------
 # Transformer (MHSA) path
 # --------------------------------------------------------------------------
@@ -360,6 +393,7 @@ def model_forward(
     gnn_act: str = "SiLU",
     window_size: Optional[int] = None,
     return_stages: bool = False,
+    mappers: str = "GraphTransformer",
 ):
     """models/encoder_processor_decoder.py:168-233 ``AnemoiModelEncProcDec.forward`` (no boundings).
 
@@ -374,10 +408,14 @@ def model_forward(
     )  # :173-179
     x_hidden = node_attributes(sd, hidden, b)  # :181
 
-    x_data_latent, x_latent = gt_forward_mapper(
-        sd, "encoder", x_data, x_hidden, graph["enc_edge_attr"], graph["enc_edge_index"], b, num_heads, act,
-        mapper_chunks,
-    )  # :188-194
+    if mappers == "GNN":
+        x_data_latent, x_latent = gnn_forward_mapper(sd, "encoder", x_data, x_hidden, graph["enc_edge_attr"],
+                                                     graph["enc_edge_index"], b, gnn_act)
+    else:
+        x_data_latent, x_latent = gt_forward_mapper(
+            sd, "encoder", x_data, x_hidden, graph["enc_edge_attr"], graph["enc_edge_index"], b, num_heads, act,
+            mapper_chunks,
+        )  # :188-194
     if processor == "GraphTransformer":
         x_proc = gt_processor(sd, "processor", x_latent, graph["proc_edge_attr"], graph["proc_edge_index"], b,
                               num_layers, num_chunks, num_heads, act)
@@ -390,10 +428,14 @@ def model_forward(
     else:
         raise ValueError(processor)
     x_latent_proc = x_proc + x_latent  # :204
-    x_out = gt_backward_mapper(
-        sd, "decoder", x_latent_proc, x_data_latent, graph["dec_edge_attr"], graph["dec_edge_index"], b, num_heads,
-        act, mapper_chunks,
-    )  # :207-213
+    if mappers == "GNN":
+        x_out = gnn_backward_mapper(sd, "decoder", x_latent_proc, x_data_latent, graph["dec_edge_attr"],
+                                    graph["dec_edge_index"], b, gnn_act)
+    else:
+        x_out = gt_backward_mapper(
+            sd, "decoder", x_latent_proc, x_data_latent, graph["dec_edge_attr"], graph["dec_edge_index"], b,
+            num_heads, act, mapper_chunks,
+        )  # :207-213
     x_out = x_out.reshape(b, ens, g, -1).to(x.dtype).clone()  # :215-224
     x_out[..., list(prognostic_out)] += x[:, -1, :, :, list(prognostic_in)]  # :227
     if return_stages:

@@ -49,6 +49,11 @@ def golden_cfg1_gnn():
 
 
 @pytest.fixture(scope="session")
+def golden_cfg1_gnn_all():
+    return load_npz("cfg1_gnn_all.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_cfg1_tfm():
     return load_npz("cfg1_tfm.npz")
 

@@ -67,7 +67,7 @@ def to_ref_graph(g):
     return ref
 
 
-def model_config(processor: str, channels: int, layers: int, heads: int):
+def model_config(processor: str, channels: int, layers: int, heads: int, mappers: str = "GraphTransformer"):
     common = {"sub_graph_edge_attributes": EDGE_ATTRS, "trainable_size": 8}
     mapper = {"activation": "GELU", "num_chunks": 1, "mlp_hidden_ratio": 4, "num_heads": heads, **common}
     procs = {
@@ -86,6 +86,12 @@ def model_config(processor: str, channels: int, layers: int, heads: int):
             "num_heads": heads, "window_size": 512, "dropout_p": 0.0,
         },
     }
+    enc = {"_target_": "anemoi.models.layers.mapper.GraphTransformerForwardMapper", **mapper}
+    dec = {"_target_": "anemoi.models.layers.mapper.GraphTransformerBackwardMapper", **mapper}
+    if mappers == "GNN":
+        gm = {"activation": "SiLU", "num_chunks": 1, "mlp_extra_layers": 0, **common}
+        enc = {"_target_": "anemoi.models.layers.mapper.GNNForwardMapper", **gm}
+        dec = {"_target_": "anemoi.models.layers.mapper.GNNBackwardMapper", **gm}
     return _ref_stubs.DotDict(
         {
             "graph": {"data": "data", "hidden": "hidden"},
@@ -93,20 +99,20 @@ def model_config(processor: str, channels: int, layers: int, heads: int):
             "model": {
                 "num_channels": channels,
                 "trainable_parameters": {"data": 8, "hidden": 8},
-                "encoder": {"_target_": "anemoi.models.layers.mapper.GraphTransformerForwardMapper", **mapper},
+                "encoder": enc,
                 "processor": procs[processor],
-                "decoder": {"_target_": "anemoi.models.layers.mapper.GraphTransformerBackwardMapper", **mapper},
+                "decoder": dec,
             },
         }
     )
 
 
 def golden_model(processor: str, fname: str, graph_name: str = "o32_ico2", channels: int = 64, layers: int = 4,
-                 heads: int = 16, n_prog: int = 10, n_forc: int = 2, n_diag: int = 1) -> dict:
+                 heads: int = 16, n_prog: int = 10, n_forc: int = 2, n_diag: int = 1, mappers: str = "GraphTransformer") -> dict:
     g = build_graph(graph_name)
     idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
     torch.manual_seed(1234)
-    model = AnemoiModelEncProcDec(model_config=model_config(processor, channels, layers, heads), data_indices=idx,
+    model = AnemoiModelEncProcDec(model_config=model_config(processor, channels, layers, heads, mappers), data_indices=idx,
                                   graph_data=to_ref_graph(g))
     randomise(model, 4321)
     model.eval()
@@ -242,6 +248,7 @@ if __name__ == "__main__":
         "GraphTransformer": golden_model("GraphTransformer", "cfg1_gt.npz"),
         "GNN": golden_model("GNN", "cfg1_gnn.npz"),
         "Transformer": golden_model("Transformer", "cfg1_tfm.npz"),
+        "GNN_all": golden_model("GNN", "cfg1_gnn_all.npz", mappers="GNN"),
     }
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0, sort_keys=True)

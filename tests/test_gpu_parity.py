@@ -221,14 +221,15 @@ def test_gt_blocks_vs_golden(golden_blocks):
     assert rel_err(yd, b["gtm.y_dst"]) < 1e-4
 
 
-def _build(graph, channels, layers, heads=16, processor="GraphTransformer", n_prog=10, n_forc=2, n_diag=1):
+def _build(graph, channels, layers, heads=16, processor="GraphTransformer", n_prog=10, n_forc=2, n_diag=1,
+           mappers="GraphTransformer"):
     from anemoi_models_amd.models import AnemoiModelEncProcDec
     from anemoi_models_amd.utils.indices import SimpleDataIndices
     from anemoi_models_amd.utils.presets import model_config
 
     idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
-    return AnemoiModelEncProcDec(model_config=model_config(processor, channels, layers, heads), data_indices=idx,
-                                 graph_data=graph), idx
+    return AnemoiModelEncProcDec(model_config=model_config(processor, channels, layers, heads, mappers=mappers),
+                                 data_indices=idx, graph_data=graph), idx
 
 
 def test_model_cfg1_vs_golden_f32(graph_o32, golden_cfg1_gt):
@@ -435,3 +436,13 @@ def test_full_size_config3_invariants(monkeypatch):
         x2 = x.clone()
         y2 = model(x2).float().cpu()
     assert torch.equal(y2, y_ref)  # deterministic: no atomics anywhere on the path
+
+
+def test_all_gnn_model_vs_golden(graph_o32, golden_cfg1_gnn_all):
+    gold = golden_cfg1_gnn_all
+    model, _ = _build(graph_o32, 64, 4, processor="GNN", mappers="GNN")
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(gold["x"].to(DEV))
+    assert rel_err(out, gold["y"]) < 1e-4

@@ -19,16 +19,18 @@ from anemoi_models_amd.utils.indices import SimpleDataIndices
 from anemoi_models_amd.utils.presets import model_config
 
 
-def build_model(graph, processor="GraphTransformer"):
+def build_model(graph, processor="GraphTransformer", mappers="GraphTransformer"):
     idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
-    return AnemoiModelEncProcDec(model_config=model_config(processor, 64, 4, 16), data_indices=idx, graph_data=graph)
+    return AnemoiModelEncProcDec(model_config=model_config(processor, 64, 4, 16, mappers=mappers), data_indices=idx,
+                                 graph_data=graph)
 
 
-@pytest.mark.parametrize("processor", ["GraphTransformer", "GNN", "Transformer"])
+@pytest.mark.parametrize("processor", ["GraphTransformer", "GNN", "Transformer", "GNN_all"])
 def test_state_dict_layout_matches_reference(graph_o32, processor):
     with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
         ref = json.load(f)[processor]
-    sd = build_model(graph_o32, processor).state_dict()
+    model = build_model(graph_o32, "GNN", "GNN") if processor == "GNN_all" else build_model(graph_o32, processor)
+    sd = model.state_dict()
     assert list(sd.keys()) == list(ref.keys()) or set(sd.keys()) == set(ref.keys())
     assert {k: list(v.shape) for k, v in sd.items()} == ref
 
@@ -164,6 +166,17 @@ def test_transformer_model_and_block_wiring_match_golden(graph_o32, golden_cfg1_
 
     gold = golden_cfg1_tfm
     model = build_model(graph_o32, "Transformer")
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model.eval()
+    with torch.no_grad():
+        out = model(gold["x"])
+    torch.testing.assert_close(out, gold["y"], atol=1e-4, rtol=1e-4)
+
+
+def test_all_gnn_model_wiring_matches_golden(graph_o32, golden_cfg1_gnn_all, monkeypatch):
+    _cpu_ops.install(monkeypatch)
+    gold = golden_cfg1_gnn_all
+    model = build_model(graph_o32, "GNN", "GNN")
     model.load_state_dict(split_prefix(gold, "sd."))
     model.eval()
     with torch.no_grad():

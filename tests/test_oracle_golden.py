@@ -72,11 +72,11 @@ def test_index_ops_bit_exact(golden_index_ops):
     assert torch.equal(ref.expand_edges(z["expand.edge_index"], inc, 3), z["expand.out"])
 
 
-def _model(gold, graph, processor):
+def _model(gold, graph, processor, mappers="GraphTransformer"):
     sd = split_prefix(gold, "sd.")
     y, st = ref.model_forward(
         sd, graph_tensors(graph), gold["x"], num_heads=16, num_layers=4, num_chunks=2,
-        prognostic_in=range(10), prognostic_out=range(10), processor=processor, return_stages=True,
+        prognostic_in=range(10), prognostic_out=range(10), processor=processor, return_stages=True, mappers=mappers,
     )
     torch.testing.assert_close(st["x_latent"], gold["stage.encoder"], atol=ATOL, rtol=RTOL)
     torch.testing.assert_close(st["x_proc"], gold["stage.processor"], atol=5 * ATOL, rtol=5 * RTOL)
@@ -99,6 +99,10 @@ def test_model_gt_block_stages(golden_cfg1_gt, graph_o32):
 
 def test_model_gnn(golden_cfg1_gnn, graph_o32):
     _model(golden_cfg1_gnn, graph_o32, "GNN")
+
+
+def test_model_gnn_mappers(golden_cfg1_gnn_all, graph_o32):
+    _model(golden_cfg1_gnn_all, graph_o32, "GNN", mappers="GNN")
 
 
 def test_model_transformer(golden_cfg1_tfm, graph_o32):
