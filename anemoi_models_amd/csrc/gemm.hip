@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ R, int64_t ldr,
                                                               bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
                                                               int K, int act, int vec_ok, int64_t n_tiles,
-                                                              int nt_count, int dbg) {
+                                                              int nt_count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -362,7 +362,6 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
       }
       const char* xs = smem + (g & 1) * BIG_STAGE;
       const char* ws = xs + BIG_M * ROW_BYTES;
-      if (dbg & 2) continue;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8_t a[4];
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
         if (sft & 1) v = make_uint4(v.z, v.w, v.x, v.y);
         const int64_t m = m0 + wm * 128 + ps * 32 + row;
         const int n = n0 + wn * 64 + rc * 8;
-        if (m < M && n < N && !(dbg & 1)) {
+        if (m < M && n < N) {
           if (vec_ok && n + 8 <= N) {
             if (R != nullptr) {
               const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
@@ -673,7 +672,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   hipLaunchKernelGGL(linear_bf16_256_kernel, dim3((unsigned)blocks), dim3(512), BIG_LDS, st,
                      static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
                      static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,
-                     vec_ok ? 1 : 0, mt * nt, (int)nt, getenv("ANEMOI_AMD_GEMM_DEBUG") ? atoi(getenv("ANEMOI_AMD_GEMM_DEBUG")) : 0);
+                     vec_ok ? 1 : 0, mt * nt, (int)nt);
   return check_launch("anemoi_linear(256x256)");
 }
 

@@ -9,6 +9,30 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// GEMM access pattern: a 64 KiB slab = 512 rows x 128 B taken from a row-major matrix with `pitch` bytes per row
+// (two operand tiles of 256 rows); consecutive slabs step 128 B along the rows.
+__global__ __launch_bounds__(512) void kstrided(const char* __restrict__ src, size_t span, int iters, int pitch,
+                                                float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float acc = 0.f;
+  const int slabs_per_row = pitch / 128;
+  for (int it = 0; it < iters; ++it) {
+    // tile origin: 512 consecutive rows; neighbouring workgroups share half of their rows (like tiles sharing a panel)
+    const size_t row0 = ((size_t)(blockIdx.x / 2) * 256 + (size_t)(it / slabs_per_row) * 4096) % (span / pitch - 512);
+    const char* p = src + row0 * pitch + (size_t)(it % slabs_per_row) * 128;
+    char* l = smem + (it & 1) * 65536 + wid * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = (wid * 8 + i) * 8 + (lane >> 3);
+      glds16(p + (size_t)r * pitch + (lane & 7) * 16, l + i * 1024);
+    }
+    __syncthreads();
+    acc += reinterpret_cast<float*>(smem)[(it & 1) * 16384 + threadIdx.x];
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void k(const char* __restrict__ src, size_t span, int iters, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,6 +84,20 @@ int main() {
       float ms; hipEventElapsedTime(&ms, a, b);
       const double bytes = 256.0 * iters * 65536.0;
       printf("span %4zu MiB mode %d: %.3f ms  %.2f TB/s aggregate  %.1f GB/s per CU\n", sp >> 20, mode, ms,
+             bytes / ms / 1e9, bytes / ms / 1e6 / 256);
+    }
+  }
+  hipFuncSetAttribute((const void*)kstrided, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  for (size_t sp : {(size_t)(16ull << 20), span}) {
+    for (int pitch : {128, 2048, 2176, 8192}) {
+      hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+      hipLaunchKernelGGL(kstrided, dim3(256), dim3(512), 131072, 0, d, sp, iters, pitch, sink); hipDeviceSynchronize();
+      hipEventRecord(a);
+      hipLaunchKernelGGL(kstrided, dim3(256), dim3(512), 131072, 0, d, sp, iters, pitch, sink);
+      hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b);
+      const double bytes = 256.0 * iters * 65536.0;
+      printf("strided span %4zu MiB pitch %5d: %.3f ms  %.2f TB/s aggregate  %.1f GB/s per CU\n", sp >> 20, pitch, ms,
              bytes / ms / 1e9, bytes / ms / 1e6 / 256);
     }
   }
