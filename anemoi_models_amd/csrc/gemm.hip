@@ -277,6 +277,7 @@ __device__ __noinline__ void store_row_tail(uint4 v, const bf16_t* __restrict__ 
 // time the CUs of one XCD work on neighbouring tiles (shared x row panels / W column panels in that XCD's L2).
 // The K-slabs of consecutive tiles form ONE double-buffered stream: slab 0 of the next tile is already in flight
 // while the current tile's epilogue runs out of a separate 32 KiB LDS scratch.
+template <int ACT, bool HAS_RES>
 __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                               const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias,
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
         for (int i = 0; i < 4; ++i) {
           float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[i][r], act);
+          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[i][r], ACT);
           const int unit = (i * 4 + fq) ^ (row & 15);
           *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) =
               make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
         const int n = n0 + wn * 64 + rc * 8;
         if (m < M && n < N) {
           if (vec_ok && n + 8 <= N) {
-            if (R != nullptr) {
+            if constexpr (HAS_RES) {
               const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
               v = make_uint4(bf16x2_add(v.x, rv.x), bf16x2_add(v.y, rv.y), bf16x2_add(v.z, rv.z),
                              bf16x2_add(v.w, rv.w));
@@ -638,7 +639,21 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
                                   hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<0, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<0, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<1, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<1, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<2, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<2, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<3, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<3, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256x4_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS) != hipSuccess)
@@ -669,10 +684,24 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
                        vec_ok ? 1 : 0, mt * nt, (int)nt);
     return check_launch("anemoi_linear(256x256, 4-stage)");
   }
-  hipLaunchKernelGGL(linear_bf16_256_kernel, dim3((unsigned)blocks), dim3(512), BIG_LDS, st,
-                     static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
-                     static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,
-                     vec_ok ? 1 : 0, mt * nt, (int)nt);
+#define LAUNCH_256_(A, RES)                                                                                    \
+  hipLaunchKernelGGL((linear_bf16_256_kernel<A, RES>), dim3((unsigned)blocks), dim3(512), BIG_LDS, st,         \
+                     static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,                  \
+                     static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,    \
+                     vec_ok ? 1 : 0, mt * nt, (int)nt)
+#define LAUNCH_256(A)                    \
+  do {                                   \
+    if (residual != nullptr) LAUNCH_256_(A, true); \
+    else LAUNCH_256_(A, false);          \
+  } while (0)
+  switch (act) {  // the activation is a compile-time constant of the kernel: no per-element switch in the epilogue
+    case ANEMOI_ACT_GELU: LAUNCH_256(ANEMOI_ACT_GELU); break;
+    case ANEMOI_ACT_SILU: LAUNCH_256(ANEMOI_ACT_SILU); break;
+    case ANEMOI_ACT_RELU: LAUNCH_256(ANEMOI_ACT_RELU); break;
+    default: LAUNCH_256(ANEMOI_ACT_NONE); break;
+  }
+#undef LAUNCH_256
+#undef LAUNCH_256_
   return check_launch("anemoi_linear(256x256)");
 }
 
