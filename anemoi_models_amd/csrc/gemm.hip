@@ -239,6 +239,36 @@ __device__ __forceinline__ uint32_t bf16x2_add(uint32_t a, uint32_t b) {
   return pack_bf16x2(lo, hi);
 }
 
+// GELU of two values on the packed-f32 pipe (v_pk_fma_f32: two lanes' worth per issue slot, no transcendentals).
+// Phi(x) = 0.5 + x Q(t), t = 2 x^2 / 25 - 1, |x| clamped to 5: a degree-10 minimax fit of (Phi(x) - 1/2) / x in x^2
+// (max |Phi error| 3.8e-6, |GELU error| < 2.5e-5 -- far below the bf16 rounding of the value this kernel stores;
+// the f32 kernel keeps the erf form in common.hpp::act_apply).  Replaces nn.GELU() of layers/block.py:504-508.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+template <int ACT>
+__device__ __forceinline__ f32x2_t act_apply2(f32x2_t x) {
+  if constexpr (ACT == ANEMOI_ACT_GELU) {
+    const f32x2_t xc = {__builtin_amdgcn_fmed3f(x.x, -5.f, 5.f), __builtin_amdgcn_fmed3f(x.y, -5.f, 5.f)};
+    const f32x2_t t = xc * xc * 0.08f - 1.0f;
+    f32x2_t q = 0.0028987061232328415f;
+    q = q * t + -0.006777674425393343f;
+    q = q * t + 0.00580402510240674f;
+    q = q * t + -0.007411926984786987f;
+    q = q * t + 0.016354311257600784f;
+    q = q * t + -0.024764036759734154f;
+    q = q * t + 0.03153576701879501f;
+    q = q * t + -0.04020122438669205f;
+    q = q * t + 0.05150570720434189f;
+    q = q * t + -0.07030709832906723f;
+    q = q * t + 0.14136408269405365f;
+    f32x2_t phi = xc * q + 0.5f;
+    phi = __builtin_elementwise_max(phi, (f32x2_t)0.f);
+    return x * phi;
+  } else {
+    return f32x2_t{act_apply(x.x, ACT), act_apply(x.y, ACT)};
+  }
+}
+
 // Tile order inside an XCD chunk: column groups of SUPER_N tile columns, row-major inside a group.  SUPER_N = 8 would
 // make the 32 tiles an XCD works on concurrently a 4 x 8 patch of the output (12 unique operand panels in that XCD's
 // L2 instead of 18 for 2 x 16).  Measured on MI355X: no gain (-3 %) over the plain row-major order, so the group
@@ -412,12 +442,11 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
         const int row = jj * 16 + fr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[i][r], ACT);
+          const f32x2_t o01 = act_apply2<ACT>(f32x2_t{acc[i][j][0], acc[i][j][1]} + f32x2_t{bv[i][0], bv[i][1]});
+          const f32x2_t o23 = act_apply2<ACT>(f32x2_t{acc[i][j][2], acc[i][j][3]} + f32x2_t{bv[i][2], bv[i][3]});
           const int unit = (i * 4 + fq) ^ (row & 15);
           *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) =
-              make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+              make_uint2(pack_bf16x2(o01.x, o01.y), pack_bf16x2(o23.x, o23.y));
         }
       }
 #pragma unroll
