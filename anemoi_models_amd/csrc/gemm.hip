@@ -17,6 +17,7 @@
 // (chunk' = chunk ^ ((row >> 1) & 7)): conflict-free for both fragment shapes.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.hpp"
 
@@ -480,6 +481,321 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
 }
 
 // =============================================================================================
+// bf16 fast path, "w4": the same 256 x 256 x 64 tile and slab stream, FOUR waves (one per SIMD) of 128 x 128 --
+// 256 accumulator registers per lane live in AGPRs (inline-asm MFMA, "+a"), the 128 fragment registers of the
+// current and the next half-slab in VGPRs.  Measured on MI355X (tools/micro/gemm_lab.hip, 8192^3, random data):
+// 1320 TFLOP/s against 1110 for the eight-wave loop above; what made the difference, in order:
+//   * a third less LDS read traffic (each wave reads 256 rows per slab instead of 192 for half the flops);
+//   * ONE memory instruction per MFMA gap, never a burst: the CU's four waves run in lockstep and share one
+//     address pipe (~16 cycles per 1 KiB LDS-DMA piece), so the 16 refill DMAs of a slab go out one per five
+//     MFMAs (~85 cycles); at one per three they queued on each other and cost ~37 cycles each of MFMA time;
+//   * the ks = 1 fragments of a slab are fetched in its first 16 MFMA gaps, so barrier 1 (gap 23) frees the WHOLE
+//     slab buffer early and its refill overlaps the remaining 100 MFMAs; barrier 2 (gap 103, counted vmcnt: only
+//     the previous slab's DMAs must have landed) publishes the other buffer, whose ks = 0 fragments are fetched in
+//     the gaps 104..119.
+// Operand rows beyond M / N are never loaded: the staging goes through buffer descriptors sized to the tile's
+// valid rows (out-of-range lanes of buffer_load ... lds deliver zeros).
+// =============================================================================================
+constexpr int W4_EPI = 4 * 8192;                    // two 4 KiB epilogue scratch buffers per wave
+constexpr int W4_LDS = 2 * BIG_STAGE + W4_EPI;      // 160 KiB: the whole LDS of a CU
+
+#define ANEMOI_MFMA_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+
+template <typename F, int... S>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, S...>) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+
+template <int ACT, bool HAS_RES>
+__global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+                                                             const bf16_t* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             const bf16_t* __restrict__ R, int64_t ldr,
+                                                             bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
+                                                             int K, int vec_ok, int64_t n_tiles, int nt_count) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int64_t q8 = n_tiles / 8, r8 = n_tiles % 8;
+  const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int64_t chunk_len = q8 + (xcd < r8 ? 1 : 0);
+  if (bix >= chunk_len) return;
+  const int nk = K / 64;  // >= 2 (launcher)
+
+  // ---- staging side.  Wave w fills LDS rows w * 64 + 8 i + (lane >> 3), i = 0..7, of both operand panels; the
+  //      source chunk is swizzled with the LDS row ((row >> 1) & 7 = (4 i + (lane >> 4)) & 7: two classes, i even/odd).
+  const int srow = lane >> 3, scp = lane & 7;
+  int vox[2], vow[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = 8 * p + srow;
+    const int c = swz(r, scp);
+    vox[p] = r * (int)ldx * 2 + c * 16;
+    vow[p] = r * K * 2 + c * 16;
+  }
+  const int xrow16 = 16 * (int)ldx * 2, wrow16 = 16 * K * 2;
+  const int xwave = wid * 64 * (int)ldx * 2, wwave = wid * 64 * K * 2;
+  __amdgpu_buffer_rsrc_t xrs, wrs;  // descriptors of the tile whose slabs are being staged
+  auto set_tile = [&](int64_t tile) {
+    int64_t mt_;
+    int nt_;
+    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+    const int64_t m0 = mt_ * BIG_M;
+    const int n0 = nt_ * BIG_N;
+    const int64_t xrows = M - m0 < BIG_M ? M - m0 : BIG_M;
+    const int wrows = N - n0 < BIG_N ? N - n0 : BIG_N;
+    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + m0 * ldx), 0, (int)(xrows * ldx * 2), 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * K), 0, wrows * K * 2, 0x00020000);
+  };
+  auto set_null = [&]() {
+    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0, 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0, 0x00020000);
+  };
+  auto dma_x = [&](int i, int kt, char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, vox[i & 1],
+                                             xwave + (i >> 1) * xrow16 + kt * ROW_BYTES, 0, 0);
+  };
+  auto dma_w = [&](int i, int kt, char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, vow[i & 1],
+                                             wwave + (i >> 1) * wrow16 + kt * ROW_BYTES, 0, 0);
+  };
+  auto stage_all = [&](int kt, int buf) {
+    char* xs = smem + buf * BIG_STAGE + wid * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dma_x(i, kt, xs + i * 1024);
+      dma_w(i, kt, xs + BIG_M * ROW_BYTES + i * 1024);
+    }
+  };
+
+  // ---- compute side
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  auto ldA = [&](int buf, int ks, int i) {  // W fragment (N side)
+    const int row = wn * 128 + i * 16 + fr;
+    return *reinterpret_cast<const bf16x8_t*>(smem + buf * BIG_STAGE + BIG_M * ROW_BYTES + row * ROW_BYTES +
+                                              (swz(row, ks * 4 + fq) << 4));
+  };
+  auto ldB = [&](int buf, int ks, int j) {  // x fragment (M side)
+    const int row = wm * 128 + j * 16 + fr;
+    return *reinterpret_cast<const bf16x8_t*>(smem + buf * BIG_STAGE + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
+  };
+  char* region = smem + 2 * BIG_STAGE + wid * 8192;
+  const int rc = lane & 7, rr = lane >> 3;
+
+  f32x4_t acc[8][8];
+  bf16x8_t a0[8], b0[8], a1[8], b1[8];
+
+  // prologue: slabs 0 and 1 of the first tile; fragments of (slab 0, ks 0)
+  set_tile(chunk_start + bix);
+  stage_all(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    b0[u] = ldB(0, 0, u);
+    a0[u] = ldA(0, 0, u);
+  }
+  stage_all(1, 1);
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int g = 0;  // running slab counter over all tiles of this workgroup: LDS stage = g & 1
+  for (int64_t li = bix; li < chunk_len; li += bpx) {
+    const int64_t tile = chunk_start + li;
+    const bool has_next = li + bpx < chunk_len;
+    int64_t mt_;
+    int nt_;
+    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+    const int64_t m0 = mt_ * BIG_M;
+    const int n0 = nt_ * BIG_N;
+
+    float bv[8][4];  // bias of this lane's 8 x 4 output columns, requested a whole K loop before its use
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int nb = n0 + wn * 128 + i * 16 + fq * 4;
+      nb = nb < N - 4 ? nb : N - 4;  // clamped, not predicated: columns >= N are never stored
+      if (bias != nullptr) {
+        VecIO<float, 4>::load(bias + nb, bv[i]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = 0.f;
+      }
+    }
+    asm volatile("s_nop 7" ::: "memory");  // AGPR zeroing (prologue / previous epilogue) -> first MFMA: hazards are ours
+
+    // One slab = 128 MFMAs; the slab two ahead in the stream (this tile's or the next one's) is staged meanwhile.  The
+    // control flow is one plain loop on purpose: with alternative slab bodies the accumulators' phi nodes fall out of
+    // the AGPR class and every MFMA gets four v_accvgpr_write in front.  After the stream's last tile the staging
+    // descriptors are empty (every lane out of range: zeros into a dead buffer), so the DMA count per slab stays 16.
+    auto slab = [&](int kt_stage, bool vm_wait) {
+      const int buf = g & 1, nbuf = buf ^ 1;
+      char* xsd = smem + buf * BIG_STAGE + wid * 8192;
+      static_for_seq(
+          [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            if constexpr (s < 64) ANEMOI_MFMA_A(acc[s >> 3][s & 7], a0[s >> 3], b0[s & 7]);
+            else ANEMOI_MFMA_A(acc[(s - 64) >> 3][s & 7], a1[(s - 64) >> 3], b1[s & 7]);
+            if constexpr (s < 16) {  // fragments of (this slab, ks = 1)
+              if constexpr (s < 8) b1[s] = ldB(buf, 1, s);
+              else a1[s - 8] = ldA(buf, 1, s - 8);
+            }
+            if constexpr (s == 23) {  // barrier 1: every wave has read this slab's buffer completely
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_s_barrier();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (s >= 24 && (s - 24) % 5 == 0 && (s - 24) / 5 < 16) {  // refill it: one DMA per 5 gaps
+              constexpr int t = (s - 24) / 5, i = t >> 1;
+              if constexpr (t & 1) dma_w(i, kt_stage, xsd + BIG_M * ROW_BYTES + i * 1024);
+              else dma_x(i, kt_stage, xsd + i * 1024);
+            }
+            if constexpr (s == 103) {  // barrier 2: the other buffer (staged one slab ago) is complete for everyone
+              if (vm_wait) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (slab 0 of a later tile: waited in the epilogue)
+              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_s_barrier();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (s >= 104 && s < 120) {  // fragments of (next slab, ks = 0)
+              constexpr int t = s - 104;
+              if constexpr (t < 8) b0[t] = ldB(nbuf, 0, t);
+              else a0[t - 8] = ldA(nbuf, 0, t - 8);
+            }
+          },
+          std::make_integer_sequence<int, 128>{});
+      ++g;
+    };
+    for (int k = 0; k < nk; ++k) {
+      if (k == nk - 2) {  // from here on the staged slabs are the next tile's
+        if (has_next) set_tile(tile + bpx);
+        else set_null();
+      }
+      slab(k + 2 < nk ? k + 2 : k + 2 - nk, k != 0 || li == bix);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA -> accumulator reads below
+
+    // ---- epilogue: 8 passes (4 row groups x 2 column halves) of [32 rows][64 cols] through two 4 KiB scratch
+    //      buffers per wave (8-byte units XOR-swizzled), read back as whole 128-byte output row segments (16 B per
+    //      lane).  With one wave per SIMD nothing else hides latency here, so this is straight-line code (the launcher
+    //      guarantees M % 256 == 0, N % 8 == 0 and 16-byte alignment: the only guard left is the column mask of a
+    //      ragged last N tile, loads are clamped instead of predicated) and the passes are software-pipelined by hand:
+    //      pass p + 1 is converted and written to LDS before pass p is read back and stored, the residual is requested
+    //      up to three passes ahead, the bias a whole K loop ahead.  The next tile's first two slabs are in flight
+    //      meanwhile; they are waited for BEFORE the first store is issued, so that the next slab's counted vmcnt never
+    //      has to wait behind this tile's 32 stores per lane (vmcnt has no separate store counter).
+    // Output / residual go through buffer descriptors of the tile (one lane-offset VGPR each, the (pass, row group)
+    // part in an SGPR): 64-bit per-access pointers would cost > 100 VGPRs here and spill.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const __amdgpu_buffer_rsrc_t yrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, 0x7fffffff, 0x00020000);
+    const int ncol = wn * 128 + rc * 8;                       // this lane's column inside the tile (+ nh * 64)
+    const int vy = (rr * (int)ldy + ncol) * 2;
+    int vr[2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      int c = ncol + nh * 64;
+      c = c < N - 8 - n0 ? c : N - 8 - n0;                    // clamped, not predicated (ragged last N tile)
+      vr[nh] = (rr * (int)ldr + c) * 2;
+    }
+    const bool col_ok[2] = {n0 + ncol < N, n0 + ncol + 64 < N};
+    auto res_fetch = [&](auto pass_tag, uint4 (&rv)[4]) {
+      constexpr int pass = decltype(pass_tag)::value, ps = pass >> 1, nh = pass & 1;
+      if constexpr (HAS_RES && pass < 8) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+              rrs, vr[nh], (wm * 128 + ps * 32 + t * 8) * (int)ldr * 2, 0);
+          rv[t] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+      }
+    };
+    auto convert_pass = [&](auto pass_tag) {  // accumulators -> bias, activation, bf16 -> scratch buffer pass & 1
+      constexpr int pass = decltype(pass_tag)::value, ps = pass >> 1, nh = pass & 1;
+      if constexpr (pass < 8) {
+        char* reg = region + (pass & 1) * 4096;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int row = jj * 16 + fr;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4_t c = acc[nh * 4 + i][ps * 2 + jj];
+            acc[nh * 4 + i][ps * 2 + jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};  // ready for the next tile
+            const f32x2_t o01 =
+                act_apply2<ACT>(f32x2_t{c[0], c[1]} + f32x2_t{bv[nh * 4 + i][0], bv[nh * 4 + i][1]});
+            const f32x2_t o23 =
+                act_apply2<ACT>(f32x2_t{c[2], c[3]} + f32x2_t{bv[nh * 4 + i][2], bv[nh * 4 + i][3]});
+            const int unit = (i * 4 + fq) ^ (row & 15);
+            *reinterpret_cast<uint2*>(reg + row * 128 + unit * 8) =
+                make_uint2(pack_bf16x2(o01.x, o01.y), pack_bf16x2(o23.x, o23.y));
+          }
+        }
+      }
+    };
+    auto store_pass = [&](auto pass_tag, const uint4 (&rv)[4]) {
+      constexpr int pass = decltype(pass_tag)::value, ps = pass >> 1, nh = pass & 1;
+      const char* reg = region + (pass & 1) * 4096;
+      uint4 v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // all four read-backs first: one LDS round trip per pass, not four
+        const int row = t * 8 + rr;
+        const int base_unit = ((2 * rc) ^ (row & 15)) & ~1;
+        v[t] = *reinterpret_cast<const uint4*>(reg + row * 128 + base_unit * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if ((t * 8 + rr) & 1) v[t] = make_uint4(v[t].z, v[t].w, v[t].x, v[t].y);
+        if constexpr (HAS_RES)
+          v[t] = make_uint4(bf16x2_add(v[t].x, rv[t].x), bf16x2_add(v[t].y, rv[t].y), bf16x2_add(v[t].z, rv[t].z),
+                            bf16x2_add(v[t].w, rv[t].w));
+        if (col_ok[nh])
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v[t].x, v[t].y, v[t].z, v[t].w}, yrs, vy,
+                                                 ((wm * 128 + ps * 32 + t * 8) * (int)ldy + nh * 64) * 2, 0);
+      }
+    };
+    // (sched_barrier: the compiler otherwise sinks the prefetches down to their first use)
+#define ANEMOI_PIN() __builtin_amdgcn_sched_barrier(0)
+    uint4 rv[3][4];
+    res_fetch(std::integral_constant<int, 0>{}, rv[0]);
+    ANEMOI_PIN();
+    convert_pass(std::integral_constant<int, 0>{});
+    convert_pass(std::integral_constant<int, 1>{});
+    ANEMOI_PIN();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's slabs 0 / 1 have landed (and residual pass 0)
+    ANEMOI_PIN();
+    res_fetch(std::integral_constant<int, 1>{}, rv[1]);
+    res_fetch(std::integral_constant<int, 2>{}, rv[2]);
+    ANEMOI_PIN();
+    store_pass(std::integral_constant<int, 0>{}, rv[0]);
+    ANEMOI_PIN();
+    res_fetch(std::integral_constant<int, 3>{}, rv[0]);
+    ANEMOI_PIN();
+    static_for_seq(
+        [&](auto q_tag) {
+          constexpr int p = decltype(q_tag)::value + 1;
+          convert_pass(std::integral_constant<int, p + 1>{});
+          ANEMOI_PIN();
+          store_pass(std::integral_constant<int, p>{}, rv[p % 3]);
+          ANEMOI_PIN();
+          if constexpr (p >= 1) res_fetch(std::integral_constant<int, p + 3>{}, rv[p % 3]);
+          ANEMOI_PIN();
+        },
+        std::make_integer_sequence<int, 7>{});
+#undef ANEMOI_PIN
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+}
+
+// =============================================================================================
 // Same tile and epilogue, deeper software pipeline: four 32 KiB LDS stages of K = 32 (64-byte rows), three
 // half-slabs of LDS-DMA always in flight, COUNTED s_waitcnt vmcnt(8|4|0) (never a drain in steady state) and raw
 // s_barrier -- the __syncthreads() of the two-stage kernel drains vmcnt(0) every slab, which exposes the ~1.5 us
@@ -687,12 +1003,26 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256x4_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS) != hipSuccess)
       return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", BIG_LDS);
+#define RAISE_W4(A, RES)                                                                          \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES>),          \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)      \
+    return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
+    RAISE_W4(0, false);
+    RAISE_W4(0, true);
+    RAISE_W4(1, false);
+    RAISE_W4(1, true);
+    RAISE_W4(2, false);
+    RAISE_W4(2, true);
+    RAISE_W4(3, false);
+    RAISE_W4(3, true);
+#undef RAISE_W4
     raised = true;
   }
-  static const int variant = [] {  // ANEMOI_AMD_GEMM_VARIANT: 2 = two-stage (default), 4 = four-stage counted-vmcnt pipeline.  Measured equal
-  // within 3 %: the main loop is bound by the ~45 GB/s/CU global->LDS DMA rate, not by its latency
+  // ANEMOI_AMD_GEMM_VARIANT: 1 = four waves x (128 x 128), AGPR accumulators (default; needs K >= 128);
+  // 2 = eight waves x (128 x 64), two LDS stages; 4 = eight waves, four K = 32 stages with counted vmcnt.
+  static const int variant = [] {
     const char* e = getenv("ANEMOI_AMD_GEMM_VARIANT");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 1;
   }();
   const int64_t mt = (M + BIG_M - 1) / BIG_M;
   const int64_t nt = (N + BIG_N - 1) / BIG_N;
@@ -706,6 +1036,28 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   }();
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
+  if (variant == 1 && K >= 128 && ldx < (int64_t)1 << 22 && ldy < (int64_t)1 << 22 && ldr < (int64_t)1 << 22 && vec_ok &&
+      M % BIG_M == 0) {
+#define LAUNCH_W4_(A, RES)                                                                                   \
+  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES>), dim3((unsigned)blocks), dim3(256), W4_LDS, st,         \
+                     static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,                \
+                     static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K,       \
+                     vec_ok ? 1 : 0, mt * nt, (int)nt)
+#define LAUNCH_W4(A)                              \
+  do {                                            \
+    if (residual != nullptr) LAUNCH_W4_(A, true); \
+    else LAUNCH_W4_(A, false);                    \
+  } while (0)
+    switch (act) {
+      case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU); break;
+      case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU); break;
+      case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU); break;
+      default: LAUNCH_W4(ANEMOI_ACT_NONE); break;
+    }
+#undef LAUNCH_W4
+#undef LAUNCH_W4_
+    return check_launch("anemoi_linear(256x256, 4 waves)");
+  }
   if (variant == 4) {
     hipLaunchKernelGGL(linear_bf16_256x4_kernel, dim3((unsigned)blocks), dim3(512), Q_LDS, st,
                        static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,

@@ -20,6 +20,20 @@ for m, n, k in SHAPES:
     b = torch.randn(n, device=dev)
     r = torch.randn(m, n, device=dev).bfloat16()
     out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+    if os.environ.get("GEMM_BENCH_BLASLT", "1") != "0":  # library yardstick: torch.nn.functional.linear -> hipBLASLt
+        bb = b.bfloat16()
+        for _ in range(3):
+            torch.nn.functional.linear(x, w, bb)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            torch.nn.functional.linear(x, w, bb)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / 10
+        print(f"M={m:7d} N={n:5d} K={k:5d} hipBLASLt (torch F.linear + bias)  {ms:8.4f} ms  "
+              f"{2 * m * n * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
     for act, res in (("Identity", None), ("GELU", None), ("Identity", r)):
         for _ in range(3):
             ops.linear(x, w, b, act=act, residual=res, out=out)
