@@ -275,15 +275,17 @@ __device__ __forceinline__ f32x2_t act_apply2(f32x2_t x) {
 // L2 instead of 18 for 2 x 16).  Measured on MI355X: no gain (-3 %) over the plain row-major order, so the group
 // width is "unbounded" (= plain order); kept as a documented experiment.
 constexpr int SUPER_N = 1 << 20;
-__device__ __forceinline__ void tile_coords(int64_t t, int nt_count, int64_t mt_count, int64_t& mt, int& nt) {
-  const int full = nt_count / SUPER_N, rem = nt_count % SUPER_N;
-  const int64_t per_group = mt_count * SUPER_N;
-  if (t < full * per_group) {
-    const int64_t cg = t / per_group, r = t % per_group;
+__device__ __forceinline__ void tile_coords(int64_t t64, int nt_count, int64_t mt_count64, int64_t& mt, int& nt) {
+  // tile counts fit 31 bits (checked by the launcher): 32-bit divisions (the 64-bit ones are ~200 instructions each)
+  const unsigned t = (unsigned)t64, mt_count = (unsigned)mt_count64;
+  const unsigned full = (unsigned)nt_count / SUPER_N, rem = (unsigned)nt_count % SUPER_N;
+  const unsigned per_group = mt_count * SUPER_N;
+  if (full != 0 && t < full * per_group) {
+    const unsigned cg = t / per_group, r = t % per_group;
     mt = r / SUPER_N;
     nt = (int)(cg * SUPER_N + r % SUPER_N);
   } else {
-    const int64_t r = t - full * per_group;
+    const unsigned r = t - full * per_group;
     mt = r / rem;
     nt = (int)(full * SUPER_N + r % rem);
   }

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Regenerates the round's measurement evidence ON THE GPU BOX (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r01'
+# Writes gpurun_out/profiles_<tag>/ (small text/JSON/CSV only); tools/update_profiles.py then copies the
+# summaries into profiles/ (tracked).  PMC passes are separate runs with --kernel-trace only (see MI355X_MICROARCH.md).
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+cd "$ROOT"
+python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_cfg3_bf16.json" 2> "$OUT/bench_cfg3_bf16.err"
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail > "$OUT/bench_cfg3_bf16_detail.txt" 2>&1
+python3 bench.py --workload cfg1 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/bench_cfg1_bf16.json" 2>/dev/null
+python3 bench.py --workload cfg2 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/bench_cfg2_bf16.json" 2>/dev/null
+python3 bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_cfg3_fp32.json" 2>/dev/null
+
+cd /tmp
+rm -rf /tmp/kt /tmp/pmcf /tmp/pmcw
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 "$ROOT/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > "$OUT/rocprof_bench.log" 2>&1
+cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null
+python3 "$ROOT/tools/summarize_trace.py" /tmp/kt > "$OUT/kernel_summary.txt" 2>&1
+
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcf -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 "$ROOT/tools/pmc_summary.py" /tmp/pmcf > "$OUT/pmc_fetch_size.txt" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcw -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 "$ROOT/tools/pmc_summary.py" /tmp/pmcw > "$OUT/pmc_write_size.txt" 2>&1
+ls -la "$OUT"
