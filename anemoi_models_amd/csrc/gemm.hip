@@ -270,25 +270,24 @@ __device__ __forceinline__ f32x2_t act_apply2(f32x2_t x) {
   }
 }
 
-// Tile order inside an XCD chunk: column groups of SUPER_N tile columns, row-major inside a group.  SUPER_N = 8 would
-// make the 32 tiles an XCD works on concurrently a 4 x 8 patch of the output (12 unique operand panels in that XCD's
-// L2 instead of 18 for 2 x 16).  Measured on MI355X: no gain (-3 %) over the plain row-major order, so the group
-// width is "unbounded" (= plain order); kept as a documented experiment.
-constexpr int SUPER_N = 1 << 20;
+// Tile order inside an XCD chunk: column groups of SUPER_N tile columns, row-major inside a group.  With SUPER_N = 8
+// the 32 tiles an XCD works on concurrently form a 4 x 8 patch of the output: 12 unique operand panels per K-slab step
+// in that XCD's L2 instead of 18 for the 2 x 16 patch of the plain order.  The eight-wave kernel did not care (-3 %);
+// the four-wave kernel stages 64 KiB per ~1.4 us and CU (~48 GB/s, what an L2 MISS stream sustains per CU) and gains
+// +11 % at 8192^3, +2..6 % at the model's shapes (SUPER_N 4 / 16 / unbounded measured: 1437 / 1396 / 1343 vs 1489).
+constexpr int SUPER_N = 8;
 __device__ __forceinline__ void tile_coords(int64_t t64, int nt_count, int64_t mt_count64, int64_t& mt, int& nt) {
-  // tile counts fit 31 bits (checked by the launcher): 32-bit divisions (the 64-bit ones are ~200 instructions each)
+  // tile counts fit 31 bits (checked by the launcher): 32-bit divisions (the 64-bit ones are ~200 instructions each).
+  // Column groups of SUPER_N tile columns, row-major inside a group; the last group takes the remainder (8..15 wide).
   const unsigned t = (unsigned)t64, mt_count = (unsigned)mt_count64;
-  const unsigned full = (unsigned)nt_count / SUPER_N, rem = (unsigned)nt_count % SUPER_N;
+  const unsigned groups = (unsigned)nt_count / SUPER_N > 1 ? (unsigned)nt_count / SUPER_N : 1;
   const unsigned per_group = mt_count * SUPER_N;
-  if (full != 0 && t < full * per_group) {
-    const unsigned cg = t / per_group, r = t % per_group;
-    mt = r / SUPER_N;
-    nt = (int)(cg * SUPER_N + r % SUPER_N);
-  } else {
-    const unsigned r = t - full * per_group;
-    mt = r / rem;
-    nt = (int)(full * SUPER_N + r % rem);
-  }
+  unsigned cg = t / per_group;
+  if (cg > groups - 1) cg = groups - 1;
+  const unsigned r = t - cg * per_group;
+  const unsigned width = cg == groups - 1 ? (unsigned)nt_count - cg * SUPER_N : (unsigned)SUPER_N;
+  mt = r / width;
+  nt = (int)(cg * SUPER_N + r % width);
 }
 
 // unaligned / ragged-N tail of one 8-column output segment (cold path, kept out of line)
@@ -498,8 +497,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
 // Operand rows beyond M / N are never loaded: the staging goes through buffer descriptors sized to the tile's
 // valid rows (out-of-range lanes of buffer_load ... lds deliver zeros).
 // =============================================================================================
-constexpr int W4_EPI = 4 * 8192;                    // two 4 KiB epilogue scratch buffers per wave
-constexpr int W4_LDS = 2 * BIG_STAGE + W4_EPI;      // 160 KiB: the whole LDS of a CU
+constexpr int W4_LDS = 2 * BIG_STAGE + 1024;        // 129 KiB: two slab buffers + the tile's bias, no epilogue scratch
 
 #define ANEMOI_MFMA_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 
@@ -527,6 +525,11 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
 
   // ---- staging side.  Wave w fills LDS rows w * 64 + 8 i + (lane >> 3), i = 0..7, of both operand panels; the
   //      source chunk is swizzled with the LDS row ((row >> 1) & 7 = (4 i + (lane >> 4)) & 7: two classes, i even/odd).
+  //      The x panel is staged row for row.  The W panel is staged PERMUTED inside every 32-row group,
+  //      LDS row 32 g + l  <-  W row 32 g + 8 ((l & 15) >> 2) + 4 (l >> 4) + (l & 3),
+  //      so that the two 16-row fragments of a group give each lane EIGHT adjacent output columns (fq * 8 + 0..7): the
+  //      epilogue stores 16 bytes per lane straight from the MFMA layout, no LDS transposition.  For the staging lane
+  //      (l = 8 (i & 3) + (lane >> 3)) the permuted row splits into a lane part and a wave-uniform part.
   const int srow = lane >> 3, scp = lane & 7;
   int vox[2], vow[2];
 #pragma unroll
@@ -534,9 +537,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     const int r = 8 * p + srow;
     const int c = swz(r, scp);
     vox[p] = r * (int)ldx * 2 + c * 16;
-    vow[p] = r * K * 2 + c * 16;
+    vow[p] = (8 * (srow >> 2) + (srow & 3)) * K * 2 + c * 16;
   }
-  const int xrow16 = 16 * (int)ldx * 2, wrow16 = 16 * K * 2;
+  const int xrow16 = 16 * (int)ldx * 2;
   const int xwave = wid * 64 * (int)ldx * 2, wwave = wid * 64 * K * 2;
   __amdgpu_buffer_rsrc_t xrs, wrs;  // descriptors of the tile whose slabs are being staged
   auto set_tile = [&](int64_t tile) {
@@ -560,7 +563,8 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   };
   auto dma_w = [&](int i, int kt, char* dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, vow[i & 1],
-                                             wwave + (i >> 1) * wrow16 + kt * ROW_BYTES, 0, 0);
+                                             wwave + (32 * (i >> 2) + 16 * (i & 1) + 4 * ((i >> 1) & 1)) * K * 2 + kt * ROW_BYTES,
+                                             0, 0);
   };
   auto stage_all = [&](int kt, int buf) {
     char* xs = smem + buf * BIG_STAGE + wid * 8192;
@@ -583,9 +587,6 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     const int row = wm * 128 + j * 16 + fr;
     return *reinterpret_cast<const bf16x8_t*>(smem + buf * BIG_STAGE + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
   };
-  char* region = smem + 2 * BIG_STAGE + wid * 8192;
-  const int rc = lane & 7, rr = lane >> 3;
-
   f32x4_t acc[8][8];
   bf16x8_t a0[8], b0[8], a1[8], b1[8];
 
@@ -603,34 +604,50 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   }
   stage_all(1, 1);
 
+  // A zero fragment for the MFMA-pipe zeroing of accumulators (D = 0 * 0 + 0), made opaque ONCE here: left a known
+  // constant, the compiler re-materialises it (v_mov) directly in front of the inline-asm MFMA that reads it -- a
+  // VALU-write -> MFMA-read hazard it does not see: stale operands, garbage instead of zeros.
+  bf16x8_t zfrag = {0, 0, 0, 0, 0, 0, 0, 0};
+  asm volatile("" : "+v"(zfrag));
+  asm volatile("s_nop 3" ::: "memory");
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc[i][j]) : "v"(zfrag));
 
+  // ONE loop over the workgroup's slab stream (tile prologue and epilogue are conditional blocks inside it): with a
+  // K loop nested in a tile loop the register allocator gave the accumulators different AGPRs inside and outside the
+  // inner loop and permuted all 256 of them (v_accvgpr_mov) at its exits -- 1k cycles per tile, and placed directly
+  // behind the last inline-asm MFMAs, whose write latency the compiler does not know: wrong values.
   int g = 0;  // running slab counter over all tiles of this workgroup: LDS stage = g & 1
-  for (int64_t li = bix; li < chunk_len; li += bpx) {
-    const int64_t tile = chunk_start + li;
-    const bool has_next = li + bpx < chunk_len;
-    int64_t mt_;
-    int nt_;
-    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
-    const int64_t m0 = mt_ * BIG_M;
-    const int n0 = nt_ * BIG_N;
-
-    float bv[8][4];  // bias of this lane's 8 x 4 output columns, requested a whole K loop before its use
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int nb = n0 + wn * 128 + i * 16 + fq * 4;
-      nb = nb < N - 4 ? nb : N - 4;  // clamped, not predicated: columns >= N are never stored
+  int64_t li = bix, tile = 0, m0 = 0;
+  int k = 0, n0 = 0;
+  bool has_next = false;
+  for (;;) {
+    if (k == 0) {
+      tile = chunk_start + li;
+      has_next = li + bpx < chunk_len;
+      int64_t mt_;
+      int nt_;
+      tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+      m0 = mt_ * BIG_M;
+      n0 = nt_ * BIG_N;
+      // The tile's 256 bias values go to LDS by one 4-byte LDS-DMA per wave (columns >= N: zeros from the descriptor's
+      // range check) and come back in the epilogue: 32 bias registers per lane would not survive the K loop unspilled.
       if (bias != nullptr) {
-        VecIO<float, 4>::load(bias + nb, bv[i]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[i][r] = 0.f;
+        const int nbias = N - n0 < BIG_N ? N - n0 : BIG_N;
+        const __amdgpu_buffer_rsrc_t brs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(bias + n0), 0, nbias * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            brs, (__attribute__((address_space(3))) void*)(smem + 2 * BIG_STAGE + wid * 256), 4, lane * 4, wid * 256, 0,
+            0);
       }
+      // accumulator zeroing (prologue / previous epilogue, MFMA pipe) -> first MFMA: pinned on both sides
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_nop 7" ::: "memory");  // AGPR zeroing (prologue / previous epilogue) -> first MFMA: hazards are ours
 
     // One slab = 128 MFMAs; the slab two ahead in the stream (this tile's or the next one's) is staged meanwhile.  The
     // control flow is one plain loop on purpose: with alternative slab bodies the accumulators' phi nodes fall out of
@@ -674,125 +691,124 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
           std::make_integer_sequence<int, 128>{});
       ++g;
     };
-    for (int k = 0; k < nk; ++k) {
-      if (k == nk - 2) {  // from here on the staged slabs are the next tile's
-        if (has_next) set_tile(tile + bpx);
-        else set_null();
-      }
-      slab(k + 2 < nk ? k + 2 : k + 2 - nk, k != 0 || li == bix);
+    if (k == nk - 2) {  // from here on the staged slabs are the next tile's
+      if (has_next) set_tile(tile + bpx);
+      else set_null();
     }
+    slab(k + 2 < nk ? k + 2 : k + 2 - nk, k != 0 || li == bix);
+    ++k;
+    if (k < nk) continue;
+    k = 0;
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA -> accumulator reads below
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue: 8 passes (4 row groups x 2 column halves) of [32 rows][64 cols] through two 4 KiB scratch
-    //      buffers per wave (8-byte units XOR-swizzled), read back as whole 128-byte output row segments (16 B per
-    //      lane).  With one wave per SIMD nothing else hides latency here, so this is straight-line code (the launcher
-    //      guarantees M % 256 == 0, N % 8 == 0 and 16-byte alignment: the only guard left is the column mask of a
-    //      ragged last N tile, loads are clamped instead of predicated) and the passes are software-pipelined by hand:
-    //      pass p + 1 is converted and written to LDS before pass p is read back and stored, the residual is requested
-    //      up to three passes ahead, the bias a whole K loop ahead.  The next tile's first two slabs are in flight
-    //      meanwhile; they are waited for BEFORE the first store is issued, so that the next slab's counted vmcnt never
-    //      has to wait behind this tile's 32 stores per lane (vmcnt has no separate store counter).
-    // Output / residual go through buffer descriptors of the tile (one lane-offset VGPR each, the (pass, row group)
-    // part in an SGPR): 64-bit per-access pointers would cost > 100 VGPRs here and spill.
+    // ---- epilogue, straight from the MFMA layout: for row group j (rows j * 16 + fr) and column group u the lane
+    //      holds acc[2 u][j] and acc[2 u + 1][j] = eight adjacent columns (W staging permutation above): bias, activation,
+    //      bf16, residual, one 16-byte store; a store instruction covers 16 rows x 64 bytes.  With one wave per SIMD
+    //      nothing else hides latency here, so this is straight-line code (the launcher guarantees M % 256 == 0,
+    //      N % 8 == 0 and 16-byte alignment: the only guard left is the column mask of a ragged last N tile, loads are
+    //      clamped instead of predicated); the residual is requested two row groups ahead, the bias a whole K loop
+    //      ahead.  The next tile's first two slabs are in flight meanwhile; they are waited for BEFORE the first store
+    //      is issued, so that the next slab's counted vmcnt never has to wait behind this tile's 32 stores per lane
+    //      (vmcnt has no separate store counter).  Output / residual go through buffer descriptors of the tile (one
+    //      lane-offset VGPR each, the row-group part in an SGPR): 64-bit per-access pointers would spill here.
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-    const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs =  // sized to the tile: masked lanes use an out-of-range offset (store dropped)
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, BIG_M * (int)ldy * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, 0x7fffffff, 0x00020000);
-    const int ncol = wn * 128 + rc * 8;                       // this lane's column inside the tile (+ nh * 64)
-    const int vy = (rr * (int)ldy + ncol) * 2;
-    int vr[2];
+    int fr_e = fr, fq_e = fq;  // opaque copies: keeps the epilogue's lane offsets from being hoisted above the K loop
+    asm volatile("" : "+v"(fr_e), "+v"(fq_e));  // (a single VGPR spilled there costs a vmcnt(0) per reload here)
+    const int ncol = wn * 128 + fq_e * 8;  // this lane's column inside the tile (+ 32 u)
+    int vy[4], vr[4];
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-      int c = ncol + nh * 64;
-      c = c < N - 8 - n0 ? c : N - 8 - n0;                    // clamped, not predicated (ragged last N tile)
-      vr[nh] = (rr * (int)ldr + c) * 2;
+    for (int u = 0; u < 4; ++u) {
+      int c = ncol + u * 32;
+      vy[u] = n0 + c < N ? (fr_e * (int)ldy + c) * 2 : 0x7f000000;  // ragged last N tile: beyond the descriptor
+      c = c < N - 8 - n0 ? c : N - 8 - n0;                          // loads: clamped instead
+      vr[u] = (fr_e * (int)ldr + c) * 2;
     }
-    const bool col_ok[2] = {n0 + ncol < N, n0 + ncol + 64 < N};
-    auto res_fetch = [&](auto pass_tag, uint4 (&rv)[4]) {
-      constexpr int pass = decltype(pass_tag)::value, ps = pass >> 1, nh = pass & 1;
-      if constexpr (HAS_RES && pass < 8) {
+    float bv[4][8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-              rrs, vr[nh], (wm * 128 + ps * 32 + t * 8) * (int)ldr * 2, 0);
-          rv[t] = make_uint4(v.x, v.y, v.z, v.w);
+    for (int u = 0; u < 4; ++u) {
+      if (bias != nullptr) {
+        VecIO<float, 8>::load(reinterpret_cast<const float*>(smem + 2 * BIG_STAGE) + ncol + u * 32, bv[u]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bv[u][r] = 0.f;
+      }
+    }
+    auto res_fetch = [&](auto j_tag, uint4 (&rv)[4]) {
+      constexpr int j = decltype(j_tag)::value;
+      if constexpr (HAS_RES && j < 8) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrs, vr[u], (wm * 128 + j * 16) * (int)ldr * 2, 0);
+          rv[u] = make_uint4(v.x, v.y, v.z, v.w);
         }
       }
     };
-    auto convert_pass = [&](auto pass_tag) {  // accumulators -> bias, activation, bf16 -> scratch buffer pass & 1
-      constexpr int pass = decltype(pass_tag)::value, ps = pass >> 1, nh = pass & 1;
-      if constexpr (pass < 8) {
-        char* reg = region + (pass & 1) * 4096;
+    // Row group j's accumulators are "touched" by an empty volatile asm first: the reads below then cannot be hoisted
+    // above it (left alone, the compiler reads all 256 accumulators into VGPRs right behind the K loop -- ahead of the
+    // hazard fence -- shuffles the overflow through v_accvgpr_mov and was observed to deliver wrong values).  They are
+    // zeroed for the next tile through the idle MFMA pipe (D = 0 * 0 + 0): an asm in program order, no v_accvgpr_write
+    // rematerialised next to the first MFMA of the next tile.
+    auto store_rows = [&](auto j_tag, const uint4 (&rv)[4]) {
+      constexpr int j = decltype(j_tag)::value;
+      f32x4_t c[8];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int row = jj * 16 + fr;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4_t c = acc[nh * 4 + i][ps * 2 + jj];
-            acc[nh * 4 + i][ps * 2 + jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};  // ready for the next tile
-            const f32x2_t o01 =
-                act_apply2<ACT>(f32x2_t{c[0], c[1]} + f32x2_t{bv[nh * 4 + i][0], bv[nh * 4 + i][1]});
-            const f32x2_t o23 =
-                act_apply2<ACT>(f32x2_t{c[2], c[3]} + f32x2_t{bv[nh * 4 + i][2], bv[nh * 4 + i][3]});
-            const int unit = (i * 4 + fq) ^ (row & 15);
-            *reinterpret_cast<uint2*>(reg + row * 128 + unit * 8) =
-                make_uint2(pack_bf16x2(o01.x, o01.y), pack_bf16x2(o23.x, o23.y));
-          }
-        }
-      }
-    };
-    auto store_pass = [&](auto pass_tag, const uint4 (&rv)[4]) {
-      constexpr int pass = decltype(pass_tag)::value, ps = pass >> 1, nh = pass & 1;
-      const char* reg = region + (pass & 1) * 4096;
-      uint4 v[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {  // all four read-backs first: one LDS round trip per pass, not four
-        const int row = t * 8 + rr;
-        const int base_unit = ((2 * rc) ^ (row & 15)) & ~1;
-        v[t] = *reinterpret_cast<const uint4*>(reg + row * 128 + base_unit * 8);
+      for (int i = 0; i < 8; ++i) {
+        asm volatile("" : "+a"(acc[i][j]));
+        c[i] = acc[i][j];
+        asm volatile("" : "+v"(c[i]));  // the copy is IN VGPRs here, before the accumulator's register is zeroed in place
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if ((t * 8 + rr) & 1) v[t] = make_uint4(v[t].z, v[t].w, v[t].x, v[t].y);
+      for (int i = 0; i < 8; ++i)  // "+a": the zeroed value keeps the accumulator's register (no copies at the loop edges)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "+a"(acc[i][j]) : "v"(zfrag));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4_t c0 = c[2 * u], c1 = c[2 * u + 1];
+        const f32x2_t o0 = act_apply2<ACT>(f32x2_t{c0[0], c0[1]} + f32x2_t{bv[u][0], bv[u][1]});
+        const f32x2_t o1 = act_apply2<ACT>(f32x2_t{c0[2], c0[3]} + f32x2_t{bv[u][2], bv[u][3]});
+        const f32x2_t o2 = act_apply2<ACT>(f32x2_t{c1[0], c1[1]} + f32x2_t{bv[u][4], bv[u][5]});
+        const f32x2_t o3 = act_apply2<ACT>(f32x2_t{c1[2], c1[3]} + f32x2_t{bv[u][6], bv[u][7]});
+        uint4 v = make_uint4(pack_bf16x2(o0.x, o0.y), pack_bf16x2(o1.x, o1.y), pack_bf16x2(o2.x, o2.y),
+                             pack_bf16x2(o3.x, o3.y));
         if constexpr (HAS_RES)
-          v[t] = make_uint4(bf16x2_add(v[t].x, rv[t].x), bf16x2_add(v[t].y, rv[t].y), bf16x2_add(v[t].z, rv[t].z),
-                            bf16x2_add(v[t].w, rv[t].w));
-        if (col_ok[nh])
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v[t].x, v[t].y, v[t].z, v[t].w}, yrs, vy,
-                                                 ((wm * 128 + ps * 32 + t * 8) * (int)ldy + nh * 64) * 2, 0);
+          v = make_uint4(bf16x2_add(v.x, rv[u].x), bf16x2_add(v.y, rv[u].y), bf16x2_add(v.z, rv[u].z),
+                         bf16x2_add(v.w, rv[u].w));
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, yrs, vy[u],
+                                               (wm * 128 + j * 16) * (int)ldy * 2, 0);
+        // Observed on gfx950: a 16-byte buffer store whose data registers are overwritten by the very next VALU
+        // instruction stores the new value in part of dword 1 (lanes 12..15 of every 16).  The compiler pads this hazard
+        // with one wait state except when soffset is an SGPR (as here), where it assumes none: pad by hand.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
     // (sched_barrier: the compiler otherwise sinks the prefetches down to their first use)
 #define ANEMOI_PIN() __builtin_amdgcn_sched_barrier(0)
     uint4 rv[3][4];
     res_fetch(std::integral_constant<int, 0>{}, rv[0]);
-    ANEMOI_PIN();
-    convert_pass(std::integral_constant<int, 0>{});
-    convert_pass(std::integral_constant<int, 1>{});
-    ANEMOI_PIN();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's slabs 0 / 1 have landed (and residual pass 0)
-    ANEMOI_PIN();
     res_fetch(std::integral_constant<int, 1>{}, rv[1]);
-    res_fetch(std::integral_constant<int, 2>{}, rv[2]);
     ANEMOI_PIN();
-    store_pass(std::integral_constant<int, 0>{}, rv[0]);
-    ANEMOI_PIN();
-    res_fetch(std::integral_constant<int, 3>{}, rv[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's slabs 0 / 1 have landed (and residual rows 0, 1)
     ANEMOI_PIN();
     static_for_seq(
-        [&](auto q_tag) {
-          constexpr int p = decltype(q_tag)::value + 1;
-          convert_pass(std::integral_constant<int, p + 1>{});
+        [&](auto j_tag) {
+          constexpr int j = decltype(j_tag)::value;
+          res_fetch(std::integral_constant<int, j + 2>{}, rv[(j + 2) % 3]);
           ANEMOI_PIN();
-          store_pass(std::integral_constant<int, p>{}, rv[p % 3]);
-          ANEMOI_PIN();
-          if constexpr (p >= 1) res_fetch(std::integral_constant<int, p + 3>{}, rv[p % 3]);
+          store_rows(j_tag, rv[j % 3]);
           ANEMOI_PIN();
         },
-        std::make_integer_sequence<int, 7>{});
+        std::make_integer_sequence<int, 8>{});
 #undef ANEMOI_PIN
+    li += bpx;
+    if (li >= chunk_len) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
@@ -1038,7 +1054,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   }();
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
-  if (variant == 1 && K >= 128 && ldx < (int64_t)1 << 22 && ldy < (int64_t)1 << 22 && ldr < (int64_t)1 << 22 && vec_ok &&
+  if (variant == 1 && K >= 128 && ldx < (int64_t)1 << 21 && ldy < (int64_t)1 << 21 && ldr < (int64_t)1 << 21 && vec_ok &&
       M % BIG_M == 0) {
 #define LAUNCH_W4_(A, RES)                                                                                   \
   hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES>), dim3((unsigned)blocks), dim3(256), W4_LDS, st,         \
