@@ -123,7 +123,7 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False):
         achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype_name]
         out["roofline"] = {
-            "kernel": "anemoi::linear_kernel (fused Linear, MFMA)", "bound": "mfma", "achieved": round(achieved, 2),
+            "kernel": "anemoi::linear_bf16_w4_kernel / linear_kernel (anemoi_linear: fused Linear, MFMA)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
             "launches": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
             "flops_per_launch": a["flops"] / a["launches"], "bytes_per_launch": a["bytes"] / a["launches"],
