@@ -118,6 +118,93 @@ static int layer_norm_launch(const void* x, int64_t ldx, const float* gamma, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// LayerNorm statistics only: stats[r] = { rstd_r, -mean_r * rstd_r }.  The normalisation itself is folded into the
+// Linear that consumes the LayerNorm (anemoi_linear_ln): one read of x instead of a read + a write + a re-read.
+// Same arithmetic as layer_norm_kernel (row in registers, two-pass f32 statistics).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, int ITEMS>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, int64_t ldx, float2* __restrict__ stats,
+                                                        int64_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float v[ITEMS][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int c = (i * 64 + lane) * VEC;
+    if (c < C) {
+      VecIO<T, VEC>::load(xr + c, v[i]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s += v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int c = (i * 64 + lane) * VEC;
+    if (c < C) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) stats[row] = make_float2(rstd, -mean * rstd);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_generic_kernel(const T* __restrict__ x, int64_t ldx,
+                                                                float2* __restrict__ stats, int64_t rows, int C,
+                                                                float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += Elem<T>::load(xr + c);
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = Elem<T>::load(xr + c) - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) stats[row] = make_float2(rstd, -mean * rstd);
+}
+
+template <typename T>
+static int row_stats_launch(const void* x, int64_t ldx, float* stats, int64_t rows, int C, float eps, hipStream_t st) {
+  constexpr int VMAX = 16 / sizeof(T);
+  const T* xp = static_cast<const T*>(x);
+  float2* sp = reinterpret_cast<float2*>(stats);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const bool aligned = (C % VMAX == 0) && (ldx % VMAX == 0) && ((uintptr_t)x % 16 == 0);
+  const int per_pass = 64 * VMAX;
+  const int items = (C + per_pass - 1) / per_pass;
+#define RS_CASE(I)                                                                                          \
+  case I:                                                                                                   \
+    hipLaunchKernelGGL((row_stats_kernel<T, VMAX, I>), grid, block, 0, st, xp, ldx, sp, rows, C, eps);      \
+    break;
+  if (aligned && items <= 8) {
+    switch (items) {
+      RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+    }
+  } else {
+    hipLaunchKernelGGL((row_stats_generic_kernel<T>), grid, block, 0, st, xp, ldx, sp, rows, C, eps);
+  }
+#undef RS_CASE
+  return check_launch("anemoi_row_stats");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Input assembly: out[(b,ens,g), :] = [x[b,:,ens,g,:] (time-major) | latlons[g] | trainable[g] | 0]
 // One thread per output element; consecutive threads write consecutive columns (coalesced store),
 // reads of x are contiguous runs of V floats.
@@ -239,6 +326,18 @@ int anemoi_layer_norm(int dtype, const void* x, int64_t ldx, const float* gamma,
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm: dtype %d", dtype);
 }
 
+int anemoi_row_stats(int dtype, const void* x, int64_t ldx, float* stats, int64_t rows, int C, float eps,
+                     anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && stats, ANEMOI_ERR_INVALID, "anemoi_row_stats: null pointer");
+  ANEMOI_REQUIRE(C > 0 && rows >= 0 && ldx >= C, ANEMOI_ERR_INVALID, "anemoi_row_stats: bad shape rows=%lld C=%d ldx=%lld",
+                 (long long)rows, C, (long long)ldx);
+  ANEMOI_REQUIRE((uintptr_t)stats % 8 == 0, ANEMOI_ERR_INVALID, "anemoi_row_stats: stats must be 8-byte aligned");
+  if (rows == 0) return ANEMOI_OK;
+  if (dtype == ANEMOI_F32) return row_stats_launch<float>(x, ldx, stats, rows, C, eps, as_stream(stream));
+  if (dtype == ANEMOI_BF16) return row_stats_launch<bf16_t>(x, ldx, stats, rows, C, eps, as_stream(stream));
+  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_row_stats: dtype %d", dtype);
+}
+
 int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
                           int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo,
                           anemoi_stream_t stream) {
@@ -324,7 +423,7 @@ int anemoi_prognostic_residual(float* y, int V_out, const float* x, int B, int T
   return check_launch("anemoi_prognostic_residual");
 }
 
-int anemoi_abi_version(void) { return 2; }
+int anemoi_abi_version(void) { return 3; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

@@ -37,21 +37,37 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// LayerNorm folded into the Linear that consumes it (anemoi_linear_ln): with W' = W * gamma (columns scaled),
+// s[n] = sum_k W'[n,k] and stats[m] = { rstd_m, -mean_m rstd_m },
+//   LN(x) W^T + b  =  rstd_m (x W'^T)[m,n] + (-mean_m rstd_m) s[n] + (b + W beta)[n]
+// i.e. the accumulator is scaled per row and shifted per (row, column) before bias / activation.
+struct LnFold {
+  const float* colsum;  // s[n], nullptr = plain Linear
+  const float2* stats;  // per row of x
+};
+
 template <typename T, typename TO, int VEC>
 __device__ __forceinline__ void epilogue_store(const float (&acc)[VEC], int64_t m, int n, int64_t M, int N,
                                                const float* __restrict__ bias, const T* __restrict__ R, int64_t ldr,
-                                               TO* __restrict__ Y, int64_t ldy, int act, bool vec_ok) {
+                                               TO* __restrict__ Y, int64_t ldy, int act, bool vec_ok, LnFold ln) {
   if (m >= M || n >= N) return;
   float o[VEC];
+  float2 st = make_float2(1.f, 0.f);
+  if (ln.stats != nullptr) st = ln.stats[m];
   if (vec_ok && n + VEC <= N) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = acc[i];
+    if (ln.stats != nullptr) {
+      float sv[VEC];
+      VecIO<float, VEC>::load(ln.colsum + n, sv);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = fmaf(o[i], st.x, st.y * sv[i]);
+    }
     if (bias != nullptr) {
       float b[VEC];
       VecIO<float, VEC>::load(bias + n, b);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] = acc[i] + b[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] = acc[i];
+      for (int i = 0; i < VEC; ++i) o[i] += b[i];
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = act_apply(o[i], act);
@@ -66,7 +82,9 @@ __device__ __forceinline__ void epilogue_store(const float (&acc)[VEC], int64_t 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       if (n + i < N) {
-        float t = acc[i] + (bias != nullptr ? bias[n + i] : 0.f);
+        float t = acc[i];
+        if (ln.stats != nullptr) t = fmaf(t, st.x, st.y * ln.colsum[n + i]);
+        t += (bias != nullptr ? bias[n + i] : 0.f);
         t = act_apply(t, act);
         if (R != nullptr) t += Elem<T>::load(R + m * ldr + n + i);
         Elem<TO>::store(Y + m * ldy + n + i, t);
@@ -79,7 +97,7 @@ template <typename T, typename TO>
 __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W,
                                                      const float* __restrict__ bias, const T* __restrict__ R,
                                                      int64_t ldr, TO* __restrict__ Y, int64_t ldy, int64_t M, int N,
-                                                     int K, int act, int vec_ok) {
+                                                     int K, int act, int vec_ok, LnFold ln) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // 2 stages x (x tile + W tile) = 64 KiB
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, in
         const int64_t m = m0 + wr * 64 + j * 16 + fr;
         const int n = n0 + wc * 64 + i * 16 + fq * 4;
         const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        epilogue_store<T, TO, 4>(v, m, n, M, N, bias, R, ldr, Y, ldy, act, vec_ok != 0);
+        epilogue_store<T, TO, 4>(v, m, n, M, N, bias, R, ldr, Y, ldy, act, vec_ok != 0, ln);
       }
   } else {
     // ------------------------------------------------------------------ f32: 32x32x2, 2x2 tiles per wave
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, in
           const int n = n0 + wc * 64 + i * 32 + 8 * g + 4 * fh;
           const float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
                               acc[i][j][4 * g + 3]};
-          epilogue_store<T, TO, 4>(v, m, n, M, N, bias, R, ldr, Y, ldy, act, vec_ok != 0);
+          epilogue_store<T, TO, 4>(v, m, n, M, N, bias, R, ldr, Y, ldy, act, vec_ok != 0, ln);
         }
   }
 }
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
 // Operand rows beyond M / N are never loaded: the staging goes through buffer descriptors sized to the tile's
 // valid rows (out-of-range lanes of buffer_load ... lds deliver zeros).
 // =============================================================================================
-constexpr int W4_LDS = 2 * BIG_STAGE + 1024;        // 129 KiB: two slab buffers + the tile's bias, no epilogue scratch
+constexpr int W4_LDS = 2 * BIG_STAGE + 2048;        // 130 KiB: two slab buffers + the tile's bias and LN column sums
 
 #define ANEMOI_MFMA_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 
@@ -506,13 +524,14 @@ __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int,
   (f(std::integral_constant<int, S>{}), ...);
 }
 
-template <int ACT, bool HAS_RES>
+template <int ACT, bool HAS_RES, bool LN>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias,
                                                              const bf16_t* __restrict__ R, int64_t ldr,
                                                              bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
-                                                             int K, int vec_ok, int64_t n_tiles, int nt_count) {
+                                                             int K, int vec_ok, int64_t n_tiles, int nt_count,
+                                                             LnFold ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -643,6 +662,14 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
             brs, (__attribute__((address_space(3))) void*)(smem + 2 * BIG_STAGE + wid * 256), 4, lane * 4, wid * 256, 0,
             0);
       }
+      if constexpr (LN) {  // the tile's column sums s[n] of W' (LayerNorm fold), same route
+        const int ncs = N - n0 < BIG_N ? N - n0 : BIG_N;
+        const __amdgpu_buffer_rsrc_t crs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(ln.colsum + n0), 0, ncs * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            crs, (__attribute__((address_space(3))) void*)(smem + 2 * BIG_STAGE + 1024 + wid * 256), 4, lane * 4,
+            wid * 256, 0, 0);
+      }
       // accumulator zeroing (prologue / previous epilogue, MFMA pipe) -> first MFMA: pinned on both sides
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 7" ::: "memory");
@@ -739,6 +766,21 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
         for (int r = 0; r < 8; ++r) bv[u][r] = 0.f;
       }
     }
+    float sv[4][8];  // LayerNorm fold: column sums of W' (LDS) and the row statistics { rstd, -mean rstd } of all 8 row groups
+    float2 rst[8];
+    if constexpr (LN) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        VecIO<float, 8>::load(reinterpret_cast<const float*>(smem + 2 * BIG_STAGE + 1024) + ncol + u * 32, sv[u]);
+      const __amdgpu_buffer_rsrc_t srs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(ln.stats + m0), 0, BIG_M * 8, 0x00020000);
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(srs, fr_e * 8, (wm * 128 + j * 16) * 8, 0);
+        rst[j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+      }
+    }
     auto res_fetch = [&](auto j_tag, uint4 (&rv)[4]) {
       constexpr int j = decltype(j_tag)::value;
       if constexpr (HAS_RES && j < 8) {
@@ -770,10 +812,22 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const f32x4_t c0 = c[2 * u], c1 = c[2 * u + 1];
-        const f32x2_t o0 = act_apply2<ACT>(f32x2_t{c0[0], c0[1]} + f32x2_t{bv[u][0], bv[u][1]});
-        const f32x2_t o1 = act_apply2<ACT>(f32x2_t{c0[2], c0[3]} + f32x2_t{bv[u][2], bv[u][3]});
-        const f32x2_t o2 = act_apply2<ACT>(f32x2_t{c1[0], c1[1]} + f32x2_t{bv[u][4], bv[u][5]});
-        const f32x2_t o3 = act_apply2<ACT>(f32x2_t{c1[2], c1[3]} + f32x2_t{bv[u][6], bv[u][7]});
+        f32x2_t p0 = f32x2_t{c0[0], c0[1]}, p1 = f32x2_t{c0[2], c0[3]}, p2 = f32x2_t{c1[0], c1[1]},
+                p3 = f32x2_t{c1[2], c1[3]};
+        if constexpr (LN) {  // rstd_m acc + (-mean_m rstd_m) s[n] + b'[n]
+          const f32x2_t r2 = f32x2_t{rst[j].x, rst[j].x}, t2 = f32x2_t{rst[j].y, rst[j].y};
+          p0 = p0 * r2 + (t2 * f32x2_t{sv[u][0], sv[u][1]} + f32x2_t{bv[u][0], bv[u][1]});
+          p1 = p1 * r2 + (t2 * f32x2_t{sv[u][2], sv[u][3]} + f32x2_t{bv[u][2], bv[u][3]});
+          p2 = p2 * r2 + (t2 * f32x2_t{sv[u][4], sv[u][5]} + f32x2_t{bv[u][4], bv[u][5]});
+          p3 = p3 * r2 + (t2 * f32x2_t{sv[u][6], sv[u][7]} + f32x2_t{bv[u][6], bv[u][7]});
+        } else {
+          p0 += f32x2_t{bv[u][0], bv[u][1]};
+          p1 += f32x2_t{bv[u][2], bv[u][3]};
+          p2 += f32x2_t{bv[u][4], bv[u][5]};
+          p3 += f32x2_t{bv[u][6], bv[u][7]};
+        }
+        const f32x2_t o0 = act_apply2<ACT>(p0), o1 = act_apply2<ACT>(p1), o2 = act_apply2<ACT>(p2),
+                      o3 = act_apply2<ACT>(p3);
         uint4 v = make_uint4(pack_bf16x2(o0.x, o0.y), pack_bf16x2(o1.x, o1.y), pack_bf16x2(o2.x, o2.y),
                              pack_bf16x2(o3.x, o3.y));
         if constexpr (HAS_RES)
@@ -997,9 +1051,14 @@ __global__ __launch_bounds__(512) void linear_bf16_256x4_kernel(const bf16_t* __
   }
 }
 
+template <typename T, typename TO>
+static int linear_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
+                         int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st,
+                         LnFold ln);
+
 static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                                   int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
-                                  hipStream_t st) {
+                                  hipStream_t st, LnFold ln = LnFold{nullptr, nullptr}) {
   static bool raised = false;
   if (!raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<0, false>),
@@ -1021,10 +1080,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256x4_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS) != hipSuccess)
       return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", BIG_LDS);
-#define RAISE_W4(A, RES)                                                                          \
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES>),          \
+#define RAISE_W4_(A, RES, LNF)                                                                    \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF>),     \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)      \
     return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
+#define RAISE_W4(A, RES) \
+  RAISE_W4_(A, RES, false); \
+  RAISE_W4_(A, RES, true)
     RAISE_W4(0, false);
     RAISE_W4(0, true);
     RAISE_W4(1, false);
@@ -1034,6 +1096,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4(3, false);
     RAISE_W4(3, true);
 #undef RAISE_W4
+#undef RAISE_W4_
     raised = true;
   }
   // ANEMOI_AMD_GEMM_VARIANT: 1 = four waves x (128 x 128), AGPR accumulators (default; needs K >= 128);
@@ -1055,12 +1118,17 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
   if (variant == 1 && K >= 128 && ldx < (int64_t)1 << 21 && ldy < (int64_t)1 << 21 && ldr < (int64_t)1 << 21 && vec_ok &&
-      M % BIG_M == 0) {
-#define LAUNCH_W4_(A, RES)                                                                                   \
-  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES>), dim3((unsigned)blocks), dim3(256), W4_LDS, st,         \
+      M % BIG_M == 0 && (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0)) {
+#define LAUNCH_W4__(A, RES, LNF)                                                                             \
+  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES, LNF>), dim3((unsigned)blocks), dim3(256), W4_LDS, st,    \
                      static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,                \
                      static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K,       \
-                     vec_ok ? 1 : 0, mt * nt, (int)nt)
+                     vec_ok ? 1 : 0, mt * nt, (int)nt, ln)
+#define LAUNCH_W4_(A, RES)                             \
+  do {                                                 \
+    if (ln.stats != nullptr) LAUNCH_W4__(A, RES, true); \
+    else LAUNCH_W4__(A, RES, false);                   \
+  } while (0)
 #define LAUNCH_W4(A)                              \
   do {                                            \
     if (residual != nullptr) LAUNCH_W4_(A, true); \
@@ -1074,8 +1142,11 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     }
 #undef LAUNCH_W4
 #undef LAUNCH_W4_
+#undef LAUNCH_W4__
     return check_launch("anemoi_linear(256x256, 4 waves)");
   }
+  if (ln.stats != nullptr)  // the older kernels have no LayerNorm fold: the general 128 x 128 kernel has
+    return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
   if (variant == 4) {
     hipLaunchKernelGGL(linear_bf16_256x4_kernel, dim3((unsigned)blocks), dim3(512), Q_LDS, st,
                        static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
@@ -1114,7 +1185,7 @@ __global__ __launch_bounds__(256) void linear_bf16_skinny_kernel(const bf16_t* _
                                                                  const float* __restrict__ bias,
                                                                  const bf16_t* __restrict__ R, int64_t ldr,
                                                                  bf16_t* __restrict__ Y, int64_t ldy, int M, int N,
-                                                                 int K, int act) {
+                                                                 int K, int act, LnFold ln) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -1142,7 +1213,9 @@ __global__ __launch_bounds__(256) void linear_bf16_skinny_kernel(const bf16_t* _
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       if (r < M) {
-        float o = act_apply(acc[r] + b, act);
+        float a = acc[r];
+        if (ln.stats != nullptr) a = fmaf(a, ln.stats[r].x, ln.stats[r].y * ln.colsum[n]);
+        float o = act_apply(a + b, act);
         o = bf16_to_f32(f32_to_bf16(o));  // same double rounding as the tiled kernel (bf16 result, then + residual)
         if (R != nullptr) o += bf16_to_f32(R[r * ldr + n]);
         Y[r * ldy + n] = f32_to_bf16(o);
@@ -1153,16 +1226,18 @@ __global__ __launch_bounds__(256) void linear_bf16_skinny_kernel(const bf16_t* _
 
 template <typename T, typename TO>
 static int linear_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
-                         int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st) {
+                         int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st,
+                         LnFold ln) {
   const int64_t mt = (M + BM - 1) / BM;
   const int64_t nt = (N + BN - 1) / BN;
   ANEMOI_REQUIRE(mt * nt < (int64_t)1 << 31, ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: grid too large");
   const bool vec_ok = (N % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)y % 16 == 0) &&
                       (bias == nullptr || (uintptr_t)bias % 16 == 0) &&
+                      (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0) &&
                       (residual == nullptr || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0));
   hipLaunchKernelGGL((linear_kernel<T, TO>), dim3((unsigned)(mt * nt)), dim3(256), 0, st, static_cast<const T*>(x),
                      ldx, static_cast<const T*>(w), bias, static_cast<const T*>(residual), ldr, static_cast<TO*>(y),
-                     ldy, M, N, K, act, vec_ok ? 1 : 0);
+                     ldy, M, N, K, act, vec_ok ? 1 : 0, ln);
   return check_launch("anemoi_linear");
 }
 
@@ -1170,44 +1245,62 @@ static int linear_launch(const void* x, int64_t ldx, const void* w, const float*
 
 using namespace anemoi;
 
-extern "C" int anemoi_linear(int dtype, int out_dtype, const void* x, int64_t ldx, const void* w, const float* bias,
-                             const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
-                             anemoi_stream_t stream) {
-  ANEMOI_REQUIRE(x && w && y, ANEMOI_ERR_INVALID, "anemoi_linear: null pointer");
-  ANEMOI_REQUIRE(M >= 0 && N > 0 && K > 0, ANEMOI_ERR_INVALID, "anemoi_linear: bad shape M=%lld N=%d K=%d",
-                 (long long)M, N, K);
+static int linear_dispatch(const char* who, int dtype, int out_dtype, const void* x, int64_t ldx, const void* w,
+                           const float* bias, LnFold ln, const void* residual, int64_t ldr, void* y, int64_t ldy,
+                           int64_t M, int N, int K, int act, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && w && y, ANEMOI_ERR_INVALID, "%s: null pointer", who);
+  ANEMOI_REQUIRE(M >= 0 && N > 0 && K > 0, ANEMOI_ERR_INVALID, "%s: bad shape M=%lld N=%d K=%d", who, (long long)M, N, K);
   ANEMOI_REQUIRE(ldx >= K && ldy >= N && (residual == nullptr || ldr >= N), ANEMOI_ERR_INVALID,
-                 "anemoi_linear: leading dimension too small");
-  ANEMOI_REQUIRE(act >= ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_linear: act %d", act);
+                 "%s: leading dimension too small", who);
+  ANEMOI_REQUIRE(act >= ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "%s: act %d", who, act);
   const int esz = dtype == ANEMOI_BF16 ? 2 : 4;
   ANEMOI_REQUIRE(((int64_t)K * esz) % ROW_BYTES == 0, ANEMOI_ERR_INVALID,
-                 "anemoi_linear: K=%d must be a multiple of %d for this dtype (pad with zeros)", K, ROW_BYTES / esz);
+                 "%s: K=%d must be a multiple of %d for this dtype (pad with zeros)", who, K, ROW_BYTES / esz);
   ANEMOI_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (ldx * esz) % 16 == 0, ANEMOI_ERR_INVALID,
-                 "anemoi_linear: x / W must be 16-byte aligned with a 16-byte multiple row pitch");
+                 "%s: x / W must be 16-byte aligned with a 16-byte multiple row pitch", who);
   if (M == 0) return ANEMOI_OK;
   hipStream_t st = as_stream(stream);
   if (dtype == ANEMOI_F32 && out_dtype == ANEMOI_F32)
-    return linear_launch<float, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
+    return linear_launch<float, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16 && M >= 1024 && N >= 256) {
     // A ragged last row tile would cost every CU of one XCD a full extra round (161 vs 160 row tiles at M = 40 962:
     // +10 %): the 256-row multiple goes to the persistent kernel, the few remaining rows to the 128 x 128 kernel.
     const int64_t m_main = M / BIG_M * BIG_M, m_tail = M - m_main;
-    if (m_tail == 0) return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
-    const int rc = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, m_main, N, K, act, st);
+    if (m_tail == 0) return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
+    const int rc = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, m_main, N, K, act, st, ln);
     if (rc != ANEMOI_OK) return rc;
     const bf16_t* xt = static_cast<const bf16_t*>(x) + m_main * ldx;
     const bf16_t* rt = residual ? static_cast<const bf16_t*>(residual) + m_main * ldr : nullptr;
     bf16_t* yt = static_cast<bf16_t*>(y) + m_main * ldy;
+    LnFold lt = ln;
+    if (lt.stats != nullptr) lt.stats += m_main;
     if (m_tail <= 8 && K % 8 == 0) {
       hipLaunchKernelGGL((linear_bf16_skinny_kernel<8>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, xt, ldx,
-                         static_cast<const bf16_t*>(w), bias, rt, ldr, yt, ldy, (int)m_tail, N, K, act);
+                         static_cast<const bf16_t*>(w), bias, rt, ldr, yt, ldy, (int)m_tail, N, K, act, lt);
       return check_launch("anemoi_linear(skinny tail)");
     }
-    return linear_launch<bf16_t, bf16_t>(xt, ldx, w, bias, rt, ldr, yt, ldy, m_tail, N, K, act, st);
+    return linear_launch<bf16_t, bf16_t>(xt, ldx, w, bias, rt, ldr, yt, ldy, m_tail, N, K, act, st, lt);
   }
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16)
-    return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
+    return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_F32)
-    return linear_launch<bf16_t, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st);
-  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: dtype %d -> %d", dtype, out_dtype);
+    return linear_launch<bf16_t, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
+  return fail(ANEMOI_ERR_UNSUPPORTED, "%s: dtype %d -> %d", who, dtype, out_dtype);
+}
+
+extern "C" int anemoi_linear(int dtype, int out_dtype, const void* x, int64_t ldx, const void* w, const float* bias,
+                             const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
+                             anemoi_stream_t stream) {
+  return linear_dispatch("anemoi_linear", dtype, out_dtype, x, ldx, w, bias, LnFold{nullptr, nullptr}, residual, ldr, y,
+                         ldy, M, N, K, act, stream);
+}
+
+extern "C" int anemoi_linear_ln(int dtype, int out_dtype, const void* x, int64_t ldx, const void* w, const float* bias,
+                                const float* colsum, const float* stats, const void* residual, int64_t ldr, void* y,
+                                int64_t ldy, int64_t M, int N, int K, int act, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(colsum && stats, ANEMOI_ERR_INVALID, "anemoi_linear_ln: null colsum / stats");
+  ANEMOI_REQUIRE((uintptr_t)stats % 8 == 0, ANEMOI_ERR_INVALID, "anemoi_linear_ln: stats must be 8-byte aligned");
+  return linear_dispatch("anemoi_linear_ln", dtype, out_dtype, x, ldx, w, bias,
+                         LnFold{colsum, reinterpret_cast<const float2*>(stats)}, residual, ldr, y, ldy, M, N, K, act,
+                         stream);
 }

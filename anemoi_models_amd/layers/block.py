@@ -113,6 +113,38 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
                                                        layers[0].weight.device))
         return w, b
 
+    # ---- LayerNorm -> Linear pairs: row statistics + anemoi_linear_ln (the normalised activation is never stored)
+    @staticmethod
+    def _ln_begin(ln: nn.LayerNorm, x: Tensor):
+        """Handle of ``LayerNorm(x)`` for ``_ln_linear``: ``(x, stats, ln)`` when folding, else ``(LN(x), None, None)``."""
+        if runtime.ln_fold_enabled(x.dtype):
+            return x, ops.row_stats(x, ln.eps), ln
+        return ops.layer_norm(x, runtime.f32c(ln.weight), runtime.f32c(ln.bias), ln.eps), None, None
+
+    def _ln_linear(self, handle, tag: str, plain, rows, params, **kw) -> Tensor:
+        """``Linear(LayerNorm(x))``.  ``plain()`` -> packed ``(w, b)`` of the unfolded route; ``rows()`` -> f32
+        ``(weight rows [N, K], bias [N] or None)`` that the fold scales by the LayerNorm weight (cached per dtype)."""
+        xin, stats, ln = handle
+        if stats is None:
+            w, b = plain()
+            return ops.linear(xin, w, b, **kw)
+        wf, bf, cs = self._packed.get(
+            (tag, "lnfold", xin.dtype), list(params) + [ln.weight, ln.bias],
+            lambda: runtime.fold_layer_norm(*rows(), ln.weight, ln.bias, xin.dtype))
+        return ops.linear(xin, wf, bf, ln=(stats, cs), **kw)
+
+    def _cat_rows(self, layers):
+        """f32 ``(cat of weights, cat of biases)`` of a list of Linear layers (input of the LayerNorm fold)."""
+        w = torch.cat([l.weight.detach().float() for l in layers], dim=0)
+        b = runtime.pack_bias([l.bias for l in layers], [l.out_features for l in layers], w.device)
+        return w, b
+
+    def _folded_rows(self, lead_layers, up: int):
+        """As ``_cat_rows`` with the ``W_u`` rows of the lin_edge fold appended (q/k/v side of the lin_edge fold, ``_folded_in``)."""
+        w, b = self._cat_rows(lead_layers)
+        wu, bu = self._query_fold(up)
+        return torch.cat([w, wu], dim=0), torch.cat([b, bu], dim=0)
+
     def _edge_params(self):
         return runtime.f32c(self.lin_edge.weight), runtime.f32c(self.lin_edge.bias)
 
@@ -160,8 +192,8 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         return torch.einsum("ohd,hda->oha", wp.view(wp.shape[0], h, d), self._edge_fold(up)).reshape(wp.shape[0],
                                                                                                        h * up)
 
-    def _folded_linears(self, tag: str, lead_layers, dtype, up: int):
-        """Packed ``[lead_layers..., W_u]`` (q/k/v side) and ``[W_p | W_t]`` (projection side) weights + biases."""
+    def _folded_in(self, tag: str, lead_layers, dtype, up: int):
+        """Packed ``[lead_layers..., W_u]`` weight + bias (q/k/v side of the lin_edge fold)."""
         edge_q = [self.lin_edge.weight, self.lin_edge.bias, self.lin_query.weight, self.lin_query.bias]
         w_in = self._packed.get((tag, "w", dtype, up), [l.weight for l in lead_layers] + edge_q,
                                 lambda: runtime.pack_weight([l.weight for l in lead_layers] + [self._query_fold(up)[0]],
@@ -171,11 +203,19 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
                                                                      [l.out_features for l in lead_layers],
                                                                      self.lin_edge.weight.device),
                                                    self._query_fold(up)[1]]).contiguous())
+        return w_in, b_in
+
+    def _folded_out(self, dtype, up: int):
+        """Packed ``[W_p | W_t]`` weight + bias (projection side of the lin_edge fold)."""
         edge_p = [self.lin_edge.weight, self.lin_edge.bias, self.projection.weight]
         w_out = self._packed.get(("projf", "w", dtype, up), edge_p,
                                  lambda: runtime.pack_weight_cols([self.projection.weight.detach().float(),
                                                                    self._projection_fold(up)], dtype))
-        return w_in, b_in, w_out, runtime.f32c(self.projection.bias)
+        return w_out, runtime.f32c(self.projection.bias)
+
+    def _fold_params(self, lead_layers):
+        return ([l.weight for l in lead_layers] + [l.bias for l in lead_layers]
+                + [self.lin_edge.weight, self.lin_edge.bias, self.lin_query.weight, self.lin_query.bias])
 
     def _node_mlp(self, y: Tensor, which: str, num_chunks: int) -> Tensor:
         """``mlp(y) + y`` with mlp = LayerNorm, Linear, act, Linear; optionally in row chunks (bounded hidden buffer)."""
@@ -223,38 +263,43 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         dtype = x.dtype
         self._check_channels(dtype)
         c = self.num_heads * self.out_channels_conv
-        xh = ops.layer_norm(x, runtime.f32c(self.layer_norm1.weight), runtime.f32c(self.layer_norm1.bias),
-                            self.layer_norm1.eps)
+        xh = self._ln_begin(self.layer_norm1, x)
         up = self.fold_width(dtype)
         if halo is not None:
             if up is None:
                 raise NotImplementedError("node-partitioned blocks need the folded edge kernel")
             n_own = x.shape[0]
-            w_kv, b_kv = self._cat_linear("kv", [self.lin_key, self.lin_value], dtype)
+            kv_layers, sq_layers = [self.lin_key, self.lin_value], [self.lin_self, self.lin_query]
             kv = torch.empty((n_own + halo.n_recv, 2 * c), dtype=dtype, device=x.device)
-            ops.linear(xh, w_kv, b_kv, out=kv[:n_own])
+            self._ln_linear(xh, "kv", lambda: self._cat_linear("kv", kv_layers, dtype),
+                            lambda: self._cat_rows(kv_layers), [l.weight for l in kv_layers] + [l.bias for l in kv_layers],
+                            out=kv[:n_own])
             pending = halo.start(kv, n_own)  # xGMI transfer of the halo k|v rows ...
-            w_squ, b_squ, wpf, bp = self._folded_linears("squ", [self.lin_self, self.lin_query], dtype, up)
-            sq = ops.linear(xh, w_squ, b_squ)  # ... overlapped with the x_r | q | u GEMM
+            wpf, bp = self._folded_out(dtype, up)
+            sq = self._ln_linear(xh, "squ", lambda: self._folded_in("squ", sq_layers, dtype, up),
+                                 lambda: self._folded_rows(sq_layers, up),
+                                 self._fold_params(sq_layers))  # ... overlapped with the x_r | q | u GEMM
             halo.finish(pending)
             att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
                                                edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
                                                ld_out=wpf.shape[1])
             y = ops.linear(att, wpf, bp, residual=x)
             return self._node_mlp(y, "dst", 1)
+        all4 = [self.lin_self, self.lin_query, self.lin_key, self.lin_value]
         if up is not None:
-            w5, b5, wpf, bp = self._folded_linears(
-                "sqkvu", [self.lin_self, self.lin_query, self.lin_key, self.lin_value], dtype, up)
-            sq = ops.linear(xh, w5, b5)  # [N, 4C + H*up] = x_r | q | k | v | u
+            wpf, bp = self._folded_out(dtype, up)
+            sq = self._ln_linear(xh, "sqkvu", lambda: self._folded_in("sqkvu", all4, dtype, up),
+                                 lambda: self._folded_rows(all4, up),
+                                 self._fold_params(all4))  # [N, 4C + H*up] = x_r | q | k | v | u
             att = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c],
                                                sq[:, 4 * c:], edge_attr_csr, plan.rowptr, plan.col, self.num_heads,
                                                up, ld_out=wpf.shape[1])
             y = ops.linear(att, wpf, bp, residual=x)  # projection(out + x_r) + x_skip, lin_edge part via W_t
             return self._node_mlp(y, "dst", 1)
-        w4, b4 = self._cat_linear("sqkv", [self.lin_self, self.lin_query, self.lin_key, self.lin_value], dtype)
         wp, bp = self._cat_linear("proj", [self.projection], dtype)
         we, be = self._edge_params()
-        sqkv = ops.linear(xh, w4, b4)  # [N, 4C] = x_r | q | k | v
+        sqkv = self._ln_linear(xh, "sqkv", lambda: self._cat_linear("sqkv", all4, dtype), lambda: self._cat_rows(all4),
+                               [l.weight for l in all4] + [l.bias for l in all4])  # [N, 4C] = x_r | q | k | v
         att = self.conv.fused(sqkv[:, c:2 * c], sqkv[:, 2 * c:3 * c], sqkv[:, 3 * c:], sqkv[:, :c], edge_attr_csr,
                               self.edge_dim, we, be, plan, self.num_heads)
         y = ops.linear(att, wp, bp, residual=x)  # projection(out + x_r) + x_skip
@@ -312,22 +357,25 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         dtype = x_dst.dtype
         self._check_channels(dtype)
         c = self.num_heads * self.out_channels_conv
-        w_kv, b_kv = self._cat_linear("kv", [self.lin_key, self.lin_value], dtype)
-        ln1, ln2 = self.layer_norm1, self.layer_norm2
-        xs = ops.layer_norm(x_src, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
+        kv_layers, sq_layers = [self.lin_key, self.lin_value], [self.lin_self, self.lin_query]
+        kv_args = ("kv", lambda: self._cat_linear("kv", kv_layers, dtype), lambda: self._cat_rows(kv_layers),
+                   [l.weight for l in kv_layers] + [l.bias for l in kv_layers])
+        xs = self._ln_begin(self.layer_norm1, x_src)
         if halo is None:
-            kv = ops.linear(xs, w_kv, b_kv)  # [N_src, 2C] = k | v
+            kv = self._ln_linear(xs, *kv_args)  # [N_src, 2C] = k | v
         else:
             n_own = x_src.shape[0]
             kv = torch.empty((n_own + halo.n_recv, 2 * c), dtype=dtype, device=x_src.device)
-            ops.linear(xs, w_kv, b_kv, out=kv[:n_own])
+            self._ln_linear(xs, *kv_args, out=kv[:n_own])
             pending = halo.start(kv, n_own)  # overlapped with the destination-side LayerNorm + GEMM below
         del xs
-        xd = ops.layer_norm(x_dst, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
+        xd = self._ln_begin(self.layer_norm2, x_dst)
         up = self.fold_width(dtype)
         if up is not None:
-            w_squ, b_squ, wp, bp = self._folded_linears("squ", [self.lin_self, self.lin_query], dtype, up)
-            sq = ops.linear(xd, w_squ, b_squ)  # [N_dst, 2C + H*up] = x_r | q | u
+            wp, bp = self._folded_out(dtype, up)
+            sq = self._ln_linear(xd, "squ", lambda: self._folded_in("squ", sq_layers, dtype, up),
+                                 lambda: self._folded_rows(sq_layers, up),
+                                 self._fold_params(sq_layers))  # [N_dst, 2C + H*up] = x_r | q | u
             del xd
             if halo is not None:
                 halo.finish(pending)
@@ -337,10 +385,11 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         else:
             if halo is not None:
                 raise NotImplementedError("node-partitioned blocks need the folded edge kernel")
-            w_sq, b_sq = self._cat_linear("sq", [self.lin_self, self.lin_query], dtype)
             wp, bp = self._cat_linear("proj", [self.projection], dtype)
             we, be = self._edge_params()
-            sq = ops.linear(xd, w_sq, b_sq)  # [N_dst, 2C] = x_r | q
+            sq = self._ln_linear(xd, "sq", lambda: self._cat_linear("sq", sq_layers, dtype),
+                                 lambda: self._cat_rows(sq_layers),
+                                 [l.weight for l in sq_layers] + [l.bias for l in sq_layers])  # [N_dst, 2C] = x_r | q
             del xd
             att = self.conv.fused(sq[:, c:], kv[:, :c], kv[:, c:], sq[:, :c], edge_attr_csr, self.edge_dim, we, be,
                                   plan, self.num_heads)

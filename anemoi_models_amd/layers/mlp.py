@@ -64,20 +64,34 @@ class NativeSequential:
         dtype = x.dtype
         last_linear = max(i for i, s in enumerate(self.steps) if s[0] == "linear")
         ends_with_ln = self.steps[-1][0] == "ln"
+        pending_ln = None  # a LayerNorm whose consumer is the next Linear: folded into it (row_stats + linear_ln)
         for i, (kind, m, act) in enumerate(self.steps):
             if i < start:
                 continue
             if kind == "linear":
+                fuse_res = residual is not None and i == last_linear and not ends_with_ln
+                last = i == len(self.steps) - 1
+                kw = dict(act=act, residual=residual if fuse_res else None, out_dtype=out_dtype if last else None)
+                if pending_ln is not None:
+                    ln, stats = pending_ln
+                    pending_ln = None
+                    wf, bf, cs = self.cache.get(("lnfold", i, dtype), [m.weight, m.bias, ln.weight, ln.bias],
+                                                lambda m=m, ln=ln: runtime.fold_layer_norm(
+                                                    m.weight.detach().float(), m.bias, ln.weight, ln.bias, dtype))
+                    x = ops.linear(x, wf, bf, ln=(stats, cs), **kw)
+                    continue
                 w = self.cache.get(("w", i, dtype), [m.weight], lambda m=m: runtime.pack_weight([m.weight], dtype))
                 b = None if m.bias is None else runtime.f32c(m.bias)
                 if x.shape[1] != w.shape[1]:
                     x = ops.convert_pad(x, dtype, w.shape[1])
-                fuse_res = residual is not None and i == last_linear and not ends_with_ln
-                last = i == len(self.steps) - 1
-                x = ops.linear(x, w, b, act=act, residual=residual if fuse_res else None,
-                               out_dtype=out_dtype if last else None)
+                x = ops.linear(x, w, b, **kw)
             else:
-                x = ops.layer_norm(x, runtime.f32c(m.weight), runtime.f32c(m.bias), m.eps)
+                nxt = self.steps[i + 1] if i + 1 < len(self.steps) else None
+                if (nxt is not None and nxt[0] == "linear" and runtime.ln_fold_enabled(dtype)
+                        and x.shape[1] % ops.k_multiple(dtype) == 0 and nxt[1].in_features == x.shape[1]):
+                    pending_ln = (m, ops.row_stats(x, m.eps))
+                else:
+                    x = ops.layer_norm(x, runtime.f32c(m.weight), runtime.f32c(m.bias), m.eps)
         if residual is not None and ends_with_ln:
             x = ops.add(x, residual)
         return x

@@ -100,10 +100,26 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, out: 
     return out
 
 
+def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
+    """LayerNorm statistics of the rows of ``x``: ``[M, 2]`` f32 = ``(rstd, -mean * rstd)`` (see ``linear(ln=...)``)."""
+    _dev(x)
+    _rows(x)
+    out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    with _Timed("row_stats", bytes=x.shape[0] * x.shape[1] * x.element_size()):
+        st = _lib.load().anemoi_row_stats(dtype_code(x.dtype), x.data_ptr(), _ld(x), out.data_ptr(), x.shape[0],
+                                          x.shape[1], eps, _stream())
+    _lib.check(st, "anemoi_row_stats")
+    return out
+
+
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "Identity",
            residual: Optional[Tensor] = None, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-           n_out: Optional[int] = None) -> Tensor:
-    """``act(x @ w.T + bias) + residual``; ``w`` is ``[N, K]`` in x's dtype with K already padded like x."""
+           n_out: Optional[int] = None, ln=None) -> Tensor:
+    """``act(x @ w.T + bias) + residual``; ``w`` is ``[N, K]`` in x's dtype with K already padded like x.
+
+    ``ln=(stats, colsum)`` folds the LayerNorm of ``x`` into the product: ``x`` is the un-normalised input,
+    ``stats = row_stats(x)``, ``w`` / ``bias`` / ``colsum`` come from ``runtime.fold_layer_norm``.
+    """
     _dev(x, w, bias, residual, out)
     _rows(x)
     if w.dtype != x.dtype or not w.is_contiguous():
@@ -119,11 +135,24 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
     alg = (x.shape[0] * k + n * k) * x.element_size() + x.shape[0] * n * (out.element_size() + (
         0 if residual is None else residual.element_size()))
     with _Timed("linear", flops=2 * x.shape[0] * n * k, bytes=alg, m=x.shape[0], n=n, k=k):
-        st = _lib.load().anemoi_linear(
-            dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
-            _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)),
-            x.shape[0], n, k, _lib.ACT_CODES[act], _stream())
-    _lib.check(st, "anemoi_linear")
+        if ln is None:
+            st = _lib.load().anemoi_linear(
+                dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
+                _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)),
+                x.shape[0], n, k, _lib.ACT_CODES[act], _stream())
+        else:
+            stats, colsum = ln
+            _dev(stats, colsum)
+            if stats.shape != (x.shape[0], 2) or stats.dtype != torch.float32 or not stats.is_contiguous():
+                raise ValueError("linear: ln stats must be the contiguous [M, 2] f32 result of row_stats(x)")
+            if colsum.numel() < n or colsum.dtype != torch.float32 or not colsum.is_contiguous():
+                raise ValueError("linear: ln colsum must be a contiguous f32 vector with one entry per output column")
+            st = _lib.load().anemoi_linear_ln(
+                dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
+                colsum.data_ptr(), stats.data_ptr(), _ptr(residual),
+                0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)), x.shape[0], n, k,
+                _lib.ACT_CODES[act], _stream())
+    _lib.check(st, "anemoi_linear" if ln is None else "anemoi_linear_ln")
     return out
 
 

@@ -202,6 +202,31 @@ def pack_weight_cols(parts: Sequence[Tensor], dtype: torch.dtype) -> Tensor:
     return out
 
 
+def ln_fold_enabled(dtype: torch.dtype) -> bool:
+    """LayerNorm -> Linear pairs run as row_stats + anemoi_linear_ln (bf16 only; ``ANEMOI_AMD_LN_FOLD=0`` disables)."""
+    return dtype == torch.bfloat16 and os.environ.get("ANEMOI_AMD_LN_FOLD", "1") != "0"
+
+
+def fold_layer_norm(w_rows: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, dtype: torch.dtype):
+    """Fold ``LayerNorm(gamma, beta)`` into the Linear ``(w_rows [N, K] f32, bias [N] f32 or None)`` that consumes it.
+
+    Returns ``(W' [N, K_pad] in dtype, b' [N] f32, colsum [N] f32)`` with ``W' = W * gamma`` (input columns scaled),
+    ``colsum = W'.sum(1)`` taken from the ROUNDED W' (so that the mean cancels exactly in the kernel's
+    ``rstd (x W'^T) - rstd mean colsum``) and ``b' = b + W beta``.
+    """
+    w = w_rows.detach().float()
+    g, bt = gamma.detach().float(), beta.detach().float()
+    k = w.shape[1]
+    kp = ops.round_up(k, ops.k_multiple(dtype))
+    wp = torch.zeros((w.shape[0], kp), dtype=dtype, device=w.device)
+    wp[:, :k] = (w * g[None, :]).to(dtype)
+    colsum = wp.float().sum(dim=1).contiguous()
+    b = w @ bt
+    if bias is not None:
+        b = b + bias.detach().float()
+    return wp, b.contiguous(), colsum
+
+
 def pack_bias(biases: Sequence[Optional[Tensor]], sizes: Sequence[int], device) -> Tensor:
     parts = [b.detach().float() if b is not None else torch.zeros(n, dtype=torch.float32, device=device)
              for b, n in zip(biases, sizes)]

@@ -73,6 +73,27 @@ int anemoi_linear(int dtype, int out_dtype, const void* x, int64_t ldx, const vo
                   anemoi_stream_t stream);
 
 /*
+ * LayerNorm statistics of the rows of x [rows, C] (ldx): stats[r] = { rstd_r, -mean_r * rstd_r } (f32 pairs, same
+ * two-pass arithmetic as anemoi_layer_norm).  First half of a LayerNorm -> Linear pair (next entry point).
+ */
+int anemoi_row_stats(int dtype, const void* x, int64_t ldx, float* stats, int64_t rows, int C, float eps,
+                     anemoi_stream_t stream);
+
+/*
+ * Linear with the LayerNorm of its input folded in:  y = act(LN(x) @ W^T + b) + residual  computed as
+ *   y[m,n] = act( rstd_m * (x @ W'^T)[m,n] + (-mean_m rstd_m) * colsum[n] + bias[n] ) + residual[m,n]
+ * where the caller passes  W' = W * gamma (input columns scaled by the LayerNorm weight, in `dtype`),
+ * colsum[n] = sum_k W'[n,k] (f32, from the rounded W'), bias = b + W beta (f32) and stats from anemoi_row_stats(x).
+ * x is the UN-normalised input: the normalised activation is never written to memory.  Replaces the pairs
+ * layer_norm1 -> lin_query/key/value/self (layers/block.py:614-618, :491-497), node_dst_mlp[0] -> node_dst_mlp[1]
+ * (:349-351) and layer_norm -> lin_qkv / mlp[0] of the transformer block (:99-105).  Same shapes / alignment as
+ * anemoi_linear; colsum 16-byte aligned for the fast path.
+ */
+int anemoi_linear_ln(int dtype, int out_dtype, const void* x, int64_t ldx, const void* w, const float* bias,
+                     const float* colsum, const float* stats, const void* residual, int64_t ldr, void* y, int64_t ldy,
+                     int64_t M, int N, int K, int act, anemoi_stream_t stream);
+
+/*
  * Edge attributes in CSR (destination-sorted) order:
  *   out[e, :] = [ a0[perm[e] % rows0, 0:d0] | a1[perm[e] % rows0, 0:d1] | 0 ... ]   (row stride ld_out)
  * and, when one_col >= 0, out[e, one_col] = 1 (the constant attribute that carries the lin_edge bias through the

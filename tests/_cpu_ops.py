@@ -20,9 +20,24 @@ def layer_norm(x, weight, bias, eps=1e-5, out=None):
     return F.layer_norm(x.float(), (x.shape[1],), weight, bias, eps).to(x.dtype)
 
 
-def linear(x, w, bias=None, *, act="Identity", residual=None, out=None, out_dtype=None, n_out=None):
+def row_stats(x, eps=1e-5):
+    xf = x.float()
+    mean = xf.mean(dim=1)
+    rstd = torch.rsqrt(xf.var(dim=1, unbiased=False) + eps)
+    return torch.stack([rstd, -mean * rstd], dim=1).contiguous()
+
+
+def linear(x, w, bias=None, *, act="Identity", residual=None, out=None, out_dtype=None, n_out=None, ln=None):
     assert x.shape[1] == w.shape[1] and w.shape[1] % (128 // x.element_size()) == 0, "K must be slab padded"
-    y = _ACT[act](F.linear(x.float(), w.float(), bias))
+    if ln is None:
+        pre = F.linear(x.float(), w.float(), bias)
+    else:  # the kernel's arithmetic: rstd (x W'^T) + (-mean rstd) colsum + b'
+        stats, colsum = ln
+        assert stats.shape == (x.shape[0], 2) and colsum.shape[0] >= w.shape[0]
+        pre = F.linear(x.float(), w.float()) * stats[:, :1] + stats[:, 1:] * colsum[None, : w.shape[0]]
+        if bias is not None:
+            pre = pre + bias
+    y = _ACT[act](pre)
     if residual is not None:
         y = y + residual.float()
     y = y.to(out_dtype or x.dtype)
@@ -144,7 +159,7 @@ def add(a, b, out=None):
 def install(monkeypatch):
     import anemoi_models_amd.ops as ops
 
-    for name in ("layer_norm", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
+    for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
                  "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                  "prognostic_residual", "convert_pad", "add"):
         monkeypatch.setattr(ops, name, globals()[name])

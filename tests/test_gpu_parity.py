@@ -68,6 +68,53 @@ def test_linear(dtype, m, n, k, act, res):
     assert rel_err(got, want) < (2e-6 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,c", [(5, 64), (300, 512), (2050, 1024), (1000, 96)])
+def test_row_stats(dtype, m, c):
+    """anemoi_row_stats = (rstd, -mean * rstd) of nn.LayerNorm's statistics (reference layers/block.py:614)."""
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(m + c)
+    x = (torch.randn(m, c, generator=g) * 1.7 + 0.4).to(dtype)
+    xf = x.double()
+    rstd = torch.rsqrt(xf.var(dim=1, unbiased=False) + 1e-5)
+    want = torch.stack([rstd, -xf.mean(dim=1) * rstd], dim=1)
+    got = ops.row_stats(x.to(DEV), 1e-5)
+    assert got.shape == (m, 2) and got.dtype == torch.float32
+    assert rel_err(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,n,k,act,res", [
+    (300, 256, 128, "GELU", False), (129, 80, 192, "Identity", True),      # 128 x 128 kernel
+    (2050, 384, 256, "Identity", False), (4099, 1280, 512, "GELU", False),  # persistent kernel + skinny tail rows
+    (2200, 512, 1024, "SiLU", True),                                        # persistent kernel + 128 x 128 tail
+])
+def test_linear_with_folded_layer_norm(dtype, m, n, k, act, res):
+    """anemoi_linear_ln: act(LayerNorm(x) W^T + b) + residual from the UN-normalised x, the row statistics and the
+    folded weights of runtime.fold_layer_norm (replaces layer_norm1 -> lin_* and node_dst_mlp[0] -> [1],
+    reference layers/block.py:614-618, :349-351)."""
+    from anemoi_models_amd import ops, runtime
+
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * 1.3 + 0.5).to(dtype)  # non-zero mean: the fold must cancel it
+    w = torch.randn(n, k, generator=g) / k**0.5
+    b = torch.randn(n, generator=g)
+    gamma = 1.0 + 0.3 * torch.randn(k, generator=g)
+    beta = 0.2 * torch.randn(k, generator=g)
+    r = torch.randn(m, n, generator=g).to(dtype) if res else None
+    acts = {"Identity": lambda t: t, "GELU": F.gelu, "SiLU": F.silu, "ReLU": F.relu}
+    xn = F.layer_norm(x.double(), (k,), gamma.double(), beta.double(), 1e-5)
+    want = acts[act](F.linear(xn, w.double(), b.double()))
+    if res:
+        want = want + r.double()
+    wf, bf, cs = runtime.fold_layer_norm(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), dtype)
+    xd = x.to(DEV)
+    got = ops.linear(xd, wf, bf, act=act, residual=None if r is None else r.to(DEV), ln=(ops.row_stats(xd, 1e-5), cs))
+    assert got.shape == (m, n) and got.dtype == dtype
+    assert rel_err(got, want) < (2e-5 if dtype == torch.float32 else 1.5e-2)
+
+
 def test_linear_f32_is_exact_fma_chain_and_bf16_to_f32_out():
     from anemoi_models_amd import ops
 
