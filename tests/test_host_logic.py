@@ -93,6 +93,25 @@ def test_gt_model_wiring_matches_golden(graph_o32, golden_cfg1_gt, monkeypatch):
     torch.testing.assert_close(y, gold["y"], atol=1e-4, rtol=1e-4)
 
 
+def test_layer_norm_fold_wiring_bf16(graph_o32, golden_cfg1_gt, monkeypatch):
+    """bf16 route with LayerNorm folded into the consuming Linear (row_stats + linear(ln=...)) against the same model
+    with the fold switched off and against the f32 golden output (host logic only; kernels are the CPU stand-ins)."""
+    _cpu_ops.install(monkeypatch)
+    gold = golden_cfg1_gt
+    model = build_model(graph_o32)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model.eval()
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    outs = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("ANEMOI_AMD_LN_FOLD", fold)
+        with torch.no_grad():
+            outs[fold] = model(gold["x"])
+    scale = float(gold["y"].abs().max())
+    assert float((outs["1"] - outs["0"]).abs().max()) < 0.03 * scale
+    assert float((outs["1"] - gold["y"]).abs().max()) < 0.05 * scale
+
+
 def test_gt_blocks_wiring_matches_golden(golden_blocks, monkeypatch):
     from anemoi_models_amd.layers.block import GraphTransformerMapperBlock
     from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
