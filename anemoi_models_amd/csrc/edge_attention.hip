@@ -303,13 +303,26 @@ struct EdgeFoldParams {
   float scale;
 };
 
+// The attribute part of the score (u . a) and of the output (sum alpha a) is the same for all LPH lanes of a head:
+// the lanes SHARE it -- lane r of a head owns the APL attributes [r * APL, r * APL + APL) (one 8/16-byte load per
+// edge), its partial u . a joins the lane's partial q . k before the head reduction (which is needed anyway), and it
+// accumulates only its own attributes.  12 + 12 FMAs per edge and lane become 2 + 2 (UP = 12, 8 lanes per head):
+// the kernel was VALU-bound (~58 VALU per edge and wave, 0.10 of its 0.17 ms on the mesh graph).
+constexpr int attrs_per_lane(int up, int lph) {  // smallest divisor of UP in {2, 4, 8, 12, 16} covering UP with LPH lanes
+  const int raw = (up + lph - 1) / lph;
+  for (int a : {2, 4, 8, 12, 16})
+    if (a >= raw && up % a == 0) return a;
+  return up;
+}
+
 template <typename T, int VEC, int LPH, int UP, int U = 4>
 __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const EdgeFoldParams p,
                                                                    const float* __restrict__ attr_,
                                                                    const int32_t* __restrict__ rowptr_,
                                                                    const int32_t* __restrict__ col_) {
   using Raw = typename RawVec<T, VEC>::type;
-  constexpr int UV = 16 / sizeof(T);  // elements per 16-byte load of u
+  constexpr int APL = attrs_per_lane(UP, LPH);
+  static_assert(UP % APL == 0 && APL * LPH >= UP, "a lane owns APL whole attributes or none");
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int xcd = blockIdx.x & 7;
@@ -326,49 +339,39 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
   const int gls = active ? gl : 0;
   const int c0 = gls * VEC;
   const int head = gls / LPH;
-  const bool head_lead = active && (gls % LPH == 0);
+  const int a0 = (gls % LPH) * APL;  // first attribute of this lane
+  const bool a_own = a0 < UP;        // the last lanes of a head own none when LPH * APL > UP (u = 0, nothing stored)
+  const int a_ld = a_own ? a0 : 0;
+  const float amask = a_own ? 1.f : 0.f;
 
   const T* qb = static_cast<const T*>(p.q) + c0;
   const T* kb = static_cast<const T*>(p.k) + c0;
   const T* vb = static_cast<const T*>(p.v) + c0;
-  const T* ub = static_cast<const T*>(p.u) + head * UP;
+  const T* ub = static_cast<const T*>(p.u) + head * UP + a_ld;
+  const float* ab = attr_ + a_ld;
 
   for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
     const int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
     QK<T, VEC> qk;
-    float u[UP];
+    float u[APL];
     {
       float qf[VEC];
       VecIO<T, VEC>::load(qb + node * p.ldq, qf);
       qk.set(qf);
-      const T* un = ub + node * p.ldu;
-      if constexpr (UP % UV == 0) {
+      VecIO<T, APL>::load(ub + node * p.ldu, u);
 #pragma unroll
-        for (int a = 0; a < UP; a += UV) {
-          float t[UV];
-          VecIO<T, UV>::load(un + a, t);
-#pragma unroll
-          for (int i = 0; i < UV; ++i) u[a + i] = t[i];
-        }
-      } else {
-#pragma unroll
-        for (int a = 0; a < UP; a += 4) {
-          float t[4];
-          VecIO<T, 4>::load(un + a, t);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) u[a + i] = t[i];
-        }
-      }
+      for (int i = 0; i < APL; ++i) u[i] *= amask;
     }
     float m = -INFINITY, l = 0.f;
-    float acc[VEC], tacc[UP];
+    float acc[VEC], tacc[APL];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int a = 0; a < UP; ++a) tacc[a] = 0.f;
+    for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
 
     for (int e = e_begin; e < e_end; e += U) {
       Raw kr[U], vr[U];
+      float at[U][APL];
       float s[U];
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
           const int64_t j = col_[e + uu];
           kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
           vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
+          VecIO<float, APL>::load(ab + (int64_t)(e + uu) * UP, at[uu]);
         }
       }
       float mb = m;
@@ -383,11 +387,10 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
       for (int uu = 0; uu < U; ++uu) {
         s[uu] = -INFINITY;
         if (e + uu < e_end) {
-          const float* at = attr_ + (int64_t)(e + uu) * UP;
-          float t = 0.f;
+          float t = qk.dot(kr[uu]);
 #pragma unroll
-          for (int a = 0; a < UP; ++a) t = fmaf(u[a], at[a], t);
-          s[uu] = (group_sum<LPH>(qk.dot(kr[uu])) + t) * p.scale;
+          for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[uu][a], t);
+          s[uu] = group_sum<LPH>(t) * p.scale;
           mb = fmaxf(mb, s[uu]);
         }
       }
@@ -396,11 +399,10 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] *= corr;
 #pragma unroll
-      for (int a = 0; a < UP; ++a) tacc[a] *= corr;
+      for (int a = 0; a < APL; ++a) tacc[a] *= corr;
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
         if (e + uu < e_end) {
-          const float* at = attr_ + (int64_t)(e + uu) * UP;
           const float pe = __expf(s[uu] - mb);
           l += pe;
           float vv[VEC];
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i], acc[i]);
 #pragma unroll
-          for (int a = 0; a < UP; ++a) tacc[a] = fmaf(pe, at[a], tacc[a]);
+          for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
         }
       }
       m = mb;
@@ -426,13 +428,11 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
     }
     T* on = static_cast<T*>(p.out) + node * p.ldo;
     if (active) VecIO<T, VEC>::store(on + c0, o);
-    if (head_lead) {
-      T* tn = on + p.C + head * UP;
+    if (active && a_own) {  // this lane's APL values of t~_i,h
+      float t4[APL];
 #pragma unroll
-      for (int a = 0; a < UP; a += 4) {
-        const float t4[4] = {tacc[a] * inv, tacc[a + 1] * inv, tacc[a + 2] * inv, tacc[a + 3] * inv};
-        VecIO<T, 4>::store(tn + a, t4);
-      }
+      for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+      VecIO<T, APL>::store(on + p.C + head * UP + a0, t4);
     }
   }
 }
