@@ -524,6 +524,48 @@ __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int,
   (f(std::integral_constant<int, S>{}), ...);
 }
 
+// One output column of up to ROWS "skinny" rows (the M % 256 <= 8 tail of a tall GEMM): the wave sweeps K with 16-byte
+// loads, f32 accumulation, wave reduction; lane 0 applies the epilogue (same double rounding as the tiled kernels).
+template <int ROWS>
+__device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W,
+                                              const float* __restrict__ bias, const bf16_t* __restrict__ R, int64_t ldr,
+                                              bf16_t* __restrict__ Y, int64_t ldy, int M, int n, int K, int act,
+                                              LnFold ln, int lane) {
+  float acc[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  const bf16_t* wrow = W + (int64_t)n * K;
+  for (int k = lane * 8; k < K; k += 512) {
+    float wv[8];
+    VecIO<bf16_t, 8>::load(wrow + k, wv);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (r < M) {
+        float xv[8];
+        VecIO<bf16_t, 8>::load(X + r * ldx + k, xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r] = fmaf(xv[i], wv[i], acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
+    const float b = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (r < M) {
+        float a = acc[r];
+        if (ln.stats != nullptr) a = fmaf(a, ln.stats[r].x, ln.stats[r].y * ln.colsum[n]);
+        float o = act_apply(a + b, act);
+        o = bf16_to_f32(f32_to_bf16(o));  // bf16 result, then + residual
+        if (R != nullptr) o += bf16_to_f32(R[r * ldr + n]);
+        Y[r * ldy + n] = f32_to_bf16(o);
+      }
+    }
+  }
+}
+
 template <int ACT, bool HAS_RES, bool LN>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
@@ -531,10 +573,19 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ R, int64_t ldr,
                                                              bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
                                                              int K, int vec_ok, int64_t n_tiles, int nt_count,
-                                                             LnFold ln) {
+                                                             LnFold ln, int m_tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // The up to 8 rows behind the last full row tile (M here is the 256-row multiple): every wave of the launch takes
+  // some output columns of them first -- a few microseconds in parallel instead of a separate launch behind this one.
+  if (m_tail > 0) {
+    LnFold lt = ln;
+    if (LN) lt.stats += M;
+    for (int n = (int)blockIdx.x * 4 + wid; n < N; n += (int)gridDim.x * 4)
+      skinny_column<8>(X + M * ldx, ldx, W, bias, HAS_RES ? R + M * ldr : nullptr, ldr, Y + M * ldy, ldy, m_tail, n, K,
+                       ACT, lt, lane);
+  }
   const int64_t xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = gridDim.x >> 3;
   const int64_t q8 = n_tiles / 8, r8 = n_tiles % 8;
   const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -1056,9 +1107,12 @@ static int linear_launch(const void* x, int64_t ldx, const void* w, const float*
                          int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st,
                          LnFold ln);
 
+// Returns through *tail_done whether the up to 8 rows behind M (m_tail) were computed by the same launch.
 static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                                   int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
-                                  hipStream_t st, LnFold ln = LnFold{nullptr, nullptr}) {
+                                  hipStream_t st, LnFold ln = LnFold{nullptr, nullptr}, int m_tail = 0,
+                                  bool* tail_done = nullptr) {
+  if (tail_done != nullptr) *tail_done = false;
   static bool raised = false;
   if (!raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<0, false>),
@@ -1119,11 +1173,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
   if (variant == 1 && K >= 128 && ldx < (int64_t)1 << 21 && ldy < (int64_t)1 << 21 && ldr < (int64_t)1 << 21 && vec_ok &&
       M % BIG_M == 0 && (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0)) {
+    const int w4_tail = (m_tail > 0 && m_tail <= 8 && K % 8 == 0) ? m_tail : 0;
+    if (tail_done != nullptr) *tail_done = w4_tail > 0;
 #define LAUNCH_W4__(A, RES, LNF)                                                                             \
   hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES, LNF>), dim3((unsigned)blocks), dim3(256), W4_LDS, st,    \
                      static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,                \
                      static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K,       \
-                     vec_ok ? 1 : 0, mt * nt, (int)nt, ln)
+                     vec_ok ? 1 : 0, mt * nt, (int)nt, ln, w4_tail)
 #define LAUNCH_W4_(A, RES)                             \
   do {                                                 \
     if (ln.stats != nullptr) LAUNCH_W4__(A, RES, true); \
@@ -1189,39 +1245,7 @@ __global__ __launch_bounds__(256) void linear_bf16_skinny_kernel(const bf16_t* _
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
-  float acc[ROWS];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  const bf16_t* wrow = W + (int64_t)n * K;
-  for (int k = lane * 8; k < K; k += 512) {
-    float wv[8];
-    VecIO<bf16_t, 8>::load(wrow + k, wv);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      if (r < M) {
-        float xv[8];
-        VecIO<bf16_t, 8>::load(X + r * ldx + k, xv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[r] = fmaf(xv[i], wv[i], acc[r]);
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
-  if (lane == 0) {
-    const float b = bias != nullptr ? bias[n] : 0.f;
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      if (r < M) {
-        float a = acc[r];
-        if (ln.stats != nullptr) a = fmaf(a, ln.stats[r].x, ln.stats[r].y * ln.colsum[n]);
-        float o = act_apply(a + b, act);
-        o = bf16_to_f32(f32_to_bf16(o));  // same double rounding as the tiled kernel (bf16 result, then + residual)
-        if (R != nullptr) o += bf16_to_f32(R[r * ldr + n]);
-        Y[r * ldy + n] = f32_to_bf16(o);
-      }
-    }
-  }
+  skinny_column<ROWS>(X, ldx, W, bias, R, ldr, Y, ldy, M, n, K, act, ln, lane);
 }
 
 template <typename T, typename TO>
@@ -1267,8 +1291,10 @@ static int linear_dispatch(const char* who, int dtype, int out_dtype, const void
     // +10 %): the 256-row multiple goes to the persistent kernel, the few remaining rows to the 128 x 128 kernel.
     const int64_t m_main = M / BIG_M * BIG_M, m_tail = M - m_main;
     if (m_tail == 0) return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
-    const int rc = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, m_main, N, K, act, st, ln);
-    if (rc != ANEMOI_OK) return rc;
+    bool tail_done = false;
+    const int rc = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, m_main, N, K, act, st, ln,
+                                          m_tail <= 8 ? (int)m_tail : 0, &tail_done);
+    if (rc != ANEMOI_OK || tail_done) return rc;
     const bf16_t* xt = static_cast<const bf16_t*>(x) + m_main * ldx;
     const bf16_t* rt = residual ? static_cast<const bf16_t*>(residual) + m_main * ldr : nullptr;
     bf16_t* yt = static_cast<bf16_t*>(y) + m_main * ldy;

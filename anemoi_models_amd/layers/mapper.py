@@ -185,6 +185,12 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
 
     def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
         ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]
+        if runtime.ln_fold_enabled(x_dst.dtype) and x_dst.shape[1] % ops.k_multiple(x_dst.dtype) == 0:
+            # LayerNorm folded into the extraction Linear (row statistics + anemoi_linear_ln)
+            wf, bf, cs = self._packed.get(("extract", "lnfold", x_dst.dtype), [lin.weight, lin.bias, ln.weight, ln.bias],
+                                          lambda: runtime.fold_layer_norm(lin.weight.detach().float(), lin.bias,
+                                                                          ln.weight, ln.bias, x_dst.dtype))
+            return ops.linear(x_dst, wf, bf, out_dtype=out_dtype, ln=(ops.row_stats(x_dst, ln.eps), cs))
         h = ops.layer_norm(x_dst, runtime.f32c(ln.weight), runtime.f32c(ln.bias), ln.eps)
         return linear_native(self._packed, "extract", lin, h, out_dtype=out_dtype)
 
