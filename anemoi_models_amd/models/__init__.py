@@ -1,3 +1,4 @@
 from .encoder_processor_decoder import AnemoiModelEncProcDec
+from .hierarchical import AnemoiModelEncProcDecHierarchical
 
-__all__ = ["AnemoiModelEncProcDec"]
+__all__ = ["AnemoiModelEncProcDec", "AnemoiModelEncProcDecHierarchical"]

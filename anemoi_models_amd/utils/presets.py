@@ -57,3 +57,15 @@ def model_config(processor: str = "GraphTransformer", channels: int = 64, layers
             },
         }
     )
+
+
+def hierarchical_model_config(channels: int = 64, heads: int = 16, hidden=("hidden_1", "hidden_2"),
+                              level_layers: int = 2, level_process: bool = True, multistep: int = 2,
+                              trainable: int = 8) -> DotDict:
+    """Config of ``AnemoiModelEncProcDecHierarchical`` (reference models/hierarchical.py:40-66 reads ``graph.hidden`` as
+    a LIST of node sets, ``model.enable_hierarchical_level_processing`` and ``model.level_process_num_layers``)."""
+    cfg = model_config("GraphTransformer", channels, level_layers, heads, multistep, trainable, proc_chunks=1)
+    cfg["graph"]["hidden"] = list(hidden)
+    cfg["model"]["enable_hierarchical_level_processing"] = level_process
+    cfg["model"]["level_process_num_layers"] = level_layers
+    return cfg

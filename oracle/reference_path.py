@@ -441,3 +441,60 @@ def model_forward(
     if return_stages:
         return x_out, {"x_latent": x_latent, "x_proc": x_proc}
     return x_out
+
+
+def hierarchical_forward(
+    sd: SD,
+    graph: Mapping[str, Tensor],
+    x: Tensor,
+    *,
+    hidden: Sequence[str],
+    num_heads: int,
+    level_layers: int,
+    prognostic_in: Sequence[int],
+    prognostic_out: Sequence[int],
+    level_process: bool = True,
+    act: str = "GELU",
+    data: str = "data",
+):
+    """models/hierarchical.py:178-308 ``AnemoiModelEncProcDecHierarchical.forward`` with GraphTransformer mappers /
+    processors (no boundings).
+
+    ``graph`` holds, per sub-module prefix ``p`` (``encoder``, ``decoder``, ``downscale.<h>``, ``upscale.<h>``,
+    ``down_level_processor.<h>``, ``up_level_processor.<h>``), the buffers ``p + ".edge_index"`` and
+    ``p + ".edge_attr"`` (``edge_index_base`` / ``edge_attr`` of layers/mapper.py:141-148).
+    """
+    b, t, ens, g, v = x.shape
+    x_data = torch.cat(
+        (x.permute(0, 2, 3, 1, 4).reshape(b * ens * g, t * v), node_attributes(sd, data, b)), dim=-1
+    )  # :183-190
+    x_hid = {h: node_attributes(sd, h, b) for h in hidden}  # :193-195
+
+    def fwd(p, xs, xd):
+        return gt_forward_mapper(sd, p, xs, xd, graph[p + ".edge_attr"], graph[p + ".edge_index"], b, num_heads, act)
+
+    def bwd(p, xs, xd):
+        return gt_backward_mapper(sd, p, xs, xd, graph[p + ".edge_attr"], graph[p + ".edge_index"], b, num_heads, act)
+
+    def proc(p, xx):
+        return gt_processor(sd, p, xx, graph[p + ".edge_attr"], graph[p + ".edge_index"], b, level_layers, 1, num_heads,
+                            act)
+
+    x_data_latent, curr = fwd("encoder", x_data, x_hid[hidden[0]])  # :204-210
+    enc, skip = {}, {}
+    for src, dst in zip(hidden[:-1], hidden[1:]):  # :217-241
+        if level_process:
+            curr = proc(f"down_level_processor.{src}", curr)
+        skip[src] = curr
+        enc[src], curr = fwd(f"downscale.{src}", curr, x_hid[dst])
+    if level_process:  # :244-250
+        curr = proc(f"down_level_processor.{hidden[-1]}", curr)
+    for dst, src in zip(reversed(hidden[:-1]), reversed(hidden[1:])):  # :253-278
+        curr = bwd(f"upscale.{src}", curr, enc[dst])
+        curr = curr + skip[dst]
+        if level_process:
+            curr = proc(f"up_level_processor.{dst}", curr)
+    x_out = bwd("decoder", curr, x_data_latent)  # :281-287
+    x_out = x_out.reshape(b, ens, g, -1).to(x.dtype).clone()  # :289-299
+    x_out[..., list(prognostic_out)] += x[:, -1, :, :, list(prognostic_in)]  # :302
+    return x_out

@@ -44,6 +44,18 @@ def golden_cfg1_gt():
 
 
 @pytest.fixture(scope="session")
+def golden_hier_gt():
+    return load_npz("hier_gt.npz")
+
+
+@pytest.fixture(scope="session")
+def graph_hier():
+    from anemoi_models_amd.graphs.synthetic import build_hierarchical_graph
+
+    return build_hierarchical_graph("o32", (2, 1))
+
+
+@pytest.fixture(scope="session")
 def golden_cfg1_gnn():
     return load_npz("cfg1_gnn.npz")
 

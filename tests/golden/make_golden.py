@@ -37,8 +37,10 @@ from anemoi.models.layers.block import GraphTransformerProcessorBlock  # noqa: E
 from anemoi.models.layers.block import TransformerProcessorBlock  # noqa: E402
 from anemoi.models.layers.mapper import GraphEdgeMixin  # noqa: E402
 from anemoi.models.models.encoder_processor_decoder import AnemoiModelEncProcDec  # noqa: E402
+from anemoi.models.models.hierarchical import AnemoiModelEncProcDecHierarchical  # noqa: E402
 
 from anemoi_models_amd.graphs.synthetic import build_graph  # noqa: E402
+from anemoi_models_amd.graphs.synthetic import build_hierarchical_graph  # noqa: E402
 from anemoi_models_amd.utils.indices import SimpleDataIndices  # noqa: E402
 
 EDGE_ATTRS = ["edge_length", "edge_dirs"]
@@ -147,6 +149,31 @@ def golden_model(processor: str, fname: str, graph_name: str = "o32_ico2", chann
     return {k: list(v.shape) for k, v in sd.items()}
 
 
+def golden_hierarchical(fname: str = "hier_gt.npz", channels: int = 64, heads: int = 16, level_layers: int = 2) -> dict:
+    """``AnemoiModelEncProcDecHierarchical`` (reference models/hierarchical.py) on O32 -> ico-2 -> ico-1."""
+    g = build_hierarchical_graph("o32", (2, 1))
+    idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+    cfg = model_config("GraphTransformer", channels, level_layers, heads)
+    cfg["graph"]["hidden"] = ["hidden_1", "hidden_2"]
+    cfg["model"]["processor"]["num_chunks"] = 1
+    cfg["model"]["enable_hierarchical_level_processing"] = True
+    cfg["model"]["level_process_num_layers"] = level_layers
+    cfg = _ref_stubs.DotDict(cfg)
+    torch.manual_seed(1234)
+    model = AnemoiModelEncProcDecHierarchical(model_config=cfg, data_indices=idx, graph_data=to_ref_graph(g))
+    randomise(model, 4321)
+    model.eval()
+    x = torch.randn((1, 2, 1, g["data"].num_nodes, idx.num_input), generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        y = model(x)
+    sd = model.state_dict()
+    out = {"x": x.numpy(), "y": y.numpy()}
+    out.update({f"sd.{k}": v.numpy() for k, v in sd.items()})
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "params", sum(p.numel() for p in model.parameters()), "y", tuple(y.shape), "|y|max", float(y.abs().max()))
+    return {k: list(v.shape) for k, v in sd.items()}
+
+
 def golden_blocks() -> None:
     gen = torch.Generator().manual_seed(99)
     out = {}
@@ -249,6 +276,7 @@ if __name__ == "__main__":
         "GNN": golden_model("GNN", "cfg1_gnn.npz"),
         "Transformer": golden_model("Transformer", "cfg1_tfm.npz"),
         "GNN_all": golden_model("GNN", "cfg1_gnn_all.npz", mappers="GNN"),
+        "Hierarchical": golden_hierarchical(),
     }
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0, sort_keys=True)

@@ -304,6 +304,42 @@ def test_model_cfg1_bf16_report(graph_o32, golden_cfg1_gt, monkeypatch):
     assert err < 5e-2
 
 
+def _build_hier(graph, channels=64, heads=16):
+    from anemoi_models_amd.models import AnemoiModelEncProcDecHierarchical
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import hierarchical_model_config
+
+    idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+    return AnemoiModelEncProcDecHierarchical(model_config=hierarchical_model_config(channels, heads),
+                                             data_indices=idx, graph_data=graph)
+
+
+def test_hierarchical_model_vs_golden_f32(graph_hier, golden_hier_gt):
+    """AnemoiModelEncProcDecHierarchical (reference models/hierarchical.py:178-308) on the HIP kernels against the
+    vectors recorded from the real reference: O32 -> ico-2 (64 ch) -> ico-1 (128 ch), level processors of 2 blocks."""
+    gold = golden_hier_gt
+    model = _build_hier(graph_hier)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        y = model(gold["x"].to(DEV))
+    assert y.dtype == torch.float32 and y.shape == gold["y"].shape
+    assert rel_err(y, gold["y"]) < 1e-4
+
+
+def test_hierarchical_model_bf16_report(graph_hier, golden_hier_gt, monkeypatch):
+    gold = golden_hier_gt
+    model = _build_hier(graph_hier)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    with torch.no_grad():
+        y = model(gold["x"].to(DEV))
+    err = rel_err(y, gold["y"])
+    print(f"hierarchical, bf16 storage / f32 accumulate vs f32 reference: max rel err {err:.3e}")
+    assert err < 5e-2
+
+
 def test_model_o96_ico5_512ch_vs_oracle_f32():
     """BASELINE config 2 shape (O96 -> ico-5, 512 ch, 16 heads) with 4 processor blocks to keep the CPU oracle fast."""
     from anemoi_models_amd.graphs.synthetic import build_graph

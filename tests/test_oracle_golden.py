@@ -130,3 +130,31 @@ def test_gt_conv_matches_dense_formulation():
                 dense[i, hh] += wn * (v[ei[0, n], hh] + ea[n, hh]).double()
     torch.testing.assert_close(out.double(), dense, atol=1e-5, rtol=1e-5)
     assert torch.all(out[nd - 1] == 0)  # isolated destination stays exactly zero
+
+
+def hier_graph_tensors(g, hidden=("hidden_1", "hidden_2"), data="data"):
+    def put(out, prefix, key):
+        st = g[key]
+        out[prefix + ".edge_index"] = st.edge_index
+        out[prefix + ".edge_attr"] = torch.cat([st["edge_length"], st["edge_dirs"]], dim=1)
+
+    out = {}
+    put(out, "encoder", (data, "to", hidden[0]))
+    put(out, "decoder", (hidden[0], "to", data))
+    for h in hidden:
+        put(out, f"down_level_processor.{h}", (h, "to", h))
+        put(out, f"up_level_processor.{h}", (h, "to", h))
+    for fine, coarse in zip(hidden[:-1], hidden[1:]):
+        put(out, f"downscale.{fine}", (fine, "to", coarse))
+        put(out, f"upscale.{coarse}", (coarse, "to", fine))
+    return out
+
+
+def test_hierarchical_model(golden_hier_gt, graph_hier):
+    """oracle.hierarchical_forward == the real AnemoiModelEncProcDecHierarchical (reference models/hierarchical.py)."""
+    gold = golden_hier_gt
+    sd = split_prefix(gold, "sd.")
+    y = ref.hierarchical_forward(sd, hier_graph_tensors(graph_hier), gold["x"], hidden=["hidden_1", "hidden_2"],
+                                 num_heads=16, level_layers=2, prognostic_in=list(range(10)),
+                                 prognostic_out=list(range(10)))
+    torch.testing.assert_close(y, gold["y"], atol=ATOL, rtol=RTOL)
