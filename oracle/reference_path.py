@@ -498,3 +498,56 @@ def hierarchical_forward(
     x_out = x_out.reshape(b, ens, g, -1).to(x.dtype).clone()  # :289-299
     x_out[..., list(prognostic_out)] += x[:, -1, :, :, list(prognostic_in)]  # :302
     return x_out
+
+
+# --------------------------------------------------------------------------
+# Interface: normaliser + predict_step (the step either side of the model forward)
+# --------------------------------------------------------------------------
+def normalizer_affine(config: Mapping, name_to_index: Mapping[str, int], statistics: Mapping):
+    """preprocessing/normalizer.py:44-105 (+ preprocessing/__init__.py:63-101): per-variable ``(mul, add)`` of
+    ``InputNormalizer`` from its config ``{default, remap, <method>: [variables]}`` and the dataset statistics."""
+    import numpy as np
+
+    default = config.get("default", "none")
+    remap = config.get("remap", {})
+    methods = {}
+    for method, variables in config.items():
+        if method in ("default", "remap") or variables is None or variables == "none":
+            continue
+        for v in ([variables] if isinstance(variables, str) else variables):
+            methods[v] = method
+    mn, mx = np.array(statistics["minimum"], copy=True), np.array(statistics["maximum"], copy=True)
+    mean, sd = np.array(statistics["mean"], copy=True), np.array(statistics["stdev"], copy=True)
+    new = {name_to_index[r]: (mn[name_to_index[s_]], mx[name_to_index[s_]], mean[name_to_index[s_]], sd[name_to_index[s_]])
+           for r, s_ in remap.items()}  # :53-60 two-step remap
+    for i, (a, b, c, d) in new.items():
+        mn[i], mx[i], mean[i], sd[i] = a, b, c, d
+    mul = np.ones((mn.size,), dtype=np.float32)
+    add = np.zeros((mn.size,), dtype=np.float32)
+    for name, i in name_to_index.items():
+        m = methods.get(name, default)
+        if m == "mean-std":  # :70-75
+            mul[i], add[i] = 1 / sd[i], -mean[i] / sd[i]
+        elif m == "std":  # :77-82
+            mul[i], add[i] = 1 / sd[i], 0
+        elif m == "min-max":  # :84-90
+            mul[i], add[i] = 1 / (mx[i] - mn[i]), -mn[i] / (mx[i] - mn[i])
+        elif m == "max":  # :92-94
+            mul[i] = 1 / mx[i]
+        elif m != "none":
+            raise ValueError(m)
+    return torch.from_numpy(mul), torch.from_numpy(add)
+
+
+def predict_step(sd: SD, graph: Mapping[str, Tensor], batch: Tensor, *, multi_step: int, **model_kwargs) -> Tensor:
+    """interface/__init__.py:97-123 ``AnemoiModelInterface.predict_step`` with one ``InputNormalizer`` named
+    ``normalizer``: normalise the input variables (preprocessing/normalizer.py:134-164, branch
+    ``x.shape[-1] == len(_input_idx)``), run the model, de-normalise the output variables (:166-205)."""
+    p = "pre_processors.processors.normalizer."
+    mul, add = sd[p + "_norm_mul"], sd[p + "_norm_add"]
+    i_in, i_out = sd[p + "_input_idx"].long(), sd[p + "_output_idx"].long()
+    x = batch * mul[i_in] + add[i_in]
+    x = x[:, 0:multi_step, None, ...]
+    model_sd = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
+    y = model_forward(model_sd, graph, x, **model_kwargs)
+    return (y - add[i_out]) / mul[i_out]

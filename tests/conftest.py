@@ -44,6 +44,11 @@ def golden_cfg1_gt():
 
 
 @pytest.fixture(scope="session")
+def golden_interface():
+    return load_npz("interface_gt.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_hier_gt():
     return load_npz("hier_gt.npz")
 

@@ -239,6 +239,15 @@ def install(reference_src: str = "/root/reference/src") -> None:
     au = mod("anemoi.utils")
     au.__path__ = []
     au.config = mod("anemoi.utils.config", DotDict=DotDict)
+    # omegaconf: the reference's IndexCollection only calls OmegaConf.to_container on plain (DotDict) configs
+    def _to_container(cfg, resolve=True):
+        if isinstance(cfg, dict):
+            return {k: _to_container(v) for k, v in cfg.items()}
+        if isinstance(cfg, (list, tuple)):
+            return [_to_container(v) for v in cfg]
+        return cfg
+
+    mod("omegaconf", OmegaConf=type("OmegaConf", (), {"to_container": staticmethod(_to_container)}))
     _ = Union
     if reference_src not in sys.path:
         sys.path.insert(0, reference_src)

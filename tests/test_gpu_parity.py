@@ -340,6 +340,20 @@ def test_hierarchical_model_bf16_report(graph_hier, golden_hier_gt, monkeypatch)
     assert err < 5e-2
 
 
+def test_interface_predict_step_vs_golden(graph_o32, golden_interface):
+    """AnemoiModelInterface.predict_step (normalise -> HIP forward -> de-normalise) against the vectors recorded from
+    the real reference interface (reference interface/__init__.py:97-123, preprocessing/normalizer.py)."""
+    from test_host_logic import build_interface
+
+    gold = golden_interface
+    iface = build_interface(graph_o32, gold)
+    iface.load_state_dict(split_prefix(gold, "sd."))
+    iface = iface.to(DEV).eval()
+    y = iface.predict_step(gold["batch"].to(DEV))
+    assert y.shape == gold["y"].shape and y.dtype == torch.float32
+    assert rel_err(y, gold["y"]) < 1e-4
+
+
 def test_model_o96_ico5_512ch_vs_oracle_f32():
     """BASELINE config 2 shape (O96 -> ico-5, 512 ch, 16 heads) with 4 processor blocks to keep the CPU oracle fast."""
     from anemoi_models_amd.graphs.synthetic import build_graph

@@ -229,3 +229,49 @@ def test_hierarchical_model_wiring_matches_golden(graph_hier, golden_hier_gt, mo
     with torch.no_grad():
         y = model(gold["x"])
     torch.testing.assert_close(y, gold["y"], atol=2e-4, rtol=2e-4)
+
+
+NORMALIZER_METHODS = {"default": "mean-std", "min-max": ["prog_3"], "max": ["prog_4"], "std": ["prog_5"],
+                      "none": ["forc_0"], "remap": {"prog_7": "prog_6"}}  # as in tests/golden/make_golden.py
+
+
+def build_interface(graph, gold):
+    from anemoi_models_amd.interface import AnemoiModelInterface
+
+    cfg = model_config("GraphTransformer", 64, 4, 16)
+    cfg["data"] = {"forcing": ["forc_0", "forc_1"], "diagnostic": ["diag_0"],
+                   "processors": {"normalizer": {"_target_": "anemoi.models.preprocessing.normalizer.InputNormalizer",
+                                                 "config": dict(NORMALIZER_METHODS)}}}
+    cfg["model"]["model"] = {"_target_": "anemoi.models.models.encoder_processor_decoder.AnemoiModelEncProcDec"}
+    cfg = type(cfg)(cfg)
+    stats = {k: v.numpy() for k, v in split_prefix(gold, "stat.").items()}
+    idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+    return AnemoiModelInterface(config=cfg, graph_data=graph, statistics=stats, data_indices=idx, metadata={})
+
+
+def test_interface_state_dict_and_normalizer_buffers_match_reference(graph_o32, golden_interface):
+    """Same state_dict layout as the reference AnemoiModelInterface, and the InputNormalizer buffers built from the
+    same config / statistics are identical to the reference's (reference preprocessing/normalizer.py:44-105)."""
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        want = json.load(f)["Interface"]
+    iface = build_interface(graph_o32, golden_interface)
+    got = {k: list(v.shape) for k, v in iface.state_dict().items()}
+    assert got == want
+    sd = split_prefix(golden_interface, "sd.")
+    for side in ("pre_processors", "post_processors"):
+        for buf in ("_norm_mul", "_norm_add", "_input_idx", "_output_idx"):
+            key = f"{side}.processors.normalizer.{buf}"
+            torch.testing.assert_close(iface.state_dict()[key].double(), sd[key].double(), atol=1e-6, rtol=1e-6)
+
+
+def test_interface_predict_step_matches_golden(graph_o32, golden_interface, monkeypatch):
+    """predict_step: normalise -> model -> de-normalise (reference interface/__init__.py:97-123)."""
+    _cpu_ops.install(monkeypatch)
+    gold = golden_interface
+    iface = build_interface(graph_o32, gold)
+    iface.load_state_dict(split_prefix(gold, "sd."))
+    iface.eval()
+    y = iface.predict_step(gold["batch"])
+    torch.testing.assert_close(y, gold["y"], atol=5e-4, rtol=5e-4)
+    with pytest.raises(AssertionError):
+        iface.predict_step(gold["batch"][0])  # 3-dimensional input: same assertion as the reference

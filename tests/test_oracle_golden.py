@@ -158,3 +158,22 @@ def test_hierarchical_model(golden_hier_gt, graph_hier):
                                  num_heads=16, level_layers=2, prognostic_in=list(range(10)),
                                  prognostic_out=list(range(10)))
     torch.testing.assert_close(y, gold["y"], atol=ATOL, rtol=RTOL)
+
+
+NORMALIZER_METHODS = {"default": "mean-std", "min-max": ["prog_3"], "max": ["prog_4"], "std": ["prog_5"],
+                      "none": ["forc_0"], "remap": {"prog_7": "prog_6"}}  # as in tests/golden/make_golden.py
+
+
+def test_normalizer_and_predict_step(golden_interface, graph_o32):
+    """oracle.normalizer_affine / predict_step == the real InputNormalizer + AnemoiModelInterface.predict_step
+    (reference preprocessing/normalizer.py, interface/__init__.py) built on the real IndexCollection."""
+    gold = golden_interface
+    sd = split_prefix(gold, "sd.")
+    names = [f"prog_{i}" for i in range(10)] + [f"forc_{i}" for i in range(2)] + ["diag_0"]
+    stats = {k: v.numpy() for k, v in split_prefix(gold, "stat.").items()}
+    mul, add = ref.normalizer_affine(NORMALIZER_METHODS, {n: i for i, n in enumerate(names)}, stats)
+    torch.testing.assert_close(mul, sd["pre_processors.processors.normalizer._norm_mul"], atol=0, rtol=1e-6)
+    torch.testing.assert_close(add, sd["pre_processors.processors.normalizer._norm_add"], atol=1e-6, rtol=1e-6)
+    y = ref.predict_step(sd, graph_tensors(graph_o32), gold["batch"], multi_step=2, num_heads=16, num_layers=4,
+                         num_chunks=2, prognostic_in=list(range(10)), prognostic_out=list(range(10)))
+    torch.testing.assert_close(y, gold["y"], atol=1e-4, rtol=1e-4)
