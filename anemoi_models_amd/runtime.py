@@ -237,3 +237,38 @@ def f32c(t: Tensor) -> Tensor:
     """f32 contiguous view of a parameter (no copy for the usual f32 parameter)."""
     t = t.detach()
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class GraphedForward:
+    """One model forward captured in a HIP graph and replayed (``torch.cuda.CUDAGraph`` is ``hipGraph`` on ROCm).
+
+    The forward is a fixed sequence of ~100 kernel launches through the C ABI; for the small configurations (O32 / O96
+    grids) the step is bound by Python + launch latency, not by the GPU.  Capture needs nothing special from the
+    kernels: they launch on torch's current stream, every buffer comes from torch's allocator (graph-private pool
+    during capture), the edge plans / packed weights are cached by the warm-up calls, and no kernel of the path
+    synchronises or allocates with hipMalloc.  Shapes and weights are frozen at capture time: re-capture after
+    ``load_state_dict`` or for a different input shape.
+    """
+
+    def __init__(self, model, example_x: Tensor, warmup: int = 2) -> None:
+        if not example_x.is_cuda:
+            raise ValueError("GraphedForward: the example input must live on the GPU")
+        self.model = model
+        self.static_x = example_x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():  # warm-up on a side stream (required before capture)
+            for _ in range(max(1, warmup)):
+                model(self.static_x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_y = model(self.static_x)
+
+    def __call__(self, x: Tensor) -> Tensor:
+        if x.shape != self.static_x.shape or x.dtype != self.static_x.dtype:
+            raise ValueError("GraphedForward: input shape / dtype differs from the captured one")
+        self.static_x.copy_(x)
+        self.graph.replay()
+        return self.static_y

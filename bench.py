@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2, help="processor blocks in the CPU-baseline sample")
     ap.add_argument("--detail", action="store_true", help="print a per-shape kernel table to stderr")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="replay the forward as one captured HIP graph (single GPU; pays off on the small workloads)")
     return ap.parse_args()
 
 
@@ -215,7 +217,15 @@ def main():
     n_mesh = graph["hidden"].num_nodes
     layers = WORKLOADS[args.workload][2]
 
+    graphed = None
+    if args.hipgraph and group is None:
+        from anemoi_models_amd.runtime import GraphedForward
+
+        graphed = GraphedForward(model, x)
+
     def step():
+        if graphed is not None:
+            return graphed(x)
         with torch.no_grad():
             return model(x, group) if group is not None else model(x)
 

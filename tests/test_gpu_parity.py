@@ -354,6 +354,24 @@ def test_interface_predict_step_vs_golden(graph_o32, golden_interface):
     assert rel_err(y, gold["y"]) < 1e-4
 
 
+def test_forward_replayed_as_hip_graph(graph_o32, golden_cfg1_gt):
+    """runtime.GraphedForward: the whole forward captured once in a HIP graph, replayed on new inputs."""
+    from anemoi_models_amd.runtime import GraphedForward
+
+    gold = golden_cfg1_gt
+    model, _ = _build(graph_o32, 64, 4)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    x = gold["x"].to(DEV)
+    graphed = GraphedForward(model, torch.zeros_like(x))
+    y = graphed(x).clone()
+    assert rel_err(y, gold["y"]) < 1e-4
+    y2 = graphed(2.0 * x).clone()  # a second replay with different data in the static input buffer
+    with torch.no_grad():
+        want2 = model(2.0 * x)
+    assert rel_err(y2, want2) < 1e-6
+
+
 def test_model_o96_ico5_512ch_vs_oracle_f32():
     """BASELINE config 2 shape (O96 -> ico-5, 512 ch, 16 heads) with 4 processor blocks to keep the CPU oracle fast."""
     from anemoi_models_amd.graphs.synthetic import build_graph
