@@ -566,7 +566,7 @@ __device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int6
   }
 }
 
-template <int ACT, bool HAS_RES, bool LN>
+template <int ACT, bool HAS_RES, bool LN, int MH>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias,
@@ -574,6 +574,13 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
                                                              bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
                                                              int K, int vec_ok, int64_t n_tiles, int nt_count,
                                                              LnFold ln, int m_tail) {
+  // MH = 16-row fragments per wave along M: 8 -> the 256 x 256 tile, 4 -> a 128 x 256 tile (wave tile 64 x 128) used for
+  // the rows of a remainder round (640 tiles on 256 CUs: the last 128 tiles become 256 half tiles = one full round).
+  constexpr int TM = MH * 32;        // tile rows
+  constexpr int NS = 8 * MH;         // MFMAs per 32-deep K step
+  constexpr int NRD = 8 + MH;        // fragment reads per K step = LDS-DMA instructions per slab and wave
+  constexpr int G1 = MH == 8 ? 23 : 15, SP = MH == 8 ? 5 : 3, G2 = MH == 8 ? 103 : 51;  // schedule (see below)
+  static_assert(G1 + 1 + (NRD - 1) * SP < G2 && G2 + NRD < 2 * NS, "slab schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -610,15 +617,15 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     vow[p] = (8 * (srow >> 2) + (srow & 3)) * K * 2 + c * 16;
   }
   const int xrow16 = 16 * (int)ldx * 2;
-  const int xwave = wid * 64 * (int)ldx * 2, wwave = wid * 64 * K * 2;
+  const int xwave = wid * (MH * 8) * (int)ldx * 2, wwave = wid * 64 * K * 2;
   __amdgpu_buffer_rsrc_t xrs, wrs;  // descriptors of the tile whose slabs are being staged
   auto set_tile = [&](int64_t tile) {
     int64_t mt_;
     int nt_;
     tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
-    const int64_t m0 = mt_ * BIG_M;
+    const int64_t m0 = mt_ * TM;
     const int n0 = nt_ * BIG_N;
-    const int64_t xrows = M - m0 < BIG_M ? M - m0 : BIG_M;
+    const int64_t xrows = M - m0 < TM ? M - m0 : TM;
     const int wrows = N - n0 < BIG_N ? N - n0 : BIG_N;
     xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + m0 * ldx), 0, (int)(xrows * ldx * 2), 0x00020000);
     wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * K), 0, wrows * K * 2, 0x00020000);
@@ -636,12 +643,14 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
                                              wwave + (32 * (i >> 2) + 16 * (i & 1) + 4 * ((i >> 1) & 1)) * K * 2 + kt * ROW_BYTES,
                                              0, 0);
   };
+  // LDS image of a slab: x panel rows 0 .. TM-1 at the stage base (wave w: rows w * MH * 8 ...), W panel at + 32 KiB
   auto stage_all = [&](int kt, int buf) {
-    char* xs = smem + buf * BIG_STAGE + wid * 8192;
+    char* xs = smem + buf * BIG_STAGE + wid * (MH * 1024);
+    char* ws = smem + buf * BIG_STAGE + BIG_M * ROW_BYTES + wid * 8192;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      dma_x(i, kt, xs + i * 1024);
-      dma_w(i, kt, xs + BIG_M * ROW_BYTES + i * 1024);
+      if (i < MH) dma_x(i, kt, xs + i * 1024);
+      dma_w(i, kt, ws + i * 1024);
     }
   };
 
@@ -654,11 +663,11 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
                                               (swz(row, ks * 4 + fq) << 4));
   };
   auto ldB = [&](int buf, int ks, int j) {  // x fragment (M side)
-    const int row = wm * 128 + j * 16 + fr;
+    const int row = wm * (MH * 16) + j * 16 + fr;
     return *reinterpret_cast<const bf16x8_t*>(smem + buf * BIG_STAGE + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
   };
-  f32x4_t acc[8][8];
-  bf16x8_t a0[8], b0[8], a1[8], b1[8];
+  f32x4_t acc[8][MH];
+  bf16x8_t a0[8], b0[MH], a1[8], b1[MH];
 
   // prologue: slabs 0 and 1 of the first tile; fragments of (slab 0, ks 0)
   set_tile(chunk_start + bix);
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    b0[u] = ldB(0, 0, u);
+    if (u < MH) b0[u] = ldB(0, 0, u);
     a0[u] = ldA(0, 0, u);
   }
   stage_all(1, 1);
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < MH; ++j)
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc[i][j]) : "v"(zfrag));
 
   // ONE loop over the workgroup's slab stream (tile prologue and epilogue are conditional blocks inside it): with a
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       int64_t mt_;
       int nt_;
       tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
-      m0 = mt_ * BIG_M;
+      m0 = mt_ * TM;
       n0 = nt_ * BIG_N;
       // The tile's 256 bias values go to LDS by one 4-byte LDS-DMA per wave (columns >= N: zeros from the descriptor's
       // range check) and come back in the epilogue: 32 bias registers per lane would not survive the K loop unspilled.
@@ -733,40 +742,45 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     // descriptors are empty (every lane out of range: zeros into a dead buffer), so the DMA count per slab stays 16.
     auto slab = [&](int kt_stage, bool vm_wait) {
       const int buf = g & 1, nbuf = buf ^ 1;
-      char* xsd = smem + buf * BIG_STAGE + wid * 8192;
+      char* xsd = smem + buf * BIG_STAGE + wid * (MH * 1024);
+      char* wsd = smem + buf * BIG_STAGE + BIG_M * ROW_BYTES + wid * 8192;
       static_for_seq(
           [&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value;
-            if constexpr (s < 64) ANEMOI_MFMA_A(acc[s >> 3][s & 7], a0[s >> 3], b0[s & 7]);
-            else ANEMOI_MFMA_A(acc[(s - 64) >> 3][s & 7], a1[(s - 64) >> 3], b1[s & 7]);
-            if constexpr (s < 16) {  // fragments of (this slab, ks = 1)
-              if constexpr (s < 8) b1[s] = ldB(buf, 1, s);
-              else a1[s - 8] = ldA(buf, 1, s - 8);
+            if constexpr (s < NS) ANEMOI_MFMA_A(acc[s / MH][s % MH], a0[s / MH], b0[s % MH]);
+            else ANEMOI_MFMA_A(acc[(s - NS) / MH][s % MH], a1[(s - NS) / MH], b1[s % MH]);
+            if constexpr (s < NRD) {  // fragments of (this slab, ks = 1)
+              if constexpr (s < MH) b1[s] = ldB(buf, 1, s);
+              else a1[s - MH] = ldA(buf, 1, s - MH);
             }
-            if constexpr (s == 23) {  // barrier 1: every wave has read this slab's buffer completely
+            if constexpr (s == G1) {  // barrier 1: every wave has read this slab's buffer completely
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
               __builtin_amdgcn_sched_barrier(0);
               __builtin_amdgcn_s_barrier();
               __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (s >= 24 && (s - 24) % 5 == 0 && (s - 24) / 5 < 16) {  // refill it: one DMA per 5 gaps
-              constexpr int t = (s - 24) / 5, i = t >> 1;
-              if constexpr (t & 1) dma_w(i, kt_stage, xsd + BIG_M * ROW_BYTES + i * 1024);
-              else dma_x(i, kt_stage, xsd + i * 1024);
+            if constexpr (s > G1 && (s - G1 - 1) % SP == 0 && (s - G1 - 1) / SP < NRD) {  // refill it: one DMA per SP gaps
+              constexpr int t = (s - G1 - 1) / SP;  // x and W pieces alternate while x pieces last
+              if constexpr (t < 2 * MH && (t & 1) == 0) dma_x(t >> 1, kt_stage, xsd + (t >> 1) * 1024);
+              else if constexpr (t < 2 * MH) dma_w(t >> 1, kt_stage, wsd + (t >> 1) * 1024);
+              else dma_w(t - MH, kt_stage, wsd + (t - MH) * 1024);
             }
-            if constexpr (s == 103) {  // barrier 2: the other buffer (staged one slab ago) is complete for everyone
-              if (vm_wait) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (slab 0 of a later tile: waited in the epilogue)
+            if constexpr (s == G2) {  // barrier 2: the other buffer (staged one slab ago) is complete for everyone
+              if (vm_wait) {  // (slab 0 of a later tile: waited in the epilogue)
+                if constexpr (MH == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+              }
               __builtin_amdgcn_sched_barrier(0);
               __builtin_amdgcn_s_barrier();
               __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (s >= 104 && s < 120) {  // fragments of (next slab, ks = 0)
-              constexpr int t = s - 104;
-              if constexpr (t < 8) b0[t] = ldB(nbuf, 0, t);
-              else a0[t - 8] = ldA(nbuf, 0, t - 8);
+            if constexpr (s > G2 && s - G2 - 1 < NRD) {  // fragments of (next slab, ks = 0)
+              constexpr int t = s - G2 - 1;
+              if constexpr (t < MH) b0[t] = ldB(nbuf, 0, t);
+              else a0[t - MH] = ldA(nbuf, 0, t - MH);
             }
           },
-          std::make_integer_sequence<int, 128>{});
+          std::make_integer_sequence<int, 2 * NS>{});
       ++g;
     };
     if (k == nk - 2) {  // from here on the staged slabs are the next tile's
@@ -793,7 +807,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     //      lane-offset VGPR each, the row-group part in an SGPR): 64-bit per-access pointers would spill here.
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     const __amdgpu_buffer_rsrc_t yrs =  // sized to the tile: masked lanes use an out-of-range offset (store dropped)
-        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, BIG_M * (int)ldy * 2, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, TM * (int)ldy * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, 0x7fffffff, 0x00020000);
     int fr_e = fr, fq_e = fq;  // opaque copies: keeps the epilogue's lane offsets from being hoisted above the K loop
@@ -818,26 +832,27 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       }
     }
     float sv[4][8];  // LayerNorm fold: column sums of W' (LDS) and the row statistics { rstd, -mean rstd } of all 8 row groups
-    float2 rst[8];
+    float2 rst[MH];
     if constexpr (LN) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         VecIO<float, 8>::load(reinterpret_cast<const float*>(smem + 2 * BIG_STAGE + 1024) + ncol + u * 32, sv[u]);
       const __amdgpu_buffer_rsrc_t srs =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(ln.stats + m0), 0, BIG_M * 8, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc((void*)(ln.stats + m0), 0, TM * 8, 0x00020000);
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(srs, fr_e * 8, (wm * 128 + j * 16) * 8, 0);
+      for (int j = 0; j < MH; ++j) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(srs, fr_e * 8, (wm * (MH * 16) + j * 16) * 8, 0);
         rst[j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
       }
     }
     auto res_fetch = [&](auto j_tag, uint4 (&rv)[4]) {
       constexpr int j = decltype(j_tag)::value;
-      if constexpr (HAS_RES && j < 8) {
+      if constexpr (HAS_RES && j < MH) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrs, vr[u], (wm * 128 + j * 16) * (int)ldr * 2, 0);
+          const u32x4_t v =
+              __builtin_amdgcn_raw_buffer_load_b128(rrs, vr[u], (wm * (MH * 16) + j * 16) * (int)ldr * 2, 0);
           rv[u] = make_uint4(v.x, v.y, v.z, v.w);
         }
       }
@@ -885,7 +900,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
           v = make_uint4(bf16x2_add(v.x, rv[u].x), bf16x2_add(v.y, rv[u].y), bf16x2_add(v.z, rv[u].z),
                          bf16x2_add(v.w, rv[u].w));
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, yrs, vy[u],
-                                               (wm * 128 + j * 16) * (int)ldy * 2, 0);
+                                               (wm * (MH * 16) + j * 16) * (int)ldy * 2, 0);
         // Observed on gfx950: a 16-byte buffer store whose data registers are overwritten by the very next VALU
         // instruction stores the new value in part of dword 1 (lanes 12..15 of every 16).  The compiler pads this hazard
         // with one wait state except when soffset is an SGPR (as here), where it assumes none: pad by hand.
@@ -910,7 +925,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
           store_rows(j_tag, rv[j % 3]);
           ANEMOI_PIN();
         },
-        std::make_integer_sequence<int, 8>{});
+        std::make_integer_sequence<int, MH>{});
 #undef ANEMOI_PIN
     li += bpx;
     if (li >= chunk_len) break;
@@ -1135,7 +1150,9 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
                             hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS) != hipSuccess)
       return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", BIG_LDS);
 #define RAISE_W4_(A, RES, LNF)                                                                    \
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF>),     \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 8>),  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 4>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)      \
     return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
 #define RAISE_W4(A, RES) \
@@ -1175,27 +1192,66 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       M % BIG_M == 0 && (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0)) {
     const int w4_tail = (m_tail > 0 && m_tail <= 8 && K % 8 == 0) ? m_tail : 0;
     if (tail_done != nullptr) *tail_done = w4_tail > 0;
-#define LAUNCH_W4__(A, RES, LNF)                                                                             \
-  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES, LNF>), dim3((unsigned)blocks), dim3(256), W4_LDS, st,    \
-                     static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,                \
-                     static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K,       \
-                     vec_ok ? 1 : 0, mt * nt, (int)nt, ln, w4_tail)
-#define LAUNCH_W4_(A, RES)                             \
-  do {                                                 \
-    if (ln.stats != nullptr) LAUNCH_W4__(A, RES, true); \
-    else LAUNCH_W4__(A, RES, false);                   \
-  } while (0)
-#define LAUNCH_W4(A)                              \
-  do {                                            \
-    if (residual != nullptr) LAUNCH_W4_(A, true); \
-    else LAUNCH_W4_(A, false);                    \
-  } while (0)
-    switch (act) {
-      case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU); break;
-      case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU); break;
-      case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU); break;
-      default: LAUNCH_W4(ANEMOI_ACT_NONE); break;
+    // Remainder round as HALF tiles: when the tiles beyond the last whole round of 256 would keep at most half of the
+    // CUs busy (N = 1024 at M = 40 960: 640 tiles = 2.5 rounds), their rows go to a second launch with 128 x 256 tiles
+    // (MH = 4): twice as many units of half the work -- 2.5+ instead of 3 rounds, no cross-workgroup traffic.
+    // ANEMOI_AMD_GEMM_HALFTILES=0 turns it off.
+    static const bool half_tiles = [] {
+      const char* e = getenv("ANEMOI_AMD_GEMM_HALFTILES");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    int64_t mt_a = mt, mt_b = 0;  // row tiles of 256 for launch A; rows of launch B = mt_b * 256 as half tiles
+    if (half_tiles && max_blocks == 256 && nt <= 256 && 256 % nt == 0) {
+      const int64_t per_round = 256 / nt;
+      const int64_t rem_mt = mt % per_round;
+      // measured: a half tile costs ~0.75 of a whole one (its 48 KiB slab per 64 MFMAs is bound by the L2 -> LDS
+      // staging rate), and a second launch ~8 us; so split only a remainder that is the whole problem (small M of a
+      // node-partitioned run: 5120 x 1024 x 4096 0.081 -> 0.052 ms) or belongs to long tiles (K >= 2048: 40 962 x 1024
+      // x 4096 0.314 -> 0.295 ms; at K = 1216 the second launch costs what the half tiles save)
+      if (rem_mt > 0 && rem_mt * nt <= 128 && (rem_mt == mt || K >= 2048)) {
+        mt_a = mt - rem_mt;
+        mt_b = rem_mt;
+      }
     }
+#define LAUNCH_W4__(A, RES, LNF, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                       \
+  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES, LNF, MHV>), dim3((unsigned)w4_blocks), dim3(256), W4_LDS, \
+                     st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,            \
+                     vec_ok ? 1 : 0, TILES, (int)nt, LNV, TAIL)
+#define LAUNCH_W4_(A, RES, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                       \
+  do {                                                                                  \
+    if (ln.stats != nullptr) LAUNCH_W4__(A, RES, true, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); \
+    else LAUNCH_W4__(A, RES, false, MHV, XP, RP, YP, LNV, MV, TILES, TAIL);             \
+  } while (0)
+#define LAUNCH_W4(A, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                \
+  do {                                                                                     \
+    if (residual != nullptr) LAUNCH_W4_(A, true, MHV, XP, RP, YP, LNV, MV, TILES, TAIL);   \
+    else LAUNCH_W4_(A, false, MHV, XP, RP, YP, LNV, MV, TILES, TAIL);                      \
+  } while (0)
+#define LAUNCH_W4_ACT(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                 \
+  switch (act) {                                                                             \
+    case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    default: LAUNCH_W4(ANEMOI_ACT_NONE, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break;       \
+  }
+    const bf16_t* xb = static_cast<const bf16_t*>(x);
+    const bf16_t* rb = static_cast<const bf16_t*>(residual);
+    bf16_t* yb = static_cast<bf16_t*>(y);
+    int64_t w4_blocks = blocks;
+    if (mt_a > 0) {
+      const int64_t m_a = mt_a * BIG_M, tiles_a = mt_a * nt;
+      const int tail_a = mt_b == 0 ? w4_tail : 0;
+      w4_blocks = tiles_a < max_blocks ? (tiles_a + 7) / 8 * 8 : max_blocks;
+      LAUNCH_W4_ACT(8, xb, rb, yb, ln, m_a, tiles_a, tail_a)
+    }
+    if (mt_b > 0) {
+      const int64_t m_a = mt_a * BIG_M, m_b = mt_b * BIG_M, tiles_b = mt_b * 2 * nt;
+      LnFold lb = ln;
+      if (lb.stats != nullptr) lb.stats += m_a;
+      w4_blocks = tiles_b < max_blocks ? (tiles_b + 7) / 8 * 8 : max_blocks;
+      LAUNCH_W4_ACT(4, xb + m_a * ldx, rb != nullptr ? rb + m_a * ldr : nullptr, yb + m_a * ldy, lb, m_b, tiles_b, w4_tail)
+    }
+#undef LAUNCH_W4_ACT
 #undef LAUNCH_W4
 #undef LAUNCH_W4_
 #undef LAUNCH_W4__
