@@ -33,14 +33,18 @@ from .shapes import split_bounds
 
 def _alltoallv(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int], group, async_op: bool = False):
     """Row-wise all-to-all-v.  RCCL path: one ``all_to_all_single`` (optionally asynchronous: it runs on RCCL's stream
-    and the returned work handle is waited for right before the consumer); other backends (gloo in CPU tests): P2P."""
+    and the returned work handle is waited for right before the consumer); other backends (gloo in CPU tests, or gloo
+    over device tensors when several debugging ranks share one GPU): blocking P2P, staged through host memory."""
     backend = dist.get_backend(group)
     if backend == "nccl":
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
-    outs = list(out.split(out_splits, dim=0))
-    ins = list(inp.split(in_splits, dim=0))
+    staged = inp.is_cuda
+    h_out = torch.empty(out.shape, dtype=out.dtype) if staged else out
+    h_inp = inp.cpu() if staged else inp
+    outs = list(h_out.split(out_splits, dim=0))
+    ins = list(h_inp.split(in_splits, dim=0))
     outs[rank].copy_(ins[rank])
     reqs = []
     for peer in range(world):
@@ -53,6 +57,18 @@ def _alltoallv(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[
             reqs.append(dist.irecv(outs[peer], g_peer, group=group))
     for r in reqs:
         r.wait()
+    if staged:
+        out.copy_(h_out)
+
+
+def _allgather_rows(out: Tensor, inp: Tensor, group) -> None:
+    """``out[r * n : (r + 1) * n] <- inp`` of rank ``r``; host-staged when the backend cannot move device memory."""
+    if dist.get_backend(group) == "nccl" or not inp.is_cuda:
+        dist.all_gather_into_tensor(out, inp, group=group)
+        return
+    h_out = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_gather_into_tensor(h_out, inp.cpu(), group=group)
+    out.copy_(h_out)
 
 
 @dataclass
@@ -289,7 +305,7 @@ def sharded_forward(model, x: Tensor, group) -> Tensor:
     send = torch.zeros((max_rows, v_out), dtype=torch.float32, device=x.device)
     send[: y_local.shape[0]] = y_local
     gathered = torch.empty((sp.world, max_rows, v_out), dtype=torch.float32, device=x.device)
-    dist.all_gather_into_tensor(gathered.view(-1, v_out), send, group=group)
+    _allgather_rows(gathered.view(-1, v_out), send, group)
     rows = torch.cat([gathered[r, :c] for r, c in enumerate(sp.dec_counts)], dim=0)
     y = torch.empty((grid, v_out), dtype=torch.float32, device=x.device)
     y[sp.dec_all_ids] = rows

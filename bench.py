@@ -101,7 +101,7 @@ def detail_table(records, dtype_name: str) -> None:
               file=sys.stderr)
 
 
-def profile_pass(model, x, group, dtype_name: str, detail: bool = False):
+def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic_ok: bool = True):
     """One instrumented forward: HIP events around every kernel launch, on the launch stream."""
     from anemoi_models_amd import ops
 
@@ -143,6 +143,8 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False):
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (PMC counters cannot be
     # collected from inside the process; see profiles/r01_traffic.json for the command and the gfx950 corrections)
     try:
+        if not traffic_ok or group is not None:  # the PMC passes were taken on config 3 / bf16 / one GPU only
+            raise KeyError("no PMC pass for this run")
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
             traffic = json.load(f)["kernels"]
         if "roofline" in out and dtype_name == "bf16":
@@ -202,6 +204,11 @@ def main():
     from anemoi_models_amd import _lib
 
     _lib.load()  # fail loudly if the HIP library is missing
+    # debugging aid for 1-GPU boxes: ANEMOI_AMD_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with host-staged gloo
+    # collectives, so that the N > 1 code path (plans, halos, gather, timing protocol) can be run -- not timed -- there
+    share_gpu = os.environ.get("ANEMOI_AMD_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
@@ -209,7 +216,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
 
     os.environ["ANEMOI_AMD_DTYPE"] = args.dtype
@@ -255,7 +265,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_mesh * layers / (elapsed / args.steps)
-    extra = profile_pass(model, x, group, args.dtype, args.detail and rank == 0)
+    extra = profile_pass(model, x, group, args.dtype, args.detail and rank == 0,
+                         traffic_ok=args.workload == "cfg3" and args.processor == "GraphTransformer")
 
     if rank == 0:
         line = {
@@ -267,7 +278,8 @@ def main():
                 "workload": WORKLOADS[args.workload][4] + ", batch 1, 2 x 90 input vars -> 80 output vars, "
                                                           "full encoder+processor+decoder forward",
                 "mesh_nodes": n_mesh, "grid_nodes": graph["data"].num_nodes, "processor_blocks": layers,
-                "parallelism": "single GPU" if world == 1 else f"mesh node-partitioned over {world} GPUs, halo all-to-all-v",
+                "parallelism": "single GPU" if world == 1 else f"mesh node-partitioned over {world} GPUs, halo all-to-all-v"
+                               + (" [DEBUG: ranks share one GPU, host-staged gloo; not a measurement]" if share_gpu else ""),
                 "device": torch.cuda.get_device_name(local_rank),
             },
         }

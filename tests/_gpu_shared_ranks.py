@@ -1,0 +1,55 @@
+"""Worker of tests/test_gpu_parity.py::test_node_partitioned_forward_ranks_sharing_one_gpu.
+
+usage: python _gpu_shared_ranks.py RANK WORLD PORT OUT GRAPH CHANNELS LAYERS HEADS DTYPE
+Every rank runs the HIP kernels on cuda:0; the collectives are gloo, staged through host memory
+(anemoi_models_amd/distributed/partition.py::_alltoallv).  Writes max |sharded - unsharded| to OUT.RANK.
+"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    out, graph_name = sys.argv[4], sys.argv[5]
+    channels, layers, heads, dtype = int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]), sys.argv[9]
+    os.environ["ANEMOI_AMD_DTYPE"] = dtype
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from anemoi_models_amd import _lib
+
+    _lib.load()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from anemoi_models_amd.graphs.synthetic import build_graph
+        from anemoi_models_amd.models import AnemoiModelEncProcDec
+        from anemoi_models_amd.utils.indices import SimpleDataIndices
+        from anemoi_models_amd.utils.presets import model_config
+
+        device = torch.device("cuda", 0)
+        graph = build_graph(graph_name)
+        idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+        torch.manual_seed(1234)  # the same weights and input on every rank
+        model = AnemoiModelEncProcDec(model_config=model_config("GraphTransformer", channels, layers, heads),
+                                      data_indices=idx, graph_data=graph).to(device).eval()
+        x = torch.randn(1, 2, 1, graph["data"].num_nodes, 12, device=device)
+        with torch.no_grad():
+            want = model(x)
+            got = model(x, dist.group.WORLD)
+            again = model(x, dist.group.WORLD)
+        torch.cuda.synchronize()
+        sp = [v for k, v in model._idx_cache.items() if k[0] == "shard_plan"][0]
+        torch.save(dict(err=float((got - want).abs().max()), rerun=float((again - got).abs().max()),
+                        scale=float(want.abs().max()), own=sp.hi - sp.lo, finite=bool(torch.isfinite(got).all())),
+                   f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

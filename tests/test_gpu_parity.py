@@ -4,6 +4,8 @@ Tolerances: f32 path <= 1e-3 relative (north star), in practice ~1e-5; bf16 path
 oracle with a bf16-appropriate bound.  Index outputs are bit exact.
 """
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -420,6 +422,34 @@ def test_node_partitioned_forward_world1_rccl(graph_o32, golden_cfg1_gt):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,graph_name,channels,layers,heads,dtype,tol", [
+    (2, "o32_ico2", 64, 4, 16, "fp32", 2e-5),
+    (2, "o32_ico2", 64, 4, 4, "bf16", 3e-2),
+    (3, "o48_ico3", 256, 4, 16, "bf16", 3e-2),
+    (4, "o96_ico5", 512, 2, 16, "bf16", 3e-2),
+])
+def test_node_partitioned_forward_ranks_sharing_one_gpu(world, graph_name, channels, layers, heads, dtype, tol, tmp_path):
+    """world > 1 on the HIP kernels: the ranks are separate processes that share cuda:0 and exchange halos through
+    host-staged gloo (a 1-GPU box has no second device for RCCL).  Sharded output == unsharded output on every rank;
+    covers the shard-shaped launches (row counts that are no multiple of the GEMM tile, halo rows, local CSR plans)."""
+    import subprocess
+    import sys
+
+    port = 29700 + (os.getpid() % 200)
+    out = str(tmp_path / "res")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_shared_ranks.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out, graph_name, str(channels),
+                               str(layers), str(heads), dtype]) for r in range(world)]
+    codes = [p.wait(timeout=900) for p in procs]
+    assert codes == [0] * world
+    infos = [torch.load(f"{out}.{r}") for r in range(world)]
+    assert sum(i["own"] for i in infos) > 0
+    for i in infos:
+        assert i["finite"]
+        assert i["rerun"] == 0.0
+        assert i["err"] <= tol * max(1.0, i["scale"]), i
 
 
 # ------------------------------------------------------------------------------------------- GNN path
