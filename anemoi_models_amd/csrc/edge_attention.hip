@@ -301,7 +301,31 @@ struct EdgeFoldParams {
   int64_t n_dst;
   int C, D, n_slices;
   float scale;
+  int stream_hint;  // 1: q / x_r / out are nontemporal so that they do not evict gathered k|v rows from the XCD's L2
 };
+
+// 16-byte streaming accesses: data that is touched exactly once per launch
+template <typename T, int VEC>
+__device__ __forceinline__ void load_stream(const T* p, float (&r)[VEC]) {
+  if constexpr (sizeof(T) * VEC == 16) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    VecIO<T, VEC>::load(reinterpret_cast<const T*>(&t), r);
+  } else {
+    VecIO<T, VEC>::load(p, r);
+  }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_stream(T* p, const float (&r)[VEC]) {
+  if constexpr (sizeof(T) * VEC == 16) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t t;
+    VecIO<T, VEC>::store(reinterpret_cast<T*>(&t), r);
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+  } else {
+    VecIO<T, VEC>::store(p, r);
+  }
+}
 
 // The attribute part of the score (u . a) and of the output (sum alpha a) is the same for all LPH lanes of a head:
 // the lanes SHARE it -- lane r of a head owns the APL attributes [r * APL, r * APL + APL) (one 8/16-byte load per
@@ -356,7 +380,8 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
     float u[APL];
     {
       float qf[VEC];
-      VecIO<T, VEC>::load(qb + node * p.ldq, qf);
+      if (p.stream_hint) load_stream<T, VEC>(qb + node * p.ldq, qf);
+      else VecIO<T, VEC>::load(qb + node * p.ldq, qf);
       qk.set(qf);
       VecIO<T, APL>::load(ub + node * p.ldu, u);
 #pragma unroll
@@ -422,12 +447,16 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
     for (int i = 0; i < VEC; ++i) o[i] = acc[i] * inv;
     if (p.xr != nullptr) {
       float r[VEC];
-      VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
+      if (p.stream_hint) load_stream<T, VEC>(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
+      else VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] += r[i];
     }
     T* on = static_cast<T*>(p.out) + node * p.ldo;
-    if (active) VecIO<T, VEC>::store(on + c0, o);
+    if (active) {
+      if (p.stream_hint) store_stream<T, VEC>(on + c0, o);
+      else VecIO<T, VEC>::store(on + c0, o);
+    }
     if (active && a_own) {  // this lane's APL values of t~_i,h
       float t4[APL];
 #pragma unroll
@@ -890,6 +919,11 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
   p.n_dst = n_dst; p.C = C; p.D = C / H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
   p.scale = 1.0f / sqrtf((float)(C / H));
+  static const int stream_hint = [] {
+    const char* e = getenv("ANEMOI_AMD_EDGE_NT");  // A/B knob; measured -3 % on all three graphs of config 3
+    return e ? atoi(e) : 1;
+  }();
+  p.stream_hint = stream_hint;
   bool ok = false;
   if (dtype == ANEMOI_F32) ok = dispatch_folded<float>(p, up, as_stream(stream));
   else if (dtype == ANEMOI_BF16) ok = dispatch_folded<bf16_t>(p, up, as_stream(stream));
