@@ -301,6 +301,30 @@ __global__ __launch_bounds__(256) void prognostic_residual_kernel(float* __restr
   }
 }
 
+// In-place autoregressive input update: one thread per (b, ens, g, v); the lane reads x[t + 1] before it writes x[t],
+// and nobody else touches column v of that grid point, so the time shift is safe in place.
+__global__ __launch_bounds__(256) void advance_input_kernel(float* __restrict__ x, int B, int T_, int Ens, int64_t G,
+                                                            int V_in, const float* __restrict__ y, int V_out,
+                                                            const float* __restrict__ forcing, int F,
+                                                            const int32_t* __restrict__ colmap) {
+  const int64_t total = (int64_t)B * Ens * G * V_in;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / V_in;  // (b, ens, g)
+    const int v = (int)(idx - row * V_in);
+    const int64_t g = row % G;
+    const int64_t be = row / G;
+    const int e = (int)(be % Ens);
+    const int64_t b = be / Ens;
+    const int64_t t_stride = (int64_t)Ens * G * V_in;
+    float* xp = x + (((b * T_) * Ens + e) * G + g) * V_in + v;  // time slice 0 of this element
+    for (int t = 0; t + 1 < T_; ++t) xp[t * t_stride] = xp[(t + 1) * t_stride];
+    const int m = colmap[v];
+    if (m >= 0) xp[(T_ - 1) * t_stride] = y[row * V_out + m];
+    else if (m <= -2 && forcing != nullptr) xp[(T_ - 1) * t_stride] = forcing[row * F + (-2 - m)];
+  }
+}
+
 static inline unsigned flat_grid(int64_t total) {
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
@@ -423,7 +447,18 @@ int anemoi_prognostic_residual(float* y, int V_out, const float* x, int B, int T
   return check_launch("anemoi_prognostic_residual");
 }
 
-int anemoi_abi_version(void) { return 3; }
+int anemoi_advance_input(float* x, int B, int T, int Ens, int64_t G, int V_in, const float* y, int V_out,
+                         const float* forcing, int F, const int32_t* colmap, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && y && colmap && B > 0 && T > 0 && Ens > 0 && G >= 0 && V_in > 0 && V_out > 0 && F >= 0,
+                 ANEMOI_ERR_INVALID, "anemoi_advance_input: bad argument");
+  const int64_t total = (int64_t)B * Ens * G * V_in;
+  if (total == 0) return ANEMOI_OK;
+  hipLaunchKernelGGL(advance_input_kernel, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), x, B, T, Ens, G,
+                     V_in, y, V_out, forcing, F, colmap);
+  return check_launch("anemoi_advance_input");
+}
+
+int anemoi_abi_version(void) { return 4; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

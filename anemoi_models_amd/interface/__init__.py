@@ -8,6 +8,7 @@ import uuid
 
 import torch
 
+from .. import ops
 from ..models.encoder_processor_decoder import instantiate
 from ..preprocessing import Processors
 
@@ -47,3 +48,45 @@ class AnemoiModelInterface(torch.nn.Module):
             x = batch[:, 0 : self.multi_step, None, ...]  # dummy ensemble dimension as 3rd index
             y_hat = self(x)
         return self.post_processors(y_hat, in_place=False)
+
+    # ------------------------------------------------------------------ autoregressive rollout (BASELINE config 4)
+    def _advance_map(self, device) -> torch.Tensor:
+        """int32 ``[V_in]`` column map of ``anemoi_advance_input``: prognostic inputs <- their output column, forcing
+        inputs <- their position in the forcing tensor (-2 - k), everything else persists (-1)."""
+        idx = self.data_indices.internal_model
+        cmap = torch.full((len(idx.input),), -1, dtype=torch.int32)
+        cmap[idx.input.prognostic.long()] = idx.output.prognostic.to(torch.int32)
+        forcing = idx.input.forcing.long()
+        cmap[forcing] = -2 - torch.arange(forcing.numel(), dtype=torch.int32)
+        return cmap.to(device)
+
+    def rollout(self, batch: torch.Tensor, n_steps: int, forcings: torch.Tensor = None, model_comm_group=None):
+        """``n_steps`` autoregressive forecasts from ``batch`` ``[batch, time, grid, input variables]`` (physical
+        values).  ``forcings`` ``[n_steps, batch, grid, n_forcing]`` holds the physical forcing inputs valid at each
+        step's output time (ordered like ``data_indices.internal_model.input.forcing``); without it the last forcing
+        values persist.  Returns ``[n_steps, batch, 1, grid, output variables]`` de-normalised predictions.
+
+        Not part of the reference repository (which stops at :meth:`predict_step`): the loop follows its caller,
+        anemoi-training's ``advance_input``.  The state stays on the device in normalised model space; the time shift
+        and the prognostic / forcing write-back are one in-place HIP kernel (``anemoi_advance_input``)."""
+        idx = self.data_indices.internal_model
+        x = self.pre_processors(batch, in_place=False)
+        assert len(x.shape) == 4, f"The input tensor has an incorrect shape: expected 4 dimensions, got {x.shape}!"
+        x = x[:, 0 : self.multi_step, None, ...].float().contiguous().clone()
+        cmap = self._advance_map(x.device)
+        f_idx = idx.input.forcing.long().to(x.device)
+        outs = []
+        with torch.no_grad():
+            for step in range(n_steps):
+                y_hat = self.model(x, model_comm_group) if model_comm_group is not None else self.model(x)
+                outs.append(self.post_processors(y_hat, in_place=False))
+                if step + 1 == n_steps:
+                    break
+                f_norm = None
+                if forcings is not None and f_idx.numel() > 0:
+                    # normalise the forcing columns with the same pre-processors: embed them in a full-width slice
+                    full = x[:, -1, 0].clone()
+                    full[..., f_idx] = forcings[step].to(full)
+                    f_norm = self.pre_processors(full[:, None], in_place=False)[:, 0][..., f_idx][:, None].contiguous()
+                ops.advance_input(x, y_hat.float().contiguous(), cmap, f_norm)
+        return torch.stack(outs)

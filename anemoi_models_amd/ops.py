@@ -321,6 +321,27 @@ def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Ten
     return out
 
 
+def advance_input(x: Tensor, y: Tensor, colmap: Tensor, forcing: Optional[Tensor] = None) -> Tensor:
+    """Autoregressive input update in place on ``x`` ``[B, T, Ens, G, V_in]`` (f32): shift the time axis by one and
+    fill the last slice from the prediction ``y`` ``[B, Ens, G, V_out]`` / the new ``forcing`` ``[B, Ens, G, F]``
+    according to ``colmap`` (int32 ``[V_in]``; see include/anemoi_amd.h: anemoi_advance_input)."""
+    _dev(x, y, colmap, forcing)
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("advance_input: x and y must be contiguous float32")
+    b, t, ens, g, v_in = x.shape
+    if tuple(y.shape[:3]) != (b, ens, g) or colmap.dtype != torch.int32 or colmap.numel() != v_in:
+        raise ValueError(f"advance_input: y {tuple(y.shape)} / colmap do not match x {tuple(x.shape)}")
+    f = 0
+    if forcing is not None:
+        if forcing.dtype != torch.float32 or not forcing.is_contiguous() or tuple(forcing.shape[:3]) != (b, ens, g):
+            raise ValueError("advance_input: forcing must be contiguous float32 [B, Ens, G, F]")
+        f = forcing.shape[-1]
+    st = _lib.load().anemoi_advance_input(x.data_ptr(), b, t, ens, g, v_in, y.data_ptr(), y.shape[-1], _ptr(forcing), f,
+                                          colmap.data_ptr(), _stream())
+    _lib.check(st, "anemoi_advance_input")
+    return x
+
+
 def prognostic_residual(y: Tensor, x: Tensor, out_idx: Tensor, in_idx: Tensor) -> Tensor:
     """In place: ``y[..., out_idx] += x[:, -1, :, :, in_idx]`` (y f32 ``[B, Ens, G, V_out]`` contiguous)."""
     _dev(y, x, out_idx, in_idx)

@@ -55,6 +55,9 @@ def parse_args():
                     help="processor family (BASELINE config 5 = --workload cfg2 --processor GNN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2, help="processor blocks in the CPU-baseline sample")
+    ap.add_argument("--rollout", type=int, default=1,
+                    help="autoregressive forecasts per step (BASELINE config 4 = --rollout 4): forward, then the "
+                         "in-place input update anemoi_advance_input, repeated")
     ap.add_argument("--detail", action="store_true", help="print a per-shape kernel table to stderr")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay the forward as one captured HIP graph (single GPU; pays off on the small workloads)")
@@ -223,7 +226,7 @@ def main():
         group = dist.group.WORLD
 
     os.environ["ANEMOI_AMD_DTYPE"] = args.dtype
-    model, graph, x, _ = build(args.workload, device, args.processor)
+    model, graph, x, idx = build(args.workload, device, args.processor)
     n_mesh = graph["hidden"].num_nodes
     layers = WORKLOADS[args.workload][2]
 
@@ -233,11 +236,30 @@ def main():
 
         graphed = GraphedForward(model, x)
 
-    def step():
+    cmap = None
+    if args.rollout > 1:  # prognostic inputs <- their output column; forcings persist (no data source in a benchmark)
+        from anemoi_models_amd import ops
+
+        cmap = torch.full((idx.num_input,), -1, dtype=torch.int32)
+        cmap[idx.internal_model.input.prognostic] = idx.internal_model.output.prognostic.to(torch.int32)
+        cmap = cmap.to(device)
+        x_state = x.clone()
+
+    def forward(inp):
         if graphed is not None:
-            return graphed(x)
+            return graphed(inp)
         with torch.no_grad():
-            return model(x, group) if group is not None else model(x)
+            return model(inp, group) if group is not None else model(inp)
+
+    def step():
+        if cmap is None:
+            return forward(x)
+        x_state.copy_(x)  # every timed step starts from the same analysis
+        for lead in range(args.rollout):
+            y = forward(x_state)
+            if lead + 1 < args.rollout:
+                ops.advance_input(x_state, y, cmap)
+        return y
 
     for _ in range(args.warmup):
         step()
@@ -264,7 +286,7 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = n_mesh * layers / (elapsed / args.steps)
+    value = n_mesh * layers * args.rollout / (elapsed / args.steps)
     extra = profile_pass(model, x, group, args.dtype, args.detail and rank == 0,
                          traffic_ok=args.workload == "cfg3" and args.processor == "GraphTransformer")
 
@@ -278,6 +300,7 @@ def main():
                 "workload": WORKLOADS[args.workload][4] + ", batch 1, 2 x 90 input vars -> 80 output vars, "
                                                           "full encoder+processor+decoder forward",
                 "mesh_nodes": n_mesh, "grid_nodes": graph["data"].num_nodes, "processor_blocks": layers,
+                "rollout_steps": args.rollout,
                 "parallelism": "single GPU" if world == 1 else f"mesh node-partitioned over {world} GPUs, halo all-to-all-v"
                                + (" [DEBUG: ranks share one GPU, host-staged gloo; not a measurement]" if share_gpu else ""),
                 "device": torch.cuda.get_device_name(local_rank),

@@ -154,6 +154,20 @@ int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int6
 int anemoi_prognostic_residual(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
                                const int32_t* out_idx, const int32_t* in_idx, int n_prog, anemoi_stream_t stream);
 
+/*
+ * Autoregressive rollout: next model input from the current one and the prediction, in place on x (f32
+ * [B, T, Ens, G, V_in]):  x[:, t] <- x[:, t+1] for t < T-1, then for the last time slice
+ *   colmap[v] >= 0  : x[b, T-1, ens, g, v] = y[b, ens, g, colmap[v]]            (prognostic variables)
+ *   colmap[v] <= -2 : x[b, T-1, ens, g, v] = forcing[b, ens, g, -2 - colmap[v]]  (forcings of the new time; skipped
+ *                     when forcing == NULL: the previous value persists)
+ *   colmap[v] == -1 : the previous value persists.
+ * The reference repository stops at one step (interface/__init__.py:97-123); this is the caller's loop
+ * (anemoi-training `advance_input`: roll the time axis, write the prognostic outputs, write the new forcings), i.e.
+ * BASELINE config 4.  y is f32 [B, Ens, G, V_out], forcing f32 [B, Ens, G, F] or NULL.
+ */
+int anemoi_advance_input(float* x, int B, int T, int Ens, int64_t G, int V_in, const float* y, int V_out,
+                         const float* forcing, int F, const int32_t* colmap, anemoi_stream_t stream);
+
 /* dtype conversion / K-padding copy: dst[r, 0:cols] = src[r, 0:cols], dst[r, cols:ld_dst] = 0. */
 int anemoi_convert_pad(int src_dtype, const void* src, int64_t ld_src, int dst_dtype, void* dst, int64_t ld_dst,
                        int64_t rows, int cols, anemoi_stream_t stream);

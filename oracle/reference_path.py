@@ -551,3 +551,35 @@ def predict_step(sd: SD, graph: Mapping[str, Tensor], batch: Tensor, *, multi_st
     model_sd = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
     y = model_forward(model_sd, graph, x, **model_kwargs)
     return (y - add[i_out]) / mul[i_out]
+
+
+def rollout(sd: SD, graph: Mapping[str, Tensor], batch: Tensor, n_steps: int, forcings: Optional[Tensor] = None, *,
+            multi_step: int, prognostic_in, prognostic_out, forcing_in=(), **model_kwargs) -> Tensor:
+    """``n_steps`` autoregressive applications of :func:`predict_step`'s model (BASELINE config 4).
+
+    PARITY UNPINNED against the reference for the loop itself: the reference repository stops at one step
+    (interface/__init__.py:97-123); the loop is its caller's (anemoi-training ``GraphForecaster.advance_input``): roll
+    the time axis of the NORMALISED input by one, write the prognostic outputs of the prediction into the last slice,
+    write the (normalised) forcings of the new time there, keep every other variable.  Each step's arithmetic is the
+    pinned :func:`model_forward`.  ``batch`` is ``[B, T, G, V_in]`` physical, ``forcings`` ``[n_steps, B, G, F]``
+    physical values of the forcing inputs valid at the time of step ``s``'s OUTPUT (consumed by step ``s + 1``);
+    returns ``[n_steps, B, 1, G, V_out]`` physical predictions.
+    """
+    p = "pre_processors.processors.normalizer."
+    mul, add = sd[p + "_norm_mul"], sd[p + "_norm_add"]
+    i_in, i_out = sd[p + "_input_idx"].long(), sd[p + "_output_idx"].long()
+    model_sd = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
+    pin, pout, fin = list(prognostic_in), list(prognostic_out), list(forcing_in)
+    x = (batch * mul[i_in] + add[i_in])[:, 0:multi_step, None, ...].clone()
+    outs = []
+    for s in range(n_steps):
+        y = model_forward(model_sd, graph, x, prognostic_in=pin, prognostic_out=pout, **model_kwargs)
+        outs.append((y - add[i_out]) / mul[i_out])
+        nxt = x.roll(-1, dims=1)
+        nxt[:, -1] = x[:, -1]
+        nxt[:, -1, :, :, pin] = y[..., pout]
+        if forcings is not None and fin:
+            f = forcings[s] * mul[i_in][fin] + add[i_in][fin]
+            nxt[:, -1, :, :, fin] = f[:, None]
+        x = nxt
+    return torch.stack(outs)

@@ -147,6 +147,18 @@ def prognostic_residual(y, x, out_idx, in_idx):
     return y
 
 
+def advance_input(x, y, colmap, forcing=None):
+    new = x.roll(-1, dims=1)
+    new[:, -1] = x[:, -1]
+    for v, m in enumerate(colmap.tolist()):
+        if m >= 0:
+            new[:, -1, :, :, v] = y[..., m]
+        elif m <= -2 and forcing is not None:
+            new[:, -1, :, :, v] = forcing[..., -2 - m]
+    x.copy_(new)
+    return x
+
+
 def convert_pad(src, dtype, ld_out=None):
     ld = src.shape[1] if ld_out is None else ld_out
     return F.pad(src, (0, ld - src.shape[1])).to(dtype)
@@ -161,5 +173,5 @@ def install(monkeypatch):
 
     for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
                  "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
-                 "prognostic_residual", "convert_pad", "add"):
+                 "prognostic_residual", "advance_input", "convert_pad", "add"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -211,8 +211,29 @@ def golden_interface(fname: str = "interface_gt.npz") -> dict:
     batch = z * torch.from_numpy(stdev)[in_idx] + torch.from_numpy(mean)[in_idx]  # physical-valued input variables
     with torch.no_grad():
         y = iface.predict_step(batch)
+    # 3-step rollout: every step is the reference's model + pre/post-processors; the loop between the steps is the
+    # caller's (anemoi-training advance_input): roll time, prognostic outputs -> last input slice, new forcings in.
+    n_roll = 3
+    zf = torch.randn((n_roll, 1, n_grid, 2), generator=torch.Generator().manual_seed(8))
+    f_in = indices.internal_model.input.forcing.long()
+    f_data = indices.data.input.full.long()[f_in]  # dataset positions of the forcing inputs (statistics are per dataset var)
+    forcings = zf * torch.from_numpy(stdev)[f_data] + torch.from_numpy(mean)[f_data]
+    with torch.no_grad():
+        x = iface.pre_processors(batch, in_place=False)[:, 0:2, None, ...].clone()
+        ys = []
+        for s_ in range(n_roll):
+            yh = iface(x)
+            ys.append(iface.post_processors(yh, in_place=False))
+            nxt = x.roll(-1, dims=1)
+            nxt[:, -1] = x[:, -1]
+            nxt[:, -1, :, :, indices.internal_model.input.prognostic] = yh[..., indices.internal_model.output.prognostic]
+            full = x[:, -1, 0].clone()
+            full[..., f_in] = forcings[s_]
+            nxt[:, -1, 0][..., f_in] = iface.pre_processors(full[:, None], in_place=False)[:, 0][..., f_in]
+            x = nxt
+    y_roll = torch.stack(ys)
     sd = iface.state_dict()
-    out = {"batch": batch.numpy(), "y": y.numpy()}
+    out = {"batch": batch.numpy(), "y": y.numpy(), "rollout_forcings": forcings.numpy(), "rollout_y": y_roll.numpy()}
     out.update({f"stat.{k}": v for k, v in statistics.items()})
     out.update({f"sd.{k}": v.numpy() for k, v in sd.items()})
     np.savez_compressed(os.path.join(HERE, fname), **out)

@@ -356,6 +356,42 @@ def test_interface_predict_step_vs_golden(graph_o32, golden_interface):
     assert rel_err(y, gold["y"]) < 1e-4
 
 
+def test_advance_input_kernel():
+    """anemoi_advance_input (in place) against the roll / index_put restatement of tests/_cpu_ops.py."""
+    import _cpu_ops
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for (b, t, e, n, v_in, v_out, f) in [(1, 2, 1, 777, 12, 11, 2), (2, 3, 2, 130, 7, 9, 0), (1, 1, 1, 65, 90, 80, 10)]:
+        x, y = torch.randn(b, t, e, n, v_in, generator=g), torch.randn(b, e, n, v_out, generator=g)
+        forcing = torch.randn(b, e, n, f, generator=g) if f else None
+        cmap = torch.full((v_in,), -1, dtype=torch.int32)
+        n_prog = min(v_in - f, v_out) - 1
+        cmap[:n_prog] = torch.randperm(v_out, generator=g)[:n_prog].to(torch.int32)
+        if f:
+            cmap[v_in - f:] = -2 - torch.arange(f, dtype=torch.int32)
+        want = _cpu_ops.advance_input(x.clone(), y, cmap, forcing)
+        got = ops.advance_input(x.clone().to(DEV), y.to(DEV), cmap.to(DEV), None if forcing is None else forcing.to(DEV))
+        assert torch.equal(got.cpu(), want)
+        if f:  # no forcing tensor: those columns persist
+            want = _cpu_ops.advance_input(x.clone(), y, cmap, None)
+            assert torch.equal(ops.advance_input(x.clone().to(DEV), y.to(DEV), cmap.to(DEV)).cpu(), want)
+
+
+def test_interface_rollout_vs_golden(graph_o32, golden_interface):
+    """AnemoiModelInterface.rollout on the HIP path: 3 autoregressive steps against vectors whose every step is the
+    real reference model + normaliser (BASELINE config 4 semantics)."""
+    from test_host_logic import build_interface
+
+    gold = golden_interface
+    iface = build_interface(graph_o32, gold)
+    iface.load_state_dict(split_prefix(gold, "sd."))
+    iface = iface.to(DEV).eval()
+    y = iface.rollout(gold["batch"].to(DEV), 3, gold["rollout_forcings"].to(DEV))
+    assert y.shape == gold["rollout_y"].shape
+    assert rel_err(y, gold["rollout_y"]) < 1e-3
+
+
 def test_forward_replayed_as_hip_graph(graph_o32, golden_cfg1_gt):
     """runtime.GraphedForward: the whole forward captured once in a HIP graph, replayed on new inputs."""
     from anemoi_models_amd.runtime import GraphedForward

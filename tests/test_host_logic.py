@@ -275,3 +275,21 @@ def test_interface_predict_step_matches_golden(graph_o32, golden_interface, monk
     torch.testing.assert_close(y, gold["y"], atol=5e-4, rtol=5e-4)
     with pytest.raises(AssertionError):
         iface.predict_step(gold["batch"][0])  # 3-dimensional input: same assertion as the reference
+
+
+def test_interface_rollout_matches_golden(graph_o32, golden_interface, monkeypatch):
+    """rollout: n x (model, advance_input) on the device-resident normalised state; every step of the recorded vectors
+    is the real reference model + normaliser (tests/golden/make_golden.py::golden_interface)."""
+    _cpu_ops.install(monkeypatch)
+    gold = golden_interface
+    iface = build_interface(graph_o32, gold)
+    iface.load_state_dict(split_prefix(gold, "sd."))
+    iface.eval()
+    y = iface.rollout(gold["batch"], 3, gold["rollout_forcings"])
+    assert y.shape == gold["rollout_y"].shape
+    torch.testing.assert_close(y, gold["rollout_y"], atol=2e-3, rtol=2e-3)
+    # without forcings the last forcing values persist: step 0 is unchanged, later steps differ
+    y2 = iface.rollout(gold["batch"], 2)
+    torch.testing.assert_close(y2[0], y[0])
+    assert (y2[1] - y[1]).abs().max() > 1e-3
+    assert iface._advance_map(torch.device("cpu")).tolist() == list(range(10)) + [-2, -3]

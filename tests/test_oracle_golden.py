@@ -177,3 +177,16 @@ def test_normalizer_and_predict_step(golden_interface, graph_o32):
     y = ref.predict_step(sd, graph_tensors(graph_o32), gold["batch"], multi_step=2, num_heads=16, num_layers=4,
                          num_chunks=2, prognostic_in=list(range(10)), prognostic_out=list(range(10)))
     torch.testing.assert_close(y, gold["y"], atol=1e-4, rtol=1e-4)
+
+
+def test_rollout_matches_reference_steps(golden_interface, graph_o32):
+    """oracle.rollout == three applications of the real reference interface (model + InputNormalizer) chained by the
+    caller's advance_input loop as recorded by tests/golden/make_golden.py::golden_interface."""
+    gold = golden_interface
+    sd = split_prefix(gold, "sd.")
+    y = ref.rollout(sd, graph_tensors(graph_o32), gold["batch"], 3, gold["rollout_forcings"], multi_step=2,
+                    num_heads=16, num_layers=4, num_chunks=2, prognostic_in=list(range(10)),
+                    prognostic_out=list(range(10)), forcing_in=[10, 11])
+    assert y.shape == gold["rollout_y"].shape
+    torch.testing.assert_close(y[0], gold["y"], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(y, gold["rollout_y"], atol=5e-4, rtol=5e-4)
