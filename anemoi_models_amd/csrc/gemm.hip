@@ -625,7 +625,8 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
     const int64_t m0 = mt_ * TM;
     const int n0 = nt_ * BIG_N;
-    const int64_t xrows = M - m0 < TM ? M - m0 : TM;
+    int64_t xrows = M - m0 < TM ? M - m0 : TM;  // ragged last row tile: rows >= M read as zeros (a half tile of the
+    xrows = xrows > 0 ? xrows : 0;              // remainder launch may lie entirely behind M)
     const int wrows = N - n0 < BIG_N ? N - n0 : BIG_N;
     xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + m0 * ldx), 0, (int)(xrows * ldx * 2), 0x00020000);
     wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * K), 0, wrows * K * 2, 0x00020000);
@@ -806,10 +807,12 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     //      (vmcnt has no separate store counter).  Output / residual go through buffer descriptors of the tile (one
     //      lane-offset VGPR each, the row-group part in an SGPR): 64-bit per-access pointers would spill here.
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    int rows_here = M - m0 < TM ? (int)(M - m0) : TM;  // ragged last row tile: the descriptors end at row M, so the
+    rows_here = rows_here > 0 ? rows_here : 0;         // stores of the rows behind it are dropped and their loads read 0
     const __amdgpu_buffer_rsrc_t yrs =  // sized to the tile: masked lanes use an out-of-range offset (store dropped)
-        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, TM * (int)ldy * 2, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, rows_here * (int)ldy * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, 0x7fffffff, 0x00020000);
+        (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, HAS_RES ? rows_here * (int)ldr * 2 : 0, 0x00020000);
     int fr_e = fr, fq_e = fq;  // opaque copies: keeps the epilogue's lane offsets from being hoisted above the K loop
     asm volatile("" : "+v"(fr_e), "+v"(fq_e));  // (a single VGPR spilled there costs a vmcnt(0) per reload here)
     const int ncol = wn * 128 + fq_e * 8;  // this lane's column inside the tile (+ 32 u)
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       for (int u = 0; u < 4; ++u)
         VecIO<float, 8>::load(reinterpret_cast<const float*>(smem + 2 * BIG_STAGE + 1024) + ncol + u * 32, sv[u]);
       const __amdgpu_buffer_rsrc_t srs =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(ln.stats + m0), 0, TM * 8, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc((void*)(ln.stats + m0), 0, rows_here * 8, 0x00020000);
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 #pragma unroll
       for (int j = 0; j < MH; ++j) {
@@ -1122,6 +1125,7 @@ static int linear_launch(const void* x, int64_t ldx, const void* w, const float*
                          int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st,
                          LnFold ln);
 
+constexpr int W4_NEEDS_WHOLE_TILES = -4242;  // internal: the caller has to split the ragged rows off itself
 // Returns through *tail_done whether the up to 8 rows behind M (m_tail) were computed by the same launch.
 static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                                   int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
@@ -1189,7 +1193,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
   if (variant == 1 && K >= 128 && ldx < (int64_t)1 << 21 && ldy < (int64_t)1 << 21 && ldr < (int64_t)1 << 21 && vec_ok &&
-      M % BIG_M == 0 && (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0)) {
+      (M % BIG_M == 0 || m_tail == 0) && (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0)) {
     const int w4_tail = (m_tail > 0 && m_tail <= 8 && K % 8 == 0) ? m_tail : 0;
     if (tail_done != nullptr) *tail_done = w4_tail > 0;
     // Remainder round as HALF tiles: when the tiles beyond the last whole round of 256 would keep at most half of the
@@ -1239,13 +1243,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     bf16_t* yb = static_cast<bf16_t*>(y);
     int64_t w4_blocks = blocks;
     if (mt_a > 0) {
-      const int64_t m_a = mt_a * BIG_M, tiles_a = mt_a * nt;
+      const int64_t m_a = mt_a * BIG_M < M ? mt_a * BIG_M : M, tiles_a = mt_a * nt;
       const int tail_a = mt_b == 0 ? w4_tail : 0;
       w4_blocks = tiles_a < max_blocks ? (tiles_a + 7) / 8 * 8 : max_blocks;
       LAUNCH_W4_ACT(8, xb, rb, yb, ln, m_a, tiles_a, tail_a)
     }
     if (mt_b > 0) {
-      const int64_t m_a = mt_a * BIG_M, m_b = mt_b * BIG_M, tiles_b = mt_b * 2 * nt;
+      const int64_t m_a = mt_a * BIG_M, m_b = M - m_a, tiles_b = mt_b * 2 * nt;  // m_b may end inside the last tile
       LnFold lb = ln;
       if (lb.stats != nullptr) lb.stats += m_a;
       w4_blocks = tiles_b < max_blocks ? (tiles_b + 7) / 8 * 8 : max_blocks;
@@ -1257,6 +1261,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
 #undef LAUNCH_W4__
     return check_launch("anemoi_linear(256x256, 4 waves)");
   }
+  if (M % BIG_M != 0) return W4_NEEDS_WHOLE_TILES;  // only the four-wave kernel takes a ragged last row tile
   if (ln.stats != nullptr)  // the older kernels have no LayerNorm fold: the general 128 x 128 kernel has
     return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
   if (variant == 4) {
@@ -1348,6 +1353,20 @@ static int linear_dispatch(const char* who, int dtype, int out_dtype, const void
     const int64_t m_main = M / BIG_M * BIG_M, m_tail = M - m_main;
     if (m_tail == 0) return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
     bool tail_done = false;
+    static const bool ragged_ok = [] {  // A/B: ANEMOI_AMD_GEMM_RAGGED=0 sends tails of 9..255 rows to a second launch
+      const char* e = getenv("ANEMOI_AMD_GEMM_RAGGED");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    static const int variant_env = [] {
+      const char* e = getenv("ANEMOI_AMD_GEMM_VARIANT");
+      return e ? atoi(e) : 1;
+    }();
+    // tails of more than 8 rows ride along as a ragged last row tile of the persistent kernel (its descriptors end at
+    // row M): the separate 128 x 128 launch they used to get ran ~35 us on a handful of CUs, 14 times per forward
+    if (m_tail > 8 && ragged_ok && variant_env == 1 && K >= 128) {
+      const int rr = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
+      if (rr != W4_NEEDS_WHOLE_TILES) return rr;
+    }
     const int rc = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, m_main, N, K, act, st, ln,
                                           m_tail <= 8 ? (int)m_tail : 0, &tail_done);
     if (rc != ANEMOI_OK || tail_done) return rc;

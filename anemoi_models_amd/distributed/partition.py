@@ -31,13 +31,43 @@ from ..runtime import EdgePlan
 from .shapes import split_bounds
 
 
+class SimulatedRank:
+    """Stand-in group for timing ONE rank of a ``world``-way partition alone (tools/sim_rank.py): the plans, shapes and
+    kernel launches are those of rank ``rank``; the exchanges move no data (halo rows read as zeros), so the results
+    are meaningless and only the compute side of the step is timed.  Never used by the product path."""
+
+    def __init__(self, rank: int, world: int) -> None:
+        self.rank_, self.world_ = rank, world
+
+    def size(self) -> int:
+        return self.world_
+
+    def rank(self) -> int:
+        return self.rank_
+
+
+def _rank(group) -> int:
+    return group.rank_ if isinstance(group, SimulatedRank) else dist.get_rank(group)
+
+
+def _world(group) -> int:
+    return group.world_ if isinstance(group, SimulatedRank) else dist.get_world_size(group)
+
+
+def _backend(group) -> str:
+    return "sim" if isinstance(group, SimulatedRank) else dist.get_backend(group)
+
+
 def _alltoallv(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int], group, async_op: bool = False):
     """Row-wise all-to-all-v.  RCCL path: one ``all_to_all_single`` (optionally asynchronous: it runs on RCCL's stream
     and the returned work handle is waited for right before the consumer); other backends (gloo in CPU tests, or gloo
     over device tensors when several debugging ranks share one GPU): blocking P2P, staged through host memory."""
-    backend = dist.get_backend(group)
+    backend = _backend(group)
     if backend == "nccl":
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+    if backend == "sim":
+        out.zero_()
+        return None
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     staged = inp.is_cuda
@@ -63,7 +93,10 @@ def _alltoallv(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[
 
 def _allgather_rows(out: Tensor, inp: Tensor, group) -> None:
     """``out[r * n : (r + 1) * n] <- inp`` of rank ``r``; host-staged when the backend cannot move device memory."""
-    if dist.get_backend(group) == "nccl" or not inp.is_cuda:
+    if _backend(group) == "sim":
+        out.view(-1, *inp.shape).copy_(inp.unsqueeze(0).expand(_world(group), *inp.shape))
+        return
+    if _backend(group) == "nccl" or not inp.is_cuda:
         dist.all_gather_into_tensor(out, inp, group=group)
         return
     h_out = torch.empty(out.shape, dtype=out.dtype)
@@ -206,7 +239,7 @@ class ShardPlan:
 
 
 def build_shard_plan(model, group, device) -> ShardPlan:
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = _rank(group), _world(group)
     order, inv = model._mesh_order(device)
     n_mesh = order.shape[0]
     bounds = split_bounds(n_mesh, world)
@@ -277,7 +310,7 @@ def sharded_forward(model, x: Tensor, group) -> Tensor:
     if model.encoder.proc.fold_width(dtype) is None:
         raise NotImplementedError("the node-partitioned forward needs the folded edge kernel for this shape / dtype")
     kmult = ops.k_multiple(dtype)
-    key = ("shard_plan", str(x.device), dist.get_world_size(group), dist.get_rank(group))
+    key = ("shard_plan", str(x.device), _world(group), _rank(group))
     if key not in model._idx_cache:
         model._idx_cache[key] = build_shard_plan(model, group, x.device)
     sp: ShardPlan = model._idx_cache[key]
