@@ -466,205 +466,6 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Software-pipelined variant of the folded kernel.  A wave's work is a stream of BATCHES (up to U edges of one
-// destination); while batch b is being reduced, the k/v gathers of batch b+1 -- and, when b+1 opens a new
-// destination, its q / u rows -- are already in flight in a second register set, and the row pointers of the
-// destination after that have been requested.  The dependent chain per destination (rowptr -> col -> k/v ->
-// softmax -> store) no longer serialises with the next one; with short in-degrees (3 for the decoder, ~8 on the
-// mesh) that chain, not bandwidth, was what bounded the simple loop.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPH, int UP>
-__global__ __launch_bounds__(256) void gt_edge_attention_folded_pipe_kernel(const EdgeFoldParams p,
-                                                                   const float* __restrict__ attr_,
-                                                                   const int32_t* __restrict__ rowptr_,
-                                                                   const int32_t* __restrict__ col_) {
-  constexpr int U = 4;
-  using Raw = typename RawVec<T, VEC>::type;
-  using URaw = typename RawVec<T, 4>::type;  // u is fetched 4 elements at a time
-  constexpr int UQ = UP / 4;
-  const int lane = threadIdx.x & 63;
-  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int xcd = blockIdx.x & 7;
-  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
-  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
-  const int slice = wave_in_xcd % p.n_slices;
-  const int64_t node_stride = waves_per_xcd / p.n_slices;
-  const int64_t n0 = p.n_dst * xcd / 8, n1 = p.n_dst * (xcd + 1) / 8;
-
-  const int lanes_total = p.C / VEC;
-  const int gl = slice * 64 + lane;
-  const bool active = gl < lanes_total;
-  const int gls = active ? gl : 0;
-  const int c0 = gls * VEC;
-  const int head = gls / LPH;
-  const bool head_lead = active && (gls % LPH == 0);
-
-  const T* qb = static_cast<const T*>(p.q) + c0;
-  const T* kb = static_cast<const T*>(p.k) + c0;
-  const T* vb = static_cast<const T*>(p.v) + c0;
-  const T* ub = static_cast<const T*>(p.u) + head * UP;
-
-  // ---- batch iterator (all wave-uniform): current batch = edges [e, min(e + U, e_end)) of `node`
-  int64_t node = n0 + wave_in_xcd / p.n_slices;
-  if (node >= n1) return;
-  int e = rowptr_[node], e_end = rowptr_[node + 1];
-  bool first = true;
-  // row pointers of the next destination, requested one destination ahead
-  int64_t node_nx = node + node_stride;
-  int nb = 0, ne = 0;
-  if (node_nx < n1) {
-    nb = rowptr_[node_nx];
-    ne = rowptr_[node_nx + 1];
-  }
-
-  auto load_batch = [&](int64_t nd, int eb, int ee, bool fst, Raw (&kr)[U], Raw (&vr)[U], Raw& qr, URaw (&ur)[UQ]) {
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu) {
-      if (eb + uu < ee) {
-        const int64_t j = col_[eb + uu];
-        kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
-        vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
-      }
-    }
-    if (fst) {
-      qr = *reinterpret_cast<const Raw*>(qb + nd * p.ldq);
-#pragma unroll
-      for (int a = 0; a < UQ; ++a) ur[a] = *reinterpret_cast<const URaw*>(ub + nd * p.ldu + 4 * a);
-    }
-  };
-
-  // ---- per-destination state
-  QK<T, VEC> qk;
-  float u[UP];
-  float m = -INFINITY, l = 0.f;
-  float acc[VEC], tacc[UP];
-
-  auto compute_batch = [&](int64_t nd, int eb, int ee, bool fst, const Raw (&kr)[U], const Raw (&vr)[U], const Raw& qr,
-                           const URaw (&ur)[UQ]) {
-    if (fst) {
-      float qf[VEC];
-      unpack<T, VEC>(qr, qf);
-      qk.set(qf);
-#pragma unroll
-      for (int a = 0; a < UQ; ++a) {
-        float t4[4];
-        unpack<T, 4>(ur[a], t4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u[4 * a + i] = t4[i];
-      }
-      m = -INFINITY;
-      l = 0.f;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int a = 0; a < UP; ++a) tacc[a] = 0.f;
-    }
-    if (eb < ee) {
-      float s[U];
-      float mb = m;
-#pragma unroll
-      for (int uu = 0; uu < U; ++uu) {
-        s[uu] = -INFINITY;
-        if (eb + uu < ee) {
-          const float* at = attr_ + (int64_t)(eb + uu) * UP;
-          float t = 0.f;
-#pragma unroll
-          for (int a = 0; a < UP; ++a) t = fmaf(u[a], at[a], t);
-          s[uu] = (group_sum<LPH>(qk.dot(kr[uu])) + t) * p.scale;
-          mb = fmaxf(mb, s[uu]);
-        }
-      }
-      const float corr = __expf(m - mb);
-      l *= corr;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] *= corr;
-#pragma unroll
-      for (int a = 0; a < UP; ++a) tacc[a] *= corr;
-#pragma unroll
-      for (int uu = 0; uu < U; ++uu) {
-        if (eb + uu < ee) {
-          const float* at = attr_ + (int64_t)(eb + uu) * UP;
-          const float pe = __expf(s[uu] - mb);
-          l += pe;
-          float vv[VEC];
-          unpack<T, VEC>(vr[uu], vv);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i], acc[i]);
-#pragma unroll
-          for (int a = 0; a < UP; ++a) tacc[a] = fmaf(pe, at[a], tacc[a]);
-        }
-      }
-      m = mb;
-    }
-    if (eb + U >= ee) {  // last batch of this destination: normalise and store
-      const float inv = 1.0f / (l + 1e-16f);
-      float o[VEC];
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] = acc[i] * inv;
-      if (p.xr != nullptr) {
-        float r[VEC];
-        VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + c0 + nd * p.ldr, r);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) o[i] += r[i];
-      }
-      T* on = static_cast<T*>(p.out) + nd * p.ldo;
-      if (active) VecIO<T, VEC>::store(on + c0, o);
-      if (head_lead) {
-        T* tn = on + p.C + head * UP;
-#pragma unroll
-        for (int a = 0; a < UP; a += 4) {
-          const float t4[4] = {tacc[a] * inv, tacc[a + 1] * inv, tacc[a + 2] * inv, tacc[a + 3] * inv};
-          VecIO<T, 4>::store(tn + a, t4);
-        }
-      }
-    }
-  };
-
-  // advance the iterator to the next batch; returns false when this wave has no more work
-  auto advance = [&](int64_t& nd, int& eb, int& ee, bool& fst) -> bool {
-    if (eb + U < ee) {
-      eb += U;
-      fst = false;
-      return true;
-    }
-    nd = node_nx;
-    if (nd >= n1) return false;
-    eb = nb;
-    ee = ne;
-    fst = true;
-    node_nx = nd + node_stride;
-    if (node_nx < n1) {
-      nb = rowptr_[node_nx];
-      ne = rowptr_[node_nx + 1];
-    }
-    return true;
-  };
-
-  Raw krA[U], vrA[U], krB[U], vrB[U], qrA, qrB;
-  URaw urA[UQ], urB[UQ];
-  load_batch(node, e, e_end, first, krA, vrA, qrA, urA);
-  bool more = true;
-  while (more) {
-    // ---- batch in set A is current; fetch its successor into set B
-    int64_t node2 = node;
-    int e2 = e, e2_end = e_end;
-    bool first2 = first;
-    const bool has2 = advance(node2, e2, e2_end, first2);
-    if (has2) load_batch(node2, e2, e2_end, first2, krB, vrB, qrB, urB);
-    compute_batch(node, e, e_end, first, krA, vrA, qrA, urA);
-    if (!has2) break;
-    // ---- batch in set B is current; fetch its successor into set A
-    node = node2;
-    e = e2;
-    e_end = e2_end;
-    first = first2;
-    more = advance(node, e, e_end, first);
-    if (more) load_batch(node, e, e_end, first, krA, vrA, qrA, urA);
-    compute_batch(node2, e2, e2_end, first2, krB, vrB, qrB, urB);
-  }
-}
-
 template <typename T, int VEC, int LPH, int UP>
 static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   constexpr int WPB = 4;
@@ -681,17 +482,10 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;  // resident workgroups per CU x 32 CUs per XCD
   if (bpx < 1) bpx = 1;
   while ((bpx * WPB) % p.n_slices != 0) ++bpx;
-  // A/B switch: ANEMOI_AMD_EDGE_PIPE=1 selects the software-pipelined variant.  Measured on MI355X (N320/ico-6,
-  // 1024 ch, bf16): simple loop 0.19 / 1.21 / 0.60 ms vs pipelined 0.30 / 1.98 / 0.79 ms (mesh / decoder /
-  // encoder graphs) -- the second register set costs one wave per SIMD, which hurts more than the overlap helps.
-  static const bool pipelined = [] {
-    const char* e = getenv("ANEMOI_AMD_EDGE_PIPE");
-    return e != nullptr && atoi(e) != 0;
-  }();
-  if (pipelined)
-    hipLaunchKernelGGL((gt_edge_attention_folded_pipe_kernel<T, VEC, LPH, UP>), dim3((unsigned)(8 * bpx)),
-                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
-  else if (edges_in_flight == 8)
+  // (a register-double-buffered software pipeline across destinations was measured and removed: 0.30 / 1.98 / 0.79 ms
+  // against 0.19 / 1.21 / 0.60 ms of this loop on the mesh / decoder / encoder graphs of config 3 -- the second
+  // register set costs a wave per SIMD, which hurts more than the overlap helps)
+  if (edges_in_flight == 8)
     hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 8>), dim3((unsigned)(8 * bpx)),
                        dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
   else if (edges_in_flight == 2)

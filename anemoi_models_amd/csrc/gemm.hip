@@ -1347,7 +1347,11 @@ static int linear_dispatch(const char* who, int dtype, int out_dtype, const void
   hipStream_t st = as_stream(stream);
   if (dtype == ANEMOI_F32 && out_dtype == ANEMOI_F32)
     return linear_launch<float, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
-  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16 && M >= 1024 && N >= 256) {
+  static const int64_t big_min_m = [] {  // A/B: rows from which the persistent 256 x 256 kernel takes over
+    const char* e = getenv("ANEMOI_AMD_GEMM_MIN_M");
+    return e ? (int64_t)atoll(e) : (int64_t)1024;
+  }();
+  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16 && M >= big_min_m && N >= 256) {
     // A ragged last row tile would cost every CU of one XCD a full extra round (161 vs 160 row tiles at M = 40 962:
     // +10 %): the 256-row multiple goes to the persistent kernel, the few remaining rows to the 128 x 128 kernel.
     const int64_t m_main = M / BIG_M * BIG_M, m_tail = M - m_main;
