@@ -1,6 +1,7 @@
 """Pre- / post-processors mirroring reference preprocessing/__init__.py:20-194 (same class names, config schema,
 ``forward(x, in_place, inverse)`` contract).  Only the pieces on the inference path are provided: the base class, the
-``Processors`` container and ``normalizer.InputNormalizer``; the imputers / remappers are not part of this build."""
+``Processors`` container, ``normalizer.InputNormalizer`` and the NaN imputers of ``imputer``; the remappers are not
+part of this build."""
 
 from __future__ import annotations
 

@@ -50,10 +50,15 @@ class SimpleDataIndices:
     """Dataset layout ``[prognostic..., forcing..., diagnostic...]``; input = all but diagnostic, output = all but
     forcing (reference data_indices/collection.py:24-103 without remapping: ``internal_*`` == the plain views)."""
 
-    def __init__(self, n_prognostic: int, n_forcing: int = 0, n_diagnostic: int = 0) -> None:
+    def __init__(self, n_prognostic: int, n_forcing: int = 0, n_diagnostic: int = 0, names=None) -> None:
         prog = [f"prog_{i}" for i in range(n_prognostic)]
         forc = [f"forc_{i}" for i in range(n_forcing)]
         diag = [f"diag_{i}" for i in range(n_diagnostic)]
+        if names is not None:  # variable names in dataset order (prognostic, forcing, diagnostic)
+            names = list(names)
+            assert len(names) == n_prognostic + n_forcing + n_diagnostic
+            prog, forc = names[:n_prognostic], names[n_prognostic:n_prognostic + n_forcing]
+            diag = names[n_prognostic + n_forcing:]
         inp = _ModelIndex(prog + forc, range(n_prognostic), forcing=range(n_prognostic, n_prognostic + n_forcing))
         out = _ModelIndex(prog + diag, range(n_prognostic),
                           diagnostic=range(n_prognostic, n_prognostic + n_diagnostic))

@@ -241,6 +241,64 @@ def golden_interface(fname: str = "interface_gt.npz") -> dict:
     return {k: list(v.shape) for k, v in sd.items()}
 
 
+IMPUTER_NAMES = ["x", "y", "z", "q", "other"]
+IMPUTER_CASES = {  # class name -> config (statistic or constant -> variables)
+    "InputImputer": {"default": "none", "mean": ["y"], "maximum": ["x"], "none": ["z"], "minimum": ["q", "other"]},
+    "InputImputerDefault": {"default": "minimum"},
+    "ConstantImputer": {"default": "none", 0: ["x"], 3.0: ["y"], 22.7: ["z"], 10: ["q"]},
+    "DynamicInputImputer": {"default": "none", "mean": ["y", "q"], "maximum": ["x"]},
+    "DynamicConstantImputer": {"default": 22.7},
+}
+
+
+def imputer_data_config(imputer_cfg: dict) -> dict:
+    return {"data": {"imputer": imputer_cfg, "forcing": ["z", "q"], "diagnostic": ["other"], "remapped": {}}}
+
+
+def golden_imputers(fname: str = "imputers.npz") -> None:
+    """The reference imputers (preprocessing/imputer.py) on the reference's own IndexCollection: a first call with the
+    training layout fixes the NaN map, then the inference input layout, then the inverse on both output layouts."""
+    from anemoi.models.preprocessing import imputer as ref_imputer
+
+    gen = torch.Generator().manual_seed(21)
+    stats = {"mean": np.array([1.0, 2.0, 3.0, 4.5, 3.0]), "stdev": np.array([0.5, 0.5, 0.5, 1.0, 14.0]),
+             "minimum": np.array([-1.0, -2.0, -3.0, -4.0, -5.0]), "maximum": np.array([11.0, 12.0, 13.0, 14.0, 15.0])}
+    out = {f"stat.{k}": v for k, v in stats.items()}
+    name_to_index = {n: i for i, n in enumerate(IMPUTER_NAMES)}
+
+    def with_nans(*shape, p=0.3):
+        t = torch.randn(shape, generator=gen)
+        t[torch.rand(shape, generator=gen) < p] = float("nan")
+        return t
+
+    for case, cfg in IMPUTER_CASES.items():
+        cls = getattr(ref_imputer, case.replace("Default", ""))
+        full = _ref_stubs.DotDict(imputer_data_config(cfg))
+        indices = IndexCollection(config=full, name_to_index=name_to_index)
+        use_stats = None if "Constant" in case else {k: v.copy() for k, v in stats.items()}
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            imp = cls(config=full.data.imputer, data_indices=indices, statistics=use_stats)
+        x_train = with_nans(2, 2, 7, 5)
+        x_train[0, 0, 3, :] = float("nan")  # a grid point that is missing in every variable
+        x_infer = with_nans(2, 2, 7, len(indices.model.input.name_to_index))
+        y_train = torch.randn((2, 7, len(indices.data.output.name_to_index)), generator=gen)
+        y_infer = torch.randn((2, 7, len(indices.model.output.name_to_index)), generator=gen)
+        t_train = imp.transform(x_train, in_place=False)
+        t_infer = imp.transform(x_infer, in_place=False)
+        inv_train = imp.inverse_transform(y_train, in_place=False)
+        inv_infer = imp.inverse_transform(y_infer, in_place=False)
+        for k, v in (("x_train", x_train), ("x_infer", x_infer), ("y_train", y_train), ("y_infer", y_infer),
+                     ("t_train", t_train), ("t_infer", t_infer), ("inv_train", inv_train), ("inv_infer", inv_infer),
+                     ("loss_mask", imp.loss_mask_training)):
+            out[f"{case}.{k}"] = v.numpy()
+        print(case, "replacement", [float(r) for r in imp.replacement], "nan in", int(torch.isnan(x_train).sum()),
+              "nan out", int(torch.isnan(t_train).sum()))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
 def golden_blocks() -> None:
     gen = torch.Generator().manual_seed(99)
     out = {}
@@ -350,3 +408,4 @@ if __name__ == "__main__":
         json.dump(keys, f, indent=0, sort_keys=True)
     golden_blocks()
     golden_index_ops()
+    golden_imputers()

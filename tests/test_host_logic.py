@@ -293,3 +293,48 @@ def test_interface_rollout_matches_golden(graph_o32, golden_interface, monkeypat
     torch.testing.assert_close(y2[0], y[0])
     assert (y2[1] - y[1]).abs().max() > 1e-3
     assert iface._advance_map(torch.device("cpu")).tolist() == list(range(10)) + [-2, -3]
+
+
+IMPUTER_CASES = {  # as in tests/golden/make_golden.py
+    "InputImputer": {"default": "none", "mean": ["y"], "maximum": ["x"], "none": ["z"], "minimum": ["q", "other"]},
+    "InputImputerDefault": {"default": "minimum"},
+    "ConstantImputer": {"default": "none", 0: ["x"], 3.0: ["y"], 22.7: ["z"], 10: ["q"]},
+    "DynamicInputImputer": {"default": "none", "mean": ["y", "q"], "maximum": ["x"]},
+    "DynamicConstantImputer": {"default": 22.7},
+}
+
+
+@pytest.mark.parametrize("case", sorted(IMPUTER_CASES))
+def test_imputers_match_reference(case):
+    """preprocessing.imputer against vectors recorded from the reference imputers on the reference IndexCollection
+    (reference preprocessing/imputer.py; cases modelled on its tests/preprocessing/test_preprocessor_imputer.py)."""
+    import warnings
+
+    import numpy as np
+
+    from anemoi_models_amd.preprocessing import imputer
+
+    with np.load(os.path.join(GOLDEN, "imputers.npz")) as z:
+        gold = {k: torch.from_numpy(z[k]) for k in z.files}
+    g = split_prefix(gold, case + ".")
+    stats = None if "Constant" in case else {k: v.numpy() for k, v in split_prefix(gold, "stat.").items()}
+    idx = SimpleDataIndices(n_prognostic=2, n_forcing=2, n_diagnostic=1, names=["x", "y", "z", "q", "other"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        imp = getattr(imputer, case.replace("Default", ""))(config=dict(IMPUTER_CASES[case]), data_indices=idx,
+                                                             statistics=stats)
+    x_train = g["x_train"].clone()
+    t_train = imp.transform(x_train, in_place=False)
+    assert torch.equal(torch.isnan(x_train), torch.isnan(g["x_train"]))  # in_place=False leaves the input alone
+    torch.testing.assert_close(t_train, g["t_train"], rtol=0, atol=0, equal_nan=True)
+    torch.testing.assert_close(imp.transform(g["x_infer"], in_place=False), g["t_infer"], rtol=0, atol=0,
+                               equal_nan=True)
+    torch.testing.assert_close(imp.inverse_transform(g["y_train"], in_place=False), g["inv_train"], rtol=0, atol=0,
+                               equal_nan=True)
+    torch.testing.assert_close(imp.inverse_transform(g["y_infer"], in_place=False), g["inv_infer"], rtol=0, atol=0,
+                               equal_nan=True)
+    torch.testing.assert_close(imp.loss_mask_training, g["loss_mask"], rtol=0, atol=0)
+    inplace = g["x_train"].clone()
+    assert imp.transform(inplace) is inplace  # in place by default
+    with pytest.raises(ValueError):
+        imp.transform(torch.zeros(2, 7, 9))
