@@ -388,9 +388,14 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
       for (int i = 0; i < APL; ++i) u[i] *= amask;
     }
     float m = -INFINITY, l = 0.f;
-    float acc[VEC], tacc[APL];
+    // the value accumulators live as f32 pairs: rescale and accumulate are v_pk_mul_f32 / v_pk_fma_f32 (two channels per
+    // issue slot) -- this loop is bound by its instruction streams, not by bytes
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    constexpr int VP = (VEC + 1) / 2;
+    f32x2_t acc[VP];
+    float tacc[APL];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
 
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
       const float corr = __expf(m - mb);
       l *= corr;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] *= corr;
+      for (int i = 0; i < VP; ++i) acc[i] *= corr;
 #pragma unroll
       for (int a = 0; a < APL; ++a) tacc[a] *= corr;
 #pragma unroll
@@ -433,7 +438,9 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
           float vv[VEC];
           unpack<T, VEC>(vr[uu], vv);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i], acc[i]);
+          for (int i = 0; i < VP; ++i)
+            acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f},
+                                               acc[i]);
 #pragma unroll
           for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
         }
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
     const float inv = 1.0f / (l + 1e-16f);
     float o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = acc[i] * inv;
+    for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
     if (p.xr != nullptr) {
       float r[VEC];
       if (p.stream_hint) load_stream<T, VEC>(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
