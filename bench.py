@@ -143,6 +143,26 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "bytes_per_launch": a["bytes"] / a["launches"],
         }
+    if "mhsa" in agg and agg["mhsa"]["ms"] > 0:  # Transformer processor: mesh-node self attention (MFMA-bound)
+        a = agg["mhsa"]
+        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[dtype_name]
+        out["roofline_mhsa"] = {
+            "kernel": "anemoi::mhsa_bf16_d64_kernel (anemoi_mhsa: flash attention on v_mfma_f32_32x32x16_bf16)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "launches": a["launches"],
+            "avg_launch_ms": round(a["ms"] / a["launches"], 4), "flops_per_launch": a["flops"] / a["launches"],
+        }
+    for name in ("gather_add_act", "segment_sum"):  # GNN processor: HBM-bound edge kernels
+        if name in agg and agg[name]["ms"] > 0:
+            a = agg[name]
+            achieved = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            out["roofline_" + name] = {
+                "kernel": "anemoi::" + name + "_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+                "bytes_per_launch": a["bytes"] / a["launches"],
+            }
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (PMC counters cannot be
     # collected from inside the process; see profiles/r01_traffic.json for the command and the gfx950 corrections)
     try:

@@ -16,6 +16,9 @@ python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail > "$OUT/bench_
 python3 bench.py --workload cfg1 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/bench_cfg1_bf16.json" 2>/dev/null
 python3 bench.py --workload cfg2 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/bench_cfg2_bf16.json" 2>/dev/null
 python3 bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_cfg3_fp32.json" 2>/dev/null
+python3 bench.py --rollout 4 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_cfg4_rollout4_bf16.json" 2>/dev/null
+python3 bench.py --workload cfg2 --processor GNN --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_cfg5_gnn_bf16.json" 2>/dev/null
+python3 bench.py --processor Transformer --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_cfg3_transformer_bf16.json" 2>/dev/null
 
 cd /tmp
 rm -rf /tmp/kt /tmp/pmcf /tmp/pmcw
@@ -27,4 +30,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcf -- python3 "$ROOT/bench.p
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmcf > "$OUT/pmc_fetch_size.txt" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcw -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmcw > "$OUT/pmc_write_size.txt" 2>&1
+# mesh-node self attention (Transformer processor): kernel trace + MFMA-busy counters of the attention kernel
+rm -rf /tmp/ktt /tmp/pmcm
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt -o kt -- python3 "$ROOT/bench.py" --processor Transformer --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 "$ROOT/tools/summarize_trace.py" /tmp/ktt > "$OUT/kernel_summary_transformer.txt" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmcm -- python3 "$ROOT/bench.py" --processor Transformer --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 "$ROOT/tools/pmc_summary.py" /tmp/pmcm mhsa > "$OUT/pmc_mhsa_mfma_busy.txt" 2>&1
 ls -la "$OUT"

@@ -20,6 +20,11 @@ for name, out in [("bench_cfg1_bf16.json", f"{tag}_bench_cfg1_bf16.json"),
                   ("bench_cfg2_bf16.json", f"{tag}_bench_cfg2_bf16.json"),
                   ("bench_cfg3_bf16.json", f"{tag}_bench_cfg3_bf16.json"),
                   ("bench_cfg3_fp32.json", f"{tag}_bench_cfg3_fp32.json"),
+                  ("bench_cfg4_rollout4_bf16.json", f"{tag}_bench_cfg4_rollout4_bf16.json"),
+                  ("bench_cfg5_gnn_bf16.json", f"{tag}_bench_cfg5_gnn_bf16.json"),
+                  ("bench_cfg3_transformer_bf16.json", f"{tag}_bench_cfg3_transformer_bf16.json"),
+                  ("kernel_summary_transformer.txt", f"{tag}_bench_cfg3_transformer_summary.txt"),
+                  ("pmc_mhsa_mfma_busy.txt", f"{tag}_mhsa_mfma_busy_pmc.txt"),
                   ("kernel_stats.csv", f"{tag}_bench_cfg3_bf16_kernel_stats.csv"),
                   ("kernel_summary.txt", f"{tag}_bench_cfg3_bf16_summary.txt"),
                   ("bench_cfg3_bf16_detail.txt", f"{tag}_bench_cfg3_bf16_per_shape.txt")]:
