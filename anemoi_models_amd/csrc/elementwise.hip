@@ -458,7 +458,7 @@ int anemoi_advance_input(float* x, int B, int T, int Ens, int64_t G, int V_in, c
   return check_launch("anemoi_advance_input");
 }
 
-int anemoi_abi_version(void) { return 4; }
+int anemoi_abi_version(void) { return 5; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

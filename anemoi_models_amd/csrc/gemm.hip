@@ -24,6 +24,7 @@
 namespace anemoi {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -44,6 +45,12 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 struct LnFold {
   const float* colsum;  // s[n], nullptr = plain Linear
   const float2* stats;  // per row of x
+  // optional OUTPUT of the four-wave bf16 kernel: per row and 128-column slot the { sum, sum of squares } of the bf16
+  // values it stores (slot = 2 * column tile + wave column), rs_slots = N / 128 -- the LayerNorm statistics of y
+  // without reading y again (anemoi_linear_stats)
+  float2* rs_partial;
+  int rs_slots;
+  int64_t* rs_rows_done;  // host side only: the launcher reports how many leading rows got their partials
 };
 
 template <typename T, typename TO, int VEC>
@@ -565,7 +572,7 @@ __device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int6
   }
 }
 
-template <int ACT, bool HAS_RES, bool LN, int MH>
+template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias,
@@ -812,9 +819,13 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
         __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, rows_here * (int)ldy * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, HAS_RES ? rows_here * (int)ldr * 2 : 0, 0x00020000);
+    // row-sum partials [row][slot] of this tile's rows; only the lanes fq == 0 store (the others: out of range)
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(RS ? ln.rs_partial + m0 * ln.rs_slots : nullptr), 0, RS ? rows_here * ln.rs_slots * 8 : 0, 0x00020000);
     int fr_e = fr, fq_e = fq;  // opaque copies: keeps the epilogue's lane offsets from being hoisted above the K loop
     asm volatile("" : "+v"(fr_e), "+v"(fq_e));  // (a single VGPR spilled there costs a vmcnt(0) per reload here)
     const int ncol = wn * 128 + fq_e * 8;  // this lane's column inside the tile (+ 32 u)
+    const int vps = fq_e == 0 ? (fr_e * ln.rs_slots + (n0 >> 7) + wn) * 8 : 0x7f000000;
     int vy[4], vr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -877,6 +888,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
 #pragma unroll
       for (int i = 0; i < 8; ++i)  // "+a": the zeroed value keeps the accumulator's register (no copies at the loop edges)
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "+a"(acc[i][j]) : "v"(zfrag));
+      float rs1 = 0.f, rs2 = 0.f;  // RS: sum / sum of squares of this lane's 32 stored values of row j * 16 + fr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const f32x4_t c0 = c[2 * u], c1 = c[2 * u + 1];
@@ -901,11 +913,35 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
         if constexpr (HAS_RES)
           v = make_uint4(bf16x2_add(v.x, rv[u].x), bf16x2_add(v.y, rv[u].y), bf16x2_add(v.z, rv[u].z),
                          bf16x2_add(v.w, rv[u].w));
+        if constexpr (RS) {  // on the ROUNDED values, pairwise: v_dot2_f32_bf16 with (1, 1) and with itself
+          const uint32_t ones = 0x3f803f80u;
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t wq = w4[q];
+            rs1 = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&wq),
+                                                  *reinterpret_cast<const bf16x2_t*>(&ones), rs1, false);
+            rs2 = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&wq),
+                                                  *reinterpret_cast<const bf16x2_t*>(&wq), rs2, false);
+          }
+        }
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, yrs, vy[u],
                                                (wm * (MH * 16) + j * 16) * (int)ldy * 2, 0);
         // Observed on gfx950: a 16-byte buffer store whose data registers are overwritten by the very next VALU
         // instruction stores the new value in part of dword 1 (lanes 12..15 of every 16).  The compiler pads this hazard
         // with one wait state except when soffset is an SGPR (as here), where it assumes none: pad by hand.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (RS) {  // the four lanes fr, fr + 16, fr + 32, fr + 48 hold the row's four 8-column groups per u
+        rs1 += __shfl_xor(rs1, 16, 64);
+        rs2 += __shfl_xor(rs2, 16, 64);
+        rs1 += __shfl_xor(rs1, 32, 64);
+        rs2 += __shfl_xor(rs2, 32, 64);
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2s_t;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2s_t{__float_as_uint(rs1), __float_as_uint(rs2)}, prs, vps,
+                                              (wm * (MH * 16) + j * 16) * ln.rs_slots * 8, 0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_nop 1" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1161,6 +1197,19 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
 #define RAISE_W4(A, RES) \
   RAISE_W4_(A, RES, false); \
   RAISE_W4_(A, RES, true)
+#define RAISE_W4_RS(RES, LNF, MHV)                                                                              \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<0, RES, LNF, MHV, true>),         \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)                     \
+    return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
+    RAISE_W4_RS(false, false, 8);
+    RAISE_W4_RS(false, true, 8);
+    RAISE_W4_RS(true, false, 8);
+    RAISE_W4_RS(true, true, 8);
+    RAISE_W4_RS(false, false, 4);
+    RAISE_W4_RS(false, true, 4);
+    RAISE_W4_RS(true, false, 4);
+    RAISE_W4_RS(true, true, 4);
+#undef RAISE_W4_RS
     RAISE_W4(0, false);
     RAISE_W4(0, true);
     RAISE_W4(1, false);
@@ -1216,27 +1265,33 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
         mt_b = rem_mt;
       }
     }
-#define LAUNCH_W4__(A, RES, LNF, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                       \
-  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES, LNF, MHV>), dim3((unsigned)w4_blocks), dim3(256), W4_LDS, \
-                     st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,            \
+#define LAUNCH_W4__(A, RES, LNF, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL)                                       \
+  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, RES, LNF, MHV, RSV>), dim3((unsigned)w4_blocks), dim3(256), W4_LDS, \
+                     st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,                 \
                      vec_ok ? 1 : 0, TILES, (int)nt, LNV, TAIL)
-#define LAUNCH_W4_(A, RES, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                       \
-  do {                                                                                  \
-    if (ln.stats != nullptr) LAUNCH_W4__(A, RES, true, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); \
-    else LAUNCH_W4__(A, RES, false, MHV, XP, RP, YP, LNV, MV, TILES, TAIL);             \
+#define LAUNCH_W4_(A, RES, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL)                             \
+  do {                                                                                             \
+    if (ln.stats != nullptr) LAUNCH_W4__(A, RES, true, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL); \
+    else LAUNCH_W4__(A, RES, false, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL);                   \
   } while (0)
-#define LAUNCH_W4(A, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                \
-  do {                                                                                     \
-    if (residual != nullptr) LAUNCH_W4_(A, true, MHV, XP, RP, YP, LNV, MV, TILES, TAIL);   \
-    else LAUNCH_W4_(A, false, MHV, XP, RP, YP, LNV, MV, TILES, TAIL);                      \
+#define LAUNCH_W4(A, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL)                                \
+  do {                                                                                          \
+    if (residual != nullptr) LAUNCH_W4_(A, true, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL);   \
+    else LAUNCH_W4_(A, false, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL);                      \
   } while (0)
-#define LAUNCH_W4_ACT(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                 \
-  switch (act) {                                                                             \
-    case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
-    case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
-    case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
-    default: LAUNCH_W4(ANEMOI_ACT_NONE, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break;       \
+#define LAUNCH_W4_ACT(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                        \
+  switch (act) {                                                                                    \
+    case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    default:                                                                                        \
+      if (rs_on) LAUNCH_W4(ANEMOI_ACT_NONE, MHV, true, XP, RP, YP, LNV, MV, TILES, TAIL);           \
+      else LAUNCH_W4(ANEMOI_ACT_NONE, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL);                \
+      break;                                                                                        \
   }
+    // row-sum partials (LnFold::rs_partial): plain epilogue only, whole 256-column tiles only
+    const bool rs_on = ln.rs_partial != nullptr && act == ANEMOI_ACT_NONE && N % BIG_N == 0;
+    if (rs_on && ln.rs_rows_done != nullptr) *ln.rs_rows_done = M;
     const bf16_t* xb = static_cast<const bf16_t*>(x);
     const bf16_t* rb = static_cast<const bf16_t*>(residual);
     bf16_t* yb = static_cast<bf16_t*>(y);
@@ -1251,6 +1306,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       const int64_t m_a = mt_a * BIG_M, m_b = M - m_a, tiles_b = mt_b * 2 * nt;  // m_b may end inside the last tile
       LnFold lb = ln;
       if (lb.stats != nullptr) lb.stats += m_a;
+      if (lb.rs_partial != nullptr) lb.rs_partial += m_a * lb.rs_slots;
       w4_blocks = tiles_b < max_blocks ? (tiles_b + 7) / 8 * 8 : max_blocks;
       LAUNCH_W4_ACT(4, xb + m_a * ldx, rb != nullptr ? rb + m_a * ldr : nullptr, yb + m_a * ldy, lb, m_b, tiles_b, w4_tail)
     }
@@ -1407,4 +1463,65 @@ extern "C" int anemoi_linear_ln(int dtype, int out_dtype, const void* x, int64_t
   return linear_dispatch("anemoi_linear_ln", dtype, out_dtype, x, ldx, w, bias,
                          LnFold{colsum, reinterpret_cast<const float2*>(stats)}, residual, ldr, y, ldy, M, N, K, act,
                          stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = x W^T + b (+ residual)  AND  the LayerNorm statistics of y's rows, without a second pass over y: the four-wave
+// kernel's epilogue leaves { sum, sum of squares } of the bf16 values it stores per (row, 128-column slot) in a
+// workspace; this tiny kernel folds the slots into { rstd, -mean rstd } (the format of anemoi_row_stats).
+// ---------------------------------------------------------------------------------------------
+namespace anemoi {
+__global__ __launch_bounds__(256) void row_sums_finalize_kernel(const float2* __restrict__ partial, int slots,
+                                                                int64_t rows, int C, float eps,
+                                                                float2* __restrict__ stats) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f, ss = 0.f;
+  for (int k = 0; k < slots; ++k) {
+    const float2 p = partial[r * slots + k];
+    s += p.x;
+    ss += p.y;
+  }
+  const float inv_c = 1.0f / (float)C;
+  const float mean = s * inv_c;
+  const float var = fmaxf(ss * inv_c - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  stats[r] = make_float2(rstd, -mean * rstd);
+}
+}  // namespace anemoi
+
+extern "C" int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const void* w, const float* bias,
+                                   const float* colsum, const float* stats_in, const void* residual, int64_t ldr,
+                                   void* y, int64_t ldy, int64_t M, int N, int K, void* workspace,
+                                   int64_t workspace_bytes, float eps, float* stats_out, anemoi_stream_t stream) {
+  using namespace anemoi;
+  ANEMOI_REQUIRE(stats_out != nullptr && (uintptr_t)stats_out % 8 == 0, ANEMOI_ERR_INVALID,
+                 "anemoi_linear_stats: stats_out must be a non-null 8-byte aligned pointer");
+  ANEMOI_REQUIRE((colsum == nullptr) == (stats_in == nullptr), ANEMOI_ERR_INVALID,
+                 "anemoi_linear_stats: colsum and stats_in come together");
+  int64_t rows_done = 0;
+  LnFold ln{colsum, reinterpret_cast<const float2*>(stats_in), nullptr, 0, nullptr};
+  const int slots = N / 128;
+  if (dtype == ANEMOI_BF16 && N % 256 == 0 && workspace != nullptr && (uintptr_t)workspace % 8 == 0 &&
+      workspace_bytes >= M * slots * 8) {
+    ln.rs_partial = static_cast<float2*>(workspace);
+    ln.rs_slots = slots;
+    ln.rs_rows_done = &rows_done;
+  }
+  const int rc = linear_dispatch("anemoi_linear_stats", dtype, dtype, x, ldx, w, bias, ln, residual, ldr, y, ldy, M, N,
+                                 K, ANEMOI_ACT_NONE, stream);
+  if (rc != ANEMOI_OK) return rc;
+  if (rows_done > 0) {
+    hipLaunchKernelGGL(row_sums_finalize_kernel, dim3((unsigned)((rows_done + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), static_cast<const float2*>(workspace), slots, rows_done, N, eps,
+                       reinterpret_cast<float2*>(stats_out));
+    const int rl = check_launch("anemoi_linear_stats(finalize)");
+    if (rl != ANEMOI_OK) return rl;
+  }
+  if (rows_done < M) {  // rows the fused path did not cover (skinny tail, other kernels): statistics from y itself
+    const int esz = dtype == ANEMOI_BF16 ? 2 : 4;
+    return anemoi_row_stats(dtype, static_cast<const char*>(y) + rows_done * ldy * esz, ldy, stats_out + 2 * rows_done,
+                            M - rows_done, N, eps, stream);
+  }
+  return ANEMOI_OK;
 }

@@ -217,7 +217,18 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         return ([l.weight for l in lead_layers] + [l.bias for l in lead_layers]
                 + [self.lin_edge.weight, self.lin_edge.bias, self.lin_query.weight, self.lin_query.bias])
 
-    def _node_mlp(self, y: Tensor, which: str, num_chunks: int) -> Tensor:
+    def _mlp_ln_eps(self, which: str, dtype) -> Optional[float]:
+        """Epsilon of the LayerNorm that opens the node MLP when its statistics can ride on the producing GEMM."""
+        mlp = self.node_dst_mlp if which == "dst" else self.node_src_mlp
+        first = mlp[0] if isinstance(mlp, nn.Sequential) else None
+        return first.eps if isinstance(first, nn.LayerNorm) and runtime.ln_fold_enabled(dtype) else None
+
+    def _next_ln_eps(self, dtype) -> Optional[float]:
+        """Processor blocks are stacked: the output enters the next block's ``layer_norm1`` (same construction)."""
+        ln1 = getattr(self, "layer_norm1", None)
+        return ln1.eps if isinstance(ln1, nn.LayerNorm) and runtime.ln_fold_enabled(dtype) else None
+
+    def _node_mlp(self, y: Tensor, which: str, num_chunks: int, out_stats_eps: Optional[float] = None) -> Tensor:
         """``mlp(y) + y`` with mlp = LayerNorm, Linear, act, Linear; optionally in row chunks (bounded hidden buffer)."""
         if which == "dst":
             if self._dst_mlp is None:
@@ -228,7 +239,7 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
                 self._src_mlp = NativeSequential(self.node_src_mlp)
             run = self._src_mlp
         if num_chunks <= 1:
-            return run(y, residual=y)
+            return run(y, residual=y, out_stats_eps=out_stats_eps)
         return torch.cat([run(c, residual=c) for c in y.tensor_split(num_chunks, dim=0) if c.shape[0] > 0], dim=0)
 
     def _check_channels(self, dtype) -> None:
@@ -283,8 +294,8 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
                                                edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
                                                ld_out=wpf.shape[1])
-            y = ops.linear(att, wpf, bp, residual=x)
-            return self._node_mlp(y, "dst", 1)
+            y = ops.linear(att, wpf, bp, residual=x, stats_eps=self._mlp_ln_eps("dst", dtype))
+            return self._node_mlp(y, "dst", 1, out_stats_eps=self._next_ln_eps(dtype))
         all4 = [self.lin_self, self.lin_query, self.lin_key, self.lin_value]
         if up is not None:
             wpf, bp = self._folded_out(dtype, up)
@@ -294,16 +305,18 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             att = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c],
                                                sq[:, 4 * c:], edge_attr_csr, plan.rowptr, plan.col, self.num_heads,
                                                up, ld_out=wpf.shape[1])
-            y = ops.linear(att, wpf, bp, residual=x)  # projection(out + x_r) + x_skip, lin_edge part via W_t
-            return self._node_mlp(y, "dst", 1)
+            # projection(out + x_r) + x_skip, lin_edge part via W_t; the statistics of the MLP's LayerNorm ride on the
+            # epilogue, those of the next block's layer_norm1 on the MLP's last Linear
+            y = ops.linear(att, wpf, bp, residual=x, stats_eps=self._mlp_ln_eps("dst", dtype))
+            return self._node_mlp(y, "dst", 1, out_stats_eps=self._next_ln_eps(dtype))
         wp, bp = self._cat_linear("proj", [self.projection], dtype)
         we, be = self._edge_params()
         sqkv = self._ln_linear(xh, "sqkv", lambda: self._cat_linear("sqkv", all4, dtype), lambda: self._cat_rows(all4),
                                [l.weight for l in all4] + [l.bias for l in all4])  # [N, 4C] = x_r | q | k | v
         att = self.conv.fused(sqkv[:, c:2 * c], sqkv[:, 2 * c:3 * c], sqkv[:, 3 * c:], sqkv[:, :c], edge_attr_csr,
                               self.edge_dim, we, be, plan, self.num_heads)
-        y = ops.linear(att, wp, bp, residual=x)  # projection(out + x_r) + x_skip
-        return self._node_mlp(y, "dst", 1)
+        y = ops.linear(att, wp, bp, residual=x, stats_eps=self._mlp_ln_eps("dst", dtype))  # projection(out + x_r) + x
+        return self._node_mlp(y, "dst", 1, out_stats_eps=self._next_ln_eps(dtype))
 
     def forward(
         self,
@@ -351,8 +364,9 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         self.layer_norm2 = nn.LayerNorm(in_channels)
 
     def native(self, x_src: Tensor, x_dst: Tensor, edge_attr_csr: Tensor, plan: EdgePlan, num_chunks: int = 1,
-               halo=None):
-        """``halo``: node-partitioned run -- ``x_src`` holds this rank's source rows, the k|v rows of the other
+               halo=None, out_stats_eps: Optional[float] = None):
+        """``out_stats_eps``: epsilon of the LayerNorm the new destination nodes enter next (its statistics then come
+        out of the node MLP's last GEMM).  ``halo``: node-partitioned run -- ``x_src`` holds this rank's source rows, the k|v rows of the other
         sources of the plan are appended by one all-to-all-v."""
         dtype = x_dst.dtype
         self._check_channels(dtype)
@@ -394,9 +408,10 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
             att = self.conv.fused(sq[:, c:], kv[:, :c], kv[:, c:], sq[:, :c], edge_attr_csr, self.edge_dim, we, be,
                                   plan, self.num_heads)
         del sq, kv
-        y = ops.linear(att, wp, bp, residual=x_dst)
+        y = ops.linear(att, wp, bp, residual=x_dst,
+                       stats_eps=self._mlp_ln_eps("dst", dtype) if num_chunks <= 1 else None)
         del att
-        new_dst = self._node_mlp(y, "dst", num_chunks)
+        new_dst = self._node_mlp(y, "dst", num_chunks, out_stats_eps=out_stats_eps)
         new_src = self._node_mlp(x_src, "src", num_chunks) if self.update_src_nodes else x_src
         return new_src, new_dst
 

@@ -99,6 +99,19 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
     def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
         return x_dst
 
+    def _block_ln_eps(self, dtype):
+        """(eps of the block's layer_norm1, layer_norm2) when their statistics can ride on the embedding GEMMs."""
+        if not runtime.ln_fold_enabled(dtype):
+            return None, None
+        return self.proc.layer_norm1.eps, self.proc.layer_norm2.eps
+
+    def _extract_ln_eps(self, dtype) -> Optional[float]:
+        """eps of the LayerNorm that opens ``node_data_extractor`` (backward mapper), else None."""
+        ext = getattr(self, "node_data_extractor", None)
+        if isinstance(ext, nn.Sequential) and isinstance(ext[0], nn.LayerNorm) and runtime.ln_fold_enabled(dtype):
+            return ext[0].eps
+        return None
+
     def native(self, x_src: Tensor, x_dst: Tensor, batch_size: int, out_dtype: Optional[torch.dtype] = None,
                src_map: Optional[Tensor] = None, dst_map: Optional[Tensor] = None) -> Tensor:
         """Inputs in the compute dtype (optionally K padded).  Returns the mapped destination nodes.
@@ -110,7 +123,7 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
         h_src, h_dst = self._embed(x_src, x_dst)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
-        _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks)
+        _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, out_stats_eps=self._extract_ln_eps(h_dst.dtype))
         return self._extract(h_dst, out_dtype)
 
     def native_local(self, x_src: Tensor, x_dst: Tensor, local_graph, out_dtype: Optional[torch.dtype] = None) -> Tensor:
@@ -120,7 +133,8 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
         h_src, h_dst = self._embed(x_src, x_dst)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
-        _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, local_graph.halo)
+        _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, local_graph.halo,
+                                    out_stats_eps=self._extract_ln_eps(h_dst.dtype))
         return self._extract(h_dst, out_dtype)
 
     def _run(self, x, batch_size: int, shard_shapes, model_comm_group) -> Tensor:
@@ -156,8 +170,9 @@ class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
         self.emb_nodes_src = nn.Linear(self.in_channels_src, self.hidden_dim)
 
     def _embed(self, x_src: Tensor, x_dst: Tensor):
-        return (linear_native(self._packed, "emb_nodes_src", self.emb_nodes_src, x_src),
-                linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst))
+        eps1, eps2 = self._block_ln_eps(x_src.dtype)  # the embeddings enter the block's layer_norm1 / layer_norm2
+        return (linear_native(self._packed, "emb_nodes_src", self.emb_nodes_src, x_src, stats_eps=eps1),
+                linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst, stats_eps=eps2))
 
     def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None):
         x_dst = self._run(x, batch_size, shard_shapes, model_comm_group)
@@ -181,7 +196,8 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
                                                  nn.Linear(self.hidden_dim, self.out_channels_dst))
 
     def _embed(self, x_src: Tensor, x_dst: Tensor):
-        return x_src, linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst)
+        return x_src, linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst,
+                                    stats_eps=self._block_ln_eps(x_dst.dtype)[1])
 
     def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
         ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]

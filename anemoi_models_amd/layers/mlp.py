@@ -59,8 +59,10 @@ class NativeSequential:
             i += 1
 
     def __call__(self, x: Tensor, residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-                 start: int = 0) -> Tensor:
-        """Run steps ``start..`` (``start`` > 0: the caller has already produced the output of the earlier steps)."""
+                 start: int = 0, out_stats_eps: Optional[float] = None) -> Tensor:
+        """Run steps ``start..`` (``start`` > 0: the caller has already produced the output of the earlier steps).
+        ``out_stats_eps``: the result feeds a LayerNorm with this epsilon next -- the last Linear's epilogue produces
+        its row statistics (``ops.linear(stats_eps=...)``)."""
         dtype = x.dtype
         last_linear = max(i for i, s in enumerate(self.steps) if s[0] == "linear")
         ends_with_ln = self.steps[-1][0] == "ln"
@@ -72,6 +74,8 @@ class NativeSequential:
                 fuse_res = residual is not None and i == last_linear and not ends_with_ln
                 last = i == len(self.steps) - 1
                 kw = dict(act=act, residual=residual if fuse_res else None, out_dtype=out_dtype if last else None)
+                if last and out_stats_eps is not None and (residual is None or fuse_res):
+                    kw["stats_eps"] = out_stats_eps
                 if pending_ln is not None:
                     ln, stats = pending_ln
                     pending_ln = None
@@ -139,7 +143,8 @@ class MLP(nn.Module):
 
 
 def linear_native(cache: runtime.PackedWeights, tag: str, lin: nn.Linear, x: Tensor, act: str = "Identity",
-                  residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+                  residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                  stats_eps: Optional[float] = None) -> Tensor:
     """One ``nn.Linear`` on the fused GEMM kernel; ``x`` may carry zero K-padding or none (it is padded here)."""
     dtype = x.dtype
     w = cache.get((tag, "w", dtype), [lin.weight], lambda: runtime.pack_weight([lin.weight], dtype))
@@ -148,4 +153,4 @@ def linear_native(cache: runtime.PackedWeights, tag: str, lin: nn.Linear, x: Ten
         if x.shape[1] != lin.in_features:
             raise ValueError(f"{tag}: input has {x.shape[1]} features, expected {lin.in_features}")
         x = ops.convert_pad(x, dtype, w.shape[1])
-    return ops.linear(x, w, b, act=act, residual=residual, out_dtype=out_dtype)
+    return ops.linear(x, w, b, act=act, residual=residual, out_dtype=out_dtype, stats_eps=stats_eps)

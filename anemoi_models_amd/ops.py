@@ -110,6 +110,9 @@ def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
     """LayerNorm statistics of the rows of ``x``: ``[M, 2]`` f32 = ``(rstd, -mean * rstd)`` (see ``linear(ln=...)``)."""
     _dev(x)
     _rows(x)
+    carried = getattr(x, "_anemoi_row_stats", None)  # left by linear(..., stats_eps=eps), which produced x
+    if carried is not None and carried[0] == eps and carried[1].shape[0] == x.shape[0]:
+        return carried[1]
     out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
     with _Timed("row_stats", bytes=x.shape[0] * x.shape[1] * x.element_size()):
         st = _lib.load().anemoi_row_stats(dtype_code(x.dtype), x.data_ptr(), _ld(x), out.data_ptr(), x.shape[0],
@@ -120,8 +123,12 @@ def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "Identity",
            residual: Optional[Tensor] = None, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-           n_out: Optional[int] = None, ln=None) -> Tensor:
+           n_out: Optional[int] = None, ln=None, stats_eps: Optional[float] = None) -> Tensor:
     """``act(x @ w.T + bias) + residual``; ``w`` is ``[N, K]`` in x's dtype with K already padded like x.
+
+    ``stats_eps``: the result is about to enter a LayerNorm with this epsilon -- its row statistics are produced by the
+    GEMM's epilogue (``anemoi_linear_stats``) and travel with the returned tensor: ``row_stats(result, stats_eps)`` then
+    costs nothing.  Identity activation, same dtype in and out; silently ignored otherwise.
 
     ``ln=(stats, colsum)`` folds the LayerNorm of ``x`` into the product: ``x`` is the un-normalised input,
     ``stats = row_stats(x)``, ``w`` / ``bias`` / ``colsum`` come from ``runtime.fold_layer_norm``.
@@ -140,8 +147,22 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
         raise RuntimeError(f"activation {act} is not supported by the fused Linear kernel")
     alg = (x.shape[0] * k + n * k) * x.element_size() + x.shape[0] * n * (out.element_size() + (
         0 if residual is None else residual.element_size()))
+    fuse_stats = stats_eps is not None and act == "Identity" and out.dtype == x.dtype and _rows(out).shape[1] == n
     with _Timed("linear", flops=2 * x.shape[0] * n * k, bytes=alg, m=x.shape[0], n=n, k=k):
-        if ln is None:
+        if fuse_stats:
+            stats_in = colsum = None
+            if ln is not None:
+                stats_in, colsum = ln
+                _dev(stats_in, colsum)
+            m_rows = x.shape[0]
+            ws = torch.empty((m_rows * max(n // 128, 1), 2), dtype=torch.float32, device=x.device)
+            stats_out = torch.empty((m_rows, 2), dtype=torch.float32, device=x.device)
+            st = _lib.load().anemoi_linear_stats(
+                dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias), _ptr(colsum), _ptr(stats_in),
+                _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)), m_rows,
+                n, k, ws.data_ptr(), ws.numel() * 4, stats_eps, stats_out.data_ptr(), _stream())
+            out._anemoi_row_stats = (stats_eps, stats_out)
+        elif ln is None:
             st = _lib.load().anemoi_linear(
                 dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
                 _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)),

@@ -94,6 +94,21 @@ int anemoi_linear_ln(int dtype, int out_dtype, const void* x, int64_t ldx, const
                      int64_t M, int N, int K, int act, anemoi_stream_t stream);
 
 /*
+ * anemoi_linear_ln / anemoi_linear without activation, plus the LayerNorm statistics of the RESULT's rows
+ * (stats_out [M, 2] f32 = { rstd, -mean * rstd } of y[m, 0:N], the format of anemoi_row_stats) for the LayerNorm that
+ * consumes y next (reference layers/block.py:631-633 node_dst_mlp[0], :614 layer_norm1 of the next block,
+ * layers/mapper.py:416 node_data_extractor[0]): on the bf16 fast path the GEMM's epilogue leaves per-row partial sums of
+ * the bf16 values it stores in `workspace` (>= M * (N / 128) * 8 bytes, 8-byte aligned; N % 256 == 0) and a tiny kernel
+ * folds them -- y is not read again.  Other shapes / dtypes (or workspace == NULL): same result through
+ * anemoi_row_stats on y.  colsum / stats_in: both NULL = plain Linear, both set = LayerNorm-folded input as in
+ * anemoi_linear_ln.  x, y, residual in `dtype`.
+ */
+int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, const float* colsum,
+                        const float* stats_in, const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int N,
+                        int K, void* workspace, int64_t workspace_bytes, float eps, float* stats_out,
+                        anemoi_stream_t stream);
+
+/*
  * Edge attributes in CSR (destination-sorted) order:
  *   out[e, :] = [ a0[perm[e] % rows0, 0:d0] | a1[perm[e] % rows0, 0:d1] | 0 ... ]   (row stride ld_out)
  * and, when one_col >= 0, out[e, one_col] = 1 (the constant attribute that carries the lin_edge bias through the

@@ -27,7 +27,8 @@ def row_stats(x, eps=1e-5):
     return torch.stack([rstd, -mean * rstd], dim=1).contiguous()
 
 
-def linear(x, w, bias=None, *, act="Identity", residual=None, out=None, out_dtype=None, n_out=None, ln=None):
+def linear(x, w, bias=None, *, act="Identity", residual=None, out=None, out_dtype=None, n_out=None, ln=None,
+           stats_eps=None):
     assert x.shape[1] == w.shape[1] and w.shape[1] % (128 // x.element_size()) == 0, "K must be slab padded"
     if ln is None:
         pre = F.linear(x.float(), w.float(), bias)

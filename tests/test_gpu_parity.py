@@ -356,6 +356,38 @@ def test_interface_predict_step_vs_golden(graph_o32, golden_interface):
     assert rel_err(y, gold["y"]) < 1e-4
 
 
+@pytest.mark.parametrize("m,n,k,res,fold", [(40962, 1024, 4096, True, False), (5121, 1024, 1216, True, False),
+                                            (67718, 1024, 192, False, False), (2304, 512, 256, True, True),
+                                            (1300, 384, 128, False, False), (700, 1024, 256, True, False)])
+def test_linear_with_row_statistics_of_the_result(m, n, k, res, fold):
+    """anemoi_linear_stats: LayerNorm statistics of y from the GEMM epilogue == anemoi_row_stats(y) on the stored y
+    (whole tiles, skinny tail, ragged tile, half-tile launch, shapes that fall back to the separate kernel)."""
+    from anemoi_models_amd import ops, runtime
+
+    g = torch.Generator().manual_seed(m + n)
+    x = (torch.randn(m, k, generator=g) * 1.5 + 0.3).bfloat16().to(DEV)
+    w32 = torch.randn(n, k, generator=g) / k**0.5
+    b = torch.randn(n, generator=g).to(DEV)
+    r = (torch.randn(m, n, generator=g) * 2.0).bfloat16().to(DEV) if res else None
+    if fold:
+        gamma, beta = (1.0 + 0.2 * torch.randn(k, generator=g)).to(DEV), (0.1 * torch.randn(k, generator=g)).to(DEV)
+        wq, bq, colsum = runtime.fold_layer_norm(w32.to(DEV), b, gamma, beta, torch.bfloat16)
+        ln = (ops.row_stats(x, 1e-5), colsum)
+        y = ops.linear(x, wq, bq, residual=r, ln=ln, stats_eps=1e-5)
+        y_plain = ops.linear(x, wq, bq, residual=r, ln=ln)
+    else:
+        w = w32.bfloat16().to(DEV)
+        y = ops.linear(x, w, b, residual=r, stats_eps=1e-5)
+        y_plain = ops.linear(x, w, b, residual=r)
+    assert torch.equal(y, y_plain)  # the statistics do not change the product
+    carried = ops.row_stats(y, 1e-5)
+    assert carried is y._anemoi_row_stats[1]
+    want = ops.row_stats(y.clone(), 1e-5)  # the clone carries nothing: separate kernel, two-pass statistics
+    assert want is not carried
+    torch.testing.assert_close(carried, want, rtol=2e-4, atol=2e-4)
+    assert ops.row_stats(y, 1e-6) is not carried  # another epsilon: recomputed
+
+
 def test_advance_input_kernel():
     """anemoi_advance_input (in place) against the roll / index_put restatement of tests/_cpu_ops.py."""
     import _cpu_ops
