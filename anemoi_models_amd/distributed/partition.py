@@ -236,6 +236,7 @@ class ShardPlan:
     dec: LocalGraph
     dec_counts: List[int]  # rows produced by every rank
     dec_all_ids: Tensor  # concatenation of every rank's dec_dst_ids (rank order)
+    gather_pos: Optional[Tensor] = None  # per grid row: its position in the padded all-gather buffer (built on first use)
 
 
 def build_shard_plan(model, group, device) -> ShardPlan:
@@ -339,9 +340,16 @@ def sharded_forward(model, x: Tensor, group) -> Tensor:
     send[: y_local.shape[0]] = y_local
     gathered = torch.empty((sp.world, max_rows, v_out), dtype=torch.float32, device=x.device)
     _allgather_rows(gathered.view(-1, v_out), send, group)
-    rows = torch.cat([gathered[r, :c] for r, c in enumerate(sp.dec_counts)], dim=0)
-    y = torch.empty((grid, v_out), dtype=torch.float32, device=x.device)
-    y[sp.dec_all_ids] = rows
+    if sp.gather_pos is None:  # grid order <- (rank, row) order of the padded buffer: ONE gather instead of cat + scatter
+        starts = torch.tensor([r * max_rows for r in range(sp.world)], device=x.device)
+        counts = torch.tensor(sp.dec_counts, device=x.device)
+        offs = torch.cumsum(counts, 0) - counts
+        rank_of = torch.repeat_interleave(torch.arange(sp.world, device=x.device), counts)
+        pos = starts[rank_of] + torch.arange(int(counts.sum()), device=x.device) - offs[rank_of]
+        gp = torch.empty(grid, dtype=torch.long, device=x.device)
+        gp[sp.dec_all_ids] = pos
+        sp.gather_pos = gp
+    y = gathered.view(-1, v_out).index_select(0, sp.gather_pos)
     y = y.view(1, ensemble_size, grid, v_out)
 
     out_idx, in_idx = model._prognostic_indices(y.device)
