@@ -1473,7 +1473,38 @@ extern "C" int anemoi_linear_ln(int dtype, int out_dtype, const void* x, int64_t
 namespace anemoi {
 __global__ __launch_bounds__(256) void row_sums_finalize_kernel(const float2* __restrict__ partial, int slots,
                                                                 int64_t rows, int C, float eps,
-                                                                float2* __restrict__ stats) {
+                                                                float2* __restrict__ stats,
+                                                                const bf16_t* __restrict__ y, int64_t ldy,
+                                                                int64_t rows_total) {
+  const int64_t fold_blocks = (rows + 255) / 256;
+  const float inv_c = 1.0f / (float)C;
+  if ((int64_t)blockIdx.x >= fold_blocks) {
+    // one of the few rows behind the tiled part (computed by the skinny pass, no partials): this block reads the row
+    const int64_t r = rows + ((int64_t)blockIdx.x - fold_blocks);
+    if (r >= rows_total) return;
+    float s = 0.f, ss = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float v = bf16_to_f32(y[r * ldy + c]);
+      s += v;
+      ss = fmaf(v, v, ss);
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    __shared__ float red[8];
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6] = s;
+      red[4 + (threadIdx.x >> 6)] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s = red[0] + red[1] + red[2] + red[3];
+      ss = red[4] + red[5] + red[6] + red[7];
+      const float mean = s * inv_c;
+      const float rstd = rsqrtf(fmaxf(ss * inv_c - mean * mean, 0.f) + eps);
+      stats[r] = make_float2(rstd, -mean * rstd);
+    }
+    return;
+  }
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   float s = 0.f, ss = 0.f;
@@ -1482,7 +1513,6 @@ __global__ __launch_bounds__(256) void row_sums_finalize_kernel(const float2* __
     s += p.x;
     ss += p.y;
   }
-  const float inv_c = 1.0f / (float)C;
   const float mean = s * inv_c;
   const float var = fmaxf(ss * inv_c - mean * mean, 0.f);
   const float rstd = rsqrtf(var + eps);
@@ -1512,13 +1542,16 @@ extern "C" int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const 
                                  K, ANEMOI_ACT_NONE, stream);
   if (rc != ANEMOI_OK) return rc;
   if (rows_done > 0) {
-    hipLaunchKernelGGL(row_sums_finalize_kernel, dim3((unsigned)((rows_done + 255) / 256)), dim3(256), 0,
+    // rows behind the tiled part (at most 8, from the skinny pass) are folded in by extra blocks of the same launch
+    const int64_t tail = (M - rows_done <= 8 && dtype == ANEMOI_BF16) ? M - rows_done : 0;
+    hipLaunchKernelGGL(row_sums_finalize_kernel, dim3((unsigned)((rows_done + 255) / 256 + tail)), dim3(256), 0,
                        as_stream(stream), static_cast<const float2*>(workspace), slots, rows_done, N, eps,
-                       reinterpret_cast<float2*>(stats_out));
+                       reinterpret_cast<float2*>(stats_out), static_cast<const bf16_t*>(y), ldy, rows_done + tail);
     const int rl = check_launch("anemoi_linear_stats(finalize)");
     if (rl != ANEMOI_OK) return rl;
+    rows_done += tail;
   }
-  if (rows_done < M) {  // rows the fused path did not cover (skinny tail, other kernels): statistics from y itself
+  if (rows_done < M) {  // rows the fused path did not cover (other kernels): statistics from y itself
     const int esz = dtype == ANEMOI_BF16 ? 2 : 4;
     return anemoi_row_stats(dtype, static_cast<const char*>(y) + rows_done * ldy * esz, ldy, stats_out + 2 * rows_done,
                             M - rows_done, N, eps, stream);
