@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __re
 // Operand rows beyond M / N are never loaded: the staging goes through buffer descriptors sized to the tile's
 // valid rows (out-of-range lanes of buffer_load ... lds deliver zeros).
 // =============================================================================================
-constexpr int W4_LDS = 2 * BIG_STAGE + 2048;        // 130 KiB: two slab buffers + the tile's bias and LN column sums
+constexpr int W4_LDS = 2 * BIG_STAGE + 4096;        // 132 KiB: two slab buffers + the tile's bias, LN column sums, LN row statistics
 
 #define ANEMOI_MFMA_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 
@@ -736,6 +736,19 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             crs, (__attribute__((address_space(3))) void*)(smem + 2 * BIG_STAGE + 1024 + wid * 256), 4, lane * 4,
             wid * 256, 0, 0);
+        // ... and the tile's row statistics { rstd, -mean rstd } (TM x 8 bytes; rows >= M: zeros): fetched here, a whole
+        // K loop ahead, they cost the epilogue no vector-memory wait (a load issued there sits behind the next tile's
+        // slab DMAs in the in-order vmcnt queue)
+        int srows = M - m0 < TM ? (int)(M - m0) : TM;
+        srows = srows > 0 ? srows : 0;
+        const __amdgpu_buffer_rsrc_t trs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(ln.stats + m0), 0, srows * 8, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (h * 1024 + wid * 256 < TM * 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                trs, (__attribute__((address_space(3))) void*)(smem + 2 * BIG_STAGE + 2048 + h * 1024 + wid * 256), 4,
+                lane * 4, h * 1024 + wid * 256, 0, 0);
       }
       // accumulator zeroing (prologue / previous epilogue, MFMA pipe) -> first MFMA: pinned on both sides
       __builtin_amdgcn_sched_barrier(0);
@@ -794,7 +807,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       if (has_next) set_tile(tile + bpx);
       else set_null();
     }
-    slab(k + 2 < nk ? k + 2 : k + 2 - nk, k != 0 || li == bix);
+    // (with a residual, slab 0 of a later tile finds its data waited for by the epilogue's vmcnt(0); without one the
+    //  epilogue only waits for slab 0 and every slab does its own counted wait)
+    slab(k + 2 < nk ? k + 2 : k + 2 - nk, !HAS_RES || k != 0 || li == bix);
     ++k;
     if (k < nk) continue;
     k = 0;
@@ -850,14 +865,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         VecIO<float, 8>::load(reinterpret_cast<const float*>(smem + 2 * BIG_STAGE + 1024) + ncol + u * 32, sv[u]);
-      const __amdgpu_buffer_rsrc_t srs =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(ln.stats + m0), 0, rows_here * 8, 0x00020000);
-      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 #pragma unroll
-      for (int j = 0; j < MH; ++j) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(srs, fr_e * 8, (wm * (MH * 16) + j * 16) * 8, 0);
-        rst[j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-      }
+      for (int j = 0; j < MH; ++j)
+        rst[j] = *reinterpret_cast<const float2*>(smem + 2 * BIG_STAGE + 2048 + (wm * (MH * 16) + j * 16 + fr_e) * 8);
     }
     auto res_fetch = [&](auto j_tag, uint4 (&rv)[4]) {
       constexpr int j = decltype(j_tag)::value;
@@ -953,7 +963,15 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     res_fetch(std::integral_constant<int, 0>{}, rv[0]);
     res_fetch(std::integral_constant<int, 1>{}, rv[1]);
     ANEMOI_PIN();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's slabs 0 / 1 have landed (and residual rows 0, 1)
+    if constexpr (HAS_RES) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's slabs 0 / 1 have landed (and residual rows 0, 1)
+    } else {
+      // nothing of this epilogue comes from vector memory (bias, column sums and row statistics sit in LDS), so only the
+      // next tile's slab 0 has to have landed before the stores queue up behind it; slab 1 (the newest NRD DMAs of this
+      // wave) stays in flight under the epilogue and is waited for by slab 0's own counted wait, ~2 us later
+      if constexpr (MH == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    }
     ANEMOI_PIN();
     static_for_seq(
         [&](auto j_tag) {
