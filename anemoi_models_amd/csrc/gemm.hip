@@ -1531,8 +1531,22 @@ __global__ __launch_bounds__(256) void row_sums_finalize_kernel(const float2* __
     s += p.x;
     ss += p.y;
   }
-  const float mean = s * inv_c;
-  const float var = fmaxf(ss * inv_c - mean * mean, 0.f);
+  float mean = s * inv_c;
+  float var = fmaxf(ss * inv_c - mean * mean, 0.f);
+  if (var < 1e-3f * ss * inv_c) {
+    // E[y^2] - mean^2 has cancelled more than three digits (|mean| >> spread: does not happen on the residual stream,
+    // but the entry point is generic): this row is redone from y itself with the two-pass formula of anemoi_row_stats
+    const bf16_t* yr = y + r * ldy;
+    float s1 = 0.f;
+    for (int c = 0; c < C; ++c) s1 += bf16_to_f32(yr[c]);
+    mean = s1 * inv_c;
+    float s2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = bf16_to_f32(yr[c]) - mean;
+      s2 = fmaf(d, d, s2);
+    }
+    var = s2 * inv_c;
+  }
   const float rstd = rsqrtf(var + eps);
   stats[r] = make_float2(rstd, -mean * rstd);
 }

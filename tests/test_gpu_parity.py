@@ -388,6 +388,23 @@ def test_linear_with_row_statistics_of_the_result(m, n, k, res, fold):
     assert ops.row_stats(y, 1e-6) is not carried  # another epsilon: recomputed
 
 
+def test_linear_row_statistics_survive_large_row_means():
+    """Rows whose mean dwarfs their spread: sum / sum-of-squares partials cancel, the fold kernel must notice and redo
+    those rows from y (two-pass), like anemoi_row_stats."""
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    m, n, k = 2048, 512, 256
+    x = torch.randn(m, k, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=g) / k**0.5 * 0.05).bfloat16().to(DEV)
+    b = torch.full((n,), 300.0).to(DEV)  # y = 300 +- 0.05: bf16 keeps steps of 2 around 300 -> a few distinct values
+    b[::2] += 2.0
+    y = ops.linear(x, w, b, stats_eps=1e-5)
+    carried = ops.row_stats(y, 1e-5)
+    want = ops.row_stats(y.clone(), 1e-5)
+    torch.testing.assert_close(carried, want, rtol=1e-3, atol=1e-3)
+
+
 def test_advance_input_kernel():
     """anemoi_advance_input (in place) against the roll / index_put restatement of tests/_cpu_ops.py."""
     import _cpu_ops
