@@ -213,7 +213,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void assemble_nodes_kernel(const float* __restrict__ x, int B, int T_, int Ens,
                                                              int64_t G, int V, const float* __restrict__ latlons,
                                                              int n_ll, const float* __restrict__ trainable, int n_tr,
-                                                             T* __restrict__ out, int64_t ldo) {
+                                                             T* __restrict__ out, int64_t ldo,
+                                                             const float* __restrict__ in_mul,
+                                                             const float* __restrict__ in_add) {
   const int64_t total = (int64_t)B * Ens * G * ldo;
   const int tv = T_ * V;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(const float* __rest
       const int64_t b = be / Ens;
       const int t = c / V, v = c - t * V;
       val = x[((((b * T_ + t) * Ens + e) * G) + g) * V + v];
+      if (in_mul != nullptr) val = val * in_mul[v] + in_add[v];  // InputNormalizer.transform folded into the read
     } else if (c < tv + n_ll) {
       val = latlons[g * n_ll + (c - tv)];
     } else if (c < tv + n_ll + n_tr) {
@@ -325,6 +328,36 @@ __global__ __launch_bounds__(256) void advance_input_kernel(float* __restrict__ 
   }
 }
 
+// y[row, c] <- ((y[row, c] + [c prognostic] normalised x[b, T-1, ens, g, src[c]]) - out_add[c]) / out_mul[c]: prognostic
+// residual and InputNormalizer.inverse_transform in one pass over the output
+__global__ __launch_bounds__(256) void finalize_output_kernel(float* __restrict__ y, int V_out,
+                                                              const float* __restrict__ x, int B, int T_, int Ens,
+                                                              int64_t G, int V_in, const int32_t* __restrict__ src,
+                                                              const float* __restrict__ in_mul,
+                                                              const float* __restrict__ in_add,
+                                                              const float* __restrict__ out_mul,
+                                                              const float* __restrict__ out_add) {
+  const int64_t total = (int64_t)B * Ens * G * V_out;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / V_out;  // (b, ens, g)
+    const int c = (int)(idx - row * V_out);
+    float val = y[idx];
+    const int sv = src[c];
+    if (sv >= 0) {
+      const int64_t g = row % G;
+      const int64_t be = row / G;
+      const int e = (int)(be % Ens);
+      const int64_t b = be / Ens;
+      float xv = x[((((b * T_ + (T_ - 1)) * Ens + e) * G) + g) * V_in + sv];
+      if (in_mul != nullptr) xv = xv * in_mul[sv] + in_add[sv];
+      val += xv;
+    }
+    if (out_mul != nullptr) val = (val - out_add[c]) / out_mul[c];
+    y[idx] = val;
+  }
+}
+
 static inline unsigned flat_grid(int64_t total) {
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
@@ -363,8 +396,10 @@ int anemoi_row_stats(int dtype, const void* x, int64_t ldx, float* stats, int64_
 }
 
 int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
-                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo,
-                          anemoi_stream_t stream) {
+                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo, const float* in_mul,
+                          const float* in_add, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE((in_mul == nullptr) == (in_add == nullptr), ANEMOI_ERR_INVALID,
+                 "anemoi_assemble_nodes: in_mul and in_add come together");
   ANEMOI_REQUIRE(out && B > 0 && Ens > 0 && G >= 0 && T >= 0 && V >= 0 && n_ll >= 0 && n_tr >= 0, ANEMOI_ERR_INVALID,
                  "anemoi_assemble_nodes: bad argument");
   ANEMOI_REQUIRE((x != nullptr) || T * V == 0, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: x is null");
@@ -376,10 +411,10 @@ int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int6
   hipStream_t st = as_stream(stream);
   if (dtype == ANEMOI_F32)
     hipLaunchKernelGGL((assemble_nodes_kernel<float>), dim3(flat_grid(total)), dim3(256), 0, st, x, B, T, Ens, G, V,
-                       latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo);
+                       latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo, in_mul, in_add);
   else if (dtype == ANEMOI_BF16)
     hipLaunchKernelGGL((assemble_nodes_kernel<bf16_t>), dim3(flat_grid(total)), dim3(256), 0, st, x, B, T, Ens, G, V,
-                       latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo);
+                       latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo, in_mul, in_add);
   else
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_assemble_nodes: dtype %d", dtype);
   return check_launch("anemoi_assemble_nodes");
@@ -458,7 +493,21 @@ int anemoi_advance_input(float* x, int B, int T, int Ens, int64_t G, int V_in, c
   return check_launch("anemoi_advance_input");
 }
 
-int anemoi_abi_version(void) { return 5; }
+int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
+                           const int32_t* src, const float* in_mul, const float* in_add, const float* out_mul,
+                           const float* out_add, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(y && x && src && B > 0 && T > 0 && Ens > 0 && G >= 0 && V_in > 0 && V_out > 0, ANEMOI_ERR_INVALID,
+                 "anemoi_finalize_output: bad argument");
+  ANEMOI_REQUIRE((in_mul == nullptr) == (in_add == nullptr) && (out_mul == nullptr) == (out_add == nullptr),
+                 ANEMOI_ERR_INVALID, "anemoi_finalize_output: mul and add come together");
+  const int64_t total = (int64_t)B * Ens * G * V_out;
+  if (total == 0) return ANEMOI_OK;
+  hipLaunchKernelGGL(finalize_output_kernel, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), y, V_out, x, B, T,
+                     Ens, G, V_in, src, in_mul, in_add, out_mul, out_add);
+  return check_launch("anemoi_finalize_output");
+}
+
+int anemoi_abi_version(void) { return 6; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

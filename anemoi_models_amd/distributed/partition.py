@@ -300,7 +300,7 @@ def build_shard_plan(model, group, device) -> ShardPlan:
     return ShardPlan(rank, world, lo, hi, enc_src_ids, enc, proc, dec_dst_ids, dec, counts, all_ids)
 
 
-def sharded_forward(model, x: Tensor, group) -> Tensor:
+def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=None) -> Tensor:
     """Full-input / full-output forward with the mesh partitioned over ``group`` (batch size 1, as in the reference)."""
     runtime.require_inference(model)
     batch_size, _, ensemble_size, grid, _ = x.shape
@@ -322,7 +322,7 @@ def sharded_forward(model, x: Tensor, group) -> Tensor:
 
     width = model.multi_step * model.num_input_channels + na.attr_ndims[data]
     x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, 1, dtype,
-                                ld_out=ops.round_up(width, kmult))
+                                ld_out=ops.round_up(width, kmult), in_affine=input_affine)
     tr_hidden = na.trainable_tensors[hidden].trainable
     x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[own_ids], None if tr_hidden is None else tr_hidden[own_ids],
                                   1, dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
@@ -351,11 +351,4 @@ def sharded_forward(model, x: Tensor, group) -> Tensor:
         sp.gather_pos = gp
     y = gathered.view(-1, v_out).index_select(0, sp.gather_pos)
     y = y.view(1, ensemble_size, grid, v_out)
-
-    out_idx, in_idx = model._prognostic_indices(y.device)
-    ops.prognostic_residual(y, x, out_idx, in_idx)
-    if y.dtype != x.dtype:
-        y = y.to(x.dtype)
-    for bounding in model.boundings:
-        y = bounding(y)
-    return y
+    return model._finish(y, x, input_affine, output_affine)

@@ -41,6 +41,16 @@ class AnemoiModelInterface(torch.nn.Module):
     def predict_step(self, batch: torch.Tensor) -> torch.Tensor:
         """``[batch, time, grid, variables]`` (physical values, input variables) -> de-normalised prediction
         ``[batch, ensemble = 1, grid, output variables]`` (reference interface/__init__.py:97-123)."""
+        fused = self._normalizer_affines(batch)
+        if fused is not None:
+            # the only processor is an InputNormalizer: its per-variable affine maps ride on the first and the last
+            # kernel of the forward (anemoi_assemble_nodes / anemoi_finalize_output) -- two passes over the grid state
+            # and two over the prediction less, same arithmetic
+            with torch.no_grad():
+                assert len(batch.shape) == 4, (
+                    f"The input tensor has an incorrect shape: expected a 4-dimensional tensor, got {batch.shape}!")
+                x = batch[:, 0 : self.multi_step, None, ...]
+                return self.model(x, input_affine=fused[0], output_affine=fused[1])
         batch = self.pre_processors(batch, in_place=False)
         with torch.no_grad():
             assert len(batch.shape) == 4, (
@@ -48,6 +58,31 @@ class AnemoiModelInterface(torch.nn.Module):
             x = batch[:, 0 : self.multi_step, None, ...]  # dummy ensemble dimension as 3rd index
             y_hat = self(x)
         return self.post_processors(y_hat, in_place=False)
+
+    def _normalizer_affines(self, batch: torch.Tensor):
+        """``((mul_in, add_in), (mul_out, add_out))`` when pre / post-processing is exactly one ``InputNormalizer``
+        acting on the model's input / output variable lists and the model accepts them; else ``None``.
+        ``ANEMOI_AMD_FUSE_NORMALIZER=0`` turns the fusion off (A/B)."""
+        import inspect
+        import os
+
+        from ..preprocessing.normalizer import InputNormalizer
+
+        mode = os.environ.get("ANEMOI_AMD_FUSE_NORMALIZER", "1")
+        if mode == "0" or batch.dim() != 4 or not (batch.is_cuda or mode == "force"):
+            return None
+        procs = list(self.pre_processors.processors.values())
+        if len(procs) != 1 or type(procs[0]) is not InputNormalizer:
+            return None
+        if "input_affine" not in inspect.signature(self.model.forward).parameters:
+            return None
+        norm = procs[0]
+        if batch.shape[-1] != norm._input_idx.numel():  # the full-variable layout is left to the generic route
+            return None
+        if self.pre_processors.first_run:  # keep the reference's one-off NaN check of the first processed batch
+            return None
+        i_in, i_out = norm._input_idx.long(), norm._output_idx.long()
+        return ((norm._norm_mul[i_in], norm._norm_add[i_in]), (norm._norm_mul[i_out], norm._norm_add[i_out]))
 
     # ------------------------------------------------------------------ autoregressive rollout (BASELINE config 4)
     def _advance_map(self, device) -> torch.Tensor:

@@ -131,11 +131,32 @@ class AnemoiModelEncProcDec(nn.Module):
             self._idx_cache[key] = (order, runtime.inverse_permutation(order))
         return self._idx_cache[key]
 
-    def forward(self, x: Tensor, model_comm_group=None) -> Tensor:
+    def _finish(self, y: Tensor, x: Tensor, input_affine=None, output_affine=None) -> Tensor:
+        """Prognostic residual, boundings, optional de-normalisation (reference :223-233 + the interface's
+        post-processor when it is a plain InputNormalizer)."""
+        key = ("residual_src", str(y.device))
+        if key not in self._idx_cache:
+            src = torch.full((self.num_output_channels,), -1, dtype=torch.int32)
+            src[torch.as_tensor(self._internal_output_idx).long()] = torch.as_tensor(self._internal_input_idx).to(torch.int32)
+            self._idx_cache[key] = src.to(y.device)
+        fuse_out = output_affine is not None and len(self.boundings) == 0
+        ops.finalize_output(y, x, self._idx_cache[key], input_affine, output_affine if fuse_out else None)
+        if y.dtype != x.dtype:
+            y = y.to(x.dtype)
+        for bounding in self.boundings:
+            y = bounding(y)
+        if output_affine is not None and not fuse_out:  # boundings act on the normalised output: de-normalise after them
+            y = (y - output_affine[1]) / output_affine[0]
+        return y
+
+    def forward(self, x: Tensor, model_comm_group=None, *, input_affine=None, output_affine=None) -> Tensor:
+        """``input_affine`` / ``output_affine`` (keyword-only extension, ``(mul, add)`` per input / output variable): ``x``
+        is the RAW state and the result is de-normalised -- ``InputNormalizer`` folded into the first and the last
+        kernel of the forward (``AnemoiModelInterface.predict_step`` uses it); default: the reference's contract."""
         if model_comm_group is not None and model_comm_group.size() > 1:
             from ..distributed.partition import sharded_forward
 
-            return sharded_forward(self, x, model_comm_group)
+            return sharded_forward(self, x, model_comm_group, input_affine=input_affine, output_affine=output_affine)
         runtime.require_inference(self)
         batch_size, _, ensemble_size, grid, _ = x.shape
         dtype = runtime.compute_dtype(x)
@@ -146,7 +167,7 @@ class AnemoiModelEncProcDec(nn.Module):
         # [x (time-major) | sin/cos latlon | trainable | 0-pad]: written once, straight into the GEMM input layout
         width = self.multi_step * self.num_input_channels + na.attr_ndims[data]
         x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, batch_size, dtype,
-                                    ld_out=ops.round_up(width, kmult))
+                                    ld_out=ops.round_up(width, kmult), in_affine=input_affine)
         # mesh rows live in an internal Morton order (gather locality of the edge kernels); only the tiny
         # per-node attribute tables are permuted, the mesh never leaves the model
         order, inv = self._mesh_order(x.device)
@@ -165,10 +186,4 @@ class AnemoiModelEncProcDec(nn.Module):
             y = y[1]
 
         y = y.view(batch_size, ensemble_size, grid, self.num_output_channels)
-        out_idx, in_idx = self._prognostic_indices(y.device)
-        ops.prognostic_residual(y, x, out_idx, in_idx)
-        if y.dtype != x.dtype:
-            y = y.to(x.dtype)
-        for bounding in self.boundings:
-            y = bounding(y)
-        return y
+        return self._finish(y, x, input_affine, output_affine)

@@ -324,9 +324,16 @@ def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Op
 
 
 def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Tensor], batch_size: int,
-                   dtype: torch.dtype, ld_out: Optional[int] = None, ensemble: int = 1) -> Tensor:
-    """Rows ``(b, ens, g)`` of ``[x (time-major) | latlons | trainable | 0-pad]`` in ``dtype``."""
+                   dtype: torch.dtype, ld_out: Optional[int] = None, ensemble: int = 1, in_affine=None) -> Tensor:
+    """Rows ``(b, ens, g)`` of ``[x (time-major) | latlons | trainable | 0-pad]`` in ``dtype``.  ``in_affine`` =
+    ``(mul, add)`` f32 ``[V]``: ``x`` is the raw state, normalised as ``x * mul + add`` while it is read."""
     _dev(x, latlons, trainable)
+    mul = add = None
+    if in_affine is not None and x is not None:
+        mul, add = (t.contiguous().float() for t in in_affine)
+        _dev(mul, add)
+        if mul.numel() != x.shape[-1] or add.numel() != x.shape[-1]:
+            raise ValueError("assemble_nodes: in_affine needs one (mul, add) pair per input variable")
     g = latlons.shape[0]
     n_ll = latlons.shape[1]
     n_tr = 0 if trainable is None else trainable.shape[1]
@@ -343,9 +350,32 @@ def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Ten
     latlons = latlons.contiguous().float()
     trainable = None if trainable is None else trainable.contiguous().float()
     st = _lib.load().anemoi_assemble_nodes(dtype_code(dtype), _ptr(x), b, t, ens, g, v, latlons.data_ptr(), n_ll,
-                                           _ptr(trainable), n_tr, out.data_ptr(), ld, _stream())
+                                           _ptr(trainable), n_tr, out.data_ptr(), ld, _ptr(mul), _ptr(add), _stream())
     _lib.check(st, "anemoi_assemble_nodes")
     return out
+
+
+def finalize_output(y: Tensor, x: Tensor, src: Tensor, in_affine=None, out_affine=None) -> Tensor:
+    """In place on the f32 output ``y`` ``[B, Ens, G, V_out]``: prognostic residual from the last time slice of ``x``
+    (``src`` int32 ``[V_out]``: input column per output column, -1 = none; ``in_affine`` normalises a raw ``x`` on the
+    fly) and, with ``out_affine = (mul, add)``, the de-normalisation ``(y - add) / mul``."""
+    _dev(y, x, src)
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise ValueError("finalize_output: y must be contiguous float32")
+    x = x.contiguous().float()
+    b, t, ens, g, v_in = x.shape
+    if src.dtype != torch.int32 or src.numel() != y.shape[-1]:
+        raise ValueError("finalize_output: src must be int32 with one entry per output column")
+    im = ia = om = oa = None
+    if in_affine is not None:
+        im, ia = (t_.contiguous().float() for t_ in in_affine)
+    if out_affine is not None:
+        om, oa = (t_.contiguous().float() for t_ in out_affine)
+    _dev(im, ia, om, oa)
+    st = _lib.load().anemoi_finalize_output(y.data_ptr(), y.shape[-1], x.data_ptr(), b, t, ens, g, v_in, src.data_ptr(),
+                                            _ptr(im), _ptr(ia), _ptr(om), _ptr(oa), _stream())
+    _lib.check(st, "anemoi_finalize_output")
+    return y
 
 
 def advance_input(x: Tensor, y: Tensor, colmap: Tensor, forcing: Optional[Tensor] = None) -> Tensor:

@@ -157,10 +157,24 @@ int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const
  * x is f32 [B, T, Ens, G, V] contiguous; out is `dtype` with leading dimension ldo >= T*V + n_ll + n_tr.
  * Replaces einops.rearrange + NamedNodesAttributes + torch.cat, models/encoder_processor_decoder.py:173-181.
  * With x == NULL (T = 0) it produces the hidden-node attribute matrix of line :181.
+ * in_mul / in_add (both NULL or both [V] f32): x is the RAW state and `x * in_mul[v] + in_add[v]` -- the
+ * InputNormalizer's transform (preprocessing/normalizer.py:134-164) -- is applied while it is read.
  */
 int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
-                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo,
-                          anemoi_stream_t stream);
+                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo, const float* in_mul,
+                          const float* in_add, anemoi_stream_t stream);
+
+/*
+ * One pass over the f32 output [B, Ens, G, V_out] that ends AnemoiModelInterface.predict_step on a raw input state:
+ *   y[.., c] += normalised x[b, T-1, ens, g, src[c]]      where src[c] >= 0 (prognostic residual,
+ *                                                          models/encoder_processor_decoder.py:227; src int32 [V_out])
+ *   y[.., c]  = (y[.., c] - out_add[c]) / out_mul[c]       (InputNormalizer.inverse_transform,
+ *                                                          preprocessing/normalizer.py:166-205; NULL/NULL = skipped)
+ * with normalised x = x * in_mul[v] + in_add[v] (NULL/NULL: x is already normalised).
+ */
+int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
+                           const int32_t* src, const float* in_mul, const float* in_add, const float* out_mul,
+                           const float* out_add, anemoi_stream_t stream);
 
 /*
  * Prognostic residual (models/encoder_processor_decoder.py:227), in place on the f32 output:

@@ -354,6 +354,11 @@ def test_interface_predict_step_vs_golden(graph_o32, golden_interface):
     y = iface.predict_step(gold["batch"].to(DEV))
     assert y.shape == gold["y"].shape and y.dtype == torch.float32
     assert rel_err(y, gold["y"]) < 1e-4
+    # later calls: the normaliser rides on anemoi_assemble_nodes / anemoi_finalize_output (raw state in, physical out)
+    assert iface._normalizer_affines(gold["batch"].to(DEV)) is not None
+    y2 = iface.predict_step(gold["batch"].to(DEV))
+    assert rel_err(y2, gold["y"]) < 1e-4
+    assert rel_err(y2, y) < 1e-5
 
 
 @pytest.mark.parametrize("m,n,k,res,fold", [(40962, 1024, 4096, True, False), (5121, 1024, 1216, True, False),

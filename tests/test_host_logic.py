@@ -338,3 +338,23 @@ def test_imputers_match_reference(case):
     assert imp.transform(inplace) is inplace  # in place by default
     with pytest.raises(ValueError):
         imp.transform(torch.zeros(2, 7, 9))
+
+
+def test_interface_predict_step_with_the_normalizer_folded_into_the_forward(graph_o32, golden_interface, monkeypatch):
+    """Second and later predict_step calls hand the raw state and the InputNormalizer's affine maps to the model
+    (assemble_nodes / finalize_output): same result as the reference interface."""
+    _cpu_ops.install(monkeypatch)
+    monkeypatch.setenv("ANEMOI_AMD_FUSE_NORMALIZER", "force")
+    gold = golden_interface
+    iface = build_interface(graph_o32, gold)
+    iface.load_state_dict(split_prefix(gold, "sd."))
+    iface.eval()
+    assert iface._normalizer_affines(gold["batch"]) is None  # first call: generic route (one-off NaN check)
+    y0 = iface.predict_step(gold["batch"])
+    fused = iface._normalizer_affines(gold["batch"])
+    assert fused is not None and fused[0][0].numel() == 12 and fused[1][0].numel() == 11
+    y1 = iface.predict_step(gold["batch"])
+    torch.testing.assert_close(y1, gold["y"], atol=5e-4, rtol=5e-4)
+    torch.testing.assert_close(y1, y0, atol=1e-5, rtol=1e-5)
+    monkeypatch.setenv("ANEMOI_AMD_FUSE_NORMALIZER", "0")
+    assert iface._normalizer_affines(gold["batch"]) is None
