@@ -446,6 +446,59 @@ def test_interface_rollout_vs_golden(graph_o32, golden_interface):
     assert rel_err(y, gold["rollout_y"]) < 1e-3
 
 
+def test_full_size_invariants_n320_ico6_1024ch(monkeypatch):
+    """BASELINE config 3 sizes (N320 -> ico-6, 1024 channels, 542 080 grid / 40 962 mesh nodes; 2 processor blocks to
+    bound the run time), where the CPU oracle takes minutes: size-independent properties instead.
+    (1) the internal Morton relabelling of the mesh is invisible in the output; (2) the reference's own chunk
+    invariance (row-chunked mapper MLP, T/layers/block/test_block_graphtransformer.py:339-377) holds, to rounding in
+    f32; (3) bf16 agrees with the exact-f32 MFMA path; (4) two runs are bit-identical (no atomics anywhere)."""
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.models import AnemoiModelEncProcDec
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    graph = build_graph("n320_ico6")
+    idx = SimpleDataIndices(n_prognostic=80, n_forcing=10, n_diagnostic=0)
+
+    def make():
+        torch.manual_seed(1234)
+        with torch.device(DEV):
+            m = AnemoiModelEncProcDec(model_config=model_config("GraphTransformer", 1024, 2, 16), data_indices=idx,
+                                      graph_data=graph.to(DEV))
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if name.endswith("trainable"):
+                    p.normal_(0.0, 0.1)
+        return m.to(DEV).eval()
+
+    x = torch.randn((1, 2, 1, graph["data"].num_nodes, idx.num_input), generator=torch.Generator().manual_seed(7)).to(DEV)
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    model = make()
+    with torch.no_grad():
+        y = model(x)
+        assert torch.isfinite(y).all() and y.shape == (1, 1, graph["data"].num_nodes, 80)
+        assert torch.equal(model(x), y)  # (4)
+        scale = float(y.abs().max())
+        monkeypatch.setenv("ANEMOI_INFERENCE_NUM_CHUNKS", "4")  # (2) bf16: the chunked MLP takes its LayerNorm statistics
+        assert float((model(x) - y).abs().max()) <= 1e-2 * scale  # from a separate two-pass kernel -> bf16 rounding flips
+        monkeypatch.delenv("ANEMOI_INFERENCE_NUM_CHUNKS")
+        monkeypatch.setenv("ANEMOI_AMD_MESH_REORDER", "0")  # (1): a fresh model (the order is cached per model)
+        y_plain_order = make()(x)
+        monkeypatch.delenv("ANEMOI_AMD_MESH_REORDER")
+        assert float((y_plain_order - y).abs().max()) <= 3e-2 * scale  # bf16: the summation order per destination changes
+        monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32")  # (3)
+        y32 = model(x)
+        assert float((y32 - y).abs().max()) <= 3e-2 * scale
+        monkeypatch.setenv("ANEMOI_INFERENCE_NUM_CHUNKS", "4")  # (2) f32: row chunks change nothing but the launch shapes
+        assert float((model(x) - y32).abs().max()) <= 1e-5 * scale
+        monkeypatch.delenv("ANEMOI_INFERENCE_NUM_CHUNKS")
+        y32_plain = None
+        monkeypatch.setenv("ANEMOI_AMD_MESH_REORDER", "0")
+        y32_plain = make()(x)
+        monkeypatch.delenv("ANEMOI_AMD_MESH_REORDER")
+        assert float((y32_plain - y32).abs().max()) <= 2e-4 * scale  # f32: only rounding of a different summation order
+
+
 def test_forward_replayed_as_hip_graph(graph_o32, golden_cfg1_gt):
     """runtime.GraphedForward: the whole forward captured once in a HIP graph, replayed on new inputs."""
     from anemoi_models_amd.runtime import GraphedForward
