@@ -1,0 +1,274 @@
+// Dense half of the backward pass (first step): what the autograd of the fused Linear and of
+// LayerNorm needs besides the forward GEMM kernels themselves.
+//   dX = dpre W            -> anemoi_linear on (dpre, W^T)          W^T from anemoi_transpose
+//   dW = dpre^T X          -> anemoi_linear on (dpre^T, X^T), f32   both from anemoi_transpose (K = rows, zero padded)
+//   db = column sums of dpre                                         anemoi_col_sum (two deterministic stages)
+//   dpre = dy * act'(pre)                                            anemoi_act_backward
+//   LayerNorm: dx per row, d gamma / d beta as column sums           anemoi_layer_norm_backward
+// Everything here is bound by HBM bandwidth; no atomics (gradients are bit-reproducible run to run).
+#include "common.hpp"
+
+namespace anemoi {
+
+// ---------------------------------------------------------------------------------------------
+// dst[c, r] = src[r, c] for r < rows, c < cols; dst rows are ld_dst long, columns rows..ld_dst-1 are zero filled (the
+// transposed matrix becomes the K-contiguous operand of a GEMM whose reduction runs over the original rows).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst,
+                                                        int64_t ld_dst, int64_t rows, int cols) {
+  __shared__ T tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(r0 + r) * ld_src + c0 + c] : (T)0;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int c = idx >> 6, r = idx & 63;
+    if (c0 + c < cols && r0 + r < ld_dst) dst[(int64_t)(c0 + c) * ld_dst + r0 + r] = tile[r][c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums, stage kernel: block b adds up rows [b * chunk, (b + 1) * chunk) of every column -> partial[b, c] (f32).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void col_sum_stage_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                            int64_t chunk, float* __restrict__ partial) {
+  const int64_t r_begin = (int64_t)blockIdx.x * chunk;
+  const int64_t r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float s = 0.f;
+    for (int64_t r = r_begin; r < r_end; ++r) s += Elem<T>::load(x + r * ldx + c);
+    partial[(int64_t)blockIdx.x * cols + c] = s;
+  }
+}
+
+template <typename T>
+static int col_sum_launch(const T* x, int64_t ldx, int64_t rows, int cols, float* out, float* workspace,
+                          int64_t workspace_floats, hipStream_t st) {
+  // stage 1: <= 2048 blocks of whole rows; stage 2: one block over the partials
+  int64_t chunk = (rows + 2047) / 2048;
+  if (chunk < 16) chunk = 16;
+  const int64_t blocks = (rows + chunk - 1) / chunk;
+  if (blocks <= 1) {
+    hipLaunchKernelGGL((col_sum_stage_kernel<T>), dim3(1), dim3(256), 0, st, x, ldx, rows, cols, rows > 0 ? rows : 1, out);
+    return check_launch("anemoi_col_sum");
+  }
+  ANEMOI_REQUIRE(workspace != nullptr && workspace_floats >= blocks * cols, ANEMOI_ERR_INVALID,
+                 "anemoi_col_sum: workspace of %lld floats required", (long long)(blocks * cols));
+  hipLaunchKernelGGL((col_sum_stage_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, rows, cols, chunk,
+                     workspace);
+  hipLaunchKernelGGL((col_sum_stage_kernel<float>), dim3(1), dim3(256), 0, st, workspace, (int64_t)cols, blocks, cols,
+                     blocks, out);
+  return check_launch("anemoi_col_sum");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dpre = dy * act'(pre)   (pre = the Linear's output before the activation, saved by the forward)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case ANEMOI_ACT_GELU: {  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    }
+    case ANEMOI_ACT_SILU: {
+      const float s = 1.0f / (1.0f + __expf(-x));
+      return s * (1.0f + x * (1.0f - s));
+    }
+    case ANEMOI_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    default: return 1.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_backward_kernel(const T* __restrict__ pre, int64_t ldp,
+                                                           const T* __restrict__ dy, int64_t ldd, T* __restrict__ out,
+                                                           int64_t ldo, int64_t rows, int cols, int act) {
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    const float g = Elem<T>::load(dy + r * ldd + c) * act_grad(Elem<T>::load(pre + r * ldp + c), act);
+    Elem<T>::store(out + r * ldo + c, g);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward.  xhat = x rstd + shift (stats = { rstd, -mean rstd } of the forward), g = dy gamma:
+//   dx = rstd (g - mean_c(g) - xhat mean_c(g xhat));   d gamma = sum_r dy xhat;   d beta = sum_r dy
+// One wave per row for dx; each workgroup (4 waves) also keeps the column partials of its ROWS_PER_WG rows and writes
+// them to partial[wg][2][C]: the column reduction is finished by col_sum's second stage.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __restrict__ x, int64_t ldx,
+                                                                  const float2* __restrict__ stats,
+                                                                  const float* __restrict__ gamma,
+                                                                  const T* __restrict__ dy, int64_t ldd,
+                                                                  T* __restrict__ dx, int64_t ldo, int64_t rows, int C,
+                                                                  int rows_per_wg, float* __restrict__ partial) {
+  extern __shared__ float lds[];  // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* my_dg = lds + (size_t)wid * 2 * C;
+  float* my_db = my_dg + C;
+  for (int c = lane; c < C; c += 64) {
+    my_dg[c] = 0.f;
+    my_db[c] = 0.f;
+  }
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r_end = r_begin + rows_per_wg < rows ? r_begin + rows_per_wg : rows;
+  const float inv_c = 1.0f / (float)C;
+  for (int64_t r = r_begin + wid; r < r_end; r += 4) {
+    const float2 st = stats[r];
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
+      const float d = Elem<T>::load(dy + r * ldd + c);
+      const float g = d * gamma[c];
+      sg += g;
+      sgx = fmaf(g, xh, sgx);
+      my_dg[c] = fmaf(d, xh, my_dg[c]);  // lane-private column slots: no race inside the wave
+      my_db[c] += d;
+    }
+    sg = wave_sum(sg) * inv_c;
+    sgx = wave_sum(sgx) * inv_c;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
+      const float g = Elem<T>::load(dy + r * ldd + c) * gamma[c];
+      Elem<T>::store(dx + r * ldo + c, st.x * (g - sg - xh * sgx));
+    }
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256)
+    out[c] = lds[c] + lds[2 * C + c] + lds[4 * C + c] + lds[6 * C + c];
+}
+
+template <typename T>
+static int layer_norm_backward_launch(const T* x, int64_t ldx, const float2* stats, const float* gamma, const T* dy,
+                                      int64_t ldd, T* dx, int64_t ldo, int64_t rows, int C, float* dgamma, float* dbeta,
+                                      float* workspace, int64_t workspace_floats, hipStream_t st) {
+  ANEMOI_REQUIRE((size_t)C * 8 * sizeof(float) <= 160 * 1024, ANEMOI_ERR_UNSUPPORTED,
+                 "anemoi_layer_norm_backward: C = %d too wide for the LDS column partials", C);
+  int rows_per_wg = (int)((rows + 1023) / 1024);
+  if (rows_per_wg < 32) rows_per_wg = 32;
+  const int64_t wgs = (rows + rows_per_wg - 1) / rows_per_wg;
+  ANEMOI_REQUIRE(workspace != nullptr && workspace_floats >= wgs * 2 * C + 2 * C, ANEMOI_ERR_INVALID,
+                 "anemoi_layer_norm_backward: workspace of %lld floats required", (long long)(wgs * 2 * C + 2 * C));
+  const size_t lds_bytes = (size_t)C * 8 * sizeof(float);
+  auto kern = layer_norm_backward_kernel<T>;
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_bytes) != hipSuccess)
+    return fail(ANEMOI_ERR_LAUNCH, "anemoi_layer_norm_backward: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds_bytes, st, x, ldx, stats, gamma, dy, ldd, dx, ldo, rows, C,
+                     rows_per_wg, workspace);
+  // [wgs, 2C] partials -> d gamma | d beta
+  float* both = workspace + wgs * 2 * C;
+  hipLaunchKernelGGL((col_sum_stage_kernel<float>), dim3(1), dim3(256), 0, st, workspace, (int64_t)2 * C, wgs, 2 * C, wgs,
+                     both);
+  if (hipMemcpyAsync(dgamma, both, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(dbeta, both + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(ANEMOI_ERR_LAUNCH, "anemoi_layer_norm_backward: device copy failed");
+  return check_launch("anemoi_layer_norm_backward");
+}
+
+static inline hipStream_t bw_stream(anemoi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline unsigned bw_grid(int64_t total) {
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace anemoi
+
+using namespace anemoi;
+
+extern "C" {
+
+int anemoi_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
+                     anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(src && dst && rows >= 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, ANEMOI_ERR_INVALID,
+                 "anemoi_transpose: bad argument");
+  if (ld_dst == 0) return ANEMOI_OK;
+  const dim3 grid((unsigned)((ld_dst + 63) / 64), (unsigned)((cols + 63) / 64));
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, bw_stream(stream), static_cast<const float*>(src),
+                       ld_src, static_cast<float*>(dst), ld_dst, rows, cols);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, bw_stream(stream),
+                       static_cast<const bf16_t*>(src), ld_src, static_cast<bf16_t*>(dst), ld_dst, rows, cols);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose: dtype %d", dtype);
+  return check_launch("anemoi_transpose");
+}
+
+int64_t anemoi_col_sum_workspace_floats(int64_t rows, int cols) {
+  int64_t chunk = (rows + 2047) / 2048;
+  if (chunk < 16) chunk = 16;
+  const int64_t blocks = (rows + chunk - 1) / chunk;
+  return blocks <= 1 ? 0 : blocks * cols;
+}
+
+int anemoi_col_sum(int dtype, const void* x, int64_t ldx, int64_t rows, int cols, float* out, float* workspace,
+                   int64_t workspace_floats, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && out && rows >= 0 && cols > 0 && ldx >= cols, ANEMOI_ERR_INVALID, "anemoi_col_sum: bad argument");
+  if (dtype == ANEMOI_F32)
+    return col_sum_launch<float>(static_cast<const float*>(x), ldx, rows, cols, out, workspace, workspace_floats,
+                                 bw_stream(stream));
+  if (dtype == ANEMOI_BF16)
+    return col_sum_launch<bf16_t>(static_cast<const bf16_t*>(x), ldx, rows, cols, out, workspace, workspace_floats,
+                                  bw_stream(stream));
+  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_col_sum: dtype %d", dtype);
+}
+
+int anemoi_act_backward(int dtype, int act, const void* pre, int64_t ldp, const void* dy, int64_t ldd, void* out,
+                        int64_t ldo, int64_t rows, int cols, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(pre && dy && out && rows >= 0 && cols > 0 && ldp >= cols && ldd >= cols && ldo >= cols,
+                 ANEMOI_ERR_INVALID, "anemoi_act_backward: bad argument");
+  ANEMOI_REQUIRE(act >= ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_act_backward: act %d", act);
+  if (rows == 0) return ANEMOI_OK;
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((act_backward_kernel<float>), dim3(bw_grid(rows * cols)), dim3(256), 0, bw_stream(stream),
+                       static_cast<const float*>(pre), ldp, static_cast<const float*>(dy), ldd, static_cast<float*>(out),
+                       ldo, rows, cols, act);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((act_backward_kernel<bf16_t>), dim3(bw_grid(rows * cols)), dim3(256), 0, bw_stream(stream),
+                       static_cast<const bf16_t*>(pre), ldp, static_cast<const bf16_t*>(dy), ldd,
+                       static_cast<bf16_t*>(out), ldo, rows, cols, act);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_act_backward: dtype %d", dtype);
+  return check_launch("anemoi_act_backward");
+}
+
+int64_t anemoi_layer_norm_backward_workspace_floats(int64_t rows, int C) {
+  int64_t rows_per_wg = (rows + 1023) / 1024;
+  if (rows_per_wg < 32) rows_per_wg = 32;
+  const int64_t wgs = (rows + rows_per_wg - 1) / rows_per_wg;
+  return wgs * 2 * C + 2 * C;
+}
+
+int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const float* stats, const float* gamma,
+                               const void* dy, int64_t ldd, void* dx, int64_t ldo, int64_t rows, int C, float* dgamma,
+                               float* dbeta, float* workspace, int64_t workspace_floats, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && stats && gamma && dy && dx && dgamma && dbeta && rows > 0 && C > 0 && ldx >= C && ldd >= C &&
+                     ldo >= C,
+                 ANEMOI_ERR_INVALID, "anemoi_layer_norm_backward: bad argument");
+  ANEMOI_REQUIRE((uintptr_t)stats % 8 == 0, ANEMOI_ERR_INVALID, "anemoi_layer_norm_backward: stats must be 8-byte aligned");
+  if (dtype == ANEMOI_F32)
+    return layer_norm_backward_launch<float>(static_cast<const float*>(x), ldx, reinterpret_cast<const float2*>(stats),
+                                             gamma, static_cast<const float*>(dy), ldd, static_cast<float*>(dx), ldo,
+                                             rows, C, dgamma, dbeta, workspace, workspace_floats, bw_stream(stream));
+  if (dtype == ANEMOI_BF16)
+    return layer_norm_backward_launch<bf16_t>(static_cast<const bf16_t*>(x), ldx,
+                                              reinterpret_cast<const float2*>(stats), gamma,
+                                              static_cast<const bf16_t*>(dy), ldd, static_cast<bf16_t*>(dx), ldo, rows,
+                                              C, dgamma, dbeta, workspace, workspace_floats, bw_stream(stream));
+  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm_backward: dtype %d", dtype);
+}
+
+}  // extern "C"

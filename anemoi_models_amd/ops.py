@@ -435,3 +435,63 @@ def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
                                 out.data_ptr(), _ld(_rows(out)), a.shape[0], a.shape[1], _stream())
     _lib.check(st, "anemoi_add")
     return out
+
+
+# ------------------------------------------------------------------------------------------ backward pass, dense half
+def transpose(x: Tensor, ld_out: Optional[int] = None) -> Tensor:
+    """``x.T`` as a new row-major matrix ``[cols, ld_out]`` (``ld_out >= rows``, extra columns zero): the K-contiguous
+    operand of a GEMM that reduces over the rows of ``x``."""
+    _dev(x)
+    rows, cols = _rows(x).shape
+    ld = rows if ld_out is None else ld_out
+    out = torch.empty((cols, ld), dtype=x.dtype, device=x.device)
+    st = _lib.load().anemoi_transpose(dtype_code(x.dtype), x.data_ptr(), _ld(x), out.data_ptr(), ld, rows, cols, _stream())
+    _lib.check(st, "anemoi_transpose")
+    return out
+
+
+def col_sum(x: Tensor) -> Tensor:
+    """f32 column sums of a row-major matrix (bias gradient), deterministic two-stage reduction."""
+    _dev(x)
+    rows, cols = _rows(x).shape
+    lib = _lib.load()
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    n_ws = lib.anemoi_col_sum_workspace_floats(rows, cols)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
+    st = lib.anemoi_col_sum(dtype_code(x.dtype), x.data_ptr(), _ld(x), rows, cols, out.data_ptr(), ws.data_ptr(), n_ws,
+                            _stream())
+    _lib.check(st, "anemoi_col_sum")
+    return out
+
+
+def act_backward(pre: Tensor, dy: Tensor, act: str) -> Tensor:
+    """``dy * act'(pre)`` (``pre`` = the Linear's result before its activation)."""
+    _dev(pre, dy)
+    rows, cols = _rows(pre).shape
+    if tuple(_rows(dy).shape) != (rows, cols) or dy.dtype != pre.dtype:
+        raise ValueError("act_backward: pre and dy must have the same shape and dtype")
+    out = torch.empty((rows, cols), dtype=pre.dtype, device=pre.device)
+    st = _lib.load().anemoi_act_backward(dtype_code(pre.dtype), _lib.ACT_CODES[act], pre.data_ptr(), _ld(pre),
+                                         dy.data_ptr(), _ld(dy), out.data_ptr(), cols, rows, cols, _stream())
+    _lib.check(st, "anemoi_act_backward")
+    return out
+
+
+def layer_norm_backward(x: Tensor, stats: Tensor, gamma: Tensor, dy: Tensor):
+    """``(dx, dgamma, dbeta)`` of ``layer_norm(x) * gamma + beta`` from the forward's ``row_stats(x)``."""
+    _dev(x, stats, gamma, dy)
+    rows, c = _rows(x).shape
+    if tuple(_rows(dy).shape) != (rows, c) or dy.dtype != x.dtype or stats.shape != (rows, 2):
+        raise ValueError("layer_norm_backward: shapes of x, dy, stats do not match")
+    lib = _lib.load()
+    dx = torch.empty((rows, c), dtype=x.dtype, device=x.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    n_ws = lib.anemoi_layer_norm_backward_workspace_floats(rows, c)
+    ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
+    gamma = gamma.detach().float().contiguous()
+    st = lib.anemoi_layer_norm_backward(dtype_code(x.dtype), x.data_ptr(), _ld(x), stats.data_ptr(), gamma.data_ptr(),
+                                        dy.data_ptr(), _ld(dy), dx.data_ptr(), c, rows, c, dgamma.data_ptr(),
+                                        dbeta.data_ptr(), ws.data_ptr(), n_ws, _stream())
+    _lib.check(st, "anemoi_layer_norm_backward")
+    return dx, dgamma, dbeta

@@ -234,6 +234,38 @@ int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, int B, int S, int H,
                 int D, int window, anemoi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward pass, dense half (first step): the pieces the autograd of the fused Linear and of
+ * LayerNorm needs besides the forward GEMM entry points (anemoi_models_amd/autograd.py):
+ *   dX = dpre W (anemoi_linear on dpre and W^T), dW = dpre^T X (anemoi_linear on the two transposes, f32 result),
+ *   db = column sums of dpre, dpre = dy * act'(pre).  What torch.autograd derives from nn.Linear / nn.GELU / nn.SiLU /
+ *   nn.LayerNorm in layers/block.py:504-508,631-633 and layers/mlp.py:74-84 when anemoi-training calls .backward().
+ * No atomics: gradients are reproducible bit for bit.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* dst[c, r] = src[r, c]; dst has leading dimension ld_dst >= rows, its columns rows..ld_dst-1 are zero filled. */
+int anemoi_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
+                     anemoi_stream_t stream);
+
+/* out[c] = sum_r x[r, c] (f32 result, two deterministic stages; workspace: anemoi_col_sum_workspace_floats floats). */
+int64_t anemoi_col_sum_workspace_floats(int64_t rows, int cols);
+int anemoi_col_sum(int dtype, const void* x, int64_t ldx, int64_t rows, int cols, float* out, float* workspace,
+                   int64_t workspace_floats, anemoi_stream_t stream);
+
+/* out = dy * act'(pre), pre = the Linear's result before its activation (ANEMOI_ACT_*; exact erf GELU derivative). */
+int anemoi_act_backward(int dtype, int act, const void* pre, int64_t ldp, const void* dy, int64_t ldd, void* out,
+                        int64_t ldo, int64_t rows, int cols, anemoi_stream_t stream);
+
+/*
+ * LayerNorm backward from the forward's row statistics (stats [rows, 2] = { rstd, -mean * rstd }, anemoi_row_stats):
+ *   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * gamma, xhat = x * rstd - mean * rstd;
+ *   dgamma[c] = sum_r dy * xhat, dbeta[c] = sum_r dy (f32).  workspace: anemoi_layer_norm_backward_workspace_floats.
+ */
+int64_t anemoi_layer_norm_backward_workspace_floats(int64_t rows, int C);
+int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const float* stats, const float* gamma,
+                               const void* dy, int64_t ldd, void* dx, int64_t ldo, int64_t rows, int C, float* dgamma,
+                               float* dbeta, float* workspace, int64_t workspace_floats, anemoi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

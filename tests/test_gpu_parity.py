@@ -734,3 +734,103 @@ def test_all_gnn_model_vs_golden(graph_o32, golden_cfg1_gnn_all):
     with torch.no_grad():
         out = model(gold["x"].to(DEV))
     assert rel_err(out, gold["y"]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- backward, dense half
+@pytest.mark.parametrize("dtype,m,k,n,act,bias,res", [
+    (torch.float32, 300, 192, 256, "GELU", True, True), (torch.float32, 1500, 128, 96, "SiLU", False, False),
+    (torch.float32, 257, 100, 64, "Identity", True, True), (torch.bfloat16, 2048, 256, 512, "GELU", True, True),
+    (torch.bfloat16, 4100, 1024, 256, "Identity", True, False),
+])
+def test_linear_backward_matches_torch_autograd(dtype, m, k, n, act, bias, res):
+    """autograd.linear: dX, dW, db, dresidual from the HIP GEMM / transpose / column-sum / act' kernels against torch's
+    autograd of the same expression in f64 on the CPU (what the reference's nn.Linear + activation differentiate to)."""
+    from anemoi_models_amd import autograd
+
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) / k**0.5)
+    b = torch.randn(n, generator=g) if bias else None
+    r = torch.randn(m, n, generator=g).to(dtype) if res else None
+    dy = torch.randn(m, n, generator=g).to(dtype)
+    # reference: f64 autograd on the (rounded) inputs
+    xr, wr = x.double().requires_grad_(), w.to(dtype).double().requires_grad_()
+    br = None if b is None else b.double().requires_grad_()
+    rr = None if r is None else r.double().requires_grad_()
+    pre = torch.nn.functional.linear(xr, wr, br)
+    yr = {"Identity": lambda t: t, "GELU": torch.nn.functional.gelu, "SiLU": torch.nn.functional.silu}[act](pre)
+    if rr is not None:
+        yr = yr + rr
+    yr.backward(dy.double())
+    xd = x.to(DEV).requires_grad_()
+    wd = w.to(DEV).requires_grad_()
+    bd = None if b is None else b.to(DEV).requires_grad_()
+    rd = None if r is None else r.to(DEV).requires_grad_()
+    y = autograd.linear(xd, wd, bd, act, rd)
+    y.backward(dy.to(DEV))
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(y.detach(), yr.detach().float()) < tol
+    assert rel_err(xd.grad, xr.grad.float()) < tol
+    assert wd.grad.dtype == torch.float32 and rel_err(wd.grad, wr.grad.float()) < tol
+    if bias:
+        assert rel_err(bd.grad, br.grad.float()) < tol
+    if res:
+        assert torch.equal(rd.grad.cpu(), dy)
+
+
+@pytest.mark.parametrize("dtype,rows,c", [(torch.float32, 1000, 256), (torch.float32, 77, 100),
+                                          (torch.bfloat16, 5000, 1024)])
+def test_layer_norm_backward_matches_torch_autograd(dtype, rows, c):
+    from anemoi_models_amd import autograd
+
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, c, generator=g) * 2.0 + 0.5).to(dtype)
+    gamma, beta = 1.0 + 0.3 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    dy = torch.randn(rows, c, generator=g).to(dtype)
+    xr, gr, br = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (c,), gr, br, 1e-5).backward(dy.double())
+    xd, gd, bd = x.to(DEV).requires_grad_(), gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    y = autograd.layer_norm(xd, gd, bd, 1e-5)
+    y.backward(dy.to(DEV))
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(xd.grad, xr.grad.float()) < tol
+    assert rel_err(gd.grad, gr.grad.float()) < tol
+    assert rel_err(bd.grad, br.grad.float()) < tol
+    y2 = autograd.layer_norm(xd, gd, bd, 1e-5)  # bit-reproducible gradients (no atomics)
+    g1 = gd.grad.clone()
+    gd.grad = None
+    y2.backward(dy.to(DEV))
+    assert torch.equal(gd.grad, g1)
+
+
+def test_node_mlp_training_step_matches_torch():
+    """y + Linear(GELU(Linear(LayerNorm(y)))) (the node MLP of a block, reference layers/block.py:504-508, 631-633):
+    forward + backward composed from autograd.layer_norm / autograd.linear against torch autograd in f64."""
+    from anemoi_models_amd import autograd
+
+    g = torch.Generator().manual_seed(9)
+    m, c = 1537, 256
+    y = torch.randn(m, c, generator=g)
+    p = {"g": 1 + 0.1 * torch.randn(c, generator=g), "b": 0.1 * torch.randn(c, generator=g),
+         "w1": torch.randn(4 * c, c, generator=g) / c**0.5, "b1": 0.1 * torch.randn(4 * c, generator=g),
+         "w2": torch.randn(c, 4 * c, generator=g) / (4 * c)**0.5, "b2": 0.1 * torch.randn(c, generator=g)}
+    dz = torch.randn(m, c, generator=g)
+
+    def run(t, dev, lin, ln):
+        yy = y.to(dev, t).requires_grad_()
+        pp = {k: v.to(dev, torch.float64 if t == torch.float64 else torch.float32).requires_grad_() for k, v in p.items()}
+        h = ln(yy, pp["g"], pp["b"])
+        z = lin(lin(h, pp["w1"], pp["b1"], "GELU", None), pp["w2"], pp["b2"], "Identity", yy)
+        z.backward(dz.to(dev, t))
+        return z.detach(), yy.grad, {k: v.grad for k, v in pp.items()}
+
+    def ref_lin(x, w, b, act, res):
+        o = torch.nn.functional.linear(x, w, b)
+        o = torch.nn.functional.gelu(o) if act == "GELU" else o
+        return o if res is None else o + res
+
+    zr, gyr, gpr = run(torch.float64, "cpu", ref_lin, lambda x, g_, b_: torch.nn.functional.layer_norm(x, (c,), g_, b_, 1e-5))
+    z, gy, gp = run(torch.float32, DEV, autograd.linear, lambda x, g_, b_: autograd.layer_norm(x, g_, b_, 1e-5))
+    assert rel_err(z, zr.float()) < 1e-4 and rel_err(gy, gyr.float()) < 1e-4
+    for k in p:
+        assert rel_err(gp[k], gpr[k].float()) < 2e-4, k
