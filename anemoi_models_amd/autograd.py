@@ -118,3 +118,90 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tensor:
     """``LayerNorm(x) * gamma + beta`` over the last dimension with gradients for ``x``, ``gamma``, ``beta``."""
     return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------ edge phase
+def _transposed_csr(plan):
+    """(rowptr_t, eid_t, dst_t) of the source-major view of a destination-sorted plan, cached on the plan."""
+    cached = getattr(plan, "_transposed", None)
+    if cached is None:
+        col = plan.col.long()
+        counts = (plan.rowptr[1:] - plan.rowptr[:-1]).long()
+        dst_of_edge = torch.repeat_interleave(torch.arange(plan.n_dst, device=col.device), counts)
+        order = torch.argsort(col, stable=True)
+        rowptr_t = torch.zeros(plan.n_src + 1, dtype=torch.int64, device=col.device)
+        torch.cumsum(torch.bincount(col, minlength=plan.n_src), 0, out=rowptr_t[1:])
+        cached = (rowptr_t.to(torch.int32), order.to(torch.int32).contiguous(),
+                  dst_of_edge[order].to(torch.int32).contiguous(), dst_of_edge)
+        plan._transposed = cached
+    return cached
+
+
+class _GTEdgeAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, x_r, u, edge_attr, plan, num_heads: int, up: int):
+        out = ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, plan.rowptr, plan.col, num_heads, up)
+        ctx.save_for_backward(q, k, v, x_r, u, edge_attr, out)
+        ctx.plan, ctx.h, ctx.up = plan, num_heads, up
+        return out
+
+    @staticmethod
+    def backward(ctx, dfull):
+        from . import _lib
+
+        q, k, v, x_r, u, edge_attr, out = ctx.saved_tensors
+        plan, h, up = ctx.plan, ctx.h, ctx.up
+        n_dst, c = q.shape
+        d = c // h
+        dtype = q.dtype
+        dfull = dfull.contiguous()
+        dout = dfull[:, :c]
+        dt = dfull[:, c:c + h * up].float().contiguous()
+        o_att = out[:, :c].float() - (0.0 if x_r is None else x_r.float())
+        dsum = ((dout.float() * o_att).view(n_dst, h, d).sum(-1)
+                + (dt * out[:, c:c + h * up].float()).view(n_dst, h, up).sum(-1)).contiguous()
+        u32 = u.float().contiguous()
+        n_edges = plan.col.shape[0]
+        dev = q.device
+        if n_edges == 0:  # no edges: out = x_r, t = 0 -- only x_r receives a gradient
+            return (torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v),
+                    None if x_r is None else dout.contiguous(), torch.zeros_like(u), torch.zeros_like(edge_attr), None,
+                    None, None)
+        alpha = torch.empty((max(n_edges, 1), h), dtype=torch.float32, device=dev)
+        ds = torch.empty((max(n_edges, 1), h), dtype=torch.float32, device=dev)
+        dq = torch.empty((n_dst, c), dtype=dtype, device=dev)
+        du = torch.empty((n_dst, h * up), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        code = ops.dtype_code(dtype)
+        stream = ops._stream()
+        kk, vv = ops._rows(k), ops._rows(v)
+        st = lib.anemoi_gt_edge_attention_folded_backward_dst(
+            code, q.data_ptr(), ops._ld(ops._rows(q)), kk.data_ptr(), vv.data_ptr(), ops._ld(kk), dout.data_ptr(),
+            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), dsum.data_ptr(), edge_attr.data_ptr(), up,
+            plan.rowptr.data_ptr(), plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(), dq.data_ptr(), c, du.data_ptr(),
+            n_dst, c, h, stream)
+        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
+        rowptr_t, eid_t, dst_t, dst_of_edge = _transposed_csr(plan)
+        n_src = k.shape[0]
+        dk = torch.empty((n_src, c), dtype=dtype, device=dev)
+        dv = torch.empty((n_src, c), dtype=dtype, device=dev)
+        st = lib.anemoi_gt_edge_attention_folded_backward_src(
+            code, q.data_ptr(), ops._ld(ops._rows(q)), dout.data_ptr(), ops._ld(ops._rows(dout)), alpha.data_ptr(),
+            ds.data_ptr(), rowptr_t.data_ptr(), eid_t.data_ptr(), dst_t.data_ptr(), dk.data_ptr(), dv.data_ptr(), c, n_src,
+            c, h, stream)
+        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_src")
+        dattr = None
+        if ctx.needs_input_grad[5] and n_edges > 0:
+            scale = 1.0 / d**0.5
+            ue = u32.view(n_dst, h, up)[dst_of_edge]  # [E, H, up]
+            dte = dt.view(n_dst, h, up)[dst_of_edge]
+            dattr = (scale * ds[:n_edges, :, None] * ue + alpha[:n_edges, :, None] * dte).sum(1)
+        dxr = None if x_r is None else dout.contiguous()
+        return dq, dk, dv, dxr, du.to(u.dtype), dattr, None, None, None
+
+
+def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor, plan,
+                      num_heads: int, up: int) -> Tensor:
+    """Differentiable ``ops.gt_edge_attention_folded``: ``[n_dst, C + H*up] = [sum alpha v (+ x_r) | sum alpha a]`` with
+    gradients for ``q, k, v, x_r, u`` (compute dtype) and ``edge_attr`` (f32 ``[E, up]``, CSR order of ``plan``)."""
+    return _GTEdgeAttention.apply(q, k, v, x_r, u, edge_attr, plan, num_heads, up)

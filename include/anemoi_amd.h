@@ -266,6 +266,28 @@ int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const floa
                                const void* dy, int64_t ldd, void* dx, int64_t ldo, int64_t rows, int C, float* dgamma,
                                float* dbeta, float* workspace, int64_t workspace_floats, anemoi_stream_t stream);
 
+/*
+ * Backward of anemoi_gt_edge_attention_folded (the edge half of SURVEY.md section 8f-1; what torch.autograd derives from
+ * GraphTransformerConv.message / softmax / aggregate, layers/conv.py:98-142, plus lin_edge through the fold).
+ * With s_e = scale (q_i.k_j + u_i.a_e), alpha = softmax over the in-edges of i, out_i = sum alpha v_j (+ x_r),
+ * t_i = sum alpha a_e, and the caller-formed dsum[i, h] = dout_i,h.(out_i,h - x_r) + dt_i,h.t_i,h:
+ *   _dst  (forward CSR):     alpha[E, H], ds[E, H] = alpha (dout_i.v_j + dt_i.a_e - dsum) (f32),
+ *                            dq_i = scale sum_e ds k_j,  du_i = scale sum_e ds a_e (f32 [n_dst, H*up])
+ *   _src  (transposed CSR):  dk_j = scale sum_{e from j} ds q_i,  dv_j = sum_{e from j} alpha dout_i
+ * (rowptr_t [n_src+1], eid_t [E] = position of the edge in the forward CSR, dst_t [E] = its destination).  The gradient
+ * of the edge attributes follows from alpha, ds, u and dt per edge and is formed by the caller.  No atomics.
+ */
+int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                                                 int64_t ldkv, const void* dout, int64_t ldd, const float* u,
+                                                 const float* dt, const float* dsum, const float* edge_attr, int up,
+                                                 const int32_t* rowptr, const int32_t* col, float* alpha, float* ds,
+                                                 void* dq, int64_t lddq, float* du, int64_t n_dst, int C, int H,
+                                                 anemoi_stream_t stream);
+int anemoi_gt_edge_attention_folded_backward_src(int dtype, const void* q, int64_t ldq, const void* dout, int64_t ldd,
+                                                 const float* alpha, const float* ds, const int32_t* rowptr_t,
+                                                 const int32_t* eid_t, const int32_t* dst_t, void* dk, void* dv,
+                                                 int64_t ldg, int64_t n_src, int C, int H, anemoi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

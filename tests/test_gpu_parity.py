@@ -834,3 +834,49 @@ def test_node_mlp_training_step_matches_torch():
     assert rel_err(z, zr.float()) < 1e-4 and rel_err(gy, gyr.float()) < 1e-4
     for k in p:
         assert rel_err(gp[k], gpr[k].float()) < 2e-4, k
+
+
+@pytest.mark.parametrize("dtype,n_src,n_dst,e,c,h", [
+    (torch.float32, 90, 70, 500, 64, 4), (torch.float32, 300, 300, 2500, 128, 16), (torch.float32, 50, 400, 1200, 256, 4),
+    (torch.bfloat16, 200, 200, 1800, 1024, 16), (torch.float32, 40, 40, 0, 64, 4),
+])
+def test_gt_edge_attention_backward_matches_torch_autograd(dtype, n_src, n_dst, e, c, h):
+    """autograd.gt_edge_attention (folded edge phase): dq, dk, dv, dx_r, du, d edge_attr from the two backward kernels
+    (destination-major + source-major, no atomics) against torch autograd in f64 of the same expression: per-edge scores
+    with the PyG softmax of oracle/pyg_semantics.py (+1e-16), isolated and high in-degree destinations included."""
+    from anemoi_models_amd import autograd, runtime
+
+    g = torch.Generator().manual_seed(n_src + e)
+    up, d = 12, c // h
+    ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, max(n_dst - 1, 1), (e,), generator=g)])
+    if e > 50:
+        ei[1, :45] = 3  # one destination with in-degree >= 45; the last destination stays isolated
+    plan = runtime.build_edge_plan(ei.to(DEV), n_src, n_dst)
+    q, k, v, xr = (torch.randn(n, c, generator=g).to(dtype) for n in (n_dst, n_src, n_src, n_dst))
+    u = (0.3 * torch.randn(n_dst, h * up, generator=g)).to(dtype)
+    attr = torch.randn(e, up, generator=g)  # already in the plan's CSR order
+    dfull = torch.randn(n_dst, c + h * up, generator=g).to(dtype)
+
+    # ---- f64 reference on the CPU
+    col, rowptr = plan.col.long().cpu(), plan.rowptr.long().cpu()
+    dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
+    r = {n_: t.double().requires_grad_() for n_, t in dict(q=q, k=k, v=v, xr=xr, u=u, a=attr).items()}
+    s = ((r["q"].view(n_dst, h, d)[dst] * r["k"].view(n_src, h, d)[col]).sum(-1)
+         + (r["u"].view(n_dst, h, up)[dst] * r["a"][:, None, :]).sum(-1)) / d**0.5  # [E, H]
+    m = torch.full((n_dst, h), -float("inf"), dtype=torch.float64).scatter_reduce(0, dst[:, None].expand(-1, h), s.detach(),
+                                                                                  "amax", include_self=True)
+    m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+    ex = torch.exp(s - m[dst])
+    alpha = ex / (torch.zeros(n_dst, h, dtype=torch.float64).index_add(0, dst, ex) + 1e-16)[dst]
+    out = torch.zeros(n_dst, h, d, dtype=torch.float64).index_add(0, dst, alpha[:, :, None] * r["v"].view(n_src, h, d)[col])
+    tt = torch.zeros(n_dst, h, up, dtype=torch.float64).index_add(0, dst, alpha[:, :, None] * r["a"][:, None, :])
+    full = torch.cat([out.reshape(n_dst, c) + r["xr"], tt.reshape(n_dst, h * up)], dim=1)
+    full.backward(dfull.double())
+
+    dev = {n_: t.to(DEV).requires_grad_() for n_, t in dict(q=q, k=k, v=v, xr=xr, u=u, a=attr).items()}
+    got = autograd.gt_edge_attention(dev["q"], dev["k"], dev["v"], dev["xr"], dev["u"], dev["a"], plan, h, up)
+    got.backward(dfull.to(DEV))
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    assert rel_err(got.detach(), full.detach().float()) < tol
+    for name in ("q", "k", "v", "xr", "u") + (("a",) if e > 0 else ()):
+        assert rel_err(dev[name].grad, r[name].grad.float()) < tol, name
