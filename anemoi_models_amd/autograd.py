@@ -205,3 +205,34 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
     """Differentiable ``ops.gt_edge_attention_folded``: ``[n_dst, C + H*up] = [sum alpha v (+ x_r) | sum alpha a]`` with
     gradients for ``q, k, v, x_r, u`` (compute dtype) and ``edge_attr`` (f32 ``[E, up]``, CSR order of ``plan``)."""
     return _GTEdgeAttention.apply(q, k, v, x_r, u, edge_attr, plan, num_heads, up)
+
+
+# ------------------------------------------------------------------------------------------ a whole processor block
+def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, plan, num_heads: int,
+                       act: str = "GELU", eps: float = 1e-5) -> Tensor:
+    """Differentiable ``GraphTransformerProcessorBlock`` (reference layers/block.py:602-635) on the HIP kernels:
+    ``sd[prefix + ".lin_query.weight"]`` etc. are the block's f32 parameters (``requires_grad`` as wanted),
+    ``edge_attr_csr`` ``[E, up]`` f32 the edge attributes in the plan's CSR order with the constant-1 column behind the
+    ``edge_dim`` real ones (``ops.edge_attr_csr``).  ``lin_edge`` is folded into the q GEMM and the projection exactly
+    as in the inference path; the fold itself is ordinary torch algebra on the parameters, so autograd carries the
+    gradients back to ``lin_edge`` / ``lin_query`` / ``projection``."""
+    g = lambda name: sd[prefix + "." + name]  # noqa: E731
+    c = x.shape[1]
+    h, up = num_heads, edge_attr_csr.shape[1]
+    d = c // h
+    edge_dim = g("lin_edge.weight").shape[1]
+    weh = torch.zeros((c, up), dtype=torch.float32, device=x.device)
+    weh = torch.cat([g("lin_edge.weight"), g("lin_edge.bias")[:, None], weh[:, edge_dim + 1:]], dim=1).view(h, d, up)
+    w_u = torch.einsum("hda,hdc->hac", weh, g("lin_query.weight").view(h, d, c)).reshape(h * up, c)
+    b_u = torch.einsum("hda,hd->ha", weh, g("lin_query.bias").view(h, d)).reshape(h * up)
+    w_in = torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight"), w_u], 0)
+    b_in = torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias"), b_u], 0)
+    xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
+    sq = linear(xh, w_in, b_in)  # x_r | q | k | v | u
+    att = gt_edge_attention(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
+                            edge_attr_csr, plan, h, up)
+    w_t = torch.einsum("ohd,hda->oha", g("projection.weight").view(c, h, d), weh).reshape(c, h * up)
+    y = linear(att, torch.cat([g("projection.weight"), w_t], dim=1), g("projection.bias"), "Identity", x)
+    h1 = layer_norm(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
+    h2 = linear(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), act)
+    return linear(h2, g("node_dst_mlp.3.weight"), g("node_dst_mlp.3.bias"), "Identity", y)

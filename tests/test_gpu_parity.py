@@ -880,3 +880,43 @@ def test_gt_edge_attention_backward_matches_torch_autograd(dtype, n_src, n_dst, 
     assert rel_err(got.detach(), full.detach().float()) < tol
     for name in ("q", "k", "v", "xr", "u") + (("a",) if e > 0 else ()):
         assert rel_err(dev[name].grad, r[name].grad.float()) < tol, name
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 8e-2)])
+def test_gt_processor_block_training_step_vs_oracle_autograd(golden_blocks, dtype, tol):
+    """Forward + backward of a whole GraphTransformerProcessorBlock on the HIP kernels (autograd.gt_processor_block)
+    against torch autograd through the oracle's restatement of the reference block (oracle.gt_processor_block,
+    reference layers/block.py:602-635) on the golden block's weights and graph: d x and the gradient of every
+    parameter, lin_edge included (it reaches the kernels only through the fold)."""
+    from anemoi_models_amd import autograd, ops, runtime
+
+    gb = golden_blocks
+    sd = {k: v for k, v in split_prefix(gb, "gtp.sd.").items()}
+    x, ea, ei = gb["gtp.x"], gb["gtp.edge_attr"], gb["gtp.edge_index"]
+    n, c = x.shape
+    heads = 16
+    gen = torch.Generator().manual_seed(4)
+    dz = torch.randn(n, c, generator=gen)
+    # ---- oracle + torch autograd (CPU, f64)
+    rsd = {"blk." + k: v.double().requires_grad_() for k, v in sd.items()}
+    xr = x.double().requires_grad_()
+    ref.gt_processor_block(rsd, "blk", xr, ea.double(), ei, heads).backward(dz.double())
+    # ---- HIP
+    plan = runtime.build_edge_plan(ei.to(DEV), n, n)
+    up = ops.round_up(ea.shape[1] + 1, 4)
+    attr = torch.zeros(ei.shape[1], up)
+    attr[:, : ea.shape[1]] = ea[plan.perm.long().cpu()]
+    attr[:, ea.shape[1]] = 1.0
+    dsd = {"blk." + k: v.to(DEV).requires_grad_() for k, v in sd.items()}
+    xd = x.to(DEV, dtype).requires_grad_()
+    z = autograd.gt_processor_block(xd, dsd, "blk", attr.to(DEV), plan, heads)
+    z.backward(dz.to(DEV, dtype))
+    assert rel_err(xd.grad, xr.grad.float()) < tol
+    scale_all = max(float(rsd["blk." + k].grad.abs().max()) for k in sd)
+    for k in sd:
+        got, want = dsd["blk." + k].grad, rsd["blk." + k].grad.float()
+        assert got is not None, k
+        # relative to the gradient's own scale, with an absolute floor: d lin_key.bias is exactly zero (a constant added
+        # to every key shifts all scores of a destination alike), what is left there is rounding noise
+        err = float((got.cpu() - want).abs().max())
+        assert err <= tol * max(float(want.abs().max()), 0.05 * scale_all), (k, err, float(want.abs().max()))
