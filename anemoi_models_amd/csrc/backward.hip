@@ -37,32 +37,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 template <typename T>
 __global__ __launch_bounds__(256) void col_sum_stage_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int cols,
                                                             int64_t chunk, float* __restrict__ partial) {
+  // grid = (row chunks, column blocks of 256): a thread owns one column of one chunk, a wave reads 64 adjacent columns
   const int64_t r_begin = (int64_t)blockIdx.x * chunk;
   const int64_t r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
-  for (int c = threadIdx.x; c < cols; c += 256) {
-    float s = 0.f;
-    for (int64_t r = r_begin; r < r_end; ++r) s += Elem<T>::load(x + r * ldx + c);
-    partial[(int64_t)blockIdx.x * cols + c] = s;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains: the loads of a column pipeline
+  int64_t r = r_begin;
+  for (; r + 3 < r_end; r += 4) {
+    s0 += Elem<T>::load(x + r * ldx + c);
+    s1 += Elem<T>::load(x + (r + 1) * ldx + c);
+    s2 += Elem<T>::load(x + (r + 2) * ldx + c);
+    s3 += Elem<T>::load(x + (r + 3) * ldx + c);
   }
+  for (; r < r_end; ++r) s0 += Elem<T>::load(x + r * ldx + c);
+  partial[(int64_t)blockIdx.x * cols + c] = (s0 + s1) + (s2 + s3);
 }
 
 template <typename T>
 static int col_sum_launch(const T* x, int64_t ldx, int64_t rows, int cols, float* out, float* workspace,
                           int64_t workspace_floats, hipStream_t st) {
-  // stage 1: <= 2048 blocks of whole rows; stage 2: one block over the partials
-  int64_t chunk = (rows + 2047) / 2048;
+  // stage 1: <= 512 chunks of whole rows x column blocks; stage 2: the chunks' partials, again per column block
+  int64_t chunk = (rows + 511) / 512;
   if (chunk < 16) chunk = 16;
   const int64_t blocks = (rows + chunk - 1) / chunk;
+  const unsigned cblocks = (unsigned)((cols + 255) / 256);
   if (blocks <= 1) {
-    hipLaunchKernelGGL((col_sum_stage_kernel<T>), dim3(1), dim3(256), 0, st, x, ldx, rows, cols, rows > 0 ? rows : 1, out);
+    hipLaunchKernelGGL((col_sum_stage_kernel<T>), dim3(1, cblocks), dim3(256), 0, st, x, ldx, rows, cols,
+                       rows > 0 ? rows : 1, out);
     return check_launch("anemoi_col_sum");
   }
   ANEMOI_REQUIRE(workspace != nullptr && workspace_floats >= blocks * cols, ANEMOI_ERR_INVALID,
                  "anemoi_col_sum: workspace of %lld floats required", (long long)(blocks * cols));
-  hipLaunchKernelGGL((col_sum_stage_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, rows, cols, chunk,
-                     workspace);
-  hipLaunchKernelGGL((col_sum_stage_kernel<float>), dim3(1), dim3(256), 0, st, workspace, (int64_t)cols, blocks, cols,
-                     blocks, out);
+  hipLaunchKernelGGL((col_sum_stage_kernel<T>), dim3((unsigned)blocks, cblocks), dim3(256), 0, st, x, ldx, rows, cols,
+                     chunk, workspace);
+  hipLaunchKernelGGL((col_sum_stage_kernel<float>), dim3(1, cblocks), dim3(256), 0, st, workspace, (int64_t)cols, blocks,
+                     cols, blocks, out);
   return check_launch("anemoi_col_sum");
 }
 
@@ -169,8 +179,8 @@ static int layer_norm_backward_launch(const T* x, int64_t ldx, const float2* sta
                      rows_per_wg, workspace);
   // [wgs, 2C] partials -> d gamma | d beta
   float* both = workspace + wgs * 2 * C;
-  hipLaunchKernelGGL((col_sum_stage_kernel<float>), dim3(1), dim3(256), 0, st, workspace, (int64_t)2 * C, wgs, 2 * C, wgs,
-                     both);
+  hipLaunchKernelGGL((col_sum_stage_kernel<float>), dim3(1, (unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, workspace,
+                     (int64_t)2 * C, wgs, 2 * C, wgs, both);
   if (hipMemcpyAsync(dgamma, both, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
       hipMemcpyAsync(dbeta, both + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(ANEMOI_ERR_LAUNCH, "anemoi_layer_norm_backward: device copy failed");
@@ -208,7 +218,7 @@ int anemoi_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int6
 }
 
 int64_t anemoi_col_sum_workspace_floats(int64_t rows, int cols) {
-  int64_t chunk = (rows + 2047) / 2048;
+  int64_t chunk = (rows + 511) / 512;
   if (chunk < 16) chunk = 16;
   const int64_t blocks = (rows + chunk - 1) / chunk;
   return blocks <= 1 ? 0 : blocks * cols;
