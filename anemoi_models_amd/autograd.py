@@ -208,6 +208,28 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
 
 
 # ------------------------------------------------------------------------------------------ a whole processor block
+def _lin_edge_fold(sd: dict, prefix: str, c: int, h: int, up: int, device):
+    """(W_u [H*up, C], b_u [H*up], W_t [C, H*up]) of the lin_edge fold, differentiable w.r.t. lin_edge / lin_query /
+    projection (see layers/block.py::_query_fold, _projection_fold of this package)."""
+    g = lambda name: sd[prefix + "." + name]  # noqa: E731
+    d = c // h
+    edge_dim = g("lin_edge.weight").shape[1]
+    pad = torch.zeros((c, up - edge_dim - 1), dtype=torch.float32, device=device)
+    weh = torch.cat([g("lin_edge.weight"), g("lin_edge.bias")[:, None], pad], dim=1).view(h, d, up)
+    w_u = torch.einsum("hda,hdc->hac", weh, g("lin_query.weight").view(h, d, c)).reshape(h * up, c)
+    b_u = torch.einsum("hda,hd->ha", weh, g("lin_query.bias").view(h, d)).reshape(h * up)
+    w_t = torch.einsum("ohd,hda->oha", g("projection.weight").view(c, h, d), weh).reshape(c, h * up)
+    return w_u, b_u, w_t
+
+
+def _gt_tail(y_att: Tensor, x_skip: Tensor, sd: dict, prefix: str, w_t: Tensor, act: str, eps: float) -> Tensor:
+    g = lambda name: sd[prefix + "." + name]  # noqa: E731
+    y = linear(y_att, torch.cat([g("projection.weight"), w_t], dim=1), g("projection.bias"), "Identity", x_skip)
+    h1 = layer_norm(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
+    h2 = linear(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), act)
+    return linear(h2, g("node_dst_mlp.3.weight"), g("node_dst_mlp.3.bias"), "Identity", y)
+
+
 def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, plan, num_heads: int,
                        act: str = "GELU", eps: float = 1e-5) -> Tensor:
     """Differentiable ``GraphTransformerProcessorBlock`` (reference layers/block.py:602-635) on the HIP kernels:
@@ -219,20 +241,30 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
     c = x.shape[1]
     h, up = num_heads, edge_attr_csr.shape[1]
-    d = c // h
-    edge_dim = g("lin_edge.weight").shape[1]
-    weh = torch.zeros((c, up), dtype=torch.float32, device=x.device)
-    weh = torch.cat([g("lin_edge.weight"), g("lin_edge.bias")[:, None], weh[:, edge_dim + 1:]], dim=1).view(h, d, up)
-    w_u = torch.einsum("hda,hdc->hac", weh, g("lin_query.weight").view(h, d, c)).reshape(h * up, c)
-    b_u = torch.einsum("hda,hd->ha", weh, g("lin_query.bias").view(h, d)).reshape(h * up)
+    w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x.device)
     w_in = torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight"), w_u], 0)
     b_in = torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias"), b_u], 0)
     xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
     sq = linear(xh, w_in, b_in)  # x_r | q | k | v | u
     att = gt_edge_attention(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
                             edge_attr_csr, plan, h, up)
-    w_t = torch.einsum("ohd,hda->oha", g("projection.weight").view(c, h, d), weh).reshape(c, h * up)
-    y = linear(att, torch.cat([g("projection.weight"), w_t], dim=1), g("projection.bias"), "Identity", x)
-    h1 = layer_norm(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
-    h2 = linear(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), act)
-    return linear(h2, g("node_dst_mlp.3.weight"), g("node_dst_mlp.3.bias"), "Identity", y)
+    return _gt_tail(att, x, sd, prefix, w_t, act, eps)
+
+
+def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, plan, num_heads: int,
+                    act: str = "GELU", eps: float = 1e-5) -> Tensor:
+    """Differentiable ``GraphTransformerMapperBlock`` (reference layers/block.py:479-550, ``update_src_nodes=False``):
+    keys / values from ``LayerNorm1(x_src)``, queries / self term from ``LayerNorm2(x_dst)``, the new destination nodes
+    are returned; same kernels and fold as :func:`gt_processor_block`."""
+    g = lambda name: sd[prefix + "." + name]  # noqa: E731
+    c = x_dst.shape[1]
+    h, up = num_heads, edge_attr_csr.shape[1]
+    w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x_dst.device)
+    xs = layer_norm(x_src, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
+    xd = layer_norm(x_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), eps)
+    kv = linear(xs, torch.cat([g("lin_key.weight"), g("lin_value.weight")], 0),
+                torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0))
+    sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
+                torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))  # x_r | q | u
+    att = gt_edge_attention(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan, h, up)
+    return _gt_tail(att, x_dst, sd, prefix, w_t, act, eps)

@@ -920,3 +920,37 @@ def test_gt_processor_block_training_step_vs_oracle_autograd(golden_blocks, dtyp
         # to every key shifts all scores of a destination alike), what is left there is rounding noise
         err = float((got.cpu() - want).abs().max())
         assert err <= tol * max(float(want.abs().max()), 0.05 * scale_all), (k, err, float(want.abs().max()))
+
+
+def test_gt_mapper_block_training_step_vs_oracle_autograd(golden_blocks):
+    """autograd.gt_mapper_block (n_src != n_dst, isolated and high in-degree destinations of the golden mapper block)
+    against torch autograd through oracle.gt_mapper_block (reference layers/block.py:479-550): d x_src, d x_dst and every
+    parameter gradient, f32."""
+    from anemoi_models_amd import autograd, ops, runtime
+
+    gb = golden_blocks
+    sd = {k: v for k, v in split_prefix(gb, "gtm.sd.").items()}
+    xs, xd, ea, ei = gb["gtm.x_src"], gb["gtm.x_dst"], gb["gtm.edge_attr"], gb["gtm.edge_index"]
+    heads = 16
+    gen = torch.Generator().manual_seed(6)
+    dz = torch.randn(xd.shape, generator=gen)
+    rsd = {"blk." + k: v.double().requires_grad_() for k, v in sd.items() if v.is_floating_point()}
+    xsr, xdr = xs.double().requires_grad_(), xd.double().requires_grad_()
+    ref.gt_mapper_block(rsd, "blk", xsr, xdr, ea.double(), ei, heads).backward(dz.double())
+    plan = runtime.build_edge_plan(ei.to(DEV), xs.shape[0], xd.shape[0])
+    up = ops.round_up(ea.shape[1] + 1, 4)
+    attr = torch.zeros(ei.shape[1], up)
+    attr[:, : ea.shape[1]] = ea[plan.perm.long().cpu()]
+    attr[:, ea.shape[1]] = 1.0
+    dsd = {"blk." + k: v.to(DEV).requires_grad_() for k, v in sd.items() if v.is_floating_point()}
+    xsd, xdd = xs.to(DEV).requires_grad_(), xd.to(DEV).requires_grad_()
+    autograd.gt_mapper_block(xsd, xdd, dsd, "blk", attr.to(DEV), plan, heads).backward(dz.to(DEV))
+    tol = 2e-3
+    assert rel_err(xsd.grad, xsr.grad.float()) < tol and rel_err(xdd.grad, xdr.grad.float()) < tol
+    used = [k for k in rsd if rsd[k].grad is not None]
+    scale_all = max(float(rsd[k].grad.abs().max()) for k in used)
+    assert len(used) >= 20
+    for k in used:
+        assert dsd[k].grad is not None, k
+        err = float((dsd[k].grad.cpu() - rsd[k].grad.float()).abs().max())
+        assert err <= tol * max(float(rsd[k].grad.abs().max()), 0.05 * scale_all), (k, err)
