@@ -268,3 +268,64 @@ def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_at
                 torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))  # x_r | q | u
     att = gt_edge_attention(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan, h, up)
     return _gt_tail(att, x_dst, sd, prefix, w_t, act, eps)
+
+
+# ------------------------------------------------------------------------------------------ the whole flat model
+def _edge_attr_csr(edge_attr_buf: Tensor, trainable: Optional[Tensor], plan, up: int) -> Tensor:
+    """``[edge_attr | trainable | 1 | 0-pad]`` f32 in the plan's CSR order (what ``anemoi_edge_attr_csr`` builds in the
+    inference path), as torch ops: differentiable w.r.t. the trainable edge tensor."""
+    parts = [edge_attr_buf.float()] + ([] if trainable is None else [trainable.float()])
+    attr = torch.cat(parts, dim=1)[plan.perm.long()]
+    e, dim = attr.shape
+    tail = torch.zeros((e, up - dim), dtype=torch.float32, device=attr.device)
+    tail[:, 0] = 1.0
+    return torch.cat([attr, tail], dim=1).contiguous()
+
+
+def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layers: int, num_chunks: int,
+                  prognostic_in, prognostic_out, dtype: torch.dtype = torch.float32, act: str = "GELU",
+                  data: str = "data", hidden: str = "hidden") -> Tensor:
+    """Differentiable forward of the flat GraphTransformer ``AnemoiModelEncProcDec`` (reference
+    models/encoder_processor_decoder.py:168-233; batch size 1, no boundings) for TRAINING on the HIP kernels.
+
+    ``sd``: the model's ``state_dict`` as f32 tensors on the device (``requires_grad`` where gradients are wanted, the
+    trainable node / edge tensors included); ``graph``: ``{enc,proc,dec}_edge_index`` (int64 ``[2, E]``) and
+    ``{enc,proc,dec}_edge_attr`` (f32 ``[E, k]``) as in ``oracle.reference_path.model_forward``.  Heavy ops are the
+    autograd Functions above; concatenations / index maps are torch glue."""
+    from . import runtime
+
+    b, t, ens, g_, v = x.shape
+    if b != 1:
+        raise NotImplementedError("autograd.model_forward: batch size 1")
+
+    def node_attrs(name):
+        parts = [sd[f"node_attributes.latlons_{name}"]]
+        tr = sd.get(f"node_attributes.trainable_tensors.{name}.trainable")
+        return torch.cat(parts + ([] if tr is None else [tr]), dim=1)
+
+    x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(ens * g_, t * v), node_attrs(data).repeat(ens, 1)], dim=1).to(dtype)
+    x_hidden = node_attrs(hidden).to(dtype)
+    n_data, n_hidden = x_data.shape[0], x_hidden.shape[0]
+    up = ops.round_up(graph["proc_edge_attr"].shape[1] + sd["processor.trainable.trainable"].shape[1] + 1, 4)
+    plans = {k: runtime.build_edge_plan(graph[f"{k}_edge_index"].to(x.device), ns, nd)
+             for k, (ns, nd) in dict(enc=(n_data, n_hidden), proc=(n_hidden, n_hidden), dec=(n_hidden, n_data)).items()}
+    attrs = {k: _edge_attr_csr(graph[f"{k}_edge_attr"].to(x.device), sd.get(f"{m}.trainable.trainable"), plans[k], up)
+             for k, m in dict(enc="encoder", proc="processor", dec="decoder").items()}
+
+    xs = linear(x_data, sd["encoder.emb_nodes_src.weight"], sd["encoder.emb_nodes_src.bias"])
+    xd = linear(x_hidden, sd["encoder.emb_nodes_dst.weight"], sd["encoder.emb_nodes_dst.bias"])
+    x_latent = gt_mapper_block(xs, xd, sd, "encoder.proc", attrs["enc"], plans["enc"], num_heads, act)
+    x_proc = x_latent
+    per_chunk = num_layers // num_chunks
+    for ci in range(num_chunks):
+        for bi in range(per_chunk):
+            x_proc = gt_processor_block(x_proc, sd, f"processor.proc.{ci}.blocks.{bi}", attrs["proc"], plans["proc"],
+                                        num_heads, act)
+    x_latent_proc = x_proc + x_latent
+    xg = linear(x_data, sd["decoder.emb_nodes_dst.weight"], sd["decoder.emb_nodes_dst.bias"])
+    out = gt_mapper_block(x_latent_proc, xg, sd, "decoder.proc", attrs["dec"], plans["dec"], num_heads, act)
+    out = layer_norm(out, sd["decoder.node_data_extractor.0.weight"], sd["decoder.node_data_extractor.0.bias"])
+    out = linear(out, sd["decoder.node_data_extractor.1.weight"], sd["decoder.node_data_extractor.1.bias"])
+    y = out.float().reshape(1, ens, g_, -1).clone()
+    y[..., list(prognostic_out)] = y[..., list(prognostic_out)] + x[:, -1, :, :, list(prognostic_in)]
+    return y
