@@ -149,6 +149,34 @@ class AnemoiModelEncProcDec(nn.Module):
             y = (y - output_affine[1]) / output_affine[0]
         return y
 
+    def _training_forward(self, x: Tensor, input_affine=None, output_affine=None) -> Tensor:
+        """Forward WITH an autograd graph (anemoi-training calls ``.backward()`` on a loss of the result): the flat
+        GraphTransformer model through ``autograd.model_forward`` -- every heavy op and its backward on the HIP kernels
+        (SURVEY §8f-1).  Single device, batch size 1, GraphTransformer mappers and processor, no boundings; everything else
+        still raises."""
+        from .. import autograd
+        from ..layers.mapper import GraphTransformerBackwardMapper
+        from ..layers.mapper import GraphTransformerForwardMapper
+        from ..layers.processor import GraphTransformerProcessor
+
+        if (input_affine is not None or output_affine is not None or len(self.boundings) > 0 or x.shape[0] != 1
+                or not isinstance(self.encoder, GraphTransformerForwardMapper)
+                or not isinstance(self.decoder, GraphTransformerBackwardMapper)
+                or not isinstance(self.processor, GraphTransformerProcessor)):
+            runtime.require_inference(self)  # raises with the forward-only message
+        sd = dict(self.named_parameters())
+        sd.update({k: v for k, v in self.named_buffers()})
+        graph = {"enc_edge_index": self.encoder.edge_index_base, "enc_edge_attr": self.encoder.edge_attr,
+                 "proc_edge_index": self.processor.edge_index_base, "proc_edge_attr": self.processor.edge_attr,
+                 "dec_edge_index": self.decoder.edge_index_base, "dec_edge_attr": self.decoder.edge_attr}
+        blocks = self.processor.proc
+        return autograd.model_forward(
+            sd, graph, x, num_heads=self.processor.proc[0].blocks[0].num_heads,
+            num_layers=sum(len(chunk.blocks) for chunk in blocks), num_chunks=len(blocks),
+            prognostic_in=[int(i) for i in self._internal_input_idx], prognostic_out=[int(i) for i in self._internal_output_idx],
+            dtype=runtime.compute_dtype(x), act=self.processor.proc[0].blocks[0].activation,
+            data=self._graph_name_data, hidden=self._graph_name_hidden)
+
     def forward(self, x: Tensor, model_comm_group=None, *, input_affine=None, output_affine=None) -> Tensor:
         """``input_affine`` / ``output_affine`` (keyword-only extension, ``(mul, add)`` per input / output variable): ``x``
         is the RAW state and the result is de-normalised -- ``InputNormalizer`` folded into the first and the last
@@ -157,6 +185,8 @@ class AnemoiModelEncProcDec(nn.Module):
             from ..distributed.partition import sharded_forward
 
             return sharded_forward(self, x, model_comm_group, input_affine=input_affine, output_affine=output_affine)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._training_forward(x, input_affine, output_affine)
         runtime.require_inference(self)
         batch_size, _, ensemble_size, grid, _ = x.shape
         dtype = runtime.compute_dtype(x)

@@ -39,11 +39,13 @@ def compute_dtype(x: Tensor) -> torch.dtype:
 
 
 def require_inference(*modules: torch.nn.Module) -> None:
-    """The HIP path is forward-only in this release: refuse to run where autograd would need a backward."""
+    """Refuse to run where autograd would need a backward that does not exist: only the flat GraphTransformer model has a
+    differentiable route (``autograd.model_forward``, single device, batch size 1)."""
     if torch.is_grad_enabled() and any(p.requires_grad for m in modules for p in m.parameters()):
         raise NotImplementedError(
-            "anemoi_models_amd: the MI355X kernels implement the forward pass only; run under torch.no_grad() / "
-            "torch.inference_mode() (backward is listed as the next step in DESIGN.md)"
+            "anemoi_models_amd: this model / call has no backward on the MI355X kernels (only the flat GraphTransformer "
+            "model, single device, batch size 1, has: autograd.model_forward); run under torch.no_grad() / "
+            "torch.inference_mode()"
         )
 
 

@@ -985,3 +985,18 @@ def test_whole_model_training_step_vs_oracle_autograd(golden_cfg1_gt, graph_o32)
         assert dsd[k].grad is not None, k
         err = float((dsd[k].grad.cpu() - rsd[k].grad.float()).abs().max())
         assert err <= 5e-3 * max(float(rsd[k].grad.abs().max()), 0.02 * scale_all), (k, err, float(rsd[k].grad.abs().max()))
+    # the nn.Module takes the same route when autograd is on: identical gradients (every kernel is deterministic)
+    model, _ = _build(graph_o32, 64, 4)
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    ym = model(x.to(DEV))
+    assert ym.requires_grad and torch.equal(ym.detach(), y.detach())
+    ym.backward(dy.to(DEV))
+    grads = dict(model.named_parameters())
+    for k in used:
+        if k in grads:  # (buffers such as the sin / cos coordinates have no .grad on the module)
+            assert torch.equal(grads[k].grad, dsd[k].grad), k
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)  # and a plain optimiser step runs on them
+    opt.step()
+    with torch.no_grad():
+        assert float((model(x.to(DEV)) - ym.detach()).abs().max()) > 0

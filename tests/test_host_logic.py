@@ -69,11 +69,21 @@ def test_expand_edges_bit_exact(golden_index_ops):
     assert torch.equal(runtime.expand_edges(z["expand.edge_index"], inc, 3), z["expand.out"])
 
 
-def test_forward_requires_no_grad(graph_o32, monkeypatch):
+def test_forward_with_gradients_enabled(graph_o32, golden_cfg1_gt, monkeypatch):
+    """With autograd on, the flat GraphTransformer model takes the differentiable route (autograd.model_forward: same
+    result as the inference route, an autograd graph behind it); model families without a backward still refuse."""
     _cpu_ops.install(monkeypatch)
     model = build_model(graph_o32)
+    model.load_state_dict(split_prefix(golden_cfg1_gt, "sd."))
+    y = model(golden_cfg1_gt["x"])
+    assert y.requires_grad and y.grad_fn is not None
+    torch.testing.assert_close(y.detach(), golden_cfg1_gt["y"], atol=5e-4, rtol=5e-4)
+    with torch.no_grad():
+        torch.testing.assert_close(model(golden_cfg1_gt["x"]), y.detach(), atol=1e-4, rtol=1e-4)
     with pytest.raises(NotImplementedError):
-        model(torch.zeros(1, 2, 1, graph_o32["data"].num_nodes, 12))
+        build_model(graph_o32, "GNN")(torch.zeros(1, 2, 1, graph_o32["data"].num_nodes, 12))
+    with pytest.raises(NotImplementedError):
+        model(golden_cfg1_gt["x"].repeat(2, 1, 1, 1, 1))  # batch > 1 has no differentiable route yet
 
 
 def test_kernels_refuse_cpu_tensors():
