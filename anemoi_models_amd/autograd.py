@@ -84,9 +84,7 @@ class _Linear(torch.autograd.Function):
                 dx = ops.convert_pad(dx, dtype, ctx.x_cols)
         if ctx.needs_input_grad[1]:
             # dW [N, K] = dpre^T [N, M] @ X [M, K]: a Linear with x' = dpre^T, weight' = X^T, reduction over the M rows
-            mp = ops.round_up(dpre.shape[0], kmul)
-            xt = ops.transpose(xk[:, :k] if xk.shape[1] != k else xk, ld_out=mp)
-            dw = ops.linear(ops.transpose(dpre, ld_out=mp), xt, out_dtype=torch.float32).to(weight.dtype)
+            dw = ops.weight_grad(dpre, xk, k).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_sum(dpre)
         if ctx.has_res and ctx.needs_input_grad[4]:

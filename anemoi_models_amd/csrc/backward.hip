@@ -16,8 +16,12 @@ namespace anemoi {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst,
-                                                        int64_t ld_dst, int64_t rows, int cols) {
+                                                        int64_t ld_dst, int64_t rows, int cols, int64_t chunk) {
   __shared__ T tile[64][65];
+  // chunked form (grid.z = chunk s): rows [s * chunk, (s + 1) * chunk) of src become the slab dst[s] = [cols, ld_dst]
+  src += (int64_t)blockIdx.z * chunk * ld_src;
+  dst += (int64_t)blockIdx.z * cols * ld_dst;
+  rows = rows - (int64_t)blockIdx.z * chunk < chunk ? rows - (int64_t)blockIdx.z * chunk : chunk;
   const int64_t r0 = (int64_t)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
   for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
@@ -208,13 +212,31 @@ int anemoi_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int6
   const dim3 grid((unsigned)((ld_dst + 63) / 64), (unsigned)((cols + 63) / 64));
   if (dtype == ANEMOI_F32)
     hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, bw_stream(stream), static_cast<const float*>(src),
-                       ld_src, static_cast<float*>(dst), ld_dst, rows, cols);
+                       ld_src, static_cast<float*>(dst), ld_dst, rows, cols, rows);
   else if (dtype == ANEMOI_BF16)
     hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, bw_stream(stream),
-                       static_cast<const bf16_t*>(src), ld_src, static_cast<bf16_t*>(dst), ld_dst, rows, cols);
+                       static_cast<const bf16_t*>(src), ld_src, static_cast<bf16_t*>(dst), ld_dst, rows, cols, rows);
   else
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose: dtype %d", dtype);
   return check_launch("anemoi_transpose");
+}
+
+int anemoi_transpose_chunked(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
+                             int64_t chunk_rows, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(src && dst && rows > 0 && cols > 0 && chunk_rows > 0 && ld_src >= cols && ld_dst >= chunk_rows,
+                 ANEMOI_ERR_INVALID, "anemoi_transpose_chunked: bad argument");
+  const int64_t chunks = (rows + chunk_rows - 1) / chunk_rows;
+  ANEMOI_REQUIRE(chunks < 65536, ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose_chunked: too many chunks");
+  const dim3 grid((unsigned)((ld_dst + 63) / 64), (unsigned)((cols + 63) / 64), (unsigned)chunks);
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, bw_stream(stream), static_cast<const float*>(src),
+                       ld_src, static_cast<float*>(dst), ld_dst, rows, cols, chunk_rows);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, bw_stream(stream),
+                       static_cast<const bf16_t*>(src), ld_src, static_cast<bf16_t*>(dst), ld_dst, rows, cols, chunk_rows);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose_chunked: dtype %d", dtype);
+  return check_launch("anemoi_transpose_chunked");
 }
 
 int64_t anemoi_col_sum_workspace_floats(int64_t rows, int cols) {

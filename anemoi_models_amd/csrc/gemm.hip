@@ -104,8 +104,12 @@ template <typename T, typename TO>
 __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W,
                                                      const float* __restrict__ bias, const T* __restrict__ R,
                                                      int64_t ldr, TO* __restrict__ Y, int64_t ldy, int64_t M, int N,
-                                                     int K, int act, int vec_ok, LnFold ln) {
+                                                     int K, int act, int vec_ok, LnFold ln, int64_t batch_sx,
+                                                     int64_t batch_sw, int64_t batch_sy) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // 2 stages x (x tile + W tile) = 64 KiB
+  X += (int64_t)blockIdx.y * batch_sx;  // batched launch (anemoi_linear_batched): independent problems along grid.y
+  W += (int64_t)blockIdx.y * batch_sw;
+  Y += (int64_t)blockIdx.y * batch_sy;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nt_count = (N + BN - 1) / BN;
@@ -1176,7 +1180,7 @@ __global__ __launch_bounds__(512) void linear_bf16_256x4_kernel(const bf16_t* __
 template <typename T, typename TO>
 static int linear_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                          int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st,
-                         LnFold ln);
+                         LnFold ln, int batch = 1, int64_t sx = 0, int64_t sw = 0, int64_t sy = 0);
 
 constexpr int W4_NEEDS_WHOLE_TILES = -4242;  // internal: the caller has to split the ragged rows off itself
 // Returns through *tail_done whether the up to 8 rows behind M (m_tail) were computed by the same launch.
@@ -1385,7 +1389,7 @@ __global__ __launch_bounds__(256) void linear_bf16_skinny_kernel(const bf16_t* _
 template <typename T, typename TO>
 static int linear_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                          int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st,
-                         LnFold ln) {
+                         LnFold ln, int batch, int64_t sx, int64_t sw, int64_t sy) {
   const int64_t mt = (M + BM - 1) / BM;
   const int64_t nt = (N + BN - 1) / BN;
   ANEMOI_REQUIRE(mt * nt < (int64_t)1 << 31, ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: grid too large");
@@ -1393,9 +1397,9 @@ static int linear_launch(const void* x, int64_t ldx, const void* w, const float*
                       (bias == nullptr || (uintptr_t)bias % 16 == 0) &&
                       (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0) &&
                       (residual == nullptr || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0));
-  hipLaunchKernelGGL((linear_kernel<T, TO>), dim3((unsigned)(mt * nt)), dim3(256), 0, st, static_cast<const T*>(x),
-                     ldx, static_cast<const T*>(w), bias, static_cast<const T*>(residual), ldr, static_cast<TO*>(y),
-                     ldy, M, N, K, act, vec_ok ? 1 : 0, ln);
+  hipLaunchKernelGGL((linear_kernel<T, TO>), dim3((unsigned)(mt * nt), (unsigned)batch), dim3(256), 0, st,
+                     static_cast<const T*>(x), ldx, static_cast<const T*>(w), bias, static_cast<const T*>(residual), ldr,
+                     static_cast<TO*>(y), ldy, M, N, K, act, vec_ok ? 1 : 0, ln, sx, sw, sy);
   return check_launch("anemoi_linear");
 }
 
@@ -1589,4 +1593,36 @@ extern "C" int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const 
                             M - rows_done, N, eps, stream);
   }
   return ANEMOI_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// `batch` independent products y[b] = x[b] w[b]^T (no bias / activation) on the 128 x 128 kernel, problems along grid.y.
+// The weight-gradient GEMMs use it as a deterministic split of their long reduction (anemoi_models_amd/autograd.py):
+// dW = sum_b dpre[b]^T X[b] over row chunks b, so that a small [N, K] result still fills the chip.
+// ---------------------------------------------------------------------------------------------
+extern "C" int anemoi_linear_batched(int dtype, int out_dtype, const void* x, int64_t ldx, int64_t stride_x,
+                                     const void* w, int64_t stride_w, void* y, int64_t ldy, int64_t stride_y, int batch,
+                                     int64_t M, int N, int K, anemoi_stream_t stream) {
+  using namespace anemoi;
+  ANEMOI_REQUIRE(x && w && y && batch > 0 && batch < 65536 && M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N,
+                 ANEMOI_ERR_INVALID, "anemoi_linear_batched: bad argument");
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4;
+  ANEMOI_REQUIRE(((int64_t)K * esz) % ROW_BYTES == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
+                     (ldx * esz) % 16 == 0 && (stride_x * esz) % 16 == 0 && (stride_w * esz) % 16 == 0,
+                 ANEMOI_ERR_INVALID, "anemoi_linear_batched: K must be a multiple of %d elements, operands 16-byte aligned",
+                 ROW_BYTES / esz);
+  if (M == 0) return ANEMOI_OK;
+  hipStream_t st = as_stream(stream);
+  const LnFold none{nullptr, nullptr, nullptr, 0, nullptr};
+  if (dtype == ANEMOI_F32 && out_dtype == ANEMOI_F32)
+    return linear_launch<float, float>(x, ldx, w, nullptr, nullptr, 0, y, ldy, M, N, K, ANEMOI_ACT_NONE, st, none, batch,
+                                       stride_x, stride_w, stride_y);
+  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_F32)
+    return linear_launch<bf16_t, float>(x, ldx, w, nullptr, nullptr, 0, y, ldy, M, N, K, ANEMOI_ACT_NONE, st, none, batch,
+                                        stride_x, stride_w, stride_y);
+  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16)
+    return linear_launch<bf16_t, bf16_t>(x, ldx, w, nullptr, nullptr, 0, y, ldy, M, N, K, ANEMOI_ACT_NONE, st, none,
+                                         batch, stride_x, stride_w, stride_y);
+  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_batched: dtype %d -> %d", dtype, out_dtype);
 }

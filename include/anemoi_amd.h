@@ -247,6 +247,18 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
 int anemoi_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
                      anemoi_stream_t stream);
 
+/* Chunked form: rows [s * chunk_rows, (s + 1) * chunk_rows) of src become slab s of dst = [chunks, cols, ld_dst]
+ * (ld_dst >= chunk_rows, zero filled behind the chunk's rows). */
+int anemoi_transpose_chunked(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
+                             int64_t chunk_rows, anemoi_stream_t stream);
+
+/* `batch` independent products y[b] = x[b] w[b]^T (strides in elements; no bias / activation): the weight-gradient GEMMs
+ * split their long reduction over the rows into `batch` chunks this way and add the partial [N, K] results with
+ * anemoi_col_sum -- deterministic, and a small result still fills the chip. */
+int anemoi_linear_batched(int dtype, int out_dtype, const void* x, int64_t ldx, int64_t stride_x, const void* w,
+                          int64_t stride_w, void* y, int64_t ldy, int64_t stride_y, int batch, int64_t M, int N, int K,
+                          anemoi_stream_t stream);
+
 /* out[c] = sum_r x[r, c] (f32 result, two deterministic stages; workspace: anemoi_col_sum_workspace_floats floats). */
 int64_t anemoi_col_sum_workspace_floats(int64_t rows, int cols);
 int anemoi_col_sum(int dtype, const void* x, int64_t ldx, int64_t rows, int cols, float* out, float* workspace,

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""One training step (forward, loss, backward) of the flat GraphTransformer model on the HIP kernels through its nn.Module
+(autograd.model_forward) at a bench workload:   python tools/train_step_bench.py [cfg1|cfg2|cfg3] [steps]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+os.environ.setdefault("ANEMOI_AMD_DTYPE", "bf16")
+dev = torch.device("cuda", 0)
+model, graph, x, _ = bench.build(workload, dev)
+model.train()
+target = torch.zeros((1, 1, graph["data"].num_nodes, 80), device=dev)
+
+
+def step():
+    y = model(x)
+    loss = ((y - target) ** 2).mean()
+    loss.backward()
+    for p in model.parameters():
+        p.grad = None
+    return float(loss)
+
+
+step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    loss = step()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / steps * 1e3
+layers = bench.WORKLOADS[workload][2]
+print(f"{workload}: forward + backward {ms:.1f} ms / step = {graph['hidden'].num_nodes * layers / ms * 1e3:.3e} mesh-node updates/s "
+      f"(loss {loss:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)", flush=True)
