@@ -17,21 +17,47 @@ namespace anemoi {
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst,
                                                         int64_t ld_dst, int64_t rows, int cols, int64_t chunk) {
-  __shared__ T tile[64][65];
+  // 64 x 64 element tile; global reads and writes are 16 bytes per lane wherever alignment and bounds allow (a wave
+  // covers 8 rows x 64 columns of 2-byte elements per access), the LDS tile is padded against bank conflicts
+  constexpr int V = 16 / sizeof(T);  // elements per 16-byte access: 8 (bf16) or 4 (f32)
+  __shared__ T tile[64][64 + V + 1];
   // chunked form (grid.z = chunk s): rows [s * chunk, (s + 1) * chunk) of src become the slab dst[s] = [cols, ld_dst]
   src += (int64_t)blockIdx.z * chunk * ld_src;
   dst += (int64_t)blockIdx.z * cols * ld_dst;
   rows = rows - (int64_t)blockIdx.z * chunk < chunk ? rows - (int64_t)blockIdx.z * chunk : chunk;
   const int64_t r0 = (int64_t)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
-  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(r0 + r) * ld_src + c0 + c] : (T)0;
+  const bool vec_in = ((uintptr_t)src % 16 == 0) && (ld_src % V == 0) && c0 + 64 <= cols;
+  const bool vec_out = ((uintptr_t)dst % 16 == 0) && (ld_dst % V == 0) && r0 + 64 <= ld_dst;
+  constexpr int PER_ROW = 64 / V;  // 16-byte pieces per tile row
+  for (int idx = threadIdx.x; idx < 64 * PER_ROW; idx += 256) {
+    const int r = idx / PER_ROW, cp = (idx % PER_ROW) * V;
+    if (vec_in && r0 + r < rows) {
+      T v[V];
+      *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(src + (r0 + r) * ld_src + c0 + cp);
+#pragma unroll
+      for (int i = 0; i < V; ++i) tile[r][cp + i] = v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        tile[r][cp + i] = (r0 + r < rows && c0 + cp + i < cols) ? src[(r0 + r) * ld_src + c0 + cp + i] : (T)0;
+    }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-    const int c = idx >> 6, r = idx & 63;
-    if (c0 + c < cols && r0 + r < ld_dst) dst[(int64_t)(c0 + c) * ld_dst + r0 + r] = tile[r][c];
+  for (int idx = threadIdx.x; idx < 64 * PER_ROW; idx += 256) {
+    const int c = idx / PER_ROW, rp = (idx % PER_ROW) * V;  // output row = source column c, V source rows per piece
+    if (c0 + c >= cols) continue;
+    T v[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = tile[rp + i][c];
+    T* out = dst + (int64_t)(c0 + c) * ld_dst + r0 + rp;
+    if (vec_out) {
+      *reinterpret_cast<uint4*>(out) = *reinterpret_cast<const uint4*>(v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        if (r0 + rp + i < ld_dst) out[i] = v[i];
+    }
   }
 }
 
@@ -118,7 +144,7 @@ __global__ __launch_bounds__(256) void act_backward_kernel(const T* __restrict__
 // One wave per row for dx; each workgroup (4 waves) also keeps the column partials of its ROWS_PER_WG rows and writes
 // them to partial[wg][2][C]: the column reduction is finished by col_sum's second stage.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NC>  // NC > 0: the lane's C / 64 <= NC column partials live in registers (NC = 0: in LDS)
 __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __restrict__ x, int64_t ldx,
                                                                   const float2* __restrict__ stats,
                                                                   const float* __restrict__ gamma,
@@ -129,9 +155,15 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float* my_dg = lds + (size_t)wid * 2 * C;
   float* my_db = my_dg + C;
-  for (int c = lane; c < C; c += 64) {
-    my_dg[c] = 0.f;
-    my_db[c] = 0.f;
+  constexpr int NR = NC > 0 ? NC : 1;
+  float rdg[NR], rdb[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) rdg[i] = rdb[i] = 0.f;
+  if constexpr (NC == 0) {
+    for (int c = lane; c < C; c += 64) {
+      my_dg[c] = 0.f;
+      my_db[c] = 0.f;
+    }
   }
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r_end = r_begin + rows_per_wg < rows ? r_begin + rows_per_wg : rows;
@@ -139,14 +171,30 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
   for (int64_t r = r_begin + wid; r < r_end; r += 4) {
     const float2 st = stats[r];
     float sg = 0.f, sgx = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
-      const float d = Elem<T>::load(dy + r * ldd + c);
-      const float g = d * gamma[c];
-      sg += g;
-      sgx = fmaf(g, xh, sgx);
-      my_dg[c] = fmaf(d, xh, my_dg[c]);  // lane-private column slots: no race inside the wave
-      my_db[c] += d;
+    if constexpr (NC > 0) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+          const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
+          const float d = Elem<T>::load(dy + r * ldd + c);
+          const float g = d * gamma[c];
+          sg += g;
+          sgx = fmaf(g, xh, sgx);
+          rdg[i] = fmaf(d, xh, rdg[i]);
+          rdb[i] += d;
+        }
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
+        const float d = Elem<T>::load(dy + r * ldd + c);
+        const float g = d * gamma[c];
+        sg += g;
+        sgx = fmaf(g, xh, sgx);
+        my_dg[c] = fmaf(d, xh, my_dg[c]);  // lane-private column slots: no race inside the wave
+        my_db[c] += d;
+      }
     }
     sg = wave_sum(sg) * inv_c;
     sgx = wave_sum(sgx) * inv_c;
@@ -154,6 +202,16 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
       const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
       const float g = Elem<T>::load(dy + r * ldd + c) * gamma[c];
       Elem<T>::store(dx + r * ldo + c, st.x * (g - sg - xh * sgx));
+    }
+  }
+  if constexpr (NC > 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        my_dg[c] = rdg[i];
+        my_db[c] = rdb[i];
+      }
     }
   }
   __syncthreads();
@@ -174,13 +232,22 @@ static int layer_norm_backward_launch(const T* x, int64_t ldx, const float2* sta
   ANEMOI_REQUIRE(workspace != nullptr && workspace_floats >= wgs * 2 * C + 2 * C, ANEMOI_ERR_INVALID,
                  "anemoi_layer_norm_backward: workspace of %lld floats required", (long long)(wgs * 2 * C + 2 * C));
   const size_t lds_bytes = (size_t)C * 8 * sizeof(float);
-  auto kern = layer_norm_backward_kernel<T>;
-  if (lds_bytes > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds_bytes) != hipSuccess)
-    return fail(ANEMOI_ERR_LAUNCH, "anemoi_layer_norm_backward: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds_bytes, st, x, ldx, stats, gamma, dy, ldd, dx, ldo, rows, C,
-                     rows_per_wg, workspace);
+  auto launch = [&](auto kern) -> int {
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return fail(ANEMOI_ERR_LAUNCH, "anemoi_layer_norm_backward: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds_bytes, st, x, ldx, stats, gamma, dy, ldd, dx, ldo, rows,
+                       C, rows_per_wg, workspace);
+    return ANEMOI_OK;
+  };
+  int rc;
+  if (C <= 256) rc = launch(layer_norm_backward_kernel<T, 4>);
+  else if (C <= 512) rc = launch(layer_norm_backward_kernel<T, 8>);
+  else if (C <= 1024) rc = launch(layer_norm_backward_kernel<T, 16>);
+  else if (C <= 2048) rc = launch(layer_norm_backward_kernel<T, 32>);
+  else rc = launch(layer_norm_backward_kernel<T, 0>);
+  if (rc != ANEMOI_OK) return rc;
   // [wgs, 2C] partials -> d gamma | d beta
   float* both = workspace + wgs * 2 * C;
   hipLaunchKernelGGL((col_sum_stage_kernel<float>), dim3(1, (unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, workspace,
