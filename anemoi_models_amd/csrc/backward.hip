@@ -112,7 +112,7 @@ static int col_sum_launch(const T* x, int64_t ldx, int64_t rows, int cols, float
 __device__ __forceinline__ float act_grad(float x, int act) {
   switch (act) {
     case ANEMOI_ACT_GELU: {  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
-      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));  // |error| <= 1.5e-7 (common.hpp)
       return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
     }
     case ANEMOI_ACT_SILU: {
@@ -121,6 +121,28 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     }
     case ANEMOI_ACT_RELU: return x > 0.f ? 1.f : 0.f;
     default: return 1.f;
+  }
+}
+
+// 16 bytes per lane when every row pitch and the width allow it (the usual case: [M, 4C] hidden activations)
+template <typename T>
+__global__ __launch_bounds__(256) void act_backward_vec_kernel(const T* __restrict__ pre, int64_t ldp,
+                                                               const T* __restrict__ dy, int64_t ldd,
+                                                               T* __restrict__ out, int64_t ldo, int64_t rows, int cols,
+                                                               int act) {
+  constexpr int V = 16 / sizeof(T);
+  const int per_row = cols / V;
+  const int64_t total = rows * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / per_row;
+    const int c = (int)(idx - r * per_row) * V;
+    float p[V], d[V];
+    VecIO<T, V>::load(pre + r * ldp + c, p);
+    VecIO<T, V>::load(dy + r * ldd + c, d);
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] *= act_grad(p[i], act);
+    VecIO<T, V>::store(out + r * ldo + c, d);
   }
 }
 
@@ -172,17 +194,25 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
     const float2 st = stats[r];
     float sg = 0.f, sgx = 0.f;
     if constexpr (NC > 0) {
+      // the lane owns V = 16 / sizeof(T) adjacent columns per group of 64 V columns: one 16-byte load per group and array
+      constexpr int V = 16 / sizeof(T);
 #pragma unroll
-      for (int i = 0; i < NC; ++i) {
-        const int c = lane + 64 * i;
+      for (int gi = 0; gi < NC / V; ++gi) {
+        const int c = (gi * 64 + lane) * V;
         if (c < C) {
-          const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
-          const float d = Elem<T>::load(dy + r * ldd + c);
-          const float g = d * gamma[c];
-          sg += g;
-          sgx = fmaf(g, xh, sgx);
-          rdg[i] = fmaf(d, xh, rdg[i]);
-          rdb[i] += d;
+          float xv[V], dv[V], gv[V];
+          VecIO<T, V>::load(x + r * ldx + c, xv);
+          VecIO<T, V>::load(dy + r * ldd + c, dv);
+          VecIO<float, V>::load(gamma + c, gv);
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float xh = xv[i] * st.x + st.y;
+            const float g = dv[i] * gv[i];
+            sg += g;
+            sgx = fmaf(g, xh, sgx);
+            rdg[gi * V + i] = fmaf(dv[i], xh, rdg[gi * V + i]);
+            rdb[gi * V + i] += dv[i];
+          }
         }
       }
     } else {
@@ -198,16 +228,37 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
     }
     sg = wave_sum(sg) * inv_c;
     sgx = wave_sum(sgx) * inv_c;
-    for (int c = lane; c < C; c += 64) {
-      const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
-      const float g = Elem<T>::load(dy + r * ldd + c) * gamma[c];
-      Elem<T>::store(dx + r * ldo + c, st.x * (g - sg - xh * sgx));
+    if constexpr (NC > 0) {
+      constexpr int V = 16 / sizeof(T);
+#pragma unroll
+      for (int gi = 0; gi < NC / V; ++gi) {
+        const int c = (gi * 64 + lane) * V;
+        if (c < C) {
+          float xv[V], dv[V], gv[V], o[V];
+          VecIO<T, V>::load(x + r * ldx + c, xv);
+          VecIO<T, V>::load(dy + r * ldd + c, dv);
+          VecIO<float, V>::load(gamma + c, gv);
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float xh = xv[i] * st.x + st.y;
+            o[i] = st.x * (dv[i] * gv[i] - sg - xh * sgx);
+          }
+          VecIO<T, V>::store(dx + r * ldo + c, o);
+        }
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
+        const float g = Elem<T>::load(dy + r * ldd + c) * gamma[c];
+        Elem<T>::store(dx + r * ldo + c, st.x * (g - sg - xh * sgx));
+      }
     }
   }
   if constexpr (NC > 0) {
+    constexpr int V = 16 / sizeof(T);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      const int c = lane + 64 * i;
+      const int c = ((i / V) * 64 + lane) * V + (i % V);
       if (c < C) {
         my_dg[c] = rdg[i];
         my_db[c] = rdb[i];
@@ -242,10 +293,13 @@ static int layer_norm_backward_launch(const T* x, int64_t ldx, const float2* sta
     return ANEMOI_OK;
   };
   int rc;
-  if (C <= 256) rc = launch(layer_norm_backward_kernel<T, 4>);
-  else if (C <= 512) rc = launch(layer_norm_backward_kernel<T, 8>);
-  else if (C <= 1024) rc = launch(layer_norm_backward_kernel<T, 16>);
-  else if (C <= 2048) rc = launch(layer_norm_backward_kernel<T, 32>);
+  constexpr int V = 16 / sizeof(T);
+  const bool vec_ok = C % V == 0 && ldx % V == 0 && ldd % V == 0 && ldo % V == 0 && (uintptr_t)x % 16 == 0 &&
+                      (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)gamma % 16 == 0;
+  if (!vec_ok) rc = launch(layer_norm_backward_kernel<T, 0>);
+  else if (C <= 64 * 8) rc = launch(layer_norm_backward_kernel<T, 8>);
+  else if (C <= 64 * 16) rc = launch(layer_norm_backward_kernel<T, 16>);
+  else if (C <= 64 * 32) rc = launch(layer_norm_backward_kernel<T, 32>);
   else rc = launch(layer_norm_backward_kernel<T, 0>);
   if (rc != ANEMOI_OK) return rc;
   // [wgs, 2C] partials -> d gamma | d beta
@@ -331,7 +385,18 @@ int anemoi_act_backward(int dtype, int act, const void* pre, int64_t ldp, const 
                  ANEMOI_ERR_INVALID, "anemoi_act_backward: bad argument");
   ANEMOI_REQUIRE(act >= ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_act_backward: act %d", act);
   if (rows == 0) return ANEMOI_OK;
-  if (dtype == ANEMOI_F32)
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
+  const bool vec_ok = cols % vec == 0 && ldp % vec == 0 && ldd % vec == 0 && ldo % vec == 0 && (uintptr_t)pre % 16 == 0 &&
+                      (uintptr_t)dy % 16 == 0 && (uintptr_t)out % 16 == 0;
+  if (vec_ok && dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((act_backward_vec_kernel<float>), dim3(bw_grid(rows * cols / vec)), dim3(256), 0, bw_stream(stream),
+                       static_cast<const float*>(pre), ldp, static_cast<const float*>(dy), ldd, static_cast<float*>(out),
+                       ldo, rows, cols, act);
+  else if (vec_ok && dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((act_backward_vec_kernel<bf16_t>), dim3(bw_grid(rows * cols / vec)), dim3(256), 0,
+                       bw_stream(stream), static_cast<const bf16_t*>(pre), ldp, static_cast<const bf16_t*>(dy), ldd,
+                       static_cast<bf16_t*>(out), ldo, rows, cols, act);
+  else if (dtype == ANEMOI_F32)
     hipLaunchKernelGGL((act_backward_kernel<float>), dim3(bw_grid(rows * cols)), dim3(256), 0, bw_stream(stream),
                        static_cast<const float*>(pre), ldp, static_cast<const float*>(dy), ldd, static_cast<float*>(out),
                        ldo, rows, cols, act);
