@@ -37,6 +37,12 @@ def _pack(w: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+import os as _os
+
+# ANEMOI_AMD_DW_GEMM=library: dW = dpre^T X through torch.mm (hipBLASLt); default: this package's kernels (chunked
+# transposes + batched 128 x 128 GEMM + deterministic partial sum)
+_DW_LIBRARY_GEMM = _os.environ.get("ANEMOI_AMD_DW_GEMM", "own") == "library"
+
 _TORCH_ACT = {"GELU": torch.nn.functional.gelu, "SiLU": torch.nn.functional.silu, "ReLU": torch.relu}
 
 
@@ -84,7 +90,11 @@ class _Linear(torch.autograd.Function):
                 dx = ops.convert_pad(dx, dtype, ctx.x_cols)
         if ctx.needs_input_grad[1]:
             # dW [N, K] = dpre^T [N, M] @ X [M, K]: a Linear with x' = dpre^T, weight' = X^T, reduction over the M rows
-            dw = ops.weight_grad(dpre, xk, k).to(weight.dtype)
+            if _DW_LIBRARY_GEMM:
+                # a plain TN GEMM (reduction over the rows): the BLAS library takes it without transposed copies
+                dw = torch.mm(dpre.t(), xk[:, :k] if xk.shape[1] != k else xk).to(weight.dtype)
+            else:
+                dw = ops.weight_grad(dpre, xk, k).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_sum(dpre)
         if ctx.has_res and ctx.needs_input_grad[4]:
