@@ -51,6 +51,10 @@ struct LnFold {
   float2* rs_partial;
   int rs_slots;
   int64_t* rs_rows_done;  // host side only: the launcher reports how many leading rows got their partials
+  // batched launch of the four-wave kernel (anemoi_linear_batched): b_count independent problems of b_tiles tiles each,
+  // operand bases b * b_sx / b_sw / b_sy elements apart; b_tiles = 0: one problem
+  int64_t b_tiles, b_sx, b_sw, b_sy;
+  int b_count;
 };
 
 template <typename T, typename TO, int VEC>
@@ -629,17 +633,19 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   const int xrow16 = 16 * (int)ldx * 2;
   const int xwave = wid * (MH * 8) * (int)ldx * 2, wwave = wid * 64 * K * 2;
   __amdgpu_buffer_rsrc_t xrs, wrs;  // descriptors of the tile whose slabs are being staged
+  const int64_t tiles_per_problem = ln.b_tiles > 0 ? ln.b_tiles : n_tiles;
   auto set_tile = [&](int64_t tile) {
     int64_t mt_;
     int nt_;
-    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+    const int64_t pb = ln.b_tiles > 0 ? tile / ln.b_tiles : 0;  // problem of a batched launch
+    tile_coords(tile - pb * tiles_per_problem, nt_count, tiles_per_problem / nt_count, mt_, nt_);
     const int64_t m0 = mt_ * TM;
     const int n0 = nt_ * BIG_N;
     int64_t xrows = M - m0 < TM ? M - m0 : TM;  // ragged last row tile: rows >= M read as zeros (a half tile of the
     xrows = xrows > 0 ? xrows : 0;              // remainder launch may lie entirely behind M)
     const int wrows = N - n0 < BIG_N ? N - n0 : BIG_N;
-    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + m0 * ldx), 0, (int)(xrows * ldx * 2), 0x00020000);
-    wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * K), 0, wrows * K * 2, 0x00020000);
+    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + pb * ln.b_sx + m0 * ldx), 0, (int)(xrows * ldx * 2), 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + pb * ln.b_sw + (int64_t)n0 * K), 0, wrows * K * 2, 0x00020000);
   };
   auto set_null = [&]() {
     xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0, 0x00020000);
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   // inner loop and permuted all 256 of them (v_accvgpr_mov) at its exits -- 1k cycles per tile, and placed directly
   // behind the last inline-asm MFMAs, whose write latency the compiler does not know: wrong values.
   int g = 0;  // running slab counter over all tiles of this workgroup: LDS stage = g & 1
-  int64_t li = bix, tile = 0, m0 = 0;
+  int64_t li = bix, tile = 0, m0 = 0, y_base = 0;
   int k = 0, n0 = 0;
   bool has_next = false;
   for (;;) {
@@ -720,7 +726,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       has_next = li + bpx < chunk_len;
       int64_t mt_;
       int nt_;
-      tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
+      const int64_t pb = ln.b_tiles > 0 ? tile / ln.b_tiles : 0;
+      y_base = pb * ln.b_sy;
+      tile_coords(tile - pb * tiles_per_problem, nt_count, tiles_per_problem / nt_count, mt_, nt_);
       m0 = mt_ * TM;
       n0 = nt_ * BIG_N;
       // The tile's 256 bias values go to LDS by one 4-byte LDS-DMA per wave (columns >= N: zeros from the descriptor's
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     int rows_here = M - m0 < TM ? (int)(M - m0) : TM;  // ragged last row tile: the descriptors end at row M, so the
     rows_here = rows_here > 0 ? rows_here : 0;         // stores of the rows behind it are dropped and their loads read 0
     const __amdgpu_buffer_rsrc_t yrs =  // sized to the tile: masked lanes use an out-of-range offset (store dropped)
-        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy + n0), 0, rows_here * (int)ldy * 2, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Y + y_base + m0 * ldy + n0), 0, rows_here * (int)ldy * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, HAS_RES ? rows_here * (int)ldr * 2 : 0, 0x00020000);
     // row-sum partials [row][slot] of this tile's rows; only the lanes fq == 0 store (the others: out of range)
@@ -1255,7 +1263,9 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   ANEMOI_REQUIRE(mt * nt < (int64_t)1 << 31, ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: grid too large");
   const bool vec_ok = (N % 8 == 0) && (ldy % 8 == 0) && ((uintptr_t)y % 16 == 0) &&
                       (bias == nullptr || (uintptr_t)bias % 16 == 0) && (residual == nullptr || (ldr % 8 == 0 && (uintptr_t)residual % 16 == 0));
-  int64_t blocks = mt * nt;
+  const bool batched = ln.b_tiles > 0;  // anemoi_linear_batched: b_count problems of mt * nt tiles each
+  const int64_t problems = batched ? ln.b_count : 1;
+  int64_t blocks = problems * mt * nt;
   static const int64_t max_blocks = [] {  // ANEMOI_AMD_GEMM_BLOCKS: tuning knob (default: one persistent WG per CU)
     const char* e = getenv("ANEMOI_AMD_GEMM_BLOCKS");
     return e ? (int64_t)atoll(e) : (int64_t)256;
@@ -1275,7 +1285,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       return e == nullptr || atoi(e) != 0;
     }();
     int64_t mt_a = mt, mt_b = 0;  // row tiles of 256 for launch A; rows of launch B = mt_b * 256 as half tiles
-    if (half_tiles && max_blocks == 256 && nt <= 256 && 256 % nt == 0) {
+    if (half_tiles && !batched && max_blocks == 256 && nt <= 256 && 256 % nt == 0) {
       const int64_t per_round = 256 / nt;
       const int64_t rem_mt = mt % per_round;
       // measured: a half tile costs ~0.75 of a whole one (its 48 KiB slab per 64 MFMAs is bound by the L2 -> LDS
@@ -1319,7 +1329,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     bf16_t* yb = static_cast<bf16_t*>(y);
     int64_t w4_blocks = blocks;
     if (mt_a > 0) {
-      const int64_t m_a = mt_a * BIG_M < M ? mt_a * BIG_M : M, tiles_a = mt_a * nt;
+      const int64_t m_a = mt_a * BIG_M < M ? mt_a * BIG_M : M, tiles_a = problems * mt_a * nt;
       const int tail_a = mt_b == 0 ? w4_tail : 0;
       w4_blocks = tiles_a < max_blocks ? (tiles_a + 7) / 8 * 8 : max_blocks;
       LAUNCH_W4_ACT(8, xb, rb, yb, ln, m_a, tiles_a, tail_a)
@@ -1338,7 +1348,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
 #undef LAUNCH_W4__
     return check_launch("anemoi_linear(256x256, 4 waves)");
   }
-  if (M % BIG_M != 0) return W4_NEEDS_WHOLE_TILES;  // only the four-wave kernel takes a ragged last row tile
+  if (M % BIG_M != 0 || batched) return W4_NEEDS_WHOLE_TILES;  // only the four-wave kernel takes ragged / batched work
   if (ln.stats != nullptr)  // the older kernels have no LayerNorm fold: the general 128 x 128 kernel has
     return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
   if (variant == 4) {
@@ -1621,8 +1631,20 @@ extern "C" int anemoi_linear_batched(int dtype, int out_dtype, const void* x, in
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_F32)
     return linear_launch<bf16_t, float>(x, ldx, w, nullptr, nullptr, 0, y, ldy, M, N, K, ANEMOI_ACT_NONE, st, none, batch,
                                         stride_x, stride_w, stride_y);
-  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16)
+  if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16) {
+    if (K >= 128 && N % 8 == 0 && ldy % 8 == 0 && (uintptr_t)y % 16 == 0 && (stride_y * 2) % 16 == 0) {
+      // the persistent 256 x 256 kernel walks the tiles of all problems as one list
+      LnFold bl = none;
+      bl.b_tiles = ((M + BIG_M - 1) / BIG_M) * ((N + BIG_N - 1) / BIG_N);
+      bl.b_sx = stride_x;
+      bl.b_sw = stride_w;
+      bl.b_sy = stride_y;
+      bl.b_count = batch;
+      const int rc = linear_bf16_256_launch(x, ldx, w, nullptr, nullptr, 0, y, ldy, M, N, K, ANEMOI_ACT_NONE, st, bl);
+      if (rc != W4_NEEDS_WHOLE_TILES) return rc;
+    }
     return linear_launch<bf16_t, bf16_t>(x, ldx, w, nullptr, nullptr, 0, y, ldy, M, N, K, ANEMOI_ACT_NONE, st, none,
                                          batch, stride_x, stride_w, stride_y);
+  }
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_batched: dtype %d -> %d", dtype, out_dtype);
 }

@@ -505,9 +505,13 @@ def weight_grad(dpre: Tensor, x: Tensor, k: int) -> Tensor:
     _dev(dpre, x)
     m, n = _rows(dpre).shape
     kmul = k_multiple(dpre.dtype)
-    tiles = ((n + 127) // 128) * ((k + 127) // 128)
-    chunks = max(1, min((256 + tiles - 1) // tiles, m // 2048))
-    chunk_rows = round_up((m + chunks - 1) // chunks, kmul)
+    # bf16: partial results in bf16 from the persistent 256 x 256 kernel (f32 accumulation inside, as an autocast matmul
+    # rounds them), summed in f32; f32: the exact 128 x 128 kernel
+    fast = dpre.dtype == torch.bfloat16 and k % 8 == 0
+    tile = 256 if fast else 128
+    tiles = ((n + tile - 1) // tile) * ((k + tile - 1) // tile)
+    chunks = max(1, min(256 // tiles if tiles <= 256 else 1, m // 2048))
+    chunk_rows = round_up((m + chunks - 1) // chunks, max(kmul, 128 if fast else kmul))
     chunks = (m + chunk_rows - 1) // chunk_rows
     lib = _lib.load()
     code = dtype_code(dpre.dtype)
@@ -517,10 +521,12 @@ def weight_grad(dpre: Tensor, x: Tensor, k: int) -> Tensor:
     _lib.check(st, "anemoi_transpose_chunked")
     st = lib.anemoi_transpose_chunked(code, x.data_ptr(), _ld(_rows(x)), bt.data_ptr(), chunk_rows, m, k, chunk_rows, _stream())
     _lib.check(st, "anemoi_transpose_chunked")
-    part = torch.empty((chunks, n, k), dtype=torch.float32, device=dpre.device)
-    st = lib.anemoi_linear_batched(code, dtype_code(torch.float32), at.data_ptr(), chunk_rows, n * chunk_rows, bt.data_ptr(),
+    part = torch.empty((chunks, n, k), dtype=dpre.dtype if fast else torch.float32, device=dpre.device)
+    st = lib.anemoi_linear_batched(code, dtype_code(part.dtype), at.data_ptr(), chunk_rows, n * chunk_rows, bt.data_ptr(),
                                    k * chunk_rows, part.data_ptr(), k, n * k, chunks, n, k, chunk_rows, _stream())
     _lib.check(st, "anemoi_linear_batched")
+    if part.dtype != torch.float32 and chunks == 1:
+        return part[0].float()
     if chunks == 1:
         return part[0]
     return col_sum(part.view(chunks, n * k)).view(n, k)
