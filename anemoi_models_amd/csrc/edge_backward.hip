@@ -39,10 +39,8 @@ struct EdgeBwdParams {
 };
 
 template <int WIDTH>
-__device__ __forceinline__ float head_sum(float v) {  // butterfly over the WIDTH adjacent lanes of a head
-#pragma unroll
-  for (int off = 1; off < WIDTH; off <<= 1) v += __shfl_xor(v, off, 64);
-  return v;
+__device__ __forceinline__ float head_sum(float v) {  // sum over the WIDTH adjacent lanes of a head (DPP, common.hpp)
+  return group_sum<WIDTH>(v);
 }
 
 template <typename T, int VEC, int LPH, int UP>
