@@ -165,9 +165,6 @@ class _GTEdgeAttention(torch.autograd.Function):
         dfull = dfull.contiguous()
         dout = dfull[:, :c]
         dt = dfull[:, c:c + h * up].float().contiguous()
-        o_att = out[:, :c].float() - (0.0 if x_r is None else x_r.float())
-        dsum = ((dout.float() * o_att).view(n_dst, h, d).sum(-1)
-                + (dt * out[:, c:c + h * up].float()).view(n_dst, h, up).sum(-1)).contiguous()
         u32 = u.float().contiguous()
         n_edges = plan.col.shape[0]
         dev = q.device
@@ -185,7 +182,8 @@ class _GTEdgeAttention(torch.autograd.Function):
         kk, vv = ops._rows(k), ops._rows(v)
         st = lib.anemoi_gt_edge_attention_folded_backward_dst(
             code, q.data_ptr(), ops._ld(ops._rows(q)), kk.data_ptr(), vv.data_ptr(), ops._ld(kk), dout.data_ptr(),
-            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), dsum.data_ptr(), edge_attr.data_ptr(), up,
+            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), out.data_ptr(), ops._ld(ops._rows(out)),
+            ops._ptr(x_r), 0 if x_r is None else ops._ld(ops._rows(x_r)), edge_attr.data_ptr(), up,
             plan.rowptr.data_ptr(), plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(), dq.data_ptr(), c, du.data_ptr(),
             n_dst, c, h, stream)
         _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")

@@ -24,7 +24,8 @@ struct EdgeBwdParams {
   const void* dout;  // [n_dst, ldd]
   const float* u;    // [n_dst, H * UP] f32
   const float* dt;   // [n_dst, H * UP] f32
-  const float* dsum; // [n_dst, H] f32
+  const void* out;   // [n_dst, ldout] forward result: out (+ x_r) | t (H * UP columns behind the C channels)
+  const void* xr;    // [n_dst, ldxr] or null
   const float* attr; // [E, UP] f32, forward CSR order
   const int32_t* rowptr;
   const int32_t* col;
@@ -32,7 +33,7 @@ struct EdgeBwdParams {
   float* ds;         // [E, H]
   void* dq;          // [n_dst, lddq]
   float* du;         // [n_dst, H * UP]
-  int64_t ldq, ldkv, ldd, lddq;
+  int64_t ldq, ldkv, ldd, lddq, ldout, ldxr;
   int64_t n_dst;
   int C, H, n_slices;
   float scale;
@@ -65,7 +66,24 @@ __global__ __launch_bounds__(256) void gt_edge_bwd_dst_kernel(const EdgeBwdParam
       uf[a] = p.u[(node * p.H + head) * UP + a];
       dtf[a] = p.dt[(node * p.H + head) * UP + a];
     }
-    const float dsum = p.dsum[node * p.H + head];
+    // Dsum_i,h = sum_e alpha_e dalpha_e = dout_i,h . (out_i,h - x_r) + dt_i,h . t_i,h, from the forward's result
+    float dsum = 0.f;
+    {
+      float of[VEC];
+      VecIO<T, VEC>::load(static_cast<const T*>(p.out) + node * p.ldout + c0, of);
+      if (p.xr != nullptr) {
+        float xf[VEC];
+        VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + node * p.ldxr + c0, xf);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) of[i] -= xf[i];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dsum = fmaf(dof[i], of[i], dsum);
+      dsum = head_sum<LPH>(dsum);
+      const T* tp = static_cast<const T*>(p.out) + node * p.ldout + p.C + head * UP;
+#pragma unroll
+      for (int a = 0; a < UP; ++a) dsum = fmaf(dtf[a], Elem<T>::load(tp + a), dsum);
+    }
     const int e_begin = p.rowptr[node], e_end = p.rowptr[node + 1];
     // ---- sweep 1: running maximum and sum of the scores (as the forward)
     float m = -INFINITY, l = 0.f;
@@ -240,22 +258,25 @@ extern "C" {
 
 int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
                                                  int64_t ldkv, const void* dout, int64_t ldd, const float* u,
-                                                 const float* dt, const float* dsum, const float* edge_attr, int up,
+                                                 const float* dt, const void* out, int64_t ldout, const void* x_r,
+                                                 int64_t ldxr, const float* edge_attr, int up,
                                                  const int32_t* rowptr, const int32_t* col, float* alpha, float* ds,
                                                  void* dq, int64_t lddq, float* du, int64_t n_dst, int C, int H,
                                                  anemoi_stream_t stream) {
-  ANEMOI_REQUIRE(q && k && v && dout && u && dt && dsum && edge_attr && rowptr && col && alpha && ds && dq && du,
+  ANEMOI_REQUIRE(q && k && v && dout && u && dt && out && edge_attr && rowptr && col && alpha && ds && dq && du,
                  ANEMOI_ERR_INVALID, "anemoi_gt_edge_attention_folded_backward_dst: null pointer");
   ANEMOI_REQUIRE(n_dst >= 0 && C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
                  "anemoi_gt_edge_attention_folded_backward_dst: bad shape");
   if (n_dst == 0) return ANEMOI_OK;
   const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
   ANEMOI_REQUIRE(ldq % vec == 0 && ldkv % vec == 0 && ldd % vec == 0 && lddq % vec == 0 && C % vec == 0 &&
+                     ldout % vec == 0 && (x_r == nullptr || (ldxr % vec == 0 && (uintptr_t)x_r % 16 == 0)) &&
                      (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
-                     (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 16 == 0,
+                     (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 16 == 0 && (uintptr_t)out % 16 == 0,
                  ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_folded_backward_dst: operands must be 16-byte aligned");
   EdgeBwdParams p;
-  p.q = q; p.k = k; p.v = v; p.dout = dout; p.u = u; p.dt = dt; p.dsum = dsum; p.attr = edge_attr;
+  p.q = q; p.k = k; p.v = v; p.dout = dout; p.u = u; p.dt = dt; p.out = out; p.xr = x_r; p.attr = edge_attr;
+  p.ldout = ldout; p.ldxr = ldxr;
   p.rowptr = rowptr; p.col = col; p.alpha = alpha; p.ds = ds; p.dq = dq; p.du = du;
   p.ldq = ldq; p.ldkv = ldkv; p.ldd = ldd; p.lddq = lddq; p.n_dst = n_dst; p.C = C; p.H = H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
