@@ -206,6 +206,68 @@ class _GTEdgeAttention(torch.autograd.Function):
         return dq, dk, dv, dxr, du.to(u.dtype), dattr, None, None, None
 
 
+class _GTEdgeAttentionSelf(torch.autograd.Function):
+    """The processor block's case: q, k, v, x_r, u are column ranges of ONE GEMM result ``sq = x_r | q | k | v | u``.  The
+    backward kernels write their gradients straight into the column ranges of one ``d sq`` buffer (strided outputs), so
+    autograd neither zero-fills nor accumulates five sliced gradients."""
+
+    @staticmethod
+    def forward(ctx, sq, edge_attr, plan, num_heads: int, up: int):
+        c = (sq.shape[1] - num_heads * up) // 4
+        out = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
+                                           edge_attr, plan.rowptr, plan.col, num_heads, up)
+        ctx.save_for_backward(sq, edge_attr, out)
+        ctx.plan, ctx.h, ctx.up, ctx.c = plan, num_heads, up, c
+        return out
+
+    @staticmethod
+    def backward(ctx, dfull):
+        from . import _lib
+
+        sq, edge_attr, out = ctx.saved_tensors
+        plan, h, up, c = ctx.plan, ctx.h, ctx.up, ctx.c
+        n, width = sq.shape
+        d = c // h
+        dtype, dev = sq.dtype, sq.device
+        dfull = dfull.contiguous()
+        dout = dfull[:, :c]
+        n_edges = plan.col.shape[0]
+        dsq = torch.empty((n, width), dtype=dtype, device=dev)
+        dsq[:, :c].copy_(dout)  # d x_r
+        if n_edges == 0:
+            dsq[:, c:].zero_()
+            return dsq, torch.zeros_like(edge_attr), None, None, None
+        dt = dfull[:, c:c + h * up].float().contiguous()
+        u32 = sq[:, 4 * c:].float().contiguous()
+        alpha = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
+        ds = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
+        du = torch.empty((n, h * up), dtype=torch.float32, device=dev)
+        lib, code, stream = _lib.load(), ops.dtype_code(dtype), ops._stream()
+        esz = sq.element_size()
+        base = sq.data_ptr()
+        gbase = dsq.data_ptr()
+        st = lib.anemoi_gt_edge_attention_folded_backward_dst(
+            code, base + c * esz, width, base + 2 * c * esz, base + 3 * c * esz, width, dout.data_ptr(),
+            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), out.data_ptr(), ops._ld(ops._rows(out)), base, width,
+            edge_attr.data_ptr(), up, plan.rowptr.data_ptr(), plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(),
+            gbase + c * esz, width, du.data_ptr(), n, c, h, stream)
+        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
+        rowptr_t, eid_t, dst_t, dst_of_edge = _transposed_csr(plan)
+        st = lib.anemoi_gt_edge_attention_folded_backward_src(
+            code, base + c * esz, width, dout.data_ptr(), ops._ld(ops._rows(dout)), alpha.data_ptr(), ds.data_ptr(),
+            rowptr_t.data_ptr(), eid_t.data_ptr(), dst_t.data_ptr(), gbase + 2 * c * esz, gbase + 3 * c * esz, width, n, c,
+            h, stream)
+        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_src")
+        dsq[:, 4 * c:].copy_(du)
+        dattr = None
+        if ctx.needs_input_grad[1]:
+            scale = 1.0 / d**0.5
+            ue = u32.view(n, h, up)[dst_of_edge]
+            dte = dt.view(n, h, up)[dst_of_edge]
+            dattr = (scale * ds[:, :, None] * ue + alpha[:, :, None] * dte).sum(1)
+        return dsq, dattr, None, None, None
+
+
 def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor, plan,
                       num_heads: int, up: int) -> Tensor:
     """Differentiable ``ops.gt_edge_attention_folded``: ``[n_dst, C + H*up] = [sum alpha v (+ x_r) | sum alpha a]`` with
@@ -252,8 +314,7 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
     b_in = torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias"), b_u], 0)
     xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
     sq = linear(xh, w_in, b_in)  # x_r | q | k | v | u
-    att = gt_edge_attention(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
-                            edge_attr_csr, plan, h, up)
+    att = _GTEdgeAttentionSelf.apply(sq, edge_attr_csr, plan, h, up)
     return _gt_tail(att, x, sd, prefix, w_t, act, eps)
 
 
