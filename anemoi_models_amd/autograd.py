@@ -64,9 +64,12 @@ class _Linear(torch.autograd.Function):
             # the pre-activation is an output of its own here (the backward needs act'(pre)); the activation and the
             # residual then run on the stored value instead of in the GEMM epilogue
             pre = ops.linear(xk, w, b)
-            y = _TORCH_ACT[act](pre.float()).to(dtype)
-            if residual is not None:
-                y = ops.add(y, residual)
+            if pre.shape[1] % (16 // pre.element_size()) == 0:
+                y = ops.act_forward(pre, act, residual)
+            else:
+                y = _TORCH_ACT[act](pre.float()).to(dtype)
+                if residual is not None:
+                    y = ops.add(y, residual)
         ctx.save_for_backward(xk, weight, pre)
         ctx.act, ctx.has_bias, ctx.has_res, ctx.k, ctx.x_cols = act, bias is not None, residual is not None, k, x.shape[1]
         return y

@@ -146,6 +146,32 @@ __global__ __launch_bounds__(256) void act_backward_vec_kernel(const T* __restri
   }
 }
 
+// y = act(pre) (+ residual): the differentiable forward keeps `pre` and applies the activation in one pass over it
+template <typename T>
+__global__ __launch_bounds__(256) void act_forward_kernel(const T* __restrict__ pre, int64_t ldp,
+                                                          const T* __restrict__ res, int64_t ldr, T* __restrict__ out,
+                                                          int64_t ldo, int64_t rows, int cols, int act) {
+  constexpr int V = 16 / sizeof(T);
+  const int per_row = cols / V;
+  const int64_t total = rows * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / per_row;
+    const int c = (int)(idx - r * per_row) * V;
+    float p[V];
+    VecIO<T, V>::load(pre + r * ldp + c, p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) p[i] = act_apply(p[i], act);
+    if (res != nullptr) {
+      float q[V];
+      VecIO<T, V>::load(res + r * ldr + c, q);
+#pragma unroll
+      for (int i = 0; i < V; ++i) p[i] += q[i];
+    }
+    VecIO<T, V>::store(out + r * ldo + c, p);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void act_backward_kernel(const T* __restrict__ pre, int64_t ldp,
                                                            const T* __restrict__ dy, int64_t ldd, T* __restrict__ out,
@@ -407,6 +433,29 @@ int anemoi_act_backward(int dtype, int act, const void* pre, int64_t ldp, const 
   else
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_act_backward: dtype %d", dtype);
   return check_launch("anemoi_act_backward");
+}
+
+int anemoi_act_forward(int dtype, int act, const void* pre, int64_t ldp, const void* residual, int64_t ldr, void* out,
+                       int64_t ldo, int64_t rows, int cols, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(pre && out && rows >= 0 && cols > 0 && ldp >= cols && ldo >= cols && (residual == nullptr || ldr >= cols),
+                 ANEMOI_ERR_INVALID, "anemoi_act_forward: bad argument");
+  ANEMOI_REQUIRE(act >= ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_act_forward: act %d", act);
+  if (rows == 0) return ANEMOI_OK;
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
+  ANEMOI_REQUIRE(cols % vec == 0 && ldp % vec == 0 && ldo % vec == 0 && (uintptr_t)pre % 16 == 0 &&
+                     (uintptr_t)out % 16 == 0 && (residual == nullptr || (ldr % vec == 0 && (uintptr_t)residual % 16 == 0)),
+                 ANEMOI_ERR_UNSUPPORTED, "anemoi_act_forward: rows must be 16-byte aligned multiples");
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((act_forward_kernel<float>), dim3(bw_grid(rows * cols / vec)), dim3(256), 0, bw_stream(stream),
+                       static_cast<const float*>(pre), ldp, static_cast<const float*>(residual), ldr,
+                       static_cast<float*>(out), ldo, rows, cols, act);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((act_forward_kernel<bf16_t>), dim3(bw_grid(rows * cols / vec)), dim3(256), 0, bw_stream(stream),
+                       static_cast<const bf16_t*>(pre), ldp, static_cast<const bf16_t*>(residual), ldr,
+                       static_cast<bf16_t*>(out), ldo, rows, cols, act);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_act_forward: dtype %d", dtype);
+  return check_launch("anemoi_act_forward");
 }
 
 int64_t anemoi_layer_norm_backward_workspace_floats(int64_t rows, int C) {

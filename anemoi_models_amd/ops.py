@@ -464,6 +464,18 @@ def col_sum(x: Tensor) -> Tensor:
     return out
 
 
+def act_forward(pre: Tensor, act: str, residual: Optional[Tensor] = None) -> Tensor:
+    """``act(pre) + residual`` in one pass (the differentiable Linear keeps ``pre`` for the backward)."""
+    _dev(pre, residual)
+    rows, cols = _rows(pre).shape
+    out = torch.empty((rows, cols), dtype=pre.dtype, device=pre.device)
+    st = _lib.load().anemoi_act_forward(dtype_code(pre.dtype), _lib.ACT_CODES[act], pre.data_ptr(), _ld(pre),
+                                        _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(),
+                                        cols, rows, cols, _stream())
+    _lib.check(st, "anemoi_act_forward")
+    return out
+
+
 def act_backward(pre: Tensor, dy: Tensor, act: str) -> Tensor:
     """``dy * act'(pre)`` (``pre`` = the Linear's result before its activation)."""
     _dev(pre, dy)

@@ -264,6 +264,10 @@ int64_t anemoi_col_sum_workspace_floats(int64_t rows, int cols);
 int anemoi_col_sum(int dtype, const void* x, int64_t ldx, int64_t rows, int cols, float* out, float* workspace,
                    int64_t workspace_floats, anemoi_stream_t stream);
 
+/* out = act(pre) (+ residual): the differentiable forward keeps `pre` for act' and applies the activation in one pass. */
+int anemoi_act_forward(int dtype, int act, const void* pre, int64_t ldp, const void* residual, int64_t ldr, void* out,
+                       int64_t ldo, int64_t rows, int cols, anemoi_stream_t stream);
+
 /* out = dy * act'(pre), pre = the Linear's result before its activation (ANEMOI_ACT_*; exact erf GELU derivative). */
 int anemoi_act_backward(int dtype, int act, const void* pre, int64_t ldp, const void* dy, int64_t ldd, void* out,
                         int64_t ldo, int64_t rows, int cols, anemoi_stream_t stream);

@@ -150,6 +150,11 @@ def prognostic_residual(y, x, out_idx, in_idx):
     return y
 
 
+def act_forward(pre, act, residual=None):
+    y = {"GELU": F.gelu, "SiLU": F.silu, "ReLU": torch.relu, "Identity": lambda t: t}[act](pre.float()).to(pre.dtype)
+    return y if residual is None else y + residual
+
+
 def finalize_output(y, x, src, in_affine=None, out_affine=None):
     last = x[:, -1]
     if in_affine is not None:
@@ -187,5 +192,5 @@ def install(monkeypatch):
 
     for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
                  "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
-                 "prognostic_residual", "finalize_output", "advance_input", "convert_pad", "add"):
+                 "prognostic_residual", "finalize_output", "advance_input", "convert_pad", "add", "act_forward"):
         monkeypatch.setattr(ops, name, globals()[name])
