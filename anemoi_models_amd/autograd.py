@@ -341,11 +341,12 @@ def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_at
 
 
 # ------------------------------------------------------------------------------------------ the whole flat model
-def _edge_attr_csr(edge_attr_buf: Tensor, trainable: Optional[Tensor], plan, up: int) -> Tensor:
+def _edge_attr_csr(edge_attr_buf: Tensor, trainable: Optional[Tensor], plan, up: int, batch_size: int = 1) -> Tensor:
     """``[edge_attr | trainable | 1 | 0-pad]`` f32 in the plan's CSR order (what ``anemoi_edge_attr_csr`` builds in the
-    inference path), as torch ops: differentiable w.r.t. the trainable edge tensor."""
+    inference path), as torch ops: differentiable w.r.t. the trainable edge tensor.  ``batch_size`` > 1: the plan spans
+    the batched graph, the attributes repeat per sample (reference layers/graph.py:37-44)."""
     parts = [edge_attr_buf.float()] + ([] if trainable is None else [trainable.float()])
-    attr = torch.cat(parts, dim=1)[plan.perm.long()]
+    attr = torch.cat(parts, dim=1).repeat(batch_size, 1)[plan.perm.long()]
     e, dim = attr.shape
     tail = torch.zeros((e, up - dim), dtype=torch.float32, device=attr.device)
     tail[:, 0] = 1.0
@@ -365,22 +366,30 @@ def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layer
     from . import runtime
 
     b, t, ens, g_, v = x.shape
-    if b != 1:
-        raise NotImplementedError("autograd.model_forward: batch size 1")
+    if ens != 1 and b != 1:
+        raise NotImplementedError("autograd.model_forward: an ensemble dimension > 1 only with batch size 1 (the "
+                                  "reference repeats the node attributes per batch element only)")
+    bs = b * ens  # rows are ordered (batch, ensemble, grid) as in the reference's rearrange (:173-177)
 
     def node_attrs(name):
         parts = [sd[f"node_attributes.latlons_{name}"]]
         tr = sd.get(f"node_attributes.trainable_tensors.{name}.trainable")
-        return torch.cat(parts + ([] if tr is None else [tr]), dim=1)
+        return torch.cat(parts + ([] if tr is None else [tr]), dim=1).repeat(bs, 1)
 
-    x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(ens * g_, t * v), node_attrs(data).repeat(ens, 1)], dim=1).to(dtype)
+    x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(bs * g_, t * v), node_attrs(data)], dim=1).to(dtype)
     x_hidden = node_attrs(hidden).to(dtype)
     n_data, n_hidden = x_data.shape[0], x_hidden.shape[0]
     up = ops.round_up(graph["proc_edge_attr"].shape[1] + sd["processor.trainable.trainable"].shape[1] + 1, 4)
-    plans = {k: runtime.build_edge_plan(graph[f"{k}_edge_index"].to(x.device), ns, nd)
-             for k, (ns, nd) in dict(enc=(n_data, n_hidden), proc=(n_hidden, n_hidden), dec=(n_hidden, n_data)).items()}
-    attrs = {k: _edge_attr_csr(graph[f"{k}_edge_attr"].to(x.device), sd.get(f"{m}.trainable.trainable"), plans[k], up)
-             for k, m in dict(enc="encoder", proc="processor", dec="decoder").items()}
+    plans, attrs = {}, {}
+    for key, mod, (ns, nd) in (("enc", "encoder", (n_data, n_hidden)), ("proc", "processor", (n_hidden, n_hidden)),
+                               ("dec", "decoder", (n_hidden, n_data))):
+        ei = graph[f"{key}_edge_index"].to(x.device)
+        if bs > 1:  # batched graph: sample i's edges are shifted by i * (nodes per sample) (layers/mapper.py:150-171)
+            inc = torch.tensor([[ns // bs], [nd // bs]], dtype=ei.dtype, device=ei.device)
+            ei = runtime.expand_edges(ei, inc, bs)
+        plans[key] = runtime.build_edge_plan(ei, ns, nd)
+        attrs[key] = _edge_attr_csr(graph[f"{key}_edge_attr"].to(x.device), sd.get(f"{mod}.trainable.trainable"), plans[key],
+                                    up, bs)
 
     xs = linear(x_data, sd["encoder.emb_nodes_src.weight"], sd["encoder.emb_nodes_src.bias"])
     xd = linear(x_hidden, sd["encoder.emb_nodes_dst.weight"], sd["encoder.emb_nodes_dst.bias"])
@@ -396,6 +405,6 @@ def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layer
     out = gt_mapper_block(x_latent_proc, xg, sd, "decoder.proc", attrs["dec"], plans["dec"], num_heads, act)
     out = layer_norm(out, sd["decoder.node_data_extractor.0.weight"], sd["decoder.node_data_extractor.0.bias"])
     out = linear(out, sd["decoder.node_data_extractor.1.weight"], sd["decoder.node_data_extractor.1.bias"])
-    y = out.float().reshape(1, ens, g_, -1).clone()
+    y = out.float().reshape(b, ens, g_, -1).clone()
     y[..., list(prognostic_out)] = y[..., list(prognostic_out)] + x[:, -1, :, :, list(prognostic_in)]
     return y

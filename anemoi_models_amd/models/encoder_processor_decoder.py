@@ -152,14 +152,14 @@ class AnemoiModelEncProcDec(nn.Module):
     def _training_forward(self, x: Tensor, input_affine=None, output_affine=None) -> Tensor:
         """Forward WITH an autograd graph (anemoi-training calls ``.backward()`` on a loss of the result): the flat
         GraphTransformer model through ``autograd.model_forward`` -- every heavy op and its backward on the HIP kernels
-        (SURVEY §8f-1).  Single device, batch size 1, GraphTransformer mappers and processor, no boundings; everything else
-        still raises."""
+        (SURVEY §8f-1).  Single device, GraphTransformer mappers and processor, no boundings; everything else still raises."""
         from .. import autograd
         from ..layers.mapper import GraphTransformerBackwardMapper
         from ..layers.mapper import GraphTransformerForwardMapper
         from ..layers.processor import GraphTransformerProcessor
 
-        if (input_affine is not None or output_affine is not None or len(self.boundings) > 0 or x.shape[0] != 1
+        if (input_affine is not None or output_affine is not None or len(self.boundings) > 0
+                or (x.shape[0] != 1 and x.shape[2] != 1)
                 or not isinstance(self.encoder, GraphTransformerForwardMapper)
                 or not isinstance(self.decoder, GraphTransformerBackwardMapper)
                 or not isinstance(self.processor, GraphTransformerProcessor)):

@@ -40,11 +40,11 @@ def compute_dtype(x: Tensor) -> torch.dtype:
 
 def require_inference(*modules: torch.nn.Module) -> None:
     """Refuse to run where autograd would need a backward that does not exist: only the flat GraphTransformer model has a
-    differentiable route (``autograd.model_forward``, single device, batch size 1)."""
+    differentiable route (``autograd.model_forward``, single device)."""
     if torch.is_grad_enabled() and any(p.requires_grad for m in modules for p in m.parameters()):
         raise NotImplementedError(
             "anemoi_models_amd: this model / call has no backward on the MI355X kernels (only the flat GraphTransformer "
-            "model, single device, batch size 1, has: autograd.model_forward); run under torch.no_grad() / "
+            "model on a single device has: autograd.model_forward); run under torch.no_grad() / "
             "torch.inference_mode()"
         )
 

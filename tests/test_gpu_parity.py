@@ -1000,3 +1000,32 @@ def test_whole_model_training_step_vs_oracle_autograd(golden_cfg1_gt, graph_o32)
     opt.step()
     with torch.no_grad():
         assert float((model(x.to(DEV)) - ym.detach()).abs().max()) > 0
+
+
+def test_whole_model_training_step_batch_2(golden_cfg1_gt, graph_o32):
+    """autograd.model_forward on a batch of two different samples (batched graph: expanded edge index, repeated node and
+    edge attributes, reference layers/mapper.py:150-171, layers/graph.py:37-44) against the oracle under torch autograd."""
+    from test_oracle_golden import graph_tensors
+
+    from anemoi_models_amd import autograd
+
+    gold = golden_cfg1_gt
+    sd = split_prefix(gold, "sd.")
+    graph = graph_tensors(graph_o32)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.cat([gold["x"], torch.randn(gold["x"].shape, generator=gen)], dim=0)
+    kw = dict(num_heads=16, num_layers=4, num_chunks=2, prognostic_in=list(range(10)), prognostic_out=list(range(10)))
+    dy = torch.randn((2,) + tuple(gold["y"].shape[1:]), generator=gen)
+    rsd = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+    yr = ref.model_forward(rsd, {k: (v.double() if v.is_floating_point() else v) for k, v in graph.items()}, x.double(), **kw)
+    yr.backward(dy.double())
+    dsd = {k: (v.to(DEV).requires_grad_() if v.is_floating_point() else v.to(DEV)) for k, v in sd.items()}
+    y = autograd.model_forward(dsd, {k: v.to(DEV) for k, v in graph.items()}, x.to(DEV), **kw)
+    assert rel_err(y.detach(), yr.detach().float()) < 1e-4
+    assert rel_err(y[:1].detach(), gold["y"]) < 1e-4
+    y.backward(dy.to(DEV))
+    used = [k for k, v in rsd.items() if v.is_floating_point() and v.grad is not None and float(v.grad.abs().max()) > 0]
+    scale_all = max(float(rsd[k].grad.abs().max()) for k in used)
+    for k in used:
+        err = float((dsd[k].grad.cpu() - rsd[k].grad.float()).abs().max())
+        assert err <= 5e-3 * max(float(rsd[k].grad.abs().max()), 0.02 * scale_all), (k, err)

@@ -82,8 +82,9 @@ def test_forward_with_gradients_enabled(graph_o32, golden_cfg1_gt, monkeypatch):
         torch.testing.assert_close(model(golden_cfg1_gt["x"]), y.detach(), atol=1e-4, rtol=1e-4)
     with pytest.raises(NotImplementedError):
         build_model(graph_o32, "GNN")(torch.zeros(1, 2, 1, graph_o32["data"].num_nodes, 12))
-    with pytest.raises(NotImplementedError):
-        model(golden_cfg1_gt["x"].repeat(2, 1, 1, 1, 1))  # batch > 1 has no differentiable route yet
+    y2 = model(golden_cfg1_gt["x"].repeat(2, 1, 1, 1, 1))  # batch 2: the batched graph, both samples alike
+    torch.testing.assert_close(y2[0].detach(), y[0].detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(y2[1].detach(), y[0].detach(), atol=1e-4, rtol=1e-4)
 
 
 def test_kernels_refuse_cpu_tensors():
