@@ -143,9 +143,20 @@ def _transposed_csr(plan):
         rowptr_t = torch.zeros(plan.n_src + 1, dtype=torch.int64, device=col.device)
         torch.cumsum(torch.bincount(col, minlength=plan.n_src), 0, out=rowptr_t[1:])
         cached = (rowptr_t.to(torch.int32), order.to(torch.int32).contiguous(),
-                  dst_of_edge[order].to(torch.int32).contiguous(), dst_of_edge)
+                  dst_of_edge[order].to(torch.int32).contiguous(), dst_of_edge.to(torch.int32).contiguous())
         plan._transposed = cached
     return cached
+
+
+def _edge_attr_grad(alpha: Tensor, ds: Tensor, u32: Tensor, dt: Tensor, dst_of_edge: Tensor, n_edges: int, h: int,
+                    up: int, d: int) -> Tensor:
+    from . import _lib
+
+    dattr = torch.empty((n_edges, up), dtype=torch.float32, device=alpha.device)
+    st = _lib.load().anemoi_gt_edge_attr_grad(alpha.data_ptr(), ds.data_ptr(), u32.data_ptr(), dt.data_ptr(),
+                                             dst_of_edge.data_ptr(), dattr.data_ptr(), n_edges, h, up, d, ops._stream())
+    _lib.check(st, "anemoi_gt_edge_attr_grad")
+    return dattr
 
 
 class _GTEdgeAttention(torch.autograd.Function):
@@ -201,10 +212,7 @@ class _GTEdgeAttention(torch.autograd.Function):
         _lib.check(st, "anemoi_gt_edge_attention_folded_backward_src")
         dattr = None
         if ctx.needs_input_grad[5] and n_edges > 0:
-            scale = 1.0 / d**0.5
-            ue = u32.view(n_dst, h, up)[dst_of_edge]  # [E, H, up]
-            dte = dt.view(n_dst, h, up)[dst_of_edge]
-            dattr = (scale * ds[:n_edges, :, None] * ue + alpha[:n_edges, :, None] * dte).sum(1)
+            dattr = _edge_attr_grad(alpha, ds, u32, dt, dst_of_edge, n_edges, h, up, d)
         dxr = None if x_r is None else dout.contiguous()
         return dq, dk, dv, dxr, du.to(u.dtype), dattr, None, None, None
 
@@ -264,10 +272,7 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
         dsq[:, 4 * c:].copy_(du)
         dattr = None
         if ctx.needs_input_grad[1]:
-            scale = 1.0 / d**0.5
-            ue = u32.view(n, h, up)[dst_of_edge]
-            dte = dt.view(n, h, up)[dst_of_edge]
-            dattr = (scale * ds[:, :, None] * ue + alpha[:, :, None] * dte).sum(1)
+            dattr = _edge_attr_grad(alpha, ds, u32, dt, dst_of_edge, n_edges, h, up, d)
         return dsq, dattr, None, None, None
 
 

@@ -203,6 +203,29 @@ __global__ __launch_bounds__(256) void gt_edge_bwd_src_kernel(const EdgeBwdSrcPa
   }
 }
 
+// d attr[e, a] = sum_h ( scale ds[e, h] u[dst(e), h, a] + alpha[e, h] dt[dst(e), h, a] ): the gradient of the edge
+// attributes (trainable edge tensor included) from what the destination-major kernel left per (edge, head).
+__global__ __launch_bounds__(256) void edge_attr_grad_kernel(const float* __restrict__ alpha, const float* __restrict__ ds,
+                                                             const float* __restrict__ u, const float* __restrict__ dt,
+                                                             const int32_t* __restrict__ dst_of_edge,
+                                                             float* __restrict__ dattr, int64_t n_edges, int H, int UP,
+                                                             float scale) {
+  const int64_t total = n_edges * UP;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / UP;
+    const int a = (int)(idx - e * UP);
+    const int64_t i = dst_of_edge[e];
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) {
+      const int64_t nh = (i * H + h) * UP + a;
+      acc = fmaf(scale * ds[e * H + h], u[nh], acc);
+      acc = fmaf(alpha[e * H + h], dt[nh], acc);
+    }
+    dattr[idx] = acc;
+  }
+}
+
 static inline unsigned bwd_blocks(int64_t units) {
   int64_t b = (units + 3) / 4;
   if (b > 256 * 8) b = 256 * 8;
@@ -313,6 +336,19 @@ int anemoi_gt_edge_attention_folded_backward_src(int dtype, const void* q, int64
   ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_folded_backward_src: unsupported D=%d dtype=%d", C / H,
                  dtype);
   return check_launch("anemoi_gt_edge_attention_folded_backward_src");
+}
+
+int anemoi_gt_edge_attr_grad(const float* alpha, const float* ds, const float* u, const float* dt,
+                             const int32_t* dst_of_edge, float* dattr, int64_t n_edges, int H, int up, int D,
+                             anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(alpha && ds && u && dt && dst_of_edge && dattr && n_edges >= 0 && H > 0 && up > 0 && D > 0,
+                 ANEMOI_ERR_INVALID, "anemoi_gt_edge_attr_grad: bad argument");
+  if (n_edges == 0) return ANEMOI_OK;
+  int64_t blocks = (n_edges * up + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(edge_attr_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     alpha, ds, u, dt, dst_of_edge, dattr, n_edges, H, up, 1.0f / sqrtf((float)D));
+  return check_launch("anemoi_gt_edge_attr_grad");
 }
 
 }  // extern "C"

@@ -507,7 +507,7 @@ int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, in
   return check_launch("anemoi_finalize_output");
 }
 
-int anemoi_abi_version(void) { return 11; }
+int anemoi_abi_version(void) { return 12; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

@@ -305,6 +305,11 @@ int anemoi_gt_edge_attention_folded_backward_src(int dtype, const void* q, int64
                                                  const float* alpha, const float* ds, const int32_t* rowptr_t,
                                                  const int32_t* eid_t, const int32_t* dst_t, void* dk, void* dv,
                                                  int64_t ldg, int64_t n_src, int C, int H, anemoi_stream_t stream);
+/* dattr[e, a] = sum_h (ds[e, h] u[dst(e), h, a] / sqrt(D) + alpha[e, h] dt[dst(e), h, a]): gradient of the edge attributes
+ * [E, up] (CSR order; the trainable edge tensor's columns included) from the _dst kernel's alpha / ds. */
+int anemoi_gt_edge_attr_grad(const float* alpha, const float* ds, const float* u, const float* dt,
+                             const int32_t* dst_of_edge, float* dattr, int64_t n_edges, int H, int up, int D,
+                             anemoi_stream_t stream);
 
 #ifdef __cplusplus
 }
