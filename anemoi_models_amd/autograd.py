@@ -375,6 +375,11 @@ def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layer
         raise NotImplementedError("autograd.model_forward: an ensemble dimension > 1 only with batch size 1 (the "
                                   "reference repeats the node attributes per batch element only)")
     bs = b * ens  # rows are ordered (batch, ensemble, grid) as in the reference's rearrange (:173-177)
+    head_dim = sd["processor.proc.0.blocks.0.lin_query.weight"].shape[0] // num_heads
+    vec = 16 // torch.empty((), dtype=dtype).element_size()
+    if head_dim % vec != 0:
+        raise NotImplementedError(f"autograd.model_forward: head size {head_dim} must be a multiple of {vec} for {dtype} "
+                                  "(the folded edge kernels own whole 16-byte channel groups per lane)")
 
     def node_attrs(name):
         parts = [sd[f"node_attributes.latlons_{name}"]]

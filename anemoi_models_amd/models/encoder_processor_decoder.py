@@ -170,11 +170,16 @@ class AnemoiModelEncProcDec(nn.Module):
                  "proc_edge_index": self.processor.edge_index_base, "proc_edge_attr": self.processor.edge_attr,
                  "dec_edge_index": self.decoder.edge_index_base, "dec_edge_attr": self.decoder.edge_attr}
         blocks = self.processor.proc
+        dtype = runtime.compute_dtype(x)  # under torch.autocast: the autocast dtype
+        with torch.autocast(device_type=x.device.type, enabled=False):  # this path picks its precisions itself
+            return self._training_forward_impl(autograd, sd, graph, x, blocks, dtype)
+
+    def _training_forward_impl(self, autograd, sd, graph, x, blocks, dtype) -> Tensor:
         return autograd.model_forward(
             sd, graph, x, num_heads=self.processor.proc[0].blocks[0].num_heads,
             num_layers=sum(len(chunk.blocks) for chunk in blocks), num_chunks=len(blocks),
             prognostic_in=[int(i) for i in self._internal_input_idx], prognostic_out=[int(i) for i in self._internal_output_idx],
-            dtype=runtime.compute_dtype(x), act=self.processor.proc[0].blocks[0].activation,
+            dtype=dtype, act=self.processor.proc[0].blocks[0].activation,
             data=self._graph_name_data, hidden=self._graph_name_hidden)
 
     def forward(self, x: Tensor, model_comm_group=None, *, input_affine=None, output_affine=None) -> Tensor:

@@ -1029,3 +1029,29 @@ def test_whole_model_training_step_batch_2(golden_cfg1_gt, graph_o32):
     for k in used:
         err = float((dsd[k].grad.cpu() - rsd[k].grad.float()).abs().max())
         assert err <= 5e-3 * max(float(rsd[k].grad.abs().max()), 0.02 * scale_all), (k, err)
+
+
+def test_training_under_autocast_bf16(golden_cfg1_gt, graph_o32, monkeypatch):
+    """anemoi-training runs bf16-mixed: under torch.autocast the nn.Module's differentiable route computes in bf16 (f32
+    parameters and parameter gradients) and stays close to the f32 route."""
+    monkeypatch.delenv("ANEMOI_AMD_DTYPE", raising=False)
+    gold = golden_cfg1_gt
+    model, _ = _build(graph_o32, 64, 4, heads=4)  # 16 channels per head: bf16 lanes own 8 (the weights do not depend on it)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV)
+    x = gold["x"].to(DEV)
+    dy = torch.randn(gold["y"].shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    y32 = model(x)
+    y32.backward(dy)
+    g32 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = model(x)
+    assert y16.dtype == torch.float32 and rel_err(y16.detach(), y32.detach()) < 3e-2
+    y16.backward(dy)
+    scale_all = max(float(g.abs().max()) for g in g32.values())
+    for k, p in model.named_parameters():
+        if k in g32:
+            assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+            err = float((p.grad - g32[k]).abs().max())
+            assert err <= 0.15 * max(float(g32[k].abs().max()), 0.05 * scale_all), (k, err)
