@@ -31,7 +31,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -65,6 +65,8 @@ SIGNATURES = {
                                       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "anemoi_finalize_output": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anemoi_bound_output": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "anemoi_prognostic_residual": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,
                                            c_void_p, c_int, c_void_p]),
     "anemoi_advance_input": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_int,

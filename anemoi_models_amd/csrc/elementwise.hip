@@ -358,6 +358,38 @@ __global__ __launch_bounds__(256) void finalize_output_kernel(float* __restrict_
   }
 }
 
+// Output boundings (reference layers/bounding.py:60-124) in place on the f32 output: one thread per (b, ens, g) row walks
+// the op list IN ORDER -- y[col] = clamp(y[col], lo, hi) * (mul >= 0 ? y[mul] : 1) -- which is the order the
+// reference's chained in-place index assignments define; then the columns listed in fin_* are de-normalised
+// ((y - add) / mul: they were left normalised by anemoi_finalize_output so that the boundings see normalised values).
+// Comparisons (not fminf / fmaxf) keep a NaN a NaN, like torch's relu / hardtanh.
+__global__ __launch_bounds__(256) void bound_output_kernel(float* __restrict__ y, int V_out, int64_t rows, int n_ops,
+                                                           const int32_t* __restrict__ op_col,
+                                                           const float* __restrict__ op_lo,
+                                                           const float* __restrict__ op_hi,
+                                                           const int32_t* __restrict__ op_mul, int n_fin,
+                                                           const int32_t* __restrict__ fin_col,
+                                                           const float* __restrict__ fin_mul,
+                                                           const float* __restrict__ fin_add) {
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    float* yr = y + row * V_out;
+    for (int i = 0; i < n_ops; ++i) {
+      const int c = op_col[i];
+      float v = yr[c];
+      const float lo = op_lo[i], hi = op_hi[i];
+      v = v < lo ? lo : (v > hi ? hi : v);
+      const int m = op_mul[i];
+      if (m >= 0) v *= yr[m];
+      yr[c] = v;
+    }
+    for (int j = 0; j < n_fin; ++j) {
+      const int c = fin_col[j];
+      yr[c] = (yr[c] - fin_add[j]) / fin_mul[j];
+    }
+  }
+}
+
 static inline unsigned flat_grid(int64_t total) {
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
@@ -507,7 +539,22 @@ int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, in
   return check_launch("anemoi_finalize_output");
 }
 
-int anemoi_abi_version(void) { return 12; }
+int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int32_t* op_col, const float* op_lo,
+                        const float* op_hi, const int32_t* op_mul, int n_fin, const int32_t* fin_col,
+                        const float* fin_mul, const float* fin_add, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(y && V_out > 0 && rows >= 0 && n_ops >= 0 && n_fin >= 0, ANEMOI_ERR_INVALID,
+                 "anemoi_bound_output: bad argument");
+  ANEMOI_REQUIRE(n_ops == 0 || (op_col && op_lo && op_hi && op_mul), ANEMOI_ERR_INVALID,
+                 "anemoi_bound_output: null op list");
+  ANEMOI_REQUIRE(n_fin == 0 || (fin_col && fin_mul && fin_add), ANEMOI_ERR_INVALID,
+                 "anemoi_bound_output: null de-normalisation list");
+  if (rows == 0 || (n_ops == 0 && n_fin == 0)) return ANEMOI_OK;
+  hipLaunchKernelGGL(bound_output_kernel, dim3(flat_grid(rows)), dim3(256), 0, as_stream(stream), y, V_out, rows, n_ops,
+                     op_col, op_lo, op_hi, op_mul, n_fin, fin_col, fin_mul, fin_add);
+  return check_launch("anemoi_bound_output");
+}
+
+int anemoi_abi_version(void) { return 13; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

@@ -28,6 +28,7 @@ from torch import Tensor
 from .. import ops
 from .. import runtime
 from ..runtime import EdgePlan
+from .khop_edges import edge_chunk_ids, partition_edges_by_dst
 from .shapes import split_bounds
 
 
@@ -265,9 +266,11 @@ def build_shard_plan(model, group, device) -> ShardPlan:
     if ei is None:
         ei = torch.zeros((2, 0), dtype=torch.int64, device=device)
     src_int, dst_int = inv[ei[0]], inv[ei[1]]
-    dst_owner = _owner(dst_int, bt)
+    # rank r's edges = chunk r of sort_edges_1hop_chunks over the Morton-relabelled destinations (original edge order)
+    dst_owner = edge_chunk_ids(dst_int, n_mesh, world)
     halo_ids, halo = _halo_lists(src_int, lambda p: dst_owner == p, bounds, rank, world, group)
-    e_ids = torch.nonzero(dst_owner == rank).flatten()
+    e_order, e_counts = partition_edges_by_dst(dst_int, n_mesh, world)
+    e_ids = e_order[sum(e_counts[:rank]):sum(e_counts[:rank + 1])]
     s = src_int[e_ids]
     own = (s >= lo) & (s < hi)
     s_local = torch.where(own, s - lo, n_own + torch.searchsorted(halo_ids, s))

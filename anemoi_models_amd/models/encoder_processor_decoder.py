@@ -139,15 +139,54 @@ class AnemoiModelEncProcDec(nn.Module):
             src = torch.full((self.num_output_channels,), -1, dtype=torch.int32)
             src[torch.as_tensor(self._internal_output_idx).long()] = torch.as_tensor(self._internal_input_idx).to(torch.int32)
             self._idx_cache[key] = src.to(y.device)
-        fuse_out = output_affine is not None and len(self.boundings) == 0
-        ops.finalize_output(y, x, self._idx_cache[key], input_affine, output_affine if fuse_out else None)
-        if y.dtype != x.dtype:
-            y = y.to(x.dtype)
-        for bounding in self.boundings:
-            y = bounding(y)
-        if output_affine is not None and not fuse_out:  # boundings act on the normalised output: de-normalise after them
-            y = (y - output_affine[1]) / output_affine[0]
-        return y
+        if len(self.boundings) == 0:
+            ops.finalize_output(y, x, self._idx_cache[key], input_affine, output_affine)
+            return y if y.dtype == x.dtype else y.to(x.dtype)
+        plan = self._bounding_plan(y.device, output_affine)
+        if plan is None:  # a bounding class this package does not know: call the modules, as the reference does
+            ops.finalize_output(y, x, self._idx_cache[key], input_affine, None)
+            if y.dtype != x.dtype:
+                y = y.to(x.dtype)
+            for bounding in self.boundings:
+                y = bounding(y)
+            if output_affine is not None:  # boundings act on the normalised output: de-normalise after them
+                y = (y - output_affine[1]) / output_affine[0]
+            return y
+        # known boundings: the columns they touch stay normalised through finalize_output (mul 1 / add 0 there) and
+        # are bounded, then de-normalised, by ONE kernel; every other column is finished by finalize_output
+        op_lists, masked_affine, fin = plan
+        ops.finalize_output(y, x, self._idx_cache[key], input_affine, masked_affine)
+        ops.bound_output(y, *op_lists, fin=fin)
+        return y if y.dtype == x.dtype else y.to(x.dtype)
+
+    def _bounding_plan(self, device, output_affine):
+        """Device-side op list of ``self.boundings`` (cached per device and output affine), ``None`` for unknown classes."""
+        from ..layers.bounding import bounded_columns
+        from ..layers.bounding import compile_boundings
+
+        key = ("boundings", str(device), None if output_affine is None else
+               (output_affine[0].data_ptr(), output_affine[0]._version, output_affine[1].data_ptr(),
+                output_affine[1]._version))
+        if key not in self._idx_cache:
+            op_list = compile_boundings(self.boundings)
+            if op_list is None:
+                self._idx_cache[key] = None
+                return None
+            lists = (torch.tensor([o[0] for o in op_list], dtype=torch.int32, device=device),
+                     torch.tensor([o[1] for o in op_list], dtype=torch.float32, device=device),
+                     torch.tensor([o[2] for o in op_list], dtype=torch.float32, device=device),
+                     torch.tensor([o[3] for o in op_list], dtype=torch.int32, device=device))
+            masked = fin = None
+            if output_affine is not None:
+                cols = torch.tensor(bounded_columns(op_list), dtype=torch.int64, device=device)
+                mul, add = (t.detach().to(device=device, dtype=torch.float32).contiguous() for t in output_affine)
+                m_mul, m_add = mul.clone(), add.clone()
+                m_mul[cols] = 1.0
+                m_add[cols] = 0.0
+                masked = (m_mul, m_add)
+                fin = (cols.to(torch.int32), mul[cols].contiguous(), add[cols].contiguous())
+            self._idx_cache[key] = (lists, masked, fin)
+        return self._idx_cache[key]
 
     def _training_forward(self, x: Tensor, input_affine=None, output_affine=None) -> Tensor:
         """Forward WITH an autograd graph (anemoi-training calls ``.backward()`` on a loss of the result): the flat

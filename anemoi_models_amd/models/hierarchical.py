@@ -156,10 +156,4 @@ class AnemoiModelEncProcDecHierarchical(AnemoiModelEncProcDec):
 
         y = first(self.decoder.native(curr, x_data, batch_size, out_dtype=torch.float32))
         y = y.view(batch_size, ensemble_size, grid, self.num_output_channels)
-        out_idx, in_idx = self._prognostic_indices(y.device)
-        ops.prognostic_residual(y, x, out_idx, in_idx)
-        if y.dtype != x.dtype:
-            y = y.to(x.dtype)
-        for bounding in self.boundings:
-            y = bounding(y)
-        return y
+        return self._finish(y, x)  # prognostic residual + boundings (reference models/hierarchical.py:300-308)

@@ -378,6 +378,32 @@ def finalize_output(y: Tensor, x: Tensor, src: Tensor, in_affine=None, out_affin
     return y
 
 
+def bound_output(y: Tensor, op_col: Tensor, op_lo: Tensor, op_hi: Tensor, op_mul: Tensor,
+                 fin: Optional[tuple] = None) -> Tensor:
+    """In place on the f32 output ``y`` ``[..., V_out]``: the ordered bounding ops (see ``layers.bounding.compile_boundings``)
+    and, with ``fin = (cols int32, mul f32, add f32)``, the de-normalisation of those columns afterwards."""
+    _dev(y, op_col, op_lo, op_hi, op_mul)
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise ValueError("bound_output: y must be contiguous float32")
+    n_ops = op_col.numel()
+    if op_col.dtype != torch.int32 or op_mul.dtype != torch.int32 or op_lo.dtype != torch.float32 or \
+            op_hi.dtype != torch.float32 or op_lo.numel() != n_ops or op_hi.numel() != n_ops or op_mul.numel() != n_ops:
+        raise ValueError("bound_output: op lists must be int32 / float32 vectors of one length")
+    fc = fm = fa = None
+    if fin is not None:
+        fc, fm, fa = fin
+        _dev(fc, fm, fa)
+        if fc.dtype != torch.int32 or fm.dtype != torch.float32 or fa.dtype != torch.float32 or \
+                fm.numel() != fc.numel() or fa.numel() != fc.numel():
+            raise ValueError("bound_output: fin = (int32 columns, f32 mul, f32 add) of one length")
+    v_out = y.shape[-1]
+    st = _lib.load().anemoi_bound_output(y.data_ptr(), v_out, y.numel() // max(v_out, 1), n_ops, _ptr(op_col),
+                                         _ptr(op_lo), _ptr(op_hi), _ptr(op_mul), 0 if fc is None else fc.numel(),
+                                         _ptr(fc), _ptr(fm), _ptr(fa), _stream())
+    _lib.check(st, "anemoi_bound_output")
+    return y
+
+
 def advance_input(x: Tensor, y: Tensor, colmap: Tensor, forcing: Optional[Tensor] = None) -> Tensor:
     """Autoregressive input update in place on ``x`` ``[B, T, Ens, G, V_in]`` (f32): shift the time axis by one and
     fill the last slice from the prediction ``y`` ``[B, Ens, G, V_out]`` / the new ``forcing`` ``[B, Ens, G, F]``

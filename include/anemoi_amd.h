@@ -177,6 +177,20 @@ int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, in
                            const float* out_add, anemoi_stream_t stream);
 
 /*
+ * Output boundings, in place on the f32 output rows [rows, V_out] (rows = B * Ens * G) after the prognostic residual:
+ * replaces the chained ReluBounding / HardtanhBounding / FractionBounding modules of
+ * models/encoder_processor_decoder.py:229-231 (layers/bounding.py:60-124).  Every row applies, IN ORDER i = 0..n_ops-1,
+ *   y[col[i]] = clamp(y[col[i]], lo[i], hi[i]) * (mul[i] >= 0 ? y[mul[i]] : 1)
+ * (ReLU: lo = 0, hi = +inf; Hardtanh: lo = min_val, hi = max_val; the fraction step: lo = -inf, hi = +inf, mul = column
+ * of total_var; NaN stays NaN), then de-normalises the n_fin columns fin_col[j]: y = (y - fin_add[j]) / fin_mul[j]
+ * (InputNormalizer.inverse_transform of the columns the boundings had to see normalised; n_fin = 0: none).
+ * All lists are device arrays (int32 / f32).
+ */
+int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int32_t* op_col, const float* op_lo,
+                        const float* op_hi, const int32_t* op_mul, int n_fin, const int32_t* fin_col,
+                        const float* fin_mul, const float* fin_add, anemoi_stream_t stream);
+
+/*
  * Prognostic residual (models/encoder_processor_decoder.py:227), in place on the f32 output:
  *   y[b, ens, g, out_idx[p]] += x[b, T-1, ens, g, in_idx[p]]   for p < n_prog.
  */

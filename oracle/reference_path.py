@@ -394,8 +394,11 @@ def model_forward(
     window_size: Optional[int] = None,
     return_stages: bool = False,
     mappers: str = "GraphTransformer",
+    boundings: Sequence[Mapping] = (),
+    name_to_index_out: Optional[Mapping[str, int]] = None,
 ):
-    """models/encoder_processor_decoder.py:168-233 ``AnemoiModelEncProcDec.forward`` (no boundings).
+    """models/encoder_processor_decoder.py:168-233 ``AnemoiModelEncProcDec.forward``; ``boundings`` = the config's
+    ``model.bounding`` list (dicts with ``_target_``), applied in order on the output (:229-231).
 
     ``graph`` holds ``enc_edge_index``/``enc_edge_attr`` (data->hidden),
     ``proc_edge_index``/``proc_edge_attr`` (hidden->hidden) and
@@ -438,6 +441,8 @@ def model_forward(
         )  # :207-213
     x_out = x_out.reshape(b, ens, g, -1).to(x.dtype).clone()  # :215-224
     x_out[..., list(prognostic_out)] += x[:, -1, :, :, list(prognostic_in)]  # :227
+    if boundings:
+        x_out = apply_boundings(x_out, boundings, name_to_index_out)  # :229-231
     if return_stages:
         return x_out, {"x_latent": x_latent, "x_proc": x_proc}
     return x_out
@@ -503,6 +508,23 @@ def hierarchical_forward(
 # --------------------------------------------------------------------------
 # Interface: normaliser + predict_step (the step either side of the model forward)
 # --------------------------------------------------------------------------
+def apply_boundings(x: Tensor, boundings: Sequence[Mapping], name_to_index: Mapping[str, int]) -> Tensor:
+    """layers/bounding.py:60-124 ``ReluBounding`` / ``HardtanhBounding`` / ``FractionBounding`` chained in config order,
+    in place; the columns are the SORTED indices of ``variables`` (data_indices/tensor.py:91-94)."""
+    for cfg in boundings:
+        kind = cfg["_target_"].rsplit(".", 1)[-1]
+        idx = sorted(name_to_index[v] for v in cfg["variables"])
+        if kind == "ReluBounding":  # :60-65
+            x[..., idx] = torch.nn.functional.relu(x[..., idx])
+        elif kind in ("HardtanhBounding", "FractionBounding"):  # :68-92
+            x[..., idx] = torch.nn.functional.hardtanh(x[..., idx], min_val=cfg["min_val"], max_val=cfg["max_val"])
+            if kind == "FractionBounding":  # :95-124
+                x[..., idx] *= x[..., [name_to_index[cfg["total_var"]]]]
+        else:
+            raise ValueError(kind)
+    return x
+
+
 def normalizer_affine(config: Mapping, name_to_index: Mapping[str, int], statistics: Mapping):
     """preprocessing/normalizer.py:44-105 (+ preprocessing/__init__.py:63-101): per-variable ``(mul, add)`` of
     ``InputNormalizer`` from its config ``{default, remap, <method>: [variables]}`` and the dataset statistics."""

@@ -166,6 +166,20 @@ def finalize_output(y, x, src, in_affine=None, out_affine=None):
     return y
 
 
+def bound_output(y, op_col, op_lo, op_hi, op_mul, fin=None):
+    """Sequential restatement of anemoi_bound_output (host-logic tests only)."""
+    for c, lo, hi, m in zip(op_col.tolist(), op_lo.tolist(), op_hi.tolist(), op_mul.tolist()):
+        v = y[..., c]
+        v = torch.where(v < lo, torch.full_like(v, lo), torch.where(v > hi, torch.full_like(v, hi), v))
+        if m >= 0:
+            v = v * y[..., m]
+        y[..., c] = v
+    if fin is not None:
+        for c, mul, add in zip(fin[0].tolist(), fin[1].tolist(), fin[2].tolist()):
+            y[..., c] = (y[..., c] - add) / mul
+    return y
+
+
 def advance_input(x, y, colmap, forcing=None):
     new = x.roll(-1, dims=1)
     new[:, -1] = x[:, -1]
@@ -192,5 +206,5 @@ def install(monkeypatch):
 
     for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
                  "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
-                 "prognostic_residual", "finalize_output", "advance_input", "convert_pad", "add", "act_forward"):
+                 "prognostic_residual", "finalize_output", "bound_output", "advance_input", "convert_pad", "add", "act_forward"):
         monkeypatch.setattr(ops, name, globals()[name])

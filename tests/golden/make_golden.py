@@ -241,6 +241,66 @@ def golden_interface(fname: str = "interface_gt.npz") -> dict:
     return {k: list(v.shape) for k, v in sd.items()}
 
 
+BOUNDING = [  # reference layers/bounding.py; prog_0 is bounded twice (chained), prog_4 is the total of a fraction pair
+    {"_target_": "anemoi.models.layers.bounding.ReluBounding", "variables": ["prog_0", "diag_0"]},
+    {"_target_": "anemoi.models.layers.bounding.HardtanhBounding", "variables": ["prog_1", "prog_0"], "min_val": -0.5,
+     "max_val": 0.75},
+    {"_target_": "anemoi.models.layers.bounding.FractionBounding", "variables": ["prog_3", "prog_2"], "min_val": 0.0,
+     "max_val": 1.0, "total_var": "prog_4"},
+]
+
+
+def golden_bounding(fname: str = "bounding_gt.npz") -> None:
+    """Config 1 with a ``bounding:`` list (reference models/encoder_processor_decoder.py:96-104, 229-231): the model
+    alone, and behind ``AnemoiModelInterface.predict_step`` with an ``InputNormalizer`` (boundings act on the normalised
+    output, the de-normalisation follows).  Same seeds as ``cfg1_gt.npz`` / ``interface_gt.npz``: boundings hold no
+    parameters, so the weights and inputs are those files' -- only the outputs are stored here."""
+    g = build_graph("o32_ico2")
+    idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+    cfg = model_config("GraphTransformer", 64, 4, 16)
+    cfg["model"]["bounding"] = [dict(b) for b in BOUNDING]
+    torch.manual_seed(1234)
+    model = AnemoiModelEncProcDec(model_config=_ref_stubs.DotDict(cfg), data_indices=idx, graph_data=to_ref_graph(g))
+    randomise(model, 4321)
+    model.eval()
+    assert len(model.boundings) == 3
+    with np.load(os.path.join(HERE, "cfg1_gt.npz")) as z:
+        for k, v in model.state_dict().items():
+            assert np.array_equal(z["sd." + k], v.numpy()), k
+        x = torch.from_numpy(z["x"])
+        y_free = torch.from_numpy(z["y"])
+    with torch.no_grad():
+        y = model(x)
+    changed = (y != y_free).any(dim=-1).flatten()
+    assert changed.float().mean() > 0.5, "the bounding list should bite on most rows"
+
+    names = [f"prog_{i}" for i in range(10)] + [f"forc_{i}" for i in range(2)] + ["diag_0"]
+    cfg = model_config("GraphTransformer", 64, 4, 16)
+    cfg["model"]["bounding"] = [dict(b) for b in BOUNDING]
+    cfg["data"] = {
+        "forcing": [f"forc_{i}" for i in range(2)], "diagnostic": ["diag_0"],
+        "processors": {"normalizer": {"_target_": "anemoi.models.preprocessing.normalizer.InputNormalizer",
+                                      "config": dict(NORMALIZER_METHODS)}},
+    }
+    cfg["model"]["model"] = {"_target_": "anemoi.models.models.encoder_processor_decoder.AnemoiModelEncProcDec"}
+    cfg = _ref_stubs.DotDict(cfg)
+    indices = IndexCollection(cfg, {n: i for i, n in enumerate(names)})
+    with np.load(os.path.join(HERE, "interface_gt.npz")) as z:
+        statistics = {k: z["stat." + k].copy() for k in ("mean", "stdev", "minimum", "maximum")}
+        batch = torch.from_numpy(z["batch"])
+        torch.manual_seed(1234)
+        iface = AnemoiModelInterface(config=cfg, graph_data=to_ref_graph(g), statistics=statistics, data_indices=indices,
+                                     metadata={})
+        randomise(iface.model, 4321)
+        iface.eval()
+        for k, v in iface.state_dict().items():
+            assert np.array_equal(z["sd." + k], v.numpy()), k
+    with torch.no_grad():
+        y_iface = iface.predict_step(batch)
+    np.savez_compressed(os.path.join(HERE, fname), y=y.numpy(), y_interface=y_iface.numpy())
+    print(fname, "rows changed by the boundings", float(changed.float().mean()), "|y|max", float(y.abs().max()))
+
+
 IMPUTER_NAMES = ["x", "y", "z", "q", "other"]
 IMPUTER_CASES = {  # class name -> config (statistic or constant -> variables)
     "InputImputer": {"default": "none", "mean": ["y"], "maximum": ["x"], "none": ["z"], "minimum": ["q", "other"]},
@@ -396,6 +456,9 @@ def golden_index_ops() -> None:
 
 
 if __name__ == "__main__":
+    if "--only-bounding" in sys.argv:
+        golden_bounding()
+        sys.exit(0)
     keys = {
         "GraphTransformer": golden_model("GraphTransformer", "cfg1_gt.npz"),
         "GNN": golden_model("GNN", "cfg1_gnn.npz"),
@@ -409,3 +472,4 @@ if __name__ == "__main__":
     golden_blocks()
     golden_index_ops()
     golden_imputers()
+    golden_bounding()

@@ -1055,3 +1055,33 @@ def test_training_under_autocast_bf16(golden_cfg1_gt, graph_o32, monkeypatch):
             assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
             err = float((p.grad - g32[k]).abs().max())
             assert err <= 0.15 * max(float(g32[k].abs().max()), 0.05 * scale_all), (k, err)
+
+
+def test_sort_edges_1hop_chunks_bit_exact_on_device(golden_index_ops):
+    """the product's edge partition on DEVICE tensors against the vectors recorded from the reference's
+    ``sort_edges_1hop_chunks`` (reference distributed/khop_edges.py:88-130), and the kernels' CSR plan as its refinement."""
+    from test_host_logic import _check_khop_against_golden
+
+    _check_khop_against_golden(golden_index_ops, DEV)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_plan_edges_are_reference_chunks_on_device(world):
+    """Rank r of the node-partitioned forward owns chunk r of ``sort_edges_1hop_chunks`` over the Morton-relabelled mesh
+    (O96 -> ico-5 graph, device tensors; integer outputs, bit exact)."""
+    from anemoi_models_amd.distributed import khop_edges as K
+    from anemoi_models_amd.distributed.partition import SimulatedRank, build_shard_plan
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from test_host_logic import build_model
+
+    graph = build_graph("o96_ico5")
+    model = build_model(graph).to(DEV)
+    order, inv = model._mesh_order(torch.device(DEV))
+    ei = model.processor.edge_index_base
+    e_ids = torch.arange(ei.shape[1], device=DEV).view(-1, 1)
+    ids_l, idx_l = K.sort_edges_1hop_chunks(order.shape[0], e_ids, inv[ei], world)
+    want_attr, want_idx = ref.sort_edges_1hop_chunks(order.shape[0], e_ids.cpu(), inv[ei].cpu(), world)  # oracle
+    for r in range(world):
+        assert torch.equal(ids_l[r].cpu(), want_attr[r]) and torch.equal(idx_l[r].cpu(), want_idx[r])
+        sp = build_shard_plan(model, SimulatedRank(r, world), torch.device(DEV))
+        assert torch.equal(sp.proc.plan.perm.long().sort().values, ids_l[r].flatten())

@@ -369,3 +369,81 @@ def test_interface_predict_step_with_the_normalizer_folded_into_the_forward(grap
     torch.testing.assert_close(y1, y0, atol=1e-5, rtol=1e-5)
     monkeypatch.setenv("ANEMOI_AMD_FUSE_NORMALIZER", "0")
     assert iface._normalizer_affines(gold["batch"]) is None
+
+
+# ------------------------------------------------------------------------------------------- a13: edge partition
+def _check_khop_against_golden(z, device):
+    from anemoi_models_amd.distributed import khop_edges as K
+
+    ei, ea = z["homo.edge_index"].to(device), z["homo.edge_attr"].to(device)
+    attr_l, idx_l = K.sort_edges_1hop_chunks(53, ea, ei, 5)
+    assert len(attr_l) == len(idx_l) == 5
+    for i in range(5):
+        assert idx_l[i].dtype == torch.int64 and idx_l[i].device == ei.device
+        assert torch.equal(idx_l[i].cpu(), z[f"homo.index{i}"]) and torch.equal(attr_l[i].cpu(), z[f"homo.attr{i}"])
+    ei, ea = z["bip.edge_index"].to(device), z["bip.edge_attr"].to(device)
+    attr_l, idx_l = K.sort_edges_1hop_chunks((70, 31), ea, ei, 4)
+    for i in range(4):
+        assert torch.equal(idx_l[i].cpu(), z[f"bip.index{i}"]) and torch.equal(attr_l[i].cpu(), z[f"bip.attr{i}"])
+    # get_k_hop_edges on one chunk = that chunk (reference distributed/khop_edges.py:24-47)
+    ei, ea = z["homo.edge_index"].to(device), z["homo.edge_attr"].to(device)
+    nodes = torch.arange(53, device=device).tensor_split(5)[2]
+    a, i2 = K.get_k_hop_edges(nodes, ea, ei)
+    assert torch.equal(i2.cpu(), z["homo.index2"]) and torch.equal(a.cpu(), z["homo.attr2"])
+    # the CSR plan of the kernels is a refinement of the partition: slots rowptr[b_r]..rowptr[b_{r+1}] = chunk r
+    from anemoi_models_amd.distributed.shapes import split_bounds
+
+    plan = runtime.build_edge_plan(z["bip.edge_index"].to(device), 70, 31)
+    b = split_bounds(31, 4)
+    for r in range(4):
+        slots = plan.perm[int(plan.rowptr[b[r]]):int(plan.rowptr[b[r + 1]])].long().sort().values
+        assert torch.equal(z["bip.edge_index"][:, slots.cpu()], z[f"bip.index{r}"])
+
+
+def test_sort_edges_1hop_chunks_bit_exact(golden_index_ops):
+    """The PRODUCT's edge partition (distributed/khop_edges.py) against the vectors recorded from the reference's
+    ``sort_edges_1hop_chunks`` (reference distributed/khop_edges.py:88-130)."""
+    _check_khop_against_golden(golden_index_ops, "cpu")
+
+
+def test_sort_edges_1hop_sharding_identity_without_group(golden_index_ops):
+    from anemoi_models_amd.distributed import khop_edges as K
+
+    z = golden_index_ops
+    a, i, sa, si = K.sort_edges_1hop_sharding(53, z["homo.edge_attr"], z["homo.edge_index"], None)
+    assert a is z["homo.edge_attr"] and i is z["homo.edge_index"] and sa == [] and si == []
+
+
+def test_get_k_hop_edges_two_hops():
+    """directed k-hop: hop 2 adds the edges INTO the sources reached at hop 1 (PyG k_hop_subgraph contract)."""
+    from anemoi_models_amd.distributed import khop_edges as K
+
+    # chain 0 -> 1 -> 2 -> 3 plus a stray edge 4 -> 0
+    ei = torch.tensor([[0, 1, 2, 4], [1, 2, 3, 0]])
+    ea = torch.arange(4.0).view(4, 1)
+    a1, i1 = K.get_k_hop_edges(torch.tensor([3]), ea, ei, 1)
+    assert i1.tolist() == [[2], [3]] and a1.flatten().tolist() == [2.0]
+    a2, i2 = K.get_k_hop_edges(torch.tensor([3]), ea, ei, 2)
+    assert i2.tolist() == [[1, 2], [2, 3]] and a2.flatten().tolist() == [1.0, 2.0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_plan_processor_edges_are_the_reference_chunks(graph_o32, world):
+    """Rank r of the node-partitioned forward owns exactly chunk r of ``sort_edges_1hop_chunks`` taken over the
+    Morton-relabelled mesh (undoing the relabel gives back original edge ids, in original order)."""
+    from anemoi_models_amd.distributed import khop_edges as K
+    from anemoi_models_amd.distributed.partition import SimulatedRank
+    from anemoi_models_amd.distributed.partition import build_shard_plan
+
+    model = build_model(graph_o32)
+    order, inv = model._mesh_order(torch.device("cpu"))
+    ei = model.processor.edge_index_base
+    n = order.shape[0]
+    e_ids = torch.arange(ei.shape[1]).view(-1, 1)
+    ids_l, idx_l = K.sort_edges_1hop_chunks(n, e_ids, inv[ei], world)
+    for r in range(world):
+        sp = build_shard_plan(model, SimulatedRank(r, world), torch.device("cpu"))
+        mine = sp.proc.plan.perm.long().sort().values
+        assert torch.equal(mine, ids_l[r].flatten())
+        assert torch.equal(order[idx_l[r]], ei[:, mine])  # relabel undone: the original (src, dst) pairs
+        assert int(idx_l[r][1].min()) >= sp.lo and int(idx_l[r][1].max()) < sp.hi
