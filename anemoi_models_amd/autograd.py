@@ -1,5 +1,5 @@
-"""Differentiable Linear / LayerNorm on the HIP kernels -- the dense half of the backward pass (first
-step; the edge-attention backward is the other half and not in this build).
+"""Differentiable Linear / LayerNorm / edge attention / whole GraphTransformer blocks and model on the HIP kernels
+(SURVEY.md §8f-1): ``AnemoiModelEncProcDec.forward`` routes here when gradients are required.
 
 ``linear(x, weight, bias, act, residual)`` and ``layer_norm(x, gamma, beta, eps)`` are ``torch.autograd.Function``s
 whose forward is the inference path's fused GEMM / LayerNorm kernel and whose backward runs on the same GEMM kernels:
@@ -12,8 +12,8 @@ whose forward is the inference path's fused GEMM / LayerNorm kernel and whose ba
 
 What torch derives for the reference's ``nn.Linear`` / ``nn.GELU`` / ``nn.LayerNorm`` (layers/block.py:504-508, 631-633,
 layers/mlp.py:74-84) when anemoi-training calls ``.backward()``.  Parameters stay f32 (their gradients too); activations
-and activation gradients are in the compute dtype.  The model classes do not use these yet (``runtime.require_inference``):
-training needs the edge-phase backward as well.
+and activation gradients are in the compute dtype.  The edge half (``gt_edge_attention``) runs on
+``csrc/edge_backward.hip``; ``gt_processor_block`` / ``gt_mapper_block`` / ``model_forward`` compose the two.
 """
 
 from __future__ import annotations
@@ -194,6 +194,8 @@ class _GTEdgeAttention(torch.autograd.Function):
         code = ops.dtype_code(dtype)
         stream = ops._stream()
         kk, vv = ops._rows(k), ops._rows(v)
+        if ops._ld(kk) != ops._ld(vv):
+            raise ValueError("gt_edge_attention: k and v must share their leading dimension (slices of one k|v buffer)")
         st = lib.anemoi_gt_edge_attention_folded_backward_dst(
             code, q.data_ptr(), ops._ld(ops._rows(q)), kk.data_ptr(), vv.data_ptr(), ops._ld(kk), dout.data_ptr(),
             ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), out.data_ptr(), ops._ld(ops._rows(out)),
@@ -360,14 +362,16 @@ def _edge_attr_csr(edge_attr_buf: Tensor, trainable: Optional[Tensor], plan, up:
 
 def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layers: int, num_chunks: int,
                   prognostic_in, prognostic_out, dtype: torch.dtype = torch.float32, act: str = "GELU",
-                  data: str = "data", hidden: str = "hidden") -> Tensor:
+                  data: str = "data", hidden: str = "hidden", plan_cache=None) -> Tensor:
     """Differentiable forward of the flat GraphTransformer ``AnemoiModelEncProcDec`` (reference
     models/encoder_processor_decoder.py:168-233; batch size 1, no boundings) for TRAINING on the HIP kernels.
 
     ``sd``: the model's ``state_dict`` as f32 tensors on the device (``requires_grad`` where gradients are wanted, the
     trainable node / edge tensors included); ``graph``: ``{enc,proc,dec}_edge_index`` (int64 ``[2, E]``) and
     ``{enc,proc,dec}_edge_attr`` (f32 ``[E, k]``) as in ``oracle.reference_path.model_forward``.  Heavy ops are the
-    autograd Functions above; concatenations / index maps are torch glue."""
+    autograd Functions above; concatenations / index maps are torch glue.  ``plan_cache`` (a ``runtime.PlanCache``, the
+    model passes its own) keeps the CSR plans -- and the transposed CSR the backward hangs on them -- across steps: without
+    it every step pays the range-check host syncs and two sorts per edge set."""
     from . import runtime
 
     b, t, ens, g_, v = x.shape
@@ -389,17 +393,23 @@ def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layer
     x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(bs * g_, t * v), node_attrs(data)], dim=1).to(dtype)
     x_hidden = node_attrs(hidden).to(dtype)
     n_data, n_hidden = x_data.shape[0], x_hidden.shape[0]
-    up = ops.round_up(graph["proc_edge_attr"].shape[1] + sd["processor.trainable.trainable"].shape[1] + 1, 4)
     plans, attrs = {}, {}
     for key, mod, (ns, nd) in (("enc", "encoder", (n_data, n_hidden)), ("proc", "processor", (n_hidden, n_hidden)),
                                ("dec", "decoder", (n_hidden, n_data))):
-        ei = graph[f"{key}_edge_index"].to(x.device)
-        if bs > 1:  # batched graph: sample i's edges are shifted by i * (nodes per sample) (layers/mapper.py:150-171)
-            inc = torch.tensor([[ns // bs], [nd // bs]], dtype=ei.dtype, device=ei.device)
-            ei = runtime.expand_edges(ei, inc, bs)
-        plans[key] = runtime.build_edge_plan(ei, ns, nd)
-        attrs[key] = _edge_attr_csr(graph[f"{key}_edge_attr"].to(x.device), sd.get(f"{mod}.trainable.trainable"), plans[key],
-                                    up, bs)
+        ei = graph[f"{key}_edge_index"]
+        if ei.device != x.device:
+            ei = ei.to(x.device)
+        inc = torch.tensor([[ns // bs], [nd // bs]], dtype=ei.dtype, device=ei.device) if bs > 1 else None
+        if plan_cache is not None:  # keyed on the edge-index tensor's identity / version and the batch size
+            plans[key] = plan_cache.get(ei, ns, nd, bs, inc)
+        else:  # batched graph: sample i's edges are shifted by i * (nodes per sample) (layers/mapper.py:150-171)
+            plans[key] = runtime.build_edge_plan(runtime.expand_edges(ei, inc, bs) if bs > 1 else ei, ns, nd)
+        # every edge set has its own attribute width (its trainable tensor may be absent or of another size): the
+        # folded width ``up`` = attributes + the constant-1 column, rounded to the kernel's 4-float granule
+        trainable = sd.get(f"{mod}.trainable.trainable")
+        width = graph[f"{key}_edge_attr"].shape[1] + (0 if trainable is None else trainable.shape[1])
+        attrs[key] = _edge_attr_csr(graph[f"{key}_edge_attr"].to(x.device), trainable, plans[key],
+                                    ops.round_up(width + 1, 4), bs)
 
     xs = linear(x_data, sd["encoder.emb_nodes_src.weight"], sd["encoder.emb_nodes_src.bias"])
     xd = linear(x_hidden, sd["encoder.emb_nodes_dst.weight"], sd["encoder.emb_nodes_dst.bias"])

@@ -219,7 +219,8 @@ class AnemoiModelEncProcDec(nn.Module):
             num_layers=sum(len(chunk.blocks) for chunk in blocks), num_chunks=len(blocks),
             prognostic_in=[int(i) for i in self._internal_input_idx], prognostic_out=[int(i) for i in self._internal_output_idx],
             dtype=dtype, act=self.processor.proc[0].blocks[0].activation,
-            data=self._graph_name_data, hidden=self._graph_name_hidden)
+            data=self._graph_name_data, hidden=self._graph_name_hidden,
+            plan_cache=self._idx_cache.setdefault("train_plans", runtime.PlanCache()))
 
     def forward(self, x: Tensor, model_comm_group=None, *, input_affine=None, output_affine=None) -> Tensor:
         """``input_affine`` / ``output_affine`` (keyword-only extension, ``(mul, add)`` per input / output variable): ``x``

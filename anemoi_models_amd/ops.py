@@ -243,6 +243,8 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     """
     _dev(q, k, v, x_r, u, edge_attr, rowptr, col, out)
     n_dst, c = _rows(q).shape
+    if _ld(_rows(k)) != _ld(_rows(v)):
+        raise ValueError("gt_edge_attention_folded: k and v must share their leading dimension")
     width = c + num_heads * up
     ld = width if ld_out is None else ld_out
     if out is None:

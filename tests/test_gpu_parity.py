@@ -585,7 +585,13 @@ def test_node_partitioned_forward_ranks_sharing_one_gpu(world, graph_name, chann
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_shared_ranks.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out, graph_name, str(channels),
                                str(layers), str(heads), dtype]) for r in range(world)]
-    codes = [p.wait(timeout=900) for p in procs]
+    try:
+        codes = [p.wait(timeout=900) for p in procs]
+    finally:  # a hung or failed rank must not leave its peers holding cuda:0 and the rendezvous port
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     assert codes == [0] * world
     infos = [torch.load(f"{out}.{r}") for r in range(world)]
     assert sum(i["own"] for i in infos) > 0
@@ -1085,3 +1091,57 @@ def test_shard_plan_edges_are_reference_chunks_on_device(world):
         assert torch.equal(ids_l[r].cpu(), want_attr[r]) and torch.equal(idx_l[r].cpu(), want_idx[r])
         sp = build_shard_plan(model, SimulatedRank(r, world), torch.device(DEV))
         assert torch.equal(sp.proc.plan.perm.long().sort().values, ids_l[r].flatten())
+
+
+def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
+    """Edge sets with their own attribute widths: encoder trainable_size 12, processor 0 (no ``processor.trainable.trainable``
+    key in the state dict at all), decoder 3, hidden nodes 0 -- the differentiable route computes the folded width per
+    edge set, as the inference route does; output and every parameter gradient against the oracle under torch autograd,
+    and the inference route on the same weights."""
+    from test_oracle_golden import graph_tensors
+
+    from anemoi_models_amd.models import AnemoiModelEncProcDec
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    cfg = model_config("GraphTransformer", 64, 2, 16, proc_chunks=1)
+    cfg["model"]["encoder"]["trainable_size"] = 12
+    cfg["model"]["processor"]["trainable_size"] = 0
+    cfg["model"]["decoder"]["trainable_size"] = 3
+    cfg["model"]["trainable_parameters"] = {"data": 5, "hidden": 0}
+    idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+    torch.manual_seed(3)
+    model = AnemoiModelEncProcDec(model_config=type(cfg)(cfg), data_indices=idx, graph_data=graph_o32)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert "processor.trainable.trainable" not in sd and sd["encoder.trainable.trainable"].shape[1] == 12
+    graph = graph_tensors(graph_o32)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 2, 1, graph_o32["data"].num_nodes, idx.num_input, generator=gen)
+    kw = dict(num_heads=16, num_layers=2, num_chunks=1, prognostic_in=list(range(10)), prognostic_out=list(range(10)))
+    rsd = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+    yr = ref.model_forward(rsd, {k: (v.double() if v.is_floating_point() else v) for k, v in graph.items()}, x.double(), **kw)
+    dy = torch.randn(yr.shape, generator=gen)
+    yr.backward(dy.double())
+    model = model.to(DEV)
+    y = model(x.to(DEV))
+    assert y.requires_grad and rel_err(y.detach(), yr.detach().float()) < 1e-4
+    y.backward(dy.to(DEV))
+    with torch.no_grad():
+        assert rel_err(model(x.to(DEV)), yr.detach().float()) < 1e-4  # inference route, same weights
+    grads = dict(model.named_parameters())
+    used = [k for k in grads if rsd[k].grad is not None and float(rsd[k].grad.abs().max()) > 0]
+    assert len(used) > 50 and "encoder.trainable.trainable" in used and "decoder.trainable.trainable" in used
+    scale_all = max(float(rsd[k].grad.abs().max()) for k in used)
+    for k in used:
+        err = float((grads[k].grad.cpu() - rsd[k].grad.float()).abs().max())
+        assert err <= 5e-3 * max(float(rsd[k].grad.abs().max()), 0.02 * scale_all), (k, err)
+    # second step: the cached plans (and their transposed CSR) are reused
+    plans = model._idx_cache["train_plans"]._plans
+    n_plans = len(plans)
+    model.zero_grad()
+    model(x.to(DEV)).backward(dy.to(DEV))
+    assert len(plans) == n_plans == 3
