@@ -280,7 +280,8 @@ def gather_add_act(t: Tensor, p_dst: Tensor, p_src: Tensor, dst: Tensor, src: Te
         return out
     if dst.dtype != torch.int32 or src.dtype != torch.int32 or dst.shape[0] != e or src.shape[0] != e:
         raise ValueError("gather_add_act: dst / src must be int32 [E]")
-    with _Timed("gather_add_act", bytes=4 * e * c * t.element_size()):
+    # compulsory bytes: t read + result written per edge, each node table once, the two index lists
+    with _Timed("gather_add_act", bytes=(2 * e + p_dst.shape[0] + p_src.shape[0]) * c * t.element_size() + 8 * e):
         st = _lib.load().anemoi_gather_add_act(dtype_code(t.dtype), t.data_ptr(), _ld(t), p_dst.data_ptr(),
                                                _ld(_rows(p_dst)), p_src.data_ptr(), _ld(_rows(p_src)), dst.data_ptr(),
                                                src.data_ptr(), out.data_ptr(), _ld(_rows(out)), e, c,

@@ -15,8 +15,10 @@ The JSON line also carries
   roofline      the dominant kernel (fused Linear, MFMA bound): algorithmic flops / measured kernel time, live,
                 from HIP events on the launch stream in a separate instrumented pass (not inside the timed region);
   roofline_edge the fused gather/scatter edge kernel against the HBM roofline (algorithmic bytes of section 8d);
-  cpu_baseline  the CPU oracle (plain PyTorch, same algorithm as the reference) timed on this host's cores on a
-                bounded sample of the same workload.
+  cpu_baseline  the CPU oracle (plain PyTorch, same algorithm as the reference) timed on this host's cores on the same
+                forward: encoder and decoder in full, a bounded number of the identical processor blocks, scaled.
+``value`` / ``ms_per_step`` come from the K-step bracket the driver's contract prescribes (mean); ``ms_per_step_median``
+/ ``value_at_median`` are the per-step median (device events on the launch stream, rank 0) SURVEY section 8d asks for.
 """
 
 from __future__ import annotations
@@ -54,7 +56,9 @@ def parse_args():
     ap.add_argument("--processor", default="GraphTransformer", choices=["GraphTransformer", "GNN", "Transformer"],
                     help="processor family (BASELINE config 5 = --workload cfg2 --processor GNN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-blocks", type=int, default=2, help="processor blocks in the CPU-baseline sample")
+    ap.add_argument("--cpu-blocks", type=int, default=None,
+                    help="processor blocks the CPU-baseline sample runs (default: 1 for cfg3, all for cfg1 / cfg2); the "
+                         "encoder and decoder always run in full")
     ap.add_argument("--rollout", type=int, default=1,
                     help="autoregressive forecasts per step (BASELINE config 4 = --rollout 4): forward, then the "
                          "in-place input update anemoi_advance_input, repeated")
@@ -163,20 +167,26 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
                 "launches": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                 "bytes_per_launch": a["bytes"] / a["launches"],
             }
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (PMC counters cannot be
-    # collected from inside the process; see profiles/r01_traffic.json for the command and the gfx950 corrections)
+    # HBM traffic per launch: PMC counters cannot be read from inside the process, so the figure is the one of the latest
+    # COMMITTED rocprofv3 --pmc passes of this same command (tools/refresh_profiles.sh -> profiles/rNN_traffic.json) and
+    # is labelled as such ("traffic_source": not measured in this run); null when no pass exists for this configuration.
     try:
-        if not traffic_ok or group is not None:  # the PMC passes were taken on config 3 / bf16 / one GPU only
+        if not traffic_ok or group is not None:  # the PMC passes are taken on config 3 / bf16 / one GPU only
             raise KeyError("no PMC pass for this run")
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        import glob
+
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))[-1]
+        with open(latest) as f:
             traffic = json.load(f)["kernels"]
+        label = f"profiles/{os.path.basename(latest)}: rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE passes of this command, " \
+                "committed earlier -- NOT measured in this run"
         if "roofline" in out and dtype_name == "bf16":
             out["roofline"]["traffic"] = traffic["linear"]["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = label
         if "roofline_edge" in out and dtype_name == "bf16":
             out["roofline_edge"]["traffic"] = traffic["gt_edge_attention"]["traffic_bytes_per_launch"]
-            out["roofline_edge"]["traffic_source"] = "profiles/r01_traffic.json"
-    except (OSError, KeyError, ValueError):
+            out["roofline_edge"]["traffic_source"] = label
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     total_ms = sum(a["ms"] for a in agg.values())
     out["kernel_time_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
@@ -185,34 +195,71 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
     return out
 
 
-def cpu_baseline(model, graph, n_blocks: int):
-    """CPU oracle (plain PyTorch restatement of the reference algorithm) on a bounded sample of the workload.
+def cpu_baseline(model, graph, x, idx, n_blocks: int):
+    """CPU oracle (plain-PyTorch restatement of the reference algorithm, oracle/reference_path.py) timed on this host's
+    cores on the SAME forward as the headline value: input assembly, encoder, processor, decoder, prognostic residual.
 
-    Sample: the first ``n_blocks`` GraphTransformer processor blocks at the full mesh size / channel width, f32, all
-    host cores PyTorch uses.  The unit is the metric's: mesh-node updates per second over those blocks.
+    Bounded sample: the encoder and the decoder run in full; of the ``L`` identical processor blocks the first
+    ``n_blocks`` run (all of them when ``n_blocks >= L``) and the step time is ``t_enc + t_blocks * L / n_blocks + t_dec``
+    -- the blocks are the same code on the same shapes, so the scaling is exact up to cache warmth.  Mapper blocks use
+    the reference's own inference chunking (``num_chunks`` 8 at the N320 grid) to bound host memory.
     """
+    import platform
+
     from oracle import reference_path as ref  # checker / baseline only
 
-    p = model.processor
-    sd = {"processor." + k: v.detach().float().cpu() for k, v in p.state_dict().items()}
-    edge_attr = ref.trainable_tensor(p.edge_attr.cpu(), sd["processor.trainable.trainable"], 1)
-    edge_index = p.edge_index_base.cpu()
-    n_mesh, c = graph["hidden"].num_nodes, model.num_channels
-    heads = p.proc[0].blocks[0].num_heads
-    xm = torch.randn(n_mesh, c, generator=torch.Generator().manual_seed(3))
-    blocks = [f"processor.proc.{ci}.blocks.{bi}" for ci in range(len(p.proc)) for bi in range(len(p.proc[ci].blocks))]
-    blocks = blocks[:n_blocks]
+    sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in model.state_dict().items()}
+    data, hidden = model._graph_name_data, model._graph_name_hidden
+
+    def edges(mod):
+        return mod.edge_attr.detach().float().cpu(), mod.edge_index_base.cpu()
+
+    heads = model.processor.proc[0].blocks[0].num_heads
+    n_layers = sum(len(chunk.blocks) for chunk in model.processor.proc)
+    names = [f"processor.proc.{ci}.blocks.{bi}" for ci, chunk in enumerate(model.processor.proc)
+             for bi in range(len(chunk.blocks))]
+    n_blocks = max(1, min(n_blocks, n_layers))
+    n_grid, n_mesh = graph[data].num_nodes, graph[hidden].num_nodes
+    mapper_chunks = 8 if n_grid > 200_000 else 1
+    xc = x.detach().float().cpu()
+    b, t, ens, g, v = xc.shape
+    tick = time.perf_counter
     with torch.no_grad():
-        ref.gt_processor_block(sd, blocks[0], xm[:256], edge_attr[:8], edge_index[:, :8] % 256, heads)  # warm-up
-        t0 = time.perf_counter()
-        for name in blocks:
-            xm = ref.gt_processor_block(sd, name, xm, edge_attr, edge_index, heads)
-        dt = time.perf_counter() - t0
+        t0 = tick()
+        x_data = torch.cat((xc.permute(0, 2, 3, 1, 4).reshape(b * ens * g, t * v), ref.node_attributes(sd, data, b)), dim=-1)
+        x_hidden = ref.node_attributes(sd, hidden, b)
+        ea, ei = edges(model.encoder)
+        _, x_latent = ref.gt_forward_mapper(sd, "encoder", x_data, x_hidden, ea, ei, b, heads, "GELU", mapper_chunks)
+        t_enc = tick() - t0
+        ea, ei = edges(model.processor)
+        edge_attr = ref.trainable_tensor(ea, sd.get("processor.trainable.trainable"), b)
+        t0 = tick()
+        xm = x_latent
+        for name in names[:n_blocks]:
+            xm = ref.gt_processor_block(sd, name, xm, edge_attr, ei, heads)
+        t_blk = tick() - t0
+        ea, ei = edges(model.decoder)
+        t0 = tick()
+        y = ref.gt_backward_mapper(sd, "decoder", xm + x_latent, x_data, ea, ei, b, heads, "GELU", mapper_chunks)
+        y = y.reshape(b, ens, g, -1).clone()
+        pin, pout = [int(i) for i in model._internal_input_idx], [int(i) for i in model._internal_output_idx]
+        y[..., pout] += xc[:, -1, :, :, pin]
+        t_dec = tick() - t0
+    t_fwd = t_enc + t_blk * n_layers / n_blocks + t_dec
+    cpu = platform.processor() or platform.machine()
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    scaled = "" if n_blocks == n_layers else f" x {n_layers}/{n_blocks}"
     return {
-        "value": round(n_mesh * len(blocks) / dt, 1), "unit": "mesh-node updates/s", "cores": torch.get_num_threads(),
-        "kind": "port",
-        "sample": f"{len(blocks)} of {len(p.proc) * len(p.proc[0].blocks)} GraphTransformer processor blocks at full "
-                  f"size ({n_mesh} mesh nodes, {c} ch, f32, CPU oracle = plain PyTorch), {dt:.1f} s; mappers excluded",
+        "value": round(n_mesh * n_layers / t_fwd, 1), "unit": "mesh-node updates/s", "cores": torch.get_num_threads(),
+        "kind": "port", "cpu": cpu,
+        "sample": f"the same forward on the CPU oracle (plain PyTorch f32, oracle/reference_path.py): input assembly + "
+                  f"encoder {t_enc:.1f} s + {n_blocks} of {n_layers} processor blocks {t_blk:.1f} s{scaled} + decoder + "
+                  f"residual {t_dec:.1f} s = {t_fwd:.1f} s per step ({n_grid} grid / {n_mesh} mesh nodes, "
+                  f"{model.num_channels} ch, mapper chunks {mapper_chunks}); measured {t_enc + t_blk + t_dec:.1f} s",
     }
 
 
@@ -292,12 +339,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # per-step marks on the launch stream (an event record costs < 1 us of host time and nothing on the device): the
+    # median step time of SURVEY section 8d next to the mean the K-step bracket gives
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1]
+                                                                             + per_step[len(per_step) // 2])
     if group is not None:
         import torch.distributed as dist
 
@@ -314,6 +369,8 @@ def main():
         line = {
             "metric": "mesh-node updates/sec (fwd step)", "value": round(value, 1), "unit": "mesh-node updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step_median": round(median_ms, 3),
+            "value_at_median": round(n_mesh * layers * args.rollout / (median_ms * 1e-3), 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {
@@ -330,7 +387,8 @@ def main():
         if args.processor != "GraphTransformer":
             line["config"]["workload"] = line["config"]["workload"].replace("GT blocks", f"{args.processor} blocks")
         if not args.no_cpu_baseline and world == 1 and args.processor == "GraphTransformer":
-            line["cpu_baseline"] = cpu_baseline(model, graph, args.cpu_blocks)
+            n_cpu = args.cpu_blocks if args.cpu_blocks is not None else (1 if args.workload == "cfg3" else layers)
+            line["cpu_baseline"] = cpu_baseline(model, graph, x, idx, n_cpu)
         print(json.dumps(line), flush=True)
     if group is not None:
         import torch.distributed as dist

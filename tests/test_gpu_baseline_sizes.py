@@ -1,0 +1,164 @@
+"""Parity at the BASELINE configurations' OWN sizes (north star: "outputs match the reference PyTorch-CPU forward on
+identical random weights and a synthetic O96 atmospheric state within 1e-3 rel fp32").
+
+* config 2: O96 -> ico-5, **all 16** GraphTransformer blocks, 512 channels, 16 heads -- f32 gated at 1e-3, bf16 reported
+  against the f32 oracle with a stated bound;
+* config 5: the same graph with 16 GNN blocks (pure edge-MLP message passing) -- f32 gated at 1e-3, bf16 with a bound;
+* config 4 semantics at O96: a 2-step autoregressive rollout behind the interface (normaliser + model + advance_input).
+
+The oracle (plain-PyTorch restatement, pinned to the reference by tests/test_oracle_golden.py) runs once per module on
+the host cores (7-15 s per forward at these sizes).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_path as ref
+from test_oracle_golden import graph_tensors
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+N_PROG, N_FORC, N_DIAG = 20, 4, 2
+BF16_BOUND = 5e-2  # bf16 storage / f32 accumulate over 16 residual blocks vs the f32 oracle (measured value is printed)
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def per_variable_rel_err(got, want):
+    """SURVEY §8d parity gate: max over output variables of ||a - b||_inf / ||b||_inf."""
+    got, want = got.float().cpu(), want.float().cpu()
+    num = (got - want).abs().flatten(0, -2).max(dim=0).values
+    den = want.abs().flatten(0, -2).max(dim=0).values.clamp_min(1e-30)
+    return float((num / den).max())
+
+
+def _make(processor):
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.models import AnemoiModelEncProcDec
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    graph = build_graph("o96_ico5")
+    idx = SimpleDataIndices(n_prognostic=N_PROG, n_forcing=N_FORC, n_diagnostic=N_DIAG)
+    torch.manual_seed(1234)
+    model = AnemoiModelEncProcDec(model_config=model_config(processor, 512, 16, 16), data_indices=idx, graph_data=graph)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    model.eval()
+    x = torch.randn(1, 2, 1, graph["data"].num_nodes, idx.num_input, generator=torch.Generator().manual_seed(7))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = ref.model_forward(sd, graph_tensors(graph), x, num_heads=16, num_layers=16, num_chunks=2,
+                                 prognostic_in=range(N_PROG), prognostic_out=range(N_PROG), processor=processor)
+    return model.to(DEV), x.to(DEV), want, graph, idx
+
+
+@pytest.fixture(scope="module")
+def o96_gt():
+    return _make("GraphTransformer")
+
+
+@pytest.fixture(scope="module")
+def o96_gnn():
+    return _make("GNN")
+
+
+def test_config2_o96_ico5_512ch_16_blocks_f32_vs_oracle(o96_gt, monkeypatch):
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32")
+    model, x, want, _, _ = o96_gt
+    with torch.no_grad():
+        got = model(x)
+    err, err_v = rel_err(got, want), per_variable_rel_err(got, want)
+    print(f"config 2 (O96 -> ico-5, 16 GT blocks, 512 ch) f32 vs CPU oracle: max rel {err:.3e}, per variable {err_v:.3e}")
+    assert got.dtype == torch.float32 and got.shape == want.shape
+    assert err < 1e-3 and err_v < 1e-3  # north-star gate
+
+
+def test_config2_o96_ico5_512ch_16_blocks_bf16_vs_oracle(o96_gt, monkeypatch):
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    model, x, want, _, _ = o96_gt
+    with torch.no_grad():
+        got = model(x)
+    err = rel_err(got, want)
+    print(f"config 2 bf16 storage / f32 accumulate vs f32 CPU oracle: max rel {err:.3e} (bound {BF16_BOUND})")
+    assert torch.isfinite(got).all() and err < BF16_BOUND
+
+
+def test_config5_gnn_o96_512ch_16_blocks_f32_vs_oracle(o96_gnn, monkeypatch):
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32")
+    model, x, want, _, _ = o96_gnn
+    with torch.no_grad():
+        got = model(x)
+    err, err_v = rel_err(got, want), per_variable_rel_err(got, want)
+    print(f"config 5 (O96, 16 GNN blocks, 512 ch) f32 vs CPU oracle: max rel {err:.3e}, per variable {err_v:.3e}")
+    assert err < 1e-3 and err_v < 1e-3
+
+
+def test_config5_gnn_o96_512ch_16_blocks_bf16_vs_oracle(o96_gnn, monkeypatch):
+    """The 512-channel bf16 route of the GNN processor (persistent GEMM, 16-byte-lane gather_add_act, segment_sum)."""
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    model, x, want, _, _ = o96_gnn
+    with torch.no_grad():
+        got = model(x)
+    err = rel_err(got, want)
+    print(f"config 5 bf16 vs f32 CPU oracle: max rel {err:.3e} (bound {BF16_BOUND})")
+    assert torch.isfinite(got).all() and err < BF16_BOUND
+
+
+def test_rollout_2_steps_o96_vs_oracle(monkeypatch):
+    """BASELINE config 4 semantics at O96 / 512 ch / 16 blocks: 2 autoregressive steps through
+    ``AnemoiModelInterface.rollout`` (normaliser folded into the first / last kernel, ``anemoi_advance_input`` between the
+    steps) against ``oracle.rollout`` (each step the pinned ``model_forward`` + the reference normaliser arithmetic)."""
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.interface import AnemoiModelInterface
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32")
+    graph = build_graph("o96_ico5")
+    n_prog, n_forc, n_diag = 10, 2, 1
+    n_all = n_prog + n_forc + n_diag
+    cfg = model_config("GraphTransformer", 512, 16, 16)
+    cfg["data"] = {"forcing": [f"forc_{i}" for i in range(n_forc)], "diagnostic": ["diag_0"],
+                   "processors": {"normalizer": {"_target_": "anemoi.models.preprocessing.normalizer.InputNormalizer",
+                                                 "config": {"default": "mean-std", "min-max": ["prog_3"],
+                                                            "max": ["prog_4"], "none": ["forc_0"]}}}}
+    cfg["model"]["model"] = {"_target_": "anemoi.models.models.encoder_processor_decoder.AnemoiModelEncProcDec"}
+    gen = torch.Generator().manual_seed(11)
+    mean = (torch.randn(n_all, generator=gen) * 3.0).numpy().astype(np.float32)
+    stdev = (0.5 + torch.rand(n_all, generator=gen) * 2.0).numpy().astype(np.float32)
+    stats = {"mean": mean, "stdev": stdev, "minimum": mean - 3.0 * stdev, "maximum": mean + 3.5 * stdev}
+    idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
+    torch.manual_seed(1234)
+    iface = AnemoiModelInterface(config=type(cfg)(cfg), graph_data=graph, statistics=stats, data_indices=idx, metadata={})
+    with torch.no_grad():
+        for name, p in iface.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    iface.eval()
+    n_grid = graph["data"].num_nodes
+    in_idx = idx.data.input.full.long()
+    z = torch.randn((1, 2, n_grid, n_prog + n_forc), generator=torch.Generator().manual_seed(7))
+    batch = z * torch.from_numpy(stdev)[in_idx] + torch.from_numpy(mean)[in_idx]
+    f_in = idx.internal_model.input.forcing.long()
+    f_data = in_idx[f_in]
+    zf = torch.randn((2, 1, n_grid, n_forc), generator=torch.Generator().manual_seed(8))
+    forcings = zf * torch.from_numpy(stdev)[f_data] + torch.from_numpy(mean)[f_data]
+    sd = {k: v.clone() for k, v in iface.state_dict().items()}
+    with torch.no_grad():
+        want = ref.rollout(sd, graph_tensors(graph), batch, 2, forcings, multi_step=2, prognostic_in=range(n_prog),
+                           prognostic_out=range(n_prog), forcing_in=f_in.tolist(), num_heads=16, num_layers=16,
+                           num_chunks=2)
+    iface = iface.to(DEV)
+    got = iface.rollout(batch.to(DEV), 2, forcings.to(DEV))
+    assert got.shape == want.shape
+    e1, e2 = per_variable_rel_err(got[0], want[0]), per_variable_rel_err(got[1], want[1])
+    print(f"O96 rollout, f32, per-variable rel err: step 1 {e1:.3e}, step 2 {e2:.3e}")
+    assert e1 < 1e-3 and e2 < 1e-3
