@@ -103,11 +103,71 @@ def build_edge_plan(edge_index: Tensor, n_src: int, n_dst: int) -> EdgePlan:
                     n_dst)
 
 
+_PLAN_DIR: Optional[str] = None
+
+
+def set_plan_cache_dir(path: Optional[str]) -> None:
+    """Directory of the on-disk plan cache (``None`` = off unless ``ANEMOI_AMD_PLAN_CACHE_DIR`` is set).
+
+    A plan is a pure function of the graph (edge index, node relabelling, batch size), so it is keyed on a content hash
+    of exactly those inputs: the same anemoi-graphs file gives the same keys in every process, on every rank, across
+    restarts.  Files are written atomically (temporary name + rename): concurrent ranks may race to
+    write the same plan and all of them read a complete file."""
+    global _PLAN_DIR
+    _PLAN_DIR = path
+
+
+def plan_cache_dir() -> Optional[str]:
+    return _PLAN_DIR or os.environ.get("ANEMOI_AMD_PLAN_CACHE_DIR") or None
+
+
+def tensor_digest(*items) -> str:
+    """Content hash (BLAKE2b-128, hex) of tensors / ints / strings / None, order sensitive."""
+    import hashlib
+
+    h = hashlib.blake2b(digest_size=16)
+    for it in items:
+        if isinstance(it, Tensor):
+            t = it.detach().cpu().contiguous()
+            h.update(f"T{t.dtype}{tuple(t.shape)}".encode())
+            h.update(t.view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+        else:
+            h.update(f"V{it!r}".encode())
+    return h.hexdigest()
+
+
+def graph_hash(graph) -> str:
+    """Content hash of a graph object (``HeteroData`` or this package's ``GraphData``): node coordinates, edge indices
+    and edge attributes of every store, in a canonical order -- the identity of an anemoi-graphs file's CONTENT."""
+    items = []
+    for name, store in sorted(graph.node_items(), key=lambda kv: kv[0]):
+        items += ["node", name, store.x]
+    edge_types = sorted(graph.edge_types) if hasattr(graph, "edge_types") else []
+    for key in edge_types:
+        store = graph[key]
+        items += ["edge", "/".join(key), store["edge_index"]]
+        for k in sorted(k for k in store.keys() if k != "edge_index"):
+            v = store[k]
+            if isinstance(v, Tensor):
+                items += [k, v]
+    return tensor_digest(*items)
+
+
 class PlanCache:
-    """Edge plans keyed by the identity + version of the edge-index tensor they were built from."""
+    """Edge plans keyed by the identity + version of the edge-index tensor they were built from; behind it, when a
+    directory is configured (:func:`set_plan_cache_dir`), an on-disk cache keyed on the CONTENT of the plan's inputs."""
 
     def __init__(self) -> None:
         self._plans: dict = {}
+
+    @staticmethod
+    def _disk_path(edge_index, n_src, n_dst, batch_size, edge_inc, src_map, dst_map) -> Optional[str]:
+        root = plan_cache_dir()
+        if root is None:
+            return None
+        key = tensor_digest("edgeplan-v1", edge_index, n_src, n_dst, batch_size, edge_inc if batch_size > 1 else None,
+                            src_map, dst_map)
+        return os.path.join(root, f"edgeplan-{key}.pt")
 
     def get(self, edge_index: Tensor, n_src: int, n_dst: int, batch_size: int = 1,
             edge_inc: Optional[Tensor] = None, src_map: Optional[Tensor] = None,
@@ -119,18 +179,47 @@ class PlanCache:
                None if dst_map is None else dst_map.data_ptr())
         plan = self._plans.get(key)
         if plan is None:
-            ei = edge_index
-            if src_map is not None or dst_map is not None:
-                src = ei[0] if src_map is None else src_map[ei[0]]
-                dst = ei[1] if dst_map is None else dst_map[ei[1]]
-                ei = torch.stack([src, dst])
-            if batch_size > 1:
-                ei = expand_edges(ei, edge_inc, batch_size)
-            plan = build_edge_plan(ei, n_src, n_dst)
+            path = self._disk_path(edge_index, n_src, n_dst, batch_size, edge_inc, src_map, dst_map)
+            if path is not None and os.path.exists(path):
+                plan = load_edge_plan(path, edge_index.device)
+            if plan is None:
+                ei = edge_index
+                if src_map is not None or dst_map is not None:
+                    src = ei[0] if src_map is None else src_map[ei[0]]
+                    dst = ei[1] if dst_map is None else dst_map[ei[1]]
+                    ei = torch.stack([src, dst])
+                if batch_size > 1:
+                    ei = expand_edges(ei, edge_inc, batch_size)
+                plan = build_edge_plan(ei, n_src, n_dst)
+                if path is not None:
+                    save_edge_plan(plan, path)
             if len(self._plans) > 16:
                 self._plans.clear()
             self._plans[key] = plan
         return plan
+
+
+def save_edge_plan(plan: EdgePlan, path: str) -> None:
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tmp = f"{path}.{os.getpid()}.tmp"
+    torch.save({"format": "anemoi_models_amd.EdgePlan/1", "rowptr": plan.rowptr.cpu(), "col": plan.col.cpu(),
+                "perm": plan.perm.cpu(), "n_src": plan.n_src, "n_dst": plan.n_dst}, tmp)
+    os.replace(tmp, path)
+
+
+def load_edge_plan(path: str, device) -> Optional[EdgePlan]:
+    """The plan stored at ``path`` on ``device``; ``None`` for a file that is not a complete, consistent plan (it is then
+    rebuilt and overwritten)."""
+    try:
+        d = torch.load(path, map_location="cpu", weights_only=True)
+        ok = (d.get("format") == "anemoi_models_amd.EdgePlan/1" and d["rowptr"].dtype == torch.int32
+              and d["rowptr"].shape[0] == d["n_dst"] + 1 and d["col"].shape == d["perm"].shape
+              and int(d["rowptr"][-1]) == d["col"].shape[0])
+    except Exception:  # noqa: BLE001  (truncated / foreign file: fall back to building)
+        return None
+    if not ok:
+        return None
+    return EdgePlan(d["rowptr"].to(device), d["col"].to(device), d["perm"].to(device), int(d["n_src"]), int(d["n_dst"]))
 
 
 def locality_order(sincos_latlon: Tensor) -> Tensor:
