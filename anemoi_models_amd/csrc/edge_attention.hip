@@ -339,8 +339,57 @@ constexpr int attrs_per_lane(int up, int lph) {  // smallest divisor of UP in {2
   return up;
 }
 
-template <typename T, int VEC, int LPH, int UP, int U = 4>
-__global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const EdgeFoldParams p,
+// Raw (unconverted) words of N consecutive elements: what a prefetched operand is carried in from one destination to the
+// next -- converting at load time would pin the s_waitcnt to the load instead of to the first use.
+template <typename T, int N>
+struct RawWords {
+  static constexpr int W = (N * (int)sizeof(T) + 3) / 4;
+  uint32_t w[W];
+  // ``base`` is wave-uniform (SGPR pair), ``off`` the lane's byte offset: the access compiles to the saddr + voffset
+  // form, so no 64-bit per-lane pointer is kept alive (this kernel lives at the 96-VGPR edge of 5 waves per SIMD)
+  __device__ __forceinline__ void load(const char* base, uint32_t off, bool nt) {
+    const T* p = reinterpret_cast<const T*>(base + off);
+    if constexpr (W % 4 == 0) {
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int i = 0; i < W / 4; ++i) {
+        const u32x4_t t = nt ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p) + i)
+                             : reinterpret_cast<const u32x4_t*>(p)[i];
+        w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+      }
+    } else if constexpr (W % 2 == 0) {
+#pragma unroll
+      for (int i = 0; i < W / 2; ++i) {
+        const uint2 t = reinterpret_cast<const uint2*>(p)[i];
+        w[2 * i] = t.x; w[2 * i + 1] = t.y;
+      }
+    } else {
+      static_assert(N * sizeof(T) % 4 == 0, "whole words");
+#pragma unroll
+      for (int i = 0; i < W; ++i) w[i] = reinterpret_cast<const uint32_t*>(p)[i];
+    }
+  }
+  __device__ __forceinline__ void get(float (&r)[N]) const {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) r[i] = __uint_as_float(w[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) r[i] = __uint_as_float((i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16));
+    }
+  }
+};
+
+// PIPE: how much of the NEXT destination is requested while the current one is processed.  The kernel is bound by its
+// chain of dependent memory round trips per destination (row pointers -> columns -> k|v gathers, q before the first
+// score, x_r before the store), not by bytes or VALU:
+//   0  nothing (the loop of the first version: every operand is requested when it is needed)
+//   1  x_r is requested together with q at the start of the destination
+//   2  + the next destination's row pointers, q, u and x_r are requested before the current one's edge loop
+//   3  + the columns of the following edge batch (this destination's next U edges, or the next destination's first U)
+//      are requested while the current batch is processed
+template <typename T, int VEC, int LPH, int UP, int U = 4, int PIPE = 3, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void gt_edge_attention_folded_kernel(const EdgeFoldParams p,
                                                                    const float* __restrict__ attr_,
                                                                    const int32_t* __restrict__ rowptr_,
                                                                    const int32_t* __restrict__ col_) {
@@ -367,29 +416,72 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
   const bool a_own = a0 < UP;        // the last lanes of a head own none when LPH * APL > UP (u = 0, nothing stored)
   const int a_ld = a_own ? a0 : 0;
   const float amask = a_own ? 1.f : 0.f;
+  const bool nt = p.stream_hint != 0;
+  const bool has_xr = p.xr != nullptr;
 
-  const T* qb = static_cast<const T*>(p.q) + c0;
-  const T* kb = static_cast<const T*>(p.k) + c0;
-  const T* vb = static_cast<const T*>(p.v) + c0;
-  const T* ub = static_cast<const T*>(p.u) + head * UP + a_ld;
-  const float* ab = attr_ + a_ld;
+  // wave-uniform row bases (bytes) + 32-bit lane offsets
+  constexpr int64_t ES = (int64_t)sizeof(T);
+  const char* qb = static_cast<const char*>(p.q);
+  const char* kb = static_cast<const char*>(p.k);
+  const char* vb = static_cast<const char*>(p.v);
+  const char* ub = static_cast<const char*>(p.u);
+  const char* rb = has_xr ? static_cast<const char*>(p.xr) : qb;
+  const int64_t ldq_b = p.ldq * ES, ldkv_b = p.ldkv * ES, ldu_b = p.ldu * ES, ldo_b = p.ldo * ES;
+  const int64_t ldr_b = (has_xr ? p.ldr : p.ldq) * ES;
+  const char* ab = reinterpret_cast<const char*>(attr_);
+  const uint32_t off_c = (uint32_t)(c0 * (int)sizeof(T));
+  const uint32_t off_u = (uint32_t)((head * UP + a_ld) * (int)sizeof(T));
+  const uint32_t off_a = (uint32_t)(a_ld * 4);
 
-  for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
-    const int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
+  int64_t node = n0 + node_first;
+  if (node >= n1) return;
+  // streaming operands of the current destination (requested one destination ahead when PIPE >= 2)
+  RawWords<T, VEC> q_raw, xr_raw;
+  RawWords<T, APL> u_raw;
+  int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
+  int cj[U];  // source rows of the edge batch about to be processed (PIPE >= 3)
+  if constexpr (PIPE >= 2) {
+    q_raw.load(qb + node * ldq_b, off_c, nt);
+    u_raw.load(ub + node * ldu_b, off_u, false);
+    xr_raw.load(rb + node * ldr_b, off_c, nt);
+  }
+  if constexpr (PIPE >= 3) {
+    const int last = e_end > e_begin ? e_end - 1 : (e_begin > 0 ? e_begin - 1 : 0);
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) cj[uu] = col_[e_begin + uu < last ? e_begin + uu : last];
+  }
+
+  for (;;) {
+    const int64_t next = node + node_stride;
+    const bool has_next = next < n1;
+    const int64_t nn = has_next ? next : node;
+    RawWords<T, VEC> q_n, xr_n;
+    RawWords<T, APL> u_n;
+    int eb_n = 0, ee_n = 0;
+    if constexpr (PIPE >= 2) {  // the next destination's streams go out first: they are the long (HBM) round trips
+      eb_n = rowptr_[nn];
+      ee_n = rowptr_[nn + 1];
+      q_n.load(qb + nn * ldq_b, off_c, nt);
+      u_n.load(ub + nn * ldu_b, off_u, false);
+      xr_n.load(rb + nn * ldr_b, off_c, nt);
+    } else {
+      q_raw.load(qb + node * ldq_b, off_c, nt);
+      u_raw.load(ub + node * ldu_b, off_u, false);
+      if constexpr (PIPE >= 1) xr_raw.load(rb + node * ldr_b, off_c, nt);
+    }
     QK<T, VEC> qk;
     float u[APL];
     {
       float qf[VEC];
-      if (p.stream_hint) load_stream<T, VEC>(qb + node * p.ldq, qf);
-      else VecIO<T, VEC>::load(qb + node * p.ldq, qf);
+      q_raw.get(qf);
       qk.set(qf);
-      VecIO<T, APL>::load(ub + node * p.ldu, u);
+      u_raw.get(u);
 #pragma unroll
       for (int i = 0; i < APL; ++i) u[i] *= amask;
     }
     float m = -INFINITY, l = 0.f;
     // the value accumulators live as f32 pairs: rescale and accumulate are v_pk_mul_f32 / v_pk_fma_f32 (two channels per
-    // issue slot) -- this loop is bound by its instruction streams, not by bytes
+    // issue slot)
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
     constexpr int VP = (VEC + 1) / 2;
     f32x2_t acc[VP];
@@ -399,6 +491,13 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
 #pragma unroll
     for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
 
+    if constexpr (PIPE >= 3) {
+      if (e_begin == e_end) {  // destination without edges: the batch loop below does not run and cannot refill cj
+        const int last = ee_n > eb_n ? ee_n - 1 : (eb_n > 0 ? eb_n - 1 : 0);
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) cj[uu] = col_[eb_n + uu < last ? eb_n + uu : last];
+      }
+    }
     for (int e = e_begin; e < e_end; e += U) {
       Raw kr[U], vr[U];
       float at[U][APL];
@@ -406,11 +505,19 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
         if (e + uu < e_end) {
-          const int64_t j = col_[e + uu];
-          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
-          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
-          VecIO<float, APL>::load(ab + (int64_t)(e + uu) * UP, at[uu]);
+          const int64_t j = PIPE >= 3 ? (int64_t)cj[uu] : (int64_t)col_[e + uu];
+          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * ldkv_b + off_c);
+          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * ldkv_b + off_c);
+          VecIO<float, APL>::load(reinterpret_cast<const float*>(ab + (int64_t)(e + uu) * (UP * 4) + off_a), at[uu]);
         }
+      }
+      if constexpr (PIPE >= 3) {  // columns of the batch after this one (clamped: never past the rows' last edge)
+        const bool more = e + U < e_end;
+        const int pb = more ? e + U : eb_n;
+        const int pe = more ? e_end : ee_n;
+        const int last = pe > pb ? pe - 1 : (pb > 0 ? pb - 1 : 0);
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) cj[uu] = col_[pb + uu < last ? pb + uu : last];
       }
       float mb = m;
 #pragma unroll
@@ -452,23 +559,35 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
     float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
-    if (p.xr != nullptr) {
+    if (has_xr) {
       float r[VEC];
-      if (p.stream_hint) load_stream<T, VEC>(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
-      else VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + c0 + node * p.ldr, r);
+      if constexpr (PIPE == 0) xr_raw.load(rb + node * ldr_b, off_c, nt);
+      xr_raw.get(r);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] += r[i];
     }
-    T* on = static_cast<T*>(p.out) + node * p.ldo;
+    char* on = static_cast<char*>(p.out) + node * ldo_b;
     if (active) {
-      if (p.stream_hint) store_stream<T, VEC>(on + c0, o);
-      else VecIO<T, VEC>::store(on + c0, o);
+      if (nt) store_stream<T, VEC>(reinterpret_cast<T*>(on + off_c), o);
+      else VecIO<T, VEC>::store(reinterpret_cast<T*>(on + off_c), o);
     }
     if (active && a_own) {  // this lane's APL values of t~_i,h
       float t4[APL];
 #pragma unroll
       for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
-      VecIO<T, APL>::store(on + p.C + head * UP + a0, t4);
+      VecIO<T, APL>::store(reinterpret_cast<T*>(on + (uint32_t)((p.C + head * UP + a0) * (int)sizeof(T))), t4);
+    }
+    if (!has_next) break;
+    node = next;
+    if constexpr (PIPE >= 2) {
+      q_raw = q_n;
+      u_raw = u_n;
+      xr_raw = xr_n;
+      e_begin = eb_n;
+      e_end = ee_n;
+    } else {
+      e_begin = rowptr_[node];
+      e_end = rowptr_[node + 1];
     }
   }
 }
@@ -492,15 +611,22 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   // (a register-double-buffered software pipeline across destinations was measured and removed: 0.30 / 1.98 / 0.79 ms
   // against 0.19 / 1.21 / 0.60 ms of this loop on the mesh / decoder / encoder graphs of config 3 -- the second
   // register set costs a wave per SIMD, which hurts more than the overlap helps)
-  if (edges_in_flight == 8)
-    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 8>), dim3((unsigned)(8 * bpx)),
-                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
-  else if (edges_in_flight == 2)
-    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 2>), dim3((unsigned)(8 * bpx)),
-                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
-  else
-    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 4>), dim3((unsigned)(8 * bpx)),
-                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
+  static const int pipe = [] {  // A/B: ANEMOI_AMD_EDGE_PIPE in {0, 1, 2, 3} (see the kernel), default 3
+    const char* e = getenv("ANEMOI_AMD_EDGE_PIPE");
+    return e ? atoi(e) : 3;
+  }();
+  const dim3 grid((unsigned)(8 * bpx)), block(64 * WPB);
+#define ANEMOI_EDGE_LAUNCH(UU, PP, MW) \
+  hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, UU, PP, MW>), grid, block, 0, st, p, p.attr, p.rowptr, p.col)
+  if (edges_in_flight == 8) ANEMOI_EDGE_LAUNCH(8, 3, 1);
+  else if (edges_in_flight == 2) ANEMOI_EDGE_LAUNCH(2, 3, 1);
+  else if (pipe == 0) ANEMOI_EDGE_LAUNCH(4, 0, 1);
+  else if (pipe == 1) ANEMOI_EDGE_LAUNCH(4, 1, 1);
+  else if (pipe == 2) ANEMOI_EDGE_LAUNCH(4, 2, 1);
+  else if (pipe == 12) ANEMOI_EDGE_LAUNCH(4, 2, 5);  // (lab: the same with the register budget of 5 waves per SIMD)
+  else if (pipe == 13) ANEMOI_EDGE_LAUNCH(4, 3, 5);
+  else ANEMOI_EDGE_LAUNCH(4, 3, 1);
+#undef ANEMOI_EDGE_LAUNCH
 }
 
 template <typename T, int VEC, int LPH>

@@ -255,17 +255,13 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, in
 }
 
 // =============================================================================================
-// bf16 256 x 256 tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), K-slab 64, two LDS
-// stages of 64 KiB.  Twice the arithmetic intensity per L2/LDS byte of the 128 x 128 kernel (which is
-// L2-bandwidth bound on this chip beyond ~900 TFLOP/s).  Tiles are mapped XCD-aware: the 8 XCDs each walk
-// a contiguous range of the (mt, nt) tile list with nt fastest, so the tiles that share an x row panel
-// run on the same XCD (private L2) back to back.  The epilogue goes through LDS so that every output /
-// residual access is a full 128-byte row segment (16 bytes per lane).
+// bf16 256 x 256 tile, K-slab 64, two LDS stages of 64 KiB: twice the arithmetic intensity per L2 / LDS byte of the
+// 128 x 128 kernel (which is L2-bandwidth bound on this chip beyond ~900 TFLOP/s).  Tiles are mapped XCD-aware: the
+// 8 XCDs each walk a contiguous range of the tile list, so the tiles that share an operand panel run on the same XCD
+// (private L2) back to back.
 // =============================================================================================
 constexpr int BIG_M = 256, BIG_N = 256;
 constexpr int BIG_STAGE = (BIG_M + BIG_N) * ROW_BYTES;  // 64 KiB
-constexpr int BIG_EPI = 8 * 4096;                       // 4 KiB epilogue scratch per wave
-constexpr int BIG_LDS = 2 * BIG_STAGE + BIG_EPI;        // 160 KiB: the whole LDS of a CU, one workgroup per CU
 
 __device__ __forceinline__ uint32_t bf16x2_add(uint32_t a, uint32_t b) {
   const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
@@ -322,202 +318,11 @@ __device__ __forceinline__ void tile_coords(int64_t t64, int nt_count, int64_t m
   nt = (int)(cg * SUPER_N + r % width);
 }
 
-// unaligned / ragged-N tail of one 8-column output segment (cold path, kept out of line)
-__device__ __noinline__ void store_row_tail(uint4 v, const bf16_t* __restrict__ R, int64_t ldr, bf16_t* __restrict__ Y,
-                                            int64_t ldy, int64_t m, int n, int N) {
-  const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    if (n + c < N) {
-      float o = __uint_as_float((c & 1) ? (wv[c >> 1] & 0xffff0000u) : (wv[c >> 1] << 16));
-      if (R != nullptr) o += bf16_to_f32(R[m * ldr + n + c]);
-      Y[m * ldy + n + c] = f32_to_bf16(o);
-    }
-  }
-}
-
-// Persistent: gridDim.x = 8 * blocks_per_xcd workgroups (one per CU); the tile list (nt fastest) is cut into 8
-// contiguous per-XCD chunks and workgroup (xcd, i) takes tiles i, i + blocks_per_xcd, ... of its chunk, so at any
-// time the CUs of one XCD work on neighbouring tiles (shared x row panels / W column panels in that XCD's L2).
-// The K-slabs of consecutive tiles form ONE double-buffered stream: slab 0 of the next tile is already in flight
-// while the current tile's epilogue runs out of a separate 32 KiB LDS scratch.
-template <int ACT, bool HAS_RES>
-__global__ __launch_bounds__(512) void linear_bf16_256_kernel(const bf16_t* __restrict__ X, int64_t ldx,
-                                                              const bf16_t* __restrict__ W,
-                                                              const float* __restrict__ bias,
-                                                              const bf16_t* __restrict__ R, int64_t ldr,
-                                                              bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
-                                                              int K, int act, int vec_ok, int64_t n_tiles,
-                                                              int nt_count) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int64_t q8 = n_tiles / 8, r8 = n_tiles % 8;
-  const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int64_t chunk_len = q8 + (xcd < r8 ? 1 : 0);
-  if (bix >= chunk_len) return;
-  const int nk = K / 64;
-
-  // staging addresses of the tile whose K-slabs are currently being issued (one set: the next tile's
-  // addresses replace them right after the current tile's last slab has been issued)
-  const int srow = lane >> 3, scp = lane & 7;
-  const int r_first = wid * 32 + srow;  // row of this lane in row group i = 0; group i adds 8 * i
-  const char* xg[4];
-  const char* wg[4];
-  auto setup = [&](int64_t tile) {
-    int64_t mt_;
-    int nt_;
-    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
-    const int64_t m0 = mt_ * BIG_M;
-    const int n0 = nt_ * BIG_N;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = r_first + 8 * i;
-      const int c = swz(r, scp);
-      int64_t gm = m0 + r;
-      if (gm > M - 1) gm = M - 1;
-      int gn = n0 + r;
-      if (gn > N - 1) gn = N - 1;
-      xg[i] = reinterpret_cast<const char*>(X + gm * ldx) + c * 16;
-      wg[i] = reinterpret_cast<const char*>(W + (int64_t)gn * K) + c * 16;
-    }
-  };
-  auto stage = [&](int kt, int buf) {
-    char* xs = smem + buf * BIG_STAGE + wid * 4096;
-    char* ws = xs + BIG_M * ROW_BYTES;
-    const int64_t koff = (int64_t)kt * ROW_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(xg[i] + koff, xs + i * 1024);
-      glds16(wg[i] + koff, ws + i * 1024);
-    }
-  };
-
-  const int wm = wid >> 2, wn = wid & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-  char* region = smem + 2 * BIG_STAGE + wid * 4096;
-  const int rc = lane & 7, rr = lane >> 3;
-
-  setup(chunk_start + bix);
-  stage(0, 0);
-  int g = 0;  // running K-slab counter over all tiles of this workgroup: LDS stage = g & 1
-  for (int64_t li = bix; li < chunk_len; li += bpx) {
-    const int64_t tile = chunk_start + li;
-    const bool has_next = li + bpx < chunk_len;
-    int64_t mt_;
-    int nt_;
-    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
-    const int64_t m0 = mt_ * BIG_M;
-    const int n0 = nt_ * BIG_N;
-
-    f32x4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < nk; ++kt, ++g) {
-      __syncthreads();  // slab g landed for every wave; everyone is done reading the other stage
-      if (kt + 1 < nk) {
-        stage(kt + 1, (g + 1) & 1);
-      } else if (has_next) {
-        setup(tile + bpx);
-        stage(0, (g + 1) & 1);
-      }
-      const char* xs = smem + (g & 1) * BIG_STAGE;
-      const char* ws = xs + BIG_M * ROW_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = wn * 64 + i * 16 + fr;
-          a[i] = *reinterpret_cast<const bf16x8_t*>(ws + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
-        }
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-          bf16x8_t b[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row = wm * 128 + (jh * 4 + j) * 16 + fr;
-            b[j] = *reinterpret_cast<const bf16x8_t*>(xs + row * ROW_BYTES + (swz(row, ks * 4 + fq) << 4));
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][jh * 4 + j] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh * 4 + j], 0, 0, 0);
-        }
-      }
-    }
-
-    // ---- epilogue: 4 passes of 32 rows through this wave's private 4 KiB scratch ([32 rows][64 cols] bf16, 8-byte
-    //      units XOR-swizzled), read back as whole 128-byte output rows (16 B per lane); the next tile's first
-    //      K-slab is in flight meanwhile.
-    float bv[4][4];  // bias of this lane's 4 x 4 output columns: one 16-byte load each, once per tile
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int nb = n0 + wn * 64 + i * 16 + fq * 4;
-      if (bias != nullptr && vec_ok && nb + 4 <= N) {
-        VecIO<float, 4>::load(bias + nb, bv[i]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[i][r] = (bias != nullptr && nb + r < N) ? bias[nb + r] : 0.f;
-      }
-    }
-    auto epilogue_pass = [&](auto ps_tag) {
-      constexpr int ps = decltype(ps_tag)::value;  // compile-time: acc[][] must be indexed statically (registers)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        constexpr int jbase = ps * 2;
-        const int j = jbase + jj;
-        const int row = jj * 16 + fr;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x2_t o01 = act_apply2<ACT>(f32x2_t{acc[i][j][0], acc[i][j][1]} + f32x2_t{bv[i][0], bv[i][1]});
-          const f32x2_t o23 = act_apply2<ACT>(f32x2_t{acc[i][j][2], acc[i][j][3]} + f32x2_t{bv[i][2], bv[i][3]});
-          const int unit = (i * 4 + fq) ^ (row & 15);
-          *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) =
-              make_uint2(pack_bf16x2(o01.x, o01.y), pack_bf16x2(o23.x, o23.y));
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = t * 8 + rr;
-        const int sft = row & 15;
-        const int base_unit = ((2 * rc) ^ sft) & ~1;
-        uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + base_unit * 8);
-        if (sft & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-        const int64_t m = m0 + wm * 128 + ps * 32 + row;
-        const int n = n0 + wn * 64 + rc * 8;
-        if (m < M && n < N) {
-          if (vec_ok && n + 8 <= N) {
-            if constexpr (HAS_RES) {
-              const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
-              v = make_uint4(bf16x2_add(v.x, rv.x), bf16x2_add(v.y, rv.y), bf16x2_add(v.z, rv.z),
-                             bf16x2_add(v.w, rv.w));
-            }
-            *reinterpret_cast<uint4*>(Y + m * ldy + n) = v;
-          } else {
-            store_row_tail(v, R, ldr, Y, ldy, m, n, N);
-          }
-        }
-      }
-    };
-    epilogue_pass(std::integral_constant<int, 0>{});
-    epilogue_pass(std::integral_constant<int, 1>{});
-    epilogue_pass(std::integral_constant<int, 2>{});
-    epilogue_pass(std::integral_constant<int, 3>{});
-  }
-}
-
 // =============================================================================================
-// bf16 fast path, "w4": the same 256 x 256 x 64 tile and slab stream, FOUR waves (one per SIMD) of 128 x 128 --
+// bf16 fast path, "w4": a persistent 256 x 256 x 64 tile and slab stream, FOUR waves (one per SIMD) of 128 x 128 --
 // 256 accumulator registers per lane live in AGPRs (inline-asm MFMA, "+a"), the 128 fragment registers of the
 // current and the next half-slab in VGPRs.  Measured on MI355X (tools/micro/gemm_lab.hip, 8192^3, random data):
-// 1320 TFLOP/s against 1110 for the eight-wave loop above; what made the difference, in order:
+// 1320 TFLOP/s against 1110 for the eight-wave (128 x 64 per wave) loop it replaced; what made the difference, in order:
 //   * a third less LDS read traffic (each wave reads 256 rows per slab instead of 192 for half the flops);
 //   * ONE memory instruction per MFMA gap, never a burst: the CU's four waves run in lockstep and share one
 //     address pipe (~16 cycles per 1 KiB LDS-DMA piece), so the 16 refill DMAs of a slab go out one per five
@@ -1001,190 +806,6 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
 
-// =============================================================================================
-// Same tile and epilogue, deeper software pipeline: four 32 KiB LDS stages of K = 32 (64-byte rows), three
-// half-slabs of LDS-DMA always in flight, COUNTED s_waitcnt vmcnt(8|4|0) (never a drain in steady state) and raw
-// s_barrier -- the __syncthreads() of the two-stage kernel drains vmcnt(0) every slab, which exposes the ~1.5 us
-// load latency against 0.85 us of MFMA work (measured: that kernel is latency-, not bandwidth-bound).
-// vmcnt counts stores too; the counted wait stays correct because loads complete in order among loads: with N
-// younger loads outstanding, "at most N operations outstanding" can only hold once every older load has landed.
-// 64-byte rows need their own bank swizzle: chunk' = chunk ^ ((-(row >> 2)) & 3) (conflict-free for the
-// 16x16x32 fragment read pattern, derived per ds_read_b128 lane group as in MI355X_MICROARCH.md section LDS).
-// =============================================================================================
-constexpr int Q_STAGE = (BIG_M + BIG_N) * 64;            // 32 KiB
-constexpr int Q_LDS = 4 * Q_STAGE + BIG_EPI;             // 160 KiB
-
-__global__ __launch_bounds__(512) void linear_bf16_256x4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
-                                                                const bf16_t* __restrict__ W,
-                                                                const float* __restrict__ bias,
-                                                                const bf16_t* __restrict__ R, int64_t ldr,
-                                                                bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
-                                                                int K, int act, int vec_ok, int64_t n_tiles,
-                                                                int nt_count) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int64_t q8 = n_tiles / 8, r8 = n_tiles % 8;
-  const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int64_t chunk_len = q8 + (xcd < r8 ? 1 : 0);
-  if (bix >= chunk_len) return;
-  const int nh = K / 32;  // half-slabs per tile
-
-  // ---- issue side of the stream: (issue_li, issue_h) runs up to three half-slabs ahead of the compute side
-  const int srow = lane >> 2;                                 // row inside a 16-row group
-  const int schunk = (lane & 3) ^ ((-(lane >> 4)) & 3);       // source chunk landing at LDS position lane & 3
-  const char* xg[2];
-  const char* wg[2];
-  int64_t issue_li = bix;
-  int issue_h = 0;
-  int issued = 0;  // half-slabs issued so far (stage = issued & 3)
-  auto setup = [&](int64_t tile) {
-    int64_t mt_;
-    int nt_;
-    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
-    const int64_t m0 = mt_ * BIG_M;
-    const int n0 = nt_ * BIG_N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wid * 2 + i) * 16 + srow;
-      int64_t gm = m0 + r;
-      if (gm > M - 1) gm = M - 1;
-      int gn = n0 + r;
-      if (gn > N - 1) gn = N - 1;
-      xg[i] = reinterpret_cast<const char*>(X + gm * ldx) + schunk * 16;
-      wg[i] = reinterpret_cast<const char*>(W + (int64_t)gn * K) + schunk * 16;
-    }
-  };
-  auto issue_next = [&]() {
-    if (issue_li >= chunk_len) return;
-    char* xs = smem + (issued & 3) * Q_STAGE + wid * 2048;
-    char* ws = xs + BIG_M * 64;
-    const int64_t koff = (int64_t)issue_h * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16(xg[i] + koff, xs + i * 1024);
-      glds16(wg[i] + koff, ws + i * 1024);
-    }
-    ++issued;
-    if (++issue_h == nh) {
-      issue_h = 0;
-      issue_li += bpx;
-      if (issue_li < chunk_len) setup(chunk_start + issue_li);
-    }
-  };
-
-  const int wm = wid >> 2, wn = wid & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int frag_off = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);  // lane part of every fragment address
-  char* region = smem + 4 * Q_STAGE + wid * 4096;
-  const int rc = lane & 7, rr = lane >> 3;
-
-  setup(chunk_start + bix);
-  issue_next();
-  issue_next();
-  issue_next();
-  int g = 0;  // half-slabs consumed so far
-  for (int64_t li = bix; li < chunk_len; li += bpx) {
-    const int64_t tile = chunk_start + li;
-    int64_t mt_;
-    int nt_;
-    tile_coords(tile, nt_count, n_tiles / nt_count, mt_, nt_);
-    const int64_t m0 = mt_ * BIG_M;
-    const int n0 = nt_ * BIG_N;
-
-    f32x4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    for (int h = 0; h < nh; ++h, ++g) {
-      // my loads of half-slab g have landed once at most (younger half-slabs) * 4 operations are outstanding
-      const int ahead = issued - g - 1;
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // everyone's part of g landed; everyone is done reading stage (g + 3) & 3
-      asm volatile("" ::: "memory");
-      issue_next();
-      const char* xs = smem + (g & 3) * Q_STAGE + wm * (128 * 64) + frag_off;
-      const char* ws = smem + (g & 3) * Q_STAGE + BIG_M * 64 + wn * (64 * 64) + frag_off;
-      bf16x8_t a[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ws + i * (16 * 64));
-#pragma unroll
-      for (int jh = 0; jh < 2; ++jh) {
-        bf16x8_t b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(xs + (jh * 4 + j) * (16 * 64));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh * 4 + j], 0, 0, 0);
-      }
-    }
-
-    // ---- epilogue (as in the two-stage kernel): private 4 KiB scratch, whole 128-byte output rows
-    float bv[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int nb = n0 + wn * 64 + i * 16 + fq * 4;
-      if (bias != nullptr && vec_ok && nb + 4 <= N) {
-        VecIO<float, 4>::load(bias + nb, bv[i]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[i][r] = (bias != nullptr && nb + r < N) ? bias[nb + r] : 0.f;
-      }
-    }
-    auto epilogue_pass = [&](auto ps_tag) {
-      constexpr int ps = decltype(ps_tag)::value;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        constexpr int jbase = ps * 2;
-        const int j = jbase + jj;
-        const int row = jj * 16 + fr;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][j][r] + bv[i][r], act);
-          const int unit = (i * 4 + fq) ^ (row & 15);
-          *reinterpret_cast<uint2*>(region + row * 128 + unit * 8) =
-              make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = t * 8 + rr;
-        const int sft = row & 15;
-        const int base_unit = ((2 * rc) ^ sft) & ~1;
-        uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + base_unit * 8);
-        if (sft & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-        const int64_t m = m0 + wm * 128 + ps * 32 + row;
-        const int n = n0 + wn * 64 + rc * 8;
-        if (m < M && n < N) {
-          if (vec_ok && n + 8 <= N) {
-            if (R != nullptr) {
-              const uint4 rv = *reinterpret_cast<const uint4*>(R + m * ldr + n);
-              v = make_uint4(bf16x2_add(v.x, rv.x), bf16x2_add(v.y, rv.y), bf16x2_add(v.z, rv.z),
-                             bf16x2_add(v.w, rv.w));
-            }
-            *reinterpret_cast<uint4*>(Y + m * ldy + n) = v;
-          } else {
-            store_row_tail(v, R, ldr, Y, ldy, m, n, N);
-          }
-        }
-      }
-    };
-    epilogue_pass(std::integral_constant<int, 0>{});
-    epilogue_pass(std::integral_constant<int, 1>{});
-    epilogue_pass(std::integral_constant<int, 2>{});
-    epilogue_pass(std::integral_constant<int, 3>{});
-  }
-}
-
 template <typename T, typename TO>
 static int linear_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                          int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act, hipStream_t st,
@@ -1199,25 +820,6 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   if (tail_done != nullptr) *tail_done = false;
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<0, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<0, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<1, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<1, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<2, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<2, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<3, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256_kernel<3, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_256x4_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS) != hipSuccess)
-      return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", BIG_LDS);
 #define RAISE_W4_(A, RES, LNF)                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 8>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
@@ -1252,12 +854,6 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
 #undef RAISE_W4_
     raised = true;
   }
-  // ANEMOI_AMD_GEMM_VARIANT: 1 = four waves x (128 x 128), AGPR accumulators (default; needs K >= 128);
-  // 2 = eight waves x (128 x 64), two LDS stages; 4 = eight waves, four K = 32 stages with counted vmcnt.
-  static const int variant = [] {
-    const char* e = getenv("ANEMOI_AMD_GEMM_VARIANT");
-    return e ? atoi(e) : 1;
-  }();
   const int64_t mt = (M + BIG_M - 1) / BIG_M;
   const int64_t nt = (N + BIG_N - 1) / BIG_N;
   ANEMOI_REQUIRE(mt * nt < (int64_t)1 << 31, ANEMOI_ERR_UNSUPPORTED, "anemoi_linear: grid too large");
@@ -1266,26 +862,18 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   const bool batched = ln.b_tiles > 0;  // anemoi_linear_batched: b_count problems of mt * nt tiles each
   const int64_t problems = batched ? ln.b_count : 1;
   int64_t blocks = problems * mt * nt;
-  static const int64_t max_blocks = [] {  // ANEMOI_AMD_GEMM_BLOCKS: tuning knob (default: one persistent WG per CU)
-    const char* e = getenv("ANEMOI_AMD_GEMM_BLOCKS");
-    return e ? (int64_t)atoll(e) : (int64_t)256;
-  }();
+  constexpr int64_t max_blocks = 256;  // one persistent workgroup per CU
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = (blocks + 7) / 8 * 8;          // whole XCD rows; surplus workgroups exit at once
-  if (variant == 1 && K >= 128 && ldx < (int64_t)1 << 21 && ldy < (int64_t)1 << 21 && ldr < (int64_t)1 << 21 && vec_ok &&
+  if (K >= 128 && ldx < (int64_t)1 << 21 && ldy < (int64_t)1 << 21 && ldr < (int64_t)1 << 21 && vec_ok &&
       (M % BIG_M == 0 || m_tail == 0) && (ln.colsum == nullptr || (uintptr_t)ln.colsum % 16 == 0)) {
     const int w4_tail = (m_tail > 0 && m_tail <= 8 && K % 8 == 0) ? m_tail : 0;
     if (tail_done != nullptr) *tail_done = w4_tail > 0;
     // Remainder round as HALF tiles: when the tiles beyond the last whole round of 256 would keep at most half of the
     // CUs busy (N = 1024 at M = 40 960: 640 tiles = 2.5 rounds), their rows go to a second launch with 128 x 256 tiles
     // (MH = 4): twice as many units of half the work -- 2.5+ instead of 3 rounds, no cross-workgroup traffic.
-    // ANEMOI_AMD_GEMM_HALFTILES=0 turns it off.
-    static const bool half_tiles = [] {
-      const char* e = getenv("ANEMOI_AMD_GEMM_HALFTILES");
-      return e == nullptr || atoi(e) != 0;
-    }();
     int64_t mt_a = mt, mt_b = 0;  // row tiles of 256 for launch A; rows of launch B = mt_b * 256 as half tiles
-    if (half_tiles && !batched && max_blocks == 256 && nt <= 256 && 256 % nt == 0) {
+    if (!batched && nt <= 256 && 256 % nt == 0) {
       const int64_t per_round = 256 / nt;
       const int64_t rem_mt = mt % per_round;
       // measured: a half tile costs ~0.75 of a whole one (its 48 KiB slab per 64 MFMAs is bound by the L2 -> LDS
@@ -1348,35 +936,9 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
 #undef LAUNCH_W4__
     return check_launch("anemoi_linear(256x256, 4 waves)");
   }
-  if (M % BIG_M != 0 || batched) return W4_NEEDS_WHOLE_TILES;  // only the four-wave kernel takes ragged / batched work
-  if (ln.stats != nullptr)  // the older kernels have no LayerNorm fold: the general 128 x 128 kernel has
-    return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
-  if (variant == 4) {
-    hipLaunchKernelGGL(linear_bf16_256x4_kernel, dim3((unsigned)blocks), dim3(512), Q_LDS, st,
-                       static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,
-                       static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,
-                       vec_ok ? 1 : 0, mt * nt, (int)nt);
-    return check_launch("anemoi_linear(256x256, 4-stage)");
-  }
-#define LAUNCH_256_(A, RES)                                                                                    \
-  hipLaunchKernelGGL((linear_bf16_256_kernel<A, RES>), dim3((unsigned)blocks), dim3(512), BIG_LDS, st,         \
-                     static_cast<const bf16_t*>(x), ldx, static_cast<const bf16_t*>(w), bias,                  \
-                     static_cast<const bf16_t*>(residual), ldr, static_cast<bf16_t*>(y), ldy, M, N, K, act,    \
-                     vec_ok ? 1 : 0, mt * nt, (int)nt)
-#define LAUNCH_256(A)                    \
-  do {                                   \
-    if (residual != nullptr) LAUNCH_256_(A, true); \
-    else LAUNCH_256_(A, false);          \
-  } while (0)
-  switch (act) {  // the activation is a compile-time constant of the kernel: no per-element switch in the epilogue
-    case ANEMOI_ACT_GELU: LAUNCH_256(ANEMOI_ACT_GELU); break;
-    case ANEMOI_ACT_SILU: LAUNCH_256(ANEMOI_ACT_SILU); break;
-    case ANEMOI_ACT_RELU: LAUNCH_256(ANEMOI_ACT_RELU); break;
-    default: LAUNCH_256(ANEMOI_ACT_NONE); break;
-  }
-#undef LAUNCH_256
-#undef LAUNCH_256_
-  return check_launch("anemoi_linear(256x256)");
+  if (M % BIG_M != 0 || batched) return W4_NEEDS_WHOLE_TILES;  // (the caller splits the ragged rows off / refuses)
+  // shapes the persistent kernel does not take (K = 64, unaligned output, ...): the general 128 x 128 kernel
+  return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
 }
 
 // =============================================================================================
@@ -1434,27 +996,16 @@ static int linear_dispatch(const char* who, int dtype, int out_dtype, const void
   hipStream_t st = as_stream(stream);
   if (dtype == ANEMOI_F32 && out_dtype == ANEMOI_F32)
     return linear_launch<float, float>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
-  static const int64_t big_min_m = [] {  // A/B: rows from which the persistent 256 x 256 kernel takes over
-    const char* e = getenv("ANEMOI_AMD_GEMM_MIN_M");
-    return e ? (int64_t)atoll(e) : (int64_t)1024;
-  }();
+  constexpr int64_t big_min_m = 1024;  // rows from which the persistent 256 x 256 kernel takes over
   if (dtype == ANEMOI_BF16 && out_dtype == ANEMOI_BF16 && M >= big_min_m && N >= 256) {
     // A ragged last row tile would cost every CU of one XCD a full extra round (161 vs 160 row tiles at M = 40 962:
     // +10 %): the 256-row multiple goes to the persistent kernel, the few remaining rows to the 128 x 128 kernel.
     const int64_t m_main = M / BIG_M * BIG_M, m_tail = M - m_main;
     if (m_tail == 0) return linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
     bool tail_done = false;
-    static const bool ragged_ok = [] {  // A/B: ANEMOI_AMD_GEMM_RAGGED=0 sends tails of 9..255 rows to a second launch
-      const char* e = getenv("ANEMOI_AMD_GEMM_RAGGED");
-      return e == nullptr || atoi(e) != 0;
-    }();
-    static const int variant_env = [] {
-      const char* e = getenv("ANEMOI_AMD_GEMM_VARIANT");
-      return e ? atoi(e) : 1;
-    }();
     // tails of more than 8 rows ride along as a ragged last row tile of the persistent kernel (its descriptors end at
     // row M): the separate 128 x 128 launch they used to get ran ~35 us on a handful of CUs, 14 times per forward
-    if (m_tail > 8 && ragged_ok && variant_env == 1 && K >= 128) {
+    if (m_tail > 8 && K >= 128) {
       const int rr = linear_bf16_256_launch(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
       if (rr != W4_NEEDS_WHOLE_TILES) return rr;
     }

@@ -106,13 +106,30 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, out: 
     return out
 
 
+def _carry_stats(y: Tensor, eps: float, stats: Tensor) -> None:
+    """Attach the LayerNorm statistics the producing GEMM's epilogue computed to ``y``.  The record pins the storage
+    pointer and torch's in-place version counter of ``y`` at this moment: any later in-place write (or a swapped
+    ``.data``) makes :func:`_carried_stats` ignore it, so stale statistics cannot be consumed silently."""
+    y._anemoi_row_stats = (eps, stats, y.data_ptr(), y._version)
+
+
+def _carried_stats(x: Tensor, eps: float) -> Optional[Tensor]:
+    rec = getattr(x, "_anemoi_row_stats", None)
+    if rec is None:
+        return None
+    r_eps, stats, ptr, version = rec
+    if r_eps != eps or stats.shape[0] != x.shape[0] or ptr != x.data_ptr() or version != x._version:
+        return None
+    return stats
+
+
 def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
     """LayerNorm statistics of the rows of ``x``: ``[M, 2]`` f32 = ``(rstd, -mean * rstd)`` (see ``linear(ln=...)``)."""
     _dev(x)
     _rows(x)
-    carried = getattr(x, "_anemoi_row_stats", None)  # left by linear(..., stats_eps=eps), which produced x
-    if carried is not None and carried[0] == eps and carried[1].shape[0] == x.shape[0]:
-        return carried[1]
+    carried = _carried_stats(x, eps)  # left by linear(..., stats_eps=eps), which produced x
+    if carried is not None:
+        return carried
     out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
     with _Timed("row_stats", bytes=x.shape[0] * x.shape[1] * x.element_size()):
         st = _lib.load().anemoi_row_stats(dtype_code(x.dtype), x.data_ptr(), _ld(x), out.data_ptr(), x.shape[0],
@@ -161,7 +178,7 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
                 dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias), _ptr(colsum), _ptr(stats_in),
                 _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)), m_rows,
                 n, k, ws.data_ptr(), ws.numel() * 4, stats_eps, stats_out.data_ptr(), _stream())
-            out._anemoi_row_stats = (stats_eps, stats_out)
+            _carry_stats(out, stats_eps, stats_out)
         elif ln is None:
             st = _lib.load().anemoi_linear(
                 dtype_code(x.dtype), dtype_code(out.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),

@@ -387,6 +387,11 @@ def test_linear_with_row_statistics_of_the_result(m, n, k, res, fold):
     assert torch.equal(y, y_plain)  # the statistics do not change the product
     carried = ops.row_stats(y, 1e-5)
     assert carried is y._anemoi_row_stats[1]
+    y2 = y.clone()
+    ops._carry_stats(y2, 1e-5, carried)
+    assert ops.row_stats(y2, 1e-5) is carried
+    y2.mul_(2.0)  # an in-place write invalidates the carried statistics: recomputed from the new values
+    assert ops.row_stats(y2, 1e-5) is not carried
     want = ops.row_stats(y.clone(), 1e-5)  # the clone carries nothing: separate kernel, two-pass statistics
     assert want is not carried
     torch.testing.assert_close(carried, want, rtol=2e-4, atol=2e-4)
@@ -1108,7 +1113,8 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
     cfg["model"]["encoder"]["trainable_size"] = 12
     cfg["model"]["processor"]["trainable_size"] = 0
     cfg["model"]["decoder"]["trainable_size"] = 3
-    cfg["model"]["trainable_parameters"] = {"data": 5, "hidden": 0}
+    cfg["model"]["trainable_parameters"]["data"] = 5
+    cfg["model"]["trainable_parameters"]["hidden"] = 0
     idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
     torch.manual_seed(3)
     model = AnemoiModelEncProcDec(model_config=type(cfg)(cfg), data_indices=idx, graph_data=graph_o32)

@@ -21,7 +21,13 @@ def main():
     ap.add_argument("--channels", type=int, default=1024)
     ap.add_argument("--heads", type=int, default=16)
     ap.add_argument("--col", default="graph", help="graph | near (sources = dst-4..dst+4: ideal locality) | random")
+    ap.add_argument("--set", default="proc", choices=["proc", "enc", "dec"],
+                    help="edge set: mesh processor, encoder (grid -> mesh), decoder (mesh -> grid)")
+    ap.add_argument("--save", default=None, help="write the output tensor here (bit-compare kernel variants)")
+    ap.add_argument("--compare", default=None, help="compare the output with a tensor written by --save")
     a = ap.parse_args()
+    if a.set != "proc":
+        return mapper(a)
     dev = torch.device("cuda", 0)
     g = build_graph(a.graph)
     ei = g[("hidden", "to", "hidden")].edge_index
@@ -54,6 +60,38 @@ def main():
         ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
                                      attr, plan.rowptr, plan.col, h, up, out=out, ld_out=ld_out)
 
+    e = plan.col.shape[0]
+    report(a, run, out, 4 * n * c * 2 + e * 52 + (n + 1) * 4, f"set=proc order={a.order} col={a.col} n={n} E={e}")
+
+
+def mapper(a):
+    """Encoder / decoder edge sets at the model's own layouts: k|v = [n_src, 2C], x_r|q|u = [n_dst, 2C + H up]."""
+    dev = torch.device("cuda", 0)
+    g = build_graph(a.graph)
+    key = ("data", "to", "hidden") if a.set == "enc" else ("hidden", "to", "data")
+    ei = g[key].edge_index
+    n_src, n_dst = g[key[0]].num_nodes, g[key[2]].num_nodes
+    lat, lon = g["hidden"].x[:, 0].double(), g["hidden"].x[:, 1].double()
+    inv = runtime.inverse_permutation(runtime.locality_order(torch.stack([lat.sin(), lon.sin(), lat.cos(), lon.cos()], 1)))
+    src, dst = (ei[0], inv[ei[1]]) if a.set == "enc" else (inv[ei[0]], ei[1])
+    plan = runtime.build_edge_plan(torch.stack([src, dst]).to(dev), n_src, n_dst)
+    c, h, up = a.channels, a.heads, 12
+    torch.manual_seed(0)
+    kv = (torch.randn(n_src, 2 * c, device=dev) * 0.5).to(torch.bfloat16)
+    sq = (torch.randn(n_dst, 2 * c + h * up, device=dev) * 0.5).to(torch.bfloat16)
+    attr = torch.randn(plan.col.shape[0], up, device=dev)
+    ld_out = ops.round_up(c + h * up, 64)
+    out = torch.zeros(n_dst, ld_out, dtype=torch.bfloat16, device=dev)
+
+    def run():
+        ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], attr, plan.rowptr,
+                                     plan.col, h, up, out=out, ld_out=ld_out)
+
+    report(a, run, out, (2 * n_dst + 2 * n_src) * c * 2 + plan.col.shape[0] * 52 + (n_dst + 1) * 4,
+           f"set={a.set} n_src={n_src} n_dst={n_dst} E={plan.col.shape[0]}")
+
+
+def report(a, run, out, alg, label):
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -64,10 +102,15 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.iters
-    e = plan.col.shape[0]
-    alg = 4 * n * c * 2 + e * 52 + (n + 1) * 4
-    print(f"order={a.order} col={a.col} n={n} E={e} {ms:.4f} ms  {alg / ms / 1e6:.0f} GB/s algorithmic "
-          f"({alg / ms / 1e6 / 80:.1f} % of 8 TB/s)", flush=True)
+    note = ""
+    if a.save:
+        torch.save(out.cpu(), a.save)
+    if a.compare:
+        want = torch.load(a.compare)
+        note = "  bit-identical to " + a.compare if torch.equal(out.cpu(), want) else \
+            f"  DIFFERS from {a.compare}: max abs {float((out.cpu().float() - want.float()).abs().max()):.3e}"
+    print(f"{label} PIPE={os.environ.get('ANEMOI_AMD_EDGE_PIPE', 'default')} {ms:.4f} ms  {alg / ms / 1e6:.0f} GB/s "
+          f"algorithmic ({alg / ms / 1e6 / 80:.1f} % of 8 TB/s){note}", flush=True)
 
 
 if __name__ == "__main__":
