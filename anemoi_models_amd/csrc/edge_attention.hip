@@ -380,16 +380,8 @@ struct RawWords {
   }
 };
 
-// PIPE: how much of the NEXT destination is requested while the current one is processed.  The kernel is bound by its
-// chain of dependent memory round trips per destination (row pointers -> columns -> k|v gathers, q before the first
-// score, x_r before the store), not by bytes or VALU:
-//   0  nothing (the loop of the first version: every operand is requested when it is needed)
-//   1  x_r is requested together with q at the start of the destination
-//   2  + the next destination's row pointers, q, u and x_r are requested before the current one's edge loop
-//   3  + the columns of the following edge batch (this destination's next U edges, or the next destination's first U)
-//      are requested while the current batch is processed
-template <typename T, int VEC, int LPH, int UP, int U = 4, int PIPE = 3, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void gt_edge_attention_folded_kernel(const EdgeFoldParams p,
+template <typename T, int VEC, int LPH, int UP, int U = 4>
+__global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const EdgeFoldParams p,
                                                                    const float* __restrict__ attr_,
                                                                    const int32_t* __restrict__ rowptr_,
                                                                    const int32_t* __restrict__ col_) {
@@ -416,72 +408,35 @@ __global__ __launch_bounds__(256, MINW) void gt_edge_attention_folded_kernel(con
   const bool a_own = a0 < UP;        // the last lanes of a head own none when LPH * APL > UP (u = 0, nothing stored)
   const int a_ld = a_own ? a0 : 0;
   const float amask = a_own ? 1.f : 0.f;
-  const bool nt = p.stream_hint != 0;
-  const bool has_xr = p.xr != nullptr;
 
-  // wave-uniform row bases (bytes) + 32-bit lane offsets
-  constexpr int64_t ES = (int64_t)sizeof(T);
-  const char* qb = static_cast<const char*>(p.q);
-  const char* kb = static_cast<const char*>(p.k);
-  const char* vb = static_cast<const char*>(p.v);
-  const char* ub = static_cast<const char*>(p.u);
-  const char* rb = has_xr ? static_cast<const char*>(p.xr) : qb;
-  const int64_t ldq_b = p.ldq * ES, ldkv_b = p.ldkv * ES, ldu_b = p.ldu * ES, ldo_b = p.ldo * ES;
-  const int64_t ldr_b = (has_xr ? p.ldr : p.ldq) * ES;
-  const char* ab = reinterpret_cast<const char*>(attr_);
-  const uint32_t off_c = (uint32_t)(c0 * (int)sizeof(T));
-  const uint32_t off_u = (uint32_t)((head * UP + a_ld) * (int)sizeof(T));
-  const uint32_t off_a = (uint32_t)(a_ld * 4);
+  const T* qb = static_cast<const T*>(p.q) + c0;
+  const T* kb = static_cast<const T*>(p.k) + c0;
+  const T* vb = static_cast<const T*>(p.v) + c0;
+  const T* ub = static_cast<const T*>(p.u) + head * UP + a_ld;
+  const float* ab = attr_ + a_ld;
 
-  int64_t node = n0 + node_first;
-  if (node >= n1) return;
-  // streaming operands of the current destination (requested one destination ahead when PIPE >= 2)
-  RawWords<T, VEC> q_raw, xr_raw;
-  RawWords<T, APL> u_raw;
-  int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
-  int cj[U];  // source rows of the edge batch about to be processed (PIPE >= 3)
-  if constexpr (PIPE >= 2) {
-    q_raw.load(qb + node * ldq_b, off_c, nt);
-    u_raw.load(ub + node * ldu_b, off_u, false);
-    xr_raw.load(rb + node * ldr_b, off_c, nt);
-  }
-  if constexpr (PIPE >= 3) {
-    const int last = e_end > e_begin ? e_end - 1 : (e_begin > 0 ? e_begin - 1 : 0);
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu) cj[uu] = col_[e_begin + uu < last ? e_begin + uu : last];
-  }
-
-  for (;;) {
-    const int64_t next = node + node_stride;
-    const bool has_next = next < n1;
-    const int64_t nn = has_next ? next : node;
-    RawWords<T, VEC> q_n, xr_n;
-    RawWords<T, APL> u_n;
-    int eb_n = 0, ee_n = 0;
-    if constexpr (PIPE >= 2) {  // the next destination's streams go out first: they are the long (HBM) round trips
-      eb_n = rowptr_[nn];
-      ee_n = rowptr_[nn + 1];
-      q_n.load(qb + nn * ldq_b, off_c, nt);
-      u_n.load(ub + nn * ldu_b, off_u, false);
-      xr_n.load(rb + nn * ldr_b, off_c, nt);
-    } else {
-      q_raw.load(qb + node * ldq_b, off_c, nt);
-      u_raw.load(ub + node * ldu_b, off_u, false);
-      if constexpr (PIPE >= 1) xr_raw.load(rb + node * ldr_b, off_c, nt);
-    }
+  for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
+    const int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
     QK<T, VEC> qk;
     float u[APL];
+    RawWords<T, VEC> xr_raw;
     {
       float qf[VEC];
-      q_raw.get(qf);
+      if (p.stream_hint) load_stream<T, VEC>(qb + node * p.ldq, qf);
+      else VecIO<T, VEC>::load(qb + node * p.ldq, qf);
       qk.set(qf);
-      u_raw.get(u);
+      VecIO<T, APL>::load(ub + node * p.ldu, u);
+      // x_r is requested here, with q, not behind the edge loop where it is consumed: one dependent HBM round trip per
+      // destination less (-2 %; requesting the NEXT destination's rows ahead as well was measured and is slower, see
+      // DESIGN.md section 4.2)
+      if (p.xr != nullptr) xr_raw.load(static_cast<const char*>(p.xr) + node * p.ldr * (int64_t)sizeof(T),
+                                       (uint32_t)(c0 * (int)sizeof(T)), p.stream_hint != 0);
 #pragma unroll
       for (int i = 0; i < APL; ++i) u[i] *= amask;
     }
     float m = -INFINITY, l = 0.f;
     // the value accumulators live as f32 pairs: rescale and accumulate are v_pk_mul_f32 / v_pk_fma_f32 (two channels per
-    // issue slot)
+    // issue slot) -- this loop is bound by its instruction streams, not by bytes
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
     constexpr int VP = (VEC + 1) / 2;
     f32x2_t acc[VP];
@@ -491,13 +446,6 @@ __global__ __launch_bounds__(256, MINW) void gt_edge_attention_folded_kernel(con
 #pragma unroll
     for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
 
-    if constexpr (PIPE >= 3) {
-      if (e_begin == e_end) {  // destination without edges: the batch loop below does not run and cannot refill cj
-        const int last = ee_n > eb_n ? ee_n - 1 : (eb_n > 0 ? eb_n - 1 : 0);
-#pragma unroll
-        for (int uu = 0; uu < U; ++uu) cj[uu] = col_[eb_n + uu < last ? eb_n + uu : last];
-      }
-    }
     for (int e = e_begin; e < e_end; e += U) {
       Raw kr[U], vr[U];
       float at[U][APL];
@@ -505,19 +453,11 @@ __global__ __launch_bounds__(256, MINW) void gt_edge_attention_folded_kernel(con
 #pragma unroll
       for (int uu = 0; uu < U; ++uu) {
         if (e + uu < e_end) {
-          const int64_t j = PIPE >= 3 ? (int64_t)cj[uu] : (int64_t)col_[e + uu];
-          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * ldkv_b + off_c);
-          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * ldkv_b + off_c);
-          VecIO<float, APL>::load(reinterpret_cast<const float*>(ab + (int64_t)(e + uu) * (UP * 4) + off_a), at[uu]);
+          const int64_t j = col_[e + uu];
+          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
+          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
+          VecIO<float, APL>::load(ab + (int64_t)(e + uu) * UP, at[uu]);
         }
-      }
-      if constexpr (PIPE >= 3) {  // columns of the batch after this one (clamped: never past the rows' last edge)
-        const bool more = e + U < e_end;
-        const int pb = more ? e + U : eb_n;
-        const int pe = more ? e_end : ee_n;
-        const int last = pe > pb ? pe - 1 : (pb > 0 ? pb - 1 : 0);
-#pragma unroll
-        for (int uu = 0; uu < U; ++uu) cj[uu] = col_[pb + uu < last ? pb + uu : last];
       }
       float mb = m;
 #pragma unroll
@@ -559,35 +499,22 @@ __global__ __launch_bounds__(256, MINW) void gt_edge_attention_folded_kernel(con
     float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
-    if (has_xr) {
+    if (p.xr != nullptr) {
       float r[VEC];
-      if constexpr (PIPE == 0) xr_raw.load(rb + node * ldr_b, off_c, nt);
       xr_raw.get(r);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] += r[i];
     }
-    char* on = static_cast<char*>(p.out) + node * ldo_b;
+    T* on = static_cast<T*>(p.out) + node * p.ldo;
     if (active) {
-      if (nt) store_stream<T, VEC>(reinterpret_cast<T*>(on + off_c), o);
-      else VecIO<T, VEC>::store(reinterpret_cast<T*>(on + off_c), o);
+      if (p.stream_hint) store_stream<T, VEC>(on + c0, o);
+      else VecIO<T, VEC>::store(on + c0, o);
     }
     if (active && a_own) {  // this lane's APL values of t~_i,h
       float t4[APL];
 #pragma unroll
       for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
-      VecIO<T, APL>::store(reinterpret_cast<T*>(on + (uint32_t)((p.C + head * UP + a0) * (int)sizeof(T))), t4);
-    }
-    if (!has_next) break;
-    node = next;
-    if constexpr (PIPE >= 2) {
-      q_raw = q_n;
-      u_raw = u_n;
-      xr_raw = xr_n;
-      e_begin = eb_n;
-      e_end = ee_n;
-    } else {
-      e_begin = rowptr_[node];
-      e_end = rowptr_[node + 1];
+      VecIO<T, APL>::store(on + p.C + head * UP + a0, t4);
     }
   }
 }
@@ -611,22 +538,15 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   // (a register-double-buffered software pipeline across destinations was measured and removed: 0.30 / 1.98 / 0.79 ms
   // against 0.19 / 1.21 / 0.60 ms of this loop on the mesh / decoder / encoder graphs of config 3 -- the second
   // register set costs a wave per SIMD, which hurts more than the overlap helps)
-  static const int pipe = [] {  // A/B: ANEMOI_AMD_EDGE_PIPE in {0, 1, 2, 3} (see the kernel), default 3
-    const char* e = getenv("ANEMOI_AMD_EDGE_PIPE");
-    return e ? atoi(e) : 3;
-  }();
-  const dim3 grid((unsigned)(8 * bpx)), block(64 * WPB);
-#define ANEMOI_EDGE_LAUNCH(UU, PP, MW) \
-  hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, UU, PP, MW>), grid, block, 0, st, p, p.attr, p.rowptr, p.col)
-  if (edges_in_flight == 8) ANEMOI_EDGE_LAUNCH(8, 3, 1);
-  else if (edges_in_flight == 2) ANEMOI_EDGE_LAUNCH(2, 3, 1);
-  else if (pipe == 0) ANEMOI_EDGE_LAUNCH(4, 0, 1);
-  else if (pipe == 1) ANEMOI_EDGE_LAUNCH(4, 1, 1);
-  else if (pipe == 2) ANEMOI_EDGE_LAUNCH(4, 2, 1);
-  else if (pipe == 12) ANEMOI_EDGE_LAUNCH(4, 2, 5);  // (lab: the same with the register budget of 5 waves per SIMD)
-  else if (pipe == 13) ANEMOI_EDGE_LAUNCH(4, 3, 5);
-  else ANEMOI_EDGE_LAUNCH(4, 3, 1);
-#undef ANEMOI_EDGE_LAUNCH
+  if (edges_in_flight == 8)
+    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 8>), dim3((unsigned)(8 * bpx)),
+                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
+  else if (edges_in_flight == 2)
+    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 2>), dim3((unsigned)(8 * bpx)),
+                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
+  else
+    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 4>), dim3((unsigned)(8 * bpx)),
+                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
 }
 
 template <typename T, int VEC, int LPH>
@@ -650,6 +570,266 @@ static bool dispatch_folded(const EdgeFoldParams& p, int up, hipStream_t st) {
     case 4: return dispatch_folded_up<T, VEC, 4>(p, up, st);
     case 8: return dispatch_folded_up<T, VEC, 8>(p, up, st);
     case 16: return dispatch_folded_up<T, VEC, 16>(p, up, st);
+    default: return false;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiled path: LDS staging of the source rows of a destination tile.
+//
+// The gather loop above pulls every k_j / v_j row slice through L2 -> L1 once per EDGE; on the mesh graph a row is
+// wanted by ~8 destinations, most of them neighbours in the (Morton) row order.  Measured on config 3's mesh launch
+// (tools/edge_lab2.sh): 0.151 ms as is, 0.109 ms without the v gathers, 0.084 ms without any gather -- the gathers
+// cost time in proportion to their bytes, VALU work costs nothing.  So this kernel moves each row slice ONCE per tile:
+//   * a workgroup owns (tile of TILE_DST = 32 consecutive destinations, one head);
+//   * the tile's unique source rows (host-built list, runtime.edge_tiles) go to LDS by LDS-DMA (buffer_load ... lds, 16 B
+//     per lane, no registers), together with the tile's q rows, its CSR slice of tile-local column slots and its edge
+//     attributes; one s_waitcnt + barrier;
+//   * then LPH lanes per destination (64 / LPH destinations per wave) run the same online-softmax loop as the gather
+//     kernel with every operand in LDS (k / v: one conflict-free ds_read_b128 per lane and edge).
+// Heads of one tile run on the same XCD (shared column / attribute lines in that L2).  Several workgroups fit a CU
+// (LDS ~50 KB at the mesh graph), so one stages while the others compute.  Same arithmetic and summation order per
+// destination as the gather kernel except for the batch size of the online softmax (U = 2 instead of 4).
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_DST = 32;
+
+// LDS regions are sized in whole LDS-DMA instructions (64 lanes x 4 or 16 bytes): the last instruction of a region
+// writes all its lanes (zeros beyond the source array) and must not reach into the next region.
+__host__ __device__ constexpr int tiled_col_bytes(int e_cap) { return (e_cap + 63) / 64 * 256; }
+__host__ __device__ constexpr int tiled_attr_bytes(int e_cap, int up) { return (e_cap * up * 4 + 1023) / 1024 * 1024; }
+
+struct EdgeTileParams {
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* xr;
+  const void* u;
+  void* out;
+  int64_t ldq, ldkv, ldr, ldu, ldo;
+  const float* attr;            // [E, UP] f32, CSR order
+  const int32_t* rowptr;        // [n_dst + 1]
+  const int32_t* tile_src_ptr;  // [n_tiles + 1]
+  const int32_t* tile_src;      // unique source rows of every tile, ascending inside a tile
+  const int32_t* col_local;     // [E] slot of the edge's source in its tile's list
+  int64_t n_dst, n_src, n_edges;
+  int n_tiles, C, D, H, s_cap, e_cap;
+  float scale;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, int64_t bytes) {
+  const int64_t lim = bytes < (int64_t)0xffffffffll ? bytes : (int64_t)0xffffffffll;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)lim, 0x00020000);
+}
+
+template <typename T, int VEC, int LPH, int UP>
+__global__ __launch_bounds__(TILE_DST* LPH) void gt_edge_attention_tiled_kernel(const EdgeTileParams p) {
+  using Raw = typename RawVec<T, VEC>::type;
+  constexpr int APL = attrs_per_lane(UP, LPH);
+  constexpr int ROWB = LPH * 16;         // bytes of one head's slice of a row
+  constexpr int GPW = 64 / LPH;          // destinations (or staged rows) per wave instruction
+  constexpr int NW = TILE_DST / GPW;     // waves per workgroup
+  constexpr int ES = (int)sizeof(T);
+  constexpr int U = 2;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_lds = smem;
+  char* v_lds = k_lds + p.s_cap * ROWB;
+  char* q_lds = v_lds + p.s_cap * ROWB;
+  char* c_lds = q_lds + TILE_DST * ROWB;
+  char* a_lds = c_lds + tiled_col_bytes(p.e_cap);  // (regions are whole LDS-DMA instructions: see tiled_lds_bytes)
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int tile = (bi / p.H) * 8 + xcd, head = bi % p.H;
+  if (tile >= p.n_tiles) return;
+  const int64_t d0 = (int64_t)tile * TILE_DST;
+  const int64_t d_end = d0 + TILE_DST < p.n_dst ? d0 + TILE_DST : p.n_dst;
+  const int e0 = p.rowptr[d0], e1 = p.rowptr[d_end];
+  const int n_e = e1 - e0;
+  const int sp0 = p.tile_src_ptr[tile], n_s = p.tile_src_ptr[tile + 1] - sp0;
+  const int g = lane / LPH, r = lane % LPH;
+
+  // ---- this lane's destination: row pointers, x_r and u slices straight into registers (requested first: HBM streams)
+  const int64_t d = d0 + wid * GPW + g;
+  const bool valid = d < d_end;
+  const int64_t dc = valid ? d : d_end - 1;
+  const int a0 = r * APL;
+  const bool a_own = a0 < UP;
+  const int a_ld = a_own ? a0 : 0;
+  const float amask = a_own ? 1.f : 0.f;
+  int eb = p.rowptr[dc] - e0, ee = p.rowptr[dc + 1] - e0;
+  if (!valid) ee = eb;
+  RawWords<T, VEC> xr_raw;
+  RawWords<T, APL> u_raw;
+  const bool has_xr = p.xr != nullptr;
+  if (has_xr)
+    xr_raw.load(static_cast<const char*>(p.xr) + dc * p.ldr * ES, (uint32_t)((head * p.D + r * VEC) * ES), true);
+  u_raw.load(static_cast<const char*>(p.u) + dc * p.ldu * ES, (uint32_t)((head * UP + a_ld) * ES), false);
+
+  // ---- staging (LDS-DMA: lane l of an instruction writes 16 bytes at lds base + 16 l)
+  {
+    const __amdgpu_buffer_rsrc_t krs = tile_rsrc(static_cast<const T*>(p.k) + head * p.D, p.n_src * p.ldkv * ES);
+    const __amdgpu_buffer_rsrc_t vrs = tile_rsrc(static_cast<const T*>(p.v) + head * p.D, p.n_src * p.ldkv * ES);
+    // (the q descriptor starts at the tile's first row: offsets stay small whatever n_dst is)
+    const __amdgpu_buffer_rsrc_t qrs =
+        tile_rsrc(static_cast<const T*>(p.q) + d0 * p.ldq + head * p.D, (int64_t)TILE_DST * p.ldq * ES);
+    for (int j = wid; j * GPW < n_s; j += NW) {  // source rows j * GPW + g
+      const int row = j * GPW + g;
+      const int src = p.tile_src[sp0 + (row < n_s ? row : n_s - 1)];
+      const int vo = (int)((uint32_t)src * (uint32_t)(p.ldkv * ES) + (uint32_t)(r * 16));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr_t)(k_lds + j * 1024), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr_t)(v_lds + j * 1024), 16, vo, 0, 0, 0);
+    }
+    {  // q rows of the tile: exactly one instruction per wave
+      const int vo = (int)(dc - d0) * (int)(p.ldq * ES) + r * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_ptr_t)(q_lds + wid * 1024), 16, vo, 0, 0, 2);
+    }
+    const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.col_local, p.n_edges * 4);
+    for (int j = wid; j * 64 < n_e; j += NW)  // tile-local column slots, 4 bytes per lane (beyond the array: zeros)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (lds_ptr_t)(c_lds + j * 256), 4, (e0 + j * 64 + lane) * 4, 0, 0, 0);
+    const __amdgpu_buffer_rsrc_t ars = tile_rsrc(p.attr, p.n_edges * (int64_t)(UP * 4));
+    constexpr int CH = UP / 4;  // 16-byte chunks per edge
+    for (int j = wid; j * 64 < n_e * CH; j += NW)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_ptr_t)(a_lds + j * 1024), 16,
+                                               (int)(((uint32_t)e0 * CH + (uint32_t)(j * 64 + lane)) * 16u), 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- compute: everything in LDS
+  QK<T, VEC> qk;
+  float u[APL];
+  {
+    float qf[VEC];
+    const Raw qr = *reinterpret_cast<const Raw*>(q_lds + (wid * GPW + g) * ROWB + r * 16);
+    unpack<T, VEC>(qr, qf);
+    qk.set(qf);
+    u_raw.get(u);
+#pragma unroll
+    for (int i = 0; i < APL; ++i) u[i] *= amask;
+  }
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  constexpr int VP = (VEC + 1) / 2;
+  f32x2_t acc[VP];
+  float tacc[APL];
+#pragma unroll
+  for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int* cl = reinterpret_cast<const int*>(c_lds);
+  const float* al = reinterpret_cast<const float*>(a_lds) + a_ld;
+  for (int e = eb; __any(e < ee); e += U) {
+    Raw kr[U], vr[U];
+    float at[U][APL];
+    bool on[U];
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) {
+      on[uu] = e + uu < ee;
+      const int ei = on[uu] ? e + uu : (n_e > 0 ? 0 : 0);
+      const int slot = n_e > 0 ? cl[ei] : 0;
+      kr[uu] = *reinterpret_cast<const Raw*>(k_lds + slot * ROWB + r * 16);
+      vr[uu] = *reinterpret_cast<const Raw*>(v_lds + slot * ROWB + r * 16);
+      VecIO<float, APL>::load(al + ei * UP, at[uu]);
+    }
+    float s[U];
+    float mb = m;
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) {
+      float t = qk.dot(kr[uu]);
+#pragma unroll
+      for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[uu][a], t);
+      s[uu] = on[uu] ? group_sum<LPH>(t) * p.scale : -INFINITY;
+      mb = fmaxf(mb, s[uu]);
+    }
+    const float corr = m == mb ? 1.f : __expf(m - mb);  // (m == mb == -inf: nothing seen yet, nothing to rescale)
+    l *= corr;
+#pragma unroll
+    for (int i = 0; i < VP; ++i) acc[i] *= corr;
+#pragma unroll
+    for (int a = 0; a < APL; ++a) tacc[a] *= corr;
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) {
+      const float pe = on[uu] ? __expf(s[uu] - mb) : 0.f;
+      l += pe;
+      float vv[VEC];
+      unpack<T, VEC>(vr[uu], vv);
+#pragma unroll
+      for (int i = 0; i < VP; ++i)
+        acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f},
+                                           acc[i]);
+#pragma unroll
+      for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
+    }
+    m = mb;
+  }
+
+  const float inv = 1.0f / (l + 1e-16f);
+  float o[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
+  if (has_xr) {
+    float rr[VEC];
+    xr_raw.get(rr);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] += rr[i];
+  }
+  if (valid) {
+    char* on_ = static_cast<char*>(p.out) + d * p.ldo * ES;
+    store_stream<T, VEC>(reinterpret_cast<T*>(on_ + (head * p.D + r * VEC) * ES), o);
+    if (a_own) {
+      float t4[APL];
+#pragma unroll
+      for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+      VecIO<T, APL>::store(reinterpret_cast<T*>(on_ + (p.C + head * UP + a0) * ES), t4);
+    }
+  }
+}
+
+static inline size_t tiled_lds_bytes(int lph, int up, int s_cap, int e_cap) {
+  return (size_t)2 * s_cap * lph * 16 + (size_t)TILE_DST * lph * 16 + (size_t)tiled_col_bytes(e_cap) +
+         (size_t)tiled_attr_bytes(e_cap, up);
+}
+
+template <typename T, int VEC, int LPH, int UP>
+static bool launch_tiled(const EdgeTileParams& p, hipStream_t st) {
+  const size_t lds = tiled_lds_bytes(LPH, UP, p.s_cap, p.e_cap);
+  if (lds > 160 * 1024) return false;
+  auto kern = gt_edge_attention_tiled_kernel<T, VEC, LPH, UP>;
+  static bool raised = false;  // per instantiation
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return false;
+    raised = true;
+  }
+  const int64_t blocks = (int64_t)((p.n_tiles + 7) / 8) * p.H * 8;
+  if (blocks >= (int64_t)1 << 31) return false;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TILE_DST * LPH), lds, st, p);
+  return true;
+}
+
+template <typename T, int VEC, int LPH>
+static bool dispatch_tiled_up(const EdgeTileParams& p, int up, hipStream_t st) {
+  switch (up) {
+    case 4: return launch_tiled<T, VEC, LPH, 4>(p, st);
+    case 8: return launch_tiled<T, VEC, LPH, 8>(p, st);
+    case 12: return launch_tiled<T, VEC, LPH, 12>(p, st);
+    case 16: return launch_tiled<T, VEC, LPH, 16>(p, st);
+    default: return false;
+  }
+}
+
+template <typename T>
+static bool dispatch_tiled(const EdgeTileParams& p, int up, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (p.D % VEC != 0 || p.C % VEC != 0) return false;
+  switch (p.D / VEC) {
+    case 2: return dispatch_tiled_up<T, VEC, 2>(p, up, st);
+    case 4: return dispatch_tiled_up<T, VEC, 4>(p, up, st);
+    case 8: return dispatch_tiled_up<T, VEC, 8>(p, up, st);
+    case 16: return dispatch_tiled_up<T, VEC, 16>(p, up, st);
     default: return false;
   }
 }
@@ -859,4 +1039,64 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
                  "anemoi_gt_edge_attention_folded: unsupported shape (D=%d, UP=%d); use anemoi_gt_edge_attention", C / H,
                  up);
   return check_launch("anemoi_gt_edge_attention_folded");
+}
+
+extern "C" int64_t anemoi_gt_edge_attention_tiled_lds_bytes(int dtype, int C, int H, int up, int s_cap, int e_cap) {
+  if (C <= 0 || H <= 0 || C % H != 0 || up <= 0 || s_cap < 0 || e_cap < 0) return -1;
+  const int vec = dtype == ANEMOI_BF16 ? 8 : 4;
+  const int d = C / H;
+  if (d % vec != 0) return -1;
+  const int lph = d / vec;
+  if (lph != 2 && lph != 4 && lph != 8 && lph != 16) return -1;
+  if (up != 4 && up != 8 && up != 12 && up != 16) return -1;
+  return (int64_t)tiled_lds_bytes(lph, up, s_cap, e_cap);
+}
+
+extern "C" int anemoi_gt_edge_attention_tiled(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                                              int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
+                                              const float* edge_attr, int up, const int32_t* rowptr,
+                                              const int32_t* tile_src_ptr, const int32_t* tile_src,
+                                              const int32_t* col_local, int s_cap, int e_cap, void* out, int64_t ldo,
+                                              int64_t n_dst, int64_t n_src, int64_t n_edges, int C, int H,
+                                              anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(q && k && v && u && out && rowptr && tile_src_ptr, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_edge_attention_tiled: null pointer");
+  ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_edge_attention_tiled: C=%d not divisible by H=%d", C, H);
+  ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
+                     (x_r == nullptr || ldr >= C),
+                 ANEMOI_ERR_INVALID, "anemoi_gt_edge_attention_tiled: leading dimension too small");
+  ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && n_edges >= 0 && s_cap >= 0 && e_cap >= 0, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_edge_attention_tiled: negative size");
+  if (n_dst == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(n_edges == 0 || (tile_src && col_local && edge_attr), ANEMOI_ERR_INVALID,
+                 "anemoi_gt_edge_attention_tiled: null edge arrays");
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4;
+  const int vec = 16 / esz;
+  const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                       ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                       (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % vec == 0)) && ldq % vec == 0 &&
+                       ldkv % vec == 0 && ldu % vec == 0 && ldo % vec == 0 && ((uintptr_t)edge_attr % 16 == 0) &&
+                       ((int64_t)up * esz) % 8 == 0 && ((int64_t)C * esz) % 16 == 0 && s_cap % 32 == 0 && e_cap % 4 == 0;
+  ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED,
+                 "anemoi_gt_edge_attention_tiled: operands must be 16-byte aligned, s_cap %% 32 == 0, e_cap %% 4 == 0");
+  // 32-bit byte offsets inside the buffer descriptors of k / v / q
+  ANEMOI_REQUIRE(n_src * ldkv * esz < ((int64_t)1 << 31) && (int64_t)32 * ldq * esz < ((int64_t)1 << 31),
+                 ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_tiled: k / v larger than 2 GiB");
+  EdgeTileParams p;
+  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
+  p.attr = edge_attr; p.rowptr = rowptr; p.tile_src_ptr = tile_src_ptr; p.tile_src = tile_src; p.col_local = col_local;
+  p.n_dst = n_dst; p.n_src = n_src; p.n_edges = n_edges;
+  p.n_tiles = (int)((n_dst + TILE_DST - 1) / TILE_DST);
+  p.C = C; p.D = C / H; p.H = H; p.s_cap = s_cap; p.e_cap = e_cap;
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  bool ok = false;
+  if (dtype == ANEMOI_F32) ok = dispatch_tiled<float>(p, up, as_stream(stream));
+  else if (dtype == ANEMOI_BF16) ok = dispatch_tiled<bf16_t>(p, up, as_stream(stream));
+  else return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_tiled: dtype %d", dtype);
+  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED,
+                 "anemoi_gt_edge_attention_tiled: unsupported shape (D=%d, UP=%d, LDS for s_cap=%d e_cap=%d)", C / H, up,
+                 s_cap, e_cap);
+  return check_launch("anemoi_gt_edge_attention_tiled");
 }

@@ -46,6 +46,23 @@ def _as_compute(x: Tensor, dtype: torch.dtype) -> Tensor:
     return x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
 
 
+
+def folded_edge_phase(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr_csr: Tensor, plan,
+                      num_heads: int, up: int, ld_out: Optional[int] = None) -> Tensor:
+    """The folded edge phase on the kernel that suits the edge set: source rows staged per destination tile in LDS
+    (``anemoi_gt_edge_attention_tiled``) where rows are shared by neighbouring destinations -- the mesh processor graph
+    --, the gather kernel (``anemoi_gt_edge_attention_folded``) otherwise.  Decided once per plan / shape."""
+    key = ("edge_tiles", q.dtype, q.shape[1], num_heads, up)
+    choice = plan.__dict__.setdefault("_kernel_choice", {})
+    if key not in choice:
+        choice[key] = runtime.use_edge_tiles(plan, q.dtype, q.shape[1], num_heads, up)
+    tiles = choice[key]
+    if tiles is not None:
+        return ops.gt_edge_attention_tiled(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, tiles, num_heads, up,
+                                           ld_out=ld_out)
+    return ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, plan.col, num_heads, up,
+                                        ld_out=ld_out)
+
 class BaseBlock(nn.Module, ABC):
     """Base class for network blocks."""
 
@@ -291,9 +308,8 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
                                  lambda: self._folded_rows(sq_layers, up),
                                  self._fold_params(sq_layers))  # ... overlapped with the x_r | q | u GEMM
             halo.finish(pending)
-            att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
-                                               edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
-                                               ld_out=wpf.shape[1])
+            att = folded_edge_phase(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan,
+                                    self.num_heads, up, ld_out=wpf.shape[1])
             y = ops.linear(att, wpf, bp, residual=x, stats_eps=self._mlp_ln_eps("dst", dtype))
             return self._node_mlp(y, "dst", 1, out_stats_eps=self._next_ln_eps(dtype))
         all4 = [self.lin_self, self.lin_query, self.lin_key, self.lin_value]
@@ -302,9 +318,8 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             sq = self._ln_linear(xh, "sqkvu", lambda: self._folded_in("sqkvu", all4, dtype, up),
                                  lambda: self._folded_rows(all4, up),
                                  self._fold_params(all4))  # [N, 4C + H*up] = x_r | q | k | v | u
-            att = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c],
-                                               sq[:, 4 * c:], edge_attr_csr, plan.rowptr, plan.col, self.num_heads,
-                                               up, ld_out=wpf.shape[1])
+            att = folded_edge_phase(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
+                                    edge_attr_csr, plan, self.num_heads, up, ld_out=wpf.shape[1])
             # projection(out + x_r) + x_skip, lin_edge part via W_t; the statistics of the MLP's LayerNorm ride on the
             # epilogue, those of the next block's layer_norm1 on the MLP's last Linear
             y = ops.linear(att, wpf, bp, residual=x, stats_eps=self._mlp_ln_eps("dst", dtype))
@@ -393,9 +408,8 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
             del xd
             if halo is not None:
                 halo.finish(pending)
-            att = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:],
-                                               edge_attr_csr, plan.rowptr, plan.col, self.num_heads, up,
-                                               ld_out=wp.shape[1])
+            att = folded_edge_phase(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan,
+                                    self.num_heads, up, ld_out=wp.shape[1])
         else:
             if halo is not None:
                 raise NotImplementedError("node-partitioned blocks need the folded edge kernel")

@@ -286,6 +286,39 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     return out
 
 
+def gt_edge_attention_tiled(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
+                            rowptr: Tensor, tiles, num_heads: int, up: int, out: Optional[Tensor] = None,
+                            ld_out: Optional[int] = None) -> Tensor:
+    """:func:`gt_edge_attention_folded` with the source rows of every 32-destination tile staged in LDS
+    (``anemoi_gt_edge_attention_tiled``).  ``tiles`` = ``runtime.edge_tiles(plan)`` (built once per graph)."""
+    _dev(q, k, v, x_r, u, edge_attr, rowptr, out, tiles.tile_src_ptr, tiles.tile_src, tiles.col_local)
+    n_dst, c = _rows(q).shape
+    if _ld(_rows(k)) != _ld(_rows(v)):
+        raise ValueError("gt_edge_attention_tiled: k and v must share their leading dimension")
+    width = c + num_heads * up
+    ld = width if ld_out is None else ld_out
+    if out is None:
+        out = torch.empty((n_dst, ld), dtype=q.dtype, device=q.device)
+        if ld > width:
+            out[:, width:].zero_()
+    n_edges = tiles.col_local.shape[0]
+    if rowptr.dtype != torch.int32 or rowptr.shape[0] != n_dst + 1 or edge_attr.shape[0] != n_edges or \
+            (n_edges > 0 and (edge_attr.shape[1] != up or not edge_attr.is_contiguous())):
+        raise ValueError("gt_edge_attention_tiled: rowptr int32 [n_dst + 1], edge_attr contiguous [E, up]")
+    if n_edges == 0:
+        edge_attr = torch.zeros((1, up), dtype=torch.float32, device=q.device)
+    alg_bytes = (2 * n_dst + 2 * k.shape[0]) * c * q.element_size() + n_edges * 52 + (n_dst + 1) * 4
+    with _Timed("gt_edge_attention", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=n_edges):
+        st = _lib.load().anemoi_gt_edge_attention_tiled(
+            dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
+            0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
+            rowptr.data_ptr(), tiles.tile_src_ptr.data_ptr(), tiles.tile_src.data_ptr(), tiles.col_local.data_ptr(),
+            tiles.s_cap, tiles.e_cap, out.data_ptr(), _ld(_rows(out)), n_dst, k.shape[0], n_edges, c, num_heads,
+            _stream())
+    _lib.check(st, "anemoi_gt_edge_attention_tiled")
+    return out
+
+
 def gather_add_act(t: Tensor, p_dst: Tensor, p_src: Tensor, dst: Tensor, src: Tensor, act: str = "Identity",
                    out: Optional[Tensor] = None) -> Tensor:
     """``act(t[e] + p_dst[dst[e]] + p_src[src[e]])`` per edge row (first edge-MLP layer of the GNN block)."""

@@ -34,7 +34,7 @@ def _worker(rank, world, port, result_file, processor="GraphTransformer", dtype=
         from anemoi_models_amd.utils.presets import model_config
 
         for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention",
-                     "gt_edge_attention_folded", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
+                     "gt_edge_attention_folded", "gt_edge_attention_tiled", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                      "prognostic_residual", "finalize_output", "convert_pad", "add", "act_forward"):
             setattr(ops, name, getattr(_cpu_ops, name))
         fname = {"GraphTransformer": "cfg1_gt.npz", "GNN": "cfg1_gnn.npz", "Transformer": "cfg1_tfm.npz"}[processor]

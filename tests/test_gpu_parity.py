@@ -216,6 +216,80 @@ def test_gt_edge_attention_folded(dtype, n_src, n_dst, e, c, h, edge_dim):
     assert rel_err(got[:, :c], want_v + xr.float()) < tol
     assert rel_err(got[:, c:c + h * up], want_t) < tol if e > 0 else torch.all(got[:, c:c + h * up] == 0)
     assert torch.all(got[:, c + h * up:] == 0)
+    # the LDS-staged kernel on the same case: same oracle, and the gather kernel's result to rounding
+    from anemoi_models_amd import _lib
+
+    tiles = runtime.edge_tiles(plan)
+    need = _lib.load().anemoi_gt_edge_attention_tiled_lds_bytes(ops.dtype_code(dtype), c, h, up, tiles.s_cap, tiles.e_cap)
+    if 0 <= need <= 160 * 1024:
+        got_t = ops.gt_edge_attention_tiled(q.to(DEV), k.to(DEV), v.to(DEV), xr.to(DEV), u.to(DEV), ea_csr, plan.rowptr,
+                                            tiles, h, up, ld_out=ld).cpu().float()
+        assert rel_err(got_t[:, :c], want_v + xr.float()) < tol
+        assert rel_err(got_t[:, c:c + h * up], want_t) < tol if e > 0 else torch.all(got_t[:, c:c + h * up] == 0)
+        assert torch.all(got_t[:, c + h * up:] == 0)
+        assert rel_err(got_t, got) < (2e-6 if dtype == torch.float32 else 1e-2)
+    else:
+        assert d // (16 // torch.empty((), dtype=dtype).element_size()) < 2 or need > 160 * 1024
+
+
+@pytest.mark.parametrize("dtype,c", [(torch.bfloat16, 1024), (torch.bfloat16, 512), (torch.float32, 1024)])
+def test_gt_edge_attention_tiled_on_the_mesh_graph(dtype, c, monkeypatch):
+    """The LDS-staged edge kernel at the processor graph of BASELINE config 2 (O96 / ico-5 mesh, Morton order): chosen
+    by the heuristic, equal to the gather kernel to rounding, deterministic, last (ragged) tile and high-degree nodes
+    included."""
+    from anemoi_models_amd import ops, runtime
+    from anemoi_models_amd.graphs.synthetic import build_graph
+
+    g = build_graph("o96_ico5")
+    n = g["hidden"].num_nodes
+    lat, lon = g["hidden"].x[:, 0].double(), g["hidden"].x[:, 1].double()
+    inv = runtime.inverse_permutation(runtime.locality_order(torch.stack([lat.sin(), lon.sin(), lat.cos(), lon.cos()], 1)))
+    ei = g[("hidden", "to", "hidden")].edge_index
+    plan = runtime.build_edge_plan(torch.stack([inv[ei[0]], inv[ei[1]]]).to(DEV), n, n)
+    h, up = 16, 12
+    assert runtime.use_edge_tiles(plan, dtype, c, h, up) is None  # opt-in: the gather kernel is the faster one today
+    monkeypatch.setenv("ANEMOI_AMD_EDGE_TILED", "1")
+    tiles = runtime.use_edge_tiles(plan, dtype, c, h, up)
+    assert tiles is not None and n % runtime.TILE_DST != 0
+    dst = plan.dst.long()
+    col = tiles.tile_src.long()[tiles.tile_src_ptr.long()[dst // runtime.TILE_DST] + tiles.col_local.long()]
+    assert torch.equal(col, plan.col.long())  # integer plan: bit exact
+    gen = torch.Generator().manual_seed(3)
+    sq = (torch.randn(n, 4 * c + h * up, generator=gen) * 0.5).to(dtype).to(DEV)
+    attr = torch.randn(plan.num_edges, up, generator=gen).to(DEV)
+    ld = ops.round_up(c + h * up, ops.k_multiple(dtype))
+    args = (sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:], attr, plan.rowptr)
+    want = ops.gt_edge_attention_folded(*args, plan.col, h, up, ld_out=ld)
+    got = ops.gt_edge_attention_tiled(*args, tiles, h, up, ld_out=ld)
+    assert rel_err(got, want) < (2e-6 if dtype == torch.float32 else 1e-2)
+    assert torch.equal(got, ops.gt_edge_attention_tiled(*args, tiles, h, up, ld_out=ld))
+    assert torch.all(got[:, c + h * up:] == 0)
+
+
+def test_model_with_the_lds_staged_edge_kernel(golden_cfg1_gt, graph_o32, monkeypatch):
+    """ANEMOI_AMD_EDGE_TILED=force routes every folded edge phase that fits LDS through anemoi_gt_edge_attention_tiled:
+    the whole model against the reference golden output (bf16: 4 heads of 16 channels; f32 heads of 4 channels stay on the
+    gather kernel) and against the default route."""
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    gold = golden_cfg1_gt
+    model, _ = _build(graph_o32, 64, 4, heads=4)
+    model.load_state_dict(split_prefix(gold, "sd."))
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        y0 = model(gold["x"].to(DEV))
+    monkeypatch.setenv("ANEMOI_AMD_EDGE_TILED", "force")
+    from anemoi_models_amd import ops
+
+    calls = []
+    real = ops.gt_edge_attention_tiled
+    monkeypatch.setattr(ops, "gt_edge_attention_tiled", lambda *a, **k: calls.append(1) or real(*a, **k))
+    model2, _ = _build(graph_o32, 64, 4, heads=4)  # fresh plans: the kernel choice is cached per plan
+    model2.load_state_dict(split_prefix(gold, "sd."))
+    model2 = model2.to(DEV).eval()
+    with torch.no_grad():
+        y1 = model2(gold["x"].to(DEV))
+    assert len(calls) >= 4  # the four processor blocks at least
+    assert rel_err(y1, y0) < 2e-2
 
 
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
