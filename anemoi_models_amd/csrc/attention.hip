@@ -1,7 +1,7 @@
 // Mesh-node multi-head self attention (K7 of SURVEY.md section 2a): softmax(Q K^T / sqrt(D)) V per (batch, head),
 // flash style (no S x S matrix in memory), directly on the fused lin_qkv output  qkv [B*S, 3C] = q | k | v.
 //
-// bf16, D = 64: matrix cores.  One wave owns 32 query rows; the scores are produced TRANSPOSED,
+// bf16, D = 64 or 32: matrix cores.  One wave owns 2 x 32 query rows; the scores are produced TRANSPOSED,
 //     S^T[key][query] = K Q^T      via v_mfma_f32_32x32x16_bf16 with A = K rows, B = Q^T,
 // so that each lane holds 16 scores of ONE query: the online-softmax row max / row sum are in-lane reductions plus a
 // single cross-half exchange.  The K rows are assigned to MFMA rows with index bits 2 and 3 swapped; with the
@@ -52,20 +52,33 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// bf16 / D = 64 MFMA kernel: 4 waves x 32 queries per workgroup, 64-key tiles
+// bf16 MFMA kernel (D = 64 / 32): 8 waves x 64 queries per workgroup, 64-key tiles
 // ---------------------------------------------------------------------------------------------
-constexpr int ATT_D = 64, ATT_KV = 64, ATT_TILE = ATT_KV * 128;  // 8 KiB per operand per stage
+constexpr int ATT_KV = 64;                                                  // keys per LDS tile
 constexpr int ATT_WAVES = 8, ATT_QPW = 64, ATT_QBLK = ATT_WAVES * ATT_QPW;  // 512 queries per workgroup
+
+// 64-byte rows (D = 32) need their own swizzle: a ds_read_b128 is served in groups of 16 lanes, which here read 16
+// different keys at the same chunk; chunk ^ ((row >> 2) & 3) spreads rows r, r + 4, r + 8, r + 12 over the four 16-byte
+// positions of the row, (row & 3) over the four 64-byte bank quarters: conflict free (128-byte rows: aswz, as the GEMM).
+__device__ __forceinline__ int aswz64(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
 // Every workgroup streams ALL keys / values of its (batch, head) through LDS, so the L2 -> LDS traffic of a layer is
 // (S / ATT_QBLK) * H * S * 256 bytes: with 128 queries per workgroup that was 54 GB per layer at S = 40 962 (the kernel
 // ran at the L2 rate, not the MFMA rate); 512 queries per workgroup and two 32-query blocks per wave (K / V^T
 // fragments read from LDS once, used by two MFMAs) cut it 4x and halve the LDS -> register traffic per MFMA.
-__global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
-                                                            const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
-                                                            int64_t ldo, int S, int S_pad, int H, int C, int window,
-                                                            float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE];  // 2 stages x (K tile + V^T tile)
+// ATT_D = 64 (config 3: 1024 channels / 16 heads) or 32 (config 2: 512 / 16): NKS = D / 16 MFMAs per S^T block along the
+// head dimension, NDT = D / 32 row blocks of O^T; the K tile has D * 2 bytes per key, the V^T tile D rows of 128 bytes.
+template <int ATT_D>
+__global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                        const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+                                                        int64_t ldo, int S, int S_pad, int H, int C, int window,
+                                                        float scale_log2e) {
+  static_assert(ATT_D == 32 || ATT_D == 64, "head sizes with an MFMA path");
+  constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32;
+  constexpr int KRB = ATT_D * 2;                        // bytes of a key row in the K tile
+  constexpr int K_TILE = ATT_KV * KRB, V_TILE = ATT_D * 128;
+  constexpr int ATT_STAGE = K_TILE + V_TILE;
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];  // 2 stages x (K tile + V^T tile)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = blockIdx.y, b = blockIdx.z;
@@ -73,7 +86,7 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
   const int half = lane >> 5, ql = lane & 31;
 
   // ---- Q^T fragments (B operand) of the wave's two 32-query blocks: Q[q][ks*16 + half*8 .. +8]
-  abf16x8_t qf[2][4];
+  abf16x8_t qf[2][NKS];
   int qn[2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
     const int qc = qn[qb] < S ? qn[qb] : S - 1;
     const bf16_t* qp = qkv + ((int64_t)b * S + qc) * ld + h * ATT_D + half * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
+    for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
   }
 
   // ---- key range of this workgroup (sliding window: only tiles that intersect any of its queries)
@@ -100,19 +113,30 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
   const int sr = wid * 8 + srow;          // tile row staged by this lane
   const int sc = aswz(sr, scp);           // source chunk landing at LDS position scp
   auto stage = [&](int kt, int buf) {
-    char* ks_ = smem + buf * 2 * ATT_TILE;
-    char* vs_ = ks_ + ATT_TILE;
-    int key = kt * ATT_KV + sr;
-    if (key > S - 1) key = S - 1;
-    aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + sc * 16, ks_ + wid * 1024);
-    aglds16(reinterpret_cast<const char*>(vbase + (int64_t)sr * S_pad + kt * ATT_KV) + sc * 16, vs_ + wid * 1024);
+    char* ks_ = smem + buf * ATT_STAGE;
+    char* vs_ = ks_ + K_TILE;
+    if constexpr (ATT_D == 64) {  // every wave: one 1 KiB piece of K (8 keys) and one of V^T (8 rows d)
+      int key = kt * ATT_KV + sr;
+      if (key > S - 1) key = S - 1;
+      aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + sc * 16, ks_ + wid * 1024);
+      aglds16(reinterpret_cast<const char*>(vbase + (int64_t)sr * S_pad + kt * ATT_KV) + sc * 16, vs_ + wid * 1024);
+    } else if (wid < 4) {  // D = 32: waves 0..3 move K (16 keys x 64 bytes each) ...
+      const int r = wid * 16 + (lane >> 2);
+      int key = kt * ATT_KV + r;
+      if (key > S - 1) key = S - 1;
+      aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + aswz64(r, lane & 3) * 16, ks_ + wid * 1024);
+    } else {  // ... waves 4..7 V^T (8 rows d x 128 bytes each)
+      const int r = (wid - 4) * 8 + srow;
+      aglds16(reinterpret_cast<const char*>(vbase + (int64_t)r * S_pad + kt * ATT_KV) + aswz(r, scp) * 16,
+              vs_ + (wid - 4) * 1024);
+    }
   };
 
-  af32x16_t o_acc[2][2];
+  af32x16_t o_acc[2][NDT];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o_acc[qb][dt][r] = 0.f;
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
@@ -125,16 +149,18 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
     const int buf = (kt - kt_begin) & 1;
     __syncthreads();
     if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
-    const char* ks_ = smem + buf * 2 * ATT_TILE;
-    const char* vs_ = ks_ + ATT_TILE;
+    const char* ks_ = smem + buf * ATT_STAGE;
+    const char* vs_ = ks_ + K_TILE;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       // ---- K fragments of this 32-key block, shared by both query blocks
       const int krow = kb * 32 + kperm;
-      abf16x8_t kf[4];
+      abf16x8_t kf[NKS];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        kf[ks] = *reinterpret_cast<const abf16x8_t*>(ks_ + krow * 128 + (aswz(krow, ks * 2 + half) << 4));
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int ch = ATT_D == 64 ? aswz(krow, ks * 2 + half) : aswz64(krow, ks * 2 + half);
+        kf[ks] = *reinterpret_cast<const abf16x8_t*>(ks_ + krow * KRB + (ch << 4));
+      }
       const int key0 = kt * ATT_KV + kb * 32 + 8 * half;
       const int blk0 = kt * ATT_KV + kb * 32;  // first key of this 32-key block
       abf16x8_t pb[2][2];
@@ -145,7 +171,8 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[qb][ks], s_acc, 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks)
+          s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[qb][ks], s_acc, 0, 0, 0);
         // ---- online softmax in the log2 domain; register r <-> key key0 + (r & 7) + 16 (r >> 3).
         //      VALU budget per element: max, fma, exp2, add (the scale rides in the fma); masking only on tiles that
         //      touch the sequence end / window edge (wave-uniform test); O is rescaled only when the max grew.
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
           const float corr = __builtin_amdgcn_exp2f(m_run[qb] - mloc);  // m_run = -inf -> 0
           l_run[qb] *= corr;
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
+          for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o_acc[qb][dt][r] *= corr;
           m_run[qb] = mloc;
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
       }
       // ---- O^T += V^T P^T : each V^T fragment feeds both query blocks
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
+      for (int dt = 0; dt < NDT; ++dt) {
         const int vrow = dt * 32 + ql;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(512) void mhsa_bf16_d64_kernel(const bf16_t* __rest
     if (qn[qb] < S) {
       bf16_t* op = out + ((int64_t)b * S + qn[qb]) * ldo + h * ATT_D;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float v4[4] = {o_acc[qb][dt][4 * g] * inv, o_acc[qb][dt][4 * g + 1] * inv,
@@ -296,7 +323,7 @@ using namespace anemoi;
 extern "C" {
 
 int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
-  if (dtype == ANEMOI_BF16 && D == ATT_D) return (int64_t)B * H * D * ((S + 63) / 64 * 64) * 2;
+  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32)) return (int64_t)B * H * D * ((S + 63) / 64 * 64) * 2;
   return 0;
 }
 
@@ -308,17 +335,23 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   ANEMOI_REQUIRE(ld >= 3 * (int64_t)C && ldo >= C, ANEMOI_ERR_INVALID, "anemoi_mhsa: leading dimension too small");
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)D);
-  if (dtype == ANEMOI_BF16 && D == ATT_D && (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 && (uintptr_t)out % 8 == 0 &&
+  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32) && (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 && (uintptr_t)out % 8 == 0 &&
       ldo % 4 == 0) {
     ANEMOI_REQUIRE(workspace != nullptr, ANEMOI_ERR_INVALID, "anemoi_mhsa: workspace of %lld bytes required",
                    (long long)anemoi_mhsa_workspace_bytes(dtype, B, S, H, D));
     const int S_pad = (S + 63) / 64 * 64;
     hipLaunchKernelGGL(transpose_v_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, st,
                        static_cast<const bf16_t*>(qkv), ld, S, S_pad, H, D, C, static_cast<bf16_t*>(workspace));
-    hipLaunchKernelGGL(mhsa_bf16_d64_kernel, dim3((S + ATT_QBLK - 1) / ATT_QBLK, H, B), dim3(64 * ATT_WAVES), 0, st,
-                       static_cast<const bf16_t*>(qkv), ld, static_cast<const bf16_t*>(workspace),
-                       static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window, scale * 1.44269504088896340736f);
-    return check_launch("anemoi_mhsa(bf16, D=64)");
+    const dim3 grid((S + ATT_QBLK - 1) / ATT_QBLK, H, B), block(64 * ATT_WAVES);
+    if (D == 64)
+      hipLaunchKernelGGL(mhsa_bf16_kernel<64>, grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                         static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
+                         scale * 1.44269504088896340736f);
+    else
+      hipLaunchKernelGGL(mhsa_bf16_kernel<32>, grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                         static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
+                         scale * 1.44269504088896340736f);
+    return check_launch("anemoi_mhsa(bf16, MFMA)");
   }
   ANEMOI_REQUIRE(D <= 128, ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa: head size %d > 128", D);
   const int64_t units = (int64_t)B * S * H;

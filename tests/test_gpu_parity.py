@@ -736,7 +736,10 @@ def _sdpa(qkv, b, h, window):
     (torch.bfloat16, 1, 300, 4, 64, -1),      # MFMA kernel, ragged S (not a multiple of 64 / 128)
     (torch.bfloat16, 2, 1000, 16, 64, -1),    # MFMA kernel, batch 2, config-3 head layout
     (torch.bfloat16, 1, 777, 2, 64, 40),      # MFMA kernel + sliding window
-    (torch.bfloat16, 1, 200, 8, 32, -1),      # generic kernel, bf16 storage
+    (torch.bfloat16, 1, 200, 8, 32, -1),      # MFMA kernel, D = 32 (config 2's head size: 512 channels / 16 heads)
+    (torch.bfloat16, 2, 1111, 16, 32, -1),    # ... batch 2, ragged S, several 64-key tiles
+    (torch.bfloat16, 1, 900, 4, 32, 70),      # ... sliding window
+    (torch.bfloat16, 1, 200, 8, 16, -1),      # generic kernel, bf16 storage
     (torch.float32, 2, 96, 8, 8, -1),         # generic kernel, the golden block shape
     (torch.float32, 1, 500, 4, 64, -1),
     (torch.float32, 1, 260, 2, 100, 25),      # odd head size + window

@@ -11,7 +11,8 @@ from anemoi_models_amd import ops  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 40962
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-D, dev = 64, "cuda"
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+dev = "cuda"
 C = H * D
 torch.manual_seed(0)
 qkv = (torch.randn(S, 3 * C, device=dev) * 1.0).bfloat16()
