@@ -285,6 +285,67 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
     return _GTEdgeAttention.apply(q, k, v, x_r, u, edge_attr, plan, num_heads, up)
 
 
+# ------------------------------------------------------------------------------------------ GNN edge phase
+class _GatherAddAct(torch.autograd.Function):
+    """``act(t[e] + p_dst[dst[e]] + p_src[src[e]])`` over the CSR slots of ``plan`` (``anemoi_gather_add_act``).  Backward:
+    the pre-activation is recomputed by the same kernel, ``d t = d out * act'(pre)``; ``d p_dst`` is the segment sum of
+    ``d t`` over the destination-sorted CSR, ``d p_src`` the segment sum over the source-major (transposed) CSR -- no
+    atomics, reproducible bit for bit."""
+
+    @staticmethod
+    def forward(ctx, t, p_dst, p_src, plan, act: str):
+        out = ops.gather_add_act(t, p_dst, p_src, plan.dst, plan.col, act=act)
+        ctx.save_for_backward(t, p_dst, p_src)
+        ctx.plan, ctx.act = plan, act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        t, p_dst, p_src = ctx.saved_tensors
+        plan, act = ctx.plan, ctx.act
+        dout = dout.contiguous()
+        if act == "Identity":
+            dpre = dout
+        else:
+            pre = ops.gather_add_act(t, p_dst, p_src, plan.dst, plan.col, act="Identity")
+            if pre.shape[1] % (16 // pre.element_size()) == 0:
+                dpre = ops.act_backward(pre, dout, act)
+            else:  # narrow rows: torch derives the activation (plumbing-sized tensors only)
+                with torch.enable_grad():
+                    pr = pre.float().requires_grad_()
+                    (dpre,) = torch.autograd.grad(_TORCH_ACT[act](pr), pr, dout.float())
+                dpre = dpre.to(dout.dtype)
+        d_dst = d_src = None
+        if ctx.needs_input_grad[1]:
+            d_dst = ops.segment_sum(dpre, plan.rowptr)
+        if ctx.needs_input_grad[2]:
+            rowptr_t, eid_t, _, _ = _transposed_csr(plan)
+            d_src = ops.segment_sum(dpre.index_select(0, eid_t.long()), rowptr_t)
+        return dpre, d_dst, d_src, None, None
+
+
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, plan):
+        ctx.plan = plan
+        return ops.segment_sum(v, plan.rowptr)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout.index_select(0, ctx.plan.dst.long()), None
+
+
+def gather_add_act(t: Tensor, p_dst: Tensor, p_src: Tensor, plan, act: str = "Identity") -> Tensor:
+    """Differentiable ``ops.gather_add_act`` (first edge-MLP layer of the GNN blocks, reference layers/conv.py:47-76)."""
+    return _GatherAddAct.apply(t, p_dst, p_src, plan, act)
+
+
+def segment_sum(v: Tensor, plan) -> Tensor:
+    """Differentiable ``ops.segment_sum``: the scatter-sum of edge rows over their destinations (reference
+    layers/conv.py:74, PyG ``scatter(reduce="sum")``)."""
+    return _SegmentSum.apply(v, plan)
+
+
 # ------------------------------------------------------------------------------------------ a whole processor block
 def _lin_edge_fold(sd: dict, prefix: str, c: int, h: int, up: int, device):
     """(W_u [H*up, C], b_u [H*up], W_t [C, H*up]) of the lin_edge fold, differentiable w.r.t. lin_edge / lin_query /

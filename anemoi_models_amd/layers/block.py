@@ -23,6 +23,7 @@ from torch import nn
 
 from .. import ops
 from .. import runtime
+from .. import training
 from ..runtime import EdgePlan
 from .conv import GraphConv
 from .conv import GraphTransformerConv
@@ -346,7 +347,8 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         if _group_size(model_comm_group) > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
             raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
-        runtime.require_inference(self)
+        if training.wants_grad(self, x, edge_attr):
+            return training.gt_processor_block(self, x, edge_attr, edge_index, size)
         dtype = runtime.compute_dtype(x)
         n = x.shape[0]
         if size is not None and tuple(size) != (n, n):
@@ -442,7 +444,8 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         if _group_size(model_comm_group) > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
             raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
-        runtime.require_inference(self)
+        if training.wants_grad(self, x[0], x[1], edge_attr):
+            return training.gt_mapper_block(self, x, edge_attr, edge_index, size)
         x_src, x_dst = x
         dtype = runtime.compute_dtype(x_dst)
         n_src, n_dst = x_src.shape[0], x_dst.shape[0]
@@ -524,9 +527,8 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
     def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
         if _group_size(model_comm_group) > 1:
             raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
-        runtime.require_inference(self)
-        if self.num_chunks > 1 and self.training:
-            pass  # edge chunking only bounds the reference's temporaries; the fused path has none
+        if training.wants_grad(self, x, edge_attr):
+            return training.gnn_processor_block(self, x, edge_attr, edge_index, size)
         dtype = runtime.compute_dtype(x)
         n = x.shape[0]
         plan = self._plans.get(edge_index, n, n)
@@ -574,7 +576,8 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
     def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
         if _group_size(model_comm_group) > 1:
             raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
-        runtime.require_inference(self)
+        if training.wants_grad(self, x[0], x[1], edge_attr):
+            return training.gnn_mapper_block(self, x, edge_attr, edge_index, size)
         x_src, x_dst = x
         dtype = runtime.compute_dtype(x_dst)
         n_src, n_dst = x_src.shape[0], x_dst.shape[0]

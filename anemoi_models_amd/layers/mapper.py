@@ -18,6 +18,7 @@ from torch import nn
 
 from .. import ops
 from .. import runtime
+from .. import training
 from .block import GraphConvMapperBlock
 from .block import GraphTransformerMapperBlock
 from .block import inference_num_chunks
@@ -140,11 +141,13 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
     def _run(self, x, batch_size: int, shard_shapes, model_comm_group) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
-        runtime.require_inference(self)
         x_src, x_dst = x
-        size = (sum(s[0] for s in shard_shapes[0]), sum(s[0] for s in shard_shapes[1]))
-        if size != (x_src.shape[0], x_dst.shape[0]):
-            raise ValueError(f"shard_shapes describe {size} nodes, inputs have {(x_src.shape[0], x_dst.shape[0])}")
+        if shard_shapes is not None:
+            size = (sum(s[0] for s in shard_shapes[0]), sum(s[0] for s in shard_shapes[1]))
+            if size != (x_src.shape[0], x_dst.shape[0]):
+                raise ValueError(f"shard_shapes describe {size} nodes, inputs have {(x_src.shape[0], x_dst.shape[0])}")
+        if training.wants_grad(self, x_src, x_dst):
+            return training.gt_mapper(self, x_src, x_dst, batch_size)
         dtype = runtime.compute_dtype(x_dst)
 
         def prep(t):
@@ -254,8 +257,9 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
     def _run(self, x, batch_size: int, shard_shapes, model_comm_group):
         if model_comm_group is not None and model_comm_group.size() > 1:
             raise NotImplementedError("GNN mappers: node-partitioned execution is not implemented yet")
-        runtime.require_inference(self)
         x_src, x_dst = x
+        if training.wants_grad(self, x_src, x_dst):
+            return training.gnn_mapper(self, x_src, x_dst, batch_size)
         dtype = runtime.compute_dtype(x_dst)
 
         def prep(t):

@@ -136,7 +136,10 @@ class MLP(nn.Module):
         return self._native
 
     def forward(self, x: Tensor) -> Tensor:
-        runtime.require_inference(self)
+        from .. import training
+
+        if training.wants_grad(self, x):
+            return training.mlp(self, training._cast(x, runtime.compute_dtype(x)))
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native()(xin.contiguous() if xin.stride(-1) != 1 else xin)

@@ -16,6 +16,7 @@ from torch import nn
 
 from .. import ops
 from .. import runtime
+from .. import training
 from .chunk import GNNProcessorChunk
 from .chunk import GraphTransformerProcessorChunk
 from .chunk import TransformerProcessorChunk
@@ -143,7 +144,8 @@ class GNNProcessor(GraphEdgeMixin, BaseProcessor):
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             raise NotImplementedError("processor-level model sharding: use the node-partitioned model forward")
-        runtime.require_inference(self)
+        if training.wants_grad(self, x):
+            return training.gnn_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)
@@ -190,7 +192,8 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
         if model_comm_group is not None and model_comm_group.size() > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
             raise NotImplementedError("processor-level model sharding: use the node-partitioned model forward")
-        runtime.require_inference(self)
+        if training.wants_grad(self, x):
+            return training.gt_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)

@@ -189,38 +189,15 @@ class AnemoiModelEncProcDec(nn.Module):
         return self._idx_cache[key]
 
     def _training_forward(self, x: Tensor, input_affine=None, output_affine=None) -> Tensor:
-        """Forward WITH an autograd graph (anemoi-training calls ``.backward()`` on a loss of the result): the flat
-        GraphTransformer model through ``autograd.model_forward`` -- every heavy op and its backward on the HIP kernels
-        (SURVEY §8f-1).  Single device, GraphTransformer mappers and processor, no boundings; everything else still raises."""
-        from .. import autograd
-        from ..layers.mapper import GraphTransformerBackwardMapper
-        from ..layers.mapper import GraphTransformerForwardMapper
-        from ..layers.processor import GraphTransformerProcessor
+        """Forward WITH an autograd graph (anemoi-training calls ``.backward()`` on a loss of the result): the reference's
+        own composition -- encoder, processor, skip, decoder, residual, boundings -- through the sub-modules' ``forward``
+        methods, which take their differentiable routes (``training.py``: every heavy op and its backward on the HIP
+        kernels, mappers and processor chunks checkpointed as in the reference).  SURVEY section 8f-1."""
+        from .. import training
 
-        if (input_affine is not None or output_affine is not None or len(self.boundings) > 0
-                or (x.shape[0] != 1 and x.shape[2] != 1)
-                or not isinstance(self.encoder, GraphTransformerForwardMapper)
-                or not isinstance(self.decoder, GraphTransformerBackwardMapper)
-                or not isinstance(self.processor, GraphTransformerProcessor)):
-            runtime.require_inference(self)  # raises with the forward-only message
-        sd = dict(self.named_parameters())
-        sd.update({k: v for k, v in self.named_buffers()})
-        graph = {"enc_edge_index": self.encoder.edge_index_base, "enc_edge_attr": self.encoder.edge_attr,
-                 "proc_edge_index": self.processor.edge_index_base, "proc_edge_attr": self.processor.edge_attr,
-                 "dec_edge_index": self.decoder.edge_index_base, "dec_edge_attr": self.decoder.edge_attr}
-        blocks = self.processor.proc
-        dtype = runtime.compute_dtype(x)  # under torch.autocast: the autocast dtype
-        with torch.autocast(device_type=x.device.type, enabled=False):  # this path picks its precisions itself
-            return self._training_forward_impl(autograd, sd, graph, x, blocks, dtype)
-
-    def _training_forward_impl(self, autograd, sd, graph, x, blocks, dtype) -> Tensor:
-        return autograd.model_forward(
-            sd, graph, x, num_heads=self.processor.proc[0].blocks[0].num_heads,
-            num_layers=sum(len(chunk.blocks) for chunk in blocks), num_chunks=len(blocks),
-            prognostic_in=[int(i) for i in self._internal_input_idx], prognostic_out=[int(i) for i in self._internal_output_idx],
-            dtype=dtype, act=self.processor.proc[0].blocks[0].activation,
-            data=self._graph_name_data, hidden=self._graph_name_hidden,
-            plan_cache=self._idx_cache.setdefault("train_plans", runtime.PlanCache()))
+        if input_affine is not None or output_affine is not None:
+            raise NotImplementedError("input_affine / output_affine belong to the inference interface (predict_step)")
+        return training.model_forward(self, x)
 
     def forward(self, x: Tensor, model_comm_group=None, *, input_affine=None, output_affine=None) -> Tensor:
         """``input_affine`` / ``output_affine`` (keyword-only extension, ``(mul, add)`` per input / output variable): ``x``

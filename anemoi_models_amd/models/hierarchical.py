@@ -118,7 +118,10 @@ class AnemoiModelEncProcDecHierarchical(AnemoiModelEncProcDec):
     def forward(self, x: Tensor, model_comm_group=None) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             raise NotImplementedError("the hierarchical model has no node-partitioned forward yet")
-        runtime.require_inference(self)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .. import training
+
+            return training.hierarchical_forward(self, x)
         batch_size, _, ensemble_size, grid, _ = x.shape
         dtype = runtime.compute_dtype(x)
         kmult = ops.k_multiple(dtype)

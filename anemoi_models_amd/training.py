@@ -1,0 +1,370 @@
+"""Differentiable forwards of the module tree: what ``module(x)`` runs when autograd is on.
+
+Every ``nn.Module`` of this package keeps two routes to the same arithmetic:
+
+* ``native`` -- the inference launch sequence (packed weights, LayerNorm folded into GEMMs, fused epilogues, HIP graph
+  friendly); taken under ``torch.no_grad()``;
+* the functions below -- the same layers composed from the ``torch.autograd.Function``s of :mod:`anemoi_models_amd.autograd`
+  (fused Linear, LayerNorm, the folded graph-transformer edge phase, the GNN gather / segment-sum), each with its forward
+  AND backward on the HIP kernels.  ``module.forward`` dispatches here whenever a gradient is wanted
+  (:func:`wants_grad`), so ``loss.backward()`` works on a block, a mapper, a processor or a whole model exactly as in
+  the reference's own tests (reference tests/layers/processor/test_graphtransformer_processor.py:145-159) and in
+  anemoi-training.
+
+Model families: flat and hierarchical GraphTransformer models, the GNN processor and GNN mappers.  The Transformer
+processor (mesh-node self attention) has no backward kernel yet and still refuses gradients.
+
+Activation checkpointing follows the reference: every mapper call and every processor chunk is wrapped in
+``torch.utils.checkpoint`` (reference models/encoder_processor_decoder.py:159-166, layers/processor.py:73-77); all
+kernels are deterministic, so the recomputation reproduces the forward bit for bit.  ``ANEMOI_AMD_CHECKPOINT=0``
+keeps every activation instead (faster, config 3 then needs ~58 GiB per sample).
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch import nn
+from torch.utils.checkpoint import checkpoint as _torch_checkpoint
+
+from . import autograd
+from . import ops
+from . import runtime
+
+
+def wants_grad(module: nn.Module, *tensors) -> bool:
+    """True when this call must build an autograd graph: grad mode on and a parameter or an input asks for a gradient."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(isinstance(t, Tensor) and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
+def _checkpoint(fn, *args):
+    if os.environ.get("ANEMOI_AMD_CHECKPOINT", "1") == "0":
+        return fn(*args)
+    return _torch_checkpoint(fn, *args, use_reentrant=False)
+
+
+def _cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    x = x if x.dtype == dtype else x.to(dtype)
+    return x if x.stride(-1) == 1 else x.contiguous()
+
+
+def _no_group(model_comm_group) -> None:
+    if model_comm_group is not None and model_comm_group.size() > 1:
+        raise NotImplementedError("training across a model communication group goes through the model root "
+                                  "(distributed.partition.sharded_training_forward)")
+
+
+# ------------------------------------------------------------------------------------------------ MLP / Sequential
+def sequential(seq: nn.Sequential, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+    """Linear / activation / LayerNorm stack with each Linear fused with the activation behind it."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            act = "Identity"
+            if i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm)):
+                act = type(mods[i + 1]).__name__
+                i += 1
+            last = i == len(mods) - 1
+            x = autograd.linear(x, m.weight, m.bias, act, residual if last else None)
+            if last:
+                residual = None
+        elif isinstance(m, nn.LayerNorm):
+            x = autograd.layer_norm(x, m.weight, m.bias, m.eps)
+        else:
+            raise NotImplementedError(f"module {type(m).__name__} has no differentiable kernel route")
+        i += 1
+    return x if residual is None else x + residual
+
+
+def mlp(module, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+    """``layers.mlp.MLP`` (reference layers/mlp.py:74-89)."""
+    from .layers.utils import CheckpointWrapper
+
+    seq = module.model.module if isinstance(module.model, CheckpointWrapper) else module.model
+    return sequential(seq, x, residual)
+
+
+# ------------------------------------------------------------------------------------------------ graph transformer
+def _block_sd(block: nn.Module) -> dict:
+    return {"b." + k: v for k, v in block.named_parameters()}
+
+
+def _check_heads(channels: int, num_heads: int, dtype: torch.dtype) -> None:
+    vec = 16 // torch.empty((), dtype=dtype).element_size()
+    if (channels // num_heads) % vec != 0:
+        raise NotImplementedError(f"graph-transformer training needs a head size that is a multiple of {vec} for {dtype} "
+                                  f"(got {channels} channels / {num_heads} heads)")
+
+
+def _gt_edge_inputs(block, edge_attr: Tensor, edge_index: Tensor, n_src: int, n_dst: int):
+    plan = block._plans.get(edge_index, n_src, n_dst)
+    up = ops.round_up(edge_attr.shape[1] + 1, 4)
+    return plan, autograd._edge_attr_csr(edge_attr, None, plan, up)
+
+
+def gt_processor_block(block, x: Tensor, edge_attr: Tensor, edge_index: Tensor, size=None):
+    """``GraphTransformerProcessorBlock.forward`` (reference layers/block.py:602-635) with an autograd graph."""
+    dtype = runtime.compute_dtype(x)
+    n = x.shape[0]
+    if size is not None and tuple(size) != (n, n):
+        raise ValueError(f"Encountered tensor with size {n} in dimension 0, but expected size {tuple(size)}")
+    _check_heads(x.shape[1], block.num_heads, dtype)
+    plan, ea = _gt_edge_inputs(block, edge_attr, edge_index, n, n)
+    y = autograd.gt_processor_block(_cast(x, dtype), _block_sd(block), "b", ea, plan, block.num_heads, block.activation,
+                                    block.layer_norm1.eps)
+    return y, edge_attr
+
+
+def gt_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None):
+    """``GraphTransformerMapperBlock.forward`` (reference layers/block.py:479-550)."""
+    if block.update_src_nodes:
+        raise NotImplementedError("update_src_nodes=True has no differentiable route (the reference's mappers use False)")
+    x_src, x_dst = x
+    dtype = runtime.compute_dtype(x_dst)
+    n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+    if size is not None and tuple(size) != (n_src, n_dst):
+        raise ValueError(f"Encountered tensors with sizes {(n_src, n_dst)}, but expected size {tuple(size)}")
+    _check_heads(x_dst.shape[1], block.num_heads, dtype)
+    plan, ea = _gt_edge_inputs(block, edge_attr, edge_index, n_src, n_dst)
+    y = autograd.gt_mapper_block(_cast(x_src, dtype), _cast(x_dst, dtype), _block_sd(block), "b", ea, plan, block.num_heads,
+                                 block.activation, block.layer_norm1.eps)
+    return (x_src, y), edge_attr
+
+
+def _set_plan_and_attrs(mod, n_src: int, n_dst: int, batch_size: int, up: Optional[int] = None):
+    """(plan, edge attributes in CSR order) of a mapper / processor: ``cat[edge_attr, trainable]`` repeated per batch
+    element (reference layers/graph.py:37-44) on the batched graph (layers/mapper.py:150-171)."""
+    plan = mod._plans.get(mod.edge_index_base, n_src, n_dst, batch_size, mod.edge_inc)
+    trainable = mod.trainable.trainable
+    if up is None:  # GNN: the plain attribute matrix
+        parts = [mod.edge_attr.float()] + ([] if trainable is None else [trainable.float()])
+        return plan, torch.cat(parts, dim=1).repeat(batch_size, 1)[plan.perm.long()]
+    return plan, autograd._edge_attr_csr(mod.edge_attr, trainable, plan, up, batch_size)
+
+
+def gt_processor(proc, x: Tensor, batch_size: int) -> Tensor:
+    """``GraphTransformerProcessor.forward`` (reference layers/processor.py:317-343): checkpointed chunks of blocks that
+    share ONE plan and ONE CSR attribute matrix."""
+    dtype = runtime.compute_dtype(x)
+    blk0 = proc.proc[0].blocks[0]
+    _check_heads(x.shape[1], blk0.num_heads, dtype)
+    n = x.shape[0]
+    plan, ea = _set_plan_and_attrs(proc, n, n, batch_size, ops.round_up(proc.edge_dim + 1, 4))
+
+    def run_chunk(chunk, h, attrs):
+        for blk in chunk.blocks:
+            h = autograd.gt_processor_block(h, _block_sd(blk), "b", attrs, plan, blk.num_heads, blk.activation,
+                                            blk.layer_norm1.eps)
+        return h
+
+    h = _cast(x, dtype)
+    for chunk in proc.proc:
+        h = _checkpoint(run_chunk, chunk, h, ea)
+    return h
+
+
+def gt_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int) -> Tensor:
+    """``GraphTransformerForwardMapper`` / ``GraphTransformerBackwardMapper`` (reference layers/mapper.py:275-418): returns
+    the mapped (and, for the backward mapper, extracted) destination nodes."""
+    dtype = runtime.compute_dtype(x_dst)
+    blk = mapper.proc
+    _check_heads(mapper.hidden_dim, blk.num_heads, dtype)
+    plan, ea = _set_plan_and_attrs(mapper, x_src.shape[0], x_dst.shape[0], batch_size, ops.round_up(mapper.edge_dim + 1, 4))
+    hs, hd = _cast(x_src, dtype), _cast(x_dst, dtype)
+    if hasattr(mapper, "emb_nodes_src"):
+        hs = autograd.linear(hs, mapper.emb_nodes_src.weight, mapper.emb_nodes_src.bias)
+    hd = autograd.linear(hd, mapper.emb_nodes_dst.weight, mapper.emb_nodes_dst.bias)
+    y = autograd.gt_mapper_block(hs, hd, _block_sd(blk), "b", ea, plan, blk.num_heads, blk.activation, blk.layer_norm1.eps)
+    ext = getattr(mapper, "node_data_extractor", None)
+    if ext is not None:
+        y = sequential(ext, y)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ GNN
+def _gnn_edge_update(conv_mlp, x_dst: Tensor, x_src: Tensor, e_csr: Tensor, plan) -> Tensor:
+    """``edge_mlp(cat[x_i, x_j, e]) + e`` (reference layers/conv.py:47-76) without the ``[E, 3C]`` concatenation: the
+    first Linear splits into a destination part, a source part (node GEMMs) and an edge part (edge GEMM); the sum and the
+    activation are the gather kernel."""
+    from .layers.utils import CheckpointWrapper
+
+    seq = conv_mlp.model.module if isinstance(conv_mlp.model, CheckpointWrapper) else conv_mlp.model
+    mods = list(seq)
+    lin1 = mods[0]
+    c = x_dst.shape[1]
+    if not isinstance(lin1, nn.Linear) or lin1.in_features != 3 * c or e_csr.shape[1] != c:
+        raise ValueError(f"GNN block expects node / edge width {lin1.in_features // 3}, got {c} / {e_csr.shape[1]}")
+    act1, rest = "Identity", mods[1:]
+    if rest and not isinstance(rest[0], (nn.Linear, nn.LayerNorm)):
+        act1, rest = type(rest[0]).__name__, rest[1:]
+    p_dst = autograd.linear(x_dst, lin1.weight[:, :c], None)
+    p_src = autograd.linear(x_src, lin1.weight[:, c:2 * c], None)
+    t = autograd.linear(e_csr, lin1.weight[:, 2 * c:], lin1.bias)
+    h = autograd.gather_add_act(t, p_dst, p_src, plan, act1)
+    return sequential(nn.Sequential(*rest), h, residual=e_csr)
+
+
+def gnn_processor_block_csr(block, x: Tensor, e_csr: Tensor, plan):
+    """``GraphConvProcessorBlock`` (reference layers/block.py:193-223) on an edge state kept in CSR order."""
+    e_new = _gnn_edge_update(block.conv.edge_mlp, x, x, e_csr, plan)
+    agg = autograd.segment_sum(e_new, plan)
+    return mlp(block.node_mlp, torch.cat([x, agg], dim=1), residual=x), e_new
+
+
+def gnn_mapper_block_csr(block, x_src: Tensor, x_dst: Tensor, e_csr: Tensor, plan):
+    """``GraphConvMapperBlock`` (reference layers/block.py:226-286)."""
+    e_new = _gnn_edge_update(block.conv.edge_mlp, x_dst, x_src, e_csr, plan)
+    agg = autograd.segment_sum(e_new, plan)
+    new_dst = mlp(block.node_mlp, torch.cat([x_dst, agg], dim=1), residual=x_dst)
+    new_src = mlp(block.node_mlp, torch.cat([x_src, x_src], dim=1), residual=x_src) if block.update_src_nodes else x_src
+    return (new_src, new_dst), e_new
+
+
+def _csr_round_trip(plan, edge_attr: Tensor, dtype):
+    perm = plan.perm.long()
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.shape[0], device=perm.device)
+    return _cast(edge_attr, dtype).index_select(0, perm), inv
+
+
+def gnn_processor_block(block, x: Tensor, edge_attr: Tensor, edge_index: Tensor, size=None):
+    """``GraphConvProcessorBlock.forward`` with the caller's edge order in and out."""
+    dtype = runtime.compute_dtype(x)
+    n = x.shape[0]
+    plan = block._plans.get(edge_index, n, n)
+    e_csr, inv = _csr_round_trip(plan, edge_attr, dtype)
+    x_new, e_new = gnn_processor_block_csr(block, _cast(x, dtype), e_csr, plan)
+    return x_new, e_new.index_select(0, inv)
+
+
+def gnn_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None):
+    x_src, x_dst = x
+    dtype = runtime.compute_dtype(x_dst)
+    n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+    if size is not None and tuple(size) != (n_src, n_dst):
+        raise ValueError(f"Encountered tensors with sizes {(n_src, n_dst)}, but expected size {tuple(size)}")
+    plan = block._plans.get(edge_index, n_src, n_dst)
+    e_csr, inv = _csr_round_trip(plan, edge_attr, dtype)
+    nodes, e_new = gnn_mapper_block_csr(block, _cast(x_src, dtype), _cast(x_dst, dtype), e_csr, plan)
+    return nodes, e_new.index_select(0, inv)
+
+
+def gnn_processor(proc, x: Tensor, batch_size: int) -> Tensor:
+    """``GNNProcessor.forward`` (reference layers/processor.py:228-250, layers/chunk.py:165-181)."""
+    dtype = runtime.compute_dtype(x)
+    n = x.shape[0]
+    plan, ea = _set_plan_and_attrs(proc, n, n, batch_size)
+
+    def run_chunk(chunk, h, e):
+        if chunk.emb_edges is not None:
+            e = mlp(chunk.emb_edges, e)
+        for blk in chunk.blocks:
+            h, e = gnn_processor_block_csr(blk, h, e, plan)
+        return h, e
+
+    h, e = _cast(x, dtype), _cast(ea, dtype)
+    for chunk in proc.proc:
+        h, e = _checkpoint(run_chunk, chunk, h, e)
+    return h
+
+
+def gnn_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int):
+    """``GNNForwardMapper`` / ``GNNBackwardMapper`` (reference layers/mapper.py:485-522, 600-705): returns
+    ``(source nodes after the block, destination nodes after the block / extraction)``."""
+    dtype = runtime.compute_dtype(x_dst)
+    plan, ea = _set_plan_and_attrs(mapper, x_src.shape[0], x_dst.shape[0], batch_size)
+    e = mlp(mapper.emb_edges, _cast(ea, dtype))
+    hs, hd = _cast(x_src, dtype), _cast(x_dst, dtype)
+    if hasattr(mapper, "emb_nodes_src"):
+        hs, hd = mlp(mapper.emb_nodes_src, hs), mlp(mapper.emb_nodes_dst, hd)
+    (hs, hd), _ = gnn_mapper_block_csr(mapper.proc, hs, hd, e, plan)
+    ext = getattr(mapper, "node_data_extractor", None)
+    if ext is not None:
+        hd = mlp(ext, hd)
+    return hs, hd
+
+
+# ------------------------------------------------------------------------------------------------ model roots
+def _node_rows(model, name: str, rows: int) -> Tensor:
+    na = model.node_attributes
+    parts = [na.latlons(name)]
+    tr = na.trainable_tensors[name].trainable
+    if tr is not None:
+        parts.append(tr)
+    return torch.cat(parts, dim=1).repeat(rows, 1)
+
+
+def _finish(model, out: Tensor, x: Tensor, b: int, ens: int, g: int) -> Tensor:
+    y = out.float().reshape(b, ens, g, -1).to(x.dtype).clone()
+    y[..., model._internal_output_idx] = y[..., model._internal_output_idx] + x[:, -1, :, :, model._internal_input_idx]
+    for bounding in model.boundings:  # in-place clamps on the cloned output: plain differentiable torch ops
+        y = bounding(y)
+    return y
+
+
+def model_forward(model, x: Tensor) -> Tensor:
+    """``AnemoiModelEncProcDec.forward`` (reference models/encoder_processor_decoder.py:168-233) through the sub-modules'
+    own ``forward`` methods -- whatever families the config names (GraphTransformer / GNN mappers and processor)."""
+    b, _, ens, g, _ = x.shape
+    if ens != 1 and b != 1:
+        raise NotImplementedError("an ensemble dimension > 1 only with batch size 1 (the reference repeats the node "
+                                  "attributes per batch element only)")
+    rows = b * ens
+    data, hidden = model._graph_name_data, model._graph_name_hidden
+    dtype = runtime.compute_dtype(x)  # under torch.autocast: the autocast dtype
+    with torch.autocast(device_type=x.device.type, enabled=False):  # this route picks its precisions itself: the
+        # activations are cast once here and every sub-module follows the dtype of what it is handed
+        x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(rows * g, -1), _node_rows(model, data, rows)], dim=1).to(dtype)
+        x_hidden = _node_rows(model, hidden, rows).to(dtype)
+        shapes = None  # (single device: the modules ignore shard shapes on this route)
+        x_data_latent, x_latent = _checkpoint(lambda a, c: model.encoder((a, c), rows, shapes), x_data, x_hidden)
+        x_proc = model.processor(x_latent, rows, shapes)
+        x_latent_proc = x_proc + x_latent
+        out = _checkpoint(lambda a, c: model.decoder((a, c), rows, shapes), x_latent_proc, x_data_latent)
+        return _finish(model, out, x, b, ens, g)
+
+
+def hierarchical_forward(model, x: Tensor) -> Tensor:
+    """``AnemoiModelEncProcDecHierarchical.forward`` (reference models/hierarchical.py:178-308): encoder, level
+    processors and downscale mappers to the coarsest level, upscale mappers with skip connections back, decoder."""
+    b, _, ens, g, _ = x.shape
+    if ens != 1 and b != 1:
+        raise NotImplementedError("an ensemble dimension > 1 only with batch size 1")
+    rows = b * ens
+    data, names = model._graph_name_data, model._graph_hidden_names
+    dtype = runtime.compute_dtype(x)
+
+    def first(out):  # GraphTransformer backward mappers return the destination nodes; forward / GNN mappers (src, dst)
+        return out[1] if isinstance(out, tuple) else out
+
+    def run(mapper, a, c):
+        return _checkpoint(lambda p, q: mapper((p, q), rows, None), a, c)
+
+    with torch.autocast(device_type=x.device.type, enabled=False):
+        x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(rows * g, -1), _node_rows(model, data, rows)], dim=1).to(dtype)
+        x_hidden = {h: _node_rows(model, h, rows).to(dtype) for h in names}
+        curr = first(run(model.encoder, x_data, x_hidden[names[0]]))
+        x_skip, x_encoded = {}, {}
+        for src, dst in zip(names[:-1], names[1:]):  # ---- down (reference :224-249)
+            if model.level_process:
+                curr = model.down_level_processor[src](curr, rows, None)
+            x_skip[src] = curr
+            out = run(model.downscale[src], curr, x_hidden[dst])
+            x_encoded[src], curr = out if isinstance(out, tuple) else (curr, out)
+        if model.level_process:  # coarsest level (reference :252-258)
+            curr = model.down_level_processor[names[-1]](curr, rows, None)
+        for dst, src in zip(reversed(names[:-1]), reversed(names[1:])):  # ---- up (reference :261-286)
+            curr = first(run(model.upscale[src], curr, x_encoded[dst])) + x_skip[dst]
+            if model.level_process:
+                curr = model.up_level_processor[dst](curr, rows, None)
+        out = first(run(model.decoder, curr, x_data))
+        return _finish(model, out, x, b, ens, g)

@@ -1222,9 +1222,9 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
     for k in used:
         err = float((grads[k].grad.cpu() - rsd[k].grad.float()).abs().max())
         assert err <= 5e-3 * max(float(rsd[k].grad.abs().max()), 0.02 * scale_all), (k, err)
-    # second step: the cached plans (and their transposed CSR) are reused
-    plans = model._idx_cache["train_plans"]._plans
-    n_plans = len(plans)
+    # second step: the modules' cached plans (and the transposed CSR hung on them) are reused
+    plan = model.processor._plans.get(model.processor.edge_index_base, 162, 162, 1, model.processor.edge_inc)
+    assert getattr(plan, "_transposed", None) is not None
     model.zero_grad()
     model(x.to(DEV)).backward(dy.to(DEV))
-    assert len(plans) == n_plans == 3
+    assert model.processor._plans.get(model.processor.edge_index_base, 162, 162, 1, model.processor.edge_inc) is plan

@@ -1,0 +1,185 @@
+"""Training of every model family that has a backward on the HIP kernels: whole-model output and
+every parameter gradient against torch autograd through the CPU oracle (f64), on the golden weights of the reference.
+
+Flat GraphTransformer model: tests/test_gpu_parity.py (``test_whole_model_training_step_*``).  Here: GNN processor with
+GraphTransformer mappers, GNN processor + GNN mappers, the hierarchical model, block-level ``.backward()`` as the
+reference's own tests do it, activation checkpointing on / off, boundings under autograd.
+"""
+
+import pytest
+import torch
+
+from conftest import split_prefix
+from oracle import reference_path as ref
+from test_oracle_golden import graph_tensors
+from test_oracle_golden import hier_graph_tensors
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+KW = dict(num_heads=16, num_layers=4, num_chunks=2, prognostic_in=list(range(10)), prognostic_out=list(range(10)))
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def _oracle_grads(fn, sd, x, dy):
+    rsd = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+    y = fn(rsd, x.double())
+    y.backward(dy.double())
+    return y.detach().float(), rsd
+
+
+def _compare_grads(model, rsd, tol=5e-3):
+    grads = dict(model.named_parameters())
+    used = [k for k in grads if rsd[k].grad is not None and float(rsd[k].grad.abs().max()) > 0]
+    scale_all = max(float(rsd[k].grad.abs().max()) for k in used)
+    for k in used:
+        assert grads[k].grad is not None, k
+        err = float((grads[k].grad.cpu() - rsd[k].grad.float()).abs().max())
+        assert err <= tol * max(float(rsd[k].grad.abs().max()), 0.02 * scale_all), (k, err, float(rsd[k].grad.abs().max()))
+    return used
+
+
+def _f64(graph):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in graph.items()}
+
+
+@pytest.mark.parametrize("mappers", ["GraphTransformer", "GNN"])
+def test_gnn_model_training_step_vs_oracle_autograd(graph_o32, golden_cfg1_gnn, golden_cfg1_gnn_all, mappers):
+    """GNN processor (edge-MLP message passing) with GraphTransformer or GNN mappers: forward + backward through the
+    nn.Module on the HIP kernels (gather_add_act / segment_sum and their backward, fused Linear, LayerNorm)."""
+    from test_gpu_parity import _build
+
+    gold = golden_cfg1_gnn if mappers == "GraphTransformer" else golden_cfg1_gnn_all
+    sd = split_prefix(gold, "sd.")
+    graph = _f64(graph_tensors(graph_o32))
+    dy = torch.randn(gold["y"].shape, generator=torch.Generator().manual_seed(2))
+    want, rsd = _oracle_grads(lambda s, xx: ref.model_forward(s, graph, xx, processor="GNN", mappers=mappers, **KW), sd,
+                              gold["x"], dy)
+    assert rel_err(want, gold["y"]) < 1e-4
+    model, _ = _build(graph_o32, 64, 4, processor="GNN", mappers=mappers)
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    y = model(gold["x"].to(DEV))
+    assert y.requires_grad and rel_err(y.detach(), gold["y"]) < 1e-4
+    y.backward(dy.to(DEV))
+    used = _compare_grads(model, rsd)
+    assert len(used) > 60 and any("conv.edge_mlp" in k for k in used) and any(k.endswith("trainable") for k in used)
+    torch.optim.SGD(model.parameters(), lr=1e-3).step()
+
+
+def test_hierarchical_model_training_step_vs_oracle_autograd(graph_hier, golden_hier_gt):
+    from test_gpu_parity import _build_hier
+
+    gold = golden_hier_gt
+    sd = split_prefix(gold, "sd.")
+    graph = _f64(hier_graph_tensors(graph_hier))
+    dy = torch.randn(gold["y"].shape, generator=torch.Generator().manual_seed(3))
+    want, rsd = _oracle_grads(
+        lambda s, xx: ref.hierarchical_forward(s, graph, xx, hidden=["hidden_1", "hidden_2"], num_heads=16, level_layers=2,
+                                               prognostic_in=list(range(10)), prognostic_out=list(range(10))),
+        sd, gold["x"], dy)
+    model = _build_hier(graph_hier)
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    y = model(gold["x"].to(DEV))
+    assert y.requires_grad and rel_err(y.detach(), gold["y"]) < 1e-4
+    y.backward(dy.to(DEV))
+    used = _compare_grads(model, rsd)
+    assert any(k.startswith("downscale.") for k in used) and any(k.startswith("up_level_processor.") for k in used)
+
+
+def test_block_level_backward_like_the_reference_tests(golden_blocks):
+    """reference tests/layers/processor/test_graphtransformer_processor.py:145-159 style: call the block, ``.backward()``
+    on a sum, every parameter has a gradient -- GraphTransformer processor block, mapper block and GNN block, checked
+    against the oracle's autograd."""
+    from anemoi_models_amd.layers.block import GraphConvProcessorBlock
+    from anemoi_models_amd.layers.block import GraphTransformerMapperBlock
+    from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
+
+    b = golden_blocks
+    # --- GraphTransformer processor block (128 channels, 16 heads of 8: f32 lanes own 4 channels)
+    sd = split_prefix(b, "gtp.sd.")
+    blk = GraphTransformerProcessorBlock(128, 512, 128, edge_dim=b["gtp.edge_attr"].shape[1], num_heads=16)
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV)
+    x = b["gtp.x"].to(DEV).requires_grad_()
+    y, ea = blk(x, b["gtp.edge_attr"].to(DEV), b["gtp.edge_index"].to(DEV), None, 1)
+    assert rel_err(y.detach(), b["gtp.y"]) < 1e-4
+    y.sum().backward()
+    rsd = {"x." + k: v.double().requires_grad_() for k, v in sd.items()}
+    xr = b["gtp.x"].double().requires_grad_()
+    ref.gt_processor_block(rsd, "x", xr, b["gtp.edge_attr"].double(), b["gtp.edge_index"], 16).sum().backward()
+    assert rel_err(x.grad, xr.grad) < 2e-3
+    for k, p in blk.named_parameters():
+        assert p.grad is not None and rel_err(p.grad, rsd["x." + k].grad) < 5e-3, k
+    # --- GraphTransformer mapper block
+    sd = split_prefix(b, "gtm.sd.")
+    blk = GraphTransformerMapperBlock(64, 256, 64, edge_dim=b["gtm.edge_attr"].shape[1], num_heads=16)
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV)
+    xs, xd = b["gtm.x_src"].to(DEV).requires_grad_(), b["gtm.x_dst"].to(DEV).requires_grad_()
+    (_, y), _ = blk((xs, xd), b["gtm.edge_attr"].to(DEV), b["gtm.edge_index"].to(DEV), None, 1,
+                    size=(xs.shape[0], xd.shape[0]))
+    assert rel_err(y.detach(), b["gtm.y_dst"]) < 1e-4
+    y.sum().backward()
+    assert xs.grad is not None and xd.grad is not None and all(p.grad is not None for p in blk.parameters())
+    # --- GNN processor block: edges in the caller's order in and out
+    sd = split_prefix(b, "gnn.sd.")
+    blk = GraphConvProcessorBlock(64, 64, mlp_extra_layers=0, activation="SiLU")
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV)
+    x, e = b["gnn.x"].to(DEV).requires_grad_(), b["gnn.edge_attr"].to(DEV).requires_grad_()
+    xn, en = blk(x, e, b["gnn.edge_index"].to(DEV), None)
+    assert rel_err(xn.detach(), b["gnn.y"]) < 1e-4 and rel_err(en.detach(), b["gnn.edges_new"]) < 1e-4
+    (xn.sum() + en.sum()).backward()
+    rsd = {"x." + k: v.double().requires_grad_() for k, v in sd.items()}
+    xr, er = b["gnn.x"].double().requires_grad_(), b["gnn.edge_attr"].double().requires_grad_()
+    xo, eo = ref.gnn_processor_block(rsd, "x", xr, er, b["gnn.edge_index"])
+    (xo.sum() + eo.sum()).backward()
+    assert rel_err(x.grad, xr.grad) < 2e-3 and rel_err(e.grad, er.grad) < 2e-3
+    for k, p in blk.named_parameters():
+        assert p.grad is not None and rel_err(p.grad, rsd["x." + k].grad) < 5e-3, k
+
+
+def test_checkpointing_reproduces_the_gradients_bit_for_bit(graph_o32, golden_cfg1_gt, monkeypatch):
+    """Mapper calls and processor chunks are recomputed in the backward (as the reference checkpoints them); all kernels
+    are deterministic, so the gradients equal those of the run that kept every activation -- and less memory is held."""
+    from test_gpu_parity import _build
+
+    gold = golden_cfg1_gt
+    dy = torch.randn(gold["y"].shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ANEMOI_AMD_CHECKPOINT", mode)
+        model, _ = _build(graph_o32, 64, 4)
+        model.load_state_dict(split_prefix(gold, "sd."))
+        model = model.to(DEV)
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        y = model(gold["x"].to(DEV))
+        held = torch.cuda.memory_allocated() - base
+        y.backward(dy)
+        res[mode] = (y.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}, held)
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, g in res["1"][1].items():
+        assert torch.equal(g, res["0"][1][k]), k
+    assert res["1"][2] < 0.6 * res["0"][2], (res["1"][2], res["0"][2])
+
+
+def test_training_with_boundings(graph_o32, golden_cfg1_gt):
+    """A model with a ``bounding:`` list under autograd: the forward equals the reference golden output and the clamps
+    cut the gradient where they bite."""
+    from conftest import load_npz
+    from test_bounding import bounded_model
+
+    model = bounded_model(graph_o32)
+    model.load_state_dict(split_prefix(golden_cfg1_gt, "sd."))
+    model = model.to(DEV)
+    y = model(golden_cfg1_gt["x"].to(DEV))
+    assert y.requires_grad and rel_err(y.detach(), load_npz("bounding_gt.npz")["y"]) < 1e-4
+    y.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
