@@ -305,7 +305,10 @@ def build_shard_plan(model, group, device) -> ShardPlan:
 
 def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=None) -> Tensor:
     """Full-input / full-output forward with the mesh partitioned over ``group`` (batch size 1, as in the reference)."""
-    runtime.require_inference(model)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+        if input_affine is not None or output_affine is not None:
+            raise NotImplementedError("input_affine / output_affine belong to the inference interface (predict_step)")
+        return sharded_training_forward(model, x, group)
     batch_size, _, ensemble_size, grid, _ = x.shape
     assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
     dtype = runtime.compute_dtype(x)
@@ -343,15 +346,166 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
     send[: y_local.shape[0]] = y_local
     gathered = torch.empty((sp.world, max_rows, v_out), dtype=torch.float32, device=x.device)
     _allgather_rows(gathered.view(-1, v_out), send, group)
-    if sp.gather_pos is None:  # grid order <- (rank, row) order of the padded buffer: ONE gather instead of cat + scatter
-        starts = torch.tensor([r * max_rows for r in range(sp.world)], device=x.device)
-        counts = torch.tensor(sp.dec_counts, device=x.device)
-        offs = torch.cumsum(counts, 0) - counts
-        rank_of = torch.repeat_interleave(torch.arange(sp.world, device=x.device), counts)
-        pos = starts[rank_of] + torch.arange(int(counts.sum()), device=x.device) - offs[rank_of]
-        gp = torch.empty(grid, dtype=torch.long, device=x.device)
-        gp[sp.dec_all_ids] = pos
-        sp.gather_pos = gp
+    _gather_positions(sp, grid, x.device)
     y = gathered.view(-1, v_out).index_select(0, sp.gather_pos)
     y = y.view(1, ensemble_size, grid, v_out)
     return model._finish(y, x, input_affine, output_affine)
+
+
+# ------------------------------------------------------------------------------------------ training (backward collectives)
+class _HaloRows(torch.autograd.Function):
+    """``[own rows | halo rows]`` of a row matrix: forward = the halo all-to-all-v of :class:`HaloExchange`; backward = the
+    REVERSE all-to-all-v (the gradients of the halo copies travel back to the ranks that own the rows, counts swapped)
+    followed by an index-add into the owners' rows.  The counterpart of the reference's autograd-wrapped collectives
+    (reference distributed/graph.py:152-162, distributed/transformer.py:144-152), moving O(boundary) rows instead of whole
+    tensors."""
+
+    @staticmethod
+    def forward(ctx, rows_own: Tensor, halo: HaloExchange) -> Tensor:
+        n_own = rows_own.shape[0]
+        full = torch.empty((n_own + halo.n_recv, rows_own.shape[1]), dtype=rows_own.dtype, device=rows_own.device)
+        full[:n_own].copy_(rows_own)
+        halo.exchange(full, n_own)
+        ctx.halo, ctx.n_own = halo, n_own
+        return full
+
+    @staticmethod
+    def backward(ctx, dfull: Tensor):
+        halo, n_own = ctx.halo, ctx.n_own
+        d_own = dfull[:n_own].clone()
+        n_send = sum(halo.send_splits)
+        if n_send > 0 or halo.n_recv > 0:
+            back = torch.empty((n_send, dfull.shape[1]), dtype=dfull.dtype, device=dfull.device)
+            _alltoallv(back, dfull[n_own:].contiguous(), halo.send_splits, halo.recv_splits, halo.group)
+            if n_send > 0:
+                d_own.index_add_(0, halo.send_idx, back)
+        return d_own, None
+
+
+class _GatherOutput(torch.autograd.Function):
+    """Padded all-gather of the per-rank output rows and their placement in grid order; backward = this rank's rows of the
+    gradient (every rank of the model group evaluates the same loss on the same full output, so the slice -- not a
+    reduction -- is the gradient: the reference's ``gather_tensor``, distributed/graph.py:60-91)."""
+
+    @staticmethod
+    def forward(ctx, y_local: Tensor, sp: "ShardPlan", group, grid: int) -> Tensor:
+        v_out = y_local.shape[1]
+        max_rows = max(sp.dec_counts)
+        send = torch.zeros((max_rows, v_out), dtype=y_local.dtype, device=y_local.device)
+        send[: y_local.shape[0]] = y_local
+        gathered = torch.empty((sp.world * max_rows, v_out), dtype=y_local.dtype, device=y_local.device)
+        _allgather_rows(gathered, send, group)
+        ctx.ids = sp.dec_dst_ids
+        return gathered.index_select(0, _gather_positions(sp, grid, y_local.device))
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        return dy.index_select(0, ctx.ids), None, None, None
+
+
+def _gather_positions(sp: "ShardPlan", grid: int, device) -> Tensor:
+    if sp.gather_pos is None:  # grid order <- (rank, row) order of the padded buffer
+        max_rows = max(sp.dec_counts)
+        starts = torch.tensor([r * max_rows for r in range(sp.world)], device=device)
+        counts = torch.tensor(sp.dec_counts, device=device)
+        offs = torch.cumsum(counts, 0) - counts
+        rank_of = torch.repeat_interleave(torch.arange(sp.world, device=device), counts)
+        pos = starts[rank_of] + torch.arange(int(counts.sum()), device=device) - offs[rank_of]
+        gp = torch.empty(grid, dtype=torch.long, device=device)
+        gp[sp.dec_all_ids] = pos
+        sp.gather_pos = gp
+    return sp.gather_pos
+
+
+def sharded_training_forward(model, x: Tensor, group) -> Tensor:
+    """The node-partitioned forward WITH an autograd graph (flat GraphTransformer model, batch size 1): the same partition
+    as :func:`sharded_forward`, every block on the differentiable kernels of ``autograd.py``, the halo exchanges and the
+    output gather as autograd functions with their backward collectives.  Each rank ends up with the gradient
+    contributions of ITS rows for every parameter: the caller sums them over the model group (what anemoi-training's DDP
+    strategy does across all ranks of a model instance)."""
+    from .. import autograd
+    from .. import training
+    from ..layers.mapper import GraphTransformerBackwardMapper
+    from ..layers.mapper import GraphTransformerForwardMapper
+    from ..layers.processor import GraphTransformerProcessor
+
+    if not (isinstance(model.encoder, GraphTransformerForwardMapper) and isinstance(model.decoder, GraphTransformerBackwardMapper)
+            and isinstance(model.processor, GraphTransformerProcessor)):
+        raise NotImplementedError("node-partitioned training: the flat GraphTransformer model only")
+    b, _, ens, grid, _ = x.shape
+    assert b == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+    if ens != 1:
+        raise NotImplementedError("node-partitioned training: ensemble size 1")
+    dtype = runtime.compute_dtype(x)
+    key = ("shard_plan", str(x.device), _world(group), _rank(group))
+    if key not in model._idx_cache:
+        model._idx_cache[key] = build_shard_plan(model, group, x.device)
+    sp: ShardPlan = model._idx_cache[key]
+    data, hidden = model._graph_name_data, model._graph_name_hidden
+    order, _ = model._mesh_order(x.device)
+    own_ids = order[sp.lo:sp.hi]
+    enc, proc, dec = model.encoder, model.processor, model.decoder
+    heads = proc.proc[0].blocks[0].num_heads
+    training._check_heads(model.num_channels, heads, dtype)
+
+    def attrs(mod, plan):
+        return autograd._edge_attr_csr(mod.edge_attr, mod.trainable.trainable, plan, ops.round_up(mod.edge_dim + 1, 4))
+
+    def mapper_block(mod, h_src_own, h_dst, lg: LocalGraph):
+        """GraphTransformerMapperBlock on a local graph: keys / values of the own source rows, halo rows appended."""
+        blk, sd = mod.proc, training._block_sd(mod.proc)
+        g = lambda name: sd["b." + name]  # noqa: E731
+        c = h_dst.shape[1]
+        up = ops.round_up(mod.edge_dim + 1, 4)
+        w_u, b_u, w_t = autograd._lin_edge_fold(sd, "b", c, heads, up, h_dst.device)
+        xs = autograd.layer_norm(h_src_own, g("layer_norm1.weight"), g("layer_norm1.bias"), blk.layer_norm1.eps)
+        xd = autograd.layer_norm(h_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), blk.layer_norm2.eps)
+        kv = autograd.linear(xs, torch.cat([g("lin_key.weight"), g("lin_value.weight")], 0),
+                             torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0))
+        if lg.halo is not None:
+            kv = _HaloRows.apply(kv, lg.halo)
+        sq = autograd.linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
+                             torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))
+        att = autograd.gt_edge_attention(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], attrs(mod, lg.plan),
+                                         lg.plan, heads, up)
+        return autograd._gt_tail(att, h_dst, sd, "b", w_t, blk.activation, blk.layer_norm1.eps)
+
+    def processor_block(blk, h, ea, lg: LocalGraph):
+        sd = training._block_sd(blk)
+        g = lambda name: sd["b." + name]  # noqa: E731
+        c = h.shape[1]
+        up = ea.shape[1]
+        w_u, b_u, w_t = autograd._lin_edge_fold(sd, "b", c, heads, up, h.device)
+        xh = autograd.layer_norm(h, g("layer_norm1.weight"), g("layer_norm1.bias"), blk.layer_norm1.eps)
+        kv = _HaloRows.apply(autograd.linear(xh, torch.cat([g("lin_key.weight"), g("lin_value.weight")], 0),
+                                             torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0)), lg.halo)
+        sq = autograd.linear(xh, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
+                             torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))
+        att = autograd.gt_edge_attention(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], ea, lg.plan, heads, up)
+        return autograd._gt_tail(att, h, sd, "b", w_t, blk.activation, blk.layer_norm1.eps)
+
+    with torch.autocast(device_type=x.device.type, enabled=False):
+        x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(grid, -1), training._node_rows(model, data, 1)], dim=1).to(dtype)
+        x_hidden = training._node_rows(model, hidden, 1).index_select(0, own_ids).to(dtype)
+        # encoder: the grid rows that feed this rank's mesh rows -- no communication (every rank holds the full input)
+        hs = autograd.linear(x_data.index_select(0, sp.enc_src_ids), enc.emb_nodes_src.weight, enc.emb_nodes_src.bias)
+        hd = autograd.linear(x_hidden, enc.emb_nodes_dst.weight, enc.emb_nodes_dst.bias)
+        x_latent = training._checkpoint(lambda a, c_: mapper_block(enc, a, c_, sp.enc), hs, hd)
+        # processor: one halo exchange of k|v rows per block, forward and (reversed) backward
+        ea = attrs(proc, sp.proc.plan)
+
+        def run_chunk(chunk, h, ea_):
+            for blk in chunk.blocks:
+                h = processor_block(blk, h, ea_, sp.proc)
+            return h
+
+        h = x_latent
+        for chunk in proc.proc:
+            h = training._checkpoint(run_chunk, chunk, h, ea)
+        x_latent_proc = h + x_latent
+        # decoder: own grid rows as destinations, own + halo mesh rows as sources
+        hd = autograd.linear(x_data.index_select(0, sp.dec_dst_ids), dec.emb_nodes_dst.weight, dec.emb_nodes_dst.bias)
+        y_local = training._checkpoint(lambda a, c_: mapper_block(dec, a, c_, sp.dec), x_latent_proc, hd)
+        y_local = training.sequential(dec.node_data_extractor, y_local).float()
+        y = _GatherOutput.apply(y_local, sp, group, grid)
+        return training._finish(model, y, x, 1, 1, grid)

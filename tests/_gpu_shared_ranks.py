@@ -1,6 +1,8 @@
 """Worker of tests/test_gpu_parity.py::test_node_partitioned_forward_ranks_sharing_one_gpu.
 
-usage: python _gpu_shared_ranks.py RANK WORLD PORT OUT GRAPH CHANNELS LAYERS HEADS DTYPE
+usage: python _gpu_shared_ranks.py RANK WORLD PORT OUT GRAPH CHANNELS LAYERS HEADS DTYPE [train]
+With ``train``: one node-partitioned training step (sharded forward with an autograd graph, backward with the reverse halo
+all-to-all-v) -- the parameter gradients summed over the ranks must equal the single-device gradients.
 Every rank runs the HIP kernels on cuda:0; the collectives are gloo, staged through host memory
 (anemoi_models_amd/distributed/partition.py::_alltoallv).  Writes max |sharded - unsharded| to OUT.RANK.
 """
@@ -44,9 +46,30 @@ def main():
             again = model(x, dist.group.WORLD)
         torch.cuda.synchronize()
         sp = [v for k, v in model._idx_cache.items() if k[0] == "shard_plan"][0]
-        torch.save(dict(err=float((got - want).abs().max()), rerun=float((again - got).abs().max()),
-                        scale=float(want.abs().max()), own=sp.hi - sp.lo, finite=bool(torch.isfinite(got).all())),
-                   f"{out}.{rank}")
+        info = dict(err=float((got - want).abs().max()), rerun=float((again - got).abs().max()),
+                    scale=float(want.abs().max()), own=sp.hi - sp.lo, finite=bool(torch.isfinite(got).all()))
+        if len(sys.argv) > 10 and sys.argv[10] == "train":
+            model.train()
+            dy = torch.randn(want.shape, generator=torch.Generator().manual_seed(5)).to(device)
+            y1 = model(x)  # single device, differentiable route
+            y1.backward(dy)
+            full = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            model.zero_grad()
+            y2 = model(x, dist.group.WORLD)  # node-partitioned, differentiable route
+            y2.backward(dy)
+            g_err, g_scale, missing = 0.0, 0.0, []
+            for k, p in model.named_parameters():
+                if k not in full:
+                    continue
+                part = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu()
+                dist.all_reduce(part)  # sum of the per-rank contributions (what DDP does over the model group)
+                g_err = max(g_err, float((part - full[k].cpu()).abs().max()))
+                g_scale = max(g_scale, float(full[k].abs().max()))
+                if p.grad is None:
+                    missing.append(k)
+            info.update(train_out_err=float((y2.detach() - y1.detach()).abs().max()), grad_err=g_err, grad_scale=g_scale,
+                        n_grads=len(full), requires_grad=bool(y2.requires_grad))
+        torch.save(info, f"{out}.{rank}")
     finally:
         dist.destroy_process_group()
 

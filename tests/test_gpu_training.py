@@ -190,3 +190,34 @@ def test_training_with_boundings(graph_o32, golden_cfg1_gt):
     assert y.requires_grad and rel_err(y.detach(), load_npz("bounding_gt.npz")["y"]) < 1e-4
     y.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("world,graph_name,channels,layers,heads", [(2, "o32_ico2", 64, 4, 4), (3, "o48_ico3", 128, 2, 8)])
+def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name, channels, layers, heads, tmp_path):
+    """Training across a model group: the sharded differentiable forward (halo all-to-all-v per block, output all-gather)
+    and its backward (reverse halo all-to-all-v + index-add, gradient slice of the gather) on the HIP kernels, the ranks
+    as separate processes sharing cuda:0 with host-staged gloo collectives.  Output == single-device output; parameter
+    gradients summed over the ranks == single-device gradients (reference distributed/graph.py:152-162 semantics)."""
+    import os
+    import subprocess
+    import sys
+
+    port = 29500 + (os.getpid() % 150)
+    out = str(tmp_path / "res")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_shared_ranks.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out, graph_name, str(channels),
+                               str(layers), str(heads), "fp32", "train"]) for r in range(world)]
+    try:
+        codes = [p.wait(timeout=900) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    assert codes == [0] * world
+    for r in range(world):
+        i = torch.load(f"{out}.{r}")
+        assert i["requires_grad"] and i["n_grads"] > 100
+        assert i["err"] <= 2e-5 * max(1.0, i["scale"]), i
+        assert i["train_out_err"] <= 2e-5 * max(1.0, i["scale"]), i
+        assert i["grad_err"] <= 2e-4 * i["grad_scale"], i
