@@ -217,7 +217,7 @@ def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name,
     assert codes == [0] * world
     for r in range(world):
         i = torch.load(f"{out}.{r}")
-        assert i["requires_grad"] and i["n_grads"] > 100
+        assert i["requires_grad"] and i["n_grads"] > 50
         assert i["err"] <= 2e-5 * max(1.0, i["scale"]), i
         assert i["train_out_err"] <= 2e-5 * max(1.0, i["scale"]), i
         assert i["grad_err"] <= 2e-4 * i["grad_scale"], i
