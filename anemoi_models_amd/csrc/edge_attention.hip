@@ -575,23 +575,29 @@ static bool dispatch_folded(const EdgeFoldParams& p, int up, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tiled path: LDS staging of the source rows of a destination tile.
+// Tiled path: LDS staging of the source rows of a destination tile, persistent and double buffered.
 //
-// The gather loop above pulls every k_j / v_j row slice through L2 -> L1 once per EDGE; on the mesh graph a row is
-// wanted by ~8 destinations, most of them neighbours in the (Morton) row order.  Measured on config 3's mesh launch
-// (tools/edge_lab2.sh): 0.151 ms as is, 0.109 ms without the v gathers, 0.084 ms without any gather -- the gathers
-// cost time in proportion to their bytes, VALU work costs nothing.  So this kernel moves each row slice ONCE per tile:
-//   * a workgroup owns (tile of TILE_DST = 32 consecutive destinations, one head);
-//   * the tile's unique source rows (host-built list, runtime.edge_tiles) go to LDS by LDS-DMA (buffer_load ... lds, 16 B
-//     per lane, no registers), together with the tile's q rows, its CSR slice of tile-local column slots and its edge
-//     attributes; one s_waitcnt + barrier;
-//   * then LPH lanes per destination (64 / LPH destinations per wave) run the same online-softmax loop as the gather
-//     kernel with every operand in LDS (k / v: one conflict-free ds_read_b128 per lane and edge).
-// Heads of one tile run on the same XCD (shared column / attribute lines in that L2).  Several workgroups fit a CU
-// (LDS ~50 KB at the mesh graph), so one stages while the others compute.  Same arithmetic and summation order per
-// destination as the gather kernel except for the batch size of the online softmax (U = 2 instead of 4).
+// The gather loop above pulls every k_j / v_j row slice through the CU's vector-memory path once per EDGE; on the mesh
+// graph a row is wanted by ~8 destinations, most of them neighbours in the (Morton) row order.  Measured on config 3's
+// mesh launch (profiles/r02_edge_kernels.md): the gather kernel's time follows the gathered bytes (texture addresser
+// busy 77 %), not its VALU work, not L2 locality, not the depth of its request chain.  This kernel moves each row slice
+// ONCE per tile:
+//   * tiles of TILE_DST = 64 consecutive destinations; the work list is the tile-major sequence of (tile, head) pairs,
+//     cut into one contiguous chunk per persistent workgroup (one per CU) -- perfectly balanced, and consecutive pairs of
+//     a workgroup share the tile;
+//   * once per tile the tile's CSR slice of tile-local column slots and its edge attributes go to LDS (LDS-DMA);
+//   * per (tile, head) the tile's UNIQUE source rows (k and v head slices, host-built list) and its q rows go to one of
+//     TWO LDS buffers by LDS-DMA (buffer_load ... lds: 16 bytes per lane, no registers): the requests for pair i + 1 are
+//     issued right after the barrier that publishes pair i, so they fly under pair i's arithmetic;
+//   * LPH lanes per destination (64 / LPH destinations per wave) run the gather kernel's online-softmax loop with every
+//     operand in LDS.  Destinations are assigned to the waves' slots in order of falling in-degree (host-built
+//     permutation per tile), so that the destinations that share a wave's loop have about the same trip count.
+// Same arithmetic, summation order and online-softmax batch (U = 4) per destination as the gather kernel: the results are
+// bit-identical.  Measured (profiles/r02_edge_kernels.md): it takes the load off the texture path as intended, but 160 KiB
+// of LDS per CU allow two waves per SIMD, and at that occupancy the loop's VALU stream (issue-bound, ~55 M instructions
+// per mesh launch) alone takes 0.22 ms -- the gather kernel (20 waves per CU) stays the default.
 // ---------------------------------------------------------------------------------------------
-constexpr int TILE_DST = 32;
+constexpr int TILE_DST = 64;
 
 // LDS regions are sized in whole LDS-DMA instructions (64 lanes x 4 or 16 bytes): the last instruction of a region
 // writes all its lanes (zeros beyond the source array) and must not reach into the next region.
@@ -611,6 +617,7 @@ struct EdgeTileParams {
   const int32_t* tile_src_ptr;  // [n_tiles + 1]
   const int32_t* tile_src;      // unique source rows of every tile, ascending inside a tile
   const int32_t* col_local;     // [E] slot of the edge's source in its tile's list
+  const int32_t* tile_order;    // [n_tiles * TILE_DST] destination row of every slot of the tile (falling degree), -1 = none
   int64_t n_dst, n_src, n_edges;
   int n_tiles, C, D, H, s_cap, e_cap;
   float scale;
@@ -625,177 +632,227 @@ template <typename T, int VEC, int LPH, int UP>
 __global__ __launch_bounds__(TILE_DST* LPH) void gt_edge_attention_tiled_kernel(const EdgeTileParams p) {
   using Raw = typename RawVec<T, VEC>::type;
   constexpr int APL = attrs_per_lane(UP, LPH);
-  constexpr int ROWB = LPH * 16;         // bytes of one head's slice of a row
-  constexpr int GPW = 64 / LPH;          // destinations (or staged rows) per wave instruction
-  constexpr int NW = TILE_DST / GPW;     // waves per workgroup
+  constexpr int ROWB = LPH * 16;      // bytes of one head's slice of a row
+  constexpr int GPW = 64 / LPH;       // destinations (or staged rows) per wave instruction
+  constexpr int NW = TILE_DST / GPW;  // waves per workgroup
   constexpr int ES = (int)sizeof(T);
-  constexpr int U = 2;
+  constexpr int U = 4;     // edges per destination and loop trip: the gather kernel's batch, so the results are bit-identical
+  constexpr int MAXG = 8;  // staged row groups per wave: s_cap <= MAXG * NW * GPW = 8 * TILE_DST (launcher)
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* k_lds = smem;
-  char* v_lds = k_lds + p.s_cap * ROWB;
-  char* q_lds = v_lds + p.s_cap * ROWB;
-  char* c_lds = q_lds + TILE_DST * ROWB;
-  char* a_lds = c_lds + tiled_col_bytes(p.e_cap);  // (regions are whole LDS-DMA instructions: see tiled_lds_bytes)
+  char* a_lds = smem;                                        // edge attributes of the tile
+  char* c_lds = a_lds + tiled_attr_bytes(p.e_cap, UP);       // tile-local column slots
+  char* b_lds = c_lds + tiled_col_bytes(p.e_cap);            // two buffers: k rows | v rows | q rows
+  const int buf_bytes = (2 * p.s_cap + TILE_DST) * ROWB;
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int tile = (bi / p.H) * 8 + xcd, head = bi % p.H;
-  if (tile >= p.n_tiles) return;
-  const int64_t d0 = (int64_t)tile * TILE_DST;
-  const int64_t d_end = d0 + TILE_DST < p.n_dst ? d0 + TILE_DST : p.n_dst;
-  const int e0 = p.rowptr[d0], e1 = p.rowptr[d_end];
-  const int n_e = e1 - e0;
-  const int sp0 = p.tile_src_ptr[tile], n_s = p.tile_src_ptr[tile + 1] - sp0;
   const int g = lane / LPH, r = lane % LPH;
-
-  // ---- this lane's destination: row pointers, x_r and u slices straight into registers (requested first: HBM streams)
-  const int64_t d = d0 + wid * GPW + g;
-  const bool valid = d < d_end;
-  const int64_t dc = valid ? d : d_end - 1;
   const int a0 = r * APL;
   const bool a_own = a0 < UP;
   const int a_ld = a_own ? a0 : 0;
   const float amask = a_own ? 1.f : 0.f;
-  int eb = p.rowptr[dc] - e0, ee = p.rowptr[dc + 1] - e0;
-  if (!valid) ee = eb;
-  RawWords<T, VEC> xr_raw;
-  RawWords<T, APL> u_raw;
   const bool has_xr = p.xr != nullptr;
-  if (has_xr)
-    xr_raw.load(static_cast<const char*>(p.xr) + dc * p.ldr * ES, (uint32_t)((head * p.D + r * VEC) * ES), true);
-  u_raw.load(static_cast<const char*>(p.u) + dc * p.ldu * ES, (uint32_t)((head * UP + a_ld) * ES), false);
 
-  // ---- staging (LDS-DMA: lane l of an instruction writes 16 bytes at lds base + 16 l)
-  {
-    const __amdgpu_buffer_rsrc_t krs = tile_rsrc(static_cast<const T*>(p.k) + head * p.D, p.n_src * p.ldkv * ES);
-    const __amdgpu_buffer_rsrc_t vrs = tile_rsrc(static_cast<const T*>(p.v) + head * p.D, p.n_src * p.ldkv * ES);
-    // (the q descriptor starts at the tile's first row: offsets stay small whatever n_dst is)
-    const __amdgpu_buffer_rsrc_t qrs =
-        tile_rsrc(static_cast<const T*>(p.q) + d0 * p.ldq + head * p.D, (int64_t)TILE_DST * p.ldq * ES);
-    for (int j = wid; j * GPW < n_s; j += NW) {  // source rows j * GPW + g
-      const int row = j * GPW + g;
-      const int src = p.tile_src[sp0 + (row < n_s ? row : n_s - 1)];
-      const int vo = (int)((uint32_t)src * (uint32_t)(p.ldkv * ES) + (uint32_t)(r * 16));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr_t)(k_lds + j * 1024), 16, vo, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr_t)(v_lds + j * 1024), 16, vo, 0, 0, 0);
-    }
-    {  // q rows of the tile: exactly one instruction per wave
-      const int vo = (int)(dc - d0) * (int)(p.ldq * ES) + r * 16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_ptr_t)(q_lds + wid * 1024), 16, vo, 0, 0, 2);
+  // this workgroup's contiguous chunk of the tile-major (tile, head) list
+  const int64_t total = (int64_t)p.n_tiles * p.H;
+  const int64_t i0 = total * blockIdx.x / gridDim.x, i1 = total * (blockIdx.x + 1) / gridDim.x;
+  if (i0 >= i1) return;
+
+  // ---- per-tile state
+  int tile = -1, e0 = 0, n_e = 0, n_s = 0;
+  int64_t d0 = 0;
+  int64_t d = 0;       // this lane's destination row (slot wid * GPW + g of the tile's order)
+  bool valid = false;
+  int eb = 0, ee = 0;  // its edges, tile-local
+  int srcoff[MAXG];    // byte offsets of the source rows this lane stages (row groups wid, wid + NW, ...)
+  int qoff = 0;
+
+  auto tile_setup = [&](int t) {  // scalars + this lane's rows; then the tile's columns and attributes go to LDS
+    tile = t;
+    d0 = (int64_t)t * TILE_DST;
+    const int64_t d_end = d0 + TILE_DST < p.n_dst ? d0 + TILE_DST : p.n_dst;
+    e0 = p.rowptr[d0];
+    n_e = p.rowptr[d_end] - e0;
+    const int sp0 = p.tile_src_ptr[t];
+    n_s = p.tile_src_ptr[t + 1] - sp0;
+    const int slot_d = p.tile_order[(int64_t)t * TILE_DST + wid * GPW + g];
+    valid = slot_d >= 0;
+    d = valid ? (int64_t)slot_d : d0;
+    eb = p.rowptr[d] - e0;
+    ee = valid ? p.rowptr[d + 1] - e0 : eb;
+    qoff = (int)(d - d0) * (int)(p.ldq * ES) + r * 16;
+#pragma unroll
+    for (int jj = 0; jj < MAXG; ++jj) {
+      const int row = (wid + jj * NW) * GPW + g;
+      const int src = p.tile_src[sp0 + (row < n_s ? row : (n_s > 0 ? n_s - 1 : 0))];
+      srcoff[jj] = (int)((uint32_t)src * (uint32_t)(p.ldkv * ES) + (uint32_t)(r * 16));
     }
     const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.col_local, p.n_edges * 4);
-    for (int j = wid; j * 64 < n_e; j += NW)  // tile-local column slots, 4 bytes per lane (beyond the array: zeros)
+    for (int j = wid; j * 64 < n_e; j += NW)  // 4 bytes per lane (beyond the array: zeros)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (lds_ptr_t)(c_lds + j * 256), 4, (e0 + j * 64 + lane) * 4, 0, 0, 0);
     const __amdgpu_buffer_rsrc_t ars = tile_rsrc(p.attr, p.n_edges * (int64_t)(UP * 4));
     constexpr int CH = UP / 4;  // 16-byte chunks per edge
     for (int j = wid; j * 64 < n_e * CH; j += NW)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_ptr_t)(a_lds + j * 1024), 16,
                                                (int)(((uint32_t)e0 * CH + (uint32_t)(j * 64 + lane)) * 16u), 0, 0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  };
 
-  // ---- compute: everything in LDS
-  QK<T, VEC> qk;
-  float u[APL];
-  {
-    float qf[VEC];
-    const Raw qr = *reinterpret_cast<const Raw*>(q_lds + (wid * GPW + g) * ROWB + r * 16);
-    unpack<T, VEC>(qr, qf);
-    qk.set(qf);
-    u_raw.get(u);
+  auto stage_head = [&](int head, int buf) {  // k / v rows of the tile's sources and the tile's q rows, head slice
+    char* kb_ = b_lds + buf * buf_bytes;
+    char* vb_ = kb_ + p.s_cap * ROWB;
+    char* qb_ = vb_ + p.s_cap * ROWB;
+    const __amdgpu_buffer_rsrc_t krs = tile_rsrc(static_cast<const T*>(p.k) + head * p.D, p.n_src * p.ldkv * ES);
+    const __amdgpu_buffer_rsrc_t vrs = tile_rsrc(static_cast<const T*>(p.v) + head * p.D, p.n_src * p.ldkv * ES);
+    const __amdgpu_buffer_rsrc_t qrs =
+        tile_rsrc(static_cast<const T*>(p.q) + d0 * p.ldq + head * p.D, (int64_t)TILE_DST * p.ldq * ES);
 #pragma unroll
-    for (int i = 0; i < APL; ++i) u[i] *= amask;
-  }
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  constexpr int VP = (VEC + 1) / 2;
-  f32x2_t acc[VP];
-  float tacc[APL];
-#pragma unroll
-  for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
-  float m = -INFINITY, l = 0.f;
-  const int* cl = reinterpret_cast<const int*>(c_lds);
-  const float* al = reinterpret_cast<const float*>(a_lds) + a_ld;
-  for (int e = eb; __any(e < ee); e += U) {
-    Raw kr[U], vr[U];
-    float at[U][APL];
-    bool on[U];
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu) {
-      on[uu] = e + uu < ee;
-      const int ei = on[uu] ? e + uu : (n_e > 0 ? 0 : 0);
-      const int slot = n_e > 0 ? cl[ei] : 0;
-      kr[uu] = *reinterpret_cast<const Raw*>(k_lds + slot * ROWB + r * 16);
-      vr[uu] = *reinterpret_cast<const Raw*>(v_lds + slot * ROWB + r * 16);
-      VecIO<float, APL>::load(al + ei * UP, at[uu]);
+    for (int jj = 0; jj < MAXG; ++jj) {
+      const int j = wid + jj * NW;
+      if (j * GPW < n_s) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr_t)(kb_ + j * 1024), 16, srcoff[jj], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr_t)(vb_ + j * 1024), 16, srcoff[jj], 0, 0, 0);
+      }
     }
-    float s[U];
-    float mb = m;
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu) {
-      float t = qk.dot(kr[uu]);
-#pragma unroll
-      for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[uu][a], t);
-      s[uu] = on[uu] ? group_sum<LPH>(t) * p.scale : -INFINITY;
-      mb = fmaxf(mb, s[uu]);
-    }
-    const float corr = m == mb ? 1.f : __expf(m - mb);  // (m == mb == -inf: nothing seen yet, nothing to rescale)
-    l *= corr;
-#pragma unroll
-    for (int i = 0; i < VP; ++i) acc[i] *= corr;
-#pragma unroll
-    for (int a = 0; a < APL; ++a) tacc[a] *= corr;
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu) {
-      const float pe = on[uu] ? __expf(s[uu] - mb) : 0.f;
-      l += pe;
-      float vv[VEC];
-      unpack<T, VEC>(vr[uu], vv);
-#pragma unroll
-      for (int i = 0; i < VP; ++i)
-        acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f},
-                                           acc[i]);
-#pragma unroll
-      for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
-    }
-    m = mb;
-  }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_ptr_t)(qb_ + wid * 1024), 16, qoff, 0, 0, 2);
+  };
 
-  const float inv = 1.0f / (l + 1e-16f);
-  float o[VEC];
+  RawWords<T, VEC> xr_cur, xr_nxt;
+  RawWords<T, APL> u_cur, u_nxt;
+  auto load_streams = [&](int head, RawWords<T, VEC>& xr_, RawWords<T, APL>& u_) {
+    if (has_xr) xr_.load(static_cast<const char*>(p.xr) + d * p.ldr * ES, (uint32_t)((head * p.D + r * VEC) * ES), true);
+    u_.load(static_cast<const char*>(p.u) + d * p.ldu * ES, (uint32_t)((head * UP + a_ld) * ES), false);
+  };
+
+  // ---- prologue: first pair of the chunk
+  tile_setup((int)(i0 / p.H));
+  stage_head((int)(i0 % p.H), 0);
+  load_streams((int)(i0 % p.H), xr_cur, u_cur);
+
+  for (int64_t i = i0; i < i1; ++i) {
+    const int head = (int)(i % p.H);
+    const int buf = (int)((i - i0) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of pair i has landed (and its older stores)
+    __syncthreads();                                   // ... everyone's; everyone is done with pair i - 1's buffer
+    // ---- requests for pair i + 1 (same tile: only the head changes) fly under pair i's arithmetic
+    const bool more = i + 1 < i1;
+    const bool same_tile = more && (int)((i + 1) / p.H) == tile;
+    if (same_tile) {
+      stage_head(head + 1, buf ^ 1);
+      load_streams(head + 1, xr_nxt, u_nxt);
+    }
+
+    // ---- compute pair i out of LDS
+    const char* kb_ = b_lds + buf * buf_bytes;
+    const char* vb_ = kb_ + p.s_cap * ROWB;
+    const char* qb_ = vb_ + p.s_cap * ROWB;
+    QK<T, VEC> qk;
+    float u[APL];
+    {
+      float qf[VEC];
+      const Raw qr = *reinterpret_cast<const Raw*>(qb_ + (wid * GPW + g) * ROWB + r * 16);
+      unpack<T, VEC>(qr, qf);
+      qk.set(qf);
+      u_cur.get(u);
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
-  if (has_xr) {
-    float rr[VEC];
-    xr_raw.get(rr);
+      for (int a = 0; a < APL; ++a) u[a] *= amask;
+    }
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    constexpr int VP = (VEC + 1) / 2;
+    f32x2_t acc[VP];
+    float tacc[APL];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] += rr[i];
-  }
-  if (valid) {
-    char* on_ = static_cast<char*>(p.out) + d * p.ldo * ES;
-    store_stream<T, VEC>(reinterpret_cast<T*>(on_ + (head * p.D + r * VEC) * ES), o);
-    if (a_own) {
-      float t4[APL];
+    for (int a = 0; a < VP; ++a) acc[a] = f32x2_t{0.f, 0.f};
 #pragma unroll
-      for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
-      VecIO<T, APL>::store(reinterpret_cast<T*>(on_ + (p.C + head * UP + a0) * ES), t4);
+    for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int* cl = reinterpret_cast<const int*>(c_lds);
+    const float* al = reinterpret_cast<const float*>(a_lds) + a_ld;
+    for (int e = eb; __any(e < ee); e += U) {
+      Raw kr[U], vr[U];
+      float at[U][APL];
+      bool on[U];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        on[uu] = e + uu < ee;
+        const int ei = on[uu] ? e + uu : 0;
+        const int slot = cl[ei];
+        kr[uu] = *reinterpret_cast<const Raw*>(kb_ + slot * ROWB + r * 16);
+        vr[uu] = *reinterpret_cast<const Raw*>(vb_ + slot * ROWB + r * 16);
+        VecIO<float, APL>::load(al + ei * UP, at[uu]);
+      }
+      float s_[U];
+      float mb = m;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        float t = qk.dot(kr[uu]);
+#pragma unroll
+        for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[uu][a], t);
+        s_[uu] = on[uu] ? group_sum<LPH>(t) * p.scale : -INFINITY;
+        mb = fmaxf(mb, s_[uu]);
+      }
+      const float corr = m == mb ? 1.f : __expf(m - mb);  // (m == mb == -inf: nothing seen yet, nothing to rescale)
+      l *= corr;
+#pragma unroll
+      for (int a = 0; a < VP; ++a) acc[a] *= corr;
+#pragma unroll
+      for (int a = 0; a < APL; ++a) tacc[a] *= corr;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        const float pe = on[uu] ? __expf(s_[uu] - mb) : 0.f;
+        l += pe;
+        float vv[VEC];
+        unpack<T, VEC>(vr[uu], vv);
+#pragma unroll
+        for (int a = 0; a < VP; ++a)
+          acc[a] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * a], 2 * a + 1 < VEC ? vv[2 * a + 1] : 0.f},
+                                             acc[a]);
+#pragma unroll
+        for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
+      }
+      m = mb;
+    }
+    const float inv = 1.0f / (l + 1e-16f);
+    float o[VEC];
+#pragma unroll
+    for (int a = 0; a < VEC; ++a) o[a] = acc[a >> 1][a & 1] * inv;
+    if (has_xr) {
+      float rr[VEC];
+      xr_cur.get(rr);
+#pragma unroll
+      for (int a = 0; a < VEC; ++a) o[a] += rr[a];
+    }
+    if (valid) {
+      char* on_ = static_cast<char*>(p.out) + d * p.ldo * ES;
+      store_stream<T, VEC>(reinterpret_cast<T*>(on_ + (head * p.D + r * VEC) * ES), o);
+      if (a_own) {
+        float t4[APL];
+#pragma unroll
+        for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+        VecIO<T, APL>::store(reinterpret_cast<T*>(on_ + (p.C + head * UP + a0) * ES), t4);
+      }
+    }
+    if (same_tile) {
+      xr_cur = xr_nxt;
+      u_cur = u_nxt;
+    } else if (more) {  // tile boundary inside the chunk (at most a few per workgroup): restage from scratch
+      __syncthreads();  // nobody reads the old tile's columns / attributes any more
+      tile_setup((int)((i + 1) / p.H));
+      stage_head((int)((i + 1) % p.H), buf ^ 1);
+      load_streams((int)((i + 1) % p.H), xr_cur, u_cur);
     }
   }
 }
 
 static inline size_t tiled_lds_bytes(int lph, int up, int s_cap, int e_cap) {
-  return (size_t)2 * s_cap * lph * 16 + (size_t)TILE_DST * lph * 16 + (size_t)tiled_col_bytes(e_cap) +
-         (size_t)tiled_attr_bytes(e_cap, up);
+  return (size_t)tiled_attr_bytes(e_cap, up) + (size_t)tiled_col_bytes(e_cap) +
+         (size_t)2 * ((size_t)2 * s_cap + TILE_DST) * lph * 16;
 }
 
 template <typename T, int VEC, int LPH, int UP>
 static bool launch_tiled(const EdgeTileParams& p, hipStream_t st) {
   const size_t lds = tiled_lds_bytes(LPH, UP, p.s_cap, p.e_cap);
-  if (lds > 160 * 1024) return false;
+  if (lds > 160 * 1024 || p.s_cap > 8 * TILE_DST) return false;
   auto kern = gt_edge_attention_tiled_kernel<T, VEC, LPH, UP>;
   static bool raised = false;  // per instantiation
   if (!raised) {
@@ -804,8 +861,14 @@ static bool launch_tiled(const EdgeTileParams& p, hipStream_t st) {
       return false;
     raised = true;
   }
-  const int64_t blocks = (int64_t)((p.n_tiles + 7) / 8) * p.H * 8;
-  if (blocks >= (int64_t)1 << 31) return false;
+  // persistent: one workgroup per CU when LDS allows only one, else as many as fit (the chunks get shorter)
+  const int64_t total = (int64_t)p.n_tiles * p.H;
+  int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)lds;
+  const int64_t by_threads = 2048 / (TILE_DST * LPH);
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu < 1) per_cu = 1;
+  int64_t blocks = 256 * per_cu;
+  if (blocks > total) blocks = total;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TILE_DST * LPH), lds, st, p);
   return true;
 }
@@ -1056,10 +1119,10 @@ extern "C" int anemoi_gt_edge_attention_tiled(int dtype, const void* q, int64_t 
                                               int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
                                               const float* edge_attr, int up, const int32_t* rowptr,
                                               const int32_t* tile_src_ptr, const int32_t* tile_src,
-                                              const int32_t* col_local, int s_cap, int e_cap, void* out, int64_t ldo,
-                                              int64_t n_dst, int64_t n_src, int64_t n_edges, int C, int H,
-                                              anemoi_stream_t stream) {
-  ANEMOI_REQUIRE(q && k && v && u && out && rowptr && tile_src_ptr, ANEMOI_ERR_INVALID,
+                                              const int32_t* col_local, const int32_t* tile_order, int s_cap,
+                                              int e_cap, void* out, int64_t ldo, int64_t n_dst, int64_t n_src,
+                                              int64_t n_edges, int C, int H, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(q && k && v && u && out && rowptr && tile_src_ptr && tile_order, ANEMOI_ERR_INVALID,
                  "anemoi_gt_edge_attention_tiled: null pointer");
   ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
                  "anemoi_gt_edge_attention_tiled: C=%d not divisible by H=%d", C, H);
@@ -1081,12 +1144,13 @@ extern "C" int anemoi_gt_edge_attention_tiled(int dtype, const void* q, int64_t 
   ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED,
                  "anemoi_gt_edge_attention_tiled: operands must be 16-byte aligned, s_cap %% 32 == 0, e_cap %% 4 == 0");
   // 32-bit byte offsets inside the buffer descriptors of k / v / q
-  ANEMOI_REQUIRE(n_src * ldkv * esz < ((int64_t)1 << 31) && (int64_t)32 * ldq * esz < ((int64_t)1 << 31),
+  ANEMOI_REQUIRE(n_src * ldkv * esz < ((int64_t)1 << 31) && (int64_t)TILE_DST * ldq * esz < ((int64_t)1 << 31),
                  ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_tiled: k / v larger than 2 GiB");
   EdgeTileParams p;
   p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out;
   p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
   p.attr = edge_attr; p.rowptr = rowptr; p.tile_src_ptr = tile_src_ptr; p.tile_src = tile_src; p.col_local = col_local;
+  p.tile_order = tile_order;
   p.n_dst = n_dst; p.n_src = n_src; p.n_edges = n_edges;
   p.n_tiles = (int)((n_dst + TILE_DST - 1) / TILE_DST);
   p.C = C; p.D = C / H; p.H = H; p.s_cap = s_cap; p.e_cap = e_cap;

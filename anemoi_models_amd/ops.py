@@ -289,9 +289,9 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
 def gt_edge_attention_tiled(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
                             rowptr: Tensor, tiles, num_heads: int, up: int, out: Optional[Tensor] = None,
                             ld_out: Optional[int] = None) -> Tensor:
-    """:func:`gt_edge_attention_folded` with the source rows of every 32-destination tile staged in LDS
+    """:func:`gt_edge_attention_folded` with the source rows of every 64-destination tile staged in LDS
     (``anemoi_gt_edge_attention_tiled``).  ``tiles`` = ``runtime.edge_tiles(plan)`` (built once per graph)."""
-    _dev(q, k, v, x_r, u, edge_attr, rowptr, out, tiles.tile_src_ptr, tiles.tile_src, tiles.col_local)
+    _dev(q, k, v, x_r, u, edge_attr, rowptr, out, tiles.tile_src_ptr, tiles.tile_src, tiles.col_local, tiles.tile_order)
     n_dst, c = _rows(q).shape
     if _ld(_rows(k)) != _ld(_rows(v)):
         raise ValueError("gt_edge_attention_tiled: k and v must share their leading dimension")
@@ -313,7 +313,7 @@ def gt_edge_attention_tiled(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tenso
             dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
             0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
             rowptr.data_ptr(), tiles.tile_src_ptr.data_ptr(), tiles.tile_src.data_ptr(), tiles.col_local.data_ptr(),
-            tiles.s_cap, tiles.e_cap, out.data_ptr(), _ld(_rows(out)), n_dst, k.shape[0], n_edges, c, num_heads,
+            tiles.tile_order.data_ptr(), tiles.s_cap, tiles.e_cap, out.data_ptr(), _ld(_rows(out)), n_dst, k.shape[0], n_edges, c, num_heads,
             _stream())
     _lib.check(st, "anemoi_gt_edge_attention_tiled")
     return out

@@ -31,7 +31,7 @@ def compute_dtype(x: Tensor) -> torch.dtype:
     if forced:
         return _FORCED_DTYPE[forced.lower()]
     if torch.is_autocast_enabled():
-        dt = torch.get_autocast_gpu_dtype()
+        dt = torch.get_autocast_dtype("cuda")
         if dt not in (torch.bfloat16, torch.float32):
             raise NotImplementedError(f"autocast dtype {dt} is not supported on the MI355X path (use bfloat16)")
         return dt
@@ -103,7 +103,7 @@ def build_edge_plan(edge_index: Tensor, n_src: int, n_dst: int) -> EdgePlan:
                     n_dst)
 
 
-TILE_DST = 32  # destinations per tile of the LDS-staged edge kernel (csrc/edge_attention.hip: TILE_DST)
+TILE_DST = 64  # destinations per tile of the LDS-staged edge kernel (csrc/edge_attention.hip: TILE_DST)
 
 
 @dataclass
@@ -113,6 +113,7 @@ class EdgeTiles:
     tile_src_ptr: Tensor  # int32 [n_tiles + 1]
     tile_src: Tensor  # int32 [sum of unique sources]
     col_local: Tensor  # int32 [E]: slot of CSR edge e's source in its tile's list
+    tile_order: Tensor  # int32 [n_tiles * TILE_DST]: destination row per slot of the tile, falling in-degree, -1 = empty
     s_cap: int  # LDS rows per tile (max unique sources, rounded up to 32)
     e_cap: int  # LDS edge slots per tile (max edges, rounded up to 4)
     reuse: float  # edges per unique (tile, source) pair: how many gathers one staged row replaces
@@ -130,7 +131,7 @@ def edge_tiles(plan: EdgePlan) -> EdgeTiles:
     if e == 0:
         tiles = EdgeTiles(torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev),
                           torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
-                          32, 4, 0.0)
+                          _tile_order(plan, n_tiles), 32, 4, 0.0)
         plan._tiles = tiles
         return tiles
     tile = plan.dst.long() // TILE_DST
@@ -144,21 +145,33 @@ def edge_tiles(plan: EdgePlan) -> EdgeTiles:
     bounds = (torch.arange(0, n_tiles + 1, device=dev) * TILE_DST).clamp_(max=plan.n_dst)
     e_per_tile = plan.rowptr.long()[bounds].diff()
     tiles = EdgeTiles(ptr.to(torch.int32), (uniq % plan.n_src).to(torch.int32).contiguous(),
-                      col_local.to(torch.int32).contiguous(), ops.round_up(int(counts.max()), 32),
+                      col_local.to(torch.int32).contiguous(), _tile_order(plan, n_tiles),
+                      ops.round_up(int(counts.max()), 32),
                       ops.round_up(int(e_per_tile.max()), 4), float(e) / float(uniq.numel()))
     plan._tiles = tiles
     return tiles
+
+
+def _tile_order(plan: EdgePlan, n_tiles: int) -> Tensor:
+    """Per tile the destination rows sorted by falling in-degree (stable), padded with -1: the slot -> row map of the
+    LDS-staged kernel (64 / LPH consecutive slots share a wave and its loop trip count)."""
+    dev = plan.rowptr.device
+    deg = torch.full((n_tiles * TILE_DST,), -1, dtype=torch.int64, device=dev)
+    deg[: plan.n_dst] = plan.rowptr[1:].long() - plan.rowptr[:-1].long()
+    order = torch.sort(deg.view(n_tiles, TILE_DST), dim=1, descending=True, stable=True).indices
+    rows = order + torch.arange(n_tiles, device=dev)[:, None] * TILE_DST
+    rows = torch.where(rows < plan.n_dst, rows, torch.full_like(rows, -1))
+    return rows.reshape(-1).to(torch.int32).contiguous()
 
 
 def use_edge_tiles(plan: EdgePlan, dtype: torch.dtype, channels: int, num_heads: int, up: int) -> Optional[EdgeTiles]:
     """The tiling when the LDS-staged kernel should run this edge set, else ``None`` (-> the gather kernel).
 
     OPT-IN (``ANEMOI_AMD_EDGE_TILED=1``: where the heuristic below says it can pay; ``=force``: wherever it fits LDS).
-    Measured on config 3's mesh graph (profiles/r02_edge_kernels.md): the staged kernel moves 2.3x fewer bytes through
-    the texture path (TA busy 19 % against 77 %) but runs 0.31 ms against the gather kernel's 0.15 ms -- a workgroup's
-    stage -> barrier -> compute phases do not overlap and three 4-wave workgroups per CU leave the VALU-side of the loop
-    (2.4x the instructions: per-lane predication, destinations of unequal degree in one wave) under-occupied.  It stays
-    in the library, tested, as the starting point for a persistent double-buffered version.
+    Measured on config 3's mesh graph (profiles/r02_edge_kernels.md): the staged kernel takes the load off the texture
+    path as intended (TA busy 19 % against 77 %, every row slice moved once per tile) but runs 0.26 ms against the
+    gather kernel's 0.15 ms: 160 KiB of LDS allow two waves per SIMD, and at that occupancy its loop's VALU stream is
+    issue-bound.  It stays in the library, tested and bit-identical to the gather kernel, as the base for a leaner loop.
 
     Heuristic: staging can pay when a staged row replaces several gathers AND the per-head re-read of the tile's edge
     attributes stays small next to it: in-degree >= 5 and >= 2.5 edges per unique (tile, source) pair -- the mesh

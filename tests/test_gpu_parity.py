@@ -250,6 +250,9 @@ def test_gt_edge_attention_tiled_on_the_mesh_graph(dtype, c, monkeypatch):
     assert runtime.use_edge_tiles(plan, dtype, c, h, up) is None  # opt-in: the gather kernel is the faster one today
     monkeypatch.setenv("ANEMOI_AMD_EDGE_TILED", "1")
     tiles = runtime.use_edge_tiles(plan, dtype, c, h, up)
+    if dtype == torch.float32 and c == 1024:
+        assert tiles is None  # f32 rows of 64 channels: two buffers of 192 source rows do not fit the 160 KiB of LDS
+        return
     assert tiles is not None and n % runtime.TILE_DST != 0
     dst = plan.dst.long()
     col = tiles.tile_src.long()[tiles.tile_src_ptr.long()[dst // runtime.TILE_DST] + tiles.col_local.long()]

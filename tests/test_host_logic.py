@@ -472,4 +472,12 @@ def test_edge_tiles_reproduce_the_plan():
             lo, hi = k * runtime.TILE_DST, min((k + 1) * runtime.TILE_DST, n_dst)
             assert int(plan.rowptr[hi] - plan.rowptr[lo]) <= t.e_cap
             assert set(seg.tolist()) == set(plan.col[int(plan.rowptr[lo]):int(plan.rowptr[hi])].tolist())
+        # slot -> destination map: a permutation of the tile's rows by falling in-degree, -1 padding behind the last row
+        order = t.tile_order.view(n_tiles, runtime.TILE_DST)
+        deg = (plan.rowptr[1:] - plan.rowptr[:-1]).long()
+        for k in range(n_tiles):
+            lo, hi = k * runtime.TILE_DST, min((k + 1) * runtime.TILE_DST, n_dst)
+            rows = order[k][order[k] >= 0].long()
+            assert sorted(rows.tolist()) == list(range(lo, hi)) and torch.all(order[k][hi - lo:] == -1)
+            assert torch.all(deg[rows][1:] <= deg[rows][:-1])
         assert runtime.edge_tiles(plan) is t  # cached on the plan
