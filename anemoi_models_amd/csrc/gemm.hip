@@ -880,6 +880,8 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       // staging rate), and a second launch ~8 us; so split only a remainder that is the whole problem (small M of a
       // node-partitioned run: 5120 x 1024 x 4096 0.081 -> 0.052 ms) or belongs to long tiles (K >= 2048: 40 962 x 1024
       // x 4096 0.314 -> 0.295 ms; at K = 1216 the second launch costs what the half tiles save)
+      // (round 2: splitting EVERY remainder of <= 128 tiles off, whatever K, measured -1 ... +9 % on the per-rank shapes
+      //  5121 x {4096, 2048, 2240, 1024} -- profiles/r02_gemm_small_m.txt -- so the rule stays)
       if (rem_mt > 0 && rem_mt * nt <= 128 && (rem_mt == mt || K >= 2048)) {
         mt_a = mt - rem_mt;
         mt_b = rem_mt;
