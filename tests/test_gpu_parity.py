@@ -1231,3 +1231,46 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
     model.zero_grad()
     model(x.to(DEV)).backward(dy.to(DEV))
     assert model.processor._plans.get(model.processor.edge_index_base, 162, 162, 1, model.processor.edge_inc) is plan
+
+
+@pytest.mark.parametrize("m,n,k,act,res,fold", [
+    (40962, 1024, 4096, "Identity", True, False),   # 640 tiles = 2.5 rounds: remainder rows as half tiles
+    (5121, 4096, 1024, "GELU", False, True),        # 320 tiles = 1.25 rounds (LayerNorm fold)
+    (5121, 1024, 4096, "Identity", True, False),    # 80 tiles: the whole problem as half tiles
+    (5121, 1024, 1216, "Identity", True, False),    # K = 19 slabs
+    (2304, 1024, 512, "SiLU", False, False),        # 36 tiles: 4 or 5 per XCD
+    (70000, 1024, 1024, "Identity", False, False),  # ragged last row tile
+])
+def test_linear_remainder_round_shapes(m, n, k, act, res, fold):
+    """Shapes whose tile count leaves a short remainder round on the 256 CUs (full mesh and per-rank sizes of config 3):
+    half-tile second launch, ragged last row tile, skinny tail rows.  Against an f64 reference, reproducible bit for bit
+    over repeated launches, and with the row statistics of the result taken by the same launch."""
+    from anemoi_models_amd import ops, runtime
+
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * 0.7 + 0.1).bfloat16()
+    w32 = torch.randn(n, k, generator=g) / k**0.5
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g).bfloat16() if res else None
+    acts = {"Identity": lambda t: t, "GELU": F.gelu, "SiLU": F.silu}
+    xd, rd = x.to(DEV), None if r is None else r.to(DEV)
+    if fold:
+        gamma, beta = 1.0 + 0.1 * torch.randn(k, generator=g), 0.1 * torch.randn(k, generator=g)
+        wq, bq, cs = runtime.fold_layer_norm(w32.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), torch.bfloat16)
+        want = acts[act](F.linear(F.layer_norm(x.double(), (k,), gamma.double(), beta.double(), 1e-5), w32.double(), b.double()))
+        run = lambda: ops.linear(xd, wq, bq, act=act, residual=rd, ln=(ops.row_stats(xd, 1e-5), cs))  # noqa: E731
+    else:
+        wq = w32.bfloat16().to(DEV)
+        want = acts[act](F.linear(x.double(), wq.cpu().double(), b.double()))
+        run = lambda: ops.linear(xd, wq, b.to(DEV), act=act, residual=rd,  # noqa: E731
+                                 stats_eps=1e-5 if act == "Identity" else None)
+    if res:
+        want = want + r.double()
+    got = run()
+    assert rel_err(got, want) < (2e-2 if fold else 1e-2)
+    for _ in range(5):
+        assert torch.equal(run(), got)
+    if not fold and act == "Identity":
+        carried = ops.row_stats(got, 1e-5)
+        fresh = ops.row_stats(got.clone(), 1e-5)
+        assert rel_err(carried, fresh) < 1e-3
