@@ -285,6 +285,30 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
     return _GTEdgeAttention.apply(q, k, v, x_r, u, edge_attr, plan, num_heads, up)
 
 
+# ------------------------------------------------------------------------------------------ mesh-node self attention
+class _MHSA(torch.autograd.Function):
+    """``softmax(Q K^T / sqrt(D)) V`` on the fused ``q | k | v`` matrix (``anemoi_mhsa``, MFMA flash kernel for bf16 head
+    sizes 64 / 32); the backward recomputes the probabilities from the saved log-sum-exp (``anemoi_mhsa_backward``)."""
+
+    @staticmethod
+    def forward(ctx, qkv: Tensor, batch_size: int, num_heads: int, window: int):
+        out, lse = ops.mhsa(qkv, batch_size, num_heads, window, return_lse=True)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.args = (batch_size, num_heads, window)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        qkv, out, lse = ctx.saved_tensors
+        b, h, w = ctx.args
+        return ops.mhsa_backward(qkv, out, dout.contiguous(), lse, b, h, w), None, None, None
+
+
+def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1) -> Tensor:
+    """Differentiable ``ops.mhsa`` (reference layers/attention.py:67-112)."""
+    return _MHSA.apply(qkv, batch_size, num_heads, window)
+
+
 # ------------------------------------------------------------------------------------------ GNN edge phase
 class _GatherAddAct(torch.autograd.Function):
     """``act(t[e] + p_dst[dst[e]] + p_src[src[e]])`` over the CSR slots of ``plan`` (``anemoi_gather_add_act``).  Backward:

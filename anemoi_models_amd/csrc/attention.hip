@@ -72,7 +72,7 @@ template <int ATT_D>
 __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                         const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                         int64_t ldo, int S, int S_pad, int H, int C, int window,
-                                                        float scale_log2e) {
+                                                        float scale_log2e, float* __restrict__ lse) {
   static_assert(ATT_D == 32 || ATT_D == 64, "head sizes with an MFMA path");
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32;
   constexpr int KRB = ATT_D * 2;                        // bytes of a key row in the K tile
@@ -242,6 +242,8 @@ __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict
   for (int qb = 0; qb < 2; ++qb) {
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (lse != nullptr && half == 0 && qn[qb] < S)  // natural-log sum-exp of the scaled scores (training: backward input)
+      lse[((int64_t)b * H + h) * S + qn[qb]] = (m_run[qb] + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
     if (qn[qb] < S) {
       bf16_t* op = out + ((int64_t)b * S + qn[qb]) * ldo + h * ATT_D;
 #pragma unroll
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict
 template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__ qkv, int64_t ld, T* __restrict__ out,
                                                            int64_t ldo, int S, int H, int D, int C, int window,
-                                                           float scale, int64_t total) {
+                                                           float scale, int64_t total, float* __restrict__ lse) {
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
   if (unit >= total) return;
@@ -306,12 +308,133 @@ __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__
   const float w = m == -INFINITY ? 0.f : __expf(m - mt);
   const float lt = wave_sum(l * w);
   const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  if (lse != nullptr && lane == 0) lse[(b * H + h) * S + q] = mt + __logf(lt);
   T* op = out + bq * ldo + h * D;
 #pragma unroll
   for (int d = 0; d < DMAX; ++d) {
     if (d < D) {
       const float o = wave_sum(acc[d] * w) * inv;
       if (lane == 0) Elem<T>::store(op + d, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of softmax(Q K^T / sqrt(D)) V (flash-attention style: nothing of size S x S is stored; the probabilities are
+// recomputed from the saved log-sum-exp).  With P_ij = exp(s_ij - lse_i), dP_ij = dO_i . v_j, delta_i = dO_i . O_i,
+// dS_ij = P_ij (dP_ij - delta_i):   dQ_i = scale sum_j dS_ij k_j,   dK_j = scale sum_i dS_ij q_i,   dV_j = sum_i P_ij dO_i.
+// VALU kernels (any head size <= 128, f32 or bf16 storage, f32 arithmetic): one wave per (query, head) for dQ / delta,
+// one wave per (key, head) for dK / dV, the other index strided over the lanes, per-lane partial vectors merged by
+// wave reductions -- no atomics, reproducible.  O(S^2 D) on the vector pipe: a correct backward for training the
+// Transformer processor at test / moderate sizes; the MFMA forward's tiling has not been carried over to it yet.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const T* __restrict__ qkv, int64_t ld, const T* __restrict__ o,
+                                                          int64_t ldo, const T* __restrict__ dout, int64_t lddo,
+                                                          const float* __restrict__ lse, float* __restrict__ delta,
+                                                          T* __restrict__ dqkv, int64_t lddq, int S, int H, int D, int C,
+                                                          int window, float scale, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
+  if (unit >= total) return;
+  const int h = (int)(unit % H);
+  const int64_t bq = unit / H;
+  const int q = (int)(bq % S);
+  const int64_t b = bq / S;
+  float qv[DMAX], dov[DMAX], acc[DMAX];
+  float dl = 0.f;
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    qv[d] = d < D ? Elem<T>::load(qkv + bq * ld + h * D + d) * scale : 0.f;
+    dov[d] = d < D ? Elem<T>::load(dout + bq * lddo + h * D + d) : 0.f;
+    if (d < D) dl = fmaf(dov[d], Elem<T>::load(o + bq * ldo + h * D + d), dl);
+    acc[d] = 0.f;
+  }
+  const float ls = lse[(b * H + h) * S + q];
+  if (lane == 0) delta[(b * H + h) * S + q] = dl;
+  int k_lo = 0, k_hi = S;
+  if (window >= 0) {
+    k_lo = q - window > 0 ? q - window : 0;
+    k_hi = q + window + 1 < S ? q + window + 1 : S;
+  }
+  for (int key = k_lo + lane; key < k_hi; key += 64) {
+    const T* kp = qkv + (b * S + key) * ld + C + h * D;
+    const T* vp = kp + C;
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D) {
+        s = fmaf(qv[d], Elem<T>::load(kp + d), s);
+        dp = fmaf(dov[d], Elem<T>::load(vp + d), dp);
+      }
+    const float ds = __expf(s - ls) * (dp - dl) * scale;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D) acc[d] = fmaf(ds, Elem<T>::load(kp + d), acc[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    if (d < D) {
+      const float v = wave_sum(acc[d]);
+      if (lane == 0) Elem<T>::store(dqkv + bq * lddq + h * D + d, v);
+    }
+  }
+}
+
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void mhsa_bwd_dkv_kernel(const T* __restrict__ qkv, int64_t ld,
+                                                           const T* __restrict__ dout, int64_t lddo,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           T* __restrict__ dqkv, int64_t lddq, int S, int H, int D, int C,
+                                                           int window, float scale, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, key, h)
+  if (unit >= total) return;
+  const int h = (int)(unit % H);
+  const int64_t bk = unit / H;
+  const int key = (int)(bk % S);
+  const int64_t b = bk / S;
+  float kv[DMAX], vv[DMAX], dk[DMAX], dv[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    kv[d] = d < D ? Elem<T>::load(qkv + bk * ld + C + h * D + d) : 0.f;
+    vv[d] = d < D ? Elem<T>::load(qkv + bk * ld + 2 * C + h * D + d) : 0.f;
+    dk[d] = 0.f;
+    dv[d] = 0.f;
+  }
+  int q_lo = 0, q_hi = S;
+  if (window >= 0) {
+    q_lo = key - window > 0 ? key - window : 0;
+    q_hi = key + window + 1 < S ? key + window + 1 : S;
+  }
+  for (int q = q_lo + lane; q < q_hi; q += 64) {
+    const T* qp = qkv + (b * S + q) * ld + h * D;
+    const T* dop = dout + (b * S + q) * lddo + h * D;
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D) {
+        s = fmaf(Elem<T>::load(qp + d), kv[d], s);
+        dp = fmaf(Elem<T>::load(dop + d), vv[d], dp);
+      }
+    const int64_t si = (b * H + h) * S + q;
+    const float p = __expf(s * scale - lse[si]);
+    const float ds = p * (dp - delta[si]) * scale;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D) {
+        dv[d] = fmaf(p, Elem<T>::load(dop + d), dv[d]);
+        dk[d] = fmaf(ds, Elem<T>::load(qp + d), dk[d]);
+      }
+  }
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    if (d < D) {
+      const float a = wave_sum(dk[d]), c = wave_sum(dv[d]);
+      if (lane == 0) {
+        Elem<T>::store(dqkv + bk * lddq + C + h * D + d, a);
+        Elem<T>::store(dqkv + bk * lddq + 2 * C + h * D + d, c);
+      }
     }
   }
 }
@@ -327,8 +450,8 @@ int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
   return 0;
 }
 
-int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, int B, int S, int H,
-                int D, int window, anemoi_stream_t stream) {
+int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
+                int H, int D, int window, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out, ANEMOI_ERR_INVALID, "anemoi_mhsa: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa: bad shape");
   const int C = H * D;
@@ -346,11 +469,11 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
     if (D == 64)
       hipLaunchKernelGGL(mhsa_bf16_kernel<64>, grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
                          static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
-                         scale * 1.44269504088896340736f);
+                         scale * 1.44269504088896340736f, lse);
     else
       hipLaunchKernelGGL(mhsa_bf16_kernel<32>, grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
                          static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
-                         scale * 1.44269504088896340736f);
+                         scale * 1.44269504088896340736f, lse);
     return check_launch("anemoi_mhsa(bf16, MFMA)");
   }
   ANEMOI_REQUIRE(D <= 128, ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa: head size %d > 128", D);
@@ -359,7 +482,7 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   dim3 grid((unsigned)((units + 3) / 4)), block(256);
 #define GEN(T, DM)                                                                                               \
   hipLaunchKernelGGL((mhsa_generic_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,           \
-                     static_cast<T*>(out), ldo, S, H, D, C, window, scale, units)
+                     static_cast<T*>(out), ldo, S, H, D, C, window, scale, units, lse)
   if (dtype == ANEMOI_F32) {
     if (D <= 32) GEN(float, 32);
     else if (D <= 64) GEN(float, 64);
@@ -373,6 +496,44 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   }
 #undef GEN
   return check_launch("anemoi_mhsa(generic)");
+}
+
+int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
+                         int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, int B, int S, int H, int D,
+                         int window, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(qkv && out && dout && lse && delta && dqkv, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: null pointer");
+  ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: bad shape");
+  const int C = H * D;
+  ANEMOI_REQUIRE(ld >= 3 * (int64_t)C && lddq >= 3 * (int64_t)C && ldo >= C && lddo >= C, ANEMOI_ERR_INVALID,
+                 "anemoi_mhsa_backward: leading dimension too small");
+  ANEMOI_REQUIRE(D <= 128, ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: head size %d > 128", D);
+  hipStream_t st = as_stream(stream);
+  const float scale = 1.0f / sqrtf((float)D);
+  const int64_t units = (int64_t)B * S * H;
+  ANEMOI_REQUIRE((units + 3) / 4 < ((int64_t)1 << 31), ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: grid too large");
+  dim3 grid((unsigned)((units + 3) / 4)), block(256);
+#define BWD(T, DM)                                                                                                    \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((mhsa_bwd_dq_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,               \
+                       static_cast<const T*>(out), ldo, static_cast<const T*>(dout), lddo, lse, delta,                \
+                       static_cast<T*>(dqkv), lddq, S, H, D, C, window, scale, units);                                \
+    hipLaunchKernelGGL((mhsa_bwd_dkv_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,              \
+                       static_cast<const T*>(dout), lddo, lse, static_cast<const float*>(delta), static_cast<T*>(dqkv), \
+                       lddq, S, H, D, C, window, scale, units);                                                       \
+  } while (0)
+  if (dtype == ANEMOI_F32) {
+    if (D <= 32) BWD(float, 32);
+    else if (D <= 64) BWD(float, 64);
+    else BWD(float, 128);
+  } else if (dtype == ANEMOI_BF16) {
+    if (D <= 32) BWD(bf16_t, 32);
+    else if (D <= 64) BWD(bf16_t, 64);
+    else BWD(bf16_t, 128);
+  } else {
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: dtype %d", dtype);
+  }
+#undef BWD
+  return check_launch("anemoi_mhsa_backward");
 }
 
 }  // extern "C"

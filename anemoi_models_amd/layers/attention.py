@@ -54,7 +54,15 @@ class MultiHeadSelfAttention(nn.Module):
         if model_comm_group is not None and model_comm_group.size() > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded accross GPUs"
             raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
-        runtime.require_inference(self)
+        from .. import autograd, training
+
+        if training.wants_grad(self, x):  # reference layers/attention.py:67-112 with an autograd graph
+            if self.dropout_p > 0.0 and self.training:
+                raise NotImplementedError("attention dropout > 0 in training is not implemented on the MI355X kernels")
+            xin = training._cast(x, runtime.compute_dtype(x))
+            qkv = autograd.linear(xin, self.lin_qkv.weight, self.lin_qkv.bias)
+            att = autograd.mhsa(qkv, batch_size, self.num_heads, self.attention_window())
+            return autograd.linear(att, self.projection.weight, self.projection.bias)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)

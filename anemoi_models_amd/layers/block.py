@@ -635,6 +635,7 @@ class TransformerProcessorBlock(BaseBlock):
     def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None) -> Tensor:
         if _group_size(model_comm_group) > 1:
             raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
-        runtime.require_inference(self)
+        if training.wants_grad(self, x):
+            return training.transformer_block(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
         return self.native(_as_compute(x, dtype), batch_size)

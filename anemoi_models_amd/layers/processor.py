@@ -97,7 +97,8 @@ class TransformerProcessor(BaseProcessor):
             ), "Only batch size of 1 is supported when model is sharded accross GPUs"
             if model_comm_group.size() > 1:
                 raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
-        runtime.require_inference(self)
+        if training.wants_grad(self, x):
+            return training.transformer_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)

@@ -356,8 +356,10 @@ def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None) -> Tens
     return out
 
 
-def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Optional[Tensor] = None) -> Tensor:
-    """Multi-head self attention on the fused ``lin_qkv`` output ``[B*S, 3C]`` -> ``[B*S, C]`` (heads concatenated)."""
+def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Optional[Tensor] = None,
+         return_lse: bool = False):
+    """Multi-head self attention on the fused ``lin_qkv`` output ``[B*S, 3C]`` -> ``[B*S, C]`` (heads concatenated).
+    ``return_lse``: also the f32 ``[B, H, S]`` log-sum-exp of the scaled scores (the backward's input)."""
     _dev(qkv, out)
     rows, c3 = _rows(qkv).shape
     c = c3 // 3
@@ -369,11 +371,31 @@ def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Op
     code = dtype_code(qkv.dtype)
     ws_bytes = lib.anemoi_mhsa_workspace_bytes(code, batch_size, s_len, num_heads, d)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 else None
+    lse = torch.empty((batch_size, num_heads, s_len), dtype=torch.float32, device=qkv.device) if return_lse else None
     with _Timed("mhsa", flops=4 * batch_size * num_heads * s_len * s_len * d, s=s_len, h=num_heads, d=d):
-        st = lib.anemoi_mhsa(code, qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)), _ptr(ws), batch_size,
-                             s_len, num_heads, d, window, _stream())
+        st = lib.anemoi_mhsa(code, qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)), _ptr(ws), _ptr(lse),
+                             batch_size, s_len, num_heads, d, window, _stream())
     _lib.check(st, "anemoi_mhsa")
-    return out
+    return (out, lse) if return_lse else out
+
+
+def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_size: int, num_heads: int,
+                  window: int = -1) -> Tensor:
+    """``d qkv`` ``[B*S, 3C]`` of :func:`mhsa` from the forward's output and log-sum-exp (``anemoi_mhsa_backward``)."""
+    _dev(qkv, out, dout, lse)
+    rows, c3 = _rows(qkv).shape
+    c = c3 // 3
+    s_len = rows // batch_size
+    dqkv = torch.empty((rows, c3), dtype=qkv.dtype, device=qkv.device)
+    delta = torch.empty((batch_size, num_heads, s_len), dtype=torch.float32, device=qkv.device)
+    if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != delta.numel():
+        raise ValueError("mhsa_backward: lse must be the contiguous f32 [B, H, S] output of mhsa(return_lse=True)")
+    st = _lib.load().anemoi_mhsa_backward(dtype_code(qkv.dtype), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)),
+                                          dout.data_ptr(), _ld(_rows(dout)), lse.data_ptr(), delta.data_ptr(),
+                                          dqkv.data_ptr(), c3, batch_size, s_len, num_heads, c // num_heads, window,
+                                          _stream())
+    _lib.check(st, "anemoi_mhsa_backward")
+    return dqkv
 
 
 def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Tensor], batch_size: int,

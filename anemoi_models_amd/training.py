@@ -11,8 +11,9 @@ Every ``nn.Module`` of this package keeps two routes to the same arithmetic:
   the reference's own tests (reference tests/layers/processor/test_graphtransformer_processor.py:145-159) and in
   anemoi-training.
 
-Model families: flat and hierarchical GraphTransformer models, the GNN processor and GNN mappers.  The Transformer
-processor (mesh-node self attention) has no backward kernel yet and still refuses gradients.
+Model families: flat and hierarchical GraphTransformer models, the GNN processor and GNN mappers, the Transformer
+processor (its attention backward is a pair of VALU kernels, ``anemoi_mhsa_backward``: correct, O(S^2 D) on the vector
+pipe -- fine for tests and moderate meshes, not yet at the speed of the MFMA forward).
 
 Activation checkpointing follows the reference: every mapper call and every processor chunk is wrapped in
 ``torch.utils.checkpoint`` (reference models/encoder_processor_decoder.py:159-166, layers/processor.py:73-77); all
@@ -291,6 +292,36 @@ def gnn_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int):
     if ext is not None:
         hd = mlp(ext, hd)
     return hs, hd
+
+
+# ------------------------------------------------------------------------------------------------ Transformer
+def transformer_block(block, x: Tensor, batch_size: int) -> Tensor:
+    """``TransformerProcessorBlock.forward`` (reference layers/block.py:99-105): ``x + proj(attn(qkv(LN x)))``, then
+    ``x + MLP(LN x)``."""
+    dtype = runtime.compute_dtype(x)
+    att = block.attention
+    if att.dropout_p > 0.0 and block.training:
+        raise NotImplementedError("attention dropout > 0 in training is not implemented on the MI355X kernels")
+    x = _cast(x, dtype)
+    h = autograd.layer_norm(x, block.layer_norm1.weight, block.layer_norm1.bias, block.layer_norm1.eps)
+    qkv = autograd.linear(h, att.lin_qkv.weight, att.lin_qkv.bias)
+    a = autograd.mhsa(qkv, batch_size, att.num_heads, att.attention_window())
+    x = autograd.linear(a, att.projection.weight, att.projection.bias, "Identity", x)
+    h = autograd.layer_norm(x, block.layer_norm2.weight, block.layer_norm2.bias, block.layer_norm2.eps)
+    return sequential(block.mlp, h, residual=x)
+
+
+def transformer_processor(proc, x: Tensor, batch_size: int) -> Tensor:
+    """``TransformerProcessor.forward`` (reference layers/processor.py:103-137): checkpointed chunks of blocks."""
+    def run_chunk(chunk, h):
+        for blk in chunk.blocks:
+            h = transformer_block(blk, h, batch_size)
+        return h
+
+    h = _cast(x, runtime.compute_dtype(x))
+    for chunk in proc.proc:
+        h = _checkpoint(run_chunk, chunk, h)
+    return h
 
 
 # ------------------------------------------------------------------------------------------------ model roots

@@ -270,8 +270,19 @@ int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* row
  * other cases use a VALU kernel (workspace may be NULL).
  */
 int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D);
-int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, int B, int S, int H,
-                int D, int window, anemoi_stream_t stream);
+int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
+                int H, int D, int window, anemoi_stream_t stream);
+
+/*
+ * Backward of anemoi_mhsa (what torch autograd derives for the reference's scaled_dot_product_attention call,
+ * layers/attention.py:99-105, when anemoi-training calls .backward()).  `lse` f32 [B, H, S] is the forward's optional
+ * output (natural-log sum-exp of the scaled scores per query and head; pass NULL to the forward when not training), `out`
+ * the forward's result, `dout` its gradient; writes dqkv [B*S, 3C] = dq | dk | dv in `dtype`.  `delta` f32 [B, H, S] is
+ * scratch.  Probabilities are recomputed from lse (nothing of size S x S is stored); no atomics.  VALU kernels, O(S^2 D).
+ */
+int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
+                         int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, int B, int S, int H, int D,
+                         int window, anemoi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Backward pass, dense half (first step): the pieces the autograd of the fused Linear and of

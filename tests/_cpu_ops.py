@@ -125,7 +125,7 @@ def segment_sum(v, rowptr, out=None):
     return y
 
 
-def mhsa(qkv, batch_size, num_heads, window=-1, out=None):
+def mhsa(qkv, batch_size, num_heads, window=-1, out=None, return_lse=False):
     rows, c3 = qkv.shape
     c = c3 // 3
     s_len, d = rows // batch_size, c // num_heads
@@ -134,8 +134,8 @@ def mhsa(qkv, batch_size, num_heads, window=-1, out=None):
     if window >= 0:
         i = torch.arange(s_len)
         sc = sc.masked_fill((i[:, None] - i[None, :]).abs() > window, float("-inf"))
-    o = torch.softmax(sc, -1) @ v
-    return o.permute(0, 2, 1, 3).reshape(rows, c).to(qkv.dtype)
+    o = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(rows, c).to(qkv.dtype)
+    return (o, torch.logsumexp(sc, -1)) if return_lse else o
 
 
 def assemble_nodes(x, latlons, trainable, batch_size, dtype, ld_out=None, ensemble=1, in_affine=None):

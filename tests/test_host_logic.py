@@ -71,8 +71,7 @@ def test_expand_edges_bit_exact(golden_index_ops):
 
 def test_forward_with_gradients_enabled(graph_o32, golden_cfg1_gt, monkeypatch):
     """With autograd on, the flat GraphTransformer model takes the differentiable route (autograd.model_forward: same
-    result as the inference route, an autograd graph behind it); the Transformer processor (no attention backward) still
-    refuses."""
+    result as the inference route, an autograd graph behind it)."""
     _cpu_ops.install(monkeypatch)
     model = build_model(graph_o32)
     model.load_state_dict(split_prefix(golden_cfg1_gt, "sd."))
@@ -81,8 +80,6 @@ def test_forward_with_gradients_enabled(graph_o32, golden_cfg1_gt, monkeypatch):
     torch.testing.assert_close(y.detach(), golden_cfg1_gt["y"], atol=5e-4, rtol=5e-4)
     with torch.no_grad():
         torch.testing.assert_close(model(golden_cfg1_gt["x"]), y.detach(), atol=1e-4, rtol=1e-4)
-    with pytest.raises(NotImplementedError):  # mesh-node self attention has no backward kernel: still forward-only
-        build_model(graph_o32, "Transformer")(torch.zeros(1, 2, 1, graph_o32["data"].num_nodes, 12))
     y2 = model(golden_cfg1_gt["x"].repeat(2, 1, 1, 1, 1))  # batch 2: the batched graph, both samples alike
     torch.testing.assert_close(y2[0].detach(), y[0].detach(), atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(y2[1].detach(), y[0].detach(), atol=1e-4, rtol=1e-4)
