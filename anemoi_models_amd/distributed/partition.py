@@ -312,9 +312,14 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
     batch_size, _, ensemble_size, grid, _ = x.shape
     assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
     dtype = runtime.compute_dtype(x)
+    from ..layers.mapper import GNNBaseMapper
+
     if not hasattr(model.encoder, "native_local") or not hasattr(model.decoder, "native_local"):
-        raise NotImplementedError("the node-partitioned forward supports the GraphTransformer mappers only")
-    if model.encoder.proc.fold_width(dtype) is None:
+        raise NotImplementedError("the node-partitioned forward supports the GraphTransformer and GNN mappers")
+    gnn_maps = isinstance(model.encoder, GNNBaseMapper)
+    if gnn_maps != isinstance(model.decoder, GNNBaseMapper):
+        raise NotImplementedError("the node-partitioned forward needs encoder and decoder of one mapper family")
+    if not gnn_maps and model.encoder.proc.fold_width(dtype) is None:
         raise NotImplementedError("the node-partitioned forward needs the folded edge kernel for this shape / dtype")
     kmult = ops.k_multiple(dtype)
     key = ("shard_plan", str(x.device), _world(group), _rank(group))
@@ -333,11 +338,19 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
     x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[own_ids], None if tr_hidden is None else tr_hidden[own_ids],
                                   1, dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
 
-    x_latent = model.encoder.native_local(x_data.index_select(0, sp.enc_src_ids), x_hidden, sp.enc)
+    if gnn_maps:
+        # GNN mappers hand the UPDATED grid embedding on to the decoder (reference layers/mapper.py:522): the rows this
+        # rank decodes are embedded and updated here, next to the rows that feed its mesh nodes (both row-local)
+        x_dec_dst, x_latent = model.encoder.native_local(x_data.index_select(0, sp.enc_src_ids), x_hidden, sp.enc,
+                                                         x_src_extra=x_data.index_select(0, sp.dec_dst_ids))
+    else:
+        x_latent = model.encoder.native_local(x_data.index_select(0, sp.enc_src_ids), x_hidden, sp.enc)
+        x_dec_dst = x_data.index_select(0, sp.dec_dst_ids)
     x_proc = model.processor.native_local(x_latent, sp.proc)
     x_latent_proc = ops.add(x_proc, x_latent)
-    y_local = model.decoder.native_local(x_latent_proc, x_data.index_select(0, sp.dec_dst_ids), sp.dec,
-                                         out_dtype=torch.float32)
+    y_local = model.decoder.native_local(x_latent_proc, x_dec_dst, sp.dec, out_dtype=torch.float32)
+    if isinstance(y_local, tuple):
+        y_local = y_local[1]
 
     # ---- all-gather (padded to the largest shard) and put the rows back into grid order
     v_out = model.num_output_channels

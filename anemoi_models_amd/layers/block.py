@@ -543,7 +543,10 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
 class GraphConvMapperBlock(GraphConvBaseBlock):
     """Edge-MLP message passing between two node sets (reference layers/block.py:226-286)."""
 
-    def native(self, x_src: Tensor, x_dst: Tensor, e_csr: Tensor, plan: EdgePlan):
+    def native(self, x_src: Tensor, x_dst: Tensor, e_csr: Tensor, plan: EdgePlan, halo=None):
+        """``halo`` (node-partitioned run, backward mapper): ``x_src`` holds this rank's source rows only; the ``W1b x``
+        rows of the halo sources arrive from their owners by one all-to-all-v (C values per row) while the destination
+        and edge GEMMs run."""
         dtype = x_dst.dtype
         c = x_dst.shape[1]
         edge_mlp, node_mlp = self.conv.edge_mlp.native(), self.node_mlp.native()
@@ -553,9 +556,18 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
                                  lambda: runtime.pack_weight([lin1.weight[:, c:2 * c]], dtype))
         w_edges = self._packed.get(("w1_edges", dtype), [lin1.weight],
                                    lambda: runtime.pack_weight([lin1.weight[:, 2 * c:]], dtype))
+        if halo is None:
+            p_src = ops.linear(x_src, w_src, None)
+            pending = None
+        else:
+            n_own = x_src.shape[0]
+            p_src = torch.empty((n_own + halo.n_recv, c), dtype=dtype, device=x_dst.device)
+            ops.linear(x_src, w_src, None, out=p_src[:n_own])
+            pending = halo.start(p_src, n_own)
         p_dst = ops.linear(x_dst, w_dst, None)
-        p_src = ops.linear(x_src, w_src, None)
         t = ops.linear(e_csr, w_edges, None if lin1.bias is None else runtime.f32c(lin1.bias))
+        if pending is not None:
+            halo.finish(pending)
         h = ops.gather_add_act(t, p_dst, p_src, plan.dst, plan.col, act=act1, out=t)
         e_new = edge_mlp(h, residual=e_csr, start=1)
         del h, t, p_dst, p_src

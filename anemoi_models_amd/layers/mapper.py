@@ -254,9 +254,35 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
         (h_src, h_dst), _ = self.proc.native(h_src, h_dst, e, plan)
         return h_src, self._extract(h_dst, out_dtype)
 
+    def native_local(self, x_src: Tensor, x_dst: Tensor, local_graph, out_dtype: Optional[torch.dtype] = None,
+                     x_src_extra: Optional[Tensor] = None):
+        """Node-partitioned run (``distributed/partition.py``): local source / destination rows, local CSR plan (``perm``
+        = original edge ids), halo source rows (backward mapper) by all-to-all-v inside the block.  ``x_src_extra``
+        (forward mapper): further SOURCE rows whose updated embedding the caller needs (the grid rows this rank decodes):
+        the source update of the block is row-local (reference layers/block.py:282), so it is evaluated on them too.
+        Returns ``(updated source rows of x_src_extra or None, destination rows)``."""
+        plan = local_graph.plan
+        dtype = x_dst.dtype
+        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm)
+        e = ops.convert_pad(ea[:, : self.edge_dim], dtype, ops.round_up(self.edge_dim, ops.k_multiple(dtype)))
+        e = self.emb_edges.native()(e)
+        h_src, h_dst = self._embed(x_src, x_dst)
+        (_, h_dst), _ = self.proc.native(h_src, h_dst, e, plan, local_graph.halo)
+        extra = None
+        if x_src_extra is not None:
+            hx = self.emb_nodes_src.native()(x_src_extra) if hasattr(self, "emb_nodes_src") else x_src_extra
+            c = hx.shape[1]
+            if self.proc.update_src_nodes:
+                xcat = torch.empty((hx.shape[0], 2 * c), dtype=dtype, device=hx.device)
+                xcat[:, :c].copy_(hx)
+                xcat[:, c:].copy_(hx)
+                hx = self.proc.node_mlp.native()(xcat, residual=hx)
+            extra = hx
+        return extra, self._extract(h_dst, out_dtype)
+
     def _run(self, x, batch_size: int, shard_shapes, model_comm_group):
         if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("GNN mappers: node-partitioned execution is not implemented yet")
+            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
         x_src, x_dst = x
         if training.wants_grad(self, x_src, x_dst):
             return training.gnn_mapper(self, x_src, x_dst, batch_size)

@@ -384,6 +384,23 @@ def main():
             },
         }
         line.update(extra)
+        if group is not None:  # what this rank puts on the wire per forward step (rank 0's numbers; xGMI all-to-all-v)
+            sp = next((v for k, v in model._idx_cache.items() if isinstance(k, tuple) and k[0] == "shard_plan"), None)
+            if sp is not None:
+                esz = 2 if args.dtype == "bf16" else 4
+                c = model.num_channels
+                proc_rows = sum(sp.proc.halo.send_splits) if sp.proc.halo is not None else 0
+                dec_rows = sum(sp.dec.halo.send_splits) if sp.dec.halo is not None else 0
+                gather_bytes = max(sp.dec_counts) * model.num_output_channels * 4
+                line["halo"] = {
+                    "exchanges_per_step": layers + (1 if sp.dec.halo is not None else 0), "own_mesh_rows": sp.hi - sp.lo,
+                    "processor_rows_sent_per_exchange": proc_rows, "processor_rows_received_per_exchange": sp.proc.halo.n_recv
+                    if sp.proc.halo is not None else 0, "decoder_rows_sent": dec_rows,
+                    "bytes_sent_per_exchange": proc_rows * 2 * c * esz,
+                    "bytes_sent_per_step": (proc_rows * layers + dec_rows) * 2 * c * esz * args.rollout,
+                    "output_all_gather_bytes_per_rank": gather_bytes, "note": "k|v rows of boundary mesh nodes (2C values "
+                    "per row), one all_to_all_single per processor block + one for the decoder; rank 0 of the group",
+                }
         if args.processor != "GraphTransformer":
             line["config"]["workload"] = line["config"]["workload"].replace("GT blocks", f"{args.processor} blocks")
         if not args.no_cpu_baseline and world == 1 and args.processor == "GraphTransformer":

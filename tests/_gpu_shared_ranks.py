@@ -37,7 +37,9 @@ def main():
         graph = build_graph(graph_name)
         idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
         torch.manual_seed(1234)  # the same weights and input on every rank
-        model = AnemoiModelEncProcDec(model_config=model_config("GraphTransformer", channels, layers, heads),
+        family = os.environ.get("ANEMOI_TEST_FAMILY", "GraphTransformer")  # GNN_all: GNN processor + GNN mappers
+        proc_, map_ = ("GNN", "GNN") if family == "GNN_all" else (family, "GraphTransformer")
+        model = AnemoiModelEncProcDec(model_config=model_config(proc_, channels, layers, heads, mappers=map_),
                                       data_indices=idx, graph_data=graph).to(device).eval()
         x = torch.randn(1, 2, 1, graph["data"].num_nodes, 12, device=device)
         with torch.no_grad():

@@ -37,13 +37,18 @@ def _worker(rank, world, port, result_file, processor="GraphTransformer", dtype=
                      "gt_edge_attention_folded", "gt_edge_attention_tiled", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                      "prognostic_residual", "finalize_output", "convert_pad", "add", "act_forward"):
             setattr(ops, name, getattr(_cpu_ops, name))
+        mappers = "GraphTransformer"
+        if processor == "GNN_all":  # GNN processor AND GNN mappers
+            processor, mappers = "GNN", "GNN"
         fname = {"GraphTransformer": "cfg1_gt.npz", "GNN": "cfg1_gnn.npz", "Transformer": "cfg1_tfm.npz"}[processor]
+        if mappers == "GNN":
+            fname = "cfg1_gnn_all.npz"
         with np.load(os.path.join(GOLDEN, fname)) as z:
             gold = {k: torch.from_numpy(z[k]) for k in z.files}
         graph = build_graph("o32_ico2")
         idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
-        model = AnemoiModelEncProcDec(model_config=model_config(processor, 64, 4, heads), data_indices=idx,
-                                      graph_data=graph)
+        model = AnemoiModelEncProcDec(model_config=model_config(processor, 64, 4, heads, mappers=mappers),
+                                      data_indices=idx, graph_data=graph)
         model.load_state_dict({k[3:]: v for k, v in gold.items() if k.startswith("sd.")})
         model.eval()
         with torch.no_grad():
@@ -94,10 +99,10 @@ def test_split_bounds_match_tensor_split():
         assert [b[i + 1] - b[i] for i in range(p)] == sizes
 
 
-@pytest.mark.parametrize("processor", ["GNN", "Transformer"])
+@pytest.mark.parametrize("processor", ["GNN", "Transformer", "GNN_all"])
 def test_sharded_forward_other_processors(processor, tmp_path):
     world = 2
-    port = 29700 + (os.getpid() % 200) + (7 if processor == "GNN" else 13)
+    port = 29700 + (os.getpid() % 200) + {"GNN": 7, "Transformer": 13, "GNN_all": 19}[processor]
     result = str(tmp_path / "res")
     mp.spawn(_worker, args=(world, port, result, processor), nprocs=world, join=True)
     for r in range(world):

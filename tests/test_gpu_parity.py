@@ -654,6 +654,8 @@ def test_node_partitioned_forward_world1_rccl(graph_o32, golden_cfg1_gt):
     (2, "o32_ico2", 64, 4, 4, "bf16", 3e-2),
     (3, "o48_ico3", 256, 4, 16, "bf16", 3e-2),
     (4, "o96_ico5", 512, 2, 16, "bf16", 3e-2),
+    (2, "o32_ico2", 64, 4, 16, "fp32:GNN_all", 2e-5),
+    (3, "o48_ico3", 256, 2, 16, "bf16:GNN_all", 3e-2),
 ])
 def test_node_partitioned_forward_ranks_sharing_one_gpu(world, graph_name, channels, layers, heads, dtype, tol, tmp_path):
     """world > 1 on the HIP kernels: the ranks are separate processes that share cuda:0 and exchange halos through
@@ -665,8 +667,10 @@ def test_node_partitioned_forward_ranks_sharing_one_gpu(world, graph_name, chann
     port = 29700 + (os.getpid() % 200)
     out = str(tmp_path / "res")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_shared_ranks.py")
+    dtype, _, family = dtype.partition(":")  # "bf16:GNN_all" = GNN processor + GNN mappers (partitioned GNN mappers)
+    env = dict(os.environ, ANEMOI_TEST_FAMILY=family or "GraphTransformer")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out, graph_name, str(channels),
-                               str(layers), str(heads), dtype]) for r in range(world)]
+                               str(layers), str(heads), dtype], env=env) for r in range(world)]
     try:
         codes = [p.wait(timeout=900) for p in procs]
     finally:  # a hung or failed rank must not leave its peers holding cuda:0 and the rendezvous port
