@@ -238,6 +238,11 @@ class ShardPlan:
     dec_counts: List[int]  # rows produced by every rank
     dec_all_ids: Tensor  # concatenation of every rank's dec_dst_ids (rank order)
     gather_pos: Optional[Tensor] = None  # per grid row: its position in the padded all-gather buffer (built on first use)
+    # autoregressive rollout with the state kept sharded: the grid rows this rank's ENCODER reads but another rank
+    # decodes (grid ids, grouped by owner) and the exchange that fetches their predictions (send_idx = positions in
+    # dec_dst_ids)
+    grid_halo_ids: Optional[Tensor] = None
+    grid_halo: Optional[HaloExchange] = None
 
 
 def build_shard_plan(model, group, device) -> ShardPlan:
@@ -300,11 +305,39 @@ def build_shard_plan(model, group, device) -> ShardPlan:
                                   n_own + int(halo_ids.numel()), int(dec_dst_ids.numel())), n_own, halo)
     counts = torch.bincount(g_owner, minlength=world).tolist()
     all_ids = torch.argsort(g_owner, stable=True)  # rank-major, ascending grid id inside a rank
-    return ShardPlan(rank, world, lo, hi, enc_src_ids, enc, proc, dec_dst_ids, dec, counts, all_ids)
+    # ---- grid halo of the rollout: encoder sources of rank p that rank p does not decode itself
+    ei = model.encoder.edge_index_base
+    e_rank = _owner(inv[ei[1]], bt)  # rank whose mesh row an encoder edge feeds
+    need = []
+    for p in range(world):
+        s = torch.unique(ei[0][e_rank == p])
+        need.append(s[g_owner[s] != p])
+    mine = need[rank]
+    mine = mine[torch.argsort(g_owner[mine], stable=True)]  # grouped by the rank that decodes them
+    recv_splits = torch.bincount(g_owner[mine], minlength=world).tolist()
+    send_parts = [torch.searchsorted(dec_dst_ids, need[p][g_owner[need[p]] == rank]) for p in range(world)]
+    grid_halo = HaloExchange(torch.cat(send_parts), [int(t.numel()) for t in send_parts], recv_splits, group)
+    return ShardPlan(rank, world, lo, hi, enc_src_ids, enc, proc, dec_dst_ids, dec, counts, all_ids,
+                     grid_halo_ids=mine, grid_halo=grid_halo)
 
 
-def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=None) -> Tensor:
-    """Full-input / full-output forward with the mesh partitioned over ``group`` (batch size 1, as in the reference)."""
+def gather_output_rows(sp: "ShardPlan", y_local: Tensor, group, grid: int) -> Tensor:
+    """All-gather (padded to the largest shard) of the per-rank output rows, put back into grid order: ``[grid, V_out]``."""
+    v_out = y_local.shape[1]
+    max_rows = max(sp.dec_counts)
+    send = torch.zeros((max_rows, v_out), dtype=torch.float32, device=y_local.device)
+    send[: y_local.shape[0]] = y_local
+    gathered = torch.empty((sp.world * max_rows, v_out), dtype=torch.float32, device=y_local.device)
+    _allgather_rows(gathered, send, group)
+    return gathered.index_select(0, _gather_positions(sp, grid, y_local.device))
+
+
+def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=None, local_output: bool = False):
+    """Full-input / full-output forward with the mesh partitioned over ``group`` (batch size 1, as in the reference).
+
+    ``local_output=True`` (rollout with the state kept sharded, :func:`advance_sharded_state`): the final all-gather is
+    skipped and ``(y_local [rows, V_out] f32 WITHOUT the prognostic residual, shard plan)`` is returned; of ``x`` only
+    the grid rows this rank's encoder and decoder read (``enc_src_ids``, ``dec_dst_ids``) need to be valid."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
         if input_affine is not None or output_affine is not None:
             raise NotImplementedError("input_affine / output_affine belong to the inference interface (predict_step)")
@@ -352,16 +385,9 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
     if isinstance(y_local, tuple):
         y_local = y_local[1]
 
-    # ---- all-gather (padded to the largest shard) and put the rows back into grid order
-    v_out = model.num_output_channels
-    max_rows = max(sp.dec_counts)
-    send = torch.zeros((max_rows, v_out), dtype=torch.float32, device=x.device)
-    send[: y_local.shape[0]] = y_local
-    gathered = torch.empty((sp.world, max_rows, v_out), dtype=torch.float32, device=x.device)
-    _allgather_rows(gathered.view(-1, v_out), send, group)
-    _gather_positions(sp, grid, x.device)
-    y = gathered.view(-1, v_out).index_select(0, sp.gather_pos)
-    y = y.view(1, ensemble_size, grid, v_out)
+    if local_output:
+        return y_local, sp
+    y = gather_output_rows(sp, y_local, group, grid).view(1, ensemble_size, grid, model.num_output_channels)
     return model._finish(y, x, input_affine, output_affine)
 
 
@@ -522,3 +548,46 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
         y_local = training.sequential(dec.node_data_extractor, y_local).float()
         y = _GatherOutput.apply(y_local, sp, group, grid)
         return training._finish(model, y, x, 1, 1, grid)
+
+
+def finish_local_rows(model, x_state: Tensor, y_local: Tensor, sp: ShardPlan) -> Tensor:
+    """Prognostic residual (from the last time slice of this rank's rows of the state) and boundings on the rows this
+    rank decodes: the row-local part of ``AnemoiModelEncProcDec._finish`` (reference :227-231)."""
+    out_idx, in_idx = model._prognostic_indices(x_state.device)
+    own = y_local.float().clone()
+    own[:, out_idx.long()] += x_state[0, -1, 0].index_select(0, sp.dec_dst_ids)[:, in_idx.long()]
+    if len(model.boundings) > 0:
+        plan = model._bounding_plan(x_state.device, None)
+        if plan is None:
+            for bounding in model.boundings:
+                own = bounding(own)
+        else:
+            ops.bound_output(own, *plan[0])
+    return own
+
+
+def sharded_state_output(model, x_state: Tensor, y_local: Tensor, sp: ShardPlan, group) -> Tensor:
+    """The full prediction ``[1, Ens, grid, V_out]`` of a step computed on a sharded state: rows finished locally, then
+    all-gathered (the residual must come from the rank that holds the row's state)."""
+    _, _, ens, grid, _ = x_state.shape
+    return gather_output_rows(sp, finish_local_rows(model, x_state, y_local, sp), group, grid).view(1, ens, grid, -1)
+
+
+def advance_sharded_state(model, x_state: Tensor, y_local: Tensor, sp: ShardPlan, colmap: Tensor,
+                          forcing: Optional[Tensor] = None) -> Tensor:
+    """One autoregressive step on a SHARDED state (no per-step all-gather): ``y_local`` are this rank's
+    decoded grid rows of the NORMALISED prediction without the prognostic residual (``sharded_forward(local_output=True)``).
+    The rows are finished locally (residual, boundings), the rows of other ranks that this rank's encoder reads arrive by
+    ONE all-to-all-v of ``[rows, V_out]`` f32 (the grid halo: a few per cent of the grid instead of all of it), and
+    ``anemoi_advance_input`` shifts the time axis in place.  Afterwards exactly the rows ``enc_src_ids`` /
+    ``dec_dst_ids`` of ``x_state`` are valid on this rank -- all the next ``sharded_forward`` reads."""
+    b, _, ens, grid, _ = x_state.shape
+    v_out = y_local.shape[1]
+    rows = torch.cat([sp.dec_dst_ids, sp.grid_halo_ids])
+    y_rows = torch.empty((rows.shape[0], v_out), dtype=torch.float32, device=x_state.device)
+    n_own = sp.dec_dst_ids.shape[0]
+    y_rows[:n_own].copy_(finish_local_rows(model, x_state, y_local, sp))
+    sp.grid_halo.exchange(y_rows, n_own)  # predictions of the encoder-halo grid rows, from the ranks that decode them
+    y_full = torch.empty((b, ens, grid, v_out), dtype=torch.float32, device=x_state.device)
+    y_full[0, 0].index_copy_(0, rows, y_rows)  # every other row stays unspecified: it is never read on this rank
+    return ops.advance_input(x_state, y_full, colmap, forcing)

@@ -95,7 +95,8 @@ class AnemoiModelInterface(torch.nn.Module):
         cmap[forcing] = -2 - torch.arange(forcing.numel(), dtype=torch.int32)
         return cmap.to(device)
 
-    def rollout(self, batch: torch.Tensor, n_steps: int, forcings: torch.Tensor = None, model_comm_group=None):
+    def rollout(self, batch: torch.Tensor, n_steps: int, forcings: torch.Tensor = None, model_comm_group=None,
+                gather: str = "all"):
         """``n_steps`` autoregressive forecasts from ``batch`` ``[batch, time, grid, input variables]`` (physical
         values).  ``forcings`` ``[n_steps, batch, grid, n_forcing]`` holds the physical forcing inputs valid at each
         step's output time (ordered like ``data_indices.internal_model.input.forcing``); without it the last forcing
@@ -103,7 +104,16 @@ class AnemoiModelInterface(torch.nn.Module):
 
         Not part of the reference repository (which stops at :meth:`predict_step`): the loop follows its caller,
         anemoi-training's ``advance_input``.  The state stays on the device in normalised model space; the time shift
-        and the prognostic / forcing write-back are one in-place HIP kernel (``anemoi_advance_input``)."""
+        and the prognostic / forcing write-back are one in-place HIP kernel (``anemoi_advance_input``).
+
+        With a model communication group, ``gather="last"`` keeps the state SHARDED between the steps: the intermediate
+        forecasts are not all-gathered (each rank holds the grid rows it decodes plus the few its encoder reads, fetched
+        by one small all-to-all-v per step) and only the last step's full prediction is returned, ``[1, batch, 1, grid,
+        output variables]``.  ``gather="all"`` (default) returns every step, each all-gathered as the reference's decoder
+        contract prescribes."""
+        if gather not in ("all", "last"):
+            raise ValueError(f"rollout: gather must be 'all' or 'last', got {gather!r}")
+        keep_sharded = gather == "last" and model_comm_group is not None and model_comm_group.size() > 1
         idx = self.data_indices.internal_model
         x = self.pre_processors(batch, in_place=False)
         assert len(x.shape) == 4, f"The input tensor has an incorrect shape: expected 4 dimensions, got {x.shape}!"
@@ -113,9 +123,19 @@ class AnemoiModelInterface(torch.nn.Module):
         outs = []
         with torch.no_grad():
             for step in range(n_steps):
-                y_hat = self.model(x, model_comm_group) if model_comm_group is not None else self.model(x)
-                outs.append(self.post_processors(y_hat, in_place=False))
-                if step + 1 == n_steps:
+                last = step + 1 == n_steps
+                y_local = None
+                if keep_sharded:
+                    from ..distributed.partition import advance_sharded_state, sharded_forward, sharded_state_output
+
+                    y_local, shard_plan = sharded_forward(self.model, x, model_comm_group, local_output=True)
+                    if last:  # the one all-gather of the rollout
+                        y_hat = sharded_state_output(self.model, x, y_local, shard_plan, model_comm_group).to(x.dtype)
+                        outs.append(self.post_processors(y_hat, in_place=False))
+                else:
+                    y_hat = self.model(x, model_comm_group) if model_comm_group is not None else self.model(x)
+                    outs.append(self.post_processors(y_hat, in_place=False))
+                if last:
                     break
                 f_norm = None
                 if forcings is not None and f_idx.numel() > 0:
@@ -123,5 +143,8 @@ class AnemoiModelInterface(torch.nn.Module):
                     full = x[:, -1, 0].clone()
                     full[..., f_idx] = forcings[step].to(full)
                     f_norm = self.pre_processors(full[:, None], in_place=False)[:, 0][..., f_idx][:, None].contiguous()
-                ops.advance_input(x, y_hat.float().contiguous(), cmap, f_norm)
+                if y_local is not None:
+                    advance_sharded_state(self.model, x, y_local, shard_plan, cmap, f_norm)
+                else:
+                    ops.advance_input(x, y_hat.float().contiguous(), cmap, f_norm)
         return torch.stack(outs)

@@ -322,6 +322,17 @@ def main():
         if cmap is None:
             return forward(x)
         x_state.copy_(x)  # every timed step starts from the same analysis
+        if group is not None:  # BASELINE config 4 on N GPUs: the state stays sharded between the lead times (one small
+            # grid-halo all-to-all-v per step), the forecast is all-gathered once, at the last lead time
+            from anemoi_models_amd.distributed.partition import advance_sharded_state, sharded_forward
+            from anemoi_models_amd.distributed.partition import sharded_state_output
+
+            with torch.no_grad():
+                for lead in range(args.rollout):
+                    y_local, sp = sharded_forward(model, x_state, group, local_output=True)
+                    if lead + 1 < args.rollout:
+                        advance_sharded_state(model, x_state, y_local, sp, cmap)
+                return sharded_state_output(model, x_state, y_local, sp, group)
         for lead in range(args.rollout):
             y = forward(x_state)
             if lead + 1 < args.rollout:

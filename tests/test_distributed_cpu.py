@@ -107,3 +107,55 @@ def test_sharded_forward_other_processors(processor, tmp_path):
     mp.spawn(_worker, args=(world, port, result, processor), nprocs=world, join=True)
     for r in range(world):
         assert torch.load(f"{result}.{r}")["err"] < 1e-4
+
+
+def _rollout_worker(rank, world, port, result_file):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+
+        import _cpu_ops
+        import anemoi_models_amd.ops as ops
+        from anemoi_models_amd.graphs.synthetic import build_graph
+        from test_host_logic import build_interface
+
+        for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
+                     "gt_edge_attention_tiled", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
+                     "prognostic_residual", "finalize_output", "bound_output", "advance_input", "convert_pad", "add",
+                     "act_forward"):
+            setattr(ops, name, getattr(_cpu_ops, name))
+        with np.load(os.path.join(GOLDEN, "interface_gt.npz")) as z:
+            gold = {k: torch.from_numpy(z[k]) for k in z.files}
+        iface = build_interface(build_graph("o32_ico2"), gold)
+        iface.load_state_dict({k[3:]: v for k, v in gold.items() if k.startswith("sd.")})
+        iface.eval()
+        batch, forc = gold["batch"], gold["rollout_forcings"]
+        every = iface.rollout(batch, 3, forc, dist.group.WORLD)                  # all-gather at every step
+        last = iface.rollout(batch, 3, forc, dist.group.WORLD, gather="last")    # state kept sharded, gather at the end
+        sp = [v for k, v in iface.model._idx_cache.items() if k[0] == "shard_plan"][0]
+        torch.save(dict(err_golden=float((every - gold["rollout_y"]).abs().max()), shape_last=tuple(last.shape),
+                        err_last=float((last[0] - every[-1]).abs().max()), scale=float(every.abs().max()),
+                        grid_halo=int(sp.grid_halo_ids.numel()), grid_sent=sum(sp.grid_halo.send_splits),
+                        grid=int(batch.shape[2])), f"{result_file}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rollout_with_the_state_kept_sharded(world, tmp_path):
+    """``rollout(..., gather="last")`` advances the state on each rank's own grid rows plus a small
+    grid halo (one all-to-all-v of predictions per step) and all-gathers only the last forecast: same result as the
+    per-step all-gather route, which itself reproduces the reference-chained golden rollout."""
+    port = 29800 + world + (os.getpid() % 150)
+    result = str(tmp_path / "res")
+    mp.spawn(_rollout_worker, args=(world, port, result), nprocs=world, join=True)
+    infos = [torch.load(f"{result}.{r}") for r in range(world)]
+    for i in infos:
+        assert i["err_golden"] < 2e-3 * i["scale"], i
+        assert i["shape_last"][0] == 1 and i["err_last"] < 1e-5 * i["scale"], i
+        assert 0 < i["grid_halo"] < i["grid"] // 2  # a boundary strip, not the grid
+    assert sum(i["grid_halo"] for i in infos) == sum(i["grid_sent"] for i in infos)
