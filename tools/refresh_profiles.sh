@@ -4,7 +4,7 @@
 # Writes gpurun_out/profiles_<tag>/ (small text/JSON/CSV only); tools/update_profiles.py then copies the
 # summaries into profiles/ (tracked).  PMC passes are separate runs with --kernel-trace only (see MI355X_MICROARCH.md).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -19,6 +19,8 @@ python3 bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/ben
 python3 bench.py --rollout 4 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_cfg4_rollout4_bf16.json" 2>/dev/null
 python3 bench.py --workload cfg2 --processor GNN --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_cfg5_gnn_bf16.json" 2>/dev/null
 python3 bench.py --processor Transformer --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_cfg3_transformer_bf16.json" 2>/dev/null
+python3 bench.py --workload cfg2 --processor Transformer --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_cfg2_transformer_bf16.json" 2>/dev/null
+python3 bench.py --workload cfg2 --steps 20 --warmup 5 > "$OUT/bench_cfg2_bf16_cpu_baseline.json" 2>/dev/null
 
 cd /tmp
 rm -rf /tmp/kt /tmp/pmcf /tmp/pmcw

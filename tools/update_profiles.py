@@ -11,7 +11,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"profiles_{tag}")
 dst = os.path.join(root, "profiles")
@@ -23,6 +23,8 @@ for name, out in [("bench_cfg1_bf16.json", f"{tag}_bench_cfg1_bf16.json"),
                   ("bench_cfg4_rollout4_bf16.json", f"{tag}_bench_cfg4_rollout4_bf16.json"),
                   ("bench_cfg5_gnn_bf16.json", f"{tag}_bench_cfg5_gnn_bf16.json"),
                   ("bench_cfg3_transformer_bf16.json", f"{tag}_bench_cfg3_transformer_bf16.json"),
+                  ("bench_cfg2_transformer_bf16.json", f"{tag}_bench_cfg2_transformer_bf16.json"),
+                  ("bench_cfg2_bf16_cpu_baseline.json", f"{tag}_bench_cfg2_bf16_cpu_baseline.json"),
                   ("kernel_summary_transformer.txt", f"{tag}_bench_cfg3_transformer_summary.txt"),
                   ("pmc_mhsa_mfma_busy.txt", f"{tag}_mhsa_mfma_busy_pmc.txt"),
                   ("kernel_stats.csv", f"{tag}_bench_cfg3_bf16_kernel_stats.csv"),
