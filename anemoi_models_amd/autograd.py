@@ -163,16 +163,16 @@ class _GTEdgeAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, x_r, u, edge_attr, plan, num_heads: int, up: int):
         out = ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, plan.rowptr, plan.col, num_heads, up)
-        ctx.save_for_backward(q, k, v, x_r, u, edge_attr, out)
-        ctx.plan, ctx.h, ctx.up = plan, num_heads, up
+        ctx.save_for_backward(q, k, v, u, edge_attr)  # the backward needs neither the result nor x_r
+        ctx.plan, ctx.h, ctx.up, ctx.has_xr = plan, num_heads, up, x_r is not None
         return out
 
     @staticmethod
     def backward(ctx, dfull):
         from . import _lib
 
-        q, k, v, x_r, u, edge_attr, out = ctx.saved_tensors
-        plan, h, up = ctx.plan, ctx.h, ctx.up
+        q, k, v, u, edge_attr = ctx.saved_tensors
+        plan, h, up, has_xr = ctx.plan, ctx.h, ctx.up, ctx.has_xr
         n_dst, c = q.shape
         d = c // h
         dtype = q.dtype
@@ -184,7 +184,7 @@ class _GTEdgeAttention(torch.autograd.Function):
         dev = q.device
         if n_edges == 0:  # no edges: out = x_r, t = 0 -- only x_r receives a gradient
             return (torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v),
-                    None if x_r is None else dout.contiguous(), torch.zeros_like(u), torch.zeros_like(edge_attr), None,
+                    dout.contiguous() if has_xr else None, torch.zeros_like(u), torch.zeros_like(edge_attr), None,
                     None, None)
         alpha = torch.empty((max(n_edges, 1), h), dtype=torch.float32, device=dev)
         ds = torch.empty((max(n_edges, 1), h), dtype=torch.float32, device=dev)
@@ -198,8 +198,7 @@ class _GTEdgeAttention(torch.autograd.Function):
             raise ValueError("gt_edge_attention: k and v must share their leading dimension (slices of one k|v buffer)")
         st = lib.anemoi_gt_edge_attention_folded_backward_dst(
             code, q.data_ptr(), ops._ld(ops._rows(q)), kk.data_ptr(), vv.data_ptr(), ops._ld(kk), dout.data_ptr(),
-            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), out.data_ptr(), ops._ld(ops._rows(out)),
-            ops._ptr(x_r), 0 if x_r is None else ops._ld(ops._rows(x_r)), edge_attr.data_ptr(), up,
+            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), edge_attr.data_ptr(), up,
             plan.rowptr.data_ptr(), plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(), dq.data_ptr(), c, du.data_ptr(),
             n_dst, c, h, stream)
         _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
@@ -215,7 +214,7 @@ class _GTEdgeAttention(torch.autograd.Function):
         dattr = None
         if ctx.needs_input_grad[5] and n_edges > 0:
             dattr = _edge_attr_grad(alpha, ds, u32, dt, dst_of_edge, n_edges, h, up, d)
-        dxr = None if x_r is None else dout.contiguous()
+        dxr = dout.contiguous() if has_xr else None
         return dq, dk, dv, dxr, du.to(u.dtype), dattr, None, None, None
 
 
@@ -229,7 +228,7 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
         c = (sq.shape[1] - num_heads * up) // 4
         out = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
                                            edge_attr, plan.rowptr, plan.col, num_heads, up)
-        ctx.save_for_backward(sq, edge_attr, out)
+        ctx.save_for_backward(sq, edge_attr)
         ctx.plan, ctx.h, ctx.up, ctx.c = plan, num_heads, up, c
         return out
 
@@ -237,7 +236,7 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
     def backward(ctx, dfull):
         from . import _lib
 
-        sq, edge_attr, out = ctx.saved_tensors
+        sq, edge_attr = ctx.saved_tensors
         plan, h, up, c = ctx.plan, ctx.h, ctx.up, ctx.c
         n, width = sq.shape
         d = c // h
@@ -261,9 +260,8 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
         gbase = dsq.data_ptr()
         st = lib.anemoi_gt_edge_attention_folded_backward_dst(
             code, base + c * esz, width, base + 2 * c * esz, base + 3 * c * esz, width, dout.data_ptr(),
-            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), out.data_ptr(), ops._ld(ops._rows(out)), base, width,
-            edge_attr.data_ptr(), up, plan.rowptr.data_ptr(), plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(),
-            gbase + c * esz, width, du.data_ptr(), n, c, h, stream)
+            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), edge_attr.data_ptr(), up, plan.rowptr.data_ptr(),
+            plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(), gbase + c * esz, width, du.data_ptr(), n, c, h, stream)
         _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
         rowptr_t, eid_t, dst_t, dst_of_edge = _transposed_csr(plan)
         st = lib.anemoi_gt_edge_attention_folded_backward_src(

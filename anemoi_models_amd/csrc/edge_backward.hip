@@ -3,13 +3,15 @@
 // Forward, per destination i, head h, in-edge e = (j -> i) with attributes a_e (constant-1 column included):
 //     s_e   = scale (q_i,h . k_j,h + u_i,h . a_e),   alpha_e = softmax_e(s_e),
 //     out_i,h = sum_e alpha_e v_j,h (+ x_r),         t_i,h = sum_e alpha_e a_e.
-// Backward, given dout (w.r.t. out) and dt (w.r.t. t) and Dsum_i,h = sum_e alpha_e dalpha_e
-// (= dout_i,h . (out_i,h - x_r) + dt_i,h . t_i,h, formed by the caller from the forward's result):
+// Backward, given dout (w.r.t. out) and dt (w.r.t. t), with Dsum_i,h = sum_e alpha_e dalpha_e accumulated in f32 over the
+// in-edges (NOT rebuilt from the forward's rounded `out - x_r`: in bf16 that difference cancels against the residual):
 //     dalpha_e = dout_i,h . v_j,h + dt_i,h . a_e,      ds_e = alpha_e (dalpha_e - Dsum_i,h),
 //     dq_i,h = scale sum_e ds_e k_j,h,   du_i,h = scale sum_e ds_e a_e,
 //     dk_j,h = scale sum_{e from j} ds_e q_i,h,   dv_j,h = sum_{e from j} alpha_e dout_i,h.
 // Two kernels, no atomics:
-//   * destination-major (the forward's CSR): two sweeps over the in-edges (max / sum of the scores, then alpha and ds),
+//   * destination-major (the forward's CSR): two sweeps over the in-edges (max / sum of the scores, then alpha, dalpha and
+//     the sums  A = sum alpha dalpha k,  B = sum alpha k,  Dsum  -- so that dq = scale (A - Dsum B), likewise du) and a
+//     third pass over the wave's own alpha / ds entries only (ds_e = alpha_e dalpha_e - alpha_e Dsum);
 //     writes alpha[E, H], ds[E, H] (f32), dq, du;
 //   * source-major (the transposed CSR, edge ids into the forward's order): dk, dv as gathers of q_i / dout_i.
 // One wave per (node, 64 x VEC channel slice), a lane owns VEC consecutive channels, LPH = D / VEC lanes form a head.
@@ -24,8 +26,6 @@ struct EdgeBwdParams {
   const void* dout;  // [n_dst, ldd]
   const float* u;    // [n_dst, H * UP] f32
   const float* dt;   // [n_dst, H * UP] f32
-  const void* out;   // [n_dst, ldout] forward result: out (+ x_r) | t (H * UP columns behind the C channels)
-  const void* xr;    // [n_dst, ldxr] or null
   const float* attr; // [E, UP] f32, forward CSR order
   const int32_t* rowptr;
   const int32_t* col;
@@ -33,7 +33,7 @@ struct EdgeBwdParams {
   float* ds;         // [E, H]
   void* dq;          // [n_dst, lddq]
   float* du;         // [n_dst, H * UP]
-  int64_t ldq, ldkv, ldd, lddq, ldout, ldxr;
+  int64_t ldq, ldkv, ldd, lddq;
   int64_t n_dst;
   int C, H, n_slices;
   float scale;
@@ -66,24 +66,6 @@ __global__ __launch_bounds__(256) void gt_edge_bwd_dst_kernel(const EdgeBwdParam
       uf[a] = p.u[(node * p.H + head) * UP + a];
       dtf[a] = p.dt[(node * p.H + head) * UP + a];
     }
-    // Dsum_i,h = sum_e alpha_e dalpha_e = dout_i,h . (out_i,h - x_r) + dt_i,h . t_i,h, from the forward's result
-    float dsum = 0.f;
-    {
-      float of[VEC];
-      VecIO<T, VEC>::load(static_cast<const T*>(p.out) + node * p.ldout + c0, of);
-      if (p.xr != nullptr) {
-        float xf[VEC];
-        VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + node * p.ldxr + c0, xf);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) of[i] -= xf[i];
-      }
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) dsum = fmaf(dof[i], of[i], dsum);
-      dsum = head_sum<LPH>(dsum);
-      const T* tp = static_cast<const T*>(p.out) + node * p.ldout + p.C + head * UP;
-#pragma unroll
-      for (int a = 0; a < UP; ++a) dsum = fmaf(dtf[a], Elem<T>::load(tp + a), dsum);
-    }
     const int e_begin = p.rowptr[node], e_end = p.rowptr[node + 1];
     // ---- sweep 1: running maximum and sum of the scores (as the forward)
     float m = -INFINITY, l = 0.f;
@@ -103,12 +85,12 @@ __global__ __launch_bounds__(256) void gt_edge_bwd_dst_kernel(const EdgeBwdParam
       m = mn;
     }
     const float inv_l = 1.0f / (l + 1e-16f);
-    // ---- sweep 2: alpha, ds and the destination-side gradients
-    float dq[VEC], du[UP];
+    // ---- sweep 2: alpha, dalpha and the alpha-weighted sums the destination-side gradients are made of
+    float ak[VEC], bk[VEC], au[UP], bu[UP], dsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) dq[i] = 0.f;
+    for (int i = 0; i < VEC; ++i) ak[i] = bk[i] = 0.f;
 #pragma unroll
-    for (int a = 0; a < UP; ++a) du[a] = 0.f;
+    for (int a = 0; a < UP; ++a) au[a] = bu[a] = 0.f;
     for (int e = e_begin; e < e_end; ++e) {
       const int64_t j = p.col[e];
       float kf[VEC], vf[VEC], af[UP];
@@ -130,22 +112,35 @@ __global__ __launch_bounds__(256) void gt_edge_bwd_dst_kernel(const EdgeBwdParam
         da = fmaf(dtf[a], af[a], da);
       }
       const float alpha = __expf(s * p.scale - m) * inv_l;
-      const float dse = alpha * (da - dsum);
+      const float w = alpha * da;
+      dsum += w;
       if (writer) {
         p.alpha[(int64_t)e * p.H + head] = alpha;
-        p.ds[(int64_t)e * p.H + head] = dse;
+        p.ds[(int64_t)e * p.H + head] = w;  // finished below, once Dsum is known
       }
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) dq[i] = fmaf(dse, kf[i], dq[i]);
+      for (int i = 0; i < VEC; ++i) {
+        ak[i] = fmaf(w, kf[i], ak[i]);
+        bk[i] = fmaf(alpha, kf[i], bk[i]);
+      }
 #pragma unroll
-      for (int a = 0; a < UP; ++a) du[a] = fmaf(dse, af[a], du[a]);
+      for (int a = 0; a < UP; ++a) {
+        au[a] = fmaf(w, af[a], au[a]);
+        bu[a] = fmaf(alpha, af[a], bu[a]);
+      }
     }
+    float dq[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) dq[i] *= p.scale;
+    for (int i = 0; i < VEC; ++i) dq[i] = (ak[i] - dsum * bk[i]) * p.scale;
     if (active) VecIO<T, VEC>::store(static_cast<T*>(p.dq) + node * p.lddq + c0, dq);
     if (writer) {
 #pragma unroll
-      for (int a = 0; a < UP; ++a) p.du[(node * p.H + head) * UP + a] = du[a] * p.scale;
+      for (int a = 0; a < UP; ++a) p.du[(node * p.H + head) * UP + a] = (au[a] - dsum * bu[a]) * p.scale;
+      // ---- pass 3: ds_e = alpha_e (dalpha_e - Dsum) on this lane's own entries (same thread wrote them above)
+      for (int e = e_begin; e < e_end; ++e) {
+        const int64_t o = (int64_t)e * p.H + head;
+        p.ds[o] = fmaf(-dsum, p.alpha[o], p.ds[o]);
+      }
     }
   }
 }
@@ -281,25 +276,22 @@ extern "C" {
 
 int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
                                                  int64_t ldkv, const void* dout, int64_t ldd, const float* u,
-                                                 const float* dt, const void* out, int64_t ldout, const void* x_r,
-                                                 int64_t ldxr, const float* edge_attr, int up,
+                                                 const float* dt, const float* edge_attr, int up,
                                                  const int32_t* rowptr, const int32_t* col, float* alpha, float* ds,
                                                  void* dq, int64_t lddq, float* du, int64_t n_dst, int C, int H,
                                                  anemoi_stream_t stream) {
-  ANEMOI_REQUIRE(q && k && v && dout && u && dt && out && edge_attr && rowptr && col && alpha && ds && dq && du,
+  ANEMOI_REQUIRE(q && k && v && dout && u && dt && edge_attr && rowptr && col && alpha && ds && dq && du,
                  ANEMOI_ERR_INVALID, "anemoi_gt_edge_attention_folded_backward_dst: null pointer");
   ANEMOI_REQUIRE(n_dst >= 0 && C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
                  "anemoi_gt_edge_attention_folded_backward_dst: bad shape");
   if (n_dst == 0) return ANEMOI_OK;
   const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
   ANEMOI_REQUIRE(ldq % vec == 0 && ldkv % vec == 0 && ldd % vec == 0 && lddq % vec == 0 && C % vec == 0 &&
-                     ldout % vec == 0 && (x_r == nullptr || (ldxr % vec == 0 && (uintptr_t)x_r % 16 == 0)) &&
                      (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
-                     (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 16 == 0 && (uintptr_t)out % 16 == 0,
+                     (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 16 == 0,
                  ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_folded_backward_dst: operands must be 16-byte aligned");
   EdgeBwdParams p;
-  p.q = q; p.k = k; p.v = v; p.dout = dout; p.u = u; p.dt = dt; p.out = out; p.xr = x_r; p.attr = edge_attr;
-  p.ldout = ldout; p.ldxr = ldxr;
+  p.q = q; p.k = k; p.v = v; p.dout = dout; p.u = u; p.dt = dt; p.attr = edge_attr;
   p.rowptr = rowptr; p.col = col; p.alpha = alpha; p.ds = ds; p.dq = dq; p.du = du;
   p.ldq = ldq; p.ldkv = ldkv; p.ldd = ldd; p.lddq = lddq; p.n_dst = n_dst; p.C = C; p.H = H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);

@@ -364,12 +364,19 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
     order, _ = model._mesh_order(x.device)
     own_ids = order[sp.lo:sp.hi]
 
+    # [x | coordinates | trainable | 1 | 0-pad] as in the single-device forward (the constant 1 carries the embedding bias
+    # of the GraphTransformer mappers' embedding fold; every rank assembles the full grid and selects its rows)
+    fold = runtime.embed_fold_enabled(dtype) and not gnn_maps
     width = model.multi_step * model.num_input_channels + na.attr_ndims[data]
-    x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, 1, dtype,
-                                ld_out=ops.round_up(width, kmult), in_affine=input_affine)
+    x_data = ops.assemble_nodes(x, na.latlons(data), model._with_ones(na.trainable_tensors[data].trainable, grid, fold),
+                                1, dtype, ld_out=model._feature_ld(width + int(fold), dtype), in_affine=input_affine)
     tr_hidden = na.trainable_tensors[hidden].trainable
-    x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[own_ids], None if tr_hidden is None else tr_hidden[own_ids],
-                                  1, dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
+    w_hidden = na.attr_ndims[hidden]
+    x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[own_ids],
+                                  model._with_ones(None if tr_hidden is None else tr_hidden[own_ids], own_ids.numel(), fold,
+                                                   device=x.device),
+                                  1, dtype, ld_out=model._feature_ld(w_hidden + int(fold), dtype))
+    one_data, one_hidden = (width, w_hidden) if fold else (None, None)
 
     if gnn_maps:
         # GNN mappers hand the UPDATED grid embedding on to the decoder (reference layers/mapper.py:522): the rows this
@@ -377,11 +384,16 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
         x_dec_dst, x_latent = model.encoder.native_local(x_data.index_select(0, sp.enc_src_ids), x_hidden, sp.enc,
                                                          x_src_extra=x_data.index_select(0, sp.dec_dst_ids))
     else:
-        x_latent = model.encoder.native_local(x_data.index_select(0, sp.enc_src_ids), x_hidden, sp.enc)
+        x_latent = model.encoder.native_local(x_data.index_select(0, sp.enc_src_ids), x_hidden, sp.enc,
+                                              one_cols=(one_data, one_hidden))
         x_dec_dst = x_data.index_select(0, sp.dec_dst_ids)
     x_proc = model.processor.native_local(x_latent, sp.proc)
     x_latent_proc = ops.add(x_proc, x_latent)
-    y_local = model.decoder.native_local(x_latent_proc, x_dec_dst, sp.dec, out_dtype=torch.float32)
+    if gnn_maps:
+        y_local = model.decoder.native_local(x_latent_proc, x_dec_dst, sp.dec, out_dtype=torch.float32)
+    else:
+        y_local = model.decoder.native_local(x_latent_proc, x_dec_dst, sp.dec, out_dtype=torch.float32,
+                                             one_cols=(None, one_data))
     if isinstance(y_local, tuple):
         y_local = y_local[1]
 

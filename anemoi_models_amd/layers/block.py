@@ -64,6 +64,42 @@ def folded_edge_phase(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
     return ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, plan.col, num_heads, up,
                                         ld_out=ld_out)
 
+class EmbeddedRows:
+    """Node rows ``h = emb(x)`` handed to a mapper block as the raw features they are embedded from.
+
+    ``x_aug = [x | 1 | 0-pad]`` (the constant-1 column ``one_col`` sits in the K padding and carries the embedding's bias),
+    ``emb`` the mapper's ``nn.Linear``.  The block's ``LayerNorm -> Linear`` on these rows then runs as ONE narrow GEMM
+    on ``x_aug`` (``runtime.fold_embedded_layer_norm``) instead of a K = C GEMM on ``h``.  ``h`` itself is present only
+    when something else needs it (the destination rows: residual of the projection); for source rows that only feed
+    k | v it is never formed, and the LayerNorm's row statistics come from a [rows, 256] side product
+    (``runtime.embedding_stats_operator``)."""
+
+    def __init__(self, x_aug: Tensor, one_col: int, emb: nn.Linear, h: Optional[Tensor], packed, tag: str) -> None:
+        self.x_aug, self.one_col, self.emb, self.h, self._packed, self._tag = x_aug, one_col, emb, h, packed, tag
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.x_aug.dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self.x_aug.device
+
+    @property
+    def shape(self):
+        return (self.x_aug.shape[0], self.emb.out_features)
+
+    def stats(self, eps: float) -> Tensor:
+        """``{rstd, -mean rstd}`` per row of ``LayerNorm(h)`` (only ``rstd`` is used by the folded product)."""
+        if self.h is not None:
+            return ops.row_stats(self.h, eps)  # carried by the embedding GEMM's epilogue
+        kp = self.x_aug.shape[1]
+        t = self._packed.get((self._tag, "embstats", self.dtype, kp, self.one_col), [self.emb.weight, self.emb.bias],
+                             lambda: runtime.embedding_stats_operator(self.emb.weight, self.emb.bias, kp, self.one_col,
+                                                                      self.dtype))
+        return ops.row_stats(ops.linear(self.x_aug, t, None, stats_eps=eps), eps)
+
+
 class BaseBlock(nn.Module, ABC):
     """Base class for network blocks."""
 
@@ -135,6 +171,8 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
     @staticmethod
     def _ln_begin(ln: nn.LayerNorm, x: Tensor):
         """Handle of ``LayerNorm(x)`` for ``_ln_linear``: ``(x, stats, ln)`` when folding, else ``(LN(x), None, None)``."""
+        if isinstance(x, EmbeddedRows):
+            return x, x.stats(ln.eps), ln
         if runtime.ln_fold_enabled(x.dtype):
             return x, ops.row_stats(x, ln.eps), ln
         return ops.layer_norm(x, runtime.f32c(ln.weight), runtime.f32c(ln.bias), ln.eps), None, None
@@ -143,6 +181,15 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         """``Linear(LayerNorm(x))``.  ``plain()`` -> packed ``(w, b)`` of the unfolded route; ``rows()`` -> f32
         ``(weight rows [N, K], bias [N] or None)`` that the fold scales by the LayerNorm weight (cached per dtype)."""
         xin, stats, ln = handle
+        if isinstance(xin, EmbeddedRows):
+            # embedding -> LayerNorm -> Linear as one product on the raw features (K = padded feature count, not C)
+            xa = xin.x_aug
+            wf, bf, zero = self._packed.get(
+                (tag, "embfold", xa.dtype, xa.shape[1], xin.one_col, xin._tag),
+                list(params) + [ln.weight, ln.bias, xin.emb.weight, xin.emb.bias],
+                lambda: runtime.fold_embedded_layer_norm(*rows(), ln.weight, ln.bias, xin.emb.weight, xin.emb.bias,
+                                                         xa.shape[1], xin.one_col, xa.dtype))
+            return ops.linear(xa, wf, bf, ln=(stats, zero), **kw)
         if stats is None:
             w, b = plain()
             return ops.linear(xin, w, b, **kw)
@@ -388,6 +435,10 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         dtype = x_dst.dtype
         self._check_channels(dtype)
         c = self.num_heads * self.out_channels_conv
+        # EmbeddedRows (mappers): the rows arrive as the raw features they are embedded from; ``h_dst`` is materialised
+        h_dst = x_dst.h if isinstance(x_dst, EmbeddedRows) else x_dst
+        if isinstance(x_src, EmbeddedRows) and x_src.h is None and self.update_src_nodes:
+            raise ValueError("update_src_nodes needs the embedded source rows")
         kv_layers, sq_layers = [self.lin_key, self.lin_value], [self.lin_self, self.lin_query]
         kv_args = ("kv", lambda: self._cat_linear("kv", kv_layers, dtype), lambda: self._cat_rows(kv_layers),
                    [l.weight for l in kv_layers] + [l.bias for l in kv_layers])
@@ -424,10 +475,12 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
             att = self.conv.fused(sq[:, c:], kv[:, :c], kv[:, c:], sq[:, :c], edge_attr_csr, self.edge_dim, we, be,
                                   plan, self.num_heads)
         del sq, kv
-        y = ops.linear(att, wp, bp, residual=x_dst,
+        y = ops.linear(att, wp, bp, residual=h_dst,
                        stats_eps=self._mlp_ln_eps("dst", dtype) if num_chunks <= 1 else None)
         del att
         new_dst = self._node_mlp(y, "dst", num_chunks, out_stats_eps=out_stats_eps)
+        if isinstance(x_src, EmbeddedRows):
+            x_src = x_src.h
         new_src = self._node_mlp(x_src, "src", num_chunks) if self.update_src_nodes else x_src
         return new_src, new_dst
 

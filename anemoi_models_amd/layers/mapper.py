@@ -19,6 +19,7 @@ from torch import nn
 from .. import ops
 from .. import runtime
 from .. import training
+from .block import EmbeddedRows
 from .block import GraphConvMapperBlock
 from .block import GraphTransformerMapperBlock
 from .block import inference_num_chunks
@@ -94,8 +95,27 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         self._plans = runtime.PlanCache()
 
     # ---- hooks specialised by the forward / backward mapper ------------------------------------
-    def _embed(self, x_src: Tensor, x_dst: Tensor):
+    def _embed(self, x_src: Tensor, x_dst: Tensor, one_cols=(None, None)):
         raise NotImplementedError
+
+    def _embedded(self, tag: str, lin: nn.Linear, x: Tensor, eps: Optional[float], one_col: Optional[int],
+                  materialise: bool):
+        """``lin(x)`` for the block -- as an ``EmbeddedRows`` handle when the block's LayerNorm -> Linear on these rows can
+        run on the raw features instead (few input features, bf16 LayerNorm-fold path): ``x`` with a constant-1 column
+        in its K padding (``one_col``: the caller already wrote it; None: an augmented copy is made here)."""
+        k_in = lin.in_features
+        if eps is None or not runtime.embed_fold_enabled(x.dtype) or 2 * (k_in + 1) > lin.out_features:
+            return linear_native(self._packed, tag, lin, x, stats_eps=eps)
+        if one_col is None:
+            kp = ops.round_up(k_in + 1, ops.k_multiple(x.dtype))
+            xa = torch.zeros((x.shape[0], kp), dtype=x.dtype, device=x.device)
+            xa[:, :k_in].copy_(x[:, :k_in])
+            xa[:, k_in].fill_(1.0)
+            x, one_col = xa, k_in
+        elif not (k_in <= one_col < x.shape[1]):
+            raise ValueError(f"{tag}: constant-1 column {one_col} outside the K padding [{k_in}, {x.shape[1]})")
+        h = linear_native(self._packed, tag, lin, x, stats_eps=eps) if materialise else None
+        return EmbeddedRows(x, one_col, lin, h, self._packed, tag)
 
     def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
         return x_dst
@@ -114,25 +134,27 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         return None
 
     def native(self, x_src: Tensor, x_dst: Tensor, batch_size: int, out_dtype: Optional[torch.dtype] = None,
-               src_map: Optional[Tensor] = None, dst_map: Optional[Tensor] = None) -> Tensor:
+               src_map: Optional[Tensor] = None, dst_map: Optional[Tensor] = None, one_cols=(None, None)) -> Tensor:
         """Inputs in the compute dtype (optionally K padded).  Returns the mapped destination nodes.
 
         ``src_map`` / ``dst_map``: optional external-id -> row relabelling when the caller keeps a node set in an
-        internal order (the model root does this for the mesh)."""
+        internal order (the model root does this for the mesh).  ``one_cols = (src, dst)``: column of ``x_src`` /
+        ``x_dst`` (inside the K padding) that already holds a constant 1 (``_embedded``), or None."""
         n_src, n_dst = x_src.shape[0], x_dst.shape[0]
         plan = self._plans.get(self.edge_index_base, n_src, n_dst, batch_size, self.edge_inc, src_map, dst_map)
         ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
-        h_src, h_dst = self._embed(x_src, x_dst)
+        h_src, h_dst = self._embed(x_src, x_dst, one_cols)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
         _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, out_stats_eps=self._extract_ln_eps(h_dst.dtype))
         return self._extract(h_dst, out_dtype)
 
-    def native_local(self, x_src: Tensor, x_dst: Tensor, local_graph, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    def native_local(self, x_src: Tensor, x_dst: Tensor, local_graph, out_dtype: Optional[torch.dtype] = None,
+                     one_cols=(None, None)) -> Tensor:
         """Node-partitioned run (``distributed/partition.py``): local source / destination rows and a local CSR plan
         whose ``perm`` holds original edge ids; halo source rows (decoder) arrive by all-to-all-v inside the block."""
         plan = local_graph.plan
         ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
-        h_src, h_dst = self._embed(x_src, x_dst)
+        h_src, h_dst = self._embed(x_src, x_dst, one_cols)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
         _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, local_graph.halo,
                                     out_stats_eps=self._extract_ln_eps(h_dst.dtype))
@@ -172,10 +194,12 @@ class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
                          src_grid_size=src_grid_size, dst_grid_size=dst_grid_size)
         self.emb_nodes_src = nn.Linear(self.in_channels_src, self.hidden_dim)
 
-    def _embed(self, x_src: Tensor, x_dst: Tensor):
+    def _embed(self, x_src: Tensor, x_dst: Tensor, one_cols=(None, None)):
         eps1, eps2 = self._block_ln_eps(x_src.dtype)  # the embeddings enter the block's layer_norm1 / layer_norm2
-        return (linear_native(self._packed, "emb_nodes_src", self.emb_nodes_src, x_src, stats_eps=eps1),
-                linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst, stats_eps=eps2))
+        # source rows feed k | v only: their embedding is never written out when it can be folded away
+        return (self._embedded("emb_nodes_src", self.emb_nodes_src, x_src, eps1, one_cols[0],
+                               materialise=self.proc.update_src_nodes),
+                self._embedded("emb_nodes_dst", self.emb_nodes_dst, x_dst, eps2, one_cols[1], materialise=True))
 
     def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None):
         x_dst = self._run(x, batch_size, shard_shapes, model_comm_group)
@@ -198,9 +222,9 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
         self.node_data_extractor = nn.Sequential(nn.LayerNorm(self.hidden_dim),
                                                  nn.Linear(self.hidden_dim, self.out_channels_dst))
 
-    def _embed(self, x_src: Tensor, x_dst: Tensor):
-        return x_src, linear_native(self._packed, "emb_nodes_dst", self.emb_nodes_dst, x_dst,
-                                    stats_eps=self._block_ln_eps(x_dst.dtype)[1])
+    def _embed(self, x_src: Tensor, x_dst: Tensor, one_cols=(None, None)):
+        return x_src, self._embedded("emb_nodes_dst", self.emb_nodes_dst, x_dst, self._block_ln_eps(x_dst.dtype)[1],
+                                     one_cols[1], materialise=True)
 
     def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
         ln, lin = self.node_data_extractor[0], self.node_data_extractor[1]

@@ -152,6 +152,10 @@ def linear_native(cache: runtime.PackedWeights, tag: str, lin: nn.Linear, x: Ten
     dtype = x.dtype
     w = cache.get((tag, "w", dtype), [lin.weight], lambda: runtime.pack_weight([lin.weight], dtype))
     b = None if lin.bias is None else runtime.f32c(lin.bias)
+    if x.shape[1] > w.shape[1] and x.shape[1] % ops.k_multiple(dtype) == 0:
+        # wider K padding than the weight needs (the columns behind in_features meet zero weights whatever they hold)
+        kp = x.shape[1]
+        w = cache.get((tag, "w", dtype, kp), [lin.weight], lambda: runtime.pack_weight([lin.weight], dtype, k_pad=kp))
     if x.shape[1] != w.shape[1]:
         if x.shape[1] != lin.in_features:
             raise ValueError(f"{tag}: input has {x.shape[1]} features, expected {lin.in_features}")

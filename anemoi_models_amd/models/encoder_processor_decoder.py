@@ -131,6 +131,33 @@ class AnemoiModelEncProcDec(nn.Module):
             self._idx_cache[key] = (order, runtime.inverse_permutation(order))
         return self._idx_cache[key]
 
+    def _with_ones(self, trainable: Optional[Tensor], n_nodes: int, enabled: bool, device=None) -> Optional[Tensor]:
+        """The per-node trainable columns with a constant-1 column appended (``assemble_nodes`` writes them behind the
+        coordinates): the bias carrier of the mappers' embedding fold."""
+        if not enabled:
+            return trainable
+        device = trainable.device if trainable is not None else (device or self.node_attributes.latlons(
+            self._graph_name_data).device)
+        key = ("ones", n_nodes, str(device))
+        if key not in self._idx_cache:
+            self._idx_cache[key] = torch.ones((n_nodes, 1), dtype=torch.float32, device=device)
+        ones = self._idx_cache[key]
+        return ones if trainable is None else torch.cat([trainable.detach().float(), ones], dim=1)
+
+    @staticmethod
+    def _feature_ld(width: int, dtype: torch.dtype) -> int:
+        """Row pitch of an assembled feature matrix: the K-slab multiple, and for bf16 at least two slabs (the
+        persistent MFMA kernel takes K >= 128; one slab of zero columns is cheaper than the generic kernel)."""
+        ld = ops.round_up(width, ops.k_multiple(dtype))
+        return max(ld, 128) if dtype == torch.bfloat16 else ld
+
+    @staticmethod
+    def _one_cols(mapper, src: Optional[int], dst: Optional[int]) -> dict:
+        """``one_cols`` keyword of the GraphTransformer mappers' ``native`` (other mapper families do not take it)."""
+        from ..layers.mapper import GraphTransformerBaseMapper
+
+        return {"one_cols": (src, dst)} if isinstance(mapper, GraphTransformerBaseMapper) else {}
+
     def _finish(self, y: Tensor, x: Tensor, input_affine=None, output_affine=None) -> Tensor:
         """Prognostic residual, boundings, optional de-normalisation (reference :223-233 + the interface's
         post-processor when it is a plain InputNormalizer)."""
@@ -216,24 +243,33 @@ class AnemoiModelEncProcDec(nn.Module):
         data, hidden = self._graph_name_data, self._graph_name_hidden
         na = self.node_attributes
 
-        # [x (time-major) | sin/cos latlon | trainable | 0-pad]: written once, straight into the GEMM input layout
+        # [x (time-major) | sin/cos latlon | trainable | 1 | 0-pad]: written once, straight into the GEMM input layout.
+        # The constant 1 in the first padding column carries the embedding bias when a GraphTransformer mapper folds
+        # its embedding into the block's first GEMMs (layers/mapper.py::_embedded); zero weights meet it otherwise.
         width = self.multi_step * self.num_input_channels + na.attr_ndims[data]
-        x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, batch_size, dtype,
-                                    ld_out=ops.round_up(width, kmult), in_affine=input_affine)
+        fold = runtime.embed_fold_enabled(dtype)
+        tr_data = na.trainable_tensors[data].trainable
+        x_data = ops.assemble_nodes(x, na.latlons(data), self._with_ones(tr_data, grid, fold), batch_size, dtype,
+                                    ld_out=self._feature_ld(width + int(fold), dtype), in_affine=input_affine)
         # mesh rows live in an internal Morton order (gather locality of the edge kernels); only the tiny
         # per-node attribute tables are permuted, the mesh never leaves the model
         order, inv = self._mesh_order(x.device)
         tr_hidden = na.trainable_tensors[hidden].trainable
-        x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[order], None if tr_hidden is None else tr_hidden[order],
-                                      batch_size, dtype, ld_out=ops.round_up(na.attr_ndims[hidden], kmult))
+        w_hidden = na.attr_ndims[hidden]
+        x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[order],
+                                      self._with_ones(None if tr_hidden is None else tr_hidden[order], order.numel(), fold),
+                                      batch_size, dtype, ld_out=self._feature_ld(w_hidden + int(fold), dtype))
+        one_data, one_hidden = (width, w_hidden) if fold else (None, None)
 
-        enc = self.encoder.native(x_data, x_hidden, batch_size, dst_map=inv)
+        enc = self.encoder.native(x_data, x_hidden, batch_size, dst_map=inv,
+                                  **self._one_cols(self.encoder, one_data, one_hidden))
         # GraphTransformer forward mapper hands the RAW data input on to the decoder (reference layers/mapper.py:345);
         # the GNN forward mapper hands on its UPDATED source embedding (reference layers/mapper.py:522)
         x_data_latent, x_latent = (x_data, enc) if not isinstance(enc, tuple) else enc
         x_proc = self.processor.native(x_latent, batch_size, node_map=inv)
         x_latent_proc = ops.add(x_proc, x_latent)
-        y = self.decoder.native(x_latent_proc, x_data_latent, batch_size, out_dtype=torch.float32, src_map=inv)
+        y = self.decoder.native(x_latent_proc, x_data_latent, batch_size, out_dtype=torch.float32, src_map=inv,
+                                **self._one_cols(self.decoder, None, one_data if x_data_latent is x_data else None))
         if isinstance(y, tuple):
             y = y[1]
 

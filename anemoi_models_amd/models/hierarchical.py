@@ -127,9 +127,12 @@ class AnemoiModelEncProcDecHierarchical(AnemoiModelEncProcDec):
         kmult = ops.k_multiple(dtype)
         data, names, na = self._graph_name_data, self._graph_hidden_names, self.node_attributes
 
+        # [x | coordinates | trainable | 1 | 0-pad]: the constant 1 serves the mappers' embedding fold (see the flat model)
         width = self.multi_step * self.num_input_channels + na.attr_ndims[data]
-        x_data = ops.assemble_nodes(x, na.latlons(data), na.trainable_tensors[data].trainable, batch_size, dtype,
-                                    ld_out=ops.round_up(width, kmult))
+        fold = runtime.embed_fold_enabled(dtype)
+        x_data = ops.assemble_nodes(x, na.latlons(data), self._with_ones(na.trainable_tensors[data].trainable, grid, fold),
+                                    batch_size, dtype, ld_out=self._feature_ld(width + int(fold), dtype))
+        one_data = width if fold else None
         x_hidden = {
             h: ops.assemble_nodes(None, na.latlons(h), na.trainable_tensors[h].trainable, batch_size, dtype,
                                   ld_out=ops.round_up(na.attr_ndims[h], kmult))
@@ -139,7 +142,8 @@ class AnemoiModelEncProcDecHierarchical(AnemoiModelEncProcDec):
         def first(out):  # GraphTransformer mappers return the destination nodes; GNN mappers (src, dst)
             return out[1] if isinstance(out, tuple) else out
 
-        curr = first(self.encoder.native(x_data, x_hidden[names[0]], batch_size))
+        curr = first(self.encoder.native(x_data, x_hidden[names[0]], batch_size,
+                                         **self._one_cols(self.encoder, one_data, None)))
         x_skip, x_encoded = {}, {}
         for src, dst in zip(names[:-1], names[1:]):  # ---- down (reference :224-249)
             if self.level_process:
@@ -157,6 +161,7 @@ class AnemoiModelEncProcDecHierarchical(AnemoiModelEncProcDec):
             if self.level_process:
                 curr = self.up_level_processor[dst].native(curr, batch_size)
 
-        y = first(self.decoder.native(curr, x_data, batch_size, out_dtype=torch.float32))
+        y = first(self.decoder.native(curr, x_data, batch_size, out_dtype=torch.float32,
+                                      **self._one_cols(self.decoder, None, one_data)))
         y = y.view(batch_size, ensemble_size, grid, self.num_output_channels)
         return self._finish(y, x)  # prognostic residual + boundings (reference models/hierarchical.py:300-308)

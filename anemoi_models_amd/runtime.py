@@ -363,11 +363,12 @@ class PackedWeights:
         self._store.clear()
 
 
-def pack_weight(weights: Sequence[Tensor], dtype: torch.dtype) -> Tensor:
-    """``cat(weights, 0)`` as ``[N, K_pad]`` in ``dtype`` with K zero padded to the kernel's K-slab multiple."""
+def pack_weight(weights: Sequence[Tensor], dtype: torch.dtype, k_pad: Optional[int] = None) -> Tensor:
+    """``cat(weights, 0)`` as ``[N, K_pad]`` in ``dtype`` with K zero padded to the kernel's K-slab multiple (or to
+    ``k_pad`` columns when the activation carries more padding than that)."""
     w = torch.cat([t.detach() for t in weights], dim=0) if len(weights) > 1 else weights[0].detach()
     k = w.shape[1]
-    kp = ops.round_up(k, ops.k_multiple(dtype))
+    kp = ops.round_up(k, ops.k_multiple(dtype)) if k_pad is None else k_pad
     out = torch.zeros((w.shape[0], kp), dtype=dtype, device=w.device)
     out[:, :k] = w.to(dtype)
     return out
@@ -406,6 +407,67 @@ def fold_layer_norm(w_rows: Tensor, bias: Optional[Tensor], gamma: Tensor, beta:
     if bias is not None:
         b = b + bias.detach().float()
     return wp, b.contiguous(), colsum
+
+
+def embed_fold_enabled(dtype: torch.dtype) -> bool:
+    """Embedding -> LayerNorm -> Linear chains of the mappers run as ONE narrow GEMM on the raw node features
+    (``fold_embedded_layer_norm``; bf16 LayerNorm-fold path only; ``ANEMOI_AMD_EMBED_FOLD=0`` disables)."""
+    return ln_fold_enabled(dtype) and os.environ.get("ANEMOI_AMD_EMBED_FOLD", "1") != "0"
+
+
+def _centered_embedding(emb_w: Tensor, emb_b: Optional[Tensor]):
+    """``(E_c [C, K], b_c [C])`` in f64 with the mean over the C output channels removed: for h = E x + b,
+    ``h - mean_c(h) = E_c x + b_c`` exactly -- the LayerNorm's mean subtraction moved into the parameters."""
+    e = emb_w.detach().double()
+    b = torch.zeros(e.shape[0], dtype=torch.float64, device=e.device) if emb_b is None else emb_b.detach().double()
+    return e - e.mean(dim=0, keepdim=True), b - b.mean()
+
+
+def fold_embedded_layer_norm(w_rows: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, emb_w: Tensor,
+                             emb_b: Optional[Tensor], k_pad: int, one_col: int, dtype: torch.dtype):
+    """Fold ``Linear(LayerNorm(emb(x)))`` (mapper embedding -> block LayerNorm -> q / k / v Linear, reference
+    layers/mapper.py:322-331 + layers/block.py:516-528) into ONE product on the raw features ``x_aug = [x | 1 | 0-pad]``:
+
+        Linear(LN(E x + b_e)) = rstd * ( F x_aug ) + b',   F = [ W' E_c | W' b_c ],  W' = W * gamma,  b' = b + W beta,
+
+    with ``E_c, b_c`` the channel-centred embedding (``_centered_embedding``) and ``rstd`` the LayerNorm's own row
+    statistic of ``E x + b_e``.  Nothing is subtracted in the epilogue (the mean is gone algebraically), so the
+    ``colsum`` the kernel multiplies ``-mean rstd`` with is returned as zeros.  ``(F [N, k_pad] dtype, b' [N] f32,
+    zeros [N] f32)``; products in f64, one rounding to ``dtype``."""
+    w = w_rows.detach().double() * gamma.detach().double()[None, :]
+    e_c, b_c = _centered_embedding(emb_w, emb_b)
+    k_in = e_c.shape[1]
+    if not (k_in <= one_col < k_pad):
+        raise ValueError(f"fold_embedded_layer_norm: constant-1 column {one_col} outside the padding [{k_in}, {k_pad})")
+    f = torch.zeros((w.shape[0], k_pad), dtype=torch.float64, device=w.device)
+    f[:, :k_in] = w @ e_c
+    f[:, one_col] = w @ b_c
+    b = w_rows.detach().double() @ beta.detach().double()
+    if bias is not None:
+        b = b + bias.detach().double()
+    return (f.to(dtype).contiguous(), b.float().contiguous(),
+            torch.zeros(w.shape[0], dtype=torch.float32, device=w.device))
+
+
+def embedding_stats_operator(emb_w: Tensor, emb_b: Optional[Tensor], k_pad: int, one_col: int, dtype: torch.dtype):
+    """``T [n, k_pad]`` (n = a multiple of 256) such that ``y = T x_aug`` has, per row, mean 0 and
+    ``sum(y^2) / n == |E_c x + b_c|^2 / C``: the LayerNorm variance of the embedded row ``E x + b_e`` without forming it.
+    A plain ``row_stats(y, eps)`` (or the statistics epilogue of the GEMM that produces ``y``) then IS
+    ``{rstd, ~0}`` of ``LayerNorm(emb(x))``.  Construction: ``A = [E_c | b_c] = Q R`` (so ``|A z| = |R z|``),
+    ``B`` an orthonormal basis of ``K + 1`` directions orthogonal to the all-ones vector in ``R^n``,
+    ``T = sqrt(n / C) B R`` -- sums of squares only, no inverse, any rank."""
+    e_c, b_c = _centered_embedding(emb_w, emb_b)
+    c, k_in = e_c.shape
+    a = torch.cat([e_c, b_c[:, None]], dim=1).cpu()  # [C, K + 1]; small, factorised on the host in f64
+    r = torch.linalg.qr(a, mode="r").R if c >= k_in + 1 else a
+    n = ops.round_up(r.shape[0] + 1, 256)
+    basis = torch.eye(n, dtype=torch.float64)[:, : r.shape[0]] - 1.0 / n
+    basis = torch.linalg.qr(basis).Q  # [n, rows(R)], every column sums to 0
+    t_small = (n / c) ** 0.5 * (basis @ r)  # [n, K + 1]
+    t = torch.zeros((n, k_pad), dtype=torch.float64)
+    t[:, :k_in] = t_small[:, :k_in]
+    t[:, one_col] = t_small[:, k_in]
+    return t.to(device=emb_w.device, dtype=dtype).contiguous()
 
 
 def pack_bias(biases: Sequence[Optional[Tensor]], sizes: Sequence[int], device) -> Tensor:

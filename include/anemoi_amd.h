@@ -336,8 +336,8 @@ int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const floa
  * Backward of anemoi_gt_edge_attention_folded (the edge half of SURVEY.md section 8f-1; what torch.autograd derives from
  * GraphTransformerConv.message / softmax / aggregate, layers/conv.py:98-142, plus lin_edge through the fold).
  * With s_e = scale (q_i.k_j + u_i.a_e), alpha = softmax over the in-edges of i, out_i = sum alpha v_j (+ x_r),
- * t_i = sum alpha a_e, and dsum[i, h] = dout_i,h.(out_i,h - x_r) + dt_i,h.t_i,h formed in the kernel from the forward's
- * result `out` ([n_dst, ldout] = out | t) and x_r:
+ * t_i = sum alpha a_e, and dsum[i, h] = sum_e alpha_e (dout_i,h.v_j,h + dt_i,h.a_e) accumulated in f32 by the kernel
+ * (the forward's result is not needed):
  *   _dst  (forward CSR):     alpha[E, H], ds[E, H] = alpha (dout_i.v_j + dt_i.a_e - dsum) (f32),
  *                            dq_i = scale sum_e ds k_j,  du_i = scale sum_e ds a_e (f32 [n_dst, H*up])
  *   _src  (transposed CSR):  dk_j = scale sum_{e from j} ds q_i,  dv_j = sum_{e from j} alpha dout_i
@@ -346,8 +346,7 @@ int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const floa
  */
 int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
                                                  int64_t ldkv, const void* dout, int64_t ldd, const float* u,
-                                                 const float* dt, const void* out, int64_t ldout, const void* x_r,
-                                                 int64_t ldxr, const float* edge_attr, int up,
+                                                 const float* dt, const float* edge_attr, int up,
                                                  const int32_t* rowptr, const int32_t* col, float* alpha, float* ds,
                                                  void* dq, int64_t lddq, float* du, int64_t n_dst, int C, int H,
                                                  anemoi_stream_t stream);

@@ -931,11 +931,13 @@ def test_node_mlp_training_step_matches_torch():
         assert rel_err(gp[k], gpr[k].float()) < 2e-4, k
 
 
-@pytest.mark.parametrize("dtype,n_src,n_dst,e,c,h", [
-    (torch.float32, 90, 70, 500, 64, 4), (torch.float32, 300, 300, 2500, 128, 16), (torch.float32, 50, 400, 1200, 256, 4),
-    (torch.bfloat16, 200, 200, 1800, 1024, 16), (torch.float32, 40, 40, 0, 64, 4),
+@pytest.mark.parametrize("dtype,n_src,n_dst,e,c,h,xr_scale", [
+    (torch.float32, 90, 70, 500, 64, 4, 1.0), (torch.float32, 300, 300, 2500, 128, 16, 1.0),
+    (torch.float32, 50, 400, 1200, 256, 4, 1.0), (torch.bfloat16, 200, 200, 1800, 1024, 16, 1.0),
+    (torch.bfloat16, 200, 200, 1800, 1024, 16, 64.0),  # residual >> attention term: the softmax-backward row sums must
+    (torch.float32, 40, 40, 0, 64, 4, 1.0),            # not be rebuilt from the rounded `out - x_r`
 ])
-def test_gt_edge_attention_backward_matches_torch_autograd(dtype, n_src, n_dst, e, c, h):
+def test_gt_edge_attention_backward_matches_torch_autograd(dtype, n_src, n_dst, e, c, h, xr_scale):
     """autograd.gt_edge_attention (folded edge phase): dq, dk, dv, dx_r, du, d edge_attr from the two backward kernels
     (destination-major + source-major, no atomics) against torch autograd in f64 of the same expression: per-edge scores
     with the PyG softmax of oracle/pyg_semantics.py (+1e-16), isolated and high in-degree destinations included."""
@@ -948,6 +950,7 @@ def test_gt_edge_attention_backward_matches_torch_autograd(dtype, n_src, n_dst, 
         ei[1, :45] = 3  # one destination with in-degree >= 45; the last destination stays isolated
     plan = runtime.build_edge_plan(ei.to(DEV), n_src, n_dst)
     q, k, v, xr = (torch.randn(n, c, generator=g).to(dtype) for n in (n_dst, n_src, n_src, n_dst))
+    xr = (xr.float() * xr_scale).to(dtype)
     u = (0.3 * torch.randn(n_dst, h * up, generator=g)).to(dtype)
     attr = torch.randn(e, up, generator=g)  # already in the plan's CSR order
     dfull = torch.randn(n_dst, c + h * up, generator=g).to(dtype)
