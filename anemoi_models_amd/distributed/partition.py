@@ -366,16 +366,16 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
 
     # [x | coordinates | trainable | 1 | 0-pad] as in the single-device forward (the constant 1 carries the embedding bias
     # of the GraphTransformer mappers' embedding fold; every rank assembles the full grid and selects its rows)
-    fold = runtime.embed_fold_enabled(dtype) and not gnn_maps
+    fold = model._embed_fold(dtype)
     width = model.multi_step * model.num_input_channels + na.attr_ndims[data]
     x_data = ops.assemble_nodes(x, na.latlons(data), model._with_ones(na.trainable_tensors[data].trainable, grid, fold),
-                                1, dtype, ld_out=model._feature_ld(width + int(fold), dtype), in_affine=input_affine)
+                                1, dtype, ld_out=model._feature_ld(width + int(fold), dtype, fold), in_affine=input_affine)
     tr_hidden = na.trainable_tensors[hidden].trainable
     w_hidden = na.attr_ndims[hidden]
     x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[own_ids],
                                   model._with_ones(None if tr_hidden is None else tr_hidden[own_ids], own_ids.numel(), fold,
                                                    device=x.device),
-                                  1, dtype, ld_out=model._feature_ld(w_hidden + int(fold), dtype))
+                                  1, dtype, ld_out=model._feature_ld(w_hidden + int(fold), dtype, fold))
     one_data, one_hidden = (width, w_hidden) if fold else (None, None)
 
     if gnn_maps:

@@ -144,12 +144,19 @@ class AnemoiModelEncProcDec(nn.Module):
         ones = self._idx_cache[key]
         return ones if trainable is None else torch.cat([trainable.detach().float(), ones], dim=1)
 
+    def _embed_fold(self, dtype: torch.dtype) -> bool:
+        """Both mappers are GraphTransformer mappers that take feature matrices with a constant-1 padding column."""
+        from ..layers.mapper import GraphTransformerBaseMapper
+
+        return (runtime.embed_fold_enabled(dtype) and isinstance(self.encoder, GraphTransformerBaseMapper)
+                and isinstance(self.decoder, GraphTransformerBaseMapper))
+
     @staticmethod
-    def _feature_ld(width: int, dtype: torch.dtype) -> int:
-        """Row pitch of an assembled feature matrix: the K-slab multiple, and for bf16 at least two slabs (the
-        persistent MFMA kernel takes K >= 128; one slab of zero columns is cheaper than the generic kernel)."""
+    def _feature_ld(width: int, dtype: torch.dtype, wide: bool = True) -> int:
+        """Row pitch of an assembled feature matrix: the K-slab multiple, and (``wide``, bf16) at least two slabs: the
+        persistent MFMA kernel takes K >= 128, one slab of zero columns is cheaper than the generic kernel."""
         ld = ops.round_up(width, ops.k_multiple(dtype))
-        return max(ld, 128) if dtype == torch.bfloat16 else ld
+        return max(ld, 128) if (wide and dtype == torch.bfloat16) else ld
 
     @staticmethod
     def _one_cols(mapper, src: Optional[int], dst: Optional[int]) -> dict:
@@ -247,10 +254,10 @@ class AnemoiModelEncProcDec(nn.Module):
         # The constant 1 in the first padding column carries the embedding bias when a GraphTransformer mapper folds
         # its embedding into the block's first GEMMs (layers/mapper.py::_embedded); zero weights meet it otherwise.
         width = self.multi_step * self.num_input_channels + na.attr_ndims[data]
-        fold = runtime.embed_fold_enabled(dtype)
+        fold = self._embed_fold(dtype)
         tr_data = na.trainable_tensors[data].trainable
         x_data = ops.assemble_nodes(x, na.latlons(data), self._with_ones(tr_data, grid, fold), batch_size, dtype,
-                                    ld_out=self._feature_ld(width + int(fold), dtype), in_affine=input_affine)
+                                    ld_out=self._feature_ld(width + int(fold), dtype, fold), in_affine=input_affine)
         # mesh rows live in an internal Morton order (gather locality of the edge kernels); only the tiny
         # per-node attribute tables are permuted, the mesh never leaves the model
         order, inv = self._mesh_order(x.device)
@@ -258,7 +265,7 @@ class AnemoiModelEncProcDec(nn.Module):
         w_hidden = na.attr_ndims[hidden]
         x_hidden = ops.assemble_nodes(None, na.latlons(hidden)[order],
                                       self._with_ones(None if tr_hidden is None else tr_hidden[order], order.numel(), fold),
-                                      batch_size, dtype, ld_out=self._feature_ld(w_hidden + int(fold), dtype))
+                                      batch_size, dtype, ld_out=self._feature_ld(w_hidden + int(fold), dtype, fold))
         one_data, one_hidden = (width, w_hidden) if fold else (None, None)
 
         enc = self.encoder.native(x_data, x_hidden, batch_size, dst_map=inv,

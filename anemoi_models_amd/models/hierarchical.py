@@ -129,9 +129,9 @@ class AnemoiModelEncProcDecHierarchical(AnemoiModelEncProcDec):
 
         # [x | coordinates | trainable | 1 | 0-pad]: the constant 1 serves the mappers' embedding fold (see the flat model)
         width = self.multi_step * self.num_input_channels + na.attr_ndims[data]
-        fold = runtime.embed_fold_enabled(dtype)
+        fold = self._embed_fold(dtype)
         x_data = ops.assemble_nodes(x, na.latlons(data), self._with_ones(na.trainable_tensors[data].trainable, grid, fold),
-                                    batch_size, dtype, ld_out=self._feature_ld(width + int(fold), dtype))
+                                    batch_size, dtype, ld_out=self._feature_ld(width + int(fold), dtype, fold))
         one_data = width if fold else None
         x_hidden = {
             h: ops.assemble_nodes(None, na.latlons(h), na.trainable_tensors[h].trainable, batch_size, dtype,

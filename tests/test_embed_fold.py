@@ -108,7 +108,7 @@ def test_mapper_fold_host_wiring(graph_o32, monkeypatch):
     assert (n_grid, 512, 128) in with_fold
     # encoder source embedding (grid rows, 256 outputs from the features) is not formed: only the decoder's remains
     assert sum(1 for s in with_fold if s == (n_grid, 256, 128)) == 1 + 1  # + the [rows, 256] statistics side product
-    assert sum(1 for s in shapes if s == (n_grid, 256, 128)) == 2
+    assert sum(1 for s in shapes if s == (n_grid, 256, 64)) == 2  # no wide padding without the fold
 
 
 @pytest.mark.gpu
