@@ -146,6 +146,11 @@ class HeadExchange:
     rows: List[int]  # mesh rows owned by every rank
     rank: int
     group: object
+    # the ranks own contiguous ranges of the INTERNAL (Morton) mesh order; a sliding attention window acts on the EXTERNAL
+    # node order, so the full sequence is permuted around the windowed attention: internal position of every external
+    # row / external row of every internal position
+    to_external: Optional[Tensor] = None
+    to_internal: Optional[Tensor] = None
 
     def _head_bounds(self, num_heads: int) -> List[int]:
         return split_bounds(num_heads, len(self.rows))
@@ -264,7 +269,7 @@ def build_shard_plan(model, group, device) -> ShardPlan:
                                   int(enc_src_ids.numel()), n_own), int(enc_src_ids.numel()), None)
 
     # ---- processor: mesh -> mesh (the Transformer processor has no edges: rows <-> heads exchange instead)
-    heads = HeadExchange([bounds[p + 1] - bounds[p] for p in range(world)], rank, group)
+    heads = HeadExchange([bounds[p + 1] - bounds[p] for p in range(world)], rank, group, inv, order)
     if not hasattr(model.processor, "edge_index_base"):
         proc = LocalGraph(None, n_own, None, heads)
     ei = getattr(model.processor, "edge_index_base", None)

@@ -686,8 +686,13 @@ class TransformerProcessorBlock(BaseBlock):
         att = self.attention
         qkv = linear_native(att._packed, "lin_qkv", att.lin_qkv, h)
         if head_exchange is not None:
-            qkv_heads = head_exchange.rows_to_heads(qkv, att.num_heads)  # [S, 3 * C_local]
-            a_heads = ops.mhsa(qkv_heads, batch_size, head_exchange.local_heads(att.num_heads), -1)
+            window = att.attention_window()
+            qkv_heads = head_exchange.rows_to_heads(qkv, att.num_heads)  # [S, 3 * C_local], internal row order
+            if window >= 0:  # the window slides over the EXTERNAL node order
+                qkv_heads = qkv_heads.index_select(0, head_exchange.to_external)
+            a_heads = ops.mhsa(qkv_heads, batch_size, head_exchange.local_heads(att.num_heads), window)
+            if window >= 0:
+                a_heads = a_heads.index_select(0, head_exchange.to_internal)
             a = head_exchange.heads_to_rows(a_heads, att.num_heads)  # [n_own, C]
         else:
             a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window())

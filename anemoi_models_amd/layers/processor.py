@@ -83,8 +83,6 @@ class TransformerProcessor(BaseProcessor):
     def native_local(self, x_own: Tensor, local_graph) -> Tensor:
         """Node-partitioned run: rows stay sharded for LayerNorm / Linear / MLP; around the attention the heads <-> rows
         all-to-all of the reference (distributed/transformer.py:85-130) gives every rank all rows of H / P heads."""
-        if self.proc[0].blocks[0].attention.attention_window() >= 0:
-            raise NotImplementedError("sliding-window attention is not available in the node-partitioned forward")
         for chunk in self.proc:
             for blk in chunk.blocks:
                 x_own = blk.native(x_own, 1, head_exchange=local_graph.heads)

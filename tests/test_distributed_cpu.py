@@ -15,9 +15,11 @@ import torch.multiprocessing as mp
 from conftest import GOLDEN, ROOT
 
 
-def _worker(rank, world, port, result_file, processor="GraphTransformer", dtype=None, heads=16):
+def _worker(rank, world, port, result_file, processor="GraphTransformer", dtype=None, heads=16, window=None):
     if dtype is not None:
         os.environ["ANEMOI_AMD_DTYPE"] = dtype
+    if window is not None:  # flash-attn's sliding window semantics (reference layers/attention.py:96) instead of SDPA-global
+        os.environ["ANEMOI_AMD_FLASH_WINDOW"] = "1"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -47,14 +49,15 @@ def _worker(rank, world, port, result_file, processor="GraphTransformer", dtype=
             gold = {k: torch.from_numpy(z[k]) for k in z.files}
         graph = build_graph("o32_ico2")
         idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
-        model = AnemoiModelEncProcDec(model_config=model_config(processor, 64, 4, heads, mappers=mappers),
-                                      data_indices=idx, graph_data=graph)
+        cfg = model_config(processor, 64, 4, heads, mappers=mappers) if window is None else model_config(
+            processor, 64, 4, heads, mappers=mappers, window_size=window)
+        model = AnemoiModelEncProcDec(model_config=cfg, data_indices=idx, graph_data=graph)
         model.load_state_dict({k[3:]: v for k, v in gold.items() if k.startswith("sd.")})
         model.eval()
         with torch.no_grad():
             y = model(gold["x"], dist.group.WORLD)
-            # the golden output belongs to 16 heads; other head counts are compared with the unsharded forward
-            want = gold["y"] if heads == 16 else model(gold["x"])
+            # the golden output belongs to 16 heads and global attention; anything else is compared with the unsharded forward
+            want = gold["y"] if heads == 16 and window is None else model(gold["x"])
         err = float((y - want).abs().max())
         # every rank must hold the full output; halo / partition sanity
         sp = [v for k, v in model._idx_cache.items() if k[0] == "shard_plan"][0]
@@ -105,6 +108,18 @@ def test_sharded_forward_other_processors(processor, tmp_path):
     port = 29700 + (os.getpid() % 200) + {"GNN": 7, "Transformer": 13, "GNN_all": 19}[processor]
     result = str(tmp_path / "res")
     mp.spawn(_worker, args=(world, port, result, processor), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.load(f"{result}.{r}")["err"] < 1e-4
+
+
+def test_sharded_forward_sliding_window_attention(tmp_path):
+    """Transformer processor with flash-attn window semantics, node-partitioned: the heads <-> rows exchange delivers the
+    full sequence in the internal mesh order, the window slides over the external order (permutation around the
+    attention) -- sharded == unsharded for a window of 12 of the 162 mesh nodes."""
+    world = 2
+    port = 29650 + (os.getpid() % 200)
+    result = str(tmp_path / "res")
+    mp.spawn(_worker, args=(world, port, result, "Transformer", None, 16, 12), nprocs=world, join=True)
     for r in range(world):
         assert torch.load(f"{result}.{r}")["err"] < 1e-4
 

@@ -873,6 +873,48 @@ def test_linear_backward_matches_torch_autograd(dtype, m, k, n, act, bias, res):
         assert torch.equal(rd.grad.cpu(), dy)
 
 
+@pytest.mark.parametrize("dtype,rows,cols,ld_out", [
+    (torch.bfloat16, 4096, 1024, None), (torch.bfloat16, 5121, 1216, 5184), (torch.bfloat16, 130, 72, 192),
+    (torch.bfloat16, 64, 64, 64), (torch.bfloat16, 1000, 100, 1024), (torch.float32, 300, 96, 320),
+])
+def test_transpose_is_exact_with_zero_padding(dtype, rows, cols, ld_out):
+    """ops.transpose (bf16: register transposition of 8 x 8 sub-blocks; ragged tiles element-wise): bit-exact, the
+    columns behind the source rows zero filled (they are K padding of the weight-gradient GEMM)."""
+    from anemoi_models_amd import ops
+
+    x = torch.randn(rows, cols + 8, generator=torch.Generator().manual_seed(rows)).to(dtype).to(DEV)[:, :cols]  # ld > cols
+    got = ops.transpose(x, ld_out)
+    ld = rows if ld_out is None else ld_out
+    assert got.shape == (cols, ld)
+    assert torch.equal(got[:, :rows], x.t())
+    assert not got[:, rows:].any()
+
+
+@pytest.mark.parametrize("m,n,k", [(40962, 1024, 192), (5121, 256, 1024), (2500, 96, 64)])
+def test_weight_grad_chunked_transposes(m, n, k):
+    """ops.weight_grad (chunked transposes + batched GEMM + column sums of the partial results) == dpre^T x."""
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(m)
+    dpre, x = torch.randn(m, n, generator=g).bfloat16().to(DEV), torch.randn(m, k, generator=g).bfloat16().to(DEV)
+    want = dpre.double().t() @ x.double()
+    got = ops.weight_grad(dpre, x, k)
+    assert got.dtype == torch.float32 and rel_err(got, want.float()) < 6e-3  # bf16 partial results per row chunk
+    assert torch.equal(got, ops.weight_grad(dpre, x, k))
+
+
+@pytest.mark.parametrize("dtype,rows,cols", [(torch.bfloat16, 40962, 4288), (torch.float32, 9000, 100),
+                                             (torch.float32, 7, 33), (torch.bfloat16, 542080, 80)])
+def test_col_sum_two_stages(dtype, rows, cols):
+    from anemoi_models_amd import ops
+
+    x = torch.randn(rows, cols, generator=torch.Generator().manual_seed(cols)).to(dtype).to(DEV)
+    got = ops.col_sum(x)
+    want = x.double().sum(dim=0)
+    assert float((got.double() - want).abs().max()) < 1e-4 * float(x.double().abs().sum(dim=0).max())
+    assert torch.equal(got, ops.col_sum(x))  # fixed summation order
+
+
 @pytest.mark.parametrize("dtype,rows,c", [(torch.float32, 1000, 256), (torch.float32, 77, 100),
                                           (torch.bfloat16, 5000, 1024)])
 def test_layer_norm_backward_matches_torch_autograd(dtype, rows, c):
