@@ -148,13 +148,39 @@ def _transposed_csr(plan):
     return cached
 
 
-def _edge_attr_grad(alpha: Tensor, ds: Tensor, u32: Tensor, dt: Tensor, dst_of_edge: Tensor, n_edges: int, h: int,
-                    up: int, d: int) -> Tensor:
+def _edge_backward(q, k, v, dout, u, dt, lse, edge_attr, plan, h: int, up: int, dq, dk, dv, du, want_dattr: bool):
+    """The three backward kernels of the folded edge phase (csrc/edge_backward.hip) on column views: ``q, dout, u, dt``
+    ``[n_dst, .]``, ``k, v`` ``[n_src, C]`` in, ``dq, du`` ``[n_dst, .]`` and ``dk, dv`` ``[n_src, C]`` out (any row
+    pitch: the processor block hands in the column ranges of ONE ``d(x_r|q|k|v|u)`` buffer).  Returns d edge_attr."""
     from . import _lib
 
-    dattr = torch.empty((n_edges, up), dtype=torch.float32, device=alpha.device)
-    st = _lib.load().anemoi_gt_edge_attr_grad(alpha.data_ptr(), ds.data_ptr(), u32.data_ptr(), dt.data_ptr(),
-                                             dst_of_edge.data_ptr(), dattr.data_ptr(), n_edges, h, up, d, ops._stream())
+    n_dst, c = q.shape
+    n_src = k.shape[0]
+    n_edges = plan.col.shape[0]
+    dev = q.device
+    alpha = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
+    w = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
+    dsum = torch.empty((n_dst, h), dtype=torch.float32, device=dev)
+    lib, code, stream = _lib.load(), ops.dtype_code(q.dtype), ops._stream()
+    ld = lambda t: ops._ld(ops._rows(t))  # noqa: E731
+    if ld(k) != ld(v) or ld(dk) != ld(dv):
+        raise ValueError("gt_edge_attention: k / v (and dk / dv) must share their leading dimension")
+    st = lib.anemoi_gt_edge_attention_folded_backward_dst(
+        code, q.data_ptr(), ld(q), k.data_ptr(), v.data_ptr(), ld(k), dout.data_ptr(), ld(dout), u.data_ptr(), ld(u),
+        dt.data_ptr(), ld(dt), lse.data_ptr(), edge_attr.data_ptr(), up, plan.rowptr.data_ptr(), plan.col.data_ptr(),
+        alpha.data_ptr(), w.data_ptr(), dsum.data_ptr(), dq.data_ptr(), ld(dq), du.data_ptr(), ld(du), n_dst, c, h, stream)
+    _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
+    rowptr_t, eid_t, dst_t, dst_of_edge = _transposed_csr(plan)
+    st = lib.anemoi_gt_edge_attention_folded_backward_src(
+        code, q.data_ptr(), ld(q), dout.data_ptr(), ld(dout), alpha.data_ptr(), w.data_ptr(), dsum.data_ptr(),
+        rowptr_t.data_ptr(), eid_t.data_ptr(), dst_t.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld(dk), n_src, c, h, stream)
+    _lib.check(st, "anemoi_gt_edge_attention_folded_backward_src")
+    if not want_dattr:
+        return None
+    dattr = torch.empty((n_edges, up), dtype=torch.float32, device=dev)
+    st = lib.anemoi_gt_edge_attr_grad(code, alpha.data_ptr(), w.data_ptr(), dsum.data_ptr(), u.data_ptr(), ld(u),
+                                      dt.data_ptr(), ld(dt), dst_of_edge.data_ptr(), dattr.data_ptr(), n_edges, h, up,
+                                      c // h, stream)
     _lib.check(st, "anemoi_gt_edge_attr_grad")
     return dattr
 
@@ -162,60 +188,28 @@ def _edge_attr_grad(alpha: Tensor, ds: Tensor, u32: Tensor, dt: Tensor, dst_of_e
 class _GTEdgeAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, x_r, u, edge_attr, plan, num_heads: int, up: int):
-        out = ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, plan.rowptr, plan.col, num_heads, up)
-        ctx.save_for_backward(q, k, v, u, edge_attr)  # the backward needs neither the result nor x_r
+        lse = torch.empty((q.shape[0], num_heads), dtype=torch.float32, device=q.device)
+        out = ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, plan.rowptr, plan.col, num_heads, up, lse=lse)
+        ctx.save_for_backward(q, k, v, u, edge_attr, lse)  # the backward needs neither the result nor x_r
         ctx.plan, ctx.h, ctx.up, ctx.has_xr = plan, num_heads, up, x_r is not None
         return out
 
     @staticmethod
     def backward(ctx, dfull):
-        from . import _lib
-
-        q, k, v, u, edge_attr = ctx.saved_tensors
+        q, k, v, u, edge_attr, lse = ctx.saved_tensors
         plan, h, up, has_xr = ctx.plan, ctx.h, ctx.up, ctx.has_xr
         n_dst, c = q.shape
-        d = c // h
-        dtype = q.dtype
         dfull = dfull.contiguous()
         dout = dfull[:, :c]
-        dt = dfull[:, c:c + h * up].float().contiguous()
-        u32 = u.float().contiguous()
-        n_edges = plan.col.shape[0]
-        dev = q.device
-        if n_edges == 0:  # no edges: out = x_r, t = 0 -- only x_r receives a gradient
-            return (torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v),
-                    dout.contiguous() if has_xr else None, torch.zeros_like(u), torch.zeros_like(edge_attr), None,
-                    None, None)
-        alpha = torch.empty((max(n_edges, 1), h), dtype=torch.float32, device=dev)
-        ds = torch.empty((max(n_edges, 1), h), dtype=torch.float32, device=dev)
-        dq = torch.empty((n_dst, c), dtype=dtype, device=dev)
-        du = torch.empty((n_dst, h * up), dtype=torch.float32, device=dev)
-        lib = _lib.load()
-        code = ops.dtype_code(dtype)
-        stream = ops._stream()
-        kk, vv = ops._rows(k), ops._rows(v)
-        if ops._ld(kk) != ops._ld(vv):
-            raise ValueError("gt_edge_attention: k and v must share their leading dimension (slices of one k|v buffer)")
-        st = lib.anemoi_gt_edge_attention_folded_backward_dst(
-            code, q.data_ptr(), ops._ld(ops._rows(q)), kk.data_ptr(), vv.data_ptr(), ops._ld(kk), dout.data_ptr(),
-            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), edge_attr.data_ptr(), up,
-            plan.rowptr.data_ptr(), plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(), dq.data_ptr(), c, du.data_ptr(),
-            n_dst, c, h, stream)
-        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
-        rowptr_t, eid_t, dst_t, dst_of_edge = _transposed_csr(plan)
-        n_src = k.shape[0]
-        dk = torch.empty((n_src, c), dtype=dtype, device=dev)
-        dv = torch.empty((n_src, c), dtype=dtype, device=dev)
-        st = lib.anemoi_gt_edge_attention_folded_backward_src(
-            code, q.data_ptr(), ops._ld(ops._rows(q)), dout.data_ptr(), ops._ld(ops._rows(dout)), alpha.data_ptr(),
-            ds.data_ptr(), rowptr_t.data_ptr(), eid_t.data_ptr(), dst_t.data_ptr(), dk.data_ptr(), dv.data_ptr(), c, n_src,
-            c, h, stream)
-        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_src")
-        dattr = None
-        if ctx.needs_input_grad[5] and n_edges > 0:
-            dattr = _edge_attr_grad(alpha, ds, u32, dt, dst_of_edge, n_edges, h, up, d)
         dxr = dout.contiguous() if has_xr else None
-        return dq, dk, dv, dxr, du.to(u.dtype), dattr, None, None, None
+        if plan.col.shape[0] == 0:  # no edges: out = x_r, t = 0 -- only x_r receives a gradient
+            return (torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v), dxr, torch.zeros_like(u),
+                    torch.zeros_like(edge_attr), None, None, None)
+        dq, du = torch.empty_like(q), torch.empty((n_dst, h * up), dtype=q.dtype, device=q.device)
+        dkv = torch.empty((k.shape[0], 2 * c), dtype=q.dtype, device=q.device)
+        dattr = _edge_backward(q, k, v, dout, u, dfull[:, c:c + h * up], lse, edge_attr, plan, h, up, dq, dkv[:, :c],
+                               dkv[:, c:], du, ctx.needs_input_grad[5])
+        return dq, dkv[:, :c], dkv[:, c:], dxr, du, dattr, None, None, None
 
 
 class _GTEdgeAttentionSelf(torch.autograd.Function):
@@ -226,53 +220,27 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sq, edge_attr, plan, num_heads: int, up: int):
         c = (sq.shape[1] - num_heads * up) // 4
+        lse = torch.empty((sq.shape[0], num_heads), dtype=torch.float32, device=sq.device)
         out = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
-                                           edge_attr, plan.rowptr, plan.col, num_heads, up)
-        ctx.save_for_backward(sq, edge_attr)
+                                           edge_attr, plan.rowptr, plan.col, num_heads, up, lse=lse)
+        ctx.save_for_backward(sq, edge_attr, lse)
         ctx.plan, ctx.h, ctx.up, ctx.c = plan, num_heads, up, c
         return out
 
     @staticmethod
     def backward(ctx, dfull):
-        from . import _lib
-
-        sq, edge_attr = ctx.saved_tensors
+        sq, edge_attr, lse = ctx.saved_tensors
         plan, h, up, c = ctx.plan, ctx.h, ctx.up, ctx.c
-        n, width = sq.shape
-        d = c // h
-        dtype, dev = sq.dtype, sq.device
         dfull = dfull.contiguous()
         dout = dfull[:, :c]
-        n_edges = plan.col.shape[0]
-        dsq = torch.empty((n, width), dtype=dtype, device=dev)
+        dsq = torch.empty_like(sq)
         dsq[:, :c].copy_(dout)  # d x_r
-        if n_edges == 0:
+        if plan.col.shape[0] == 0:
             dsq[:, c:].zero_()
             return dsq, torch.zeros_like(edge_attr), None, None, None
-        dt = dfull[:, c:c + h * up].float().contiguous()
-        u32 = sq[:, 4 * c:].float().contiguous()
-        alpha = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
-        ds = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
-        du = torch.empty((n, h * up), dtype=torch.float32, device=dev)
-        lib, code, stream = _lib.load(), ops.dtype_code(dtype), ops._stream()
-        esz = sq.element_size()
-        base = sq.data_ptr()
-        gbase = dsq.data_ptr()
-        st = lib.anemoi_gt_edge_attention_folded_backward_dst(
-            code, base + c * esz, width, base + 2 * c * esz, base + 3 * c * esz, width, dout.data_ptr(),
-            ops._ld(ops._rows(dout)), u32.data_ptr(), dt.data_ptr(), edge_attr.data_ptr(), up, plan.rowptr.data_ptr(),
-            plan.col.data_ptr(), alpha.data_ptr(), ds.data_ptr(), gbase + c * esz, width, du.data_ptr(), n, c, h, stream)
-        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
-        rowptr_t, eid_t, dst_t, dst_of_edge = _transposed_csr(plan)
-        st = lib.anemoi_gt_edge_attention_folded_backward_src(
-            code, base + c * esz, width, dout.data_ptr(), ops._ld(ops._rows(dout)), alpha.data_ptr(), ds.data_ptr(),
-            rowptr_t.data_ptr(), eid_t.data_ptr(), dst_t.data_ptr(), gbase + 2 * c * esz, gbase + 3 * c * esz, width, n, c,
-            h, stream)
-        _lib.check(st, "anemoi_gt_edge_attention_folded_backward_src")
-        dsq[:, 4 * c:].copy_(du)
-        dattr = None
-        if ctx.needs_input_grad[1]:
-            dattr = _edge_attr_grad(alpha, ds, u32, dt, dst_of_edge, n_edges, h, up, d)
+        dattr = _edge_backward(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], dout, sq[:, 4 * c:],
+                               dfull[:, c:c + h * up], lse, edge_attr, plan, h, up, dsq[:, c:2 * c], dsq[:, 2 * c:3 * c],
+                               dsq[:, 3 * c:4 * c], dsq[:, 4 * c:], ctx.needs_input_grad[1])
         return dsq, dattr, None, None, None
 
 

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "edge_common.hpp"
 
 namespace anemoi {
 
@@ -35,28 +36,6 @@ struct EdgeAttnParams {
   float scale;
 };
 
-template <typename T, int VEC>
-struct RawVec;
-template <>
-struct RawVec<float, 4> { using type = float4; };
-template <>
-struct RawVec<float, 2> { using type = float2; };
-template <>
-struct RawVec<float, 1> { using type = float; };
-template <>
-struct RawVec<bf16_t, 8> { using type = uint4; };
-template <>
-struct RawVec<bf16_t, 4> { using type = uint2; };
-template <>
-struct RawVec<bf16_t, 2> { using type = uint32_t; };
-template <>
-struct RawVec<bf16_t, 1> { using type = uint16_t; };
-
-template <typename T, int VEC>
-__device__ __forceinline__ void unpack(const typename RawVec<T, VEC>::type& raw, float (&r)[VEC]) {
-  VecIO<T, VEC>::load(reinterpret_cast<const T*>(&raw), r);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Fast path: compile-time VEC (channels per lane), LPH (lanes per head) and EDP (edge_dim padded to 4).
 //
@@ -68,51 +47,6 @@ __device__ __forceinline__ void unpack(const typename RawVec<T, VEC>::type& raw,
 // touched twice per destination node (u in the prologue, W t in the epilogue) and lives in LDS in a
 // lane-major layout so that each access is one conflict-free ds_read_b128 per 4 channels.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VEC>
-struct QK;  // dot product of the lane's q and k slices
-
-template <int VEC>
-struct QK<float, VEC> {
-  using Raw = typename RawVec<float, VEC>::type;
-  float q[VEC];
-  __device__ __forceinline__ void set(const float (&qf)[VEC]) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) q[i] = qf[i];
-  }
-  __device__ __forceinline__ float dot(const Raw& kr) const {
-    float kk[VEC];
-    unpack<float, VEC>(kr, kk);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) s = fmaf(q[i], kk[i], s);
-    return s;
-  }
-};
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-
-template <int VEC>
-struct QK<bf16_t, VEC> {
-  using Raw = typename RawVec<bf16_t, VEC>::type;
-  static_assert(VEC % 2 == 0, "bf16 fast path packs channel pairs");
-  uint32_t q[VEC / 2];  // q stays packed: v_dot2c_f32_bf16 multiplies bf16 pairs exactly and accumulates in f32
-  __device__ __forceinline__ void set(const float (&qf)[VEC]) {
-#pragma unroll
-    for (int i = 0; i < VEC / 2; ++i) q[i] = pack_bf16x2(qf[2 * i], qf[2 * i + 1]);
-  }
-  __device__ __forceinline__ float dot(const Raw& kr) const {
-    const uint32_t* kw = reinterpret_cast<const uint32_t*>(&kr);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC / 2; ++i) {
-      uint32_t a = q[i], b = kw[i];
-      s = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf16x2_t*>(&a), *reinterpret_cast<bf16x2_t*>(&b), s,
-                                          false);
-    }
-    return s;
-  }
-};
-
 template <typename T, int VEC, int LPH, int EDP>
 __global__ __launch_bounds__(256) void gt_edge_attention_kernel(const EdgeAttnParams p,
                                                                 const float* __restrict__ attr_,
@@ -294,6 +228,7 @@ struct EdgeFoldParams {
   const void* xr;
   const void* u;
   void* out;
+  float* lse;  // optional [n_dst, H]: m + log(l + 1e-16) of the destination's softmax (alpha = exp(s - lse)), for the backward
   int64_t ldq, ldkv, ldr, ldu, ldo;
   const float* attr;
   const int32_t* rowptr;
@@ -302,82 +237,6 @@ struct EdgeFoldParams {
   int C, D, n_slices;
   float scale;
   int stream_hint;  // 1: q / x_r / out are nontemporal so that they do not evict gathered k|v rows from the XCD's L2
-};
-
-// 16-byte streaming accesses: data that is touched exactly once per launch
-template <typename T, int VEC>
-__device__ __forceinline__ void load_stream(const T* p, float (&r)[VEC]) {
-  if constexpr (sizeof(T) * VEC == 16) {
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-    VecIO<T, VEC>::load(reinterpret_cast<const T*>(&t), r);
-  } else {
-    VecIO<T, VEC>::load(p, r);
-  }
-}
-template <typename T, int VEC>
-__device__ __forceinline__ void store_stream(T* p, const float (&r)[VEC]) {
-  if constexpr (sizeof(T) * VEC == 16) {
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t t;
-    VecIO<T, VEC>::store(reinterpret_cast<T*>(&t), r);
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
-  } else {
-    VecIO<T, VEC>::store(p, r);
-  }
-}
-
-// The attribute part of the score (u . a) and of the output (sum alpha a) is the same for all LPH lanes of a head:
-// the lanes SHARE it -- lane r of a head owns the APL attributes [r * APL, r * APL + APL) (one 8/16-byte load per
-// edge), its partial u . a joins the lane's partial q . k before the head reduction (which is needed anyway), and it
-// accumulates only its own attributes.  12 + 12 FMAs per edge and lane become 2 + 2 (UP = 12, 8 lanes per head):
-// the kernel was VALU-bound (~58 VALU per edge and wave, 0.10 of its 0.17 ms on the mesh graph).
-constexpr int attrs_per_lane(int up, int lph) {  // smallest divisor of UP in {2, 4, 8, 12, 16} covering UP with LPH lanes
-  const int raw = (up + lph - 1) / lph;
-  for (int a : {2, 4, 8, 12, 16})
-    if (a >= raw && up % a == 0) return a;
-  return up;
-}
-
-// Raw (unconverted) words of N consecutive elements: what a prefetched operand is carried in from one destination to the
-// next -- converting at load time would pin the s_waitcnt to the load instead of to the first use.
-template <typename T, int N>
-struct RawWords {
-  static constexpr int W = (N * (int)sizeof(T) + 3) / 4;
-  uint32_t w[W];
-  // ``base`` is wave-uniform (SGPR pair), ``off`` the lane's byte offset: the access compiles to the saddr + voffset
-  // form, so no 64-bit per-lane pointer is kept alive (this kernel lives at the 96-VGPR edge of 5 waves per SIMD)
-  __device__ __forceinline__ void load(const char* base, uint32_t off, bool nt) {
-    const T* p = reinterpret_cast<const T*>(base + off);
-    if constexpr (W % 4 == 0) {
-      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-#pragma unroll
-      for (int i = 0; i < W / 4; ++i) {
-        const u32x4_t t = nt ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p) + i)
-                             : reinterpret_cast<const u32x4_t*>(p)[i];
-        w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
-      }
-    } else if constexpr (W % 2 == 0) {
-#pragma unroll
-      for (int i = 0; i < W / 2; ++i) {
-        const uint2 t = reinterpret_cast<const uint2*>(p)[i];
-        w[2 * i] = t.x; w[2 * i + 1] = t.y;
-      }
-    } else {
-      static_assert(N * sizeof(T) % 4 == 0, "whole words");
-#pragma unroll
-      for (int i = 0; i < W; ++i) w[i] = reinterpret_cast<const uint32_t*>(p)[i];
-    }
-  }
-  __device__ __forceinline__ void get(float (&r)[N]) const {
-    if constexpr (sizeof(T) == 4) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) r[i] = __uint_as_float(w[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < N; ++i) r[i] = __uint_as_float((i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16));
-    }
-  }
 };
 
 template <typename T, int VEC, int LPH, int UP, int U = 4>
@@ -516,6 +375,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
       for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
       VecIO<T, APL>::store(on + p.C + head * UP + a0, t4);
     }
+    if (p.lse != nullptr && active && (gls % LPH) == 0) p.lse[node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);
   }
 }
 
@@ -1061,8 +921,8 @@ extern "C" int anemoi_gt_edge_attention(int dtype, const void* q, int64_t ldq, c
 extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
                                                int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
                                                const float* edge_attr, int up, const int32_t* rowptr,
-                                               const int32_t* col, void* out, int64_t ldo, int64_t n_dst, int C, int H,
-                                               anemoi_stream_t stream) {
+                                               const int32_t* col, void* out, int64_t ldo, float* lse, int64_t n_dst,
+                                               int C, int H, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(q && k && v && u && out && rowptr, ANEMOI_ERR_INVALID,
                  "anemoi_gt_edge_attention_folded: null pointer");
   ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
@@ -1083,7 +943,7 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
                        ((int64_t)up * esz) % 8 == 0 && ((int64_t)C * esz) % 16 == 0;
   ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_folded: operands must be 16-byte aligned");
   EdgeFoldParams p;
-  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out;
+  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out; p.lse = lse;
   p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
   p.attr = edge_attr; p.rowptr = rowptr; p.col = col;
   p.n_dst = n_dst; p.C = C; p.D = C / H;

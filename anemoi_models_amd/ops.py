@@ -252,13 +252,17 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], ed
 
 def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
                              rowptr: Tensor, col: Tensor, num_heads: int, up: int, out: Optional[Tensor] = None,
-                             ld_out: Optional[int] = None) -> Tensor:
+                             ld_out: Optional[int] = None, lse: Optional[Tensor] = None) -> Tensor:
     """Edge phase with lin_edge folded away: returns ``[n_dst, ld_out]`` = ``[sum alpha v (+ x_r) | t (H*up) | 0-pad]``.
 
     ``u`` is ``[n_dst, H*up]`` (extra columns of the q/k/v GEMM), ``edge_attr`` ``[E, up]`` f32 in CSR order with the
-    constant-1 column.  Columns beyond ``C + H*up`` (K padding for the projection GEMM) are zero filled.
+    constant-1 column.  Columns beyond ``C + H*up`` (K padding for the projection GEMM) are zero filled.  ``lse``
+    (optional f32 ``[n_dst, H]``, contiguous) receives the softmax normaliser per destination and head (training).
     """
-    _dev(q, k, v, x_r, u, edge_attr, rowptr, col, out)
+    _dev(q, k, v, x_r, u, edge_attr, rowptr, col, out, lse)
+    if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous()
+                            or tuple(lse.shape) != (_rows(q).shape[0], num_heads)):
+        raise ValueError("gt_edge_attention_folded: lse must be a contiguous f32 [n_dst, H] tensor")
     n_dst, c = _rows(q).shape
     if _ld(_rows(k)) != _ld(_rows(v)):
         raise ValueError("gt_edge_attention_folded: k and v must share their leading dimension")
@@ -281,7 +285,7 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
         st = _lib.load().anemoi_gt_edge_attention_folded(
             dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
             0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
-            rowptr.data_ptr(), col.data_ptr(), out.data_ptr(), _ld(_rows(out)), n_dst, c, num_heads, _stream())
+            rowptr.data_ptr(), col.data_ptr(), out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
     _lib.check(st, "anemoi_gt_edge_attention_folded")
     return out
 

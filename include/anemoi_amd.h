@@ -145,10 +145,12 @@ int anemoi_gt_edge_attention(int dtype, const void* q, int64_t ldq, const void* 
  * order with a constant 1 in column edge_dim, and out (ldo >= C + H*up) receives
  *   out[:, 0:C] = sum_j alpha_ij v_j (+ x_r)      out[:, C:C+H*up] = t_i,h      (alpha as defined above, incl. 1e-16).
  * up is 4, 8, 12 or 16; D = C/H must be a multiple of the 16-byte vector width with D/vec a power of two <= 16.
+ * lse (optional, f32 [n_dst, H]): the softmax normaliser max + log(sum exp + 1e-16) per destination and head, i.e.
+ * alpha_ij = exp(s_ij - lse_i); what the backward needs to rebuild alpha in one sweep.  NULL: not written.
  */
 int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                                     const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
-                                    int up, const int32_t* rowptr, const int32_t* col, void* out, int64_t ldo,
+                                    int up, const int32_t* rowptr, const int32_t* col, void* out, int64_t ldo, float* lse,
                                     int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
@@ -335,30 +337,32 @@ int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const floa
 /*
  * Backward of anemoi_gt_edge_attention_folded (the edge half of SURVEY.md section 8f-1; what torch.autograd derives from
  * GraphTransformerConv.message / softmax / aggregate, layers/conv.py:98-142, plus lin_edge through the fold).
- * With s_e = scale (q_i.k_j + u_i.a_e), alpha = softmax over the in-edges of i, out_i = sum alpha v_j (+ x_r),
- * t_i = sum alpha a_e, and dsum[i, h] = sum_e alpha_e (dout_i,h.v_j,h + dt_i,h.a_e) accumulated in f32 by the kernel
- * (the forward's result is not needed):
- *   _dst  (forward CSR):     alpha[E, H], ds[E, H] = alpha (dout_i.v_j + dt_i.a_e - dsum) (f32),
- *                            dq_i = scale sum_e ds k_j,  du_i = scale sum_e ds a_e (f32 [n_dst, H*up])
+ * With s_e = scale (q_i.k_j + u_i.a_e), alpha_e = exp(s_e - lse_i) (lse: the forward's optional output), out_i = sum alpha
+ * v_j (+ x_r), t_i = sum alpha a_e, and for the incoming gradients dout [n_dst, C] and dt [n_dst, H*up]:
+ *   w_e = alpha_e (dout_i,h.v_j,h + dt_i,h.a_e),   dsum[i, h] = sum_e w_e,   ds_e = w_e - alpha_e dsum[i, h]
+ *   _dst  (forward CSR, ONE sweep over the in-edges):  alpha[E, H], w[E, H], dsum[n_dst, H] (f32);
+ *                            dq_i = scale sum_e ds k_j,  du_i = scale sum_e ds a_e   (activation dtype, any leading dim)
  *   _src  (transposed CSR):  dk_j = scale sum_{e from j} ds q_i,  dv_j = sum_{e from j} alpha dout_i
- * (rowptr_t [n_src+1], eid_t [E] = position of the edge in the forward CSR, dst_t [E] = its destination).  The gradient
- * of the edge attributes follows from alpha, ds, u and dt per edge and is formed by the caller.  No atomics.
+ *   anemoi_gt_edge_attr_grad: dattr[e, a] = sum_h (scale ds[e, h] u[dst(e), h, a] + alpha[e, h] dt[dst(e), h, a]), the
+ *                            gradient of the edge attributes [E, up] (CSR order; trainable edge tensor columns included)
+ * (rowptr_t [n_src+1], eid_t [E] = position of the edge in the forward CSR, dst_t [E] = its destination; u / dt / du are
+ * [n_dst, H*up] column ranges in the activation dtype, dst_of_edge [E] the destination of every CSR slot).  dsum is
+ * accumulated in f32 over the edges, never rebuilt from the forward's rounded output.  No atomics.
  */
 int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
-                                                 int64_t ldkv, const void* dout, int64_t ldd, const float* u,
-                                                 const float* dt, const float* edge_attr, int up,
-                                                 const int32_t* rowptr, const int32_t* col, float* alpha, float* ds,
-                                                 void* dq, int64_t lddq, float* du, int64_t n_dst, int C, int H,
-                                                 anemoi_stream_t stream);
+                                                 int64_t ldkv, const void* dout, int64_t ldd, const void* u, int64_t ldu,
+                                                 const void* dt, int64_t lddt, const float* lse, const float* edge_attr,
+                                                 int up, const int32_t* rowptr, const int32_t* col, float* alpha,
+                                                 float* w, float* dsum, void* dq, int64_t lddq, void* du, int64_t lddu,
+                                                 int64_t n_dst, int C, int H, anemoi_stream_t stream);
 int anemoi_gt_edge_attention_folded_backward_src(int dtype, const void* q, int64_t ldq, const void* dout, int64_t ldd,
-                                                 const float* alpha, const float* ds, const int32_t* rowptr_t,
-                                                 const int32_t* eid_t, const int32_t* dst_t, void* dk, void* dv,
-                                                 int64_t ldg, int64_t n_src, int C, int H, anemoi_stream_t stream);
-/* dattr[e, a] = sum_h (ds[e, h] u[dst(e), h, a] / sqrt(D) + alpha[e, h] dt[dst(e), h, a]): gradient of the edge attributes
- * [E, up] (CSR order; the trainable edge tensor's columns included) from the _dst kernel's alpha / ds. */
-int anemoi_gt_edge_attr_grad(const float* alpha, const float* ds, const float* u, const float* dt,
-                             const int32_t* dst_of_edge, float* dattr, int64_t n_edges, int H, int up, int D,
-                             anemoi_stream_t stream);
+                                                 const float* alpha, const float* w, const float* dsum,
+                                                 const int32_t* rowptr_t, const int32_t* eid_t, const int32_t* dst_t,
+                                                 void* dk, void* dv, int64_t ldg, int64_t n_src, int C, int H,
+                                                 anemoi_stream_t stream);
+int anemoi_gt_edge_attr_grad(int dtype, const float* alpha, const float* w, const float* dsum, const void* u, int64_t ldu,
+                             const void* dt, int64_t lddt, const int32_t* dst_of_edge, float* dattr, int64_t n_edges,
+                             int H, int up, int D, anemoi_stream_t stream);
 
 #ifdef __cplusplus
 }
