@@ -399,12 +399,40 @@ def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_at
 
 
 # ------------------------------------------------------------------------------------------ the whole flat model
+class _PermuteRows(torch.autograd.Function):
+    """``x[perm]`` for a PERMUTATION ``perm`` of the rows (an edge plan's ``perm`` / its inverse): the backward is the
+    inverse row copy, not the sort-based accumulation torch derives for a general advanced index (1.7 ms per step on the
+    542 080-edge attribute matrices of config 3)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, perm: Tensor):
+        if perm.shape[0] != x.shape[0]:
+            raise ValueError("permute_rows: the index must be a permutation of the rows")
+        ctx.save_for_backward(perm)
+        return x.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (perm,) = ctx.saved_tensors
+        out = torch.empty_like(g)
+        out.index_copy_(0, perm, g)
+        return out, None
+
+
+def permute_rows(x: Tensor, perm: Tensor) -> Tensor:
+    """Differentiable ``x[perm]`` for a row permutation ``perm`` (int64)."""
+    return _PermuteRows.apply(x, perm)
+
+
 def _edge_attr_csr(edge_attr_buf: Tensor, trainable: Optional[Tensor], plan, up: int, batch_size: int = 1) -> Tensor:
     """``[edge_attr | trainable | 1 | 0-pad]`` f32 in the plan's CSR order (what ``anemoi_edge_attr_csr`` builds in the
     inference path), as torch ops: differentiable w.r.t. the trainable edge tensor.  ``batch_size`` > 1: the plan spans
     the batched graph, the attributes repeat per sample (reference layers/graph.py:37-44)."""
     parts = [edge_attr_buf.float()] + ([] if trainable is None else [trainable.float()])
-    attr = torch.cat(parts, dim=1).repeat(batch_size, 1)[plan.perm.long()]
+    attr = torch.cat(parts, dim=1).repeat(batch_size, 1)
+    perm = plan.perm.long()
+    # a whole-graph plan permutes the rows; a rank-local plan of the node-partitioned run selects its edges
+    attr = permute_rows(attr, perm) if perm.shape[0] == attr.shape[0] else attr[perm]
     e, dim = attr.shape
     tail = torch.zeros((e, up - dim), dtype=torch.float32, device=attr.device)
     tail[:, 0] = 1.0

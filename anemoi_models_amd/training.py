@@ -148,7 +148,7 @@ def _set_plan_and_attrs(mod, n_src: int, n_dst: int, batch_size: int, up: Option
     trainable = mod.trainable.trainable
     if up is None:  # GNN: the plain attribute matrix
         parts = [mod.edge_attr.float()] + ([] if trainable is None else [trainable.float()])
-        return plan, torch.cat(parts, dim=1).repeat(batch_size, 1)[plan.perm.long()]
+        return plan, autograd.permute_rows(torch.cat(parts, dim=1).repeat(batch_size, 1), plan.perm.long())
     return plan, autograd._edge_attr_csr(mod.edge_attr, trainable, plan, up, batch_size)
 
 
@@ -234,7 +234,7 @@ def _csr_round_trip(plan, edge_attr: Tensor, dtype):
     perm = plan.perm.long()
     inv = torch.empty_like(perm)
     inv[perm] = torch.arange(perm.shape[0], device=perm.device)
-    return _cast(edge_attr, dtype).index_select(0, perm), inv
+    return autograd.permute_rows(_cast(edge_attr, dtype), perm), inv
 
 
 def gnn_processor_block(block, x: Tensor, edge_attr: Tensor, edge_index: Tensor, size=None):
@@ -244,7 +244,7 @@ def gnn_processor_block(block, x: Tensor, edge_attr: Tensor, edge_index: Tensor,
     plan = block._plans.get(edge_index, n, n)
     e_csr, inv = _csr_round_trip(plan, edge_attr, dtype)
     x_new, e_new = gnn_processor_block_csr(block, _cast(x, dtype), e_csr, plan)
-    return x_new, e_new.index_select(0, inv)
+    return x_new, autograd.permute_rows(e_new, inv)
 
 
 def gnn_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None):
@@ -256,7 +256,7 @@ def gnn_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None)
     plan = block._plans.get(edge_index, n_src, n_dst)
     e_csr, inv = _csr_round_trip(plan, edge_attr, dtype)
     nodes, e_new = gnn_mapper_block_csr(block, _cast(x_src, dtype), _cast(x_dst, dtype), e_csr, plan)
-    return nodes, e_new.index_select(0, inv)
+    return nodes, autograd.permute_rows(e_new, inv)
 
 
 def gnn_processor(proc, x: Tensor, batch_size: int) -> Tensor:
@@ -336,7 +336,12 @@ def _node_rows(model, name: str, rows: int) -> Tensor:
 
 def _finish(model, out: Tensor, x: Tensor, b: int, ens: int, g: int) -> Tensor:
     y = out.float().reshape(b, ens, g, -1).to(x.dtype).clone()
-    y[..., model._internal_output_idx] = y[..., model._internal_output_idx] + x[:, -1, :, :, model._internal_input_idx]
+    key = ("prognostic_long", str(x.device))  # index tensors resident on the device: a Python list here costs an upload
+    if key not in model._idx_cache:           # and a device synchronisation per step
+        model._idx_cache[key] = tuple(torch.as_tensor(i).to(device=x.device, dtype=torch.int64)
+                                      for i in (model._internal_output_idx, model._internal_input_idx))
+    o_idx, i_idx = model._idx_cache[key]
+    y[..., o_idx] = y[..., o_idx] + x[:, -1].index_select(-1, i_idx)
     for bounding in model.boundings:  # in-place clamps on the cloned output: plain differentiable torch ops
         y = bounding(y)
     return y

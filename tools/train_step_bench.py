@@ -35,6 +35,22 @@ for _ in range(steps):
     loss = step()
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
+# where the step's wall time goes: host enqueue (the launches of the differentiable route are issued from Python) vs GPU
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+y = model(x)
+t_host_f = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_f = time.perf_counter() - t0
+loss_t = ((y - target) ** 2).mean()
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+loss_t.backward()
+t_host_b = time.perf_counter() - t1
+torch.cuda.synchronize()
+t_b = time.perf_counter() - t1
+print(f"{workload}: differentiable forward {t_f * 1e3:.1f} ms (host enqueue {t_host_f * 1e3:.1f}), backward {t_b * 1e3:.1f} ms "
+      f"(host enqueue {t_host_b * 1e3:.1f})", flush=True)
 layers = bench.WORKLOADS[workload][2]
 print(f"{workload}: forward + backward {ms:.1f} ms / step = {graph['hidden'].num_nodes * layers / ms * 1e3:.3e} mesh-node updates/s "
       f"(loss {loss:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)", flush=True)
