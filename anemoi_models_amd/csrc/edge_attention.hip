@@ -918,6 +918,144 @@ extern "C" int anemoi_gt_edge_attention(int dtype, const void* q, int64_t ldq, c
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention: dtype %d", dtype);
 }
 
+// ---------------------------------------------------------------------------------------------
+// GraphTransformerConv as the reference exposes it (layers/conv.py:98-142): the per-edge features e_ij = lin_edge(a_ij)
+// arrive as an explicit [E, C] matrix (CSR order) instead of being folded away:
+//     s = q_i . (k_j + e_ij) / sqrt(D),  alpha = segment_softmax_i(s) (+1e-16),  out_i = sum_j alpha (v_j + e_ij).
+// Same wave / lane mapping and online softmax as the fused kernels; the edge rows are streamed (read once, in order), so
+// this costs 2 C bytes per edge more than the folded kernel -- it exists for callers that use the conv on its own.
+// ---------------------------------------------------------------------------------------------
+struct EdgeConvParams {
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* e;  // [E, lde] CSR order
+  void* out;
+  int64_t ldq, ldkv, lde, ldo;
+  int64_t n_dst;
+  int C, D, n_slices;
+  float scale;
+};
+
+template <typename T, int VEC, int LPH>
+__global__ __launch_bounds__(256) void gt_conv_kernel(const EdgeConvParams p, const int32_t* __restrict__ rowptr_,
+                                                      const int32_t* __restrict__ col_) {
+  using Raw = typename RawVec<T, VEC>::type;
+  constexpr int U = 2;
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
+  const int slice = wave_in_xcd % p.n_slices;
+  const int64_t node_first = wave_in_xcd / p.n_slices;
+  const int64_t node_stride = waves_per_xcd / p.n_slices;
+  const int64_t n0 = p.n_dst * xcd / 8, n1 = p.n_dst * (xcd + 1) / 8;
+  const int lanes_total = p.C / VEC;
+  const int gl = slice * 64 + lane;
+  const bool active = gl < lanes_total;
+  const int c0 = (active ? gl : 0) * VEC;
+  const T* qb = static_cast<const T*>(p.q) + c0;
+  const T* kb = static_cast<const T*>(p.k) + c0;
+  const T* vb = static_cast<const T*>(p.v) + c0;
+  const T* eb = static_cast<const T*>(p.e) + c0;
+  for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
+    const int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
+    float qf[VEC], acc[VEC];
+    VecIO<T, VEC>::load(qb + node * p.ldq, qf);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int e = e_begin; e < e_end; e += U) {
+      Raw kr[U], vr[U], er[U];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          const int64_t j = col_[e + uu];
+          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
+          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
+          er[uu] = *reinterpret_cast<const Raw*>(eb + (int64_t)(e + uu) * p.lde);
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          float kk[VEC], vv[VEC], ee[VEC];
+          unpack<T, VEC>(kr[uu], kk);
+          unpack<T, VEC>(vr[uu], vv);
+          unpack<T, VEC>(er[uu], ee);
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) t = fmaf(qf[i], kk[i] + ee[i], t);
+          const float s = group_sum<LPH>(t) * p.scale;
+          const float mn = fmaxf(m, s);
+          const float corr = __expf(m - mn), pe = __expf(s - mn);
+          l = l * corr + pe;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i] + ee[i], acc[i] * corr);
+          m = mn;
+        }
+      }
+    }
+    const float inv = 1.0f / (l + 1e-16f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] *= inv;
+    if (active) VecIO<T, VEC>::store(static_cast<T*>(p.out) + node * p.ldo + c0, acc);
+  }
+}
+
+template <typename T>
+static bool dispatch_conv(const EdgeConvParams& p, const int32_t* rowptr, const int32_t* col, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (p.D % VEC != 0 || p.C % VEC != 0) return false;
+  const int64_t units_per_xcd = ((p.n_dst + 7) / 8) * p.n_slices;
+  int64_t bpx = (units_per_xcd + 3) / 4;
+  if (bpx > 32 * 5) bpx = 32 * 5;
+  if (bpx < 1) bpx = 1;
+  while ((bpx * 4) % p.n_slices != 0) ++bpx;
+  const dim3 grid((unsigned)(8 * bpx)), block(256);
+  switch (p.D / VEC) {
+#define ANEMOI_CONV(L)                                                                        \
+  case L:                                                                                     \
+    hipLaunchKernelGGL((gt_conv_kernel<T, VEC, L>), grid, block, 0, st, p, rowptr, col);       \
+    return true;
+    ANEMOI_CONV(1)
+    ANEMOI_CONV(2)
+    ANEMOI_CONV(4)
+    ANEMOI_CONV(8)
+    ANEMOI_CONV(16)
+#undef ANEMOI_CONV
+    default: return false;
+  }
+}
+
+extern "C" int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                              const void* edges, int64_t lde, const int32_t* rowptr, const int32_t* col, void* out,
+                              int64_t ldo, int64_t n_dst, int C, int H, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(q && k && v && out && rowptr, ANEMOI_ERR_INVALID, "anemoi_gt_conv: null pointer");
+  ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0 && n_dst >= 0 && ldq >= C && ldkv >= C && ldo >= C && lde >= C,
+                 ANEMOI_ERR_INVALID, "anemoi_gt_conv: bad shape");
+  if (n_dst == 0) return ANEMOI_OK;
+  ANEMOI_REQUIRE(col != nullptr && edges != nullptr, ANEMOI_ERR_INVALID, "anemoi_gt_conv: null edge arrays");
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
+  ANEMOI_REQUIRE((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)edges % 16 == 0 &&
+                     (uintptr_t)out % 16 == 0 && ldq % vec == 0 && ldkv % vec == 0 && lde % vec == 0 && ldo % vec == 0,
+                 ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv: operands must be 16-byte aligned");
+  EdgeConvParams p;
+  p.q = q; p.k = k; p.v = v; p.e = edges; p.out = out;
+  p.ldq = ldq; p.ldkv = ldkv; p.lde = lde; p.ldo = ldo;
+  p.n_dst = n_dst; p.C = C; p.D = C / H;
+  p.n_slices = (C + 64 * vec - 1) / (64 * vec);
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  bool ok = false;
+  if (dtype == ANEMOI_F32) ok = dispatch_conv<float>(p, rowptr, col, as_stream(stream));
+  else if (dtype == ANEMOI_BF16) ok = dispatch_conv<bf16_t>(p, rowptr, col, as_stream(stream));
+  else return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv: dtype %d", dtype);
+  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv: head size %d needs a multiple of %d channels (<= %d)", C / H, vec,
+                 16 * vec);
+  return check_launch("anemoi_gt_conv");
+}
+
 extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
                                                int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
                                                const float* edge_attr, int up, const int32_t* rowptr,

@@ -34,6 +34,7 @@ class GraphTransformerConv(nn.Module):
         super().__init__()
         self.out_channels = out_channels
         self.dropout = dropout
+        self._plans = None  # plan cache of the stand-alone forward (runtime.PlanCache, created on first use)
 
     def fused(self, query: Tensor, key: Tensor, value: Tensor, x_r: Optional[Tensor], edge_attr_csr: Tensor,
               edge_dim: int, w_edge: Tensor, b_edge: Tensor, plan: EdgePlan, num_heads: int) -> Tensor:
@@ -47,11 +48,37 @@ class GraphTransformerConv(nn.Module):
         return ops.gt_edge_attention(query, key, value, x_r, edge_attr_csr, edge_dim, w_edge, b_edge, plan.rowptr,
                                      plan.col, num_heads)
 
-    def forward(self, query, key, value, edge_attr, edge_index, size=None):
-        raise NotImplementedError(
-            "GraphTransformerConv is fused with lin_edge on the MI355X path: call it through "
-            "GraphTransformerProcessorBlock / GraphTransformerMapperBlock (or use .fused())"
-        )
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, edge_attr: Tensor, edge_index: Tensor,
+                size=None) -> Tensor:
+        """The reference's call (layers/conv.py:98-142): ``query [N_dst, H, D]``, ``key / value [N_src, H, D]``,
+        ``edge_attr [E, H, D]`` (= ``lin_edge`` of the raw attributes), ``edge_index [2, E]`` -> ``[N_dst, H, D]``.
+        One kernel (``anemoi_gt_conv``) over a destination-sorted plan that is cached per ``edge_index`` tensor.  The
+        block mirrors do not come through here (they fold ``lin_edge`` into the neighbouring GEMMs); inference only."""
+        import torch
+
+        from .. import runtime
+
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("attention dropout > 0 is not implemented on the MI355X path")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (query, key, value, edge_attr)):
+            raise NotImplementedError("GraphTransformerConv.forward on its own is an inference call on the MI355X path; "
+                                      "gradients flow through the block / mapper / processor / model forwards")
+        if edge_attr is None:
+            raise ValueError("GraphTransformerConv needs edge features (the reference adds them to key and value)")
+        n_dst, heads, d = query.shape
+        n_src = key.shape[0]
+        if size is not None and tuple(size) != (n_src, n_dst):
+            raise ValueError(f"Encountered tensors with sizes {(n_src, n_dst)}, but expected size {tuple(size)}")
+        if self._plans is None:
+            self._plans = runtime.PlanCache()
+        plan = self._plans.get(edge_index, n_src, n_dst)
+        dtype = runtime.compute_dtype(query)
+        c = heads * d
+        flat = lambda t: (t if t.dtype == dtype else t.to(dtype)).reshape(t.shape[0], c).contiguous()  # noqa: E731
+        kv = torch.cat([flat(key), flat(value)], dim=1)  # one k | v buffer: the kernel gathers both with one row pitch
+        edges = flat(edge_attr).index_select(0, plan.perm.long())
+        out = ops.gt_conv(flat(query), kv[:, :c], kv[:, c:], edges, plan.rowptr, plan.col, heads)
+        return out.view(n_dst, heads, d).to(query.dtype)
 
 
 class GraphConv(nn.Module):

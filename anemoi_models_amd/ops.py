@@ -290,6 +290,29 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     return out
 
 
+def gt_conv(q: Tensor, k: Tensor, v: Tensor, edges_csr: Tensor, rowptr: Tensor, col: Tensor, num_heads: int) -> Tensor:
+    """``GraphTransformerConv`` with explicit per-edge features (reference layers/conv.py:98-142): ``q [n_dst, C]``,
+    ``k, v [n_src, C]``, ``edges_csr [E, C]`` in the CSR order of ``(rowptr, col)``; returns ``[n_dst, C]``."""
+    _dev(q, k, v, edges_csr, rowptr, col)
+    n_dst, c = _rows(q).shape
+    if _ld(_rows(k)) != _ld(_rows(v)):
+        raise ValueError("gt_conv: k and v must share their leading dimension")
+    if rowptr.dtype != torch.int32 or col.dtype != torch.int32 or rowptr.shape[0] != n_dst + 1:
+        raise ValueError("gt_conv: rowptr/col must be int32 with rowptr of length n_dst + 1")
+    if edges_csr.shape[0] != col.shape[0] or edges_csr.dtype != q.dtype:
+        raise ValueError("gt_conv: edges must be [E, C] in the activation dtype")
+    out = torch.empty((n_dst, c), dtype=q.dtype, device=q.device)
+    if col.shape[0] == 0:
+        return out.zero_()
+    alg_bytes = (2 * n_dst + 2 * k.shape[0] + col.shape[0]) * c * q.element_size() + col.shape[0] * 4 + (n_dst + 1) * 4
+    with _Timed("gt_conv", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
+        st = _lib.load().anemoi_gt_conv(dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)),
+                                        edges_csr.data_ptr(), _ld(_rows(edges_csr)), rowptr.data_ptr(), col.data_ptr(),
+                                        out.data_ptr(), _ld(out), n_dst, c, num_heads, _stream())
+    _lib.check(st, "anemoi_gt_conv")
+    return out
+
+
 def gt_edge_attention_tiled(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
                             rowptr: Tensor, tiles, num_heads: int, up: int, out: Optional[Tensor] = None,
                             ld_out: Optional[int] = None) -> Tensor:

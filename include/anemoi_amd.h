@@ -154,6 +154,16 @@ int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const
                                     int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
+ * GraphTransformerConv with explicit per-edge features (the callable the reference exposes, layers/conv.py:98-142):
+ *   s_ij = q_i . (k_j + e_ij) / sqrt(D),  alpha = softmax over the in-edges of i (+1e-16),  out_i = sum_j alpha (v_j + e_ij)
+ * q [n_dst, C], k / v [n_src, C], edges [E, C] in the CSR order of (rowptr, col) (= lin_edge(edge_attr)[perm]), all in
+ * the activation dtype.  The block mirrors never call this (they fold lin_edge away, see above).
+ */
+int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* edges,
+                   int64_t lde, const int32_t* rowptr, const int32_t* col, void* out, int64_t ldo, int64_t n_dst, int C,
+                   int H, anemoi_stream_t stream);
+
+/*
  * The folded edge phase with LDS staging of the source rows (same inputs / outputs as anemoi_gt_edge_attention_folded,
  * same reference lines: layers/conv.py:98-142 + PyG propagate / softmax / scatter): destinations are cut into tiles of 64
  * consecutive rows; persistent workgroups walk the tile-major (tile, head) list, copy the tile's UNIQUE source rows

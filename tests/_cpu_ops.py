@@ -80,6 +80,19 @@ def gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, rowptr, col, num_heads,
     return F.pad(res, (0, ld - res.shape[1])).to(q.dtype)
 
 
+def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads):
+    n_dst, c = q.shape
+    d = c // num_heads
+    dst = torch.repeat_interleave(torch.arange(n_dst), (rowptr[1:] - rowptr[:-1]).long())
+    src = col.long()
+    e = edges_csr.float().reshape(-1, num_heads, d)
+    kj = k.float().reshape(-1, num_heads, d)[src] + e
+    vj = v.float().reshape(-1, num_heads, d)[src] + e
+    score = (q.float().reshape(n_dst, num_heads, d)[dst] * kj).sum(-1) / d**0.5
+    alpha = segment_softmax(score, dst, n_dst)
+    return scatter_sum(vj * alpha.unsqueeze(-1), dst, n_dst).reshape(n_dst, c).to(q.dtype)
+
+
 def gt_edge_attention_tiled(q, k, v, x_r, u, edge_attr, rowptr, tiles, num_heads, up, out=None, ld_out=None):
     """CPU stand-in of anemoi_gt_edge_attention_tiled: the source of every CSR slot is rebuilt from the TILING alone
     (tile list + local slot), so the host-logic tests exercise runtime.edge_tiles as well."""
@@ -216,6 +229,6 @@ def install(monkeypatch):
     import anemoi_models_amd.ops as ops
 
     for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded", "gt_edge_attention_tiled",
-                 "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
+                 "gt_conv", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                  "prognostic_residual", "finalize_output", "bound_output", "advance_input", "convert_pad", "add", "act_forward"):
         monkeypatch.setattr(ops, name, globals()[name])

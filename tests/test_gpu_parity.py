@@ -143,6 +143,34 @@ def _edge_case(n_src, n_dst, e, c, h, edge_dim, seed):
     return ei, q, k, v, xr, ea, we, be
 
 
+@pytest.mark.parametrize("dtype,n_src,n_dst,e,c,h", [
+    (torch.float32, 180, 90, 500, 64, 16), (torch.float32, 300, 200, 2000, 512, 16), (torch.bfloat16, 120, 100, 900, 1024, 16),
+    (torch.bfloat16, 150, 150, 700, 128, 16), (torch.float32, 20, 10, 0, 64, 16),
+])
+def test_graph_transformer_conv_module_forward(dtype, n_src, n_dst, e, c, h):
+    """GraphTransformerConv.forward as the reference calls it (layers/conv.py:98-142: q / k / v [N, H, D], projected edge
+    features [E, H, D], edge_index) on anemoi_gt_conv vs oracle.gt_conv -- isolated and high in-degree destinations."""
+    from anemoi_models_amd.layers.conv import GraphTransformerConv
+
+    g = torch.Generator().manual_seed(n_src + e)
+    d = c // h
+    ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, max(n_dst - 1, 1), (e,), generator=g)])
+    if e > 50:
+        ei[1, :45] = 3
+    q, k, v = (torch.randn(n, h, d, generator=g).to(dtype) for n in (n_dst, n_src, n_src))
+    edges = torch.randn(e, h, d, generator=g).to(dtype)
+    want = ref.gt_conv(q.float(), k.float(), v.float(), edges.float(), ei, n_dst)
+    conv = GraphTransformerConv(out_channels=d).eval()
+    with torch.no_grad():
+        got = conv(q.to(DEV), k.to(DEV), v.to(DEV), edges.to(DEV), ei.to(DEV), size=(n_src, n_dst))
+        again = conv(q.to(DEV), k.to(DEV), v.to(DEV), edges.to(DEV), ei.to(DEV))  # cached plan
+    assert got.shape == (n_dst, h, d) and got.dtype == dtype
+    assert rel_err(got, want) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert torch.equal(got, again)
+    with pytest.raises(ValueError):
+        conv(q.to(DEV), k.to(DEV), v.to(DEV), edges.to(DEV), ei.to(DEV), size=(n_src + 1, n_dst))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("n_src,n_dst,e,c,h,edge_dim", [
     (180, 90, 500, 64, 16, 11),     # cfg1 shape class: D=4

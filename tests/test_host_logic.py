@@ -478,3 +478,22 @@ def test_edge_tiles_reproduce_the_plan():
             assert sorted(rows.tolist()) == list(range(lo, hi)) and torch.all(order[k][hi - lo:] == -1)
             assert torch.all(deg[rows][1:] <= deg[rows][:-1])
         assert runtime.edge_tiles(plan) is t  # cached on the plan
+
+
+def test_graph_transformer_conv_forward_host_wiring(monkeypatch):
+    """GraphTransformerConv.forward (reference layers/conv.py:98-142 call signature): plan, CSR permutation of the edge
+    features and reshapes around the kernel, on the CPU stand-in, against oracle.gt_conv."""
+    import _cpu_ops
+    from anemoi_models_amd.layers.conv import GraphTransformerConv
+    from oracle import reference_path as ref
+
+    _cpu_ops.install(monkeypatch)
+    g = torch.Generator().manual_seed(11)
+    n_src, n_dst, e, h, d = 40, 25, 300, 4, 8
+    ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, n_dst - 1, (e,), generator=g)])
+    q, k, v = (torch.randn(n, h, d, generator=g) for n in (n_dst, n_src, n_src))
+    edges = torch.randn(e, h, d, generator=g)
+    with torch.no_grad():
+        got = GraphTransformerConv(out_channels=d).eval()(q, k, v, edges, ei, size=(n_src, n_dst))
+    torch.testing.assert_close(got, ref.gt_conv(q, k, v, edges, ei, n_dst), atol=1e-5, rtol=1e-5)
+    assert float(got[n_dst - 1].abs().max()) == 0.0  # isolated destination
