@@ -31,14 +31,14 @@ if what in ("transpose", "all"):
     for rows, cols in ((40962, 1024), (40962, 4096), (542080, 1024), (40962, 192)):
         x = torch.randn(rows, cols, device=dev).bfloat16()
         y = torch.empty_like(x)
-        gb = 2 * x.numel() * 2 / 1e9
+        gb = 2 * x.numel() * 2 / 1e6  # GB moved per call / time in ms = TB/s
         t_copy = timed(lambda: y.copy_(x))
         t_tr = timed(lambda: ops.transpose(x, ops.round_up(rows, 64)))
         t_torch = timed(lambda: x.t().contiguous())
         t_cs = timed(lambda: ops.col_sum(x))
-        print(f"[{rows} x {cols}] bf16: copy {t_copy * 1e3:7.1f} us ({gb / t_copy:6.0f} GB/s)  ops.transpose {t_tr * 1e3:7.1f} us "
-              f"({gb / t_tr:6.0f} GB/s)  torch t().contiguous() {t_torch * 1e3:7.1f} us  col_sum {t_cs * 1e3:7.1f} us "
-              f"({gb / 2 / t_cs:6.0f} GB/s)")
+        print(f"[{rows} x {cols}] bf16: copy {t_copy * 1e3:7.1f} us ({gb / t_copy / 1e3:4.1f} TB/s)  ops.transpose {t_tr * 1e3:7.1f} us "
+              f"({gb / t_tr / 1e3:4.1f} TB/s)  torch t().contiguous() {t_torch * 1e3:7.1f} us  col_sum {t_cs * 1e3:7.1f} us "
+              f"({gb / 2 / t_cs / 1e3:4.1f} TB/s)")
 
 if what in ("edge", "all"):
     from anemoi_models_amd.graphs.synthetic import build_graph
