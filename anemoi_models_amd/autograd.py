@@ -63,6 +63,11 @@ class _Linear(torch.autograd.Function):
         else:
             # the pre-activation is an output of its own here (the backward needs act'(pre)); the activation and the
             # residual then run on the stored value instead of in the GEMM epilogue
+            if residual is None and act in ("GELU", "SiLU", "ReLU") and w.shape[0] % (16 // w.element_size()) == 0:
+                pre, y = ops.linear_dual(xk, w, b, act)  # one launch: the pre-activation is a second output
+                ctx.save_for_backward(xk, weight, pre)
+                ctx.act, ctx.has_bias, ctx.has_res, ctx.k, ctx.x_cols = act, bias is not None, False, k, x.shape[1]
+                return y
             pre = ops.linear(xk, w, b)
             if pre.shape[1] % (16 // pre.element_size()) == 0:
                 y = ops.act_forward(pre, act, residual)
@@ -96,9 +101,12 @@ class _Linear(torch.autograd.Function):
             if _DW_LIBRARY_GEMM:
                 # a plain TN GEMM (reduction over the rows): the BLAS library takes it without transposed copies
                 dw = torch.mm(dpre.t(), xk[:, :k] if xk.shape[1] != k else xk).to(weight.dtype)
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
+                dw, db = ops.weight_grad(dpre, xk, k, want_bias=True)  # the bias gradient rides on dpre's transpose
+                dw = dw.to(weight.dtype)
             else:
                 dw = ops.weight_grad(dpre, xk, k).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_sum(dpre)
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = dy

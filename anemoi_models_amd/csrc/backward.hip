@@ -70,16 +70,23 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 // operands) take an element-wise path in the same kernel.  The LDS kernel above moved 1.9 TB/s (eight 2-byte LDS reads
 // per 16 bytes written).
 // ---------------------------------------------------------------------------------------------
+// ``colsum`` (optional, bf16 sources): partial column sums [gridDim.z * tiles_per_chunk, cols] f32 -- row tile t of chunk
+// z leaves the sums of its 64 source rows in row z * tiles_per_chunk + t.  The bias gradient (column sums of dpre) then
+// costs one pass over that small matrix instead of a second pass over dpre (anemoi_col_sum: 6.4 ms per config-3 step).
 __global__ __launch_bounds__(256) void transpose_b16_kernel(const uint16_t* __restrict__ src, int64_t ld_src,
                                                             uint16_t* __restrict__ dst, int64_t ld_dst, int64_t rows,
-                                                            int cols, int64_t chunk) {
+                                                            int cols, int64_t chunk, float* __restrict__ colsum,
+                                                            int tiles_per_chunk) {
   src += (int64_t)blockIdx.z * chunk * ld_src;
   dst += (int64_t)blockIdx.z * cols * ld_dst;
   rows = rows - (int64_t)blockIdx.z * chunk < chunk ? rows - (int64_t)blockIdx.z * chunk : chunk;
   const int lane = threadIdx.x & 63;
-  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;  // a wave per tile, four row tiles per block
+  const int tile_r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // a wave per tile, four row tiles per block
+  const int64_t r0 = (int64_t)tile_r * 64;
   const int c0 = blockIdx.y * 64;
   if (r0 >= ld_dst) return;
+  float* cs_row = colsum != nullptr && tile_r < tiles_per_chunk
+                      ? colsum + ((int64_t)blockIdx.z * tiles_per_chunk + tile_r) * cols : nullptr;
   const bool whole = ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (ld_src % 8 == 0) && (ld_dst % 8 == 0) &&
                      c0 + 64 <= cols && r0 + 64 <= rows;
   if (whole) {
@@ -100,6 +107,30 @@ __global__ __launch_bounds__(256) void transpose_b16_kernel(const uint16_t* __re
       }
       *reinterpret_cast<uint4*>(dst + (int64_t)(c0 + cp + c) * ld_dst + r0 + rg) = make_uint4(o[0], o[1], o[2], o[3]);
     }
+    if (cs_row != nullptr) {  // column sums of the tile: this lane's 8 rows, then the 8 row groups (lane bits 3..5)
+      float cs[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t* wv = reinterpret_cast<const uint32_t*>(&in[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cs[2 * j] += __uint_as_float(wv[j] << 16);
+          cs[2 * j + 1] += __uint_as_float(wv[j] & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cs[j] += __shfl_xor(cs[j], 8, 64);
+        cs[j] += __shfl_xor(cs[j], 16, 64);
+        cs[j] += __shfl_xor(cs[j], 32, 64);
+      }
+      if (rg == 0) {
+        *reinterpret_cast<float4*>(cs_row + c0 + cp) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(cs_row + c0 + cp + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+      }
+    }
     return;
   }
   // ragged tile: element-wise, output-major (lanes along the output row), zero fill behind the last source row
@@ -107,6 +138,11 @@ __global__ __launch_bounds__(256) void transpose_b16_kernel(const uint16_t* __re
     const int c = idx >> 6;
     const int64_t r = r0 + (idx & 63);
     if (c0 + c < cols && r < ld_dst) dst[(int64_t)(c0 + c) * ld_dst + r] = r < rows ? src[r * ld_src + c0 + c] : (uint16_t)0;
+  }
+  if (cs_row != nullptr && c0 + lane < cols) {  // lane = column: the tile's (at most 64) valid rows
+    float t = 0.f;
+    for (int64_t r = r0; r < r0 + 64 && r < rows; ++r) t += __uint_as_float((uint32_t)src[r * ld_src + c0 + lane] << 16);
+    cs_row[c0 + lane] = t;
   }
 }
 
@@ -443,16 +479,23 @@ int anemoi_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int6
   else if (dtype == ANEMOI_BF16)
     hipLaunchKernelGGL(transpose_b16_kernel, dim3((unsigned)((ld_dst + 255) / 256), grid.y), dim3(256), 0,
                        bw_stream(stream), static_cast<const uint16_t*>(src), ld_src, static_cast<uint16_t*>(dst), ld_dst,
-                       rows, cols, rows);
+                       rows, cols, rows, static_cast<float*>(nullptr), 0);
   else
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose: dtype %d", dtype);
   return check_launch("anemoi_transpose");
 }
 
+int64_t anemoi_transpose_colsum_rows(int64_t rows, int64_t chunk_rows) {
+  if (rows <= 0 || chunk_rows <= 0) return 0;
+  return ((rows + chunk_rows - 1) / chunk_rows) * ((chunk_rows + 63) / 64);
+}
+
 int anemoi_transpose_chunked(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
-                             int64_t chunk_rows, anemoi_stream_t stream) {
+                             int64_t chunk_rows, float* colsum_partial, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(src && dst && rows > 0 && cols > 0 && chunk_rows > 0 && ld_src >= cols && ld_dst >= chunk_rows,
                  ANEMOI_ERR_INVALID, "anemoi_transpose_chunked: bad argument");
+  ANEMOI_REQUIRE(colsum_partial == nullptr || (dtype == ANEMOI_BF16 && cols % 4 == 0 && (uintptr_t)colsum_partial % 16 == 0),
+                 ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose_chunked: column-sum partials need bf16 and cols % 4 == 0");
   const int64_t chunks = (rows + chunk_rows - 1) / chunk_rows;
   ANEMOI_REQUIRE(chunks < 65536, ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose_chunked: too many chunks");
   const dim3 grid((unsigned)((ld_dst + 63) / 64), (unsigned)((cols + 63) / 64), (unsigned)chunks);
@@ -462,7 +505,7 @@ int anemoi_transpose_chunked(int dtype, const void* src, int64_t ld_src, void* d
   else if (dtype == ANEMOI_BF16)
     hipLaunchKernelGGL(transpose_b16_kernel, dim3((unsigned)((ld_dst + 255) / 256), grid.y, grid.z), dim3(256), 0,
                        bw_stream(stream), static_cast<const uint16_t*>(src), ld_src, static_cast<uint16_t*>(dst), ld_dst,
-                       rows, cols, chunk_rows);
+                       rows, cols, chunk_rows, colsum_partial, (int)((chunk_rows + 63) / 64));
   else
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_transpose_chunked: dtype %d", dtype);
   return check_launch("anemoi_transpose_chunked");

@@ -385,7 +385,7 @@ __device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int6
   }
 }
 
-template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false>
+template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false, bool DUAL = false>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias,
@@ -393,6 +393,10 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
                                                              bf16_t* __restrict__ Y, int64_t ldy, int64_t M, int N,
                                                              int K, int vec_ok, int64_t n_tiles, int nt_count,
                                                              LnFold ln, int m_tail) {
+  // DUAL (training forward, anemoi_linear_dual): R is a second OUTPUT [M, ldr] that receives the pre-activation
+  // x W^T + b (rounded to bf16) next to Y = act(x W^T + b) -- the backward needs act'(pre), and a separate activation
+  // pass over [M, 4C] costs more than the extra 16-byte store per lane and row group here.  No residual in this mode.
+  static_assert(!DUAL || (!HAS_RES && !LN && !RS && ACT != 0), "DUAL: activation, no residual / LayerNorm fold / row sums");
   // MH = 16-row fragments per wave along M: 8 -> the 256 x 256 tile, 4 -> a 128 x 256 tile (wave tile 64 x 128) used for
   // the rows of a remainder round (640 tiles on 256 CUs: the last 128 tiles become 256 half tiles = one full round).
   constexpr int TM = MH * 32;        // tile rows
@@ -650,7 +654,8 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     const __amdgpu_buffer_rsrc_t yrs =  // sized to the tile: masked lanes use an out-of-range offset (store dropped)
         __builtin_amdgcn_make_buffer_rsrc((void*)(Y + y_base + m0 * ldy + n0), 0, rows_here * (int)ldy * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(HAS_RES ? R + m0 * ldr + n0 : Y), 0, HAS_RES ? rows_here * (int)ldr * 2 : 0, 0x00020000);
+        (void*)((HAS_RES || DUAL) ? R + m0 * ldr + n0 : Y), 0, (HAS_RES || DUAL) ? rows_here * (int)ldr * 2 : 0,
+        0x00020000);
     // row-sum partials [row][slot] of this tile's rows; only the lanes fq == 0 store (the others: out of range)
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(RS ? ln.rs_partial + m0 * ln.rs_slots : nullptr), 0, RS ? rows_here * ln.rs_slots * 8 : 0, 0x00020000);
@@ -663,8 +668,12 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     for (int u = 0; u < 4; ++u) {
       int c = ncol + u * 32;
       vy[u] = n0 + c < N ? (fr_e * (int)ldy + c) * 2 : 0x7f000000;  // ragged last N tile: beyond the descriptor
-      c = c < N - 8 - n0 ? c : N - 8 - n0;                          // loads: clamped instead
-      vr[u] = (fr_e * (int)ldr + c) * 2;
+      if constexpr (DUAL) {
+        vr[u] = n0 + c < N ? (fr_e * (int)ldr + c) * 2 : 0x7f000000;  // second output: masked like the first
+      } else {
+        c = c < N - 8 - n0 ? c : N - 8 - n0;                        // loads: clamped instead
+        vr[u] = (fr_e * (int)ldr + c) * 2;
+      }
     }
     float bv[4][8];
 #pragma unroll
@@ -732,6 +741,14 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
           p1 += f32x2_t{bv[u][2], bv[u][3]};
           p2 += f32x2_t{bv[u][4], bv[u][5]};
           p3 += f32x2_t{bv[u][6], bv[u][7]};
+        }
+        if constexpr (DUAL) {  // the pre-activation, as the backward will read it
+          __builtin_amdgcn_raw_buffer_store_b128(
+              u32x4_t{pack_bf16x2(p0.x, p0.y), pack_bf16x2(p1.x, p1.y), pack_bf16x2(p2.x, p2.y), pack_bf16x2(p3.x, p3.y)},
+              rrs, vr[u], (wm * (MH * 16) + j * 16) * (int)ldr * 2, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");  // (the store-data hazard described below)
+          __builtin_amdgcn_sched_barrier(0);
         }
         const f32x2_t o0 = act_apply2<ACT>(p0), o1 = act_apply2<ACT>(p1), o2 = act_apply2<ACT>(p2),
                       o3 = act_apply2<ACT>(p3);
@@ -816,7 +833,8 @@ constexpr int W4_NEEDS_WHOLE_TILES = -4242;  // internal: the caller has to spli
 static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                                   int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
                                   hipStream_t st, LnFold ln = LnFold{nullptr, nullptr}, int m_tail = 0,
-                                  bool* tail_done = nullptr) {
+                                  bool* tail_done = nullptr, bool dual = false) {
+  // dual: `residual` / ldr name the second OUTPUT (pre-activation) of the DUAL instantiations; whole tiles only
   if (tail_done != nullptr) *tail_done = false;
   static bool raised = false;
   if (!raised) {
@@ -842,6 +860,17 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4_RS(true, false, 4);
     RAISE_W4_RS(true, true, 4);
 #undef RAISE_W4_RS
+#define RAISE_W4_DUAL(A, MHV)                                                                                    \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, false, false, MHV, false, true>), \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)                      \
+    return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
+    RAISE_W4_DUAL(1, 8);
+    RAISE_W4_DUAL(1, 4);
+    RAISE_W4_DUAL(2, 8);
+    RAISE_W4_DUAL(2, 4);
+    RAISE_W4_DUAL(3, 8);
+    RAISE_W4_DUAL(3, 4);
+#undef RAISE_W4_DUAL
     RAISE_W4(0, false);
     RAISE_W4(0, true);
     RAISE_W4(1, false);
@@ -901,8 +930,18 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     if (residual != nullptr) LAUNCH_W4_(A, true, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL);   \
     else LAUNCH_W4_(A, false, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL);                      \
   } while (0)
+#define LAUNCH_W4_DUAL(A, MHV, XP, RP, YP, LNV, MV, TILES)                                                            \
+  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, false, false, MHV, false, true>), dim3((unsigned)w4_blocks), dim3(256), \
+                     W4_LDS, st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,             \
+                     vec_ok ? 1 : 0, TILES, (int)nt, LNV, 0)
 #define LAUNCH_W4_ACT(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                        \
-  switch (act) {                                                                                    \
+  if (dual) {                                                                                       \
+    switch (act) {                                                                                  \
+      case ANEMOI_ACT_GELU: LAUNCH_W4_DUAL(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
+      case ANEMOI_ACT_SILU: LAUNCH_W4_DUAL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
+      default: LAUNCH_W4_DUAL(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES); break;               \
+    }                                                                                               \
+  } else switch (act) {                                                                             \
     case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
     case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
     case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
@@ -933,12 +972,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       LAUNCH_W4_ACT(4, xb + m_a * ldx, rb != nullptr ? rb + m_a * ldr : nullptr, yb + m_a * ldy, lb, m_b, tiles_b, w4_tail)
     }
 #undef LAUNCH_W4_ACT
+#undef LAUNCH_W4_DUAL
 #undef LAUNCH_W4
 #undef LAUNCH_W4_
 #undef LAUNCH_W4__
     return check_launch("anemoi_linear(256x256, 4 waves)");
   }
-  if (M % BIG_M != 0 || batched) return W4_NEEDS_WHOLE_TILES;  // (the caller splits the ragged rows off / refuses)
+  if (M % BIG_M != 0 || batched || dual) return W4_NEEDS_WHOLE_TILES;  // (the caller splits the ragged rows off / refuses)
   // shapes the persistent kernel does not take (K = 64, unaligned output, ...): the general 128 x 128 kernel
   return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
 }
@@ -1118,6 +1158,28 @@ __global__ __launch_bounds__(256) void row_sums_finalize_kernel(const float2* __
   stats[r] = make_float2(rstd, -mean * rstd);
 }
 }  // namespace anemoi
+
+// y = act(x W^T + b) AND pre = x W^T + b (bf16) from one launch of the persistent kernel (training forward: the backward
+// needs act'(pre)).  bf16, whole 256-row tiles, the fast path's shape / alignment rules; ANEMOI_ERR_UNSUPPORTED otherwise
+// (the caller then runs anemoi_linear + anemoi_act_forward).
+extern "C" int anemoi_linear_dual(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* pre,
+                                  int64_t ldp, void* y, int64_t ldy, int64_t M, int N, int K, int act,
+                                  anemoi_stream_t stream) {
+  using namespace anemoi;
+  ANEMOI_REQUIRE(x && w && pre && y, ANEMOI_ERR_INVALID, "anemoi_linear_dual: null pointer");
+  ANEMOI_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && ldp >= N, ANEMOI_ERR_INVALID,
+                 "anemoi_linear_dual: bad shape");
+  ANEMOI_REQUIRE(act > ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_linear_dual: act %d", act);
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 && M % BIG_M == 0 && N >= 256 && N % 8 == 0 && K >= 128 && K % 64 == 0 &&
+                     (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)pre % 16 == 0 &&
+                     (uintptr_t)y % 16 == 0 && ldx % 8 == 0 && ldp % 8 == 0 && ldy % 8 == 0,
+                 ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_dual: bf16, M a multiple of 256, N >= 256, K >= 128, 16-byte aligned");
+  if (M == 0) return ANEMOI_OK;
+  const int rc = linear_bf16_256_launch(x, ldx, w, bias, pre, ldp, y, ldy, M, N, K, act, as_stream(stream),
+                                        LnFold{nullptr, nullptr}, 0, nullptr, true);
+  if (rc == W4_NEEDS_WHOLE_TILES) return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_dual: shape not taken by the fast path");
+  return rc;
+}
 
 extern "C" int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const void* w, const float* bias,
                                    const float* colsum, const float* stats_in, const void* residual, int64_t ldr,

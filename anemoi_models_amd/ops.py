@@ -592,6 +592,31 @@ def col_sum(x: Tensor) -> Tensor:
     return out
 
 
+def linear_dual(x: Tensor, w: Tensor, bias: Optional[Tensor], act: str):
+    """``(pre, y) = (x @ w.T + bias, act(pre))``: the training forward of Linear + activation.  One launch
+    (``anemoi_linear_dual``) for the whole 256-row tiles of a bf16 product, the GEMM + activation pass pair for the rest."""
+    _dev(x, w, bias)
+    m, k = _rows(x).shape
+    n = w.shape[0]
+    if w.dtype != x.dtype or not w.is_contiguous() or w.shape[1] != k:
+        raise ValueError("linear_dual: weight must be contiguous [N, K] in the activation dtype, K as x")
+    m_main = (m // 256) * 256 if (x.dtype == torch.bfloat16 and n >= 256 and n % 8 == 0 and k >= 128 and k % 64 == 0
+                                  and _ld(x) % 8 == 0) else 0
+    if m_main < 1024:
+        pre = linear(x, w, bias)
+        return pre, act_forward(pre, act)
+    pre = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    with _Timed("linear", flops=2 * m_main * n * k, bytes=(m_main * k + n * k + 2 * m_main * n) * 2, m=m_main, n=n, k=k):
+        st = _lib.load().anemoi_linear_dual(dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
+                                            pre.data_ptr(), n, y.data_ptr(), n, m_main, n, k, _lib.ACT_CODES[act], _stream())
+    _lib.check(st, "anemoi_linear_dual")
+    if m_main < m:  # the ragged rows
+        linear(x[m_main:], w, bias, out=pre[m_main:])
+        y[m_main:].copy_(act_forward(pre[m_main:], act))
+    return pre, y
+
+
 def act_forward(pre: Tensor, act: str, residual: Optional[Tensor] = None) -> Tensor:
     """``act(pre) + residual`` in one pass (the differentiable Linear keeps ``pre`` for the backward)."""
     _dev(pre, residual)
@@ -637,11 +662,13 @@ def layer_norm_backward(x: Tensor, stats: Tensor, gamma: Tensor, dy: Tensor):
     return dx, dgamma, dbeta
 
 
-def weight_grad(dpre: Tensor, x: Tensor, k: int) -> Tensor:
+def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False):
     """``dW [N, k] = dpre^T @ x[:, :k]`` in f32 (``dpre [M, N]``, ``x [M, >= k]`` in the compute dtype): the reduction
     over the M rows is cut into chunks -- chunked transposes, one batched GEMM on the 128 x 128 kernel, a deterministic
     sum of the partial results -- so that a small ``[N, k]`` result still fills the chip (a 1024 x 192 gradient over
-    542 080 rows took 7 ms on 16 workgroups without the split)."""
+    542 080 rows took 7 ms on 16 workgroups without the split).  ``want_bias``: returns ``(dW, db)`` with
+    ``db = dpre.sum(0)`` (f32); for bf16 the column sums come out of the transpose of ``dpre`` (per-tile partials), not
+    out of a second pass over it."""
     _dev(dpre, x)
     m, n = _rows(dpre).shape
     kmul = k_multiple(dpre.dtype)
@@ -657,16 +684,25 @@ def weight_grad(dpre: Tensor, x: Tensor, k: int) -> Tensor:
     code = dtype_code(dpre.dtype)
     at = torch.empty((chunks, n, chunk_rows), dtype=dpre.dtype, device=dpre.device)
     bt = torch.empty((chunks, k, chunk_rows), dtype=dpre.dtype, device=dpre.device)
-    st = lib.anemoi_transpose_chunked(code, dpre.data_ptr(), _ld(dpre), at.data_ptr(), chunk_rows, m, n, chunk_rows, _stream())
+    partial = None
+    if want_bias and fast and n % 4 == 0:
+        partial = torch.empty((lib.anemoi_transpose_colsum_rows(m, chunk_rows), n), dtype=torch.float32, device=dpre.device)
+    st = lib.anemoi_transpose_chunked(code, dpre.data_ptr(), _ld(dpre), at.data_ptr(), chunk_rows, m, n, chunk_rows,
+                                      _ptr(partial), _stream())
     _lib.check(st, "anemoi_transpose_chunked")
-    st = lib.anemoi_transpose_chunked(code, x.data_ptr(), _ld(_rows(x)), bt.data_ptr(), chunk_rows, m, k, chunk_rows, _stream())
+    st = lib.anemoi_transpose_chunked(code, x.data_ptr(), _ld(_rows(x)), bt.data_ptr(), chunk_rows, m, k, chunk_rows, None,
+                                      _stream())
     _lib.check(st, "anemoi_transpose_chunked")
     part = torch.empty((chunks, n, k), dtype=dpre.dtype if fast else torch.float32, device=dpre.device)
     st = lib.anemoi_linear_batched(code, dtype_code(part.dtype), at.data_ptr(), chunk_rows, n * chunk_rows, bt.data_ptr(),
                                    k * chunk_rows, part.data_ptr(), k, n * k, chunks, n, k, chunk_rows, _stream())
     _lib.check(st, "anemoi_linear_batched")
     if part.dtype != torch.float32 and chunks == 1:
-        return part[0].float()
-    if chunks == 1:
-        return part[0]
-    return col_sum(part.view(chunks, n * k)).view(n, k)
+        dw = part[0].float()
+    elif chunks == 1:
+        dw = part[0]
+    else:
+        dw = col_sum(part.view(chunks, n * k)).view(n, k)
+    if not want_bias:
+        return dw
+    return dw, (col_sum(partial) if partial is not None else col_sum(dpre))

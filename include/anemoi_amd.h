@@ -310,9 +310,13 @@ int anemoi_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int6
                      anemoi_stream_t stream);
 
 /* Chunked form: rows [s * chunk_rows, (s + 1) * chunk_rows) of src become slab s of dst = [chunks, cols, ld_dst]
- * (ld_dst >= chunk_rows, zero filled behind the chunk's rows). */
+ * (ld_dst >= chunk_rows, zero filled behind the chunk's rows).  colsum_partial (optional, bf16 sources, cols % 4 == 0):
+ * f32 [anemoi_transpose_colsum_rows(rows, chunk_rows), cols] -- every 64-row tile leaves the column sums of its source
+ * rows there; their sum over the rows (anemoi_col_sum) is the column sum of src (the bias gradient, without a second pass
+ * over dpre). */
+int64_t anemoi_transpose_colsum_rows(int64_t rows, int64_t chunk_rows);
 int anemoi_transpose_chunked(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
-                             int64_t chunk_rows, anemoi_stream_t stream);
+                             int64_t chunk_rows, float* colsum_partial, anemoi_stream_t stream);
 
 /* `batch` independent products y[b] = x[b] w[b]^T (strides in elements; no bias / activation): the weight-gradient GEMMs
  * split their long reduction over the rows into `batch` chunks this way and add the partial [N, K] results with
@@ -333,6 +337,15 @@ int anemoi_act_forward(int dtype, int act, const void* pre, int64_t ldp, const v
 /* out = dy * act'(pre), pre = the Linear's result before its activation (ANEMOI_ACT_*; exact erf GELU derivative). */
 int anemoi_act_backward(int dtype, int act, const void* pre, int64_t ldp, const void* dy, int64_t ldd, void* out,
                         int64_t ldo, int64_t rows, int cols, anemoi_stream_t stream);
+
+/*
+ * Training forward of Linear + activation: y = act(x W^T + b) and pre = x W^T + b (rounded to the activation dtype) from
+ * ONE launch (the backward multiplies by act'(pre); nn.Linear + nn.GELU of layers/mlp.py:74-84, layers/block.py:504-508
+ * under autograd).  bf16 only, M a multiple of 256, N >= 256, K >= 128 (multiple of 64), 16-byte aligned operands;
+ * ANEMOI_ERR_UNSUPPORTED otherwise -- the caller then runs anemoi_linear followed by anemoi_act_forward.
+ */
+int anemoi_linear_dual(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* pre, int64_t ldp,
+                       void* y, int64_t ldy, int64_t M, int N, int K, int act, anemoi_stream_t stream);
 
 /*
  * LayerNorm backward from the forward's row statistics (stats [rows, 2] = { rstd, -mean * rstd }, anemoi_row_stats):

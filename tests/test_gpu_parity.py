@@ -901,6 +901,27 @@ def test_linear_backward_matches_torch_autograd(dtype, m, k, n, act, bias, res):
         assert torch.equal(rd.grad.cpu(), dy)
 
 
+@pytest.mark.parametrize("m,n,k,act", [(4100, 4096, 1024, "GELU"), (1024, 256, 128, "SiLU"), (2560, 264, 192, "ReLU"),
+                                       (40962, 1024, 256, "GELU"), (300, 512, 128, "GELU")])
+def test_linear_dual_output(m, n, k, act):
+    """ops.linear_dual (anemoi_linear_dual: pre-activation as a second output of the GEMM epilogue) against the two-pass
+    route it replaces in the training forward: the same pre-activation bit for bit, the activation within one bf16
+    rounding (it is applied to the unrounded accumulator here), ragged rows / columns included."""
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=g) / k**0.5).bfloat16().to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    pre, y = ops.linear_dual(x, w, b, act)
+    pre2 = ops.linear(x, w, b)
+    assert torch.equal(pre, pre2)
+    y2 = ops.act_forward(pre2, act)
+    assert rel_err(y, y2) < 1e-2 and float((y.float() - y2.float()).abs().max()) <= 2.0**-7 * float(y2.float().abs().max())
+    want = {"GELU": F.gelu, "SiLU": F.silu, "ReLU": F.relu}[act](x.float() @ w.float().t() + b)
+    assert rel_err(y, want) < 1e-2
+
+
 @pytest.mark.parametrize("dtype,rows,cols,ld_out", [
     (torch.bfloat16, 4096, 1024, None), (torch.bfloat16, 5121, 1216, 5184), (torch.bfloat16, 130, 72, 192),
     (torch.bfloat16, 64, 64, 64), (torch.bfloat16, 1000, 100, 1024), (torch.float32, 300, 96, 320),
@@ -929,6 +950,12 @@ def test_weight_grad_chunked_transposes(m, n, k):
     got = ops.weight_grad(dpre, x, k)
     assert got.dtype == torch.float32 and rel_err(got, want.float()) < 6e-3  # bf16 partial results per row chunk
     assert torch.equal(got, ops.weight_grad(dpre, x, k))
+    # the bias gradient from the per-tile column sums the transpose of dpre leaves behind (ragged last tiles included)
+    dw2, db = ops.weight_grad(dpre, x, k, want_bias=True)
+    assert torch.equal(dw2, got)
+    want_b = dpre.double().sum(dim=0)
+    assert float((db.double() - want_b).abs().max()) < 1e-5 * float(dpre.double().abs().sum(dim=0).max())
+    assert torch.equal(db, ops.weight_grad(dpre, x, k, want_bias=True)[1])
 
 
 @pytest.mark.parametrize("dtype,rows,cols", [(torch.bfloat16, 40962, 4288), (torch.float32, 9000, 100),
