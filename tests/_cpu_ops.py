@@ -48,6 +48,11 @@ def linear(x, w, bias=None, *, act="Identity", residual=None, out=None, out_dtyp
     return y
 
 
+def linear_dual(x, w, bias, act):
+    pre = linear(x, w, bias)
+    return pre, _ACT[act](pre.float()).to(pre.dtype)
+
+
 def edge_attr_csr(a0, a1, perm, ld_out=None, one_col=-1):
     rows = perm.long() % a0.shape[0]
     parts = [a0[rows].float()] + ([] if a1 is None else [a1[rows].float()])
@@ -228,7 +233,7 @@ def add(a, b, out=None):
 def install(monkeypatch):
     import anemoi_models_amd.ops as ops
 
-    for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded", "gt_edge_attention_tiled",
+    for name in ("layer_norm", "row_stats", "linear", "linear_dual", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded", "gt_edge_attention_tiled",
                  "gt_conv", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                  "prognostic_residual", "finalize_output", "bound_output", "advance_input", "convert_pad", "add", "act_forward"):
         monkeypatch.setattr(ops, name, globals()[name])
