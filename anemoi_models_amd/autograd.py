@@ -113,6 +113,68 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, None, dres
 
 
+class _MLP2(torch.autograd.Function):
+    """``Linear2(act(Linear1(x))) + residual`` as ONE node of the autograd graph (the node MLPs of every block,
+    reference layers/block.py:504-508, layers/mlp.py:74-84).  Forward: the pre-activation is a second output of the first
+    GEMM (``ops.linear_dual``), the residual rides in the second GEMM's epilogue.  Backward: the dX GEMM of Linear2
+    multiplies by ``act'(pre)`` in its epilogue (``ops.linear_actgrad``) and so delivers the gradient of Linear1's
+    pre-activation directly; bias gradients come from the weight-gradient transposes.  bf16 with slab-multiple widths;
+    :func:`mlp2` composes two :class:`_Linear` nodes otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act: str, residual):
+        dtype = x.dtype
+        w1p, w2p = _pack(w1, dtype), _pack(w2, dtype)
+        pre, h = ops.linear_dual(x, w1p, None if b1 is None else b1.detach().float().contiguous(), act)
+        y = ops.linear(h, w2p, None if b2 is None else b2.detach().float().contiguous(), residual=residual)
+        ctx.save_for_backward(x, w1, w2, pre, h)
+        ctx.act, ctx.has_b1, ctx.has_b2, ctx.has_res = act, b1 is not None, b2 is not None, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, pre, h = ctx.saved_tensors
+        dtype = x.dtype
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        dx = dw1 = db1 = dw2 = db2 = None
+        if need[3]:
+            if ctx.has_b2 and need[4]:
+                dw2, db2 = ops.weight_grad(dy, h, w2.shape[1], want_bias=True)
+            else:
+                dw2 = ops.weight_grad(dy, h, w2.shape[1])
+            dw2 = dw2.to(w2.dtype)
+        if db2 is None and ctx.has_b2 and need[4]:
+            db2 = ops.col_sum(dy)
+        if need[0] or need[1] or (ctx.has_b1 and need[2]):
+            # d pre = (dy W2) * act'(pre): Linear2's dX GEMM with the activation's derivative in its epilogue
+            dpre = ops.linear_actgrad(dy, ops.transpose(w2.detach().to(dtype).contiguous()), pre, ctx.act)
+            if need[1]:
+                if ctx.has_b1 and need[2]:
+                    dw1, db1 = ops.weight_grad(dpre, x, w1.shape[1], want_bias=True)
+                else:
+                    dw1 = ops.weight_grad(dpre, x, w1.shape[1])
+                dw1 = dw1.to(w1.dtype)
+            if db1 is None and ctx.has_b1 and need[2]:
+                db1 = ops.col_sum(dpre)
+            if need[0]:
+                dx = ops.linear(dpre, ops.transpose(w1.detach().to(dtype).contiguous()))
+        return dx, dw1, db1, dw2, db2, None, (dy if ctx.has_res and need[6] else None)
+
+
+def mlp2(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], act: str,
+         residual: Optional[Tensor] = None) -> Tensor:
+    """``linear(linear(x, w1, b1, act), w2, b2, residual=residual)`` -- fused into one autograd node (:class:`_MLP2`) when
+    the shapes allow the fused GEMM epilogues (bf16, every width a multiple of the 64-element K slab)."""
+    km = ops.k_multiple(x.dtype)
+    fused = (x.dtype == torch.bfloat16 and act in ("GELU", "SiLU", "ReLU") and x.shape[1] == w1.shape[1]
+             and w1.shape[1] % km == 0 and w1.shape[0] % km == 0 and w2.shape[0] % km == 0 and w2.shape[1] == w1.shape[0]
+             and x.shape[0] >= 1024 and w1.shape[0] >= 256 and w2.shape[0] >= 256 and x.is_contiguous())
+    if not fused:
+        return linear(linear(x, w1, b1, act), w2, b2, "Identity", residual)
+    return _MLP2.apply(x, w1, b1, w2, b2, act, residual)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
@@ -363,8 +425,8 @@ def _gt_tail(y_att: Tensor, x_skip: Tensor, sd: dict, prefix: str, w_t: Tensor, 
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
     y = linear(y_att, torch.cat([g("projection.weight"), w_t], dim=1), g("projection.bias"), "Identity", x_skip)
     h1 = layer_norm(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
-    h2 = linear(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), act)
-    return linear(h2, g("node_dst_mlp.3.weight"), g("node_dst_mlp.3.bias"), "Identity", y)
+    return mlp2(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), g("node_dst_mlp.3.weight"),
+                g("node_dst_mlp.3.bias"), act, y)
 
 
 def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, plan, num_heads: int,

@@ -298,6 +298,33 @@ __device__ __forceinline__ f32x2_t act_apply2(f32x2_t x) {
   }
 }
 
+// act'(x) for the backward's dX epilogue (GMUL mode of the four-wave kernel): out = acc * act'(pre).  GELU: the derivative
+// d/dx [x Phi(x)] = Phi(x) + x phi(x) as 1/2 + x_c S(x_c^2), x_c = clamp(x, +-4), S of degree 8 fitted to the exact
+// derivative on Chebyshev nodes (|error| < 5.5e-4 everywhere, 6.5e-5 inside the clamp; bf16 resolves 3.9e-3) -- the same
+// ten packed instructions per pair of values as the forward's polynomial, no transcendental.
+template <int ACT>
+__device__ __forceinline__ f32x2_t act_grad2(f32x2_t x) {
+  if constexpr (ACT == ANEMOI_ACT_GELU) {
+    const f32x2_t xc = {__builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f)};
+    const f32x2_t t = xc * xc;
+    f32x2_t q = 9.3872902156732022e-10f;
+    q = q * t + -7.9411323687314723e-08f;
+    q = q * t + 2.950694481564598e-06f;
+    q = q * t + -6.3805510857940873e-05f;
+    q = q * t + 0.00089759489254071564f;
+    q = q * t + -0.0086697042593016048f;
+    q = q * t + 0.05833774383148245f;
+    q = q * t + -0.26469170897426864f;
+    q = q * t + 0.79756480213010039f;
+    return xc * q + 0.5f;
+  } else if constexpr (ACT == ANEMOI_ACT_SILU) {
+    const f32x2_t sg = {__frcp_rn(1.0f + __expf(-x.x)), __frcp_rn(1.0f + __expf(-x.y))};
+    return sg * (x * (1.0f - sg) + 1.0f);
+  } else {
+    return f32x2_t{x.x > 0.f ? 1.f : 0.f, x.y > 0.f ? 1.f : 0.f};
+  }
+}
+
 // Tile order inside an XCD chunk: column groups of SUPER_N tile columns, row-major inside a group.  With SUPER_N = 8
 // the 32 tiles an XCD works on concurrently form a 4 x 8 patch of the output: 12 unique operand panels per K-slab step
 // in that XCD's L2 instead of 18 for the 2 x 16 patch of the plain order.  The eight-wave kernel did not care (-3 %);
@@ -385,7 +412,7 @@ __device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int6
   }
 }
 
-template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false, bool DUAL = false>
+template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false, bool DUAL = false, bool GMUL = false>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias,
@@ -397,6 +424,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   // x W^T + b (rounded to bf16) next to Y = act(x W^T + b) -- the backward needs act'(pre), and a separate activation
   // pass over [M, 4C] costs more than the extra 16-byte store per lane and row group here.  No residual in this mode.
   static_assert(!DUAL || (!HAS_RES && !LN && !RS && ACT != 0), "DUAL: activation, no residual / LayerNorm fold / row sums");
+  // GMUL (backward, anemoi_linear_actgrad): R is the saved pre-activation, the result is acc * act'(R) -- the dX GEMM of
+  // the Linear BEHIND an activation delivers the gradient of the Linear IN FRONT of it, no separate act' pass.
+  static_assert(!GMUL || (HAS_RES && !LN && !RS && !DUAL && ACT != 0), "GMUL: pre-activation in R, no other epilogue mode");
   // MH = 16-row fragments per wave along M: 8 -> the 256 x 256 tile, 4 -> a 128 x 256 tile (wave tile 64 x 128) used for
   // the rows of a remainder round (640 tiles on 256 CUs: the last 128 tiles become 256 half tiles = one full round).
   constexpr int TM = MH * 32;        // tile rows
@@ -750,11 +780,22 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
           asm volatile("s_nop 1" ::: "memory");  // (the store-data hazard described below)
           __builtin_amdgcn_sched_barrier(0);
         }
-        const f32x2_t o0 = act_apply2<ACT>(p0), o1 = act_apply2<ACT>(p1), o2 = act_apply2<ACT>(p2),
-                      o3 = act_apply2<ACT>(p3);
+        f32x2_t o0, o1, o2, o3;
+        if constexpr (GMUL) {
+          auto up2 = [](uint32_t w2) { return f32x2_t{__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u)}; };
+          o0 = p0 * act_grad2<ACT>(up2(rv[u].x));
+          o1 = p1 * act_grad2<ACT>(up2(rv[u].y));
+          o2 = p2 * act_grad2<ACT>(up2(rv[u].z));
+          o3 = p3 * act_grad2<ACT>(up2(rv[u].w));
+        } else {
+          o0 = act_apply2<ACT>(p0);
+          o1 = act_apply2<ACT>(p1);
+          o2 = act_apply2<ACT>(p2);
+          o3 = act_apply2<ACT>(p3);
+        }
         uint4 v = make_uint4(pack_bf16x2(o0.x, o0.y), pack_bf16x2(o1.x, o1.y), pack_bf16x2(o2.x, o2.y),
                              pack_bf16x2(o3.x, o3.y));
-        if constexpr (HAS_RES)
+        if constexpr (HAS_RES && !GMUL)
           v = make_uint4(bf16x2_add(v.x, rv[u].x), bf16x2_add(v.y, rv[u].y), bf16x2_add(v.z, rv[u].z),
                          bf16x2_add(v.w, rv[u].w));
         if constexpr (RS) {  // on the ROUNDED values, pairwise: v_dot2_f32_bf16 with (1, 1) and with itself
@@ -833,8 +874,10 @@ constexpr int W4_NEEDS_WHOLE_TILES = -4242;  // internal: the caller has to spli
 static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                                   int64_t ldr, void* y, int64_t ldy, int64_t M, int N, int K, int act,
                                   hipStream_t st, LnFold ln = LnFold{nullptr, nullptr}, int m_tail = 0,
-                                  bool* tail_done = nullptr, bool dual = false) {
-  // dual: `residual` / ldr name the second OUTPUT (pre-activation) of the DUAL instantiations; whole tiles only
+                                  bool* tail_done = nullptr, int epi = 0) {
+  // epi 1 (DUAL): `residual` / ldr name the second OUTPUT (pre-activation); epi 2 (GMUL): they name the saved
+  // pre-activation and the result is acc * act'(it).  Whole tiles only in both modes.
+  const bool dual = epi == 1, gmul = epi == 2;
   if (tail_done != nullptr) *tail_done = false;
   static bool raised = false;
   if (!raised) {
@@ -871,6 +914,17 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4_DUAL(3, 8);
     RAISE_W4_DUAL(3, 4);
 #undef RAISE_W4_DUAL
+#define RAISE_W4_GMUL(A, MHV)                                                                                          \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, true, false, MHV, false, false, true>), \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)                            \
+    return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
+    RAISE_W4_GMUL(1, 8);
+    RAISE_W4_GMUL(1, 4);
+    RAISE_W4_GMUL(2, 8);
+    RAISE_W4_GMUL(2, 4);
+    RAISE_W4_GMUL(3, 8);
+    RAISE_W4_GMUL(3, 4);
+#undef RAISE_W4_GMUL
     RAISE_W4(0, false);
     RAISE_W4(0, true);
     RAISE_W4(1, false);
@@ -934,8 +988,18 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   hipLaunchKernelGGL((linear_bf16_w4_kernel<A, false, false, MHV, false, true>), dim3((unsigned)w4_blocks), dim3(256), \
                      W4_LDS, st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,             \
                      vec_ok ? 1 : 0, TILES, (int)nt, LNV, 0)
+#define LAUNCH_W4_GMUL(A, MHV, XP, RP, YP, LNV, MV, TILES)                                                                  \
+  hipLaunchKernelGGL((linear_bf16_w4_kernel<A, true, false, MHV, false, false, true>), dim3((unsigned)w4_blocks), dim3(256), \
+                     W4_LDS, st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,                   \
+                     vec_ok ? 1 : 0, TILES, (int)nt, LNV, 0)
 #define LAUNCH_W4_ACT(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                        \
-  if (dual) {                                                                                       \
+  if (gmul) {                                                                                       \
+    switch (act) {                                                                                  \
+      case ANEMOI_ACT_GELU: LAUNCH_W4_GMUL(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
+      case ANEMOI_ACT_SILU: LAUNCH_W4_GMUL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
+      default: LAUNCH_W4_GMUL(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES); break;               \
+    }                                                                                               \
+  } else if (dual) {                                                                                \
     switch (act) {                                                                                  \
       case ANEMOI_ACT_GELU: LAUNCH_W4_DUAL(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
       case ANEMOI_ACT_SILU: LAUNCH_W4_DUAL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
@@ -973,12 +1037,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     }
 #undef LAUNCH_W4_ACT
 #undef LAUNCH_W4_DUAL
+#undef LAUNCH_W4_GMUL
 #undef LAUNCH_W4
 #undef LAUNCH_W4_
 #undef LAUNCH_W4__
     return check_launch("anemoi_linear(256x256, 4 waves)");
   }
-  if (M % BIG_M != 0 || batched || dual) return W4_NEEDS_WHOLE_TILES;  // (the caller splits the ragged rows off / refuses)
+  if (M % BIG_M != 0 || batched || epi != 0) return W4_NEEDS_WHOLE_TILES;  // (the caller splits the ragged rows off / refuses)
   // shapes the persistent kernel does not take (K = 64, unaligned output, ...): the general 128 x 128 kernel
   return linear_launch<bf16_t, bf16_t>(x, ldx, w, bias, residual, ldr, y, ldy, M, N, K, act, st, ln);
 }
@@ -1176,8 +1241,31 @@ extern "C" int anemoi_linear_dual(int dtype, const void* x, int64_t ldx, const v
                  ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_dual: bf16, M a multiple of 256, N >= 256, K >= 128, 16-byte aligned");
   if (M == 0) return ANEMOI_OK;
   const int rc = linear_bf16_256_launch(x, ldx, w, bias, pre, ldp, y, ldy, M, N, K, act, as_stream(stream),
-                                        LnFold{nullptr, nullptr}, 0, nullptr, true);
+                                        LnFold{nullptr, nullptr}, 0, nullptr, 1);
   if (rc == W4_NEEDS_WHOLE_TILES) return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_dual: shape not taken by the fast path");
+  return rc;
+}
+
+// y = (x W^T) * act'(pre): the backward's dX GEMM of the Linear behind an activation, delivering the gradient of the
+// pre-activation of the Linear in front of it (x = dy [M, K], W = W2^T [N, K], pre [M, N]).  Same shape rules as
+// anemoi_linear_dual; ANEMOI_ERR_UNSUPPORTED otherwise (the caller then runs anemoi_linear + anemoi_act_backward).
+extern "C" int anemoi_linear_actgrad(int dtype, const void* x, int64_t ldx, const void* w, const void* pre, int64_t ldp,
+                                     void* y, int64_t ldy, int64_t M, int N, int K, int act, anemoi_stream_t stream) {
+  using namespace anemoi;
+  ANEMOI_REQUIRE(x && w && pre && y, ANEMOI_ERR_INVALID, "anemoi_linear_actgrad: null pointer");
+  ANEMOI_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && ldp >= N, ANEMOI_ERR_INVALID,
+                 "anemoi_linear_actgrad: bad shape");
+  ANEMOI_REQUIRE(act > ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_linear_actgrad: act %d", act);
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 && M % BIG_M == 0 && N >= 256 && N % 8 == 0 && K >= 128 && K % 64 == 0 &&
+                     (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)pre % 16 == 0 &&
+                     (uintptr_t)y % 16 == 0 && ldx % 8 == 0 && ldp % 8 == 0 && ldy % 8 == 0,
+                 ANEMOI_ERR_UNSUPPORTED,
+                 "anemoi_linear_actgrad: bf16, M a multiple of 256, N >= 256, K >= 128, 16-byte aligned");
+  if (M == 0) return ANEMOI_OK;
+  const int rc = linear_bf16_256_launch(x, ldx, w, nullptr, pre, ldp, y, ldy, M, N, K, act, as_stream(stream),
+                                        LnFold{nullptr, nullptr}, 0, nullptr, 2);
+  if (rc == W4_NEEDS_WHOLE_TILES)
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_actgrad: shape not taken by the fast path");
   return rc;
 }
 

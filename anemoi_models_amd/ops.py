@@ -617,6 +617,29 @@ def linear_dual(x: Tensor, w: Tensor, bias: Optional[Tensor], act: str):
     return pre, y
 
 
+def linear_actgrad(x: Tensor, w: Tensor, pre: Tensor, act: str) -> Tensor:
+    """``(x @ w.T) * act'(pre)``: the dX GEMM of the Linear behind an activation with the activation's derivative in its
+    epilogue (``anemoi_linear_actgrad``; whole 256-row tiles of a bf16 product, GEMM + ``act_backward`` for the rest)."""
+    _dev(x, w, pre)
+    m, k = _rows(x).shape
+    n = w.shape[0]
+    if w.dtype != x.dtype or not w.is_contiguous() or w.shape[1] != k or tuple(_rows(pre).shape) != (m, n):
+        raise ValueError("linear_actgrad: w must be contiguous [N, K] in the activation dtype, pre [M, N]")
+    m_main = (m // 256) * 256 if (x.dtype == torch.bfloat16 and n >= 256 and n % 8 == 0 and k >= 128 and k % 64 == 0
+                                  and _ld(x) % 8 == 0 and _ld(_rows(pre)) % 8 == 0) else 0
+    if m_main < 1024:
+        return act_backward(pre, linear(x, w), act)
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    with _Timed("linear", flops=2 * m_main * n * k, bytes=(m_main * k + n * k + 2 * m_main * n) * 2, m=m_main, n=n, k=k):
+        st = _lib.load().anemoi_linear_actgrad(dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), pre.data_ptr(),
+                                               _ld(_rows(pre)), out.data_ptr(), n, m_main, n, k, _lib.ACT_CODES[act],
+                                               _stream())
+    _lib.check(st, "anemoi_linear_actgrad")
+    if m_main < m:
+        out[m_main:].copy_(act_backward(pre[m_main:], linear(x[m_main:], w), act))
+    return out
+
+
 def act_forward(pre: Tensor, act: str, residual: Optional[Tensor] = None) -> Tensor:
     """``act(pre) + residual`` in one pass (the differentiable Linear keeps ``pre`` for the backward)."""
     _dev(pre, residual)

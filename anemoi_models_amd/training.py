@@ -69,6 +69,18 @@ def sequential(seq: nn.Sequential, x: Tensor, residual: Optional[Tensor] = None)
     i = 0
     while i < len(mods):
         m = mods[i]
+        if (isinstance(m, nn.Linear) and i + 2 < len(mods) and isinstance(mods[i + 2], nn.Linear)
+                and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm))
+                and (i + 3 == len(mods) or isinstance(mods[i + 3], (nn.Linear, nn.LayerNorm)))):
+            # Linear -> activation -> Linear: one autograd node (pre-activation from the first GEMM's epilogue, act' in the
+            # second GEMM's backward epilogue)
+            last = i + 2 == len(mods) - 1
+            x = autograd.mlp2(x, m.weight, m.bias, mods[i + 2].weight, mods[i + 2].bias, type(mods[i + 1]).__name__,
+                              residual if last else None)
+            if last:
+                residual = None
+            i += 3
+            continue
         if isinstance(m, nn.Linear):
             act = "Identity"
             if i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm)):

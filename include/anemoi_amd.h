@@ -348,6 +348,15 @@ int anemoi_linear_dual(int dtype, const void* x, int64_t ldx, const void* w, con
                        void* y, int64_t ldy, int64_t M, int N, int K, int act, anemoi_stream_t stream);
 
 /*
+ * Backward counterpart: y = (x W^T) * act'(pre) in one launch -- with x = dy and W = W2^T this is the dX GEMM of the
+ * Linear BEHIND an activation delivering d pre of the Linear in front of it (what autograd derives for
+ * Linear -> GELU -> Linear, layers/mlp.py:74-84), without a separate act' pass.  GELU': degree-8 polynomial in x^2 of the
+ * exact derivative, |error| < 5.5e-4.  Same shape rules / fallback as anemoi_linear_dual.
+ */
+int anemoi_linear_actgrad(int dtype, const void* x, int64_t ldx, const void* w, const void* pre, int64_t ldp, void* y,
+                          int64_t ldy, int64_t M, int N, int K, int act, anemoi_stream_t stream);
+
+/*
  * LayerNorm backward from the forward's row statistics (stats [rows, 2] = { rstd, -mean * rstd }, anemoi_row_stats):
  *   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * gamma, xhat = x * rstd - mean * rstd;
  *   dgamma[c] = sum_r dy * xhat, dbeta[c] = sum_r dy (f32).  workspace: anemoi_layer_norm_backward_workspace_floats.

@@ -970,6 +970,60 @@ def test_col_sum_two_stages(dtype, rows, cols):
     assert torch.equal(got, ops.col_sum(x))  # fixed summation order
 
 
+@pytest.mark.parametrize("m,k,hid,n,act,res", [(2500, 256, 1024, 256, "GELU", True), (4096, 512, 2048, 512, "SiLU", False),
+                                               (1100, 1024, 4096, 1024, "GELU", True), (300, 64, 256, 64, "GELU", True)])
+def test_mlp2_fused_node_matches_torch_autograd(m, k, hid, n, act, res):
+    """autograd.mlp2 (Linear -> act -> Linear (+ residual) as one autograd node: pre-activation from the first GEMM's
+    epilogue, act' in the epilogue of the second GEMM's dX product, bias gradients from the transposes) against torch
+    autograd in f64 -- and against the two-node composition it replaces (last case: shapes that stay unfused)."""
+    from anemoi_models_amd import autograd
+
+    g = torch.Generator().manual_seed(m + hid)
+    dt = torch.bfloat16
+    x = torch.randn(m, k, generator=g).to(dt)
+    w1, b1 = torch.randn(hid, k, generator=g) / k**0.5, 0.3 * torch.randn(hid, generator=g)
+    w2, b2 = torch.randn(n, hid, generator=g) / hid**0.5, 0.3 * torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g).to(dt) if res else None
+    dy = torch.randn(m, n, generator=g).to(dt)
+    ref_p = [t.double().requires_grad_() for t in (x, w1.to(dt), b1, w2.to(dt), b2)]
+    actf = {"GELU": F.gelu, "SiLU": F.silu}[act]
+    yr = F.linear(actf(F.linear(ref_p[0], ref_p[1], ref_p[2])), ref_p[3], ref_p[4])
+    if res:
+        yr = yr + r.double()
+    yr.backward(dy.double())
+    dev_p = [t.to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+    rd = None if r is None else r.to(DEV).requires_grad_()
+    y = autograd.mlp2(dev_p[0], dev_p[1], dev_p[2], dev_p[3], dev_p[4], act, rd)
+    y.backward(dy.to(DEV))
+    assert rel_err(y.detach(), yr.detach().float()) < 3e-2
+    for got, want, name in zip(dev_p, ref_p, ("x", "w1", "b1", "w2", "b2")):
+        assert rel_err(got.grad, want.grad.float()) < 3e-2, name
+    if res:
+        assert torch.equal(rd.grad.cpu(), dy)
+    g1 = [p.grad.clone() for p in dev_p]  # reproducible bit for bit
+    for p in dev_p:
+        p.grad = None
+    autograd.mlp2(dev_p[0], dev_p[1], dev_p[2], dev_p[3], dev_p[4], act, rd).backward(dy.to(DEV))
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, dev_p))
+
+
+@pytest.mark.parametrize("act", ["GELU", "SiLU", "ReLU"])
+def test_linear_actgrad_epilogue(act):
+    """ops.linear_actgrad == act_backward(pre, linear(x, w)) up to the epilogue's derivative polynomial (GELU': 5.5e-4)."""
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    m, k, n = 2600, 256, 1024
+    x = torch.randn(m, k, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=g) / k**0.5).bfloat16().to(DEV)
+    pre = (2.5 * torch.randn(m, n, generator=g)).bfloat16().to(DEV)
+    got = ops.linear_actgrad(x, w, pre, act)
+    p = pre.double().cpu().requires_grad_()
+    {"GELU": F.gelu, "SiLU": F.silu, "ReLU": F.relu}[act](p).sum().backward()
+    want = (x.double().cpu() @ w.double().cpu().t()) * p.grad
+    assert rel_err(got, want.float()) < 1e-2
+
+
 @pytest.mark.parametrize("dtype,rows,c", [(torch.float32, 1000, 256), (torch.float32, 77, 100),
                                           (torch.bfloat16, 5000, 1024)])
 def test_layer_norm_backward_matches_torch_autograd(dtype, rows, c):
