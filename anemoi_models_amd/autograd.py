@@ -314,6 +314,46 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
         return dsq, dattr, None, None, None
 
 
+class _GTEdgeAttentionMapper(torch.autograd.Function):
+    """The mapper block's case: ``sq = x_r | q | u`` ``[n_dst, 2C + H*up]`` and ``kv = k | v`` ``[n_src, 2C]`` are GEMM
+    results consumed whole; the backward fills ONE ``d sq`` and ONE ``d kv`` buffer through strided outputs.  With five
+    sliced inputs autograd zero-fills and adds a full-width buffer per slice -- on the 542 080 grid rows of config 3 that
+    was 6 ms of fills and adds per training step."""
+
+    @staticmethod
+    def forward(ctx, sq, kv, edge_attr, plan, num_heads: int, up: int):
+        c = kv.shape[1] // 2
+        lse = torch.empty((sq.shape[0], num_heads), dtype=torch.float32, device=sq.device)
+        out = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr,
+                                           plan.rowptr, plan.col, num_heads, up, lse=lse)
+        ctx.save_for_backward(sq, kv, edge_attr, lse)
+        ctx.plan, ctx.h, ctx.up, ctx.c = plan, num_heads, up, c
+        return out
+
+    @staticmethod
+    def backward(ctx, dfull):
+        sq, kv, edge_attr, lse = ctx.saved_tensors
+        plan, h, up, c = ctx.plan, ctx.h, ctx.up, ctx.c
+        dfull = dfull.contiguous()
+        dout = dfull[:, :c]
+        dsq = torch.empty_like(sq)
+        dsq[:, :c].copy_(dout)  # d x_r
+        if plan.col.shape[0] == 0:
+            dsq[:, c:].zero_()
+            return dsq, torch.zeros_like(kv), torch.zeros_like(edge_attr), None, None, None
+        dkv = torch.empty_like(kv)
+        dattr = _edge_backward(sq[:, c:2 * c], kv[:, :c], kv[:, c:], dout, sq[:, 2 * c:], dfull[:, c:c + h * up], lse,
+                               edge_attr, plan, h, up, dsq[:, c:2 * c], dkv[:, :c], dkv[:, c:], dsq[:, 2 * c:],
+                               ctx.needs_input_grad[2])
+        return dsq, dkv, dattr, None, None, None
+
+
+def gt_edge_attention_packed(sq: Tensor, kv: Tensor, edge_attr: Tensor, plan, num_heads: int, up: int) -> Tensor:
+    """:func:`gt_edge_attention` on the packed GEMM results ``sq = x_r | q | u`` ``[n_dst, 2C + H*up]`` and
+    ``kv = k | v`` ``[n_src, 2C]`` (the mapper blocks' layout): gradients arrive as one ``d sq`` and one ``d kv``."""
+    return _GTEdgeAttentionMapper.apply(sq, kv, edge_attr, plan, num_heads, up)
+
+
 def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor, plan,
                       num_heads: int, up: int) -> Tensor:
     """Differentiable ``ops.gt_edge_attention_folded``: ``[n_dst, C + H*up] = [sum alpha v (+ x_r) | sum alpha a]`` with
@@ -464,7 +504,7 @@ def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_at
                 torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0))
     sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
                 torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))  # x_r | q | u
-    att = gt_edge_attention(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan, h, up)
+    att = gt_edge_attention_packed(sq, kv, edge_attr_csr, plan, h, up)
     return _gt_tail(att, x_dst, sd, prefix, w_t, act, eps)
 
 

@@ -522,8 +522,7 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
             kv = _HaloRows.apply(kv, lg.halo)
         sq = autograd.linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
                              torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))
-        att = autograd.gt_edge_attention(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], attrs(mod, lg.plan),
-                                         lg.plan, heads, up)
+        att = autograd.gt_edge_attention_packed(sq, kv, attrs(mod, lg.plan), lg.plan, heads, up)
         return autograd._gt_tail(att, h_dst, sd, "b", w_t, blk.activation, blk.layer_norm1.eps)
 
     def processor_block(blk, h, ea, lg: LocalGraph):
@@ -537,7 +536,7 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
                                              torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0)), lg.halo)
         sq = autograd.linear(xh, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
                              torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))
-        att = autograd.gt_edge_attention(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], ea, lg.plan, heads, up)
+        att = autograd.gt_edge_attention_packed(sq, kv, ea, lg.plan, heads, up)
         return autograd._gt_tail(att, h, sd, "b", w_t, blk.activation, blk.layer_norm1.eps)
 
     with torch.autocast(device_type=x.device.type, enabled=False):

@@ -353,7 +353,11 @@ def _finish(model, out: Tensor, x: Tensor, b: int, ens: int, g: int) -> Tensor:
         model._idx_cache[key] = tuple(torch.as_tensor(i).to(device=x.device, dtype=torch.int64)
                                       for i in (model._internal_output_idx, model._internal_input_idx))
     o_idx, i_idx = model._idx_cache[key]
-    y[..., o_idx] = y[..., o_idx] + x[:, -1].index_select(-1, i_idx)
+    # the prognostic residual as ONE full-width addend (zeros outside the prognostic columns): a plain add in the graph --
+    # reading y[..., o_idx] instead costs torch's sort-based index accumulation in the backward (1.8 ms per step)
+    res = torch.zeros_like(y)
+    res[..., o_idx] = x[:, -1].index_select(-1, i_idx).to(y.dtype)
+    y = y + res
     for bounding in model.boundings:  # in-place clamps on the cloned output: plain differentiable torch ops
         y = bounding(y)
     return y
