@@ -12,6 +12,7 @@ from ctypes import c_char_p
 from ctypes import c_float
 from ctypes import c_int
 from ctypes import c_int64
+from ctypes import c_uint32
 from ctypes import c_void_p
 
 import torch  # noqa: F401  -- FIRST: puts torch's bundled HIP runtime (libamdhip64.so.7) in the process so that
@@ -31,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -71,9 +72,9 @@ SIGNATURES = {
     "anemoi_segment_sum": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "anemoi_mhsa_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                            c_int, c_void_p]),
+                            c_int, c_float, c_uint32, c_void_p]),
     "anemoi_mhsa_backward": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_void_p]),
     "anemoi_assemble_nodes": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "anemoi_finalize_output": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,

@@ -363,26 +363,31 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
 
 # ------------------------------------------------------------------------------------------ mesh-node self attention
 class _MHSA(torch.autograd.Function):
-    """``softmax(Q K^T / sqrt(D)) V`` on the fused ``q | k | v`` matrix (``anemoi_mhsa``, MFMA flash kernel for bf16 head
-    sizes 64 / 32); the backward recomputes the probabilities from the saved log-sum-exp (``anemoi_mhsa_backward``)."""
+    """``dropout(softmax(Q K^T / sqrt(D))) V`` on the fused ``q | k | v`` matrix (``anemoi_mhsa``, MFMA flash kernel for
+    bf16 head sizes 64 / 32 without dropout); the backward recomputes the probabilities from the saved log-sum-exp and the
+    dropout mask from the saved seed (``anemoi_mhsa_backward``)."""
 
     @staticmethod
-    def forward(ctx, qkv: Tensor, batch_size: int, num_heads: int, window: int):
-        out, lse = ops.mhsa(qkv, batch_size, num_heads, window, return_lse=True)
+    def forward(ctx, qkv: Tensor, batch_size: int, num_heads: int, window: int, dropout_p: float, seed: int):
+        out, lse = ops.mhsa(qkv, batch_size, num_heads, window, return_lse=True, dropout_p=dropout_p, dropout_seed=seed)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.args = (batch_size, num_heads, window)
+        ctx.args = (batch_size, num_heads, window, dropout_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         qkv, out, lse = ctx.saved_tensors
-        b, h, w = ctx.args
-        return ops.mhsa_backward(qkv, out, dout.contiguous(), lse, b, h, w), None, None, None
+        b, h, w, p, seed = ctx.args
+        return ops.mhsa_backward(qkv, out, dout.contiguous(), lse, b, h, w, p, seed), None, None, None, None, None
 
 
-def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1) -> Tensor:
-    """Differentiable ``ops.mhsa`` (reference layers/attention.py:67-112)."""
-    return _MHSA.apply(qkv, batch_size, num_heads, window)
+def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, dropout_p: float = 0.0,
+         seed: Optional[int] = None) -> Tensor:
+    """Differentiable ``ops.mhsa`` (reference layers/attention.py:67-112).  ``dropout_p`` > 0: attention dropout with a
+    mask derived from ``seed`` (default: drawn from torch's CPU generator, so ``torch.manual_seed`` reproduces it)."""
+    if dropout_p > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+    return _MHSA.apply(qkv, batch_size, num_heads, window, float(dropout_p), int(seed or 0))
 
 
 # ------------------------------------------------------------------------------------------ GNN edge phase

@@ -259,13 +259,50 @@ __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Attention dropout (reference layers/attention.py:90-105: dropout_p of SDPA / flash-attn in training mode).  The keep
+// mask of probability (b, h, i, j) is a counter-based hash of its index and a per-call seed -- nothing is stored, the
+// backward kernels rebuild exactly the same mask.  Kept probabilities are scaled by 1 / (1 - p); the softmax normaliser
+// is taken before the dropout, as in the reference.  p >= 1 drops everything (output and gradients 0).
+// ---------------------------------------------------------------------------------------------
+struct AttnDropout {
+  uint32_t threshold;  // keep  <=>  hash >= threshold  (threshold = p * 2^32; 0: no dropout)
+  uint32_t seed;
+  float keep_scale;    // 1 / (1 - p), 0 when p >= 1
+  int drop_all;
+};
+
+__device__ __forceinline__ float dropout_keep(const AttnDropout& dr, int64_t row, int col) {
+  // row = (b * H + h) * S + i, col = j
+  if (dr.threshold == 0 && !dr.drop_all) return 1.0f;
+  if (dr.drop_all) return 0.0f;
+  uint32_t x = (uint32_t)row * 0x9E3779B1u ^ (uint32_t)(row >> 32) * 0x85EBCA77u ^ (uint32_t)col * 0xC2B2AE3Du ^ dr.seed;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x >= dr.threshold ? dr.keep_scale : 0.0f;
+}
+
+static inline AttnDropout make_dropout(float p, uint32_t seed) {
+  AttnDropout dr;
+  dr.seed = seed;
+  dr.drop_all = p >= 1.0f ? 1 : 0;
+  const double t = p <= 0.f ? 0.0 : (double)p * 4294967296.0;
+  dr.threshold = dr.drop_all ? 0xffffffffu : (uint32_t)(t > 4294967295.0 ? 4294967295.0 : t);
+  dr.keep_scale = (p > 0.f && p < 1.0f) ? 1.0f / (1.0f - p) : (p >= 1.0f ? 0.f : 1.0f);
+  return dr;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic kernel (f32 or bf16 storage, any D <= 128): one wave per (query, head); lane l takes keys l, l+64, ...
 // with its own running (max, sum, acc[D]); the 64 partial states are merged at the end.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__ qkv, int64_t ld, T* __restrict__ out,
                                                            int64_t ldo, int S, int H, int D, int C, int window,
-                                                           float scale, int64_t total, float* __restrict__ lse) {
+                                                           float scale, int64_t total, float* __restrict__ lse,
+                                                           const AttnDropout dr) {
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
   if (unit >= total) return;
@@ -295,10 +332,11 @@ __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__
       if (d < D) s = fmaf(qv[d], Elem<T>::load(kp + d), s);
     const float mn = fmaxf(m, s);
     const float corr = __expf(m - mn), pe = __expf(s - mn);
-    l = l * corr + pe;
+    l = l * corr + pe;  // the normaliser sees every key; dropout acts on the normalised probabilities
+    const float pk = pe * dropout_keep(dr, (b * H + h) * S + q, key);
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
-      if (d < D) acc[d] = acc[d] * corr + pe * Elem<T>::load(vp + d);
+      if (d < D) acc[d] = acc[d] * corr + pk * Elem<T>::load(vp + d);
     m = mn;
   }
   // merge the 64 lane states
@@ -333,7 +371,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const T* __restrict__ 
                                                           int64_t ldo, const T* __restrict__ dout, int64_t lddo,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           T* __restrict__ dqkv, int64_t lddq, int S, int H, int D, int C,
-                                                          int window, float scale, int64_t total) {
+                                                          int window, float scale, int64_t total, const AttnDropout dr) {
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
   if (unit >= total) return;
@@ -367,7 +405,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const T* __restrict__ 
         s = fmaf(qv[d], Elem<T>::load(kp + d), s);
         dp = fmaf(dov[d], Elem<T>::load(vp + d), dp);
       }
-    const float ds = __expf(s - ls) * (dp - dl) * scale;
+    // with dropout: O = (keep / (1 - p) * P) V, so dP = keep / (1 - p) * (dO . v) and sum_j P dP = dO . O = dl still
+    const float ds = __expf(s - ls) * (dp * dropout_keep(dr, (b * H + h) * S + q, key) - dl) * scale;
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
       if (d < D) acc[d] = fmaf(ds, Elem<T>::load(kp + d), acc[d]);
@@ -386,7 +425,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkv_kernel(const T* __restrict__
                                                            const T* __restrict__ dout, int64_t lddo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            T* __restrict__ dqkv, int64_t lddq, int S, int H, int D, int C,
-                                                           int window, float scale, int64_t total) {
+                                                           int window, float scale, int64_t total, const AttnDropout dr) {
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, key, h)
   if (unit >= total) return;
@@ -419,11 +458,13 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkv_kernel(const T* __restrict__
       }
     const int64_t si = (b * H + h) * S + q;
     const float p = __expf(s * scale - lse[si]);
-    const float ds = p * (dp - delta[si]) * scale;
+    const float keep = dropout_keep(dr, si, key);
+    const float ds = p * (dp * keep - delta[si]) * scale;
+    const float pd = p * keep;
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
       if (d < D) {
-        dv[d] = fmaf(p, Elem<T>::load(dop + d), dv[d]);
+        dv[d] = fmaf(pd, Elem<T>::load(dop + d), dv[d]);
         dk[d] = fmaf(ds, Elem<T>::load(qp + d), dk[d]);
       }
   }
@@ -451,15 +492,19 @@ int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
 }
 
 int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
-                int H, int D, int window, anemoi_stream_t stream) {
+                int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out, ANEMOI_ERR_INVALID, "anemoi_mhsa: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa: bad shape");
   const int C = H * D;
   ANEMOI_REQUIRE(ld >= 3 * (int64_t)C && ldo >= C, ANEMOI_ERR_INVALID, "anemoi_mhsa: leading dimension too small");
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)D);
-  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32) && (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 && (uintptr_t)out % 8 == 0 &&
-      ldo % 4 == 0) {
+  ANEMOI_REQUIRE(dropout_p >= 0.f && dropout_p <= 1.f, ANEMOI_ERR_INVALID, "anemoi_mhsa: dropout_p %g outside [0, 1]",
+                 (double)dropout_p);
+  const AttnDropout dr = make_dropout(dropout_p, dropout_seed);
+  // (attention dropout runs on the generic kernel: the MFMA kernel keeps its probabilities in packed MFMA operands)
+  if (dropout_p == 0.f && dtype == ANEMOI_BF16 && (D == 64 || D == 32) && (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 &&
+      (uintptr_t)out % 8 == 0 && ldo % 4 == 0) {
     ANEMOI_REQUIRE(workspace != nullptr, ANEMOI_ERR_INVALID, "anemoi_mhsa: workspace of %lld bytes required",
                    (long long)anemoi_mhsa_workspace_bytes(dtype, B, S, H, D));
     const int S_pad = (S + 63) / 64 * 64;
@@ -482,7 +527,7 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   dim3 grid((unsigned)((units + 3) / 4)), block(256);
 #define GEN(T, DM)                                                                                               \
   hipLaunchKernelGGL((mhsa_generic_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,           \
-                     static_cast<T*>(out), ldo, S, H, D, C, window, scale, units, lse)
+                     static_cast<T*>(out), ldo, S, H, D, C, window, scale, units, lse, dr)
   if (dtype == ANEMOI_F32) {
     if (D <= 32) GEN(float, 32);
     else if (D <= 64) GEN(float, 64);
@@ -500,13 +545,16 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
 
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
                          int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, int B, int S, int H, int D,
-                         int window, anemoi_stream_t stream) {
+                         int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out && dout && lse && delta && dqkv, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: bad shape");
   const int C = H * D;
   ANEMOI_REQUIRE(ld >= 3 * (int64_t)C && lddq >= 3 * (int64_t)C && ldo >= C && lddo >= C, ANEMOI_ERR_INVALID,
                  "anemoi_mhsa_backward: leading dimension too small");
   ANEMOI_REQUIRE(D <= 128, ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: head size %d > 128", D);
+  ANEMOI_REQUIRE(dropout_p >= 0.f && dropout_p <= 1.f, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: dropout_p %g outside [0, 1]",
+                 (double)dropout_p);
+  const AttnDropout dr = make_dropout(dropout_p, dropout_seed);
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)D);
   const int64_t units = (int64_t)B * S * H;
@@ -516,10 +564,10 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
   do {                                                                                                                \
     hipLaunchKernelGGL((mhsa_bwd_dq_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,               \
                        static_cast<const T*>(out), ldo, static_cast<const T*>(dout), lddo, lse, delta,                \
-                       static_cast<T*>(dqkv), lddq, S, H, D, C, window, scale, units);                                \
+                       static_cast<T*>(dqkv), lddq, S, H, D, C, window, scale, units, dr);                            \
     hipLaunchKernelGGL((mhsa_bwd_dkv_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,              \
                        static_cast<const T*>(dout), lddo, lse, static_cast<const float*>(delta), static_cast<T*>(dqkv), \
-                       lddq, S, H, D, C, window, scale, units);                                                       \
+                       lddq, S, H, D, C, window, scale, units, dr);                                                   \
   } while (0)
   if (dtype == ANEMOI_F32) {
     if (D <= 32) BWD(float, 32);

@@ -43,11 +43,19 @@ class MultiHeadSelfAttention(nn.Module):
             return int(self.window_size[0])
         return -1
 
+    def dropout(self):
+        """``(dropout_p, seed)`` of this call: the reference drops attention probabilities in training mode only
+        (layers/attention.py:90); the seed comes from torch's CPU generator (``torch.manual_seed`` reproduces the mask)."""
+        import torch
+
+        if not self.training or self.dropout_p <= 0.0:
+            return 0.0, 0
+        return float(self.dropout_p), int(torch.randint(0, 2**31 - 1, (1,)).item())
+
     def native(self, x: Tensor, batch_size: int) -> Tensor:
-        if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("attention dropout > 0 is not implemented on the MI355X path")
         qkv = linear_native(self._packed, "lin_qkv", self.lin_qkv, x)  # [B*S, 3C] = q | k | v
-        att = ops.mhsa(qkv, batch_size, self.num_heads, self.attention_window())
+        p, seed = self.dropout()
+        att = ops.mhsa(qkv, batch_size, self.num_heads, self.attention_window(), dropout_p=p, dropout_seed=seed)
         return linear_native(self._packed, "projection", self.projection, att)
 
     def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None) -> Tensor:
@@ -57,11 +65,10 @@ class MultiHeadSelfAttention(nn.Module):
         from .. import autograd, training
 
         if training.wants_grad(self, x):  # reference layers/attention.py:67-112 with an autograd graph
-            if self.dropout_p > 0.0 and self.training:
-                raise NotImplementedError("attention dropout > 0 in training is not implemented on the MI355X kernels")
             xin = training._cast(x, runtime.compute_dtype(x))
             qkv = autograd.linear(xin, self.lin_qkv.weight, self.lin_qkv.bias)
-            att = autograd.mhsa(qkv, batch_size, self.num_heads, self.attention_window())
+            p, seed = self.dropout()
+            att = autograd.mhsa(qkv, batch_size, self.num_heads, self.attention_window(), p, seed)
             return autograd.linear(att, self.projection.weight, self.projection.bias)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)

@@ -685,7 +685,11 @@ class TransformerProcessorBlock(BaseBlock):
         h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
         att = self.attention
         qkv = linear_native(att._packed, "lin_qkv", att.lin_qkv, h)
+        drop_p, drop_seed = att.dropout()
         if head_exchange is not None:
+            if drop_p > 0.0:
+                raise NotImplementedError("attention dropout in the node-partitioned forward (the ranks would need one "
+                                          "mask over the gathered sequence)")
             window = att.attention_window()
             qkv_heads = head_exchange.rows_to_heads(qkv, att.num_heads)  # [S, 3 * C_local], internal row order
             if window >= 0:  # the window slides over the EXTERNAL node order
@@ -695,7 +699,7 @@ class TransformerProcessorBlock(BaseBlock):
                 a_heads = a_heads.index_select(0, head_exchange.to_internal)
             a = head_exchange.heads_to_rows(a_heads, att.num_heads)  # [n_own, C]
         else:
-            a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window())
+            a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window(), dropout_p=drop_p, dropout_seed=drop_seed)
         x = linear_native(att._packed, "projection", att.projection, a, residual=x)  # x + attention(...)
         if self._mlp is None:
             self._mlp = NativeSequential(self.mlp)

@@ -384,9 +384,10 @@ def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None) -> Tens
 
 
 def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Optional[Tensor] = None,
-         return_lse: bool = False):
+         return_lse: bool = False, dropout_p: float = 0.0, dropout_seed: int = 0):
     """Multi-head self attention on the fused ``lin_qkv`` output ``[B*S, 3C]`` -> ``[B*S, C]`` (heads concatenated).
-    ``return_lse``: also the f32 ``[B, H, S]`` log-sum-exp of the scaled scores (the backward's input)."""
+    ``return_lse``: also the f32 ``[B, H, S]`` log-sum-exp of the scaled scores (the backward's input).
+    ``dropout_p`` / ``dropout_seed``: attention dropout (training mode of the reference), mask = hash(index, seed)."""
     _dev(qkv, out)
     rows, c3 = _rows(qkv).shape
     c = c3 // 3
@@ -401,13 +402,14 @@ def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Op
     lse = torch.empty((batch_size, num_heads, s_len), dtype=torch.float32, device=qkv.device) if return_lse else None
     with _Timed("mhsa", flops=4 * batch_size * num_heads * s_len * s_len * d, s=s_len, h=num_heads, d=d):
         st = lib.anemoi_mhsa(code, qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)), _ptr(ws), _ptr(lse),
-                             batch_size, s_len, num_heads, d, window, _stream())
+                             batch_size, s_len, num_heads, d, window, float(dropout_p), int(dropout_seed) & 0xFFFFFFFF,
+                             _stream())
     _lib.check(st, "anemoi_mhsa")
     return (out, lse) if return_lse else out
 
 
 def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_size: int, num_heads: int,
-                  window: int = -1) -> Tensor:
+                  window: int = -1, dropout_p: float = 0.0, dropout_seed: int = 0) -> Tensor:
     """``d qkv`` ``[B*S, 3C]`` of :func:`mhsa` from the forward's output and log-sum-exp (``anemoi_mhsa_backward``)."""
     _dev(qkv, out, dout, lse)
     rows, c3 = _rows(qkv).shape
@@ -420,7 +422,7 @@ def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_siz
     st = _lib.load().anemoi_mhsa_backward(dtype_code(qkv.dtype), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)),
                                           dout.data_ptr(), _ld(_rows(dout)), lse.data_ptr(), delta.data_ptr(),
                                           dqkv.data_ptr(), c3, batch_size, s_len, num_heads, c // num_heads, window,
-                                          _stream())
+                                          float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, _stream())
     _lib.check(st, "anemoi_mhsa_backward")
     return dqkv
 

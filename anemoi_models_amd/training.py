@@ -312,12 +312,11 @@ def transformer_block(block, x: Tensor, batch_size: int) -> Tensor:
     ``x + MLP(LN x)``."""
     dtype = runtime.compute_dtype(x)
     att = block.attention
-    if att.dropout_p > 0.0 and block.training:
-        raise NotImplementedError("attention dropout > 0 in training is not implemented on the MI355X kernels")
     x = _cast(x, dtype)
     h = autograd.layer_norm(x, block.layer_norm1.weight, block.layer_norm1.bias, block.layer_norm1.eps)
     qkv = autograd.linear(h, att.lin_qkv.weight, att.lin_qkv.bias)
-    a = autograd.mhsa(qkv, batch_size, att.num_heads, att.attention_window())
+    p, seed = att.dropout()  # attention dropout in training mode (reference layers/attention.py:90)
+    a = autograd.mhsa(qkv, batch_size, att.num_heads, att.attention_window(), p, seed)
     x = autograd.linear(a, att.projection.weight, att.projection.bias, "Identity", x)
     h = autograd.layer_norm(x, block.layer_norm2.weight, block.layer_norm2.bias, block.layer_norm2.eps)
     return sequential(block.mlp, h, residual=x)

@@ -278,12 +278,15 @@ int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* row
  * flash style, on the fused lin_qkv output qkv [B*S, 3C] = q | k | v (leading dimension ld), C = H*D.
  * Replaces the rearranges + flash_attn_func / scaled_dot_product_attention of layers/attention.py:76-108.
  * window < 0: global attention (the reference's SDPA fallback); window >= 0: flash-attn sliding window |i - j| <= window.
- * bf16 with D = 64 runs on MFMA and needs `workspace` of anemoi_mhsa_workspace_bytes() bytes (V transposed);
+ * bf16 with D = 64 or 32 runs on MFMA and needs `workspace` of anemoi_mhsa_workspace_bytes() bytes (V transposed);
  * other cases use a VALU kernel (workspace may be NULL).
+ * dropout_p in [0, 1] (attention dropout of the reference in training mode, layers/attention.py:90): probabilities are
+ * dropped AFTER normalisation by a counter-based hash of (batch, head, query, key) and `dropout_seed`, kept ones scaled
+ * by 1 / (1 - p); the backward rebuilds the same mask from the same seed.  dropout_p > 0 always takes the VALU kernel.
  */
 int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
-                int H, int D, int window, anemoi_stream_t stream);
+                int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream);
 
 /*
  * Backward of anemoi_mhsa (what torch autograd derives for the reference's scaled_dot_product_attention call,
@@ -294,7 +297,7 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
  */
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
                          int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, int B, int S, int H, int D,
-                         int window, anemoi_stream_t stream);
+                         int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Backward pass, dense half (first step): the pieces the autograd of the fused Linear and of

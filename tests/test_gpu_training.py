@@ -271,3 +271,85 @@ def test_transformer_model_training_step_vs_oracle_autograd(graph_o32, golden_cf
     y.backward(dy.to(DEV))
     used = _compare_grads(model, rsd)
     assert any("attention.lin_qkv" in k for k in used) and any("attention.projection" in k for k in used)
+
+
+def _dropout_keep_mask(seed: int, p: float, b: int, h: int, s: int) -> torch.Tensor:
+    """The kernels' counter-based keep mask (csrc/attention.hip::dropout_keep) restated with torch integer arithmetic:
+    [B, H, S, S] of 0 / 1."""
+    m32 = 0xFFFFFFFF
+    row = torch.arange(b * h * s, dtype=torch.int64).view(b, h, s, 1)  # (b * H + h) * S + i
+    col = torch.arange(s, dtype=torch.int64).view(1, 1, 1, s)
+    x = ((row & m32) * 0x9E3779B1) & m32
+    x = x ^ (((row >> 32) * 0x85EBCA77) & m32) ^ ((col * 0xC2B2AE3D) & m32) ^ (seed & m32)
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & m32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & m32
+    x = x ^ (x >> 16)
+    thr = min(int(p * 4294967296.0), 4294967295)
+    return (x >= thr).to(torch.float64) if p < 1.0 else torch.zeros(b, h, s, s, dtype=torch.float64)
+
+
+@pytest.mark.parametrize("dtype,b,s,h,d,window,p", [
+    (torch.float32, 2, 150, 3, 5, -1, 0.3), (torch.float32, 1, 97, 2, 16, 20, 0.5), (torch.bfloat16, 1, 200, 4, 64, -1, 0.1),
+    (torch.float32, 1, 64, 2, 8, -1, 1.0), (torch.bfloat16, 2, 130, 4, 32, -1, 0.25),
+])
+def test_mhsa_attention_dropout_forward_and_backward(dtype, b, s, h, d, window, p):
+    """Attention dropout (reference layers/attention.py:90-105, training mode): forward and gradients against torch
+    autograd in f64 through dropout(softmax(.)) V with the SAME mask (the kernels' hash restated above); the fraction of
+    kept probabilities matches 1 - p; p = 1 drops everything."""
+    from anemoi_models_amd import autograd
+
+    g = torch.Generator().manual_seed(s + d)
+    seed = 123456789 + s
+    c = h * d
+    qkv = (torch.randn(b * s, 3 * c, generator=g) * 0.8).to(dtype)
+    dout = torch.randn(b * s, c, generator=g).to(dtype)
+    keep = _dropout_keep_mask(seed, p, b, h, s)
+    if 0.0 < p < 1.0:
+        assert abs(float(keep.mean()) - (1.0 - p)) < 0.02
+    ref_in = qkv.double().requires_grad_()
+    q, k, v = (t.reshape(b, s, h, d).permute(0, 2, 1, 3) for t in ref_in.split(c, dim=1))
+    sc = q @ k.transpose(-1, -2) / d**0.5
+    if window >= 0:
+        i = torch.arange(s)
+        sc = sc.masked_fill((i[:, None] - i[None, :]).abs() > window, float("-inf"))
+    prob = torch.softmax(sc, -1) * keep * (1.0 / (1.0 - p) if p < 1.0 else 0.0)
+    want = (prob @ v).permute(0, 2, 1, 3).reshape(b * s, c)
+    want.backward(dout.double())
+    x = qkv.to(DEV).requires_grad_()
+    got = autograd.mhsa(x, b, h, window, p, seed)
+    got.backward(dout.to(DEV))
+    if p >= 1.0:
+        assert not got.detach().any() and not x.grad.any()
+        return
+    assert rel_err(got.detach(), want.detach()) < (2e-5 if dtype == torch.float32 else 2e-2)
+    assert rel_err(x.grad, ref_in.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    # the same seed gives the same mask, another seed another one
+    again = autograd.mhsa(qkv.to(DEV), b, h, window, p, seed)
+    other = autograd.mhsa(qkv.to(DEV), b, h, window, p, seed + 1)
+    assert torch.equal(again, got.detach()) and not torch.equal(other, got.detach())
+
+
+@pytest.mark.parametrize("batch_size,num_heads,mult,p", [(3, 4, 5, 0.4), (8, 1, 10, 0.0), (2, 20, 1, 1.0), (5, 7, 3, 0.73)])
+def test_multi_head_self_attention_module_like_the_reference_tests(batch_size, num_heads, mult, p):
+    """reference tests/layers/test_attention.py:38-78: a MultiHeadSelfAttention in its default (training) mode with an
+    arbitrary dropout_p and small odd head sizes: forward shape, backward to the input."""
+    from anemoi_models_amd.layers.attention import MultiHeadSelfAttention
+
+    embed_dim = num_heads * mult
+    torch.manual_seed(7)
+    mhsa = MultiHeadSelfAttention(num_heads, embed_dim, dropout_p=p).to(DEV)
+    assert mhsa.training and mhsa.dropout_p == p
+    x = torch.randn(batch_size * 2, embed_dim, device=DEV, requires_grad=True)
+    out = mhsa.forward(x, [list(x.shape)], batch_size)
+    assert out.shape == x.shape
+    out.sum().backward()
+    assert x.grad is not None and x.grad.shape == x.shape and bool(torch.isfinite(x.grad).all())
+    with torch.no_grad():  # inference route of a module left in training mode: dropout still applies, eval() removes it
+        y_train = mhsa(x.detach(), [list(x.shape)], batch_size)
+        mhsa.eval()
+        y_eval, y_eval2 = mhsa(x.detach(), [list(x.shape)], batch_size), mhsa(x.detach(), [list(x.shape)], batch_size)
+    assert torch.equal(y_eval, y_eval2)
+    if 0.0 < p < 1.0:
+        assert not torch.equal(y_train, y_eval)
