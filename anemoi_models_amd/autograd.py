@@ -192,7 +192,12 @@ class _LayerNorm(torch.autograd.Function):
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = "Identity",
            residual: Optional[Tensor] = None) -> Tensor:
     """``act(x @ weight.T + bias) + residual`` with gradients for ``x``, ``weight``, ``bias`` and ``residual``.
-    ``x`` / ``residual`` in the compute dtype (f32 or bf16), ``weight [N, K]`` / ``bias [N]`` f32 parameters."""
+    ``x`` / ``residual`` in the compute dtype (f32 or bf16), ``weight [N, K]`` / ``bias [N]`` f32 parameters.  ``act``
+    outside the kernel's epilogues (Identity / GELU / SiLU / ReLU; the reference takes any ``torch.nn`` activation by
+    name): the product runs here, the activation as a torch module behind it."""
+    if act not in ("Identity", "GELU", "SiLU", "ReLU"):
+        y = getattr(torch.nn, act)()(_Linear.apply(x, weight, bias, "Identity", None))
+        return y if residual is None else y + residual
     return _Linear.apply(x, weight, bias, act, residual)
 
 

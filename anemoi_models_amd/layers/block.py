@@ -158,6 +158,23 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         self._dst_mlp: Optional[NativeSequential] = None
         self._src_mlp: Optional[NativeSequential] = None
 
+    # ---- the reference's head / sequence re-sharding helpers (layers/block.py:366-414) -----------------
+    def shard_qkve_heads(self, query: Tensor, key: Tensor, value: Tensor, edges: Tensor, shapes: tuple, batch_size: int,
+                         model_comm_group=None):
+        """``(batch grid) (heads vars) -> (batch grid) heads vars`` for q, k, v and the projected edge features.  Within
+        one process the reference's head exchange is the identity; across a model group this package partitions by mesh
+        node at the model root instead (``distributed/partition.py``), so a group of more than one rank is refused."""
+        if _group_size(model_comm_group) > 1:
+            raise NotImplementedError("block-level head sharding: use the node-partitioned model forward")
+        h, d = self.num_heads, self.out_channels_conv
+        return tuple(t.reshape(t.shape[0], h, d) for t in (query, key, value, edges))
+
+    def shard_output_seq(self, out: Tensor, shapes: tuple, batch_size: int, model_comm_group=None) -> Tensor:
+        """``(batch grid) heads vars -> (batch grid) (heads vars)`` (reference layers/block.py:401-414)."""
+        if _group_size(model_comm_group) > 1:
+            raise NotImplementedError("block-level sequence sharding: use the node-partitioned model forward")
+        return out.reshape(out.shape[0], -1)
+
     # ---- packed parameters -------------------------------------------------------------------
     def _cat_linear(self, tag: str, layers, dtype):
         w = self._packed.get((tag, "w", dtype), [l.weight for l in layers],

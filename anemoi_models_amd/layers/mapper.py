@@ -45,6 +45,58 @@ class BaseMapper(nn.Module, ABC):
         if cpu_offload:
             raise NotImplementedError("cpu_offload is not supported on the MI355X path (288 GB HBM per GPU)")
 
+    # ---- the reference's pre / post processing hooks (layers/mapper.py:68-116, 412-418, 690-694) --------------------
+    # ``forward`` runs fused launch sequences and does not come through these; they are kept, with the reference's
+    # signatures and return values, for callers (and the reference's own tests) that use a mapper piecewise.
+    @staticmethod
+    def _single_group(model_comm_group) -> None:
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
+
+    @staticmethod
+    def _apply(module: nn.Module, x: Tensor) -> Tensor:
+        """An embedding / extraction sub-module on node rows, on the HIP kernels with or without an autograd graph."""
+        from .mlp import MLP, NativeSequential
+
+        if isinstance(module, MLP):
+            return module(x)
+        dtype = runtime.compute_dtype(x)
+        seq = module if isinstance(module, nn.Sequential) else nn.Sequential(module)
+        if training.wants_grad(seq, x):
+            return training.sequential(seq, training._cast(x, dtype))
+        xin = x if x.dtype == dtype else x.to(dtype)
+        return NativeSequential(seq)(xin if xin.stride(-1) == 1 else xin.contiguous())
+
+    def pre_process(self, x, shard_shapes, model_comm_group=None):
+        """``(x_src, x_dst, shapes_src, shapes_dst)`` (reference layers/mapper.py:68-89)."""
+        self._single_group(model_comm_group)
+        shapes_src, shapes_dst = shard_shapes
+        x_src, x_dst = x
+        return x_src, x_dst, shapes_src, shapes_dst
+
+    def post_process(self, x_dst, shapes_dst, model_comm_group=None):
+        self._single_group(model_comm_group)
+        return x_dst
+
+
+class ForwardMapperPreProcessMixin:
+    """data -> hidden: both node sets are embedded (reference layers/mapper.py:105-116)."""
+
+    def pre_process(self, x, shard_shapes, model_comm_group=None):
+        from ..distributed.shapes import change_channels_in_shape
+
+        x_src, x_dst, shapes_src, shapes_dst = super().pre_process(x, shard_shapes, model_comm_group)
+        return (self._apply(self.emb_nodes_src, x_src), self._apply(self.emb_nodes_dst, x_dst),
+                change_channels_in_shape(shapes_src, self.hidden_dim), change_channels_in_shape(shapes_dst, self.hidden_dim))
+
+
+class BackwardMapperPostProcessMixin:
+    """hidden -> data: the output variables are extracted (reference layers/mapper.py:96-102)."""
+
+    def post_process(self, x_dst, shapes_dst, model_comm_group=None):
+        self._single_group(model_comm_group)
+        return self._apply(self.node_data_extractor, x_dst)
+
 
 class GraphEdgeMixin:
     """Edge buffers of a sub-graph (reference layers/mapper.py:119-171)."""
@@ -179,7 +231,7 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         return self.native(prep(x_src), prep(x_dst), batch_size)
 
 
-class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
+class GraphTransformerForwardMapper(ForwardMapperPreProcessMixin, GraphTransformerBaseMapper):
     """data -> hidden (reference layers/mapper.py:275-345): both node sets are embedded."""
 
     def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
@@ -206,7 +258,7 @@ class GraphTransformerForwardMapper(GraphTransformerBaseMapper):
         return x[0], x_dst  # the RAW source tensor is handed back (reference layers/mapper.py:344-345)
 
 
-class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
+class GraphTransformerBackwardMapper(BackwardMapperPostProcessMixin, GraphTransformerBaseMapper):
     """hidden -> data (reference layers/mapper.py:348-418): only the destination is embedded, then extracted."""
 
     def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
@@ -221,6 +273,14 @@ class GraphTransformerBackwardMapper(GraphTransformerBaseMapper):
                          src_grid_size=src_grid_size, dst_grid_size=dst_grid_size)
         self.node_data_extractor = nn.Sequential(nn.LayerNorm(self.hidden_dim),
                                                  nn.Linear(self.hidden_dim, self.out_channels_dst))
+
+    def pre_process(self, x, shard_shapes, model_comm_group=None):
+        """Only the destination is embedded; the source already lives in the hidden space (reference :412-418)."""
+        from ..distributed.shapes import change_channels_in_shape
+
+        x_src, x_dst, shapes_src, shapes_dst = super().pre_process(x, shard_shapes, model_comm_group)
+        return (x_src, self._apply(self.emb_nodes_dst, x_dst), change_channels_in_shape(shapes_src, self.hidden_dim),
+                change_channels_in_shape(shapes_dst, self.hidden_dim))
 
     def _embed(self, x_src: Tensor, x_dst: Tensor, one_cols=(None, None)):
         return x_src, self._embedded("emb_nodes_dst", self.emb_nodes_dst, x_dst, self._block_ln_eps(x_dst.dtype)[1],
@@ -322,7 +382,7 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
         return self._run(x, batch_size, shard_shapes, model_comm_group)
 
 
-class GNNForwardMapper(GNNBaseMapper):
+class GNNForwardMapper(ForwardMapperPreProcessMixin, GNNBaseMapper):
     def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
                  trainable_size: int = 8, out_channels_dst: Optional[int] = None, num_chunks: int = 1,
                  cpu_offload: bool = False, activation: str = "SiLU", mlp_extra_layers: int = 0, sub_graph=None,
@@ -344,7 +404,7 @@ class GNNForwardMapper(GNNBaseMapper):
         return self.emb_nodes_src.native()(x_src), self.emb_nodes_dst.native()(x_dst)
 
 
-class GNNBackwardMapper(GNNBaseMapper):
+class GNNBackwardMapper(BackwardMapperPostProcessMixin, GNNBaseMapper):
     def __init__(self, in_channels_src: int = 0, in_channels_dst: int = 0, hidden_dim: int = 128,
                  trainable_size: int = 8, out_channels_dst: Optional[int] = None, num_chunks: int = 1,
                  cpu_offload: bool = False, activation: str = "SiLU", mlp_extra_layers: int = 0, sub_graph=None,
@@ -361,6 +421,14 @@ class GNNBackwardMapper(GNNBaseMapper):
         self.node_data_extractor = MLP(in_features=self.hidden_dim, hidden_dim=self.hidden_dim,
                                        out_features=self.out_channels_dst, n_extra_layers=mlp_extra_layers,
                                        activation=self.activation, layer_norm=False, final_activation=False)
+
+    def pre_process(self, x, shard_shapes, model_comm_group=None):
+        """Both node sets already live in the hidden space: only the shapes change (reference :690-694)."""
+        from ..distributed.shapes import change_channels_in_shape
+
+        x_src, x_dst, shapes_src, shapes_dst = super().pre_process(x, shard_shapes, model_comm_group)
+        return (x_src, x_dst, change_channels_in_shape(shapes_src, self.hidden_dim),
+                change_channels_in_shape(shapes_dst, self.hidden_dim))
 
     def _extract(self, x_dst: Tensor, out_dtype) -> Tensor:
         return self.node_data_extractor.native()(x_dst, out_dtype=out_dtype)

@@ -21,6 +21,20 @@ from .utils import CheckpointWrapper
 LOGGER = logging.getLogger(__name__)
 
 
+FUSED_ACTIVATIONS = ("Identity", "GELU", "SiLU", "ReLU")  # epilogues of the fused Linear kernel
+
+
+def fused_activation_name(module: nn.Module) -> Optional[str]:
+    """Name of the GEMM epilogue that computes ``module``, or None when it has to run as a torch op behind the Linear
+    (the reference takes any ``torch.nn`` activation by name, layers/mlp.py:66-72; e.g. ``Tanh`` in its block tests)."""
+    name = type(module).__name__
+    if name not in FUSED_ACTIVATIONS:
+        return None
+    if name == "GELU" and getattr(module, "approximate", "none") != "none":
+        return None  # the kernel's GELU is the exact erf form
+    return name
+
+
 def activation_class(name: str):
     """``getattr(nn, name)`` with the reference's error behaviour (layers/mlp.py:66-72, layers/block.py:75-79)."""
     try:
@@ -49,13 +63,15 @@ class NativeSequential:
             if isinstance(m, nn.Linear):
                 act = "Identity"
                 if i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm)):
-                    act = type(mods[i + 1]).__name__
-                    i += 1
+                    fused = fused_activation_name(mods[i + 1])
+                    if fused is not None:
+                        act = fused
+                        i += 1
                 self.steps.append(("linear", m, act))
             elif isinstance(m, nn.LayerNorm):
                 self.steps.append(("ln", m, None))
-            else:
-                raise NotImplementedError(f"module {type(m).__name__} cannot be fused into the native MLP")
+            else:  # an activation without a GEMM epilogue (Tanh, LeakyReLU, ...): a torch op on the Linear's result
+                self.steps.append(("act", m, None))
             i += 1
 
     def __call__(self, x: Tensor, residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
@@ -65,7 +81,7 @@ class NativeSequential:
         its row statistics (``ops.linear(stats_eps=...)``)."""
         dtype = x.dtype
         last_linear = max(i for i, s in enumerate(self.steps) if s[0] == "linear")
-        ends_with_ln = self.steps[-1][0] == "ln"
+        ends_with_ln = self.steps[-1][0] != "linear"  # something (LayerNorm / torch activation) follows the last Linear
         pending_ln = None  # a LayerNorm whose consumer is the next Linear: folded into it (row_stats + linear_ln)
         for i, (kind, m, act) in enumerate(self.steps):
             if i < start:
@@ -89,6 +105,8 @@ class NativeSequential:
                 if x.shape[1] != w.shape[1]:
                     x = ops.convert_pad(x, dtype, w.shape[1])
                 x = ops.linear(x, w, b, **kw)
+            elif kind == "act":
+                x = m(x)
             else:
                 nxt = self.steps[i + 1] if i + 1 < len(self.steps) else None
                 if (nxt is not None and nxt[0] == "linear" and runtime.ln_fold_enabled(dtype)
@@ -138,6 +156,10 @@ class MLP(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         from .. import training
 
+        if x.dim() != 2:  # nn.Linear semantics: any leading dimensions (reference tests/layers/test_mlp.py: [B, N, F])
+            lead = x.shape[:-1]
+            y = self.forward(x.reshape(-1, x.shape[-1]))
+            return y.reshape(*lead, y.shape[-1])
         if training.wants_grad(self, x):
             return training.mlp(self, training._cast(x, runtime.compute_dtype(x)))
         dtype = runtime.compute_dtype(x)

@@ -65,26 +65,29 @@ def _no_group(model_comm_group) -> None:
 # ------------------------------------------------------------------------------------------------ MLP / Sequential
 def sequential(seq: nn.Sequential, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
     """Linear / activation / LayerNorm stack with each Linear fused with the activation behind it."""
+    from .layers.mlp import fused_activation_name
+
     mods = list(seq)
     i = 0
     while i < len(mods):
         m = mods[i]
         if (isinstance(m, nn.Linear) and i + 2 < len(mods) and isinstance(mods[i + 2], nn.Linear)
-                and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm))
+                and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm)) and fused_activation_name(mods[i + 1])
                 and (i + 3 == len(mods) or isinstance(mods[i + 3], (nn.Linear, nn.LayerNorm)))):
             # Linear -> activation -> Linear: one autograd node (pre-activation from the first GEMM's epilogue, act' in the
             # second GEMM's backward epilogue)
             last = i + 2 == len(mods) - 1
-            x = autograd.mlp2(x, m.weight, m.bias, mods[i + 2].weight, mods[i + 2].bias, type(mods[i + 1]).__name__,
-                              residual if last else None)
+            x = autograd.mlp2(x, m.weight, m.bias, mods[i + 2].weight, mods[i + 2].bias,
+                              fused_activation_name(mods[i + 1]), residual if last else None)
             if last:
                 residual = None
             i += 3
             continue
         if isinstance(m, nn.Linear):
             act = "Identity"
-            if i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm)):
-                act = type(mods[i + 1]).__name__
+            if (i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Linear, nn.LayerNorm))
+                    and fused_activation_name(mods[i + 1])):
+                act = fused_activation_name(mods[i + 1])
                 i += 1
             last = i == len(mods) - 1
             x = autograd.linear(x, m.weight, m.bias, act, residual if last else None)
@@ -92,8 +95,8 @@ def sequential(seq: nn.Sequential, x: Tensor, residual: Optional[Tensor] = None)
                 residual = None
         elif isinstance(m, nn.LayerNorm):
             x = autograd.layer_norm(x, m.weight, m.bias, m.eps)
-        else:
-            raise NotImplementedError(f"module {type(m).__name__} has no differentiable kernel route")
+        else:  # an activation without a GEMM epilogue (the reference takes any torch.nn activation): plain torch autograd
+            x = m(x)
         i += 1
     return x if residual is None else x + residual
 
