@@ -353,6 +353,63 @@ class _GTEdgeAttentionMapper(torch.autograd.Function):
         return dsq, dkv, dattr, None, None, None
 
 
+class _GTConv(torch.autograd.Function):
+    """``GraphTransformerConv`` on explicit per-edge features ``e [E, C]`` (CSR order) ``+ x_r``: the route of the blocks
+    for edge_dim values the folded kernels do not take (any edge_dim; reference layers/conv.py:98-142).  ``lin_edge`` is a
+    differentiable Linear in front of it; backward = the two kernels of ``csrc/edge_backward.hip`` (explicit-edge
+    variants), which also return ``d e``."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, e, x_r, plan, num_heads: int):
+        lse = torch.empty((q.shape[0], num_heads), dtype=torch.float32, device=q.device)
+        out = ops.gt_conv(q, k, v, e, plan.rowptr, plan.col, num_heads, x_r=x_r, lse=lse)
+        ctx.save_for_backward(q, k, v, e, lse)
+        ctx.plan, ctx.h, ctx.has_xr = plan, num_heads, x_r is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib
+
+        q, k, v, e, lse = ctx.saved_tensors
+        plan, h = ctx.plan, ctx.h
+        dout = dout.contiguous()
+        dxr = dout if ctx.has_xr else None
+        n_dst, c = q.shape
+        n_src, n_edges = k.shape[0], plan.col.shape[0]
+        if n_edges == 0:
+            return torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v), torch.zeros_like(e), dxr, None, None
+        dev = q.device
+        alpha = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
+        w = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
+        dsum = torch.empty((n_dst, h), dtype=torch.float32, device=dev)
+        dq = torch.empty((n_dst, c), dtype=q.dtype, device=dev)
+        dkv = torch.empty((n_src, 2 * c), dtype=q.dtype, device=dev)
+        de = torch.empty((n_edges, c), dtype=q.dtype, device=dev)
+        lib, code, stream = _lib.load(), ops.dtype_code(q.dtype), ops._stream()
+        ld = lambda t: ops._ld(ops._rows(t))  # noqa: E731
+        if ld(k) != ld(v):
+            raise ValueError("gt_conv: k and v must share their leading dimension (slices of one k | v buffer)")
+        st = lib.anemoi_gt_conv_backward_dst(code, q.data_ptr(), ld(q), k.data_ptr(), v.data_ptr(), ld(k), e.data_ptr(), ld(e),
+                                             dout.data_ptr(), ld(dout), lse.data_ptr(), plan.rowptr.data_ptr(),
+                                             plan.col.data_ptr(), alpha.data_ptr(), w.data_ptr(), dsum.data_ptr(),
+                                             dq.data_ptr(), c, n_dst, c, h, stream)
+        _lib.check(st, "anemoi_gt_conv_backward_dst")
+        rowptr_t, eid_t, dst_t, _ = _transposed_csr(plan)
+        st = lib.anemoi_gt_conv_backward_src(code, q.data_ptr(), ld(q), dout.data_ptr(), ld(dout), alpha.data_ptr(),
+                                             w.data_ptr(), dsum.data_ptr(), rowptr_t.data_ptr(), eid_t.data_ptr(),
+                                             dst_t.data_ptr(), dkv.data_ptr(), dkv[:, c:].data_ptr(), 2 * c, de.data_ptr(), c,
+                                             n_src, c, h, stream)
+        _lib.check(st, "anemoi_gt_conv_backward_src")
+        return dq, dkv[:, :c], dkv[:, c:], de, dxr, None, None
+
+
+def gt_conv(q: Tensor, k: Tensor, v: Tensor, e_csr: Tensor, x_r: Optional[Tensor], plan, num_heads: int) -> Tensor:
+    """Differentiable ``ops.gt_conv``: gradients for ``q, k, v`` (``k`` / ``v`` slices of one buffer), the per-edge
+    features ``e_csr [E, C]`` and ``x_r``."""
+    return _GTConv.apply(q, k, v, e_csr, x_r, plan, num_heads)
+
+
 def gt_edge_attention_packed(sq: Tensor, kv: Tensor, edge_attr: Tensor, plan, num_heads: int, up: int) -> Tensor:
     """:func:`gt_edge_attention` on the packed GEMM results ``sq = x_r | q | u`` ``[n_dst, 2C + H*up]`` and
     ``kv = k | v`` ``[n_src, 2C]`` (the mapper blocks' layout): gradients arrive as one ``d sq`` and one ``d kv``."""
@@ -471,9 +528,22 @@ def _lin_edge_fold(sd: dict, prefix: str, c: int, h: int, up: int, device):
     return w_u, b_u, w_t
 
 
-def _gt_tail(y_att: Tensor, x_skip: Tensor, sd: dict, prefix: str, w_t: Tensor, act: str, eps: float) -> Tensor:
+FOLD_MAX_UP = 16  # widest per-head edge representation of the folded edge kernels (edge_dim + 1 rounded up to 4)
+
+
+def _explicit_edge_features(sd: dict, prefix: str, edge_attr_csr: Tensor, dtype: torch.dtype) -> Tensor:
+    """``lin_edge(a)`` as an explicit ``[E, C]`` matrix in CSR order (the route for ``up > FOLD_MAX_UP``): the attribute
+    matrix carries a constant 1 behind the ``edge_dim`` real columns, so ``[W_e | b_e | 0]`` is the whole Linear."""
+    w_e, b_e = sd[prefix + ".lin_edge.weight"], sd[prefix + ".lin_edge.bias"]
+    up, edge_dim = edge_attr_csr.shape[1], w_e.shape[1]
+    pad = torch.zeros((w_e.shape[0], up - edge_dim - 1), dtype=w_e.dtype, device=w_e.device)
+    return linear(edge_attr_csr.to(dtype), torch.cat([w_e, b_e[:, None], pad], dim=1), None)
+
+
+def _gt_tail(y_att: Tensor, x_skip: Tensor, sd: dict, prefix: str, w_t: Optional[Tensor], act: str, eps: float) -> Tensor:
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
-    y = linear(y_att, torch.cat([g("projection.weight"), w_t], dim=1), g("projection.bias"), "Identity", x_skip)
+    w_p = g("projection.weight") if w_t is None else torch.cat([g("projection.weight"), w_t], dim=1)
+    y = linear(y_att, w_p, g("projection.bias"), "Identity", x_skip)
     h1 = layer_norm(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
     return mlp2(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), g("node_dst_mlp.3.weight"),
                 g("node_dst_mlp.3.bias"), act, y)
@@ -490,6 +560,13 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
     c = x.shape[1]
     h, up = num_heads, edge_attr_csr.shape[1]
+    if up > FOLD_MAX_UP:  # many edge attributes: lin_edge as a GEMM, the conv on explicit per-edge features
+        xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
+        sq = linear(xh, torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight")], 0),
+                    torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias")], 0))
+        att = gt_conv(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:], _explicit_edge_features(sd, prefix, edge_attr_csr, x.dtype),
+                      sq[:, :c], plan, h)
+        return _gt_tail(att, x, sd, prefix, None, act, eps)
     w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x.device)
     w_in = torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight"), w_u], 0)
     b_in = torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias"), b_u], 0)
@@ -507,11 +584,17 @@ def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_at
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
     c = x_dst.shape[1]
     h, up = num_heads, edge_attr_csr.shape[1]
-    w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x_dst.device)
     xs = layer_norm(x_src, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
     xd = layer_norm(x_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), eps)
     kv = linear(xs, torch.cat([g("lin_key.weight"), g("lin_value.weight")], 0),
                 torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0))
+    if up > FOLD_MAX_UP:  # see gt_processor_block
+        sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight")], 0),
+                    torch.cat([g("lin_self.bias"), g("lin_query.bias")], 0))
+        att = gt_conv(sq[:, c:], kv[:, :c], kv[:, c:], _explicit_edge_features(sd, prefix, edge_attr_csr, x_dst.dtype),
+                      sq[:, :c], plan, h)
+        return _gt_tail(att, x_dst, sd, prefix, None, act, eps)
+    w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x_dst.device)
     sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
                 torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))  # x_r | q | u
     att = gt_edge_attention_packed(sq, kv, edge_attr_csr, plan, h, up)

@@ -929,9 +929,11 @@ struct EdgeConvParams {
   const void* q;
   const void* k;
   const void* v;
-  const void* e;  // [E, lde] CSR order
+  const void* e;   // [E, lde] CSR order
+  const void* xr;  // optional [n_dst, ldr]: added to the result (the blocks' x_r = lin_self(x))
   void* out;
-  int64_t ldq, ldkv, lde, ldo;
+  float* lse;      // optional [n_dst, H] for the backward
+  int64_t ldq, ldkv, lde, ldo, ldr;
   int64_t n_dst;
   int C, D, n_slices;
   float scale;
@@ -1000,7 +1002,15 @@ __global__ __launch_bounds__(256) void gt_conv_kernel(const EdgeConvParams p, co
     const float inv = 1.0f / (l + 1e-16f);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] *= inv;
+    if (p.xr != nullptr) {
+      float r[VEC];
+      VecIO<T, VEC>::load(static_cast<const T*>(p.xr) + node * p.ldr + c0, r);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += r[i];
+    }
     if (active) VecIO<T, VEC>::store(static_cast<T*>(p.out) + node * p.ldo + c0, acc);
+    if (p.lse != nullptr && active && ((active ? gl : 0) % LPH) == 0)
+      p.lse[node * (p.C / p.D) + (active ? gl : 0) / LPH] = m + __logf(l + 1e-16f);
   }
 }
 
@@ -1030,20 +1040,23 @@ static bool dispatch_conv(const EdgeConvParams& p, const int32_t* rowptr, const 
 }
 
 extern "C" int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
-                              const void* edges, int64_t lde, const int32_t* rowptr, const int32_t* col, void* out,
-                              int64_t ldo, int64_t n_dst, int C, int H, anemoi_stream_t stream) {
+                              const void* edges, int64_t lde, const void* x_r, int64_t ldr, const int32_t* rowptr,
+                              const int32_t* col, void* out, int64_t ldo, float* lse, int64_t n_dst, int C, int H,
+                              anemoi_stream_t stream) {
   ANEMOI_REQUIRE(q && k && v && out && rowptr, ANEMOI_ERR_INVALID, "anemoi_gt_conv: null pointer");
-  ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0 && n_dst >= 0 && ldq >= C && ldkv >= C && ldo >= C && lde >= C,
+  ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0 && n_dst >= 0 && ldq >= C && ldkv >= C && ldo >= C && lde >= C &&
+                     (x_r == nullptr || ldr >= C),
                  ANEMOI_ERR_INVALID, "anemoi_gt_conv: bad shape");
   if (n_dst == 0) return ANEMOI_OK;
   ANEMOI_REQUIRE(col != nullptr && edges != nullptr, ANEMOI_ERR_INVALID, "anemoi_gt_conv: null edge arrays");
   const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
   ANEMOI_REQUIRE((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)edges % 16 == 0 &&
-                     (uintptr_t)out % 16 == 0 && ldq % vec == 0 && ldkv % vec == 0 && lde % vec == 0 && ldo % vec == 0,
+                     (uintptr_t)out % 16 == 0 && ldq % vec == 0 && ldkv % vec == 0 && lde % vec == 0 && ldo % vec == 0 &&
+                     (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % vec == 0)),
                  ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv: operands must be 16-byte aligned");
   EdgeConvParams p;
-  p.q = q; p.k = k; p.v = v; p.e = edges; p.out = out;
-  p.ldq = ldq; p.ldkv = ldkv; p.lde = lde; p.ldo = ldo;
+  p.q = q; p.k = k; p.v = v; p.e = edges; p.out = out; p.xr = x_r; p.lse = lse;
+  p.ldq = ldq; p.ldkv = ldkv; p.lde = lde; p.ldo = ldo; p.ldr = ldr;
   p.n_dst = n_dst; p.C = C; p.D = C / H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
   p.scale = 1.0f / sqrtf((float)(C / H));

@@ -285,6 +285,197 @@ __global__ __launch_bounds__(256) void edge_attr_grad_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of anemoi_gt_conv (explicit per-edge features e_ij [E, C] in CSR order -- the route for edge_dim values the
+// folded kernels do not cover): with k'_e = k_j + e_e, v'_e = v_j + e_e the formulas above hold with k', v' in place of
+// k, v and no attribute terms; in addition  d e_e = alpha_e dout_i + scale ds_e q_i  -- exactly the per-edge terms of
+// dv_j and dk_j, so the source-major kernel stores them on its way ([E, C], CSR position eid_t).
+// ---------------------------------------------------------------------------------------------
+struct ConvBwdParams {
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* e;
+  const void* dout;
+  const float* lse;
+  float* alpha;
+  float* w;
+  float* dsum;
+  void* dq;
+  int64_t ldq, ldkv, lde, ldd, lddq;
+  int64_t n_dst;
+  int C, H, n_slices;
+  float scale;
+};
+
+template <typename T, int VEC, int LPH, int U>
+__global__ __launch_bounds__(256) void gt_conv_bwd_dst_kernel(const ConvBwdParams p, const int32_t* __restrict__ rowptr_,
+                                                              const int32_t* __restrict__ col_) {
+  using Raw = typename RawVec<T, VEC>::type;
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
+  const int slice = wave_in_xcd % p.n_slices;
+  const int64_t node_first = wave_in_xcd / p.n_slices;
+  const int64_t node_stride = waves_per_xcd / p.n_slices;
+  const int64_t n0 = p.n_dst * xcd / 8, n1 = p.n_dst * (xcd + 1) / 8;
+  const int lanes_total = p.C / VEC;
+  const int gl = slice * 64 + lane;
+  const bool active = gl < lanes_total;
+  const int gls = active ? gl : 0;
+  const int c0 = gls * VEC;
+  const int head = gls / LPH;
+  const bool writer = active && (gls % LPH) == 0;
+  const T* qb = static_cast<const T*>(p.q) + c0;
+  const T* kb = static_cast<const T*>(p.k) + c0;
+  const T* vb = static_cast<const T*>(p.v) + c0;
+  const T* eb = static_cast<const T*>(p.e) + c0;
+  const T* dob = static_cast<const T*>(p.dout) + c0;
+  for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
+    const int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
+    float qf[VEC], dof[VEC], ak[VEC], bk[VEC], dsum = 0.f;
+    VecIO<T, VEC>::load(qb + node * p.ldq, qf);
+    VecIO<T, VEC>::load(dob + node * p.ldd, dof);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ak[i] = bk[i] = 0.f;
+    const float lse = p.lse[node * p.H + head];
+    for (int e = e_begin; e < e_end; e += U) {
+      Raw kr[U], vr[U], er[U];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          const int64_t j = col_[e + uu];
+          kr[uu] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
+          vr[uu] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
+          er[uu] = *reinterpret_cast<const Raw*>(eb + (int64_t)(e + uu) * p.lde);
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          float kk[VEC], vv[VEC], ee[VEC];
+          unpack<T, VEC>(kr[uu], kk);
+          unpack<T, VEC>(vr[uu], vv);
+          unpack<T, VEC>(er[uu], ee);
+          float ts = 0.f, td = 0.f;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            kk[i] += ee[i];
+            ts = fmaf(qf[i], kk[i], ts);
+            td = fmaf(dof[i], vv[i] + ee[i], td);
+          }
+          const float s = group_sum<LPH>(ts) * p.scale;
+          const float da = group_sum<LPH>(td);
+          const float alpha = __expf(s - lse);
+          const float w = alpha * da;
+          dsum += w;
+          if (writer) {
+            p.alpha[(int64_t)(e + uu) * p.H + head] = alpha;
+            p.w[(int64_t)(e + uu) * p.H + head] = w;
+          }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            ak[i] = fmaf(w, kk[i], ak[i]);
+            bk[i] = fmaf(alpha, kk[i], bk[i]);
+          }
+        }
+      }
+    }
+    float dq[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dq[i] = (ak[i] - dsum * bk[i]) * p.scale;
+    if (active) VecIO<T, VEC>::store(static_cast<T*>(p.dq) + node * p.lddq + c0, dq);
+    if (writer) p.dsum[node * p.H + head] = dsum;
+  }
+}
+
+struct ConvBwdSrcParams {
+  const void* q;
+  const void* dout;
+  const float* alpha;
+  const float* w;
+  const float* dsum;
+  void* dk;
+  void* dv;
+  void* de;  // [E, ldde] CSR order
+  int64_t ldq, ldd, ldg, ldde;
+  int64_t n_src;
+  int C, H, n_slices;
+  float scale;
+};
+
+template <typename T, int VEC, int LPH, int U>
+__global__ __launch_bounds__(256) void gt_conv_bwd_src_kernel(const ConvBwdSrcParams p,
+                                                              const int32_t* __restrict__ rowptr_t,
+                                                              const int32_t* __restrict__ eid_t,
+                                                              const int32_t* __restrict__ dst_t) {
+  using Raw = typename RawVec<T, VEC>::type;
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
+  const int slice = wave_in_xcd % p.n_slices;
+  const int64_t node_first = wave_in_xcd / p.n_slices;
+  const int64_t node_stride = waves_per_xcd / p.n_slices;
+  const int64_t n0 = p.n_src * xcd / 8, n1 = p.n_src * (xcd + 1) / 8;
+  const int lanes_total = p.C / VEC;
+  const int gl = slice * 64 + lane;
+  const bool active = gl < lanes_total;
+  const int gls = active ? gl : 0;
+  const int c0 = gls * VEC;
+  const int head = gls / LPH;
+  const T* qb = static_cast<const T*>(p.q) + c0;
+  const T* dob = static_cast<const T*>(p.dout) + c0;
+  T* deb = static_cast<T*>(p.de) + c0;
+  for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
+    const int t_begin = rowptr_t[node], t_end = rowptr_t[node + 1];
+    float dk[VEC], dv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dk[i] = dv[i] = 0.f;
+    for (int t = t_begin; t < t_end; t += U) {
+      Raw qr[U], dor[U];
+      float al[U], ww[U], dsm[U];
+      int64_t eid[U];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (t + uu < t_end) {
+          const int64_t e = eid_t[t + uu], i_dst = dst_t[t + uu];
+          eid[uu] = e;
+          qr[uu] = *reinterpret_cast<const Raw*>(qb + i_dst * p.ldq);
+          dor[uu] = *reinterpret_cast<const Raw*>(dob + i_dst * p.ldd);
+          al[uu] = p.alpha[e * p.H + head];
+          ww[uu] = p.w[e * p.H + head];
+          dsm[uu] = p.dsum[i_dst * p.H + head];
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (t + uu < t_end) {
+          const float dse = fmaf(-al[uu], dsm[uu], ww[uu]) * p.scale;  // scale ds_e
+          float qf[VEC], dof[VEC], de[VEC];
+          unpack<T, VEC>(qr[uu], qf);
+          unpack<T, VEC>(dor[uu], dof);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float gk = dse * qf[i], gv = al[uu] * dof[i];
+            dk[i] += gk;
+            dv[i] += gv;
+            de[i] = gk + gv;
+          }
+          if (active) VecIO<T, VEC>::store(deb + eid[uu] * p.ldde, de);
+        }
+      }
+    }
+    if (active) {
+      VecIO<T, VEC>::store(static_cast<T*>(p.dk) + node * p.ldg + c0, dk);
+      VecIO<T, VEC>::store(static_cast<T*>(p.dv) + node * p.ldg + c0, dv);
+    }
+  }
+}
+
 // the forward's launch geometry: blocks of 4 waves, block b on XCD b % 8, up to 32 CUs x wgs_per_cu blocks per XCD
 static inline unsigned bwd_blocks(int64_t n_nodes, int n_slices, int wgs_per_cu) {
   const int64_t units_per_xcd = ((n_nodes + 7) / 8) * n_slices;
@@ -438,6 +629,86 @@ int anemoi_gt_edge_attr_grad(int dtype, const float* alpha, const float* w, cons
   else
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attr_grad: dtype %d", dtype);
   return check_launch("anemoi_gt_edge_attr_grad");
+}
+
+int anemoi_gt_conv_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                const void* edges, int64_t lde, const void* dout, int64_t ldd, const float* lse,
+                                const int32_t* rowptr, const int32_t* col, float* alpha, float* w, float* dsum, void* dq,
+                                int64_t lddq, int64_t n_dst, int C, int H, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(q && k && v && edges && dout && lse && rowptr && col && alpha && w && dsum && dq, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_conv_backward_dst: null pointer");
+  ANEMOI_REQUIRE(n_dst >= 0 && C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID, "anemoi_gt_conv_backward_dst: bad shape");
+  if (n_dst == 0) return ANEMOI_OK;
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
+  ANEMOI_REQUIRE(ldq % vec == 0 && ldkv % vec == 0 && lde % vec == 0 && ldd % vec == 0 && lddq % vec == 0 && C % vec == 0 &&
+                     (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
+                     (uintptr_t)edges % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 16 == 0,
+                 ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv_backward_dst: operands must be 16-byte aligned");
+  ConvBwdParams p;
+  p.q = q; p.k = k; p.v = v; p.e = edges; p.dout = dout; p.lse = lse; p.alpha = alpha; p.w = w; p.dsum = dsum; p.dq = dq;
+  p.ldq = ldq; p.ldkv = ldkv; p.lde = lde; p.ldd = ldd; p.lddq = lddq; p.n_dst = n_dst; p.C = C; p.H = H;
+  p.n_slices = (C + 64 * vec - 1) / (64 * vec);
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(bwd_blocks(n_dst, p.n_slices, 4)), block(256);
+  const int D = C / H;
+  bool ok = D % vec == 0;
+#define ANEMOI_CONV_DST(TT, VV, L)                                                                          \
+  case L:                                                                                                   \
+    hipLaunchKernelGGL((gt_conv_bwd_dst_kernel<TT, VV, L, 2>), grid, block, 0, st, p, rowptr, col);         \
+    break;
+  if (ok && dtype == ANEMOI_F32) {
+    switch (D / 4) { ANEMOI_CONV_DST(float, 4, 1) ANEMOI_CONV_DST(float, 4, 2) ANEMOI_CONV_DST(float, 4, 4)
+                     ANEMOI_CONV_DST(float, 4, 8) ANEMOI_CONV_DST(float, 4, 16) default: ok = false; }
+  } else if (ok && dtype == ANEMOI_BF16) {
+    switch (D / 8) { ANEMOI_CONV_DST(bf16_t, 8, 1) ANEMOI_CONV_DST(bf16_t, 8, 2) ANEMOI_CONV_DST(bf16_t, 8, 4)
+                     ANEMOI_CONV_DST(bf16_t, 8, 8) ANEMOI_CONV_DST(bf16_t, 8, 16) default: ok = false; }
+  } else {
+    ok = false;
+  }
+#undef ANEMOI_CONV_DST
+  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv_backward_dst: unsupported D=%d dtype=%d", D, dtype);
+  return check_launch("anemoi_gt_conv_backward_dst");
+}
+
+int anemoi_gt_conv_backward_src(int dtype, const void* q, int64_t ldq, const void* dout, int64_t ldd, const float* alpha,
+                                const float* w, const float* dsum, const int32_t* rowptr_t, const int32_t* eid_t,
+                                const int32_t* dst_t, void* dk, void* dv, int64_t ldg, void* dedges, int64_t ldde,
+                                int64_t n_src, int C, int H, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(q && dout && alpha && w && dsum && rowptr_t && eid_t && dst_t && dk && dv && dedges, ANEMOI_ERR_INVALID,
+                 "anemoi_gt_conv_backward_src: null pointer");
+  ANEMOI_REQUIRE(n_src >= 0 && C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID, "anemoi_gt_conv_backward_src: bad shape");
+  if (n_src == 0) return ANEMOI_OK;
+  const int esz = dtype == ANEMOI_BF16 ? 2 : 4, vec = 16 / esz;
+  ANEMOI_REQUIRE(ldq % vec == 0 && ldd % vec == 0 && ldg % vec == 0 && ldde % vec == 0 && C % vec == 0 &&
+                     (uintptr_t)q % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dk % 16 == 0 &&
+                     (uintptr_t)dv % 16 == 0 && (uintptr_t)dedges % 16 == 0,
+                 ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv_backward_src: operands must be 16-byte aligned");
+  ConvBwdSrcParams p;
+  p.q = q; p.dout = dout; p.alpha = alpha; p.w = w; p.dsum = dsum; p.dk = dk; p.dv = dv; p.de = dedges;
+  p.ldq = ldq; p.ldd = ldd; p.ldg = ldg; p.ldde = ldde; p.n_src = n_src; p.C = C; p.H = H;
+  p.n_slices = (C + 64 * vec - 1) / (64 * vec);
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(bwd_blocks(n_src, p.n_slices, 5)), block(256);
+  const int D = C / H;
+  bool ok = D % vec == 0;
+#define ANEMOI_CONV_SRC(TT, VV, L)                                                                                    \
+  case L:                                                                                                             \
+    hipLaunchKernelGGL((gt_conv_bwd_src_kernel<TT, VV, L, 2>), grid, block, 0, st, p, rowptr_t, eid_t, dst_t);        \
+    break;
+  if (ok && dtype == ANEMOI_F32) {
+    switch (D / 4) { ANEMOI_CONV_SRC(float, 4, 1) ANEMOI_CONV_SRC(float, 4, 2) ANEMOI_CONV_SRC(float, 4, 4)
+                     ANEMOI_CONV_SRC(float, 4, 8) ANEMOI_CONV_SRC(float, 4, 16) default: ok = false; }
+  } else if (ok && dtype == ANEMOI_BF16) {
+    switch (D / 8) { ANEMOI_CONV_SRC(bf16_t, 8, 1) ANEMOI_CONV_SRC(bf16_t, 8, 2) ANEMOI_CONV_SRC(bf16_t, 8, 4)
+                     ANEMOI_CONV_SRC(bf16_t, 8, 8) ANEMOI_CONV_SRC(bf16_t, 8, 16) default: ok = false; }
+  } else {
+    ok = false;
+  }
+#undef ANEMOI_CONV_SRC
+  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv_backward_src: unsupported D=%d dtype=%d", D, dtype);
+  return check_launch("anemoi_gt_conv_backward_src");
 }
 
 }  // extern "C"

@@ -290,10 +290,12 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     return out
 
 
-def gt_conv(q: Tensor, k: Tensor, v: Tensor, edges_csr: Tensor, rowptr: Tensor, col: Tensor, num_heads: int) -> Tensor:
+def gt_conv(q: Tensor, k: Tensor, v: Tensor, edges_csr: Tensor, rowptr: Tensor, col: Tensor, num_heads: int,
+            x_r: Optional[Tensor] = None, lse: Optional[Tensor] = None) -> Tensor:
     """``GraphTransformerConv`` with explicit per-edge features (reference layers/conv.py:98-142): ``q [n_dst, C]``,
-    ``k, v [n_src, C]``, ``edges_csr [E, C]`` in the CSR order of ``(rowptr, col)``; returns ``[n_dst, C]``."""
-    _dev(q, k, v, edges_csr, rowptr, col)
+    ``k, v [n_src, C]``, ``edges_csr [E, C]`` in the CSR order of ``(rowptr, col)``; returns ``[n_dst, C]`` (``+ x_r``).
+    ``lse`` (optional f32 ``[n_dst, H]``) receives the softmax normaliser (training)."""
+    _dev(q, k, v, edges_csr, rowptr, col, x_r, lse)
     n_dst, c = _rows(q).shape
     if _ld(_rows(k)) != _ld(_rows(v)):
         raise ValueError("gt_conv: k and v must share their leading dimension")
@@ -303,12 +305,15 @@ def gt_conv(q: Tensor, k: Tensor, v: Tensor, edges_csr: Tensor, rowptr: Tensor, 
         raise ValueError("gt_conv: edges must be [E, C] in the activation dtype")
     out = torch.empty((n_dst, c), dtype=q.dtype, device=q.device)
     if col.shape[0] == 0:
-        return out.zero_()
+        if lse is not None:
+            lse.fill_(float("-inf"))
+        return out.zero_() if x_r is None else out.copy_(x_r)
     alg_bytes = (2 * n_dst + 2 * k.shape[0] + col.shape[0]) * c * q.element_size() + col.shape[0] * 4 + (n_dst + 1) * 4
     with _Timed("gt_conv", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
         st = _lib.load().anemoi_gt_conv(dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)),
-                                        edges_csr.data_ptr(), _ld(_rows(edges_csr)), rowptr.data_ptr(), col.data_ptr(),
-                                        out.data_ptr(), _ld(out), n_dst, c, num_heads, _stream())
+                                        edges_csr.data_ptr(), _ld(_rows(edges_csr)), _ptr(x_r),
+                                        0 if x_r is None else _ld(_rows(x_r)), rowptr.data_ptr(), col.data_ptr(),
+                                        out.data_ptr(), _ld(out), _ptr(lse), n_dst, c, num_heads, _stream())
     _lib.check(st, "anemoi_gt_conv")
     return out
 

@@ -157,11 +157,23 @@ int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const
  * GraphTransformerConv with explicit per-edge features (the callable the reference exposes, layers/conv.py:98-142):
  *   s_ij = q_i . (k_j + e_ij) / sqrt(D),  alpha = softmax over the in-edges of i (+1e-16),  out_i = sum_j alpha (v_j + e_ij)
  * q [n_dst, C], k / v [n_src, C], edges [E, C] in the CSR order of (rowptr, col) (= lin_edge(edge_attr)[perm]), all in
- * the activation dtype.  The block mirrors never call this (they fold lin_edge away, see above).
+ * the activation dtype; x_r (optional) is added to the result, lse (optional f32 [n_dst, H]) receives the softmax
+ * normaliser for the backward.  The block mirrors fold lin_edge away (see above) and come here only for edge_dim values
+ * the folded / fused kernels do not cover (any edge_dim works on this route).
+ * Backward (same structure as the folded backward below, with k + e, v + e in place of k, v):
+ *   _dst: alpha, w [E, H], dsum [n_dst, H] (f32), dq;   _src: dk, dv and d edges [E, C] (CSR order) = alpha dout_i + scale ds q_i.
  */
 int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* edges,
-                   int64_t lde, const int32_t* rowptr, const int32_t* col, void* out, int64_t ldo, int64_t n_dst, int C,
-                   int H, anemoi_stream_t stream);
+                   int64_t lde, const void* x_r, int64_t ldr, const int32_t* rowptr, const int32_t* col, void* out,
+                   int64_t ldo, float* lse, int64_t n_dst, int C, int H, anemoi_stream_t stream);
+int anemoi_gt_conv_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                const void* edges, int64_t lde, const void* dout, int64_t ldd, const float* lse,
+                                const int32_t* rowptr, const int32_t* col, float* alpha, float* w, float* dsum, void* dq,
+                                int64_t lddq, int64_t n_dst, int C, int H, anemoi_stream_t stream);
+int anemoi_gt_conv_backward_src(int dtype, const void* q, int64_t ldq, const void* dout, int64_t ldd, const float* alpha,
+                                const float* w, const float* dsum, const int32_t* rowptr_t, const int32_t* eid_t,
+                                const int32_t* dst_t, void* dk, void* dv, int64_t ldg, void* dedges, int64_t ldde,
+                                int64_t n_src, int C, int H, anemoi_stream_t stream);
 
 /*
  * The folded edge phase with LDS staging of the source rows (same inputs / outputs as anemoi_gt_edge_attention_folded,

@@ -85,7 +85,7 @@ def gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, rowptr, col, num_heads,
     return F.pad(res, (0, ld - res.shape[1])).to(q.dtype)
 
 
-def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads):
+def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads, x_r=None, lse=None):
     n_dst, c = q.shape
     d = c // num_heads
     dst = torch.repeat_interleave(torch.arange(n_dst), (rowptr[1:] - rowptr[:-1]).long())
@@ -95,7 +95,8 @@ def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads):
     vj = v.float().reshape(-1, num_heads, d)[src] + e
     score = (q.float().reshape(n_dst, num_heads, d)[dst] * kj).sum(-1) / d**0.5
     alpha = segment_softmax(score, dst, n_dst)
-    return scatter_sum(vj * alpha.unsqueeze(-1), dst, n_dst).reshape(n_dst, c).to(q.dtype)
+    out = scatter_sum(vj * alpha.unsqueeze(-1), dst, n_dst).reshape(n_dst, c)
+    return (out if x_r is None else out + x_r.float()).to(q.dtype)
 
 
 def gt_edge_attention_tiled(q, k, v, x_r, u, edge_attr, rowptr, tiles, num_heads, up, out=None, ld_out=None):

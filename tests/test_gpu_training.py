@@ -353,3 +353,50 @@ def test_multi_head_self_attention_module_like_the_reference_tests(batch_size, n
     assert torch.equal(y_eval, y_eval2)
     if 0.0 < p < 1.0:
         assert not torch.equal(y_train, y_eval)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 8e-2)])
+def test_blocks_with_many_edge_attributes_train_through_the_explicit_conv(dtype, tol, monkeypatch):
+    """edge_dim = 39 (the reference's own mapper tests use 1 + 32 attributes + 6 trainable): beyond the folded edge
+    kernels' width, so the differentiable blocks run lin_edge as a GEMM and the conv on explicit per-edge features
+    (anemoi_gt_conv + its backward kernels).  Forward and every gradient against the oracle's autograd; the inference
+    route (generic kernel) agrees with the training route."""
+    from anemoi_models_amd.layers.block import GraphTransformerMapperBlock, GraphTransformerProcessorBlock
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32" if dtype == torch.float32 else "bf16")
+    g = torch.Generator().manual_seed(39)
+    c, h, edge_dim, n, n_src, e = 128, 8, 39, 150, 210, 1200
+    torch.manual_seed(5)
+    # --- processor block
+    blk = GraphTransformerProcessorBlock(c, 2 * c, c, edge_dim=edge_dim, num_heads=h)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n - 1, (e,), generator=g)])
+    x0, ea0 = torch.randn(n, c, generator=g), torch.randn(e, edge_dim, generator=g)
+    rsd = {"x." + k: v.detach().double().requires_grad_() for k, v in blk.named_parameters()}
+    xr, ear = x0.double().requires_grad_(), ea0.double().requires_grad_()
+    want = ref.gt_processor_block(rsd, "x", xr, ear, ei, h)
+    want.sum().backward()
+    blk = blk.to(DEV)
+    x, ea = x0.to(DEV).requires_grad_(), ea0.to(DEV).requires_grad_()
+    y, _ = blk(x, ea, ei.to(DEV), None, 1)
+    assert rel_err(y.detach(), want.detach()) < tol
+    y.sum().backward()
+    assert rel_err(x.grad, xr.grad) < tol and rel_err(ea.grad, ear.grad) < tol
+    _compare_block_grads(blk, rsd, tol=tol)
+    with torch.no_grad():
+        y_inf, _ = blk(x.detach(), ea.detach(), ei.to(DEV), None, 1)
+    assert rel_err(y_inf, want.detach()) < tol
+    # --- mapper block
+    blk = GraphTransformerMapperBlock(c, 2 * c, c, edge_dim=edge_dim, num_heads=h)
+    ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, n - 1, (e,), generator=g)])
+    xs0, xd0 = torch.randn(n_src, c, generator=g), torch.randn(n, c, generator=g)
+    rsd = {"x." + k: v.detach().double().requires_grad_() for k, v in blk.named_parameters()}
+    xsr, xdr, ear = xs0.double().requires_grad_(), xd0.double().requires_grad_(), ea0.double().requires_grad_()
+    want = ref.gt_mapper_block(rsd, "x", xsr, xdr, ear, ei, h)
+    want.sum().backward()
+    blk = blk.to(DEV)
+    xs, xd, ea = xs0.to(DEV).requires_grad_(), xd0.to(DEV).requires_grad_(), ea0.to(DEV).requires_grad_()
+    (_, y), _ = blk((xs, xd), ea, ei.to(DEV), None, 1, size=(n_src, n))
+    assert rel_err(y.detach(), want.detach()) < tol
+    y.sum().backward()
+    assert rel_err(xs.grad, xsr.grad) < tol and rel_err(xd.grad, xdr.grad) < tol and rel_err(ea.grad, ear.grad) < tol
+    _compare_block_grads(blk, rsd, tol=tol)

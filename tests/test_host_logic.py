@@ -497,3 +497,60 @@ def test_graph_transformer_conv_forward_host_wiring(monkeypatch):
         got = GraphTransformerConv(out_channels=d).eval()(q, k, v, edges, ei, size=(n_src, n_dst))
     torch.testing.assert_close(got, ref.gt_conv(q, k, v, edges, ei, n_dst), atol=1e-5, rtol=1e-5)
     assert float(got[n_dst - 1].abs().max()) == 0.0  # isolated destination
+
+
+def test_reference_piecewise_api_of_blocks_and_mappers(graph_o32, monkeypatch):
+    """The hooks the reference exposes next to ``forward`` (and its own tests call): block ``shard_qkve_heads`` /
+    ``shard_output_seq`` (layers/block.py:366-414), mapper ``pre_process`` / ``post_process`` (layers/mapper.py:68-116,
+    412-418, 690-694) -- shapes, shape bookkeeping and values for a single process."""
+    import _cpu_ops
+    from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
+    from anemoi_models_amd.layers.mapper import GraphTransformerBackwardMapper, GraphTransformerForwardMapper
+
+    _cpu_ops.install(monkeypatch)
+    blk = GraphTransformerProcessorBlock(in_channels=64, hidden_dim=128, out_channels=64, edge_dim=5, num_heads=4)
+    q, k, v, e = (torch.randn(30, 64) for _ in range(4))
+    q3, k3, v3, e3 = blk.shard_qkve_heads(q, k, v, e, (10, 10, 10), 1)
+    assert q3.shape == (30, 4, 16) and torch.equal(q3.reshape(30, 64), q) and torch.equal(e3.reshape(30, 64), e)
+    assert torch.equal(blk.shard_output_seq(q3, (10, 10, 10), 1), q)
+
+    sub = graph_o32[("data", "to", "hidden")]
+    n_src, n_dst = graph_o32["data"].num_nodes, graph_o32["hidden"].num_nodes
+    kw = dict(hidden_dim=64, trainable_size=4, num_heads=4, sub_graph=sub, sub_graph_edge_attributes=["edge_length", "edge_dirs"],
+              src_grid_size=n_src, dst_grid_size=n_dst)
+    fwd = GraphTransformerForwardMapper(in_channels_src=7, in_channels_dst=5, **kw).eval()
+    x = (torch.randn(n_src, 7), torch.randn(n_dst, 5))
+    shapes = ([[n_src, 7]], [[n_dst, 5]])
+    with torch.no_grad():
+        xs, xd, ss, sd = fwd.pre_process(x, shapes)
+    assert xs.shape == (n_src, 64) and xd.shape == (n_dst, 64) and ss == [[n_src, 64]] and sd == [[n_dst, 64]]
+    torch.testing.assert_close(xs, fwd.emb_nodes_src(x[0]), atol=1e-5, rtol=1e-5)
+    assert fwd.post_process(xd, sd) is xd
+    sub_b = graph_o32[("hidden", "to", "data")]
+    bwd = GraphTransformerBackwardMapper(in_channels_src=64, in_channels_dst=5, hidden_dim=64, out_channels_dst=3,
+                                         trainable_size=4, num_heads=4, sub_graph=sub_b,
+                                         sub_graph_edge_attributes=["edge_length", "edge_dirs"], src_grid_size=n_dst,
+                                         dst_grid_size=n_src).eval()
+    with torch.no_grad():
+        hs, hd, ss, sd = bwd.pre_process((torch.randn(n_dst, 64), torch.randn(n_src, 5)), ([[n_dst, 64]], [[n_src, 5]]))
+        out = bwd.post_process(hd, sd)
+    assert hs.shape == (n_dst, 64) and hd.shape == (n_src, 64) and sd == [[n_src, 64]] and out.shape == (n_src, 3)
+    torch.testing.assert_close(out, bwd.node_data_extractor(hd), atol=1e-5, rtol=1e-5)
+
+
+def test_mlp_leading_dimensions_and_unfused_activation(monkeypatch):
+    """MLP on [B, N, F] inputs (nn.Linear semantics, reference tests/layers/test_mlp.py) and an activation the GEMM
+    epilogue does not have (the reference takes any torch.nn activation by name): a torch op behind the Linear."""
+    import _cpu_ops
+    from anemoi_models_amd.layers.mlp import MLP
+
+    _cpu_ops.install(monkeypatch)
+    torch.manual_seed(3)
+    for act in ("SiLU", "Tanh"):
+        mlp = MLP(64, 128, 36, activation=act, layer_norm=True).eval()
+        x = torch.randn(2, 50, 64)
+        with torch.no_grad():
+            y = mlp(x)
+            want = mlp.model(x)  # the nn.Sequential itself on torch ops
+        assert y.shape == (2, 50, 36)
+        torch.testing.assert_close(y, want, atol=2e-5, rtol=2e-5)
