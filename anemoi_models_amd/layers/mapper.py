@@ -54,7 +54,7 @@ class BaseMapper(nn.Module, ABC):
             raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
 
     @staticmethod
-    def _apply(module: nn.Module, x: Tensor) -> Tensor:
+    def _apply_module(module: nn.Module, x: Tensor) -> Tensor:
         """An embedding / extraction sub-module on node rows, on the HIP kernels with or without an autograd graph."""
         from .mlp import MLP, NativeSequential
 
@@ -86,7 +86,7 @@ class ForwardMapperPreProcessMixin:
         from ..distributed.shapes import change_channels_in_shape
 
         x_src, x_dst, shapes_src, shapes_dst = super().pre_process(x, shard_shapes, model_comm_group)
-        return (self._apply(self.emb_nodes_src, x_src), self._apply(self.emb_nodes_dst, x_dst),
+        return (self._apply_module(self.emb_nodes_src, x_src), self._apply_module(self.emb_nodes_dst, x_dst),
                 change_channels_in_shape(shapes_src, self.hidden_dim), change_channels_in_shape(shapes_dst, self.hidden_dim))
 
 
@@ -95,7 +95,7 @@ class BackwardMapperPostProcessMixin:
 
     def post_process(self, x_dst, shapes_dst, model_comm_group=None):
         self._single_group(model_comm_group)
-        return self._apply(self.node_data_extractor, x_dst)
+        return self._apply_module(self.node_data_extractor, x_dst)
 
 
 class GraphEdgeMixin:
@@ -279,7 +279,7 @@ class GraphTransformerBackwardMapper(BackwardMapperPostProcessMixin, GraphTransf
         from ..distributed.shapes import change_channels_in_shape
 
         x_src, x_dst, shapes_src, shapes_dst = super().pre_process(x, shard_shapes, model_comm_group)
-        return (x_src, self._apply(self.emb_nodes_dst, x_dst), change_channels_in_shape(shapes_src, self.hidden_dim),
+        return (x_src, self._apply_module(self.emb_nodes_dst, x_dst), change_channels_in_shape(shapes_src, self.hidden_dim),
                 change_channels_in_shape(shapes_dst, self.hidden_dim))
 
     def _embed(self, x_src: Tensor, x_dst: Tensor, one_cols=(None, None)):
