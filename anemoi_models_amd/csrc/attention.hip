@@ -147,6 +147,12 @@ __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict
   if (kt_begin < kt_end) stage(kt_begin, 0);
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
+    // This wave's LDS-DMA of tile kt has to have LANDED before the barrier publishes the buffer.  The compiler does not
+    // count an LDS-DMA as a writer of the LDS it reads below: in this loop it emitted the vmcnt(0) once in front of the loop
+    // and only lgkmcnt(0) at the barrier, so a tile whose DMA outlasted the previous tile's arithmetic was read half
+    // landed (intermittent 10-40 % errors in single rows, ~5 % of calls at B x H = 32 workgroups; found in round 2 by
+    // tools/mhsa_stress.py).  Explicit wait, as in the GEMM kernels.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
     const char* ks_ = smem + buf * ATT_STAGE;
@@ -302,14 +308,17 @@ template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__ qkv, int64_t ld, T* __restrict__ out,
                                                            int64_t ldo, int S, int H, int D, int C, int window,
                                                            float scale, int64_t total, float* __restrict__ lse,
-                                                           const AttnDropout dr) {
+                                                           const AttnDropout dr, int q_begin, int q_count) {
+  // queries [q_begin, q_begin + q_count) of every batch element (the whole sequence, or the few rows the MFMA kernel's
+  // 512-query blocks leave over)
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
   if (unit >= total) return;
   const int h = (int)(unit % H);
-  const int64_t bq = unit / H;
-  const int q = (int)(bq % S);
-  const int64_t b = bq / S;
+  const int64_t bql = unit / H;
+  const int q = q_begin + (int)(bql % q_count);
+  const int64_t b = bql / q_count;
+  const int64_t bq = b * S + q;
   const T* qp = qkv + bq * ld + h * D;
   float qv[DMAX], acc[DMAX];
 #pragma unroll
@@ -510,7 +519,22 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
     const int S_pad = (S + 63) / 64 * 64;
     hipLaunchKernelGGL(transpose_v_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, st,
                        static_cast<const bf16_t*>(qkv), ld, S, S_pad, H, D, C, static_cast<bf16_t*>(workspace));
-    const dim3 grid((S + ATT_QBLK - 1) / ATT_QBLK, H, B), block(64 * ATT_WAVES);
+    // A workgroup streams ALL keys whatever its number of queries, so a last block of a few queries costs a whole block:
+    // refined icosahedral meshes have 10 * 4^k + 2 nodes -- at S = 40 962 the 2 left-over queries x 16 heads were 16 extra
+    // workgroups = a sixth round on 256 CUs (+16 % of the layer).  Up to 16 such rows go to the generic kernel instead.
+    const int rem = S % ATT_QBLK;
+    const int s_main = (S > ATT_QBLK && rem > 0 && rem <= 16) ? S - rem : S;
+    if (s_main < S) {
+      const int64_t units = (int64_t)B * rem * H;
+      dim3 ggrid((unsigned)((units + 3) / 4)), gblock(256);
+      if (D == 64)
+        hipLaunchKernelGGL((mhsa_generic_kernel<bf16_t, 64>), ggrid, gblock, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                           static_cast<bf16_t*>(out), ldo, S, H, D, C, window, scale, units, lse, dr, s_main, rem);
+      else
+        hipLaunchKernelGGL((mhsa_generic_kernel<bf16_t, 32>), ggrid, gblock, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                           static_cast<bf16_t*>(out), ldo, S, H, D, C, window, scale, units, lse, dr, s_main, rem);
+    }
+    const dim3 grid((s_main + ATT_QBLK - 1) / ATT_QBLK, H, B), block(64 * ATT_WAVES);
     if (D == 64)
       hipLaunchKernelGGL(mhsa_bf16_kernel<64>, grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
                          static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
@@ -527,7 +551,7 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   dim3 grid((unsigned)((units + 3) / 4)), block(256);
 #define GEN(T, DM)                                                                                               \
   hipLaunchKernelGGL((mhsa_generic_kernel<T, DM>), grid, block, 0, st, static_cast<const T*>(qkv), ld,           \
-                     static_cast<T*>(out), ldo, S, H, D, C, window, scale, units, lse, dr)
+                     static_cast<T*>(out), ldo, S, H, D, C, window, scale, units, lse, dr, 0, S)
   if (dtype == ANEMOI_F32) {
     if (D <= 32) GEN(float, 32);
     else if (D <= 64) GEN(float, 64);

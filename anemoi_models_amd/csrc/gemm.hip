@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, in
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-      __syncthreads();  // tile kt landed (vmcnt(0) is part of the barrier while an LDS-DMA is in flight)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA of tile kt has landed (explicit: the
+      __syncthreads();                                    // compiler does not always count it at the barrier)
       if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
       const char* xs = smem + (kt & 1) * (2 * TILE_BYTES);
       const char* ws = xs + TILE_BYTES;
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ X, in
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the bf16 loop above)
       __syncthreads();
       if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
       const char* xs = smem + (kt & 1) * (2 * TILE_BYTES);

@@ -774,6 +774,8 @@ def _sdpa(qkv, b, h, window):
     (torch.bfloat16, 1, 200, 8, 32, -1),      # MFMA kernel, D = 32 (config 2's head size: 512 channels / 16 heads)
     (torch.bfloat16, 2, 1111, 16, 32, -1),    # ... batch 2, ragged S, several 64-key tiles
     (torch.bfloat16, 1, 900, 4, 32, 70),      # ... sliding window
+    (torch.bfloat16, 2, 1026, 4, 64, -1),     # 2 * 512 + 2 queries (icosahedral meshes: 10 * 4^k + 2): the two left-over
+    (torch.bfloat16, 1, 2562, 8, 32, 100),    # rows run on the generic kernel, not as a workgroup of their own
     (torch.bfloat16, 1, 200, 8, 16, -1),      # generic kernel, bf16 storage
     (torch.float32, 2, 96, 8, 8, -1),         # generic kernel, the golden block shape
     (torch.float32, 1, 500, 4, 64, -1),

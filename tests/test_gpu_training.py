@@ -225,7 +225,7 @@ def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name,
 
 @pytest.mark.parametrize("dtype,b,s,h,d,window", [
     (torch.float32, 2, 300, 4, 64, -1), (torch.float32, 1, 257, 2, 24, 30), (torch.bfloat16, 1, 700, 8, 64, -1),
-    (torch.bfloat16, 2, 333, 16, 32, -1), (torch.bfloat16, 1, 400, 2, 64, 50),
+    (torch.bfloat16, 2, 333, 16, 32, -1), (torch.bfloat16, 1, 400, 2, 64, 50), (torch.bfloat16, 1, 1026, 2, 64, -1),
 ])
 def test_mhsa_backward_vs_torch_autograd(dtype, b, s, h, d, window):
     """anemoi_mhsa_backward (probabilities recomputed from the forward's log-sum-exp) against torch autograd through an
