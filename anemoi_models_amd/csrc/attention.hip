@@ -78,7 +78,9 @@ __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict
   constexpr int KRB = ATT_D * 2;                        // bytes of a key row in the K tile
   constexpr int K_TILE = ATT_KV * KRB, V_TILE = ATT_D * 128;
   constexpr int ATT_STAGE = K_TILE + V_TILE;
-  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];  // 2 stages x (K tile + V^T tile)
+  constexpr int N_STAGE = 3;  // ring of tile buffers: tile kt + 2 is requested while tile kt is computed
+  constexpr int DMA_PER_STAGE = ATT_D == 64 ? 2 : 1;  // LDS-DMA instructions per wave and tile
+  __shared__ __attribute__((aligned(16))) char smem[N_STAGE * ATT_STAGE];  // stages x (K tile + V^T tile)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = blockIdx.y, b = blockIdx.z;
@@ -145,16 +147,24 @@ __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict
   const int kperm = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
 
   if (kt_begin < kt_end) stage(kt_begin, 0);
+  if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    // This wave's LDS-DMA of tile kt has to have LANDED before the barrier publishes the buffer.  The compiler does not
-    // count an LDS-DMA as a writer of the LDS it reads below: in this loop it emitted the vmcnt(0) once in front of the loop
-    // and only lgkmcnt(0) at the barrier, so a tile whose DMA outlasted the previous tile's arithmetic was read half
-    // landed (intermittent 10-40 % errors in single rows, ~5 % of calls at B x H = 32 workgroups; found in round 2 by
-    // tools/mhsa_stress.py).  Explicit wait, as in the GEMM kernels.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
+    const int buf = (kt - kt_begin) % N_STAGE;
+    // This wave's LDS-DMA of tile kt has to have LANDED before the barrier publishes the buffer; tile kt + 1 may stay in
+    // flight (vmcnt counts this wave's requests in order, DMA_PER_STAGE per tile).  The compiler does not count an LDS-DMA
+    // as a writer of the LDS read below: with a plain __syncthreads() it emitted vmcnt(0) once in front of the loop and
+    // only lgkmcnt(0) at the barrier, so a tile whose DMA outlasted the previous tile's arithmetic was read half landed
+    // (intermittent 10-40 % errors in single rows, ~5 % of the calls at B x H = 32 workgroups; found in round 2 by
+    // tools/mhsa_stress.py).  Explicit counted waits, as in the GEMM kernels; the ring of three buffers keeps a whole
+    // tile time between a request and its wait.
+    if (kt + 1 < kt_end) {
+      if constexpr (DMA_PER_STAGE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();  // everyone's share of tile kt is in LDS; everyone is done with tile kt - 1 (the buffer refilled next)
+    if (kt + 2 < kt_end) stage(kt + 2, (kt + 2 - kt_begin) % N_STAGE);
     const char* ks_ = smem + buf * ATT_STAGE;
     const char* vs_ = ks_ + K_TILE;
 #pragma unroll
@@ -367,6 +377,126 @@ __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// The few queries the MFMA kernel's 512-query blocks leave over (S = 10 * 4^k + 2 on refined icosahedral meshes): a
+// workgroup of the MFMA kernel streams ALL keys whatever its number of queries, so 2 left-over rows x 16 heads were a sixth
+// round of workgroups on 256 CUs (+16 % per layer at S = 40 962).  Here the key range of every (batch, query, head) is
+// split over n_split waves (flash-decoding style): a wave runs the online softmax of its key chunk (lane = key, 16-byte
+// loads) and leaves { max, sum, acc[D] } in a workspace; a second kernel merges the chunks.  bf16, D = 32 / 64.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void mhsa_tail_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int S, int H, int C,
+                                                        int window, float scale, int q_begin, int q_count, int n_split,
+                                                        int chunk, int64_t total, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h, split)
+  if (unit >= total) return;
+  const int split = (int)(unit % n_split);
+  const int64_t u2 = unit / n_split;
+  const int h = (int)(u2 % H);
+  const int64_t bql = u2 / H;
+  const int q = q_begin + (int)(bql % q_count);
+  const int64_t b = bql / q_count;
+  float qv[D], acc[D];
+  {
+    const bf16_t* qp = qkv + (b * S + q) * ld + h * D;
+#pragma unroll
+    for (int d8 = 0; d8 < D / 8; ++d8) {
+      float t[8];
+      VecIO<bf16_t, 8>::load(qp + d8 * 8, t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qv[d8 * 8 + i] = t[i] * scale;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  int k_lo = split * chunk, k_hi = k_lo + chunk < S ? k_lo + chunk : S;
+  if (window >= 0) {
+    k_lo = k_lo > q - window ? k_lo : q - window;
+    k_hi = k_hi < q + window + 1 ? k_hi : q + window + 1;
+  }
+  for (int key = k_lo + lane; key < k_hi; key += 64) {
+    const bf16_t* kp = qkv + (b * S + key) * ld + C + h * D;
+    const bf16_t* vp = kp + C;
+    float s = 0.f;
+#pragma unroll
+    for (int d8 = 0; d8 < D / 8; ++d8) {
+      float t[8];
+      VecIO<bf16_t, 8>::load(kp + d8 * 8, t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s = fmaf(qv[d8 * 8 + i], t[i], s);
+    }
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), pe = __expf(s - mn);
+    l = l * corr + pe;
+#pragma unroll
+    for (int d8 = 0; d8 < D / 8; ++d8) {
+      float t[8];
+      VecIO<bf16_t, 8>::load(vp + d8 * 8, t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[d8 * 8 + i] = acc[d8 * 8 + i] * corr + pe * t[i];
+    }
+    m = mn;
+  }
+  float mt = m;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mt = fmaxf(mt, __shfl_xor(mt, off, 64));
+  const float w = m == -INFINITY ? 0.f : __expf(m - mt);
+  const float lt = wave_sum(l * w);
+  float* pp = part + unit * (D + 2);
+  if (lane == 0) {
+    pp[0] = mt;
+    pp[1] = lt;
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float o = wave_sum(acc[d] * w);
+    if (lane == 0) pp[2 + d] = o;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void mhsa_tail_merge_kernel(const float* __restrict__ part, bf16_t* __restrict__ out,
+                                                              int64_t ldo, float* __restrict__ lse, int S, int H,
+                                                              int q_begin, int q_count, int n_split, int64_t n_units) {
+  // one thread per (unit, d): n_split partial states -> the normalised output row slice
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_units * D) return;
+  const int d = (int)(idx % D);
+  const int64_t u2 = idx / D;  // (b, q, h)
+  const int h = (int)(u2 % H);
+  const int64_t bql = u2 / H;
+  const int q = q_begin + (int)(bql % q_count);
+  const int64_t b = bql / q_count;
+  const float* pp = part + u2 * n_split * (D + 2);
+  float mt = -INFINITY;
+  for (int sidx = 0; sidx < n_split; ++sidx) mt = fmaxf(mt, pp[sidx * (D + 2)]);
+  float lt = 0.f, o = 0.f;
+  for (int sidx = 0; sidx < n_split; ++sidx) {
+    const float mi = pp[sidx * (D + 2)];
+    const float w = mi == -INFINITY ? 0.f : __expf(mi - mt);
+    lt = fmaf(pp[sidx * (D + 2) + 1], w, lt);
+    o = fmaf(pp[sidx * (D + 2) + 2 + d], w, o);
+  }
+  Elem<bf16_t>::store(out + (b * S + q) * ldo + h * D + d, lt > 0.f ? o / lt : 0.f);
+  if (lse != nullptr && d == 0) lse[(b * H + h) * S + q] = mt + __logf(lt);
+}
+
+// left-over rows of the MFMA path and the split of their key range (0 rows: the MFMA kernel takes everything)
+static inline int mhsa_tail_rows(int S) {
+  const int rem = S % 512;
+  return (S > 512 && rem > 0 && rem <= 16) ? rem : 0;
+}
+static inline int mhsa_tail_splits(int B, int S, int H) {
+  const int rem = mhsa_tail_rows(S);
+  if (rem == 0) return 0;
+  int64_t n = 4096 / ((int64_t)B * rem * H);
+  const int64_t max_split = (S + 255) / 256;  // at least 256 keys per wave
+  if (n > max_split) n = max_split;
+  return (int)(n < 1 ? 1 : n);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of softmax(Q K^T / sqrt(D)) V (flash-attention style: nothing of size S x S is stored; the probabilities are
 // recomputed from the saved log-sum-exp).  With P_ij = exp(s_ij - lse_i), dP_ij = dO_i . v_j, delta_i = dO_i . O_i,
 // dS_ij = P_ij (dP_ij - delta_i):   dQ_i = scale sum_j dS_ij k_j,   dK_j = scale sum_i dS_ij q_i,   dV_j = sum_i P_ij dO_i.
@@ -495,8 +625,13 @@ using namespace anemoi;
 
 extern "C" {
 
+static inline int64_t mhsa_vt_bytes(int B, int S, int H, int D) {
+  return ((int64_t)B * H * D * ((S + 63) / 64 * 64) * 2 + 255) / 256 * 256;
+}
+
 int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
-  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32)) return (int64_t)B * H * D * ((S + 63) / 64 * 64) * 2;
+  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32))  // V^T, then the partial states of the left-over rows' key chunks
+    return mhsa_vt_bytes(B, S, H, D) + (int64_t)B * mhsa_tail_rows(S) * H * mhsa_tail_splits(B, S, H) * (D + 2) * 4;
   return 0;
 }
 
@@ -519,20 +654,26 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
     const int S_pad = (S + 63) / 64 * 64;
     hipLaunchKernelGGL(transpose_v_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, st,
                        static_cast<const bf16_t*>(qkv), ld, S, S_pad, H, D, C, static_cast<bf16_t*>(workspace));
-    // A workgroup streams ALL keys whatever its number of queries, so a last block of a few queries costs a whole block:
-    // refined icosahedral meshes have 10 * 4^k + 2 nodes -- at S = 40 962 the 2 left-over queries x 16 heads were 16 extra
-    // workgroups = a sixth round on 256 CUs (+16 % of the layer).  Up to 16 such rows go to the generic kernel instead.
-    const int rem = S % ATT_QBLK;
-    const int s_main = (S > ATT_QBLK && rem > 0 && rem <= 16) ? S - rem : S;
-    if (s_main < S) {
-      const int64_t units = (int64_t)B * rem * H;
-      dim3 ggrid((unsigned)((units + 3) / 4)), gblock(256);
-      if (D == 64)
-        hipLaunchKernelGGL((mhsa_generic_kernel<bf16_t, 64>), ggrid, gblock, 0, st, static_cast<const bf16_t*>(qkv), ld,
-                           static_cast<bf16_t*>(out), ldo, S, H, D, C, window, scale, units, lse, dr, s_main, rem);
-      else
-        hipLaunchKernelGGL((mhsa_generic_kernel<bf16_t, 32>), ggrid, gblock, 0, st, static_cast<const bf16_t*>(qkv), ld,
-                           static_cast<bf16_t*>(out), ldo, S, H, D, C, window, scale, units, lse, dr, s_main, rem);
+    // the few queries behind the last whole 512-query block: key-split kernels above (not a workgroup of their own)
+    const int rem = mhsa_tail_rows(S);
+    const int s_main = S - rem;
+    if (rem > 0) {
+      const int n_split = mhsa_tail_splits(B, S, H);
+      const int chunk = (S + n_split - 1) / n_split;
+      const int64_t n_units = (int64_t)B * rem * H, total = n_units * n_split;
+      float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + mhsa_vt_bytes(B, S, H, D));
+      const dim3 tgrid((unsigned)((total + 3) / 4)), tblock(256);
+      if (D == 64) {
+        hipLaunchKernelGGL(mhsa_tail_kernel<64>, tgrid, tblock, 0, st, static_cast<const bf16_t*>(qkv), ld, S, H, C, window,
+                           scale, s_main, rem, n_split, chunk, total, part);
+        hipLaunchKernelGGL(mhsa_tail_merge_kernel<64>, dim3((unsigned)((n_units * 64 + 255) / 256)), dim3(256), 0, st, part,
+                           static_cast<bf16_t*>(out), ldo, lse, S, H, s_main, rem, n_split, n_units);
+      } else {
+        hipLaunchKernelGGL(mhsa_tail_kernel<32>, tgrid, tblock, 0, st, static_cast<const bf16_t*>(qkv), ld, S, H, C, window,
+                           scale, s_main, rem, n_split, chunk, total, part);
+        hipLaunchKernelGGL(mhsa_tail_merge_kernel<32>, dim3((unsigned)((n_units * 32 + 255) / 256)), dim3(256), 0, st, part,
+                           static_cast<bf16_t*>(out), ldo, lse, S, H, s_main, rem, n_split, n_units);
+      }
     }
     const dim3 grid((s_main + ATT_QBLK - 1) / ATT_QBLK, H, B), block(64 * ATT_WAVES);
     if (D == 64)
