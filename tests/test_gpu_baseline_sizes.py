@@ -162,3 +162,30 @@ def test_rollout_2_steps_o96_vs_oracle(monkeypatch):
     e1, e2 = per_variable_rel_err(got[0], want[0]), per_variable_rel_err(got[1], want[1])
     print(f"O96 rollout, f32, per-variable rel err: step 1 {e1:.3e}, step 2 {e2:.3e}")
     assert e1 < 1e-3 and e2 < 1e-3
+
+
+@pytest.mark.parametrize("processor", ["GraphTransformer", "GNN", "Transformer"])
+def test_forward_is_bit_reproducible_under_repetition(processor, monkeypatch):
+    """No kernel of the path uses atomics, so two runs of one input must agree bit for bit; a difference is a race (the
+    round-2 attention bug showed exactly this way).  BASELINE config 2 sizes, bf16, shifting allocations between the runs."""
+    import random
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    import bench
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    model, _graph, x, _ = bench.build("cfg2", torch.device("cuda", 0), processor)
+    model.eval()
+    random.seed(2)
+    first = None
+    for it in range(12):
+        junk = [torch.full((random.randint(1, 1 << 21),), float("nan"), device="cuda") for _ in range(random.randint(0, 3))]
+        with torch.no_grad():
+            y = model(x)
+        del junk
+        assert bool(torch.isfinite(y).all())
+        if first is None:
+            first = y.clone()
+        else:
+            assert torch.equal(first, y), f"run {it} differs from run 0"
