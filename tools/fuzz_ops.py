@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""Differential fuzzing of the kernels behind anemoi_models_amd.ops against plain torch: random shapes (ragged row / column
+tiles, remainder rounds, K slab counts), random epilogue combinations, random graphs.  Complements the fixed-shape parity
+tests; prints every case that exceeds its tolerance.   python tools/fuzz_ops.py [cases per op] [seed]"""
+import os
+import random
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from anemoi_models_amd import ops, runtime  # noqa: E402
+
+dev = "cuda"
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = random.Random(seed)
+ACT = {"Identity": lambda t: t, "GELU": F.gelu, "SiLU": F.silu, "ReLU": F.relu}
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6))
+
+
+def fuzz_linear():
+    bad = 0
+    for case in range(n_cases):
+        dtype = torch.bfloat16 if rng.random() < 0.8 else torch.float32
+        km = 64 if dtype == torch.bfloat16 else 32
+        m = rng.choice([rng.randint(1, 300), rng.randint(1000, 3000), 256 * rng.randint(4, 12), 256 * rng.randint(4, 12) + rng.randint(1, 9),
+                        5121, 1024, 2048 + rng.randint(1, 255)])
+        n = rng.choice([8 * rng.randint(1, 40), 256 * rng.randint(1, 9), 256 * rng.randint(1, 8) + 8 * rng.randint(1, 31), 80, 192, 1216])
+        k = km * rng.randint(1, 24)
+        act = rng.choice(list(ACT))
+        use_bias, use_res = rng.random() < 0.7, rng.random() < 0.4
+        use_ln = rng.random() < 0.3 and dtype == torch.bfloat16
+        want_stats = rng.random() < 0.3 and act == "Identity"
+        g = torch.Generator().manual_seed(seed * 100003 + case)
+        x = torch.randn(m, k, generator=g).to(dtype)
+        w = (torch.randn(n, k, generator=g) / k**0.5).to(dtype)
+        b = torch.randn(n, generator=g) if use_bias else None
+        r = torch.randn(m, n, generator=g).to(dtype) if use_res else None
+        xd, wd = x.to(dev), w.to(dev)
+        kw = dict(act=act, residual=None if r is None else r.to(dev))
+        pre = x.float() @ w.float().t()
+        if use_ln:
+            stats = torch.stack([torch.rand(m, generator=g) + 0.5, torch.randn(m, generator=g)], 1)
+            cs = torch.randn(n, generator=g)
+            pre = pre * stats[:, :1] + stats[:, 1:] * cs[None, :]
+            kw["ln"] = (stats.to(dev), cs.to(dev))
+        if b is not None:
+            pre = pre + b
+        want = ACT[act](pre)
+        if r is not None:
+            want = want + r.float()
+        if want_stats:
+            kw["stats_eps"] = 1e-5
+        try:
+            got = ops.linear(xd, wd, None if b is None else b.to(dev), **kw)
+            torch.cuda.synchronize()
+        except (NotImplementedError, ValueError) as e:  # shapes the entry points refuse are fine; wrong answers are not
+            print(f"  linear case {case}: refused ({type(e).__name__}: {str(e)[:80]}) m={m} n={n} k={k} {dtype}")
+            continue
+        tol = 2e-2 if dtype == torch.bfloat16 else 2e-4
+        err = rel(got.cpu(), want)
+        ok = err < tol
+        if want_stats and ok:
+            st = ops.row_stats(got, 1e-5).cpu()
+            gf = got.float().cpu()
+            rstd = torch.rsqrt(gf.var(dim=1, unbiased=False) + 1e-5)
+            ok = rel(st[:, 0], rstd) < 5e-3 and float((st[:, 1] + gf.mean(dim=1) * rstd).abs().max()) < 5e-3 * max(1.0, float((gf.mean(1) * rstd).abs().max()))
+        if not ok:
+            bad += 1
+            print(f"  linear case {case}: err {err:.3e} m={m} n={n} k={k} {dtype} act={act} bias={use_bias} res={use_res} "
+                  f"ln={use_ln} stats={want_stats}", flush=True)
+    print(f"linear: {bad} bad of {n_cases}", flush=True)
+
+
+def fuzz_edge_attention():
+    from oracle import reference_path as ref
+
+    bad = 0
+    for case in range(n_cases // 3):
+        dtype = torch.bfloat16 if rng.random() < 0.6 else torch.float32
+        h = rng.choice([4, 8, 16])
+        d = rng.choice([8, 16, 32, 64]) if dtype == torch.bfloat16 else rng.choice([4, 8, 16, 32, 64])
+        c = h * d
+        n_src, n_dst = rng.randint(1, 400), rng.randint(1, 400)
+        e = rng.choice([0, rng.randint(1, 50), rng.randint(200, 4000)])
+        edge_dim = rng.choice([3, 7, 11, 15])
+        g = torch.Generator().manual_seed(seed * 7919 + case)
+        ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, n_dst, (e,), generator=g)])
+        if e > 100:
+            ei[1, : e // 4] = rng.randrange(n_dst)  # one high in-degree destination
+        q, xr = (torch.randn(n_dst, c, generator=g).to(dtype) for _ in range(2))
+        k, v = (torch.randn(n_src, c, generator=g).to(dtype) for _ in range(2))
+        attr = torch.randn(e, edge_dim, generator=g)
+        we, be = torch.randn(c, edge_dim, generator=g) * 0.3, torch.randn(c, generator=g) * 0.1
+        edges = (attr @ we.t() + be).view(e, h, d)
+        want = ref.gt_conv(q.float().view(n_dst, h, d), k.float().view(n_src, h, d), v.float().view(n_src, h, d), edges, ei,
+                           n_dst).reshape(n_dst, c) + xr.float()
+        plan = runtime.build_edge_plan(ei.to(dev), n_src, n_dst)
+        ea = ops.edge_attr_csr(attr.to(dev), None, plan.perm)
+        kv = torch.cat([k, v], 1).to(dev)
+        got = ops.gt_edge_attention(q.to(dev), kv[:, :c], kv[:, c:], xr.to(dev), ea, edge_dim, we.to(dev), be.to(dev), plan.rowptr,
+                                    plan.col, h)
+        err = rel(got.cpu(), want)
+        if not err < (3e-2 if dtype == torch.bfloat16 else 2e-4):
+            bad += 1
+            print(f"  edge attention case {case}: err {err:.3e} {dtype} n_src={n_src} n_dst={n_dst} e={e} h={h} d={d} edge_dim={edge_dim}",
+                  flush=True)
+    print(f"gt_edge_attention: {bad} bad of {n_cases // 3}", flush=True)
+
+
+def fuzz_rows():
+    bad = 0
+    for case in range(n_cases // 3):
+        dtype = torch.bfloat16 if rng.random() < 0.5 else torch.float32
+        rows, c = rng.randint(1, 5000), rng.choice([64, 128, 192, 512, 1024, 1216])
+        g = torch.Generator().manual_seed(seed * 31 + case)
+        x = (torch.randn(rows, c, generator=g) * 2 + 0.3).to(dtype)
+        gm, bt = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+        want = F.layer_norm(x.float(), (c,), gm, bt, 1e-5)
+        got = ops.layer_norm(x.to(dev), gm.to(dev), bt.to(dev), 1e-5)
+        tr = ops.transpose(x.to(dev), ops.round_up(rows, 64))
+        cs = ops.col_sum(x.to(dev)).cpu()
+        ok = rel(got.cpu(), want) < (2e-2 if dtype == torch.bfloat16 else 1e-5) and torch.equal(tr[:, :rows].cpu(), x.t()) and \
+            not bool(tr[:, rows:].any()) and rel(cs, x.double().sum(0).float()) < 1e-4
+        if not ok:
+            bad += 1
+            print(f"  row kernels case {case}: {dtype} rows={rows} c={c}", flush=True)
+    print(f"layer_norm / transpose / col_sum: {bad} bad of {n_cases // 3}", flush=True)
+
+
+fuzz_linear()
+fuzz_edge_attention()
+fuzz_rows()
