@@ -22,6 +22,7 @@ namespace anemoi {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float af32x16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 __device__ __forceinline__ void aglds16(const void* gptr, void* lptr) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
@@ -220,22 +221,28 @@ __global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict
         }
         const float m_neg = m_run[qb] == -INFINITY ? 0.f : -m_run[qb];  // fully masked so far: exp2(-inf) = 0 below
         float p[16];
-        float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 16; ++r)
           p[r] = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, m_neg));  // bare v_exp_f32: argument <= 0
-          psum += p[r];
-        }
-        l_run[qb] += psum;
-        // ---- P^T fragments: registers 0..7 / 8..15 are 8 contiguous keys each (v_cvt_pk_bf16_f32: 2 values / instr)
+        // ---- P^T fragments: registers 0..7 / 8..15 are 8 contiguous keys each (v_cvt_pk_bf16_f32: 2 values / instr).
+        //      The row sum is taken from the PACKED pairs (v_dot2_f32_bf16 with (1, 1): 8 instructions instead of 16
+        //      adds -- the loop is bound by its VALU stream, tools/micro/attn_lab.py) and so normalises exactly the
+        //      rounded probabilities the P V product multiplies.
+        float psum = 0.f;
+        const uint32_t ones2 = 0x3f803f80u;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           uint32_t w[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i) {
             asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
+            uint32_t wi = w[i];
+            psum = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&wi),
+                                                   *reinterpret_cast<const bf16x2_t*>(&ones2), psum, false);
+          }
           pb[qb][kk] = *reinterpret_cast<abf16x8_t*>(w);
         }
+        l_run[qb] += psum;
       }
       // ---- O^T += V^T P^T : each V^T fragment feeds both query blocks
 #pragma unroll
