@@ -1,19 +1,23 @@
-"""Differentiable Linear / LayerNorm / edge attention / whole GraphTransformer blocks and model on the HIP kernels
-(SURVEY.md §8f-1): ``AnemoiModelEncProcDec.forward`` routes here when gradients are required.
+"""Autograd functions of the differentiable route: forward AND backward on the HIP kernels.
 
-``linear(x, weight, bias, act, residual)`` and ``layer_norm(x, gamma, beta, eps)`` are ``torch.autograd.Function``s
-whose forward is the inference path's fused GEMM / LayerNorm kernel and whose backward runs on the same GEMM kernels:
-
-* ``dX = dpre @ W``            -> ``ops.linear(dpre, W^T)``            (``W^T`` by ``anemoi_transpose``)
-* ``dW = dpre^T @ X`` (f32)    -> ``ops.linear(dpre^T, X^T, f32 out)`` (reduction over the rows, zero padded to K slabs)
-* ``db = sum_rows dpre``       -> ``anemoi_col_sum``
-* ``dpre = dy * act'(pre)``    -> ``anemoi_act_backward`` (the pre-activation is saved: one extra GEMM output)
-* LayerNorm                    -> ``anemoi_layer_norm_backward`` from the forward's row statistics
-
-What torch derives for the reference's ``nn.Linear`` / ``nn.GELU`` / ``nn.LayerNorm`` (layers/block.py:504-508, 631-633,
-layers/mlp.py:74-84) when anemoi-training calls ``.backward()``.  Parameters stay f32 (their gradients too); activations
-and activation gradients are in the compute dtype.  The edge half (``gt_edge_attention``) runs on
-``csrc/edge_backward.hip``; ``gt_processor_block`` / ``gt_mapper_block`` / ``model_forward`` compose the two.
+Dense half
+* ``linear(x, weight, bias, act, residual)``: forward = the fused GEMM (with an activation: ``anemoi_linear_dual``, the
+  pre-activation as a second output); backward ``dX = dpre W`` and ``dW = dpre^T X`` (f32) on the same GEMM kernels over
+  operands from the register transposes, ``db`` from the per-tile column sums those transposes leave behind;
+* ``mlp2(x, w1, b1, w2, b2, act, residual)``: Linear -> act -> Linear (+ residual) as ONE node; the second Linear's dX
+  GEMM applies ``act'(pre)`` in its epilogue (``anemoi_linear_actgrad``);
+* ``layer_norm``: ``anemoi_layer_norm_backward`` from the forward's row statistics.
+Edge half (``csrc/edge_backward.hip``)
+* ``gt_edge_attention`` / ``gt_edge_attention_packed`` / the processor block's ``_GTEdgeAttentionSelf``: the folded edge
+  phase; the forward leaves the softmax normaliser, the backward is one batched sweep per direction;
+* ``gt_conv``: the conv on explicit per-edge features (any edge_dim);
+* ``gather_add_act`` / ``segment_sum`` (GNN), ``mhsa`` (+ attention dropout), ``permute_rows``.
+``gt_processor_block`` / ``gt_mapper_block`` compose them exactly as the inference path composes its launches; the
+``lin_edge`` fold is torch algebra on the parameters, so autograd carries gradients back to ``lin_edge`` / ``lin_query`` /
+``projection``.  What torch derives for the reference's ``nn.Linear`` / ``nn.GELU`` / ``nn.LayerNorm`` /
+``GraphTransformerConv`` (layers/block.py:504-508, 602-635, layers/conv.py:98-142, layers/mlp.py:74-84) when
+anemoi-training calls ``.backward()``.  Parameters and their gradients stay f32; activations and activation gradients
+are in the compute dtype.  No atomics anywhere: gradients are reproducible bit for bit.
 """
 
 from __future__ import annotations
@@ -36,12 +40,6 @@ def _pack(w: Tensor, dtype: torch.dtype) -> Tensor:
     out[:, :k] = w.detach().to(dtype)
     return out
 
-
-import os as _os
-
-# ANEMOI_AMD_DW_GEMM=library: dW = dpre^T X through torch.mm (hipBLASLt); default: this package's kernels (chunked
-# transposes + batched 128 x 128 GEMM + deterministic partial sum)
-_DW_LIBRARY_GEMM = _os.environ.get("ANEMOI_AMD_DW_GEMM", "own") == "library"
 
 _TORCH_ACT = {"GELU": torch.nn.functional.gelu, "SiLU": torch.nn.functional.silu, "ReLU": torch.relu}
 
@@ -98,10 +96,7 @@ class _Linear(torch.autograd.Function):
                 dx = ops.convert_pad(dx, dtype, ctx.x_cols)
         if ctx.needs_input_grad[1]:
             # dW [N, K] = dpre^T [N, M] @ X [M, K]: a Linear with x' = dpre^T, weight' = X^T, reduction over the M rows
-            if _DW_LIBRARY_GEMM:
-                # a plain TN GEMM (reduction over the rows): the BLAS library takes it without transposed copies
-                dw = torch.mm(dpre.t(), xk[:, :k] if xk.shape[1] != k else xk).to(weight.dtype)
-            elif ctx.has_bias and ctx.needs_input_grad[2]:
+            if ctx.has_bias and ctx.needs_input_grad[2]:
                 dw, db = ops.weight_grad(dpre, xk, k, want_bias=True)  # the bias gradient rides on dpre's transpose
                 dw = dw.to(weight.dtype)
             else:
