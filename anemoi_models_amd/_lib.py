@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -79,8 +79,10 @@ SIGNATURES = {
     "anemoi_mhsa_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_float, c_uint32, c_void_p]),
+    "anemoi_mhsa_backward_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa_backward": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_void_p]),
+                                     c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32,
+                                     c_void_p]),
     "anemoi_assemble_nodes": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "anemoi_finalize_output": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,

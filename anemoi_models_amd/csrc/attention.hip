@@ -34,14 +34,16 @@ __device__ __forceinline__ int aswz(int row, int chunk) { return chunk ^ ((row >
 // vt[b, h, d, s] = qkv[b*S + s, 2C + h*D + d]   (zero padded to S_pad keys)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int S, int S_pad,
-                                                          int H, int D, int C, bf16_t* __restrict__ vt) {
+                                                          int H, int D, int C, bf16_t* __restrict__ vt,
+                                                          int col0 = -1) {  // first source column (default: v = 2 C)
+  if (col0 < 0) col0 = 2 * C;
   __shared__ bf16_t tile[64][66];
   const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   for (int d0 = 0; d0 < D; d0 += 64) {
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
       const int s = s0 + r, d = d0 + c;
-      tile[r][c] = (s < S && d < D) ? qkv[((int64_t)b * S + s) * ld + 2 * C + h * D + d] : (bf16_t)0;
+      tile[r][c] = (s < S && d < D) ? qkv[((int64_t)b * S + s) * ld + col0 + h * D + d] : (bf16_t)0;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
@@ -504,6 +506,278 @@ static inline int mhsa_tail_splits(int B, int S, int H) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// MFMA backward (bf16, D = 64 / 32): two kernels, no atomics.
+//   delta_i = dO_i . O_i                                              (mhsa_delta_kernel)
+//   dKV kernel: a wave owns 32 keys (K / V fragments and the dK^T / dV^T accumulators in registers), the workgroup's four
+//     waves share 32-query tiles in LDS.  Scores are produced as S = Q K^T (queries in the accumulator registers, keys in
+//     the lanes; the query rows are fed in the forward's bit-2/3-swapped order, so registers 0..7 / 8..15 are 8 contiguous
+//     queries each = the B-operand fragments of the two products that follow):
+//         P = exp2(S c - lse),  dP = dO V^T,  dS = P (dP - delta),   dV^T += dO^T P,   dK^T += Q^T dS.
+//   dQ kernel: a wave owns 32 queries; S^T = K Q^T exactly as in the forward (keys in the registers),
+//         dP^T = V dO^T,  dS^T = P^T (dP^T - delta),   dQ^T += K^T dS^T.
+//   The A operands with the reduction along the sequence (dO^T, Q^T, K^T) come from transposed copies [B, H, D, S_pad]
+//   made once per call (transpose_v_kernel), as V^T in the forward.  Tiles are staged with plain loads and a barrier; four
+//   workgroups per CU hide the latency (correctness-first structure: 16 / 12 MFMAs per 32 x 32 block pair against the
+//   forward's 8).  The VALU kernels below took 46 s per layer at S = 40 962 (config 3) -- unusable; they remain for f32,
+//   other head sizes and attention dropout.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mhsa_delta_kernel(const bf16_t* __restrict__ o, int64_t ldo,
+                                                         const bf16_t* __restrict__ dout, int64_t lddo,
+                                                         float* __restrict__ delta, int S, int H, int D, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
+  if (unit >= total) return;
+  const int h = (int)(unit % H);
+  const int64_t bq = unit / H;
+  const int q = (int)(bq % S);
+  const int64_t b = bq / S;
+  float v = 0.f;
+  if (lane < D) v = Elem<bf16_t>::load(o + bq * ldo + h * D + lane) * Elem<bf16_t>::load(dout + bq * lddo + h * D + lane);
+  v = wave_sum(v);
+  if (lane == 0) delta[(b * H + h) * S + q] = v;
+}
+
+__device__ __forceinline__ int att_row_perm(int ql) { return (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1); }
+
+template <int ATT_D>
+__device__ __forceinline__ int att_rswz(int row, int chunk) {  // swizzle of a row-major [rows x D] bf16 tile
+  return ATT_D == 64 ? aswz(row, chunk) : aswz64(row, chunk);
+}
+
+template <int ATT_D>
+__global__ __launch_bounds__(256) void mhsa_bwd_dkv_mfma_kernel(
+    const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
+    const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT, const float* __restrict__ lse,
+    const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window,
+    float scale, float scale_log2e) {
+  constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;  // chunks of 16 bytes per row
+  __shared__ __attribute__((aligned(16))) char q_s[32 * RB], do_s[32 * RB], qt_s[ATT_D * 64], dot_s[ATT_D * 64];
+  __shared__ float lse_s[32], dl_s[32];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int key0 = (blockIdx.x * 4 + wid) * 32, key = key0 + ql, kc = key < S ? key : S - 1;
+  // stationary B fragments: lane = key column, 8 consecutive d per k-step
+  abf16x8_t kf[NKS], vf[NKS];
+  {
+    const bf16_t* kp = qkv + ((int64_t)b * S + kc) * ld + C + h * ATT_D + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      kf[ks] = *reinterpret_cast<const abf16x8_t*>(kp + ks * 16);
+      vf[ks] = *reinterpret_cast<const abf16x8_t*>(kp + C + ks * 16);
+    }
+  }
+  af32x16_t dk[NDT], dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+  // query tiles that can see any key of this workgroup
+  int qt_begin = 0, qt_end = (S + 31) / 32;
+  if (window >= 0) {
+    const int lo = (int)blockIdx.x * 128 - window, hi = (int)blockIdx.x * 128 + 127 + window;
+    qt_begin = lo > 0 ? lo / 32 : 0;
+    const int e = hi / 32 + 1;
+    qt_end = e < qt_end ? e : qt_end;
+  }
+  const int prow = att_row_perm(ql);
+  const int t = threadIdx.x;
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    __syncthreads();  // the previous tile has been consumed
+    if (t < 32 * CPR) {  // Q and dO rows of the tile (row-major, swizzled)
+      const int r = t / CPR, ch = t % CPR;
+      int q = qt * 32 + r;
+      q = q < S ? q : S - 1;
+      const int64_t row = (int64_t)b * S + q;
+      *reinterpret_cast<uint4*>(q_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) =
+          *reinterpret_cast<const uint4*>(qkv + row * ld + h * ATT_D + ch * 8);
+      *reinterpret_cast<uint4*>(do_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) =
+          *reinterpret_cast<const uint4*>(dout + row * lddo + h * ATT_D + ch * 8);
+    }
+    if (t < ATT_D * 4) {  // Q^T and dO^T: D rows of 32 queries (64 bytes)
+      const int d = t >> 2, ch = t & 3;
+      const int64_t off = (((int64_t)b * H + h) * ATT_D + d) * S_pad + qt * 32 + ch * 8;
+      *reinterpret_cast<uint4*>(qt_s + d * 64 + (aswz64(d, ch) << 4)) = *reinterpret_cast<const uint4*>(qT + off);
+      *reinterpret_cast<uint4*>(dot_s + d * 64 + (aswz64(d, ch) << 4)) = *reinterpret_cast<const uint4*>(doT + off);
+    }
+    if (t < 32) {
+      const int q = qt * 32 + t;
+      lse_s[t] = q < S ? lse[((int64_t)b * H + h) * S + q] * 1.44269504088896340736f : INFINITY;  // q >= S: P = 0
+      dl_s[t] = q < S ? delta[((int64_t)b * H + h) * S + q] : 0.f;
+    }
+    __syncthreads();
+    // ---- S = Q K^T and dP = dO V^T: lane = key, register r <-> query 8 half + (r & 7) + 16 (r >> 3) of the tile
+    af32x16_t s_acc, dp_acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_acc[r] = dp_acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ch = att_rswz<ATT_D>(prow, ks * 2 + half);
+      const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(q_s + prow * RB + (ch << 4));
+      const abf16x8_t a2 = *reinterpret_cast<const abf16x8_t*>(do_s + prow * RB + (ch << 4));
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s_acc, 0, 0, 0);
+      dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vf[ks], dp_acc, 0, 0, 0);
+    }
+    float p[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = 8 * half + (r & 7) + 16 * (r >> 3);
+      float pe = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, -lse_s[qi]));
+      if (window >= 0) {
+        const int dq_ = qt * 32 + qi - key;
+        pe = (dq_ <= window && -dq_ <= window) ? pe : 0.f;
+      }
+      p[r] = pe;
+      ds[r] = pe * (dp_acc[r] - dl_s[qi]);
+    }
+    abf16x8_t pb[2], dsb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint32_t w1[4], w2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2[i]) : "v"(ds[kk * 8 + 2 * i]), "v"(ds[kk * 8 + 2 * i + 1]));
+      }
+      pb[kk] = *reinterpret_cast<abf16x8_t*>(w1);
+      dsb[kk] = *reinterpret_cast<abf16x8_t*>(w2);
+    }
+    // ---- dV^T += dO^T P,  dK^T += Q^T dS   (A rows = d, reduction over the tile's queries)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int drow = dt * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int off = drow * 64 + (aswz64(drow, kk * 2 + half) << 4);
+        const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(dot_s + off);
+        const abf16x8_t a2 = *reinterpret_cast<const abf16x8_t*>(qt_s + off);
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[kk], dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb[kk], dk[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (key < S) {  // lane = key; register r <-> d = dt * 32 + 8 (r >> 2) + 4 half + (r & 3)
+    bf16_t* kp = dqkv + ((int64_t)b * S + key) * lddq + C + h * ATT_D;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float k4[4] = {dk[dt][4 * g] * scale, dk[dt][4 * g + 1] * scale, dk[dt][4 * g + 2] * scale,
+                             dk[dt][4 * g + 3] * scale};
+        const float v4[4] = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
+        VecIO<bf16_t, 4>::store(kp + dt * 32 + 8 * g + 4 * half, k4);
+        VecIO<bf16_t, 4>::store(kp + C + dt * 32 + 8 * g + 4 * half, v4);
+      }
+  }
+}
+
+template <int ATT_D>
+__global__ __launch_bounds__(256) void mhsa_bwd_dq_mfma_kernel(
+    const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
+    const bf16_t* __restrict__ kT, const float* __restrict__ lse, const float* __restrict__ delta,
+    bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window, float scale, float scale_log2e) {
+  constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;
+  __shared__ __attribute__((aligned(16))) char k_s[32 * RB], v_s[32 * RB], kt_s[ATT_D * 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q = (blockIdx.x * 4 + wid) * 32 + ql, qc = q < S ? q : S - 1;
+  abf16x8_t qf[NKS], dof[NKS];  // B fragments: lane = query column, 8 consecutive d per k-step
+  {
+    const bf16_t* qp = qkv + ((int64_t)b * S + qc) * ld + h * ATT_D + half * 8;
+    const bf16_t* dp = dout + ((int64_t)b * S + qc) * lddo + h * ATT_D + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
+      dof[ks] = *reinterpret_cast<const abf16x8_t*>(dp + ks * 16);
+    }
+  }
+  const float lse2 = q < S ? lse[((int64_t)b * H + h) * S + q] * 1.44269504088896340736f : INFINITY;
+  const float dl = q < S ? delta[((int64_t)b * H + h) * S + q] : 0.f;
+  af32x16_t dq[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  int kt_begin = 0, kt_end = (S + 31) / 32;
+  if (window >= 0) {
+    const int lo = (int)blockIdx.x * 128 - window, hi = (int)blockIdx.x * 128 + 127 + window;
+    kt_begin = lo > 0 ? lo / 32 : 0;
+    const int e = hi / 32 + 1;
+    kt_end = e < kt_end ? e : kt_end;
+  }
+  const int prow = att_row_perm(ql);
+  const int t = threadIdx.x;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();
+    if (t < 32 * CPR) {
+      const int r = t / CPR, ch = t % CPR;
+      int key = kt * 32 + r;
+      key = key < S ? key : S - 1;
+      const bf16_t* kp = qkv + ((int64_t)b * S + key) * ld + C + h * ATT_D + ch * 8;
+      *reinterpret_cast<uint4*>(k_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) = *reinterpret_cast<const uint4*>(kp);
+      *reinterpret_cast<uint4*>(v_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) = *reinterpret_cast<const uint4*>(kp + C);
+    }
+    if (t < ATT_D * 4) {
+      const int d = t >> 2, ch = t & 3;
+      const int64_t off = (((int64_t)b * H + h) * ATT_D + d) * S_pad + kt * 32 + ch * 8;
+      *reinterpret_cast<uint4*>(kt_s + d * 64 + (aswz64(d, ch) << 4)) = *reinterpret_cast<const uint4*>(kT + off);
+    }
+    __syncthreads();
+    // ---- S^T = K Q^T and dP^T = V dO^T: lane = query, register r <-> key 8 half + (r & 7) + 16 (r >> 3) of the tile
+    af32x16_t s_acc, dp_acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_acc[r] = dp_acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ch = att_rswz<ATT_D>(prow, ks * 2 + half);
+      const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(k_s + prow * RB + (ch << 4));
+      const abf16x8_t a2 = *reinterpret_cast<const abf16x8_t*>(v_s + prow * RB + (ch << 4));
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s_acc, 0, 0, 0);
+      dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dof[ks], dp_acc, 0, 0, 0);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + 8 * half + (r & 7) + 16 * (r >> 3);
+      float pe = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, -lse2));
+      bool ok = key < S;
+      if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
+      pe = ok ? pe : 0.f;
+      ds[r] = pe * (dp_acc[r] - dl);
+    }
+    abf16x8_t dsb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint32_t w2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2[i]) : "v"(ds[kk * 8 + 2 * i]), "v"(ds[kk * 8 + 2 * i + 1]));
+      dsb[kk] = *reinterpret_cast<abf16x8_t*>(w2);
+    }
+    // ---- dQ^T += K^T dS^T
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int drow = dt * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(kt_s + drow * 64 + (aswz64(drow, kk * 2 + half) << 4));
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb[kk], dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (q < S) {
+    bf16_t* qp = dqkv + ((int64_t)b * S + q) * lddq + h * ATT_D;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float q4[4] = {dq[dt][4 * g] * scale, dq[dt][4 * g + 1] * scale, dq[dt][4 * g + 2] * scale,
+                             dq[dt][4 * g + 3] * scale};
+        VecIO<bf16_t, 4>::store(qp + dt * 32 + 8 * g + 4 * half, q4);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of softmax(Q K^T / sqrt(D)) V (flash-attention style: nothing of size S x S is stored; the probabilities are
 // recomputed from the saved log-sum-exp).  With P_ij = exp(s_ij - lse_i), dP_ij = dO_i . v_j, delta_i = dO_i . O_i,
 // dS_ij = P_ij (dP_ij - delta_i):   dQ_i = scale sum_j dS_ij k_j,   dK_j = scale sum_i dS_ij q_i,   dV_j = sum_i P_ij dO_i.
@@ -715,9 +989,14 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   return check_launch("anemoi_mhsa(generic)");
 }
 
+int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int D) {
+  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32)) return 3 * mhsa_vt_bytes(B, S, H, D);  // Q^T, K^T, dO^T
+  return 0;
+}
+
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
-                         int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, int B, int S, int H, int D,
-                         int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream) {
+                         int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, void* workspace, int B,
+                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out && dout && lse && delta && dqkv, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: bad shape");
   const int C = H * D;
@@ -731,6 +1010,37 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
   const float scale = 1.0f / sqrtf((float)D);
   const int64_t units = (int64_t)B * S * H;
   ANEMOI_REQUIRE((units + 3) / 4 < ((int64_t)1 << 31), ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: grid too large");
+  if (dropout_p == 0.f && dtype == ANEMOI_BF16 && (D == 64 || D == 32) && workspace != nullptr &&
+      (uintptr_t)workspace % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)out % 2 == 0 &&
+      (uintptr_t)dqkv % 8 == 0 && ld % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0) {
+    // MFMA route: delta, the three transposed operands, then the two kernels
+    const int S_pad = (S + 63) / 64 * 64;
+    const bf16_t* qkvb = static_cast<const bf16_t*>(qkv);
+    const bf16_t* dob = static_cast<const bf16_t*>(dout);
+    bf16_t* qT = static_cast<bf16_t*>(workspace);
+    bf16_t* kT = reinterpret_cast<bf16_t*>(static_cast<char*>(workspace) + mhsa_vt_bytes(B, S, H, D));
+    bf16_t* doT = reinterpret_cast<bf16_t*>(static_cast<char*>(workspace) + 2 * mhsa_vt_bytes(B, S, H, D));
+    hipLaunchKernelGGL(mhsa_delta_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(out), ldo, dob, lddo, delta, S, H, D, units);
+    const dim3 tgrid(S_pad / 64, H, B), tblock(256);
+    hipLaunchKernelGGL(transpose_v_kernel, tgrid, tblock, 0, st, qkvb, ld, S, S_pad, H, D, C, qT, 0);
+    hipLaunchKernelGGL(transpose_v_kernel, tgrid, tblock, 0, st, qkvb, ld, S, S_pad, H, D, C, kT, C);
+    hipLaunchKernelGGL(transpose_v_kernel, tgrid, tblock, 0, st, dob, lddo, S, S_pad, H, D, C, doT, 0);
+    const dim3 grid128((S + 127) / 128, H, B), block256(256);
+    const float sl2 = scale * 1.44269504088896340736f;
+    if (D == 64) {
+      hipLaunchKernelGGL(mhsa_bwd_dkv_mfma_kernel<64>, grid128, block256, 0, st, qkvb, ld, dob, lddo, qT, doT, lse, delta,
+                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
+      hipLaunchKernelGGL(mhsa_bwd_dq_mfma_kernel<64>, grid128, block256, 0, st, qkvb, ld, dob, lddo, kT, lse, delta,
+                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
+    } else {
+      hipLaunchKernelGGL(mhsa_bwd_dkv_mfma_kernel<32>, grid128, block256, 0, st, qkvb, ld, dob, lddo, qT, doT, lse, delta,
+                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
+      hipLaunchKernelGGL(mhsa_bwd_dq_mfma_kernel<32>, grid128, block256, 0, st, qkvb, ld, dob, lddo, kT, lse, delta,
+                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
+    }
+    return check_launch("anemoi_mhsa_backward(bf16, MFMA)");
+  }
   dim3 grid((unsigned)((units + 3) / 4)), block(256);
 #define BWD(T, DM)                                                                                                    \
   do {                                                                                                                \

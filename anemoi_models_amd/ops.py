@@ -424,10 +424,13 @@ def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_siz
     delta = torch.empty((batch_size, num_heads, s_len), dtype=torch.float32, device=qkv.device)
     if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != delta.numel():
         raise ValueError("mhsa_backward: lse must be the contiguous f32 [B, H, S] output of mhsa(return_lse=True)")
-    st = _lib.load().anemoi_mhsa_backward(dtype_code(qkv.dtype), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)),
-                                          dout.data_ptr(), _ld(_rows(dout)), lse.data_ptr(), delta.data_ptr(),
-                                          dqkv.data_ptr(), c3, batch_size, s_len, num_heads, c // num_heads, window,
-                                          float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, _stream())
+    lib = _lib.load()
+    ws_bytes = lib.anemoi_mhsa_backward_workspace_bytes(dtype_code(qkv.dtype), batch_size, s_len, num_heads, c // num_heads)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 and dropout_p == 0.0 else None
+    st = lib.anemoi_mhsa_backward(dtype_code(qkv.dtype), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)),
+                                  dout.data_ptr(), _ld(_rows(dout)), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), c3,
+                                  _ptr(ws), batch_size, s_len, num_heads, c // num_heads, window, float(dropout_p),
+                                  int(dropout_seed) & 0xFFFFFFFF, _stream())
     _lib.check(st, "anemoi_mhsa_backward")
     return dqkv
 

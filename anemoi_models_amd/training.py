@@ -12,8 +12,7 @@ Every ``nn.Module`` of this package keeps two routes to the same arithmetic:
   anemoi-training.
 
 Model families: flat and hierarchical GraphTransformer models, the GNN processor and GNN mappers, the Transformer
-processor (its attention backward is a pair of VALU kernels, ``anemoi_mhsa_backward``: correct, O(S^2 D) on the vector
-pipe -- fine for tests and moderate meshes, not yet at the speed of the MFMA forward).
+processor (bf16 head sizes 64 / 32: MFMA attention forward and backward; other cases and attention dropout: VALU kernels).
 
 Activation checkpointing follows the reference: every mapper call and every processor chunk is wrapped in
 ``torch.utils.checkpoint`` (reference models/encoder_processor_decoder.py:159-166, layers/processor.py:73-77); all

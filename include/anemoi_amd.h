@@ -305,11 +305,15 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
  * layers/attention.py:99-105, when anemoi-training calls .backward()).  `lse` f32 [B, H, S] is the forward's optional
  * output (natural-log sum-exp of the scaled scores per query and head; pass NULL to the forward when not training), `out`
  * the forward's result, `dout` its gradient; writes dqkv [B*S, 3C] = dq | dk | dv in `dtype`.  `delta` f32 [B, H, S] is
- * scratch.  Probabilities are recomputed from lse (nothing of size S x S is stored); no atomics.  VALU kernels, O(S^2 D).
+ * scratch.  Probabilities are recomputed from lse (nothing of size S x S is stored); no atomics.  bf16 with D = 64 / 32
+ * and dropout_p = 0: MFMA kernels (one pass with the keys stationary for dK / dV, one with the queries stationary for dQ)
+ * on a `workspace` of anemoi_mhsa_backward_workspace_bytes() bytes (Q^T, K^T, dO^T); otherwise VALU kernels, O(S^2 D) on
+ * the vector pipe (workspace may be NULL).
  */
+int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
-                         int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, int B, int S, int H, int D,
-                         int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream);
+                         int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, void* workspace, int B,
+                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Backward pass, dense half (first step): the pieces the autograd of the fused Linear and of
