@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """One training step (forward, loss, backward) of the flat GraphTransformer model on the HIP kernels through its nn.Module
-(autograd.model_forward) at a bench workload:   python tools/train_step_bench.py [cfg1|cfg2|cfg3] [steps]"""
+at a bench workload:
+   python tools/train_step_bench.py [cfg1|cfg2|cfg3] [steps] [GraphTransformer|GNN|Transformer]"""
 import os
 import sys
 import time
@@ -12,9 +13,10 @@ import bench  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+processor = sys.argv[3] if len(sys.argv) > 3 else "GraphTransformer"
 os.environ.setdefault("ANEMOI_AMD_DTYPE", "bf16")
 dev = torch.device("cuda", 0)
-model, graph, x, _ = bench.build(workload, dev)
+model, graph, x, _ = bench.build(workload, dev, processor)
 model.train()
 target = torch.zeros((1, 1, graph["data"].num_nodes, 80), device=dev)
 
@@ -49,8 +51,8 @@ loss_t.backward()
 t_host_b = time.perf_counter() - t1
 torch.cuda.synchronize()
 t_b = time.perf_counter() - t1
-print(f"{workload}: differentiable forward {t_f * 1e3:.1f} ms (host enqueue {t_host_f * 1e3:.1f}), backward {t_b * 1e3:.1f} ms "
+print(f"{workload} {processor}: differentiable forward {t_f * 1e3:.1f} ms (host enqueue {t_host_f * 1e3:.1f}), backward {t_b * 1e3:.1f} ms "
       f"(host enqueue {t_host_b * 1e3:.1f})", flush=True)
 layers = bench.WORKLOADS[workload][2]
-print(f"{workload}: forward + backward {ms:.1f} ms / step = {graph['hidden'].num_nodes * layers / ms * 1e3:.3e} mesh-node updates/s "
+print(f"{workload} {processor}: forward + backward {ms:.1f} ms / step = {graph['hidden'].num_nodes * layers / ms * 1e3:.3e} mesh-node updates/s "
       f"(loss {loss:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)", flush=True)
