@@ -551,6 +551,10 @@ class GraphConvBaseBlock(BaseBlock, ABC):
         self._packed = runtime.PackedWeights()
         self._plans = runtime.PlanCache()
 
+    @abstractmethod
+    def forward(self, x, edge_attr: Tensor, edge_index: Tensor, shapes: tuple, model_comm_group=None, size=None):
+        """``(new nodes, new edge state)`` -- reference layers/block.py:157-167."""
+
 
 class GraphConvProcessorBlock(GraphConvBaseBlock):
     """Edge-MLP message passing on one node set (reference layers/block.py:170-223, layers/conv.py:27-76)."""

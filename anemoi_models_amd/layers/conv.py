@@ -89,3 +89,33 @@ class GraphConv(nn.Module):
         super().__init__()
         self.edge_mlp = MLP(3 * in_channels, out_channels, out_channels, n_extra_layers=mlp_extra_layers,
                             activation=activation)
+        self._plans = None  # plan cache of the stand-alone forward (runtime.PlanCache, created on first use)
+
+    def forward(self, x, edge_attr: Tensor, edge_index: Tensor, size=None):
+        """The reference's call (layers/conv.py:62-76): ``x`` is one node tensor or a ``(x_src, x_dst)`` pair, ``edge_attr
+        [E, C]`` and ``edge_index [2, E]`` in the caller's edge order -> ``(out [N_dst, C], edges_new [E, C])`` with
+        ``edges_new = edge_mlp(cat[x_i, x_j, edge_attr]) + edge_attr`` and ``out`` its sum over the destinations.
+
+        The ``[E, 3C]`` concatenation is never formed: the first Linear splits into two node GEMMs and one edge GEMM,
+        the gather kernel adds them and applies the activation, the rest of the MLP runs on the edge rows and a CSR
+        segment sum aggregates.  Differentiable (the same autograd nodes the blocks use); the block mirrors call the
+        pieces directly so that they can also fuse the node-side GEMMs."""
+        import torch
+
+        from .. import autograd, runtime, training
+
+        x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
+        n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+        if size is not None and tuple(size) != (n_src, n_dst):
+            raise ValueError(f"Encountered tensors with sizes {(n_src, n_dst)}, but expected size {tuple(size)}")
+        if self._plans is None:
+            self._plans = runtime.PlanCache()
+        plan = self._plans.get(edge_index, n_src, n_dst)
+        dtype = runtime.compute_dtype(x_dst)
+        grad = training.wants_grad(self, x_src, x_dst, edge_attr)
+        with torch.enable_grad() if grad else torch.no_grad():
+            e_csr, inv = training._csr_round_trip(plan, edge_attr, dtype)
+            e_new = training._gnn_edge_update(self.edge_mlp, training._cast(x_dst, dtype), training._cast(x_src, dtype),
+                                              e_csr, plan)
+            out = autograd.segment_sum(e_new, plan)
+            return out, autograd.permute_rows(e_new, inv)

@@ -40,15 +40,25 @@ class NamedNodesAttributes(nn.Module):
 
     def __init__(self, num_trainable_params: int, graph_data) -> None:
         super().__init__()
+        self.define_fixed_attributes(graph_data, num_trainable_params)
+        self.trainable_tensors = nn.ModuleDict()
+        for name, nodes in graph_data.node_items():
+            self.register_coordinates(name, nodes.x)
+            self.register_tensor(name, num_trainable_params)
+
+    def define_fixed_attributes(self, graph_data, num_trainable_params: int) -> None:
+        """Node counts and attribute widths (2 x coordinate dims + trainable) per node set."""
         names = list(graph_data.node_types)
         self.num_nodes = {n: graph_data[n].num_nodes for n in names}
         self.attr_ndims = {n: 2 * graph_data[n].x.shape[1] + num_trainable_params for n in names}
-        self.trainable_tensors = nn.ModuleDict()
-        for name, nodes in graph_data.node_items():
-            coords = nodes.x
-            self.register_buffer(f"latlons_{name}", torch.cat([torch.sin(coords), torch.cos(coords)], dim=-1),
-                                 persistent=True)
-            self.trainable_tensors[name] = TrainableTensor(self.num_nodes[name], num_trainable_params)
+
+    def register_coordinates(self, name: str, node_coords: Tensor) -> None:
+        """``[sin(coords) | cos(coords)]`` as the persistent buffer ``latlons_<name>``."""
+        self.register_buffer(f"latlons_{name}", torch.cat([torch.sin(node_coords), torch.cos(node_coords)], dim=-1),
+                             persistent=True)
+
+    def register_tensor(self, name: str, num_trainable_params: int) -> None:
+        self.trainable_tensors[name] = TrainableTensor(self.num_nodes[name], num_trainable_params)
 
     def get_coordinates(self, name: str) -> Tensor:
         sc = getattr(self, f"latlons_{name}")

@@ -148,7 +148,7 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
 
     # ---- hooks specialised by the forward / backward mapper ------------------------------------
     def _embed(self, x_src: Tensor, x_dst: Tensor, one_cols=(None, None)):
-        raise NotImplementedError
+        return x_src, x_dst  # the base mapper embeds nothing (reference BaseMapper.pre_process, layers/mapper.py:87-96)
 
     def _embedded(self, tag: str, lin: nn.Linear, x: Tensor, eps: Optional[float], one_col: Optional[int],
                   materialise: bool):
@@ -229,6 +229,11 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
             return t if t.stride(-1) == 1 else t.contiguous()
 
         return self.native(prep(x_src), prep(x_dst), batch_size)
+
+    def forward(self, x, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
+        """Reference layers/mapper.py:239-272: pre-process, one mapper block over the sub-graph, post-process -> the
+        destination nodes."""
+        return self._run(x, batch_size, shard_shapes, model_comm_group)
 
 
 class GraphTransformerForwardMapper(ForwardMapperPreProcessMixin, GraphTransformerBaseMapper):
@@ -317,6 +322,17 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
                              n_extra_layers=mlp_extra_layers, activation=activation)
         self.trainable = TrainableTensor(trainable_size=trainable_size, tensor_size=self.edge_attr.shape[0])
         self._plans = runtime.PlanCache()
+
+    def prepare_edges(self, size, batch_size: int, model_comm_group=None):
+        """Reference layers/mapper.py:485-495: ``(emb_edges(cat[edge_attr, trainable]) [E * batch, hidden], edge_index
+        [2, E * batch])`` in the sub-graph's edge order (a single model rank keeps that order; the reference only
+        re-sorts for its 1-hop sharding).  The mapper forward does not come through here: it embeds the edges already
+        in destination-sorted order."""
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
+        edge_attr = self.trainable(self.edge_attr, batch_size)
+        edge_index = self._expand_edges(self.edge_index_base, self.edge_inc, batch_size)
+        return self.emb_edges(edge_attr), edge_index
 
     # hooks: the forward mapper embeds both node sets, the backward mapper extracts the output variables
     def _embed(self, x_src: Tensor, x_dst: Tensor):

@@ -112,6 +112,19 @@ class AnemoiModelEncProcDec(nn.Module):
             self._internal_output_idx
         ), f"Internal model indices must match {self._internal_input_idx} != {self._internal_output_idx}"
 
+    def _run_mapper(self, mapper: nn.Module, data, batch_size: int, shard_shapes, model_comm_group=None,
+                    use_reentrant: bool = False):
+        """One mapper call as the reference makes it (models/encoder_processor_decoder.py:127-165): under activation
+        checkpointing when an autograd graph is being built.  ``forward`` does not come through here -- it drives the
+        mappers' ``native`` entry points on padded / re-ordered rows; this is for callers that compose the sub-modules
+        themselves (reference-style subclasses)."""
+        kwargs = dict(batch_size=batch_size, shard_shapes=shard_shapes, model_comm_group=model_comm_group)
+        if not torch.is_grad_enabled():
+            return mapper(data, **kwargs)
+        from torch.utils.checkpoint import checkpoint
+
+        return checkpoint(mapper, data, **kwargs, use_reentrant=use_reentrant)
+
     def _prognostic_indices(self, device):
         key = str(device)
         if key not in self._idx_cache:

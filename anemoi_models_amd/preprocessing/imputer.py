@@ -92,6 +92,11 @@ class BaseImputer(BasePreprocessor):
         """``[grid, variables]`` NaN map of the first element of every leading dimension."""
         return torch.isnan(x.reshape(-1, x.shape[-2], x.shape[-1])[0])
 
+    def _expand_subset_mask(self, x: Tensor, idx_src: int) -> Tensor:
+        """NaN map of one source variable broadcast over the leading dimensions of ``x`` (reference :106-108); the
+        transforms use the batched ``_fill`` over all variables of a layout instead of one masked store per variable."""
+        return self.nan_locations[:, idx_src].expand(*x.shape[:-2], -1)
+
     def _fill(self, x: Tensor, mask: Tensor, dst: Tensor, val) -> Tensor:
         if dst.numel() > 0:
             cols = x[..., dst]

@@ -400,3 +400,48 @@ def test_blocks_with_many_edge_attributes_train_through_the_explicit_conv(dtype,
     y.sum().backward()
     assert rel_err(xs.grad, xsr.grad) < tol and rel_err(xd.grad, xdr.grad) < tol and rel_err(ea.grad, ear.grad) < tol
     _compare_block_grads(blk, rsd, tol=tol)
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_graph_conv_module_forward_and_backward(golden_blocks, pair):
+    """``GraphConv.forward`` on its own (reference layers/conv.py:62-76): ``edges_new = edge_mlp(cat[x_i, x_j, e]) + e``
+    in the caller's edge order and its sum over the destinations, outputs and all gradients against plain torch f64."""
+    from anemoi_models_amd.layers.conv import GraphConv
+
+    b = golden_blocks
+    sd = {k[len("conv."):]: v for k, v in split_prefix(b, "gnn.sd.").items() if k.startswith("conv.")}
+    conv = GraphConv(64, 64, mlp_extra_layers=0, activation="SiLU")
+    conv.load_state_dict(sd)
+    conv = conv.to(DEV)
+    ei = b["gnn.edge_index"]
+    n = b["gnn.x"].shape[0]
+    torch.manual_seed(3)
+    x_src = b["gnn.x"].clone()
+    x_dst = torch.randn(n, 64) if pair else x_src
+    e = b["gnn.edge_attr"].clone()
+    xs, xd, eg = x_src.to(DEV).requires_grad_(), x_dst.to(DEV).requires_grad_(), e.to(DEV).requires_grad_()
+    out, edges_new = conv((xs, xd) if pair else xs, eg, ei.to(DEV), size=(n, n) if pair else None)
+    w_out, w_e = torch.randn(n, 64), torch.randn(ei.shape[1], 64)
+    ((out * w_out.to(DEV)).sum() + (edges_new * w_e.to(DEV)).sum()).backward()
+
+    rsd = {k: v.double().requires_grad_() for k, v in sd.items()}
+    xs_r, xd_r, e_r = x_src.double().requires_grad_(), x_dst.double().requires_grad_(), e.double().requires_grad_()
+    x_j, x_i = xs_r[ei[0]], (xd_r if pair else xs_r)[ei[1]]
+    F = torch.nn.functional
+    h = F.silu(F.linear(torch.cat([x_i, x_j, e_r], 1), rsd["edge_mlp.model.0.weight"], rsd["edge_mlp.model.0.bias"]))
+    h = F.silu(F.linear(h, rsd["edge_mlp.model.2.weight"], rsd["edge_mlp.model.2.bias"]))
+    h = F.linear(h, rsd["edge_mlp.model.4.weight"], rsd["edge_mlp.model.4.bias"])
+    h = F.layer_norm(h, (64,), rsd["edge_mlp.model.5.weight"], rsd["edge_mlp.model.5.bias"], 1e-5)
+    en_r = h + e_r
+    out_r = torch.zeros(n, 64, dtype=torch.float64).index_add(0, ei[1], en_r)
+    ((out_r * w_out.double()).sum() + (en_r * w_e.double()).sum()).backward()
+
+    assert rel_err(edges_new.detach(), en_r.detach()) < 1e-4 and rel_err(out.detach(), out_r.detach()) < 1e-4
+    assert rel_err(eg.grad, e_r.grad) < 2e-3 and rel_err(xs.grad, xs_r.grad) < 2e-3
+    if pair:
+        assert rel_err(xd.grad, xd_r.grad) < 2e-3
+    for k, p in conv.named_parameters():
+        assert rel_err(p.grad, rsd[k].grad) < 5e-3, k
+    with torch.no_grad():  # the inference route gives the same numbers
+        out2, en2 = conv((xs, xd) if pair else xs, eg, ei.to(DEV))
+    assert rel_err(out2, out.detach()) < 1e-5 and rel_err(en2, edges_new.detach()) < 1e-5

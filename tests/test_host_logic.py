@@ -171,6 +171,18 @@ def test_gnn_model_and_block_wiring_match_golden(graph_o32, golden_cfg1_gnn, gol
     torch.testing.assert_close(y, b["gnn.y"], atol=2e-5, rtol=2e-5)
     torch.testing.assert_close(e_new, b["gnn.edges_new"], atol=2e-5, rtol=2e-5)  # returned in the caller's edge order
 
+    # the conv on its own (reference layers/conv.py:62-76): (sum over destinations, new edge state)
+    with torch.no_grad():
+        out, edges_new = blk.conv(b["gnn.x"], b["gnn.edge_attr"], b["gnn.edge_index"])
+        out_pair, _ = blk.conv((b["gnn.x"], b["gnn.x"]), b["gnn.edge_attr"], b["gnn.edge_index"],
+                               size=(b["gnn.x"].shape[0],) * 2)
+    torch.testing.assert_close(edges_new, b["gnn.edges_new"], atol=2e-5, rtol=2e-5)
+    agg = torch.zeros_like(b["gnn.x"]).index_add_(0, b["gnn.edge_index"][1], b["gnn.edges_new"])
+    torch.testing.assert_close(out, agg, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(out_pair, out)
+    with pytest.raises(ValueError):
+        blk.conv(b["gnn.x"], b["gnn.edge_attr"], b["gnn.edge_index"], size=(3, 3))
+
     gold = golden_cfg1_gnn
     model = build_model(graph_o32, "GNN")
     model.load_state_dict(split_prefix(gold, "sd."))
@@ -211,6 +223,22 @@ def test_all_gnn_model_wiring_matches_golden(graph_o32, golden_cfg1_gnn_all, mon
     with torch.no_grad():
         out = model(gold["x"])
     torch.testing.assert_close(out, gold["y"], atol=1e-4, rtol=1e-4)
+
+    # the reference's per-mapper entry points: prepare_edges (layers/mapper.py:485-495) and _run_mapper (models/
+    # encoder_processor_decoder.py:127-165)
+    dec = model.decoder
+    e_attr, e_index = dec.prepare_edges((dec.edge_inc[0, 0].item(), dec.edge_inc[1, 0].item()), 2)
+    n_e = dec.edge_attr.shape[0]
+    assert e_attr.shape == (2 * n_e, dec.hidden_dim) and e_index.shape == (2, 2 * n_e)
+    torch.testing.assert_close(e_index[:, n_e:], dec.edge_index_base + dec.edge_inc)
+    torch.testing.assert_close(e_attr[:n_e], e_attr[n_e:])
+    n_h, n_d = model.node_attributes.num_nodes["hidden"], model.node_attributes.num_nodes["data"]
+    x_h, x_d = torch.randn(n_h, dec.hidden_dim), torch.randn(n_d, dec.hidden_dim)  # both already in the hidden space
+    shapes = ([[n_h, dec.hidden_dim]], [[n_d, dec.hidden_dim]])
+    with torch.no_grad():
+        direct = dec((x_h, x_d), batch_size=1, shard_shapes=shapes)
+        via = model._run_mapper(dec, (x_h, x_d), batch_size=1, shard_shapes=shapes)
+    torch.testing.assert_close(via, direct)
 
 
 def build_hierarchical(graph):
