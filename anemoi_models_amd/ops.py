@@ -9,6 +9,7 @@ them with CPU tensors raises.  (CPU tests of the host logic substitute this modu
 
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -708,6 +709,22 @@ def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False):
     # bf16: partial results in bf16 from the persistent 256 x 256 kernel (f32 accumulation inside, as an autocast matmul
     # rounds them), summed in f32; f32: the exact 128 x 128 kernel
     fast = dpre.dtype == torch.bfloat16 and k % 8 == 0
+    xr = _rows(x)
+    if (fast and n % 8 == 0 and _ld(dpre) % 8 == 0 and _ld(xr) % 8 == 0 and dpre.data_ptr() % 16 == 0
+            and xr.data_ptr() % 16 == 0 and m >= 128 and os.environ.get("ANEMOI_AMD_DW_TN", "1") != "0"):
+        # no transposed copies: the TN kernel reads dpre and x as they lie (ds_read_b64_tr_b16 fragments), f32 partials
+        tiles = ((n + 255) // 256) * ((k + 255) // 256)
+        chunks = max(1, min(256 // tiles if tiles <= 256 else 1, m // 2048))
+        ld_max = max(_ld(dpre), _ld(xr))
+        row_cap = ((1 << 31) - 1) // (2 * ld_max) // 64 * 64  # descriptor range of one chunk
+        chunk_rows = max(128, min(round_up((m + chunks - 1) // chunks, 64), row_cap))
+        chunks = (m + chunk_rows - 1) // chunk_rows
+        part = torch.empty((chunks, n, k), dtype=torch.float32, device=dpre.device)
+        st = _lib.load().anemoi_weight_grad_tn(dpre.data_ptr(), _ld(dpre), xr.data_ptr(), _ld(xr), part.data_ptr(), m, n, k,
+                                               chunk_rows, _stream())
+        _lib.check(st, "anemoi_weight_grad_tn")
+        dw = part[0] if chunks == 1 else col_sum(part.view(chunks, n * k)).view(n, k)
+        return (dw, col_sum(dpre)) if want_bias else dw
     tile = 256 if fast else 128
     tiles = ((n + tile - 1) // tile) * ((k + tile - 1) // tile)
     chunks = max(1, min(256 // tiles if tiles <= 256 else 1, m // 2048))

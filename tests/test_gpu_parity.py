@@ -962,11 +962,36 @@ def test_transpose_is_exact_with_zero_padding(dtype, rows, cols, ld_out):
     assert not got[:, rows:].any()
 
 
-@pytest.mark.parametrize("m,n,k", [(40962, 1024, 192), (5121, 256, 1024), (2500, 96, 64)])
-def test_weight_grad_chunked_transposes(m, n, k):
-    """ops.weight_grad (chunked transposes + batched GEMM + column sums of the partial results) == dpre^T x."""
+@pytest.mark.parametrize("m,n,k,ld_extra", [
+    (40962, 1024, 192, 0), (5121, 256, 1024, 0), (2500, 96, 64, 0), (40962, 2240, 1024, 0), (130, 8, 8, 0),
+    (4099, 264, 520, 24), (128, 256, 256, 0), (70000, 80, 1024, 8),
+])
+def test_weight_grad_without_transposes(m, n, k, ld_extra):
+    """ops.weight_grad on the TN kernel (anemoi_weight_grad_tn: operands as they lie, ds_read_b64_tr_b16 fragments, f32
+    partial tiles per row chunk) == dpre^T x in f64: ragged row chunks / column tiles, pitches wider than the matrices
+    (column views of wider tensors), random data (a swapped or mis-permuted fragment cannot pass)."""
     from anemoi_models_amd import ops
 
+    g = torch.Generator().manual_seed(m + n)
+    dfull = torch.randn(m, n + ld_extra, generator=g).bfloat16().to(DEV)
+    xfull = torch.randn(m, k + 2 * ld_extra, generator=g).bfloat16().to(DEV)
+    dpre, x = dfull[:, ld_extra:], xfull[:, ld_extra:ld_extra + k]  # 16-byte aligned column views when ld_extra > 0
+    want = dpre.double().t() @ x.double()
+    got, db = ops.weight_grad(dpre, x, k, want_bias=True)
+    assert got.dtype == torch.float32 and got.shape == (n, k)
+    assert rel_err(got, want.float()) < 2e-5  # bf16 products are exact in f32; f32 accumulation over the rows
+    assert torch.equal(got, ops.weight_grad(dpre, x, k))  # deterministic
+    want_b = dpre.double().sum(dim=0)
+    assert float((db.double() - want_b).abs().max()) < 1e-5 * float(dpre.double().abs().sum(dim=0).max())
+
+
+@pytest.mark.parametrize("m,n,k", [(40962, 1024, 192), (5121, 256, 1024), (2500, 96, 64)])
+def test_weight_grad_chunked_transposes(m, n, k, monkeypatch):
+    """ops.weight_grad, older route kept behind ANEMOI_AMD_DW_TN=0 and for operands the TN kernel does not take (chunked
+    transposes + batched GEMM + column sums of the partial results) == dpre^T x."""
+    from anemoi_models_amd import ops
+
+    monkeypatch.setenv("ANEMOI_AMD_DW_TN", "0")
     g = torch.Generator().manual_seed(m)
     dpre, x = torch.randn(m, n, generator=g).bfloat16().to(DEV), torch.randn(m, k, generator=g).bfloat16().to(DEV)
     want = dpre.double().t() @ x.double()
