@@ -97,7 +97,8 @@ SIGNATURES = {
     "anemoi_transpose_colsum_rows": (c_int64, [c_int64, c_int64]),
     "anemoi_transpose_chunked": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p,
                                          c_void_p]),
-    "anemoi_weight_grad_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "anemoi_weight_grad_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                      c_void_p]),
     "anemoi_linear_batched": (c_int, [c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "anemoi_col_sum_workspace_floats": (c_int64, [c_int64, c_int]),

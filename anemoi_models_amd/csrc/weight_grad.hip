@@ -44,6 +44,7 @@ constexpr int TN_STAGE = 2 * TN_PANEL;            // 64 KiB: dY panel + x panel
 constexpr int TN_LDS = 2 * TN_STAGE;              // two stages
 
 #define ANEMOI_TN_MFMA(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+#define ANEMOI_TN_MFMA_V(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 
 // One 16-byte-per-lane LDS-DMA (64 lanes -> 1 KiB at LDS byte address `lds`), issued from inline asm ON PURPOSE: the
 // compiler's wait-count pass knows the builtin form writes LDS and puts an s_waitcnt vmcnt(0) in front of the next LDS
@@ -70,11 +71,13 @@ __device__ __forceinline__ void tn_static_for(F&& f, std::integer_sequence<int, 
 
 // out [chunks][N][K] f32 (row pitch K); dY [M, ldy], x [M, ldx] bf16; chunk c covers rows c * chunk_rows ... (zeros
 // behind row M through the buffer descriptors' range check).
+// NJ: dY fragments per wave whose column sums (bias gradient) this wave accumulates: 0 (no bias), 1, 2 or 4.
+template <int NJ>
 __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy,
                                                              const bf16_t* __restrict__ X, int64_t ldx,
-                                                             float* __restrict__ OUT, int64_t M, int N, int K,
-                                                             int chunk_rows, int64_t n_tiles, int tiles_per_chunk,
-                                                             int kt_count) {
+                                                             float* __restrict__ OUT, float* __restrict__ DB,
+                                                             int64_t M, int N, int K, int chunk_rows, int64_t n_tiles,
+                                                             int tiles_per_chunk, int kt_count) {
   constexpr int NS = 64;    // MFMAs per 32-deep reduction step
   constexpr int NRD = 16;   // fragments per step = LDS-DMA instructions per slab and wave
   constexpr int G1 = 23, SP = 5, G2 = 103;
@@ -166,7 +169,34 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
 
   wf32x4_t acc[8][8];
   wbf16x8_t a0[8], b0[8], a1[8], b1[8];
-
+  // Bias gradient db[n] = sum_m dY[m, n] (NJ > 0): the dY fragments pass through the registers of 2 * kt_count waves
+  // (both x-column halves of every x-column tile), so the 8 fragments of a wave's dY half are shared out among the
+  // first `holders` = 2 * min(kt_count, 4) of them: wave sel takes j = sel, sel + holders, ... (at most NJ), reads that
+  // fragment ONCE MORE from LDS -- a run-time j is only a run-time LDS address -- and adds one MFMA with an all-ones "A"
+  // fragment per reduction step (every accumulator row then holds the column sums): NJ extra MFMAs per 64, no branches
+  // in the slab, no pass over dY of its own.  A wave without a fragment (or slot q >= its count) multiplies by zeros.
+  constexpr int NJX = NJ > 0 ? NJ : 1;
+  wf32x4_t bs[NJX];
+  wbf16x8_t bq0[NJX], bq1[NJX], onesq[NJX];
+  int rbq[NJX], rbq_next[NJX], jq[NJX];
+#pragma unroll
+  for (int q = 0; q < NJX; ++q) {
+    bs[q] = wf32x4_t{0.f, 0.f, 0.f, 0.f};
+    rbq[q] = rbq_next[q] = rb[0];
+    jq[q] = -1;
+  }
+  const int holders_k = kt_count < 4 ? kt_count : 4;
+  auto bias_slots = [&](int64_t t, int (&addr)[NJX], int (&jj)[NJX]) {  // this wave's fragments in tile t
+    const int kt_idx = (int)((t % tiles_per_chunk) % kt_count);
+    const int sel = kt_idx * 2 + wn;
+#pragma unroll
+    for (int q = 0; q < NJX; ++q) {
+      const int j = sel + q * 2 * holders_k;
+      const bool on = kt_idx < holders_k && j < 8;
+      jj[q] = on ? j : -1;
+      addr[q] = rbase + ((8 * wm + ((on ? j : 0) ^ gl)) << 5);
+    }
+  };
   set_tile(chunk_start + bix);
   stage_all(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,6 +207,11 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
   for (int u = 0; u < 8; ++u) {
     b0[u] = ldB(0, 0, u);
     a0[u] = ldA(0, 0, u);
+  }
+  if constexpr (NJ > 0) {
+    bias_slots(chunk_start + bix, rbq, jq);
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) bq0[q] = ld_frag(rbq[q]);
   }
   stage_all(1, 1);
 
@@ -197,11 +232,20 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
     if (k == 0) {
       tile = chunk_start + li;
       has_next = li + bpx < chunk_len;
+      if constexpr (NJ > 0) {
+        bias_slots(tile, rbq, jq);
+        const wbf16x8_t one8 = {1, 1, 1, 1, 1, 1, 1, 1}, zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+          onesq[q] = jq[q] >= 0 ? one8 : zero8;
+          asm volatile("" : "+v"(onesq[q]));
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 7" ::: "memory");  // accumulator zeroing (MFMA pipe) -> first MFMA
       __builtin_amdgcn_sched_barrier(0);
     }
-    auto slab = [&](int kt_stage) {
+    auto slab = [&](int kt_stage, bool last_slab) {
       const int buf = g & 1, nbuf = buf ^ 1;
       const unsigned ysd = lds0 + buf * TN_STAGE + wid * 8192;
       const unsigned xsd = ysd + TN_PANEL;
@@ -210,6 +254,17 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
             constexpr int s = decltype(s_tag)::value;
             if constexpr (s < NS) ANEMOI_TN_MFMA(acc[s / 8][s % 8], a0[s / 8], b0[s % 8]);
             else ANEMOI_TN_MFMA(acc[(s - NS) / 8][s % 8], a1[(s - NS) / 8], b1[s % 8]);
+            if constexpr (NJ > 0 && (s == NS - 1 || s == 2 * NS - 1)) {  // column sums of this step's extra dY fragments
+#pragma unroll
+              for (int q = 0; q < NJ; ++q) {
+                if constexpr (s < NS) ANEMOI_TN_MFMA_V(bs[q], onesq[q], bq0[q]);
+                else ANEMOI_TN_MFMA_V(bs[q], onesq[q], bq1[q]);
+              }
+            }
+            if constexpr (NJ > 0 && s >= NRD && s < NRD + NJ)  // extra fragments of (this slab, ks = 1): before barrier 1
+              bq1[s - NRD] = ld_frag(buf * TN_STAGE + 32 * 512 + rbq[s - NRD]);
+            if constexpr (NJ > 0 && s > G2 + NRD && s - G2 - 1 - NRD < NJ)  // ... of (next slab, ks = 0)
+              bq0[s - G2 - 1 - NRD] = ld_frag(nbuf * TN_STAGE + (last_slab ? rbq_next : rbq)[s - G2 - 1 - NRD]);
             if constexpr (s < NRD) {  // fragments of (this slab, ks = 1)
               if constexpr (s < 8) b1[s] = ldB(buf, 1, s);
               else a1[s - 8] = ldA(buf, 1, s - 8);
@@ -243,8 +298,12 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
     if (k == nk - 2) {  // from here on the staged slabs are the next tile's
       if (has_next) set_tile(tile + bpx);
       else set_null();
+      if constexpr (NJ > 0) {
+        int jn[NJX];
+        bias_slots(has_next ? tile + bpx : tile, rbq_next, jn);
+      }
     }
-    slab(k + 2 < nk ? k + 2 : k + 2 - nk);
+    slab(k + 2 < nk ? k + 2 : k + 2 - nk, k == nk - 1);
     ++k;
     if (k < nk) continue;
     k = 0;
@@ -293,6 +352,14 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
           }
         },
         std::make_integer_sequence<int, 8>{});
+    if constexpr (NJ > 0) {  // every row of bs[q] holds the column sums of dY columns n0 + 128 wm + 16 jq + fr over this chunk
+#pragma unroll
+      for (int q = 0; q < NJ; ++q) {
+        const int n = n0 + 128 * wm + 16 * jq[q] + fr_e;
+        if (jq[q] >= 0 && fq_e == 0 && n < N) DB[(int64_t)c * N + n] = bs[q][0];
+        bs[q] = wf32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     li += bpx;
     if (li >= chunk_len) break;
   }
@@ -302,9 +369,10 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
 }  // namespace
 }  // namespace anemoi
 
-// partial [chunks][N][K] f32 <- per-chunk dY^T x;  chunks = ceil(M / chunk_rows)
-extern "C" int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x, int64_t ldx, void* partial, int64_t M,
-                                     int N, int K, int chunk_rows, anemoi_stream_t stream) {
+// partial [chunks][N][K] f32 <- per-chunk dY^T x;  bias_partial (optional) [chunks][N] f32 <- per-chunk column sums of dY
+extern "C" int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x, int64_t ldx, void* partial,
+                                     void* bias_partial, int64_t M, int N, int K, int chunk_rows,
+                                     anemoi_stream_t stream) {
   using namespace anemoi;
   ANEMOI_REQUIRE(dy && x && partial && M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && chunk_rows > 0,
                  ANEMOI_ERR_INVALID, "anemoi_weight_grad_tn: bad argument");
@@ -324,14 +392,29 @@ extern "C" int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x,
                  "anemoi_weight_grad_tn: too many tiles");
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(weight_grad_tn_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS) != hipSuccess)
-      return fail(ANEMOI_ERR_LAUNCH, "anemoi_weight_grad_tn: cannot raise the dynamic LDS limit to %d", TN_LDS);
+    const void* kernels[4] = {reinterpret_cast<const void*>(weight_grad_tn_kernel<0>),
+                              reinterpret_cast<const void*>(weight_grad_tn_kernel<1>),
+                              reinterpret_cast<const void*>(weight_grad_tn_kernel<2>),
+                              reinterpret_cast<const void*>(weight_grad_tn_kernel<4>)};
+    for (const void* kp : kernels)
+      if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS) != hipSuccess)
+        return fail(ANEMOI_ERR_LAUNCH, "anemoi_weight_grad_tn: cannot raise the dynamic LDS limit to %d", TN_LDS);
     raised = true;
   }
   int64_t blocks = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;  // one persistent workgroup per CU, whole XCD rows
-  hipLaunchKernelGGL(weight_grad_tn_kernel, dim3((unsigned)blocks), dim3(256), TN_LDS, as_stream(stream),
-                     static_cast<const bf16_t*>(dy), ldy, static_cast<const bf16_t*>(x), ldx,
-                     static_cast<float*>(partial), M, N, K, chunk_rows, tiles, nt * kt, kt);
+  const int holders = 2 * (kt < 4 ? kt : 4);
+  const int nj = bias_partial == nullptr ? 0 : (8 + holders - 1) / holders;  // 4, 2, 2, 1 for 1, 2, 3, >= 4 x-column tiles
+#define ANEMOI_TN_LAUNCH(NJV)                                                                                          \
+  hipLaunchKernelGGL(weight_grad_tn_kernel<NJV>, dim3((unsigned)blocks), dim3(256), TN_LDS, as_stream(stream),          \
+                     static_cast<const bf16_t*>(dy), ldy, static_cast<const bf16_t*>(x), ldx,                           \
+                     static_cast<float*>(partial), static_cast<float*>(bias_partial), M, N, K, chunk_rows, tiles, nt * kt, \
+                     kt)
+  switch (nj) {
+    case 0: ANEMOI_TN_LAUNCH(0); break;
+    case 1: ANEMOI_TN_LAUNCH(1); break;
+    case 2: ANEMOI_TN_LAUNCH(2); break;
+    default: ANEMOI_TN_LAUNCH(4); break;
+  }
+#undef ANEMOI_TN_LAUNCH
   return check_launch("anemoi_weight_grad_tn");
 }
