@@ -52,17 +52,15 @@ class GraphTransformerConv(nn.Module):
                 size=None) -> Tensor:
         """The reference's call (layers/conv.py:98-142): ``query [N_dst, H, D]``, ``key / value [N_src, H, D]``,
         ``edge_attr [E, H, D]`` (= ``lin_edge`` of the raw attributes), ``edge_index [2, E]`` -> ``[N_dst, H, D]``.
-        One kernel (``anemoi_gt_conv``) over a destination-sorted plan that is cached per ``edge_index`` tensor.  The
-        block mirrors do not come through here (they fold ``lin_edge`` into the neighbouring GEMMs); inference only."""
+        One kernel (``anemoi_gt_conv``) over a destination-sorted plan that is cached per ``edge_index`` tensor; with
+        gradients required, the same kernel as an autograd node (``autograd.gt_conv``).  The block mirrors do not come
+        through here (they fold ``lin_edge`` into the neighbouring GEMMs)."""
         import torch
 
         from .. import runtime
 
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("attention dropout > 0 is not implemented on the MI355X path")
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (query, key, value, edge_attr)):
-            raise NotImplementedError("GraphTransformerConv.forward on its own is an inference call on the MI355X path; "
-                                      "gradients flow through the block / mapper / processor / model forwards")
         if edge_attr is None:
             raise ValueError("GraphTransformerConv needs edge features (the reference adds them to key and value)")
         n_dst, heads, d = query.shape
@@ -74,10 +72,16 @@ class GraphTransformerConv(nn.Module):
         plan = self._plans.get(edge_index, n_src, n_dst)
         dtype = runtime.compute_dtype(query)
         c = heads * d
-        flat = lambda t: (t if t.dtype == dtype else t.to(dtype)).reshape(t.shape[0], c).contiguous()  # noqa: E731
+        flat = lambda t: (t if t.dtype == dtype else t.to(dtype)).reshape(t.shape[0], c)  # noqa: E731
         kv = torch.cat([flat(key), flat(value)], dim=1)  # one k | v buffer: the kernel gathers both with one row pitch
-        edges = flat(edge_attr).index_select(0, plan.perm.long())
-        out = ops.gt_conv(flat(query), kv[:, :c], kv[:, c:], edges, plan.rowptr, plan.col, heads)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (query, key, value, edge_attr)):
+            from .. import autograd  # explicit-edge backward kernels (anemoi_gt_conv_backward_dst / _src)
+
+            edges = autograd.permute_rows(flat(edge_attr).contiguous(), plan.perm.long())
+            out = autograd.gt_conv(flat(query).contiguous(), kv[:, :c], kv[:, c:], edges, None, plan, heads)
+        else:
+            edges = flat(edge_attr).index_select(0, plan.perm.long())
+            out = ops.gt_conv(flat(query).contiguous(), kv[:, :c], kv[:, c:], edges, plan.rowptr, plan.col, heads)
         return out.view(n_dst, heads, d).to(query.dtype)
 
 

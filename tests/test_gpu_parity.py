@@ -169,6 +169,18 @@ def test_graph_transformer_conv_module_forward(dtype, n_src, n_dst, e, c, h):
     assert torch.equal(got, again)
     with pytest.raises(ValueError):
         conv(q.to(DEV), k.to(DEV), v.to(DEV), edges.to(DEV), ei.to(DEV), size=(n_src + 1, n_dst))
+    # ... and under autograd (the reference's conv is differentiable on its own): every input gradient vs the oracle's
+    if e > 0:
+        leaves = [t.to(DEV).requires_grad_() for t in (q, k, v, edges)]
+        out = conv(*leaves, ei.to(DEV))
+        assert rel_err(out.detach(), want) < (1e-5 if dtype == torch.float32 else 2e-2)
+        w_out = torch.randn(n_dst, h, d, generator=g)
+        (out.float() * w_out.to(DEV)).sum().backward()
+        refs = [t.double().requires_grad_() for t in (q, k, v, edges)]
+        (ref.gt_conv(*refs, ei, n_dst) * w_out.double()).sum().backward()
+        for got_t, ref_t, name in zip(leaves, refs, ("query", "key", "value", "edge_attr")):
+            assert got_t.grad is not None and got_t.grad.shape == ref_t.shape, name
+            assert rel_err(got_t.grad, ref_t.grad) < (1e-4 if dtype == torch.float32 else 4e-2), name
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
