@@ -88,7 +88,10 @@ struct VecIO<float, VEC> {
     }
   }
   static __device__ __forceinline__ void store(float* p, const float (&r)[VEC]) {
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 8) {
+      reinterpret_cast<float4*>(p)[0] = make_float4(r[0], r[1], r[2], r[3]);
+      reinterpret_cast<float4*>(p)[1] = make_float4(r[4], r[5], r[6], r[7]);
+    } else if constexpr (VEC == 4) {
       *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
     } else if constexpr (VEC == 2) {
       *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]);
