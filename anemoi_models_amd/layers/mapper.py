@@ -194,7 +194,8 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         ``x_dst`` (inside the K padding) that already holds a constant 1 (``_embedded``), or None."""
         n_src, n_dst = x_src.shape[0], x_dst.shape[0]
         plan = self._plans.get(self.edge_index_base, n_src, n_dst, batch_size, self.edge_inc, src_map, dst_map)
-        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
+        ea = runtime.edge_attr_csr_cached(self._packed, self.edge_attr, self.trainable.trainable, plan,
+                                          *self.proc.edge_layout(x_dst.dtype))
         h_src, h_dst = self._embed(x_src, x_dst, one_cols)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
         _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, out_stats_eps=self._extract_ln_eps(h_dst.dtype))
@@ -205,7 +206,8 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
         """Node-partitioned run (``distributed/partition.py``): local source / destination rows and a local CSR plan
         whose ``perm`` holds original edge ids; halo source rows (decoder) arrive by all-to-all-v inside the block."""
         plan = local_graph.plan
-        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm, *self.proc.edge_layout(x_dst.dtype))
+        ea = runtime.edge_attr_csr_cached(self._packed, self.edge_attr, self.trainable.trainable, plan,
+                                          *self.proc.edge_layout(x_dst.dtype))
         h_src, h_dst = self._embed(x_src, x_dst, one_cols)
         num_chunks = self.proc.num_chunks if self.training else inference_num_chunks()
         _, h_dst = self.proc.native(h_src, h_dst, ea, plan, num_chunks, local_graph.halo,

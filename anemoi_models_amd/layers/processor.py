@@ -165,6 +165,7 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
         )
         self.offload_layers(cpu_offload)
         self._plans = runtime.PlanCache()
+        self._packed = runtime.PackedWeights()
 
     def native(self, x: Tensor, batch_size: int, node_map: Optional[Tensor] = None) -> Tensor:
         """x ``[B * N, C]`` in the compute dtype -> processed nodes (same dtype).
@@ -172,8 +173,8 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
         ``node_map``: optional external-id -> row relabelling when ``x`` is kept in an internal node order."""
         n = x.shape[0]
         plan = self._plans.get(self.edge_index_base, n, n, batch_size, self.edge_inc, node_map, node_map)
-        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm,
-                               *self.proc[0].blocks[0].edge_layout(x.dtype))
+        ea = runtime.edge_attr_csr_cached(self._packed, self.edge_attr, self.trainable.trainable, plan,
+                                          *self.proc[0].blocks[0].edge_layout(x.dtype))
         for chunk in self.proc:
             x = chunk.native(x, ea, plan)
         return x
@@ -181,8 +182,8 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
     def native_local(self, x_own: Tensor, local_graph) -> Tensor:
         """Node-partitioned run (``distributed/partition.py``): this rank's mesh rows in, same rows out."""
         plan = local_graph.plan
-        ea = ops.edge_attr_csr(self.edge_attr, self.trainable.trainable, plan.perm,
-                               *self.proc[0].blocks[0].edge_layout(x_own.dtype))
+        ea = runtime.edge_attr_csr_cached(self._packed, self.edge_attr, self.trainable.trainable, plan,
+                                          *self.proc[0].blocks[0].edge_layout(x_own.dtype))
         for chunk in self.proc:
             x_own = chunk.native(x_own, ea, plan, local_graph.halo)
         return x_own

@@ -363,6 +363,17 @@ class PackedWeights:
         self._store.clear()
 
 
+def edge_attr_csr_cached(cache: PackedWeights, edge_attr: Tensor, trainable: Optional[Tensor], plan, *layout) -> Tensor:
+    """``ops.edge_attr_csr(edge_attr, trainable, plan.perm, *layout)`` -- the sub-graph's edge attributes next to the
+    trainable edge tensor, gathered into the plan's CSR order -- kept until one of the two tensors changes (pointer or
+    in-place version, as every derived weight): in inference they never do, and the gather (1.6 M decoder edges at
+    config 3) leaves the per-step stream.  The entry holds the plan, so its identity cannot be recycled."""
+    def build():
+        return plan, ops.edge_attr_csr(edge_attr, trainable, plan.perm, *layout)
+
+    return cache.get(("edge_attr_csr", id(plan), layout), [edge_attr, trainable], build)[1]
+
+
 def pack_weight(weights: Sequence[Tensor], dtype: torch.dtype, k_pad: Optional[int] = None) -> Tensor:
     """``cat(weights, 0)`` as ``[N, K_pad]`` in ``dtype`` with K zero padded to the kernel's K-slab multiple (or to
     ``k_pad`` columns when the activation carries more padding than that)."""

@@ -101,6 +101,19 @@ def test_gt_model_wiring_matches_golden(graph_o32, golden_cfg1_gt, monkeypatch):
     with torch.no_grad():
         y = model(gold["x"])
     torch.testing.assert_close(y, gold["y"], atol=1e-4, rtol=1e-4)
+    # the gathered edge attributes are kept between calls (runtime.edge_attr_csr_cached) -- and dropped when the trainable
+    # edge tensor or the attribute buffer is written to in place (an optimiser step, a loaded checkpoint)
+    calls = []
+    real = _cpu_ops.edge_attr_csr
+    monkeypatch.setattr("anemoi_models_amd.ops.edge_attr_csr", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        y2 = model(gold["x"])
+        assert not calls and torch.equal(y2, y)
+        model.processor.trainable.trainable.add_(0.5)
+        y3 = model(gold["x"])
+        assert len(calls) == 1 and not torch.allclose(y3, y)
+        model.processor.trainable.trainable.sub_(0.5)
+        torch.testing.assert_close(model(gold["x"]), y, atol=1e-5, rtol=1e-5)
 
 
 def test_layer_norm_fold_wiring_bf16(graph_o32, golden_cfg1_gt, monkeypatch):
