@@ -18,7 +18,7 @@ No all-reduce anywhere in the forward.  All index plumbing is torch; the arithme
 
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import List, Optional
 
 import torch
@@ -113,17 +113,30 @@ class HaloExchange:
     send_splits: List[int]
     recv_splits: List[int]
     group: object
+    # send buffers by (dtype, width), allocated once: the same exchange runs in every block of every step, and a block's
+    # pack is ordered behind the previous block's transfer (``finish`` lets the stream wait for it) -- one buffer is enough
+    _send: dict = field(default_factory=dict, repr=False, compare=False)
 
     @property
     def n_recv(self) -> int:
         return sum(self.recv_splits)
+
+    def _pack(self, rows: Tensor, n_own: int) -> Tensor:
+        """The rows the other ranks need, packed in destination-rank order (one gather kernel) into the resident buffer."""
+        key = (rows.dtype, rows.shape[1], rows.device)
+        buf = self._send.get(key)
+        if buf is None:
+            buf = self._send[key] = torch.empty((self.send_idx.shape[0], rows.shape[1]), dtype=rows.dtype,
+                                                device=rows.device)
+        return torch.index_select(rows[:n_own], 0, self.send_idx, out=buf)
 
     def start(self, rows: Tensor, n_own: int):
         """Begin ``rows[n_own : n_own + n_recv] <-`` the rows this rank's halo needs (``rows[:n_own]`` are its own).
 
         Returns a handle for :meth:`finish`; between the two the caller may launch work that does not touch the halo
         rows (the x_r | q | u GEMM), which overlaps with the xGMI transfer."""
-        send = rows[:n_own].index_select(0, self.send_idx)
+        send = self._pack(rows, n_own) if not (torch.is_grad_enabled() and rows.requires_grad) else \
+            rows[:n_own].index_select(0, self.send_idx)
         work = _alltoallv(rows[n_own:n_own + self.n_recv], send, self.recv_splits, self.send_splits, self.group,
                           async_op=True)
         return (work, send)  # keep the send buffer alive until the transfer has been waited for

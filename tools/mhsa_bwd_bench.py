@@ -9,7 +9,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anemoi_models_amd import autograd  # noqa: E402
 
-for (s, h, d) in [(10242, 16, 32), (40962, 16, 64)]:
+shapes = [(10242, 16, 32), (40962, 16, 64)]
+if len(sys.argv) > 1:  # S,H,D triples
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for (s, h, d) in shapes:
     c = h * d
     x = (torch.randn(s, 3 * c, device="cuda") * 0.5).bfloat16().requires_grad_()
     dy = torch.randn(s, c, device="cuda").bfloat16()
