@@ -173,9 +173,10 @@ def mlp2(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[T
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
-        stats = ops.row_stats(x, eps)
+        y, stats = ops.layer_norm_with_stats(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(),
+                                             eps)
         ctx.save_for_backward(x, stats, gamma)
-        return ops.layer_norm(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), eps)
+        return y
 
     @staticmethod
     def backward(ctx, dy: Tensor):

@@ -16,7 +16,8 @@ template <typename T, int VEC, int ITEMS>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
-                                                         int64_t ldy, int64_t rows, int C, float eps) {
+                                                         int64_t ldy, int64_t rows, int C, float eps,
+                                                         float2* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (stats != nullptr && lane == 0) stats[row] = make_float2(rstd, -mean * rstd);  // as row_stats_kernel leaves them
   T* yr = y + row * ldy;
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void layer_norm_generic_kernel(const T* __rest
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta,
                                                                  T* __restrict__ y, int64_t ldy, int64_t rows,
-                                                                 int C, float eps) {
+                                                                 int C, float eps, float2* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -84,13 +86,14 @@ __global__ __launch_bounds__(256) void layer_norm_generic_kernel(const T* __rest
     q += d * d;
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (stats != nullptr && lane == 0) stats[row] = make_float2(rstd, -mean * rstd);
   T* yr = y + row * ldy;
   for (int c = lane; c < C; c += 64) Elem<T>::store(yr + c, (Elem<T>::load(xr + c) - mean) * rstd * gamma[c] + beta[c]);
 }
 
 template <typename T>
 static int layer_norm_launch(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
-                             int64_t rows, int C, float eps, hipStream_t st) {
+                             int64_t rows, int C, float eps, hipStream_t st, float2* stats = nullptr) {
   constexpr int VMAX = 16 / sizeof(T);
   const T* xp = static_cast<const T*>(x);
   T* yp = static_cast<T*>(y);
@@ -103,7 +106,7 @@ static int layer_norm_launch(const void* x, int64_t ldx, const float* gamma, con
 #define LN_CASE(I)                                                                                       \
   case I:                                                                                                \
     hipLaunchKernelGGL((layer_norm_kernel<T, VMAX, I>), grid, block, 0, st, xp, ldx, gamma, beta, yp, ldy, \
-                       rows, C, eps);                                                                    \
+                       rows, C, eps, stats);                                                             \
     break;
   if (aligned && items <= 8) {
     switch (items) {
@@ -111,7 +114,7 @@ static int layer_norm_launch(const void* x, int64_t ldx, const float* gamma, con
     }
   } else {
     hipLaunchKernelGGL((layer_norm_generic_kernel<T>), grid, block, 0, st, xp, ldx, gamma, beta, yp, ldy, rows, C,
-                       eps);
+                       eps, stats);
   }
 #undef LN_CASE
   return check_launch("anemoi_layer_norm");
@@ -459,6 +462,21 @@ int anemoi_layer_norm(int dtype, const void* x, int64_t ldx, const float* gamma,
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm: dtype %d", dtype);
 }
 
+int anemoi_layer_norm_stats(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                            int64_t ldy, float* stats, int64_t rows, int C, float eps, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && y && gamma && beta && stats, ANEMOI_ERR_INVALID, "anemoi_layer_norm_stats: null pointer");
+  ANEMOI_REQUIRE(C > 0 && rows >= 0 && ldx >= C && ldy >= C && (uintptr_t)stats % 8 == 0, ANEMOI_ERR_INVALID,
+                 "anemoi_layer_norm_stats: bad shape rows=%lld C=%d ldx=%lld ldy=%lld (stats 8-byte aligned)",
+                 (long long)rows, C, (long long)ldx, (long long)ldy);
+  if (rows == 0) return ANEMOI_OK;
+  float2* sp = reinterpret_cast<float2*>(stats);
+  if (dtype == ANEMOI_F32)
+    return layer_norm_launch<float>(x, ldx, gamma, beta, y, ldy, rows, C, eps, as_stream(stream), sp);
+  if (dtype == ANEMOI_BF16)
+    return layer_norm_launch<bf16_t>(x, ldx, gamma, beta, y, ldy, rows, C, eps, as_stream(stream), sp);
+  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm_stats: dtype %d", dtype);
+}
+
 int anemoi_row_stats(int dtype, const void* x, int64_t ldx, float* stats, int64_t rows, int C, float eps,
                      anemoi_stream_t stream) {
   ANEMOI_REQUIRE(x && stats, ANEMOI_ERR_INVALID, "anemoi_row_stats: null pointer");
@@ -608,7 +626,7 @@ int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int3
   return check_launch("anemoi_bound_output");
 }
 
-int anemoi_abi_version(void) { return 26; }
+int anemoi_abi_version(void) { return 27; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

@@ -107,6 +107,20 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, out: 
     return out
 
 
+def layer_norm_with_stats(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
+    """``(LayerNorm(x), row statistics [M, 2] f32 = (rstd, -mean * rstd))`` from ONE pass over ``x`` (the training forward
+    keeps the statistics for the backward; ``row_stats`` + ``layer_norm`` read ``x`` twice)."""
+    _dev(x, weight, bias)
+    _rows(x)
+    out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    stats = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    st = _lib.load().anemoi_layer_norm_stats(dtype_code(x.dtype), x.data_ptr(), _ld(x), weight.data_ptr(), bias.data_ptr(),
+                                             out.data_ptr(), _ld(out), stats.data_ptr(), x.shape[0], x.shape[1], eps,
+                                             _stream())
+    _lib.check(st, "anemoi_layer_norm_stats")
+    return out, stats
+
+
 def _carry_stats(y: Tensor, eps: float, stats: Tensor) -> None:
     """Attach the LayerNorm statistics the producing GEMM's epilogue computed to ``y``.  The record pins the storage
     pointer and torch's in-place version counter of ``y`` at this moment: any later in-place write (or a swapped

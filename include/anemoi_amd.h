@@ -58,6 +58,11 @@ const char* anemoi_last_error(void);
 int anemoi_layer_norm(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                       int64_t ldy, int64_t rows, int C, float eps, anemoi_stream_t stream);
 
+/* The same, and stats[r] = { rstd_r, -mean_r * rstd_r } (f32 pairs, as anemoi_row_stats leaves them) out of the same pass:
+ * the training forward keeps them for anemoi_layer_norm_backward instead of reading x a second time. */
+int anemoi_layer_norm_stats(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                            int64_t ldy, float* stats, int64_t rows, int C, float eps, anemoi_stream_t stream);
+
 /*
  * Fused Linear: y = act(x @ W^T + bias) + residual, on MFMA.
  *   x [M, K] (ldx), W [N, K] row-major contiguous in `dtype` (nn.Linear layout), bias [N] f32 or NULL,

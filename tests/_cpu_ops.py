@@ -20,6 +20,10 @@ def layer_norm(x, weight, bias, eps=1e-5, out=None):
     return F.layer_norm(x.float(), (x.shape[1],), weight, bias, eps).to(x.dtype)
 
 
+def layer_norm_with_stats(x, weight, bias, eps=1e-5):
+    return layer_norm(x, weight, bias, eps), row_stats(x, eps)
+
+
 def row_stats(x, eps=1e-5):
     xf = x.float()
     mean = xf.mean(dim=1)
@@ -235,7 +239,7 @@ def add(a, b, out=None):
 def install(monkeypatch):
     import anemoi_models_amd.ops as ops
 
-    for name in ("layer_norm", "row_stats", "linear", "linear_dual", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded", "gt_edge_attention_tiled",
+    for name in ("layer_norm", "layer_norm_with_stats", "row_stats", "linear", "linear_dual", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded", "gt_edge_attention_tiled",
                  "gt_conv", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                  "prognostic_residual", "finalize_output", "bound_output", "advance_input", "convert_pad", "add", "act_forward"):
         monkeypatch.setattr(ops, name, globals()[name])

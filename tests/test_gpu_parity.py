@@ -44,6 +44,9 @@ def test_layer_norm(dtype, rows, c):
     got = ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV))
     assert got.dtype == dtype
     assert rel_err(got, want) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # one pass, two results (training forward): the same output bit for bit, the statistics of ops.row_stats bit for bit
+    got2, stats = ops.layer_norm_with_stats(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert torch.equal(got2, got) and torch.equal(stats, ops.row_stats(x.to(DEV)))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
