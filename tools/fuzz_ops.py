@@ -133,6 +133,31 @@ def fuzz_rows():
     print(f"layer_norm / transpose / col_sum: {bad} bad of {n_cases // 3}", flush=True)
 
 
+def fuzz_weight_grad():
+    """dW = dpre^T x and db on the TN kernel: random row counts (ragged chunks), column counts (ragged 256-tiles, 1-6 x-column
+    tiles = every share-out of the bias fragments), pitches wider than the matrices, against f64."""
+    bad = 0
+    for case in range(n_cases // 2):
+        m = rng.choice([rng.randint(128, 700), rng.randint(2000, 9000), 2048 * rng.randint(2, 6) + rng.randint(0, 70), 40962])
+        n = 8 * rng.choice([rng.randint(1, 40), 32 * rng.randint(1, 5), 32 * rng.randint(1, 4) + rng.randint(1, 31)])
+        k = 8 * rng.choice([rng.randint(1, 40), 32 * rng.randint(1, 6), 32 * rng.randint(1, 5) + rng.randint(1, 31)])
+        pad_d, pad_x = 8 * rng.randint(0, 3), 8 * rng.randint(0, 3)
+        g = torch.Generator().manual_seed(seed * 7919 + case)
+        dfull = torch.randn(m, n + pad_d, generator=g).bfloat16().to(dev)
+        xfull = torch.randn(m, k + pad_x, generator=g).bfloat16().to(dev)
+        dpre, x = dfull[:, pad_d:], xfull[:, :k]
+        dw, db = ops.weight_grad(dpre, x, k, want_bias=True)
+        want = dpre.double().t() @ x.double()
+        want_b = dpre.double().sum(0)
+        ok = rel(dw, want.float()) < 3e-5 and float((db.double() - want_b).abs().max()) < 1e-5 * float(
+            dpre.double().abs().sum(0).max()) and torch.equal(dw, ops.weight_grad(dpre, x, k))
+        if not ok:
+            bad += 1
+            print(f"  weight_grad case {case}: m={m} n={n} k={k} pads {pad_d} {pad_x}: dW {rel(dw, want.float()):.2e}", flush=True)
+    print(f"weight_grad (TN kernel): {bad} bad of {n_cases // 2}", flush=True)
+
+
 fuzz_linear()
 fuzz_edge_attention()
 fuzz_rows()
+fuzz_weight_grad()
