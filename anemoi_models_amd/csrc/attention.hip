@@ -72,7 +72,9 @@ __device__ __forceinline__ int aswz64(int row, int chunk) { return chunk ^ ((row
 // ATT_D = 64 (config 3: 1024 channels / 16 heads) or 32 (config 2: 512 / 16): NKS = D / 16 MFMAs per S^T block along the
 // head dimension, NDT = D / 32 row blocks of O^T; the K tile has D * 2 bytes per key, the V^T tile D rows of 128 bytes.
 template <int ATT_D>
-__global__ __launch_bounds__(512) void mhsa_bf16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+// (D = 32: capped at 128 registers = two workgroups per CU, six spilled values, 0.79 -> 0.69 ms at S = 10 242; the same cap
+//  at D = 64 spills 73 registers into the tile loop: 8.2 -> 23 ms, so D = 64 stays at one workgroup per CU)
+__global__ __launch_bounds__(512, ATT_D == 32 ? 4 : 2) void mhsa_bf16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                         const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                         int64_t ldo, int S, int S_pad, int H, int C, int window,
                                                         float scale_log2e, float* __restrict__ lse) {
@@ -544,8 +546,11 @@ __device__ __forceinline__ int att_rswz(int row, int chunk) {  // swizzle of a r
   return ATT_D == 64 ? aswz(row, chunk) : aswz64(row, chunk);
 }
 
+// (three waves per SIMD: the tile loop -- plain loads, two barriers per 32-query tile -- hides its latency by occupancy
+//  only; at the 212 registers the allocator takes unasked it runs two waves per SIMD, capped at 168 it spills ten and the
+//  backward of a layer at S = 40 962 goes 45.5 -> 39.3 ms; a cap of 128 spills 47)
 template <int ATT_D>
-__global__ __launch_bounds__(256) void mhsa_bwd_dkv_mfma_kernel(
+__global__ __launch_bounds__(256, 3) void mhsa_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
     const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT, const float* __restrict__ lse,
     const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window,
