@@ -174,3 +174,113 @@ def test_rollout_with_the_state_kept_sharded(world, tmp_path):
         assert i["shape_last"][0] == 1 and i["err_last"] < 1e-5 * i["scale"], i
         assert 0 < i["grid_halo"] < i["grid"] // 2  # a boundary strip, not the grid
     assert sum(i["grid_halo"] for i in infos) == sum(i["grid_sent"] for i in infos)
+
+
+def _collectives_worker(rank, world, port, result_file):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from anemoi_models_amd.distributed.graph import gather_tensor, reduce_shard_tensor, reduce_tensor, shard_tensor
+        from anemoi_models_amd.distributed.graph import sync_tensor
+        from anemoi_models_amd.distributed.transformer import shard_heads, shard_sequence
+
+        g = dist.group.WORLD
+        rows = [3, 5, 4][:world]  # unequal shards
+        shapes = [[n, 6] for n in rows]
+
+        def rnd(seed, *shape):
+            return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+        xs = [rnd(10 + r, rows[r], 6) for r in range(world)]          # what every rank holds
+        ws = [rnd(20 + r, sum(rows), 6) for r in range(world)]        # every rank's weights on a gathered tensor
+        vs = [rnd(30 + r, rows[r], 6) for r in range(world)]          # ... on its own shard
+        full = torch.cat(xs, 0)
+        lo = sum(rows[:rank])
+        own = slice(lo, lo + rows[rank])
+        errs = {}
+
+        def check(name, got, want):
+            errs[name] = float((got - want).abs().max()) if got.shape == want.shape else float("inf")
+
+        # gather forward / take backward
+        x = xs[rank].clone().requires_grad_()
+        y = gather_tensor(x, 0, shapes, g)
+        check("gather.fwd", y.detach(), full)
+        (y * ws[rank]).sum().backward()
+        check("gather.bwd", x.grad, ws[rank][own])
+        # take forward / gather backward (and the variant that fills only the own slot)
+        x = full.clone().requires_grad_()
+        y = shard_tensor(x, 0, shapes, g)
+        check("shard.fwd", y.detach(), xs[rank])
+        (y * vs[rank]).sum().backward()
+        check("shard.bwd", x.grad, torch.cat(vs, 0))
+        x = full.clone().requires_grad_()
+        (shard_tensor(x, 0, shapes, g, gather_in_backward=False) * vs[rank]).sum().backward()
+        want = torch.zeros_like(full)
+        want[own] = vs[rank]
+        check("shard.bwd_local", x.grad, want)
+        # column shards of a 3-D tensor: dim = -1 style use (dim index 2)
+        cols = [2, 4, 1][:world]
+        cshapes = [[2, 3, c] for c in cols]
+        parts = [rnd(40 + r, 2, 3, cols[r]) for r in range(world)]
+        y = gather_tensor(parts[rank].clone(), 2, cshapes, g)
+        check("gather.dim2", y, torch.cat(parts, 2))
+        # all-reduce forward, identity backward (bf16 input: f32 accumulation, result rounded once)
+        same = [rnd(50 + r, 4, 6) for r in range(world)]
+        x = same[rank].clone().requires_grad_()
+        y = reduce_tensor(x, g)
+        check("reduce.fwd", y.detach(), sum(same))
+        (y * 2.0).sum().backward()
+        check("reduce.bwd", x.grad, torch.full_like(x, 2.0))
+        yb = reduce_tensor(same[rank].bfloat16(), g)
+        check("reduce.bf16", yb.float(), sum(s.bfloat16().float() for s in same).bfloat16().float())
+        # gather forward, all-reduce + split backward
+        x = xs[rank].clone().requires_grad_()
+        (sync_tensor(x, 0, shapes, g) * ws[rank]).sum().backward()
+        check("sync.bwd", x.grad, sum(ws)[own])
+        # all-reduce + split forward, gather backward
+        fulls = [rnd(60 + r, sum(rows), 6) for r in range(world)]
+        x = fulls[rank].clone().requires_grad_()
+        y = reduce_shard_tensor(x, 0, shapes, g)
+        check("reduce_shard.fwd", y.detach(), sum(fulls)[own])
+        (y * vs[rank]).sum().backward()
+        check("reduce_shard.bwd", x.grad, torch.cat(vs, 0))
+        # heads <-> sequence (batch 2, heads 2 * world, channels 3; sequence shards as tensor_split cuts them)
+        heads, n_total = 2 * world, 4 * world + 1
+        seq = [len(c) for c in torch.tensor_split(torch.arange(n_total), world)]
+        sshapes = [[n, 3] for n in seq]
+        qs = [rnd(70 + r, 2, heads, seq[r], 3) for r in range(world)]
+        q_full = torch.cat(qs, 2)
+        x = qs[rank].clone().requires_grad_()
+        y = shard_heads(x, sshapes, g)
+        check("heads.fwd", y.detach(), q_full[:, 2 * rank: 2 * rank + 2])
+        z = shard_sequence(y, sshapes, g)
+        check("heads.roundtrip", z.detach(), qs[rank])
+        us = [rnd(80 + r, 2, 2, n_total, 3) for r in range(world)]  # weights on every rank's head shard
+        (y * us[rank]).sum().backward()
+        s0 = sum(seq[:rank])
+        check("heads.bwd", x.grad, torch.cat(us, 1)[:, :, s0: s0 + seq[rank]])
+        # no group: identity, the input itself
+        t = rnd(1, 3, 3)
+        errs["identity"] = 0.0 if (shard_tensor(t, 0, shapes, None) is t and gather_tensor(t, 0, shapes, None) is t
+                                   and shard_heads(t, sshapes, None) is t) else 1.0
+        torch.save(errs, f"{result_file}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_collective_operators(world, tmp_path):
+    """shard / gather / reduce / sync / reduce_shard / shard_heads / shard_sequence (reference distributed/graph.py:19-137,
+    distributed/transformer.py:85-130): forward values and gradients on unequal shards against what one process computes
+    from all ranks' tensors."""
+    port = 29300 + (os.getpid() % 200) + world
+    result = str(tmp_path / "res")
+    mp.spawn(_collectives_worker, args=(world, port, result), nprocs=world, join=True)
+    for r in range(world):
+        errs = torch.load(f"{result}.{r}")
+        assert len(errs) == 16, sorted(errs)
+        for name, e in errs.items():
+            assert e < 1e-6, (r, name, e)
