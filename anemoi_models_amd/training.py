@@ -155,10 +155,12 @@ def gt_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None):
     return (x_src, y), edge_attr
 
 
-def _set_plan_and_attrs(mod, n_src: int, n_dst: int, batch_size: int, up: Optional[int] = None):
+def _set_plan_and_attrs(mod, n_src: int, n_dst: int, batch_size: int, up: Optional[int] = None,
+                        src_map: Optional[Tensor] = None, dst_map: Optional[Tensor] = None):
     """(plan, edge attributes in CSR order) of a mapper / processor: ``cat[edge_attr, trainable]`` repeated per batch
-    element (reference layers/graph.py:37-44) on the batched graph (layers/mapper.py:150-171)."""
-    plan = mod._plans.get(mod.edge_index_base, n_src, n_dst, batch_size, mod.edge_inc)
+    element (reference layers/graph.py:37-44) on the batched graph (layers/mapper.py:150-171).  ``src_map`` / ``dst_map``:
+    external node id -> row, when the caller keeps a node set in an internal order (the model root: Morton-ordered mesh)."""
+    plan = mod._plans.get(mod.edge_index_base, n_src, n_dst, batch_size, mod.edge_inc, src_map, dst_map)
     trainable = mod.trainable.trainable
     if up is None:  # GNN: the plain attribute matrix
         parts = [mod.edge_attr.float()] + ([] if trainable is None else [trainable.float()])
@@ -166,14 +168,14 @@ def _set_plan_and_attrs(mod, n_src: int, n_dst: int, batch_size: int, up: Option
     return plan, autograd._edge_attr_csr(mod.edge_attr, trainable, plan, up, batch_size)
 
 
-def gt_processor(proc, x: Tensor, batch_size: int) -> Tensor:
+def gt_processor(proc, x: Tensor, batch_size: int, node_map: Optional[Tensor] = None) -> Tensor:
     """``GraphTransformerProcessor.forward`` (reference layers/processor.py:317-343): checkpointed chunks of blocks that
     share ONE plan and ONE CSR attribute matrix."""
     dtype = runtime.compute_dtype(x)
     blk0 = proc.proc[0].blocks[0]
     _check_heads(x.shape[1], blk0.num_heads, dtype)
     n = x.shape[0]
-    plan, ea = _set_plan_and_attrs(proc, n, n, batch_size, ops.round_up(proc.edge_dim + 1, 4))
+    plan, ea = _set_plan_and_attrs(proc, n, n, batch_size, ops.round_up(proc.edge_dim + 1, 4), node_map, node_map)
 
     def run_chunk(chunk, h, attrs):
         for blk in chunk.blocks:
@@ -187,13 +189,15 @@ def gt_processor(proc, x: Tensor, batch_size: int) -> Tensor:
     return h
 
 
-def gt_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int) -> Tensor:
+def gt_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int, src_map: Optional[Tensor] = None,
+              dst_map: Optional[Tensor] = None) -> Tensor:
     """``GraphTransformerForwardMapper`` / ``GraphTransformerBackwardMapper`` (reference layers/mapper.py:275-418): returns
     the mapped (and, for the backward mapper, extracted) destination nodes."""
     dtype = runtime.compute_dtype(x_dst)
     blk = mapper.proc
     _check_heads(mapper.hidden_dim, blk.num_heads, dtype)
-    plan, ea = _set_plan_and_attrs(mapper, x_src.shape[0], x_dst.shape[0], batch_size, ops.round_up(mapper.edge_dim + 1, 4))
+    plan, ea = _set_plan_and_attrs(mapper, x_src.shape[0], x_dst.shape[0], batch_size, ops.round_up(mapper.edge_dim + 1, 4),
+                                   src_map, dst_map)
     hs, hd = _cast(x_src, dtype), _cast(x_dst, dtype)
     if hasattr(mapper, "emb_nodes_src"):
         hs = autograd.linear(hs, mapper.emb_nodes_src.weight, mapper.emb_nodes_src.bias)
@@ -273,11 +277,11 @@ def gnn_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None)
     return nodes, autograd.permute_rows(e_new, inv)
 
 
-def gnn_processor(proc, x: Tensor, batch_size: int) -> Tensor:
+def gnn_processor(proc, x: Tensor, batch_size: int, node_map: Optional[Tensor] = None) -> Tensor:
     """``GNNProcessor.forward`` (reference layers/processor.py:228-250, layers/chunk.py:165-181)."""
     dtype = runtime.compute_dtype(x)
     n = x.shape[0]
-    plan, ea = _set_plan_and_attrs(proc, n, n, batch_size)
+    plan, ea = _set_plan_and_attrs(proc, n, n, batch_size, None, node_map, node_map)
 
     def run_chunk(chunk, h, e):
         if chunk.emb_edges is not None:
@@ -292,11 +296,12 @@ def gnn_processor(proc, x: Tensor, batch_size: int) -> Tensor:
     return h
 
 
-def gnn_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int):
+def gnn_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int, src_map: Optional[Tensor] = None,
+               dst_map: Optional[Tensor] = None):
     """``GNNForwardMapper`` / ``GNNBackwardMapper`` (reference layers/mapper.py:485-522, 600-705): returns
     ``(source nodes after the block, destination nodes after the block / extraction)``."""
     dtype = runtime.compute_dtype(x_dst)
-    plan, ea = _set_plan_and_attrs(mapper, x_src.shape[0], x_dst.shape[0], batch_size)
+    plan, ea = _set_plan_and_attrs(mapper, x_src.shape[0], x_dst.shape[0], batch_size, None, src_map, dst_map)
     e = mlp(mapper.emb_edges, _cast(ea, dtype))
     hs, hd = _cast(x_src, dtype), _cast(x_dst, dtype)
     if hasattr(mapper, "emb_nodes_src"):
@@ -377,12 +382,41 @@ def model_forward(model, x: Tensor) -> Tensor:
     with torch.autocast(device_type=x.device.type, enabled=False):  # this route picks its precisions itself: the
         # activations are cast once here and every sub-module follows the dtype of what it is handed
         x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(rows * g, -1), _node_rows(model, data, rows)], dim=1).to(dtype)
-        x_hidden = _node_rows(model, hidden, rows).to(dtype)
+        x_hidden = _node_rows(model, hidden, rows)
         shapes = None  # (single device: the modules ignore shard shapes on this route)
-        x_data_latent, x_latent = _checkpoint(lambda a, c: model.encoder((a, c), rows, shapes), x_data, x_hidden)
-        x_proc = model.processor(x_latent, rows, shapes)
+        # As in inference, the mesh rows live in the internal Morton order between encoder and decoder (gather locality of
+        # the edge kernels, forward AND backward): only the small attribute table is permuted, the plans relabel the
+        # mesh side of every edge.  Graph processors only -- a sliding attention window is defined on the external order.
+        from .layers.mapper import GNNBaseMapper, GraphTransformerBaseMapper
+        from .layers.processor import GNNProcessor, GraphTransformerProcessor
+
+        inv = None
+        graph_proc = isinstance(model.processor, (GraphTransformerProcessor, GNNProcessor))
+        if graph_proc and all(isinstance(m, (GraphTransformerBaseMapper, GNNBaseMapper)) for m in (model.encoder, model.decoder)):
+            order, inv = model._mesh_order(x.device)
+            n_mesh = order.numel()
+            idx = order if rows == 1 else (torch.arange(rows, device=order.device)[:, None] * n_mesh + order[None, :]).reshape(-1)
+            x_hidden = autograd.permute_rows(x_hidden, idx) if x_hidden.requires_grad else x_hidden.index_select(0, idx)
+        x_hidden = x_hidden.to(dtype)
+
+        def run_mapper(mapper, a, c, src_map, dst_map):
+            if inv is None:
+                return mapper((a, c), rows, shapes)
+            if isinstance(mapper, GraphTransformerBaseMapper):
+                y = gt_mapper(mapper, a, c, rows, src_map, dst_map)
+                return (a, y) if hasattr(mapper, "emb_nodes_src") else y  # forward mapper: raw source handed on
+            hs, hd = gnn_mapper(mapper, a, c, rows, src_map, dst_map)
+            return (hs, hd) if hasattr(mapper, "emb_nodes_src") else hd
+
+        x_data_latent, x_latent = _checkpoint(lambda a, c: run_mapper(model.encoder, a, c, None, inv), x_data, x_hidden)
+        if inv is None:
+            x_proc = model.processor(x_latent, rows, shapes)
+        elif isinstance(model.processor, GraphTransformerProcessor):
+            x_proc = gt_processor(model.processor, x_latent, rows, inv)
+        else:
+            x_proc = gnn_processor(model.processor, x_latent, rows, inv)
         x_latent_proc = x_proc + x_latent
-        out = _checkpoint(lambda a, c: model.decoder((a, c), rows, shapes), x_latent_proc, x_data_latent)
+        out = _checkpoint(lambda a, c: run_mapper(model.decoder, a, c, inv, None), x_latent_proc, x_data_latent)
         return _finish(model, out, x, b, ens, g)
 
 
