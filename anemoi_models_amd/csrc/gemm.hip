@@ -430,11 +430,14 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   // the Linear BEHIND an activation delivers the gradient of the Linear IN FRONT of it, no separate act' pass.
   static_assert(!GMUL || (HAS_RES && !LN && !RS && !DUAL && ACT != 0), "GMUL: pre-activation in R, no other epilogue mode");
   // MH = 16-row fragments per wave along M: 8 -> the 256 x 256 tile, 4 -> a 128 x 256 tile (wave tile 64 x 128) used for
-  // the rows of a remainder round (640 tiles on 256 CUs: the last 128 tiles become 256 half tiles = one full round).
+  // the rows of a remainder round (640 tiles on 256 CUs: the last 128 tiles become 256 half tiles = one full round),
+  // 6 -> a 192 x 256 tile for small problems whose 256-row tiles quantise badly (5121 x 4096: 320 tiles = 2 rounds, as
+  // 432 tiles of 7/8 the staged bytes = 2 shorter rounds; 5121 x 2048: 160 -> 216 of the 256 CUs busy, shorter tiles).
   constexpr int TM = MH * 32;        // tile rows
   constexpr int NS = 8 * MH;         // MFMAs per 32-deep K step
   constexpr int NRD = 8 + MH;        // fragment reads per K step = LDS-DMA instructions per slab and wave
-  constexpr int G1 = MH == 8 ? 23 : 15, SP = MH == 8 ? 5 : 3, G2 = MH == 8 ? 103 : 51;  // schedule (see below)
+  constexpr int G1 = MH == 8 ? 23 : MH == 6 ? 17 : 15, SP = MH == 8 ? 5 : MH == 6 ? 4 : 3,
+                G2 = MH == 8 ? 103 : MH == 6 ? 78 : 51;  // schedule (see below)
   static_assert(G1 + 1 + (NRD - 1) * SP < G2 && G2 + NRD < 2 * NS, "slab schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -639,10 +642,8 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
               else dma_w(t - MH, kt_stage, wsd + (t - MH) * 1024);
             }
             if constexpr (s == G2) {  // barrier 2: the other buffer (staged one slab ago) is complete for everyone
-              if (vm_wait) {  // (slab 0 of a later tile: waited in the epilogue)
-                if constexpr (MH == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-              }
+              if (vm_wait)  // (slab 0 of a later tile: waited in the epilogue) -- all but this slab's own NRD refills
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRD) : "memory");
               __builtin_amdgcn_sched_barrier(0);
               __builtin_amdgcn_s_barrier();
               __builtin_amdgcn_sched_barrier(0);
@@ -846,8 +847,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       // nothing of this epilogue comes from vector memory (bias, column sums and row statistics sit in LDS), so only the
       // next tile's slab 0 has to have landed before the stores queue up behind it; slab 1 (the newest NRD DMAs of this
       // wave) stays in flight under the epilogue and is waited for by slab 0's own counted wait, ~2 us later
-      if constexpr (MH == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRD) : "memory");
     }
     ANEMOI_PIN();
     static_for_seq(
@@ -886,6 +886,8 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
 #define RAISE_W4_(A, RES, LNF)                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 8>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 6>),  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
       hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 4>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)      \
     return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
@@ -900,6 +902,10 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4_RS(false, true, 8);
     RAISE_W4_RS(true, false, 8);
     RAISE_W4_RS(true, true, 8);
+    RAISE_W4_RS(false, false, 6);
+    RAISE_W4_RS(false, true, 6);
+    RAISE_W4_RS(true, false, 6);
+    RAISE_W4_RS(true, true, 6);
     RAISE_W4_RS(false, false, 4);
     RAISE_W4_RS(false, true, 4);
     RAISE_W4_RS(true, false, 4);
@@ -994,6 +1000,16 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   hipLaunchKernelGGL((linear_bf16_w4_kernel<A, true, false, MHV, false, false, true>), dim3((unsigned)w4_blocks), dim3(256), \
                      W4_LDS, st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,                   \
                      vec_ok ? 1 : 0, TILES, (int)nt, LNV, 0)
+#define LAUNCH_W4_PLAIN(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                      \
+  switch (act) {                                                                                    \
+    case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+    default:                                                                                        \
+      if (rs_on) LAUNCH_W4(ANEMOI_ACT_NONE, MHV, true, XP, RP, YP, LNV, MV, TILES, TAIL);           \
+      else LAUNCH_W4(ANEMOI_ACT_NONE, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL);                \
+      break;                                                                                        \
+  }
 #define LAUNCH_W4_ACT(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                        \
   if (gmul) {                                                                                       \
     switch (act) {                                                                                  \
@@ -1007,15 +1023,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       case ANEMOI_ACT_SILU: LAUNCH_W4_DUAL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
       default: LAUNCH_W4_DUAL(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES); break;               \
     }                                                                                               \
-  } else switch (act) {                                                                             \
-    case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
-    case ANEMOI_ACT_SILU: LAUNCH_W4(ANEMOI_ACT_SILU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
-    case ANEMOI_ACT_RELU: LAUNCH_W4(ANEMOI_ACT_RELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
-    default:                                                                                        \
-      if (rs_on) LAUNCH_W4(ANEMOI_ACT_NONE, MHV, true, XP, RP, YP, LNV, MV, TILES, TAIL);           \
-      else LAUNCH_W4(ANEMOI_ACT_NONE, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL);                \
-      break;                                                                                        \
-  }
+  } else LAUNCH_W4_PLAIN(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)
     // row-sum partials (LnFold::rs_partial): plain epilogue only, whole 256-column tiles only
     const bool rs_on = ln.rs_partial != nullptr && act == ANEMOI_ACT_NONE && N % BIG_N == 0;
     if (rs_on && ln.rs_rows_done != nullptr) *ln.rs_rows_done = M;
@@ -1023,6 +1031,19 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     const bf16_t* rb = static_cast<const bf16_t*>(residual);
     bf16_t* yb = static_cast<bf16_t*>(y);
     int64_t w4_blocks = blocks;
+    // 192-row tiles for small problems: a tile stages 7/8 of the bytes of a 256-row one (the loop is bound by staging),
+    // so they pay when they do not add a round -- or fill more of the chip inside one (measured in profiles/r02_gemm_small_m.txt)
+    static const bool mh6_on = [] { const char* e = getenv("ANEMOI_AMD_GEMM_MH6"); return e == nullptr || atoi(e) != 0; }();
+    if (mh6_on && !batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
+      const int64_t mt6 = (M + 191) / 192, r8 = (mt * nt + max_blocks - 1) / max_blocks,
+                    r6 = (mt6 * nt + max_blocks - 1) / max_blocks;
+      if (r6 * 0.875 < r8 * 0.97) {
+        const int64_t tiles6 = mt6 * nt;
+        w4_blocks = tiles6 < max_blocks ? (tiles6 + 7) / 8 * 8 : max_blocks;
+        LAUNCH_W4_PLAIN(6, xb, rb, yb, ln, M, tiles6, w4_tail)
+        mt_a = 0;  // done
+      }
+    }
     if (mt_a > 0) {
       const int64_t m_a = mt_a * BIG_M < M ? mt_a * BIG_M : M, tiles_a = problems * mt_a * nt;
       const int tail_a = mt_b == 0 ? w4_tail : 0;
@@ -1038,6 +1059,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       LAUNCH_W4_ACT(4, xb + m_a * ldx, rb != nullptr ? rb + m_a * ldr : nullptr, yb + m_a * ldy, lb, m_b, tiles_b, w4_tail)
     }
 #undef LAUNCH_W4_ACT
+#undef LAUNCH_W4_PLAIN
 #undef LAUNCH_W4_DUAL
 #undef LAUNCH_W4_GMUL
 #undef LAUNCH_W4

@@ -1480,6 +1480,11 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
     (5121, 1024, 1216, "Identity", True, False),    # K = 19 slabs
     (2304, 1024, 512, "SiLU", False, False),        # 36 tiles: 4 or 5 per XCD
     (70000, 1024, 1024, "Identity", False, False),  # ragged last row tile
+    (5121, 2048, 1024, "Identity", True, False),    # 160 tiles -> 216 tiles of 192 rows (MH = 6), residual + row statistics
+    (5121, 2240, 1024, "Identity", False, True),    # ... ragged last column tile, LayerNorm fold
+    (10242, 2048, 512, "GELU", False, False),       # config 2's fc1: 320 tiles = 2 rounds -> 432 shorter ones
+    (5000, 4096, 1024, "Identity", True, False),    # 192-row tiles with a ragged last row tile (5000 = 26 * 192 + 8)
+    (4800, 4096, 512, "SiLU", False, False),        # 25 * 192 rows exactly
 ])
 def test_linear_remainder_round_shapes(m, n, k, act, res, fold):
     """Shapes whose tile count leaves a short remainder round on the 256 CUs (full mesh and per-rank sizes of config 3):
