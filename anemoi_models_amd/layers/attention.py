@@ -58,10 +58,46 @@ class MultiHeadSelfAttention(nn.Module):
         att = ops.mhsa(qkv, batch_size, self.num_heads, self.attention_window(), dropout_p=p, dropout_seed=seed)
         return linear_native(self._packed, "projection", self.projection, att)
 
+    def _sharded(self, x: Tensor, shapes: list, model_comm_group) -> Tensor:
+        """The reference's sequence-sharded call (layers/attention.py:72-112 with a model group): every rank holds a row
+        range of the sequence; q, k, v go through ``shard_heads`` (all of the sequence, this rank's heads), the attention
+        runs on the local heads, ``shard_sequence`` brings the rows back.  The collectives are autograd nodes
+        (``distributed/collectives.py``), so the same code trains.  (The model root does not come through here: its
+        node-partitioned forward exchanges heads itself, ``distributed/partition.py::HeadExchange``.)"""
+        from .. import autograd, training
+        from ..distributed.transformer import shard_heads, shard_sequence
+
+        grad = training.wants_grad(self, x)
+        dtype = runtime.compute_dtype(x)
+        xin = training._cast(x, dtype)
+        if grad:
+            qkv = autograd.linear(xin, self.lin_qkv.weight, self.lin_qkv.bias)
+        else:
+            qkv = linear_native(self._packed, "lin_qkv", self.lin_qkv, xin)
+        n_local, h, d = qkv.shape[0], self.num_heads, self.head_dim
+        # [n_local, 3, H, D] -> three (1, H, n_local, D) tensors, the layout the reference hands to shard_heads
+        q, k, v = (qkv.view(n_local, 3, h, d)[:, i].permute(1, 0, 2).unsqueeze(0) for i in range(3))
+        q, k, v = (shard_heads(t, shapes=shapes, mgroup=model_comm_group) for t in (q, k, v))
+        h_loc, n_all = q.shape[1], q.shape[2]
+        fused = torch.stack([t[0].permute(1, 0, 2) for t in (q, k, v)], dim=1).reshape(n_all, 3 * h_loc * d).contiguous()
+        p, seed = self.dropout()
+        if p > 0.0:
+            raise NotImplementedError("attention dropout across a model group (the ranks would need one mask)")
+        if grad:
+            att = autograd.mhsa(fused, 1, h_loc, self.attention_window(), 0.0, 0)
+        else:
+            att = ops.mhsa(fused, 1, h_loc, self.attention_window())
+        att = att.view(n_all, h_loc, d).permute(1, 0, 2).unsqueeze(0)  # (1, H_local, N, D)
+        att = shard_sequence(att, shapes=shapes, mgroup=model_comm_group)  # (1, H, n_local, D)
+        att = att[0].permute(1, 0, 2).reshape(n_local, h * d).contiguous()
+        if grad:
+            return autograd.linear(att, self.projection.weight, self.projection.bias)
+        return linear_native(self._packed, "projection", self.projection, att)
+
     def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded accross GPUs"
-            raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
+            return self._sharded(x, shapes, model_comm_group)
         from .. import autograd, training
 
         if training.wants_grad(self, x):  # reference layers/attention.py:67-112 with an autograd graph

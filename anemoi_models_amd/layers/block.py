@@ -727,9 +727,30 @@ class TransformerProcessorBlock(BaseBlock):
         h = ops.layer_norm(x, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
         return self._mlp(h, residual=x)
 
+    def _sharded(self, x: Tensor, shapes: list, batch_size: int, model_comm_group) -> Tensor:
+        """Sequence-sharded call as in the reference (layers/block.py:99-105 with a model group): everything but the
+        attention is row-local; the attention module reshards rows <-> heads around its kernel."""
+        from .. import autograd
+
+        grad = training.wants_grad(self, x)
+        dtype = runtime.compute_dtype(x)
+        x = _as_compute(x, dtype)
+        ln1, ln2 = self.layer_norm1, self.layer_norm2
+        if grad:
+            h = autograd.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
+            x = x + self.attention(h, shapes, batch_size, model_comm_group)
+            h = autograd.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
+            return training.sequential(self.mlp, h, residual=x)
+        h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
+        x = ops.add(x, self.attention(h, shapes, batch_size, model_comm_group))
+        if self._mlp is None:
+            self._mlp = NativeSequential(self.mlp)
+        h = ops.layer_norm(x, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
+        return self._mlp(h, residual=x)
+
     def forward(self, x: Tensor, shapes: list, batch_size: int, model_comm_group=None) -> Tensor:
         if _group_size(model_comm_group) > 1:
-            raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
+            return self._sharded(x, shapes, batch_size, model_comm_group)
         if training.wants_grad(self, x):
             return training.transformer_block(self, x, batch_size)
         dtype = runtime.compute_dtype(x)

@@ -94,7 +94,12 @@ class TransformerProcessor(BaseProcessor):
                 model_comm_group.size() == 1 or batch_size == 1
             ), "Only batch size of 1 is supported when model is sharded accross GPUs"
             if model_comm_group.size() > 1:
-                raise NotImplementedError("head-sharded attention across a model group is not implemented yet")
+                # the reference's protocol (layers/processor.py:103-137): x is this rank's row shard, shard_shapes the row
+                # counts of all ranks; every block reshards rows <-> heads around its attention
+                for chunk in self.proc:
+                    for blk in chunk.blocks:
+                        x = blk(x, shard_shapes, batch_size, model_comm_group)
+                return x
         if training.wants_grad(self, x):
             return training.transformer_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)

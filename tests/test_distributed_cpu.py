@@ -284,3 +284,63 @@ def test_reference_collective_operators(world, tmp_path):
         assert len(errs) == 16, sorted(errs)
         for name, e in errs.items():
             assert e < 1e-6, (r, name, e)
+
+
+def _sharded_attention_worker(rank, world, port, result_file):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _cpu_ops
+        import anemoi_models_amd.ops as ops
+        from anemoi_models_amd.distributed.shapes import get_shape_shards
+        from anemoi_models_amd.layers.attention import MultiHeadSelfAttention
+
+        for name in ("linear", "mhsa", "convert_pad"):
+            setattr(ops, name, getattr(_cpu_ops, name))
+        torch.manual_seed(0)
+        att = MultiHeadSelfAttention(num_heads=4, embed_dim=64, window_size=None, dropout_p=0.0).eval()
+        n = 37
+        x = torch.randn(n, 64, generator=torch.Generator().manual_seed(1))
+        shapes = get_shape_shards(x, 0, dist.group.WORLD)
+        lo = sum(s[0] for s in shapes[:rank])
+        own = slice(lo, lo + shapes[rank][0])
+        with torch.no_grad():
+            want = att(x, [list(x.shape)], 1)
+            got = att(x[own].contiguous(), shapes, 1, dist.group.WORLD)
+        err = float((got - want[own]).abs().max())
+        # the whole block (LayerNorms, MLP and residuals are row-local)
+        from anemoi_models_amd.layers.block import TransformerProcessorBlock
+
+        for name in ("layer_norm", "add", "act_forward"):
+            setattr(ops, name, getattr(_cpu_ops, name))
+        blk = TransformerProcessorBlock(64, 128, 4, "GELU", window_size=None, dropout_p=0.0).eval()
+        with torch.no_grad():
+            want = blk(x, [list(x.shape)], 1)
+            got = blk(x[own].contiguous(), shapes, 1, dist.group.WORLD)
+        err = max(err, float((got - want[own]).abs().max()))
+        # ... and the processor (reference layers/processor.py:103-137: shard shapes + group handed to every block)
+        from anemoi_models_amd.layers.processor import TransformerProcessor
+
+        proc = TransformerProcessor(num_layers=2, window_size=None, num_channels=64, num_chunks=1, num_heads=4,
+                                    mlp_hidden_ratio=2, dropout_p=0.0).eval()
+        with torch.no_grad():
+            want = proc(x, 1, [list(x.shape)])
+            got = proc(x[own].contiguous(), 1, shapes, dist.group.WORLD)
+        err = max(err, float((got - want[own]).abs().max()))
+        torch.save(err, f"{result_file}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_module_level_sequence_sharded_attention(tmp_path):
+    """MultiHeadSelfAttention.forward(x_shard, shapes, 1, group) as the reference shards it (layers/attention.py:72-112:
+    shard_heads -> attention on the local heads -> shard_sequence), world 2 with unequal row shards, against the
+    unsharded module."""
+    port = 29500 + (os.getpid() % 200)
+    result = str(tmp_path / "res")
+    mp.spawn(_sharded_attention_worker, args=(2, port, result), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(f"{result}.{r}") < 1e-5
