@@ -161,19 +161,34 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
     # ---- the reference's head / sequence re-sharding helpers (layers/block.py:366-414) -----------------
     def shard_qkve_heads(self, query: Tensor, key: Tensor, value: Tensor, edges: Tensor, shapes: tuple, batch_size: int,
                          model_comm_group=None):
-        """``(batch grid) (heads vars) -> (batch grid) heads vars`` for q, k, v and the projected edge features.  Within
-        one process the reference's head exchange is the identity; across a model group this package partitions by mesh
-        node at the model root instead (``distributed/partition.py``), so a group of more than one rank is refused."""
-        if _group_size(model_comm_group) > 1:
-            raise NotImplementedError("block-level head sharding: use the node-partitioned model forward")
+        """``(batch grid) (heads vars) -> (batch grid) heads vars`` for q, k, v and the projected edge features; with a
+        model group, the reference's exchange (layers/block.py:366-399): every tensor goes through ``shard_heads`` -- all
+        nodes / edges of the group, this rank's heads -- with ``shapes = (source, destination, edge)`` shard shapes.  (The
+        model root does not use it: it partitions by mesh node, ``distributed/partition.py``.)"""
         h, d = self.num_heads, self.out_channels_conv
-        return tuple(t.reshape(t.shape[0], h, d) for t in (query, key, value, edges))
+        if _group_size(model_comm_group) <= 1:
+            return tuple(t.reshape(t.shape[0], h, d) for t in (query, key, value, edges))
+        from ..distributed.transformer import shard_heads
+
+        assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+        shapes_src, shapes_dst, shapes_edges = shapes
+        out = []
+        for t, shp in ((query, shapes_dst), (key, shapes_src), (value, shapes_src), (edges, shapes_edges)):
+            t = t.reshape(1, t.shape[0], h, d).permute(0, 2, 1, 3)  # batch heads grid vars
+            t = shard_heads(t, shapes=shp, mgroup=model_comm_group)
+            out.append(t[0].permute(1, 0, 2).contiguous())  # grid heads vars
+        return tuple(out)
 
     def shard_output_seq(self, out: Tensor, shapes: tuple, batch_size: int, model_comm_group=None) -> Tensor:
-        """``(batch grid) heads vars -> (batch grid) (heads vars)`` (reference layers/block.py:401-414)."""
-        if _group_size(model_comm_group) > 1:
-            raise NotImplementedError("block-level sequence sharding: use the node-partitioned model forward")
-        return out.reshape(out.shape[0], -1)
+        """``(batch grid) heads vars -> (batch grid) (heads vars)`` (reference layers/block.py:401-414); with a model
+        group the destination rows come back through ``shard_sequence`` (all heads, this rank's rows)."""
+        if _group_size(model_comm_group) <= 1:
+            return out.reshape(out.shape[0], -1)
+        from ..distributed.transformer import shard_sequence
+
+        t = out.permute(1, 0, 2).unsqueeze(0)  # batch heads grid vars
+        t = shard_sequence(t, shapes=shapes[1], mgroup=model_comm_group)
+        return t[0].permute(1, 0, 2).reshape(t.shape[2], -1).contiguous()
 
     # ---- packed parameters -------------------------------------------------------------------
     def _cat_linear(self, tag: str, layers, dtype):

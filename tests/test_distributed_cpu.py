@@ -330,6 +330,25 @@ def _sharded_attention_worker(rank, world, port, result_file):
             want = proc(x, 1, [list(x.shape)])
             got = proc(x[own].contiguous(), 1, shapes, dist.group.WORLD)
         err = max(err, float((got - want[own]).abs().max()))
+        # the graph blocks' resharding helpers (reference layers/block.py:366-414): q on the destination shards, k / v on
+        # the source shards, the projected edge features on the edge shards -> all rows, this rank's heads; and back
+        from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
+
+        gblk = GraphTransformerProcessorBlock(64, 128, 64, edge_dim=3, num_heads=4)
+        n_src, n_e = 29, 41
+        full = {k: torch.randn(m, 64, generator=torch.Generator().manual_seed(s_))
+                for k, m, s_ in (("q", n, 5), ("k", n_src, 6), ("v", n_src, 7), ("e", n_e, 8))}
+        shp = {k: get_shape_shards(t, 0, dist.group.WORLD) for k, t in full.items()}
+        mine = {k: t[sum(r[0] for r in shp[k][:rank]): sum(r[0] for r in shp[k][:rank + 1])].contiguous()
+                for k, t in full.items()}
+        q, k, v, e = gblk.shard_qkve_heads(mine["q"], mine["k"], mine["v"], mine["e"], (shp["k"], shp["q"], shp["e"]), 1,
+                                           dist.group.WORLD)
+        hs = slice(2 * rank, 2 * rank + 2)  # 4 heads over 2 ranks
+        for got_t, name in ((q, "q"), (k, "k"), (v, "v"), (e, "e")):
+            want_t = full[name].view(-1, 4, 16)[:, hs]
+            err = max(err, float((got_t - want_t).abs().max()) if got_t.shape == want_t.shape else 1e9)
+        back = gblk.shard_output_seq(q, (shp["k"], shp["q"], shp["e"]), 1, dist.group.WORLD)
+        err = max(err, float((back - mine["q"]).abs().max()) if back.shape == mine["q"].shape else 1e9)
         torch.save(err, f"{result_file}.{rank}")
     finally:
         dist.destroy_process_group()
