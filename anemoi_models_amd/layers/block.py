@@ -413,6 +413,28 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
         y = ops.linear(att, wp, bp, residual=x, stats_eps=self._mlp_ln_eps("dst", dtype))  # projection(out + x_r) + x
         return self._node_mlp(y, "dst", 1, out_stats_eps=self._next_ln_eps(dtype))
 
+    def _sharded(self, x: Tensor, edge_attr: Tensor, edge_index: Tensor, shapes: tuple, batch_size: int, model_comm_group,
+                 size=None) -> Tensor:
+        """The reference's module-level protocol across a model group (layers/block.py:602-635 with ``shard_qkve_heads`` /
+        ``shard_output_seq``): ``x`` and ``edge_attr`` are this rank's row / edge shards, ``edge_index`` the whole edge
+        list.  Everything is row-local except the conv, which runs on all nodes and edges for this rank's heads
+        (``GraphTransformerConv.forward`` = ``anemoi_gt_conv``).  One code path on the autograd nodes (they run their
+        forward kernels under ``no_grad`` as well); the model root partitions by mesh node instead and is the fast route."""
+        from .. import autograd
+
+        dtype = runtime.compute_dtype(x)
+        x = _as_compute(x, dtype)
+        ln = self.layer_norm1
+        h = autograd.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        x_r, q, k, v = (autograd.linear(h, lin.weight, lin.bias) for lin in (self.lin_self, self.lin_query, self.lin_key,
+                                                                              self.lin_value))
+        e = autograd.linear(_as_compute(edge_attr, dtype), self.lin_edge.weight, self.lin_edge.bias)
+        q, k, v, e = self.shard_qkve_heads(q, k, v, e, shapes, batch_size, model_comm_group)
+        out = self.conv(q, k, v, e, edge_index, size=size)
+        out = self.shard_output_seq(out, shapes, batch_size, model_comm_group)
+        out = autograd.linear(out + x_r, self.projection.weight, self.projection.bias, "Identity", x)
+        return training.sequential(self.node_dst_mlp, out, residual=out)
+
     def forward(
         self,
         x: Tensor,
@@ -425,7 +447,7 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
     ):
         if _group_size(model_comm_group) > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
-            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+            return self._sharded(x, edge_attr, edge_index, shapes, batch_size, model_comm_group, size), edge_attr
         if training.wants_grad(self, x, edge_attr):
             return training.gt_processor_block(self, x, edge_attr, edge_index, size)
         dtype = runtime.compute_dtype(x)
@@ -516,6 +538,31 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         new_src = self._node_mlp(x_src, "src", num_chunks) if self.update_src_nodes else x_src
         return new_src, new_dst
 
+    def _sharded(self, x, edge_attr: Tensor, edge_index: Tensor, shapes: tuple, batch_size: int, model_comm_group, size=None):
+        """The reference's module-level protocol across a model group (layers/block.py:479-550): row shards of the source
+        and destination nodes, an edge shard of the attributes, the whole edge index; heads exchanged around the conv
+        (see ``GraphTransformerProcessorBlock._sharded``)."""
+        from .. import autograd
+
+        if self.update_src_nodes:
+            raise NotImplementedError("update_src_nodes=True across a model group (the reference's mappers use False)")
+        x_src, x_dst = x
+        dtype = runtime.compute_dtype(x_dst)
+        x_src, x_dst = _as_compute(x_src, dtype), _as_compute(x_dst, dtype)
+        ln1, ln2 = self.layer_norm1, self.layer_norm2
+        hs = autograd.layer_norm(x_src, ln1.weight, ln1.bias, ln1.eps)
+        hd = autograd.layer_norm(x_dst, ln2.weight, ln2.bias, ln2.eps)
+        x_r = autograd.linear(hd, self.lin_self.weight, self.lin_self.bias)
+        q = autograd.linear(hd, self.lin_query.weight, self.lin_query.bias)
+        k = autograd.linear(hs, self.lin_key.weight, self.lin_key.bias)
+        v = autograd.linear(hs, self.lin_value.weight, self.lin_value.bias)
+        e = autograd.linear(_as_compute(edge_attr, dtype), self.lin_edge.weight, self.lin_edge.bias)
+        q, k, v, e = self.shard_qkve_heads(q, k, v, e, shapes, batch_size, model_comm_group)
+        out = self.conv(q, k, v, e, edge_index, size=size)
+        out = self.shard_output_seq(out, shapes, batch_size, model_comm_group)
+        out = autograd.linear(out + x_r, self.projection.weight, self.projection.bias, "Identity", x_dst)
+        return x_src, training.sequential(self.node_dst_mlp, out, residual=out)
+
     def forward(
         self,
         x,
@@ -528,7 +575,7 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
     ):
         if _group_size(model_comm_group) > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
-            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+            return self._sharded(x, edge_attr, edge_index, shapes, batch_size, model_comm_group, size), edge_attr
         if training.wants_grad(self, x[0], x[1], edge_attr):
             return training.gt_mapper_block(self, x, edge_attr, edge_index, size)
         x_src, x_dst = x

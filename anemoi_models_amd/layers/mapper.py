@@ -69,13 +69,11 @@ class BaseMapper(nn.Module, ABC):
 
     def pre_process(self, x, shard_shapes, model_comm_group=None):
         """``(x_src, x_dst, shapes_src, shapes_dst)`` (reference layers/mapper.py:68-89)."""
-        self._single_group(model_comm_group)
         shapes_src, shapes_dst = shard_shapes
         x_src, x_dst = x
         return x_src, x_dst, shapes_src, shapes_dst
 
     def post_process(self, x_dst, shapes_dst, model_comm_group=None):
-        self._single_group(model_comm_group)
         return x_dst
 
 
@@ -85,7 +83,11 @@ class ForwardMapperPreProcessMixin:
     def pre_process(self, x, shard_shapes, model_comm_group=None):
         from ..distributed.shapes import change_channels_in_shape
 
+        from ..distributed.graph import shard_tensor
+
         x_src, x_dst, shapes_src, shapes_dst = super().pre_process(x, shard_shapes, model_comm_group)
+        x_src = shard_tensor(x_src, 0, shapes_src, model_comm_group)  # (identity without a model group)
+        x_dst = shard_tensor(x_dst, 0, shapes_dst, model_comm_group)
         return (self._apply_module(self.emb_nodes_src, x_src), self._apply_module(self.emb_nodes_dst, x_dst),
                 change_channels_in_shape(shapes_src, self.hidden_dim), change_channels_in_shape(shapes_dst, self.hidden_dim))
 
@@ -94,8 +96,11 @@ class BackwardMapperPostProcessMixin:
     """hidden -> data: the output variables are extracted (reference layers/mapper.py:96-102)."""
 
     def post_process(self, x_dst, shapes_dst, model_comm_group=None):
-        self._single_group(model_comm_group)
-        return self._apply_module(self.node_data_extractor, x_dst)
+        from ..distributed.graph import gather_tensor
+        from ..distributed.shapes import change_channels_in_shape
+
+        x_dst = self._apply_module(self.node_data_extractor, x_dst)
+        return gather_tensor(x_dst, 0, change_channels_in_shape(shapes_dst, self.out_channels_dst), model_comm_group)
 
 
 class GraphEdgeMixin:
@@ -214,9 +219,27 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
                                     out_stats_eps=self._extract_ln_eps(h_dst.dtype))
         return self._extract(h_dst, out_dtype)
 
+    def _run_sharded(self, x, batch_size: int, shard_shapes, model_comm_group) -> Tensor:
+        """The reference's mapper forward across a model group (layers/mapper.py:239-272): the edge attributes are sharded
+        along the edge list, the edge index stays whole, ``pre_process`` shards / embeds the nodes, the block exchanges
+        heads around its conv, ``post_process`` extracts (and, for the backward mapper, gathers) the destination rows."""
+        from ..distributed.graph import shard_tensor
+        from ..distributed.shapes import get_shape_shards
+
+        size = (sum(s_[0] for s_ in shard_shapes[0]), sum(s_[0] for s_ in shard_shapes[1]))
+        edge_attr = self.trainable(self.edge_attr, batch_size)
+        edge_index = self._expand_edges(self.edge_index_base, self.edge_inc, batch_size)
+        shapes_edge_attr = get_shape_shards(edge_attr, 0, model_comm_group)
+        edge_attr = shard_tensor(edge_attr, 0, shapes_edge_attr, model_comm_group)
+        x_src, x_dst, shapes_src, shapes_dst = self.pre_process(x, shard_shapes, model_comm_group)
+        (x_src, x_dst), edge_attr = self.proc((x_src, x_dst), edge_attr, edge_index, (shapes_src, shapes_dst, shapes_edge_attr),
+                                              batch_size, model_comm_group, size=size)
+        return self.post_process(x_dst, shapes_dst, model_comm_group)
+
     def _run(self, x, batch_size: int, shard_shapes, model_comm_group) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
+            assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+            return self._run_sharded(x, batch_size, shard_shapes, model_comm_group)
         x_src, x_dst = x
         if shard_shapes is not None:
             size = (sum(s[0] for s in shard_shapes[0]), sum(s[0] for s in shard_shapes[1]))
@@ -285,7 +308,10 @@ class GraphTransformerBackwardMapper(BackwardMapperPostProcessMixin, GraphTransf
         """Only the destination is embedded; the source already lives in the hidden space (reference :412-418)."""
         from ..distributed.shapes import change_channels_in_shape
 
+        from ..distributed.graph import shard_tensor
+
         x_src, x_dst, shapes_src, shapes_dst = super().pre_process(x, shard_shapes, model_comm_group)
+        x_dst = shard_tensor(x_dst, 0, shapes_dst, model_comm_group)  # (identity without a model group)
         return (x_src, self._apply_module(self.emb_nodes_dst, x_dst), change_channels_in_shape(shapes_src, self.hidden_dim),
                 change_channels_in_shape(shapes_dst, self.hidden_dim))
 

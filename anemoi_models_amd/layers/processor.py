@@ -196,7 +196,21 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None, *args, **kwargs) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
             assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
-            raise NotImplementedError("processor-level model sharding: use the node-partitioned model forward")
+            # the reference's protocol (layers/processor.py:317-343): x is this rank's row shard; the edge attributes are
+            # sharded along the edge list, the edge index stays whole; every block exchanges heads around its conv
+            from ..distributed.graph import shard_tensor
+            from ..distributed.shapes import get_shape_shards
+
+            edge_attr = self.trainable(self.edge_attr, batch_size)
+            edge_index = self._expand_edges(self.edge_index_base, self.edge_inc, batch_size)
+            shapes_edge_attr = get_shape_shards(edge_attr, 0, model_comm_group)
+            edge_attr = shard_tensor(edge_attr, 0, shapes_edge_attr, model_comm_group)
+            n_all = sum(s_[0] for s_ in shard_shapes)
+            for chunk in self.proc:
+                for blk in chunk.blocks:
+                    x, edge_attr = blk(x, edge_attr, edge_index, (shard_shapes, shard_shapes, shapes_edge_attr), batch_size,
+                                       model_comm_group, size=(n_all, n_all))
+            return x
         if training.wants_grad(self, x):
             return training.gt_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
