@@ -660,9 +660,22 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
         ops.segment_sum(e_new, plan.rowptr, out=xcat[:, c:])  # scatter-sum over destinations
         return node_mlp(xcat, residual=x), e_new
 
+    def _sharded(self, x, edge_attr, edge_index, shapes, model_comm_group, size=None):
+        """The reference's module-level protocol across a model group (layers/block.py:193-223): ``x`` is this rank's row
+        shard, ``edge_attr`` / ``edge_index`` its 1-hop edge shard (global node ids).  ``sync_tensor`` gathers the nodes,
+        the conv updates the local edges and sums them over ALL destinations, ``shard_tensor`` keeps this rank's rows."""
+        from ..distributed.graph import shard_tensor, sync_tensor
+
+        dtype = runtime.compute_dtype(x)
+        x = _as_compute(x, dtype)
+        x_in = sync_tensor(x, 0, shapes[1], model_comm_group)
+        out, edges_new = self.conv(x_in, _as_compute(edge_attr, dtype), edge_index, size=size)
+        out = shard_tensor(out, 0, shapes[1], model_comm_group, gather_in_backward=False)
+        return training.mlp(self.node_mlp, torch.cat([x, out], dim=1), residual=x), edges_new
+
     def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
         if _group_size(model_comm_group) > 1:
-            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+            return self._sharded(x, edge_attr, edge_index, shapes, model_comm_group, size)
         if training.wants_grad(self, x, edge_attr):
             return training.gnn_processor_block(self, x, edge_attr, edge_index, size)
         dtype = runtime.compute_dtype(x)
@@ -721,9 +734,24 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         new_src = update(x_src, None) if self.update_src_nodes else x_src  # reference block.py:282
         return (new_src, new_dst), e_new
 
+    def _sharded(self, x, edge_attr, edge_index, shapes, model_comm_group, size=None):
+        """Reference layers/block.py:249-286 across a model group: both node sets gathered (``sync_tensor``), the conv on
+        the local 1-hop edges, this rank's destination rows kept; the source update is row-local."""
+        from ..distributed.graph import shard_tensor, sync_tensor
+
+        dtype = runtime.compute_dtype(x[1])
+        x_src, x_dst = _as_compute(x[0], dtype), _as_compute(x[1], dtype)
+        x_in = (sync_tensor(x_src, 0, shapes[0], model_comm_group), sync_tensor(x_dst, 0, shapes[1], model_comm_group))
+        out, edges_new = self.conv(x_in, _as_compute(edge_attr, dtype), edge_index, size=size)
+        out = shard_tensor(out, 0, shapes[1], model_comm_group, gather_in_backward=False)
+        new_dst = training.mlp(self.node_mlp, torch.cat([x_dst, out], dim=1), residual=x_dst)
+        new_src = x_src if not self.update_src_nodes else training.mlp(self.node_mlp, torch.cat([x_src, x_src], dim=1),
+                                                                      residual=x_src)
+        return (new_src, new_dst), edges_new
+
     def forward(self, x, edge_attr, edge_index, shapes, model_comm_group=None, size=None):
         if _group_size(model_comm_group) > 1:
-            raise NotImplementedError("block-level model sharding: use the node-partitioned model forward")
+            return self._sharded(x, edge_attr, edge_index, shapes, model_comm_group, size)
         if training.wants_grad(self, x[0], x[1], edge_attr):
             return training.gnn_mapper_block(self, x, edge_attr, edge_index, size)
         x_src, x_dst = x

@@ -356,10 +356,16 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
         [2, E * batch])`` in the sub-graph's edge order (a single model rank keeps that order; the reference only
         re-sorts for its 1-hop sharding).  The mapper forward does not come through here: it embeds the edges already
         in destination-sorted order."""
-        if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
+        from ..distributed.graph import shard_tensor
+        from ..distributed.khop_edges import sort_edges_1hop_sharding
+
         edge_attr = self.trainable(self.edge_attr, batch_size)
         edge_index = self._expand_edges(self.edge_index_base, self.edge_inc, batch_size)
+        if model_comm_group is not None and model_comm_group.size() > 1:  # this rank's 1-hop edge shard
+            edge_attr, edge_index, shapes_edge_attr, shapes_edge_idx = sort_edges_1hop_sharding(size, edge_attr, edge_index,
+                                                                                                model_comm_group)
+            edge_index = shard_tensor(edge_index, 1, shapes_edge_idx, model_comm_group)
+            edge_attr = shard_tensor(edge_attr, 0, shapes_edge_attr, model_comm_group)
         return self.emb_edges(edge_attr), edge_index
 
     # hooks: the forward mapper embeds both node sets, the backward mapper extracts the output variables
@@ -410,7 +416,14 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
 
     def _run(self, x, batch_size: int, shard_shapes, model_comm_group):
         if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
+            # the reference's mapper forward across a model group (layers/mapper.py:497-522)
+            assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+            size = (sum(s_[0] for s_ in shard_shapes[0]), sum(s_[0] for s_ in shard_shapes[1]))
+            edge_attr, edge_index = self.prepare_edges(size, batch_size, model_comm_group)
+            x_src, x_dst, shapes_src, shapes_dst = self.pre_process(x, shard_shapes, model_comm_group)
+            (x_src, x_dst), _ = self.proc((x_src, x_dst), edge_attr, edge_index, (shapes_src, shapes_dst), model_comm_group,
+                                          size=size)
+            return x_src, self.post_process(x_dst, shapes_dst, model_comm_group)
         x_src, x_dst = x
         if training.wants_grad(self, x_src, x_dst):
             return training.gnn_mapper(self, x_src, x_dst, batch_size)

@@ -147,7 +147,24 @@ class GNNProcessor(GraphEdgeMixin, BaseProcessor):
 
     def forward(self, x: Tensor, batch_size: int, shard_shapes, model_comm_group=None) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("processor-level model sharding: use the node-partitioned model forward")
+            # the reference's protocol (layers/processor.py:228-250): edges sorted into the 1-hop neighbourhoods of the
+            # ranks' destination ranges, attributes AND index sharded; x is this rank's row shard
+            from ..distributed.graph import shard_tensor
+            from ..distributed.khop_edges import sort_edges_1hop_sharding
+            from ..distributed.shapes import change_channels_in_shape
+
+            shape_nodes = change_channels_in_shape(shard_shapes, self.num_channels)
+            edge_attr = self.trainable(self.edge_attr, batch_size)
+            edge_index = self._expand_edges(self.edge_index_base, self.edge_inc, batch_size)
+            target_nodes = sum(s_[0] for s_ in shape_nodes)
+            edge_attr, edge_index, shapes_edge_attr, shapes_edge_idx = sort_edges_1hop_sharding(
+                target_nodes, edge_attr, edge_index, model_comm_group)
+            edge_index = shard_tensor(edge_index, 1, shapes_edge_idx, model_comm_group)
+            edge_attr = shard_tensor(edge_attr, 0, shapes_edge_attr, model_comm_group)
+            for chunk in self.proc:
+                x, edge_attr = chunk(x, edge_attr, edge_index, (shape_nodes, shape_nodes), model_comm_group,
+                                     size=(target_nodes, target_nodes))
+            return x
         if training.wants_grad(self, x):
             return training.gnn_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)

@@ -453,3 +453,74 @@ def test_module_level_sharded_graph_transformer_block_and_processor(tmp_path):
     mp.spawn(_sharded_gt_worker, args=(2, port, result), nprocs=2, join=True)
     for r in range(2):
         assert torch.load(f"{result}.{r}") < 2e-5
+
+
+def _sharded_gnn_worker(rank, world, port, result_file):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _cpu_ops
+        import anemoi_models_amd.ops as ops
+        from anemoi_models_amd.distributed.shapes import get_shape_shards
+        from anemoi_models_amd.graphs.synthetic import build_graph
+        from anemoi_models_amd.layers.mapper import GNNBackwardMapper, GNNForwardMapper
+        from anemoi_models_amd.layers.processor import GNNProcessor
+
+        for name in ("layer_norm", "layer_norm_with_stats", "row_stats", "linear", "linear_dual", "edge_attr_csr",
+                     "gather_add_act", "segment_sum", "convert_pad", "add", "act_forward"):
+            setattr(ops, name, getattr(_cpu_ops, name))
+        g = dist.group.WORLD
+        torch.manual_seed(0)
+        gen = torch.Generator().manual_seed(4)
+        c = 64
+        graph = build_graph("o32_ico2")
+        n_h, n_d = graph["hidden"].num_nodes, graph["data"].num_nodes
+        attrs = ["edge_length", "edge_dirs"]
+        proc = GNNProcessor(num_layers=2, trainable_size=2, num_channels=c, num_chunks=1, mlp_extra_layers=0,
+                            sub_graph=graph[("hidden", "to", "hidden")], sub_graph_edge_attributes=attrs, src_grid_size=n_h,
+                            dst_grid_size=n_h).eval()
+        with torch.no_grad():
+            proc.trainable.trainable.normal_(0.0, 0.3, generator=torch.Generator().manual_seed(9))
+        xh = torch.randn(n_h, c, generator=gen)
+        sh = get_shape_shards(xh, 0, g)
+        hrows = slice(sum(s[0] for s in sh[:rank]), sum(s[0] for s in sh[:rank + 1]))
+        with torch.no_grad():
+            want = proc(xh, 1, [list(xh.shape)])
+            got = proc(xh[hrows].contiguous(), 1, sh, g)
+        err = float((got - want[hrows]).abs().max())
+        enc = GNNForwardMapper(in_channels_src=20, in_channels_dst=6, hidden_dim=c, trainable_size=2, mlp_extra_layers=0,
+                               sub_graph=graph[("data", "to", "hidden")], sub_graph_edge_attributes=attrs, src_grid_size=n_d,
+                               dst_grid_size=n_h).eval()
+        dec = GNNBackwardMapper(in_channels_src=c, in_channels_dst=c, hidden_dim=c, trainable_size=2, out_channels_dst=7,
+                                mlp_extra_layers=0, sub_graph=graph[("hidden", "to", "data")], sub_graph_edge_attributes=attrs,
+                                src_grid_size=n_h, dst_grid_size=n_d).eval()
+        xd, xh6 = torch.randn(n_d, 20, generator=gen), torch.randn(n_h, 6, generator=gen)
+        sd_, sh6 = get_shape_shards(xd, 0, g), get_shape_shards(xh6, 0, g)
+        drows = slice(sum(s[0] for s in sd_[:rank]), sum(s[0] for s in sd_[:rank + 1]))
+        with torch.no_grad():
+            want_src, want_dst = enc((xd, xh6), 1, ([list(xd.shape)], [list(xh6.shape)]))
+            got_src, got_dst = enc((xd, xh6), 1, (sd_, sh6), g)  # full inputs in, row shards of both node sets out
+        err = max(err, float((got_dst - want_dst[hrows]).abs().max()), float((got_src - want_src[drows]).abs().max()))
+        xs, xdl = torch.randn(n_h, c, generator=gen), torch.randn(n_d, c, generator=gen)
+        sdl = get_shape_shards(xdl, 0, g)
+        with torch.no_grad():
+            want = dec((xs, xdl), 1, ([list(xs.shape)], [list(xdl.shape)]))
+            got = dec((xs[hrows].contiguous(), xdl[drows].contiguous()), 1, (sh, sdl), g)  # gathered output
+        err = max(err, float((got - want).abs().max()) if got.shape == want.shape else 1e9)
+        torch.save(err, f"{result_file}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_module_level_sharded_gnn_processor_and_mappers(tmp_path):
+    """GNNProcessor / GNNForwardMapper / GNNBackwardMapper called as the reference calls them across a model group
+    (layers/processor.py:228-250, layers/mapper.py:485-522, 600-705, layers/block.py:193-286: 1-hop edge shards,
+    ``sync_tensor`` of the nodes, conv, ``shard_tensor`` of the sums): world 2 against the unsharded modules."""
+    port = 29100 + (os.getpid() % 200)
+    result = str(tmp_path / "res")
+    mp.spawn(_sharded_gnn_worker, args=(2, port, result), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(f"{result}.{r}") < 2e-5
