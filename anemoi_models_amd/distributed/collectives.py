@@ -31,7 +31,7 @@ operator               forward                     backward
 
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, List, Sequence
 
 import torch
 import torch.distributed as dist

@@ -9,7 +9,6 @@ kernels as the flat model (every mapper / processor is one of ``layers/mapper.py
 
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 from torch import Tensor
