@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -40,6 +40,8 @@ SIGNATURES = {
     "anemoi_last_error": (c_char_p, []),
     "anemoi_layer_norm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                   c_float, c_void_p]),
+    "anemoi_layer_norm_residual": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                           c_int64, c_int, c_float, c_void_p]),
     "anemoi_layer_norm_stats": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                         c_int, c_float, c_void_p]),
     "anemoi_linear": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,

@@ -12,12 +12,20 @@ namespace anemoi {
 // Two-pass statistics in f32 (mean, then centred sum of squares) -- same formula as ATen's CPU
 // kernel up to summation order.
 // ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float round_to(float v);
+template <>
+__device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
 template <typename T, int VEC, int ITEMS>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          int64_t ldy, int64_t rows, int C, float eps,
-                                                         float2* __restrict__ stats) {
+                                                         float2* __restrict__ stats, const T* __restrict__ res = nullptr,
+                                                         int64_t ldr = 0) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -61,6 +69,12 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x
       VecIO<float, VEC>::load(beta + c, b);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      if (res != nullptr) {  // LayerNorm(x) + residual, rounded as two separate operations would round it
+        float r[VEC];
+        VecIO<T, VEC>::load(res + row * ldr + c, r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = round_to<T>(o[j]) + r[j];
+      }
       VecIO<T, VEC>::store(yr + c, o);
     }
   }
@@ -72,7 +86,8 @@ __global__ __launch_bounds__(256) void layer_norm_generic_kernel(const T* __rest
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta,
                                                                  T* __restrict__ y, int64_t ldy, int64_t rows,
-                                                                 int C, float eps, float2* __restrict__ stats) {
+                                                                 int C, float eps, float2* __restrict__ stats,
+                                                                 const T* __restrict__ res = nullptr, int64_t ldr = 0) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -88,25 +103,31 @@ __global__ __launch_bounds__(256) void layer_norm_generic_kernel(const T* __rest
   const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
   if (stats != nullptr && lane == 0) stats[row] = make_float2(rstd, -mean * rstd);
   T* yr = y + row * ldy;
-  for (int c = lane; c < C; c += 64) Elem<T>::store(yr + c, (Elem<T>::load(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+  for (int c = lane; c < C; c += 64) {
+    float o = (Elem<T>::load(xr + c) - mean) * rstd * gamma[c] + beta[c];
+    if (res != nullptr) o = round_to<T>(o) + Elem<T>::load(res + row * ldr + c);
+    Elem<T>::store(yr + c, o);
+  }
 }
 
 template <typename T>
 static int layer_norm_launch(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
-                             int64_t rows, int C, float eps, hipStream_t st, float2* stats = nullptr) {
+                             int64_t rows, int C, float eps, hipStream_t st, float2* stats = nullptr,
+                             const void* residual = nullptr, int64_t ldr = 0) {
   constexpr int VMAX = 16 / sizeof(T);
   const T* xp = static_cast<const T*>(x);
   T* yp = static_cast<T*>(y);
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const T* rp = static_cast<const T*>(residual);
   const bool aligned = (C % VMAX == 0) && (ldx % VMAX == 0) && (ldy % VMAX == 0) &&
                        ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
-                       ((uintptr_t)beta % 16 == 0);
+                       ((uintptr_t)beta % 16 == 0) && (residual == nullptr || (ldr % VMAX == 0 && (uintptr_t)residual % 16 == 0));
   const int per_pass = 64 * VMAX;
   const int items = (C + per_pass - 1) / per_pass;
 #define LN_CASE(I)                                                                                       \
   case I:                                                                                                \
     hipLaunchKernelGGL((layer_norm_kernel<T, VMAX, I>), grid, block, 0, st, xp, ldx, gamma, beta, yp, ldy, \
-                       rows, C, eps, stats);                                                             \
+                       rows, C, eps, stats, rp, ldr);                                                    \
     break;
   if (aligned && items <= 8) {
     switch (items) {
@@ -114,7 +135,7 @@ static int layer_norm_launch(const void* x, int64_t ldx, const float* gamma, con
     }
   } else {
     hipLaunchKernelGGL((layer_norm_generic_kernel<T>), grid, block, 0, st, xp, ldx, gamma, beta, yp, ldy, rows, C,
-                       eps, stats);
+                       eps, stats, rp, ldr);
   }
 #undef LN_CASE
   return check_launch("anemoi_layer_norm");
@@ -462,6 +483,21 @@ int anemoi_layer_norm(int dtype, const void* x, int64_t ldx, const float* gamma,
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm: dtype %d", dtype);
 }
 
+int anemoi_layer_norm_residual(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                               const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t rows, int C, float eps,
+                               anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && y && gamma && beta && residual, ANEMOI_ERR_INVALID, "anemoi_layer_norm_residual: null pointer");
+  ANEMOI_REQUIRE(C > 0 && rows >= 0 && ldx >= C && ldy >= C && ldr >= C, ANEMOI_ERR_INVALID,
+                 "anemoi_layer_norm_residual: bad shape rows=%lld C=%d ldx=%lld ldr=%lld ldy=%lld", (long long)rows, C,
+                 (long long)ldx, (long long)ldr, (long long)ldy);
+  if (rows == 0) return ANEMOI_OK;
+  if (dtype == ANEMOI_F32)
+    return layer_norm_launch<float>(x, ldx, gamma, beta, y, ldy, rows, C, eps, as_stream(stream), nullptr, residual, ldr);
+  if (dtype == ANEMOI_BF16)
+    return layer_norm_launch<bf16_t>(x, ldx, gamma, beta, y, ldy, rows, C, eps, as_stream(stream), nullptr, residual, ldr);
+  return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm_residual: dtype %d", dtype);
+}
+
 int anemoi_layer_norm_stats(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                             int64_t ldy, float* stats, int64_t rows, int C, float eps, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(x && y && gamma && beta && stats, ANEMOI_ERR_INVALID, "anemoi_layer_norm_stats: null pointer");
@@ -626,7 +662,7 @@ int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int3
   return check_launch("anemoi_bound_output");
 }
 
-int anemoi_abi_version(void) { return 27; }
+int anemoi_abi_version(void) { return 28; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

@@ -113,7 +113,11 @@ class NativeSequential:
                         and x.shape[1] % ops.k_multiple(dtype) == 0 and nxt[1].in_features == x.shape[1]):
                     pending_ln = (m, ops.row_stats(x, m.eps))
                 else:
-                    x = ops.layer_norm(x, runtime.f32c(m.weight), runtime.f32c(m.bias), m.eps)
+                    fuse = residual is not None and ends_with_ln and i == len(self.steps) - 1 and residual.dtype == x.dtype
+                    x = ops.layer_norm(x, runtime.f32c(m.weight), runtime.f32c(m.bias), m.eps,
+                                       residual=residual if fuse else None)  # trailing LayerNorm + skip connection: one pass
+                    if fuse:
+                        residual = None
         if residual is not None and ends_with_ln:
             x = ops.add(x, residual)
         return x

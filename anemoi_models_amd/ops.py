@@ -94,11 +94,22 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:
-    _dev(x, weight, bias, out)
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None,
+               residual: Optional[Tensor] = None) -> Tensor:
+    """``LayerNorm(x)`` (``+ residual`` in the same pass: the trailing LayerNorm of an MLP followed by its skip connection)."""
+    _dev(x, weight, bias, out, residual)
     _rows(x)
     if out is None:
         out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        if residual.dtype != x.dtype or residual.shape != x.shape:
+            raise ValueError("layer_norm: the residual must have the shape and dtype of x")
+        with _Timed("layer_norm", bytes=3 * x.shape[0] * x.shape[1] * x.element_size()):
+            st = _lib.load().anemoi_layer_norm_residual(dtype_code(x.dtype), x.data_ptr(), _ld(x), weight.data_ptr(),
+                                                        bias.data_ptr(), residual.data_ptr(), _ld(_rows(residual)),
+                                                        out.data_ptr(), _ld(_rows(out)), x.shape[0], x.shape[1], eps, _stream())
+        _lib.check(st, "anemoi_layer_norm_residual")
+        return out
     with _Timed("layer_norm", bytes=2 * x.shape[0] * x.shape[1] * x.element_size()):
         st = _lib.load().anemoi_layer_norm(dtype_code(x.dtype), x.data_ptr(), _ld(x), weight.data_ptr(),
                                            bias.data_ptr(), out.data_ptr(), _ld(_rows(out)), x.shape[0], x.shape[1],

@@ -58,6 +58,13 @@ const char* anemoi_last_error(void);
 int anemoi_layer_norm(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                       int64_t ldy, int64_t rows, int C, float eps, anemoi_stream_t stream);
 
+/* y = LayerNorm(x) + residual in one pass (each term rounded to the activation dtype first, as the two separate
+ * operations of the reference round: the trailing LayerNorm of layers/mlp.py:74-84 followed by "+ x" / "+ edge_attr" in
+ * layers/block.py:222, layers/conv.py:70). */
+int anemoi_layer_norm_residual(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                               const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t rows, int C, float eps,
+                               anemoi_stream_t stream);
+
 /* The same, and stats[r] = { rstd_r, -mean_r * rstd_r } (f32 pairs, as anemoi_row_stats leaves them) out of the same pass:
  * the training forward keeps them for anemoi_layer_norm_backward instead of reading x a second time. */
 int anemoi_layer_norm_stats(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,

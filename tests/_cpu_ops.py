@@ -16,7 +16,13 @@ from oracle.pyg_semantics import segment_softmax
 _ACT = {"Identity": lambda t: t, "GELU": F.gelu, "SiLU": F.silu, "ReLU": F.relu}
 
 
-def layer_norm(x, weight, bias, eps=1e-5, out=None):
+def layer_norm(x, weight, bias, eps=1e-5, out=None, residual=None):
+    if residual is not None:
+        return layer_norm(x, weight, bias, eps, out) + residual
+    return _layer_norm_plain(x, weight, bias, eps, out)
+
+
+def _layer_norm_plain(x, weight, bias, eps=1e-5, out=None):
     return F.layer_norm(x.float(), (x.shape[1],), weight, bias, eps).to(x.dtype)
 
 

@@ -47,6 +47,9 @@ def test_layer_norm(dtype, rows, c):
     # one pass, two results (training forward): the same output bit for bit, the statistics of ops.row_stats bit for bit
     got2, stats = ops.layer_norm_with_stats(x.to(DEV), w.to(DEV), b.to(DEV))
     assert torch.equal(got2, got) and torch.equal(stats, ops.row_stats(x.to(DEV)))
+    # LayerNorm + skip connection in one pass == the two operations, rounding included
+    r = torch.randn(rows, c, generator=g).to(dtype).to(DEV)
+    assert torch.equal(ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), residual=r), got + r)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
