@@ -487,20 +487,25 @@ def _gather_positions(sp: "ShardPlan", grid: int, device) -> Tensor:
 
 
 def sharded_training_forward(model, x: Tensor, group) -> Tensor:
-    """The node-partitioned forward WITH an autograd graph (flat GraphTransformer model, batch size 1): the same partition
+    """The node-partitioned forward WITH an autograd graph (flat model, GraphTransformer or GNN mappers around a
+    GraphTransformer or GNN processor, batch size 1): the same partition
     as :func:`sharded_forward`, every block on the differentiable kernels of ``autograd.py``, the halo exchanges and the
     output gather as autograd functions with their backward collectives.  Each rank ends up with the gradient
     contributions of ITS rows for every parameter: the caller sums them over the model group (what anemoi-training's DDP
     strategy does across all ranks of a model instance)."""
     from .. import autograd
     from .. import training
-    from ..layers.mapper import GraphTransformerBackwardMapper
-    from ..layers.mapper import GraphTransformerForwardMapper
+    from ..layers.mapper import GNNBaseMapper
+    from ..layers.mapper import GraphTransformerBaseMapper
+    from ..layers.processor import GNNProcessor
     from ..layers.processor import GraphTransformerProcessor
 
-    if not (isinstance(model.encoder, GraphTransformerForwardMapper) and isinstance(model.decoder, GraphTransformerBackwardMapper)
-            and isinstance(model.processor, GraphTransformerProcessor)):
-        raise NotImplementedError("node-partitioned training: the flat GraphTransformer model only")
+    gt_maps = isinstance(model.encoder, GraphTransformerBaseMapper) and isinstance(model.decoder, GraphTransformerBaseMapper)
+    gnn_maps = isinstance(model.encoder, GNNBaseMapper) and isinstance(model.decoder, GNNBaseMapper)
+    gt_proc, gnn_proc = isinstance(model.processor, GraphTransformerProcessor), isinstance(model.processor, GNNProcessor)
+    if not ((gt_maps or gnn_maps) and (gt_proc or gnn_proc)):
+        raise NotImplementedError("node-partitioned training: GraphTransformer or GNN mappers (one family for both) around "
+                                  "a GraphTransformer or GNN processor")
     b, _, ens, grid, _ = x.shape
     assert b == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
     if ens != 1:
@@ -514,8 +519,40 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
     order, _ = model._mesh_order(x.device)
     own_ids = order[sp.lo:sp.hi]
     enc, proc, dec = model.encoder, model.processor, model.decoder
-    heads = proc.proc[0].blocks[0].num_heads
-    training._check_heads(model.num_channels, heads, dtype)
+    heads = proc.proc[0].blocks[0].num_heads if gt_proc else (enc.proc.num_heads if gt_maps else 1)
+    if gt_proc or gt_maps:
+        training._check_heads(model.num_channels, heads, dtype)
+
+    def gnn_attrs(mod, plan):  # the plain attribute matrix [edge_attr | trainable] in the local plan's CSR order
+        parts = [mod.edge_attr.float()] + ([] if mod.trainable.trainable is None else [mod.trainable.trainable.float()])
+        return training._cast(torch.cat(parts, dim=1).index_select(0, plan.perm.long()), dtype)  # (this rank's edges only)
+
+    def gnn_encoder(src_rows, extra_rows, x_hid):
+        """GNNForwardMapper on the local graph (all sources local): (updated embedding of ``extra_rows`` -- the grid rows
+        this rank decodes, reference layers/mapper.py:522 --, new mesh rows)."""
+        e = training.mlp(enc.emb_edges, gnn_attrs(enc, sp.enc.plan))
+        hs, hd = training.mlp(enc.emb_nodes_src, src_rows), training.mlp(enc.emb_nodes_dst, x_hid)
+        (_, hd), _ = training.gnn_mapper_block_csr(enc.proc, hs, hd, e, sp.enc.plan)
+        hx = training.mlp(enc.emb_nodes_src, extra_rows)
+        if enc.proc.update_src_nodes:  # row-local update of the source embedding (reference layers/block.py:282)
+            hx = training.mlp(enc.proc.node_mlp, torch.cat([hx, hx], dim=1), residual=hx)
+        return hx, hd
+
+    def gnn_decoder(h_mesh_own, h_grid_own):
+        e = training.mlp(dec.emb_edges, gnn_attrs(dec, sp.dec.plan))
+        src = _HaloRows.apply(h_mesh_own, sp.dec.halo) if sp.dec.halo is not None else h_mesh_own
+        (_, hd), _ = training.gnn_mapper_block_csr(dec.proc, src, h_grid_own, e, sp.dec.plan)
+        return training.mlp(dec.node_data_extractor, hd)
+
+    def gnn_processor_chunk(chunk, h, e):
+        if chunk.emb_edges is not None:
+            e = training.mlp(chunk.emb_edges, e)
+        for blk in chunk.blocks:  # GraphConvProcessorBlock: the sources are the own rows + the halo rows of their owners
+            src = _HaloRows.apply(h, sp.proc.halo) if sp.proc.halo is not None else h
+            e = training._gnn_edge_update(blk.conv.edge_mlp, h, src, e, sp.proc.plan)
+            agg = autograd.segment_sum(e, sp.proc.plan)
+            h = training.mlp(blk.node_mlp, torch.cat([h, agg], dim=1), residual=h)
+        return h, e
 
     def attrs(mod, plan):
         return autograd._edge_attr_csr(mod.edge_attr, mod.trainable.trainable, plan, ops.round_up(mod.edge_dim + 1, 4))
@@ -556,25 +593,38 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
         x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(grid, -1), training._node_rows(model, data, 1)], dim=1).to(dtype)
         x_hidden = training._node_rows(model, hidden, 1).index_select(0, own_ids).to(dtype)
         # encoder: the grid rows that feed this rank's mesh rows -- no communication (every rank holds the full input)
-        hs = autograd.linear(x_data.index_select(0, sp.enc_src_ids), enc.emb_nodes_src.weight, enc.emb_nodes_src.bias)
-        hd = autograd.linear(x_hidden, enc.emb_nodes_dst.weight, enc.emb_nodes_dst.bias)
-        x_latent = training._checkpoint(lambda a, c_: mapper_block(enc, a, c_, sp.enc), hs, hd)
-        # processor: one halo exchange of k|v rows per block, forward and (reversed) backward
-        ea = attrs(proc, sp.proc.plan)
+        if gt_maps:
+            hs = autograd.linear(x_data.index_select(0, sp.enc_src_ids), enc.emb_nodes_src.weight, enc.emb_nodes_src.bias)
+            hd = autograd.linear(x_hidden, enc.emb_nodes_dst.weight, enc.emb_nodes_dst.bias)
+            x_latent = training._checkpoint(lambda a, c_: mapper_block(enc, a, c_, sp.enc), hs, hd)
+            x_dec_dst = None
+        else:
+            x_dec_dst, x_latent = training._checkpoint(gnn_encoder, x_data.index_select(0, sp.enc_src_ids),
+                                                       x_data.index_select(0, sp.dec_dst_ids), x_hidden)
+        # processor: one halo exchange per block (k|v rows / node rows), forward and (reversed) backward
+        if gt_proc:
+            ea = attrs(proc, sp.proc.plan)
 
-        def run_chunk(chunk, h, ea_):
-            for blk in chunk.blocks:
-                h = processor_block(blk, h, ea_, sp.proc)
-            return h
+            def run_chunk(chunk, h, ea_):
+                for blk in chunk.blocks:
+                    h = processor_block(blk, h, ea_, sp.proc)
+                return h
 
-        h = x_latent
-        for chunk in proc.proc:
-            h = training._checkpoint(run_chunk, chunk, h, ea)
+            h = x_latent
+            for chunk in proc.proc:
+                h = training._checkpoint(run_chunk, chunk, h, ea)
+        else:
+            h, e = x_latent, gnn_attrs(proc, sp.proc.plan)
+            for chunk in proc.proc:
+                h, e = training._checkpoint(gnn_processor_chunk, chunk, h, e)
         x_latent_proc = h + x_latent
         # decoder: own grid rows as destinations, own + halo mesh rows as sources
-        hd = autograd.linear(x_data.index_select(0, sp.dec_dst_ids), dec.emb_nodes_dst.weight, dec.emb_nodes_dst.bias)
-        y_local = training._checkpoint(lambda a, c_: mapper_block(dec, a, c_, sp.dec), x_latent_proc, hd)
-        y_local = training.sequential(dec.node_data_extractor, y_local).float()
+        if gt_maps:
+            hd = autograd.linear(x_data.index_select(0, sp.dec_dst_ids), dec.emb_nodes_dst.weight, dec.emb_nodes_dst.bias)
+            y_local = training._checkpoint(lambda a, c_: mapper_block(dec, a, c_, sp.dec), x_latent_proc, hd)
+            y_local = training.sequential(dec.node_data_extractor, y_local).float()
+        else:
+            y_local = training._checkpoint(gnn_decoder, x_latent_proc, x_dec_dst).float()
         y = _GatherOutput.apply(y_local, sp, group, grid)
         return training._finish(model, y, x, 1, 1, grid)
 

@@ -192,8 +192,12 @@ def test_training_with_boundings(graph_o32, golden_cfg1_gt):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
 
 
-@pytest.mark.parametrize("world,graph_name,channels,layers,heads", [(2, "o32_ico2", 64, 4, 4), (3, "o48_ico3", 128, 2, 8)])
-def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name, channels, layers, heads, tmp_path):
+@pytest.mark.parametrize("world,graph_name,channels,layers,heads,family", [
+    (2, "o32_ico2", 64, 4, 4, "GraphTransformer"), (3, "o48_ico3", 128, 2, 8, "GraphTransformer"),
+    (2, "o32_ico2", 64, 2, 4, "GNN"),       # GNN processor between GraphTransformer mappers
+    (3, "o32_ico2", 64, 2, 4, "GNN_all"),   # GNN processor and GNN mappers
+])
+def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name, channels, layers, heads, family, tmp_path):
     """Training across a model group: the sharded differentiable forward (halo all-to-all-v per block, output all-gather)
     and its backward (reverse halo all-to-all-v + index-add, gradient slice of the gather) on the HIP kernels, the ranks
     as separate processes sharing cuda:0 with host-staged gloo collectives.  Output == single-device output; parameter
@@ -205,8 +209,9 @@ def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name,
     port = 29500 + (os.getpid() % 150)
     out = str(tmp_path / "res")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_shared_ranks.py")
+    env = dict(os.environ, ANEMOI_TEST_FAMILY=family)
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out, graph_name, str(channels),
-                               str(layers), str(heads), "fp32", "train"]) for r in range(world)]
+                               str(layers), str(heads), "fp32", "train"], env=env) for r in range(world)]
     try:
         codes = [p.wait(timeout=900) for p in procs]
     finally:
@@ -217,7 +222,7 @@ def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name,
     assert codes == [0] * world
     for r in range(world):
         i = torch.load(f"{out}.{r}")
-        assert i["requires_grad"] and i["n_grads"] > 50
+        assert i["requires_grad"] and i["n_grads"] > 40
         assert i["err"] <= 2e-5 * max(1.0, i["scale"]), i
         assert i["train_out_err"] <= 2e-5 * max(1.0, i["scale"]), i
         assert i["grad_err"] <= 2e-4 * i["grad_scale"], i
