@@ -90,7 +90,12 @@ def _collect(t: Tensor, dim: int, shapes: Sequence, group, communicate: bool = T
         send = front.new_zeros((longest, *rest))
         send[: lengths[rank]].copy_(front)
     recv = front.new_empty((world * longest, *rest))
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if send.is_cuda and dist.get_backend(group) != "nccl":  # (debugging ranks sharing one GPU over gloo: through the host)
+        h_recv = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(h_recv, send.cpu(), group=group)
+        recv.copy_(h_recv)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
     if all(n == longest for n in lengths):
         out = recv
     else:
@@ -102,10 +107,15 @@ def _total(t: Tensor, group, use_fp32: bool = True) -> Tensor:
     """Sum over the ranks (f32 accumulation by default)."""
     if _size(group) == 1:
         return t
+    staged = t.is_cuda and dist.get_backend(group) != "nccl"  # (debugging ranks sharing one GPU over gloo)
     if use_fp32 and t.dtype != torch.float32:
-        acc = t.float()
+        acc = t.float().cpu() if staged else t.float()
         dist.all_reduce(acc, group=group)
-        return acc.to(t.dtype)
+        return acc.to(device=t.device, dtype=t.dtype)
+    if staged:
+        acc = t.cpu().contiguous()
+        dist.all_reduce(acc, group=group)
+        return acc.to(t.device)
     out = t.contiguous().clone() if use_fp32 else t
     dist.all_reduce(out, group=group)
     return out

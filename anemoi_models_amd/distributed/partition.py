@@ -502,10 +502,13 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
 
     gt_maps = isinstance(model.encoder, GraphTransformerBaseMapper) and isinstance(model.decoder, GraphTransformerBaseMapper)
     gnn_maps = isinstance(model.encoder, GNNBaseMapper) and isinstance(model.decoder, GNNBaseMapper)
+    from ..layers.processor import TransformerProcessor
+
     gt_proc, gnn_proc = isinstance(model.processor, GraphTransformerProcessor), isinstance(model.processor, GNNProcessor)
-    if not ((gt_maps or gnn_maps) and (gt_proc or gnn_proc)):
+    tfm_proc = isinstance(model.processor, TransformerProcessor)
+    if not ((gt_maps or gnn_maps) and (gt_proc or gnn_proc or tfm_proc)):
         raise NotImplementedError("node-partitioned training: GraphTransformer or GNN mappers (one family for both) around "
-                                  "a GraphTransformer or GNN processor")
+                                  "a GraphTransformer, GNN or Transformer processor")
     b, _, ens, grid, _ = x.shape
     assert b == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
     if ens != 1:
@@ -520,6 +523,8 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
     own_ids = order[sp.lo:sp.hi]
     enc, proc, dec = model.encoder, model.processor, model.decoder
     heads = proc.proc[0].blocks[0].num_heads if gt_proc else (enc.proc.num_heads if gt_maps else 1)
+    if tfm_proc and proc.proc[0].blocks[0].attention.num_heads % sp.world != 0:
+        raise NotImplementedError("node-partitioned training of the Transformer processor needs heads divisible by the group size")
     if gt_proc or gt_maps:
         training._check_heads(model.num_channels, heads, dtype)
 
@@ -613,10 +618,18 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
             h = x_latent
             for chunk in proc.proc:
                 h = training._checkpoint(run_chunk, chunk, h, ea)
-        else:
+        elif gnn_proc:
             h, e = x_latent, gnn_attrs(proc, sp.proc.plan)
             for chunk in proc.proc:
                 h, e = training._checkpoint(gnn_processor_chunk, chunk, h, e)
+        else:
+            # Transformer processor: the modules' own sequence-sharded route (rows <-> heads exchanges as autograd nodes,
+            # layers/attention.py::_sharded).  Global attention does not care which rows a rank holds; a sliding window is
+            # defined on the external node order, which the Morton-ordered partition does not keep.
+            if proc.proc[0].blocks[0].attention.attention_window() >= 0:
+                raise NotImplementedError("node-partitioned training with a sliding attention window")
+            rows_of = sp.proc.heads.rows
+            h = proc(x_latent, 1, [[r_, x_latent.shape[1]] for r_ in rows_of], group)
         x_latent_proc = h + x_latent
         # decoder: own grid rows as destinations, own + halo mesh rows as sources
         if gt_maps:

@@ -196,6 +196,7 @@ def test_training_with_boundings(graph_o32, golden_cfg1_gt):
     (2, "o32_ico2", 64, 4, 4, "GraphTransformer"), (3, "o48_ico3", 128, 2, 8, "GraphTransformer"),
     (2, "o32_ico2", 64, 2, 4, "GNN"),       # GNN processor between GraphTransformer mappers
     (3, "o32_ico2", 64, 2, 4, "GNN_all"),   # GNN processor and GNN mappers
+    (2, "o32_ico2", 64, 2, 4, "Transformer"),  # rows <-> heads exchanges around the attention, as autograd nodes
 ])
 def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name, channels, layers, heads, family, tmp_path):
     """Training across a model group: the sharded differentiable forward (halo all-to-all-v per block, output all-gather)
