@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -101,8 +101,8 @@ SIGNATURES = {
     "anemoi_transpose_colsum_rows": (c_int64, [c_int64, c_int64]),
     "anemoi_transpose_chunked": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p,
                                          c_void_p]),
-    "anemoi_weight_grad_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                      c_void_p]),
+    "anemoi_weight_grad_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                      c_int, c_int, c_int, c_void_p]),
     "anemoi_linear_batched": (c_int, [c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "anemoi_col_sum_workspace_floats": (c_int64, [c_int64, c_int]),

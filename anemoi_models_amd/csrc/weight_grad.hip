@@ -76,8 +76,9 @@ template <int NJ>
 __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy,
                                                              const bf16_t* __restrict__ X, int64_t ldx,
                                                              float* __restrict__ OUT, float* __restrict__ DB,
-                                                             int64_t M, int N, int K, int chunk_rows, int64_t n_tiles,
-                                                             int tiles_per_chunk, int kt_count) {
+                                                             int64_t out_stride, int64_t db_stride, int64_t M, int N, int K,
+                                                             int chunk_rows, int64_t n_tiles, int tiles_per_chunk,
+                                                             int kt_count) {
   constexpr int NS = 64;    // MFMAs per 32-deep reduction step
   constexpr int NRD = 16;   // fragments per step = LDS-DMA instructions per slab and wave
   constexpr int G1 = 23, SP = 5, G2 = 103;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
     tile_parts(tile, c, n0, k0);
     int rows_here = N - n0 < TN_TILE ? N - n0 : TN_TILE;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(OUT + ((int64_t)c * N + n0) * K), 0, rows_here * K * 4, 0x00020000);
+        (void*)(OUT + (int64_t)c * out_stride + (int64_t)n0 * K), 0, rows_here * K * 4, 0x00020000);
     int fr_e = fr, fq_e = fq;
     asm volatile("" : "+v"(fr_e), "+v"(fq_e));
     int vo[8];
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
 #pragma unroll
       for (int q = 0; q < NJ; ++q) {
         const int n = n0 + 128 * wm + 16 * jq[q] + fr_e;
-        if (jq[q] >= 0 && fq_e == 0 && n < N) DB[(int64_t)c * N + n] = bs[q][0];
+        if (jq[q] >= 0 && fq_e == 0 && n < N) DB[(int64_t)c * db_stride + n] = bs[q][0];
         bs[q] = wf32x4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -369,13 +370,17 @@ __global__ __launch_bounds__(256) void weight_grad_tn_kernel(const bf16_t* __res
 }  // namespace
 }  // namespace anemoi
 
-// partial [chunks][N][K] f32 <- per-chunk dY^T x;  bias_partial (optional) [chunks][N] f32 <- per-chunk column sums of dY
+// partial [chunks][N][K] f32 <- per-chunk dY^T x;  bias_partial (optional) [chunks][N] f32 <- per-chunk column sums of dY;
+// chunk c of either starts partial_stride / bias_stride floats behind chunk c - 1 (>= N * K / >= N: the two may share
+// one buffer [chunks][N * K + N], which a single anemoi_col_sum then reduces over the chunks)
 extern "C" int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x, int64_t ldx, void* partial,
-                                     void* bias_partial, int64_t M, int N, int K, int chunk_rows,
-                                     anemoi_stream_t stream) {
+                                     int64_t partial_stride, void* bias_partial, int64_t bias_stride, int64_t M, int N,
+                                     int K, int chunk_rows, anemoi_stream_t stream) {
   using namespace anemoi;
   ANEMOI_REQUIRE(dy && x && partial && M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && chunk_rows > 0,
                  ANEMOI_ERR_INVALID, "anemoi_weight_grad_tn: bad argument");
+  ANEMOI_REQUIRE(partial_stride >= (int64_t)N * K && partial_stride % 4 == 0 && (bias_partial == nullptr || bias_stride >= N),
+                 ANEMOI_ERR_INVALID, "anemoi_weight_grad_tn: chunk strides must cover a chunk (partial: a multiple of 4 floats)");
   ANEMOI_REQUIRE(chunk_rows % TN_ROWS == 0 && chunk_rows >= 2 * TN_ROWS, ANEMOI_ERR_INVALID,
                  "anemoi_weight_grad_tn: chunk_rows must be a multiple of %d, at least %d", TN_ROWS, 2 * TN_ROWS);
   ANEMOI_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)partial % 16 == 0 && ldy % 8 == 0 &&
@@ -407,8 +412,8 @@ extern "C" int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x,
 #define ANEMOI_TN_LAUNCH(NJV)                                                                                          \
   hipLaunchKernelGGL(weight_grad_tn_kernel<NJV>, dim3((unsigned)blocks), dim3(256), TN_LDS, as_stream(stream),          \
                      static_cast<const bf16_t*>(dy), ldy, static_cast<const bf16_t*>(x), ldx,                           \
-                     static_cast<float*>(partial), static_cast<float*>(bias_partial), M, N, K, chunk_rows, tiles, nt * kt, \
-                     kt)
+                     static_cast<float*>(partial), static_cast<float*>(bias_partial), partial_stride, bias_stride, M, N, K, \
+                     chunk_rows, tiles, nt * kt, kt)
   switch (nj) {
     case 0: ANEMOI_TN_LAUNCH(0); break;
     case 1: ANEMOI_TN_LAUNCH(1); break;

@@ -744,15 +744,17 @@ def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False):
         row_cap = ((1 << 31) - 1) // (2 * ld_max) // 64 * 64  # descriptor range of one chunk
         chunk_rows = max(128, min(round_up((m + chunks - 1) // chunks, 64), row_cap))
         chunks = (m + chunk_rows - 1) // chunk_rows
-        part = torch.empty((chunks, n, k), dtype=torch.float32, device=dpre.device)
-        bpart = torch.empty((chunks, n), dtype=torch.float32, device=dpre.device) if want_bias else None
-        st = _lib.load().anemoi_weight_grad_tn(dpre.data_ptr(), _ld(dpre), xr.data_ptr(), _ld(xr), part.data_ptr(),
-                                               _ptr(bpart), m, n, k, chunk_rows, _stream())
+        # one buffer [chunks, n * k (+ n)]: the weight partials and, behind them, the bias partials of a chunk -- ONE column
+        # sum over the chunks finishes both
+        width = n * k + (n if want_bias else 0)
+        part = torch.empty((chunks, width), dtype=torch.float32, device=dpre.device)
+        st = _lib.load().anemoi_weight_grad_tn(dpre.data_ptr(), _ld(dpre), xr.data_ptr(), _ld(xr), part.data_ptr(), width,
+                                               part[:, n * k:].data_ptr() if want_bias else None, width, m, n, k, chunk_rows,
+                                               _stream())
         _lib.check(st, "anemoi_weight_grad_tn")
-        dw = part[0] if chunks == 1 else col_sum(part.view(chunks, n * k)).view(n, k)
-        if not want_bias:
-            return dw
-        return dw, (bpart[0] if chunks == 1 else col_sum(bpart))
+        total = part[0] if chunks == 1 else col_sum(part)
+        dw = total[: n * k].view(n, k)
+        return (dw, total[n * k:]) if want_bias else dw
     tile = 256 if fast else 128
     tiles = ((n + tile - 1) // tile) * ((k + tile - 1) // tile)
     chunks = max(1, min(256 // tiles if tiles <= 256 else 1, m // 2048))

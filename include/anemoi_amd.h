@@ -351,12 +351,14 @@ int anemoi_transpose_chunked(int dtype, const void* src, int64_t ld_src, void* d
 
 /* Weight gradient without transposed copies (bf16): partial[c] [N, K] f32 (contiguous, c = 0 .. ceil(M / chunk_rows) - 1)
  * <- sum over the rows m of chunk c of dy[m, :N]^T x[m, :K]; bias_partial (optional) [chunks, N] f32 <- the column sums of
- * dy over the chunk (the bias gradient, out of the same pass).  dy [M, ldy], x [M, ldx] row-major, 16-byte aligned, pitches
+ * dy over the chunk (the bias gradient, out of the same pass).  partial_stride / bias_stride: floats between the chunks of
+ * either (>= N * K / >= N) -- both may live in one [chunks, N * K + N] buffer that one anemoi_col_sum reduces.  dy [M, ldy], x [M, ldx] row-major, 16-byte aligned, pitches
  * and N, K multiples of 8; chunk_rows a multiple of 64, >= 128, chunk_rows * pitch * 2 < 2 GiB.  The caller adds the
  * chunks (anemoi_col_sum).  Replaces autograd's grad_output.t() @ input of every nn.Linear under
  * models/encoder_processor_decoder.py:167-233 (training). */
-int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x, int64_t ldx, void* partial, void* bias_partial,
-                          int64_t M, int N, int K, int chunk_rows, anemoi_stream_t stream);
+int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x, int64_t ldx, void* partial, int64_t partial_stride,
+                          void* bias_partial, int64_t bias_stride, int64_t M, int N, int K, int chunk_rows,
+                          anemoi_stream_t stream);
 
 /* `batch` independent products y[b] = x[b] w[b]^T (strides in elements; no bias / activation): the weight-gradient GEMMs
  * split their long reduction over the rows into `batch` chunks this way and add the partial [N, K] results with
