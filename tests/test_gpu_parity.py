@@ -983,6 +983,8 @@ def test_transpose_is_exact_with_zero_padding(dtype, rows, cols, ld_out):
 @pytest.mark.parametrize("m,n,k,ld_extra", [
     (40962, 1024, 192, 0), (5121, 256, 1024, 0), (2500, 96, 64, 0), (40962, 2240, 1024, 0), (130, 8, 8, 0),
     (4099, 264, 520, 24), (128, 256, 256, 0), (70000, 80, 1024, 8),
+    (2048, 4352, 4096, 0),   # 272 tiles on 256 workgroups: some walk two tiles (tile transition, bias slots of the next tile)
+    (3000, 2304, 8192, 0),   # 288 tiles, 32 x-column tiles (only the first four share out the bias fragments)
 ])
 def test_weight_grad_without_transposes(m, n, k, ld_extra):
     """ops.weight_grad on the TN kernel (anemoi_weight_grad_tn: operands as they lie, ds_read_b64_tr_b16 fragments, f32
