@@ -451,3 +451,31 @@ def test_graph_conv_module_forward_and_backward(golden_blocks, pair):
     with torch.no_grad():  # the inference route gives the same numbers
         out2, en2 = conv((xs, xd) if pair else xs, eg, ei.to(DEV))
     assert rel_err(out2, out.detach()) < 1e-5 and rel_err(en2, edges_new.detach()) < 1e-5
+
+
+def test_module_level_model_groups_ranks_sharing_one_gpu(tmp_path):
+    """The reference's module-level calls with a model group on the HIP kernels (reference layers/processor.py:103-343,
+    layers/mapper.py:239-418): GraphTransformer / GNN / Transformer processors forward AND backward, GraphTransformer
+    mappers forward, two ranks sharing cuda:0 (gloo through host memory) against the unsharded modules; the parameter
+    gradients summed over the ranks equal the unsharded gradients."""
+    import os
+    import subprocess
+    import sys
+
+    port = 29700 + (os.getpid() % 150)
+    out = str(tmp_path / "res")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_shared_modules.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), out]) for r in range(2)]
+    try:
+        codes = [p.wait(timeout=900) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    assert codes == [0, 0]
+    for r in range(2):
+        info = torch.load(f"{out}.{r}")
+        assert len(info) == 8, sorted(info)
+        for k, v in info.items():
+            assert v < (2e-5 if k.endswith(".fwd") else 2e-4), (r, k, v)
