@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -35,6 +36,21 @@ inline int check_launch(const char* what) {
   do {                                  \
     if (!(cond)) return ::anemoi::fail(code, __VA_ARGS__); \
   } while (0)
+
+// "Has this call site prepared its kernels on the CURRENT device yet?" -- for hipFuncSetAttribute(MaxDynamicShared
+// MemorySize), which is a per-device property of a kernel: one bit per device ordinal, atomics only (two threads racing
+// through the first call both set the (idempotent) attribute; neither launches before it is set).
+struct PerDeviceOnce {
+  std::atomic<uint64_t> done_mask[4] = {};  // 256 device ordinals
+  // the current device's ordinal when this call site has not prepared it yet, else -1
+  int pending() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    dev &= 255;
+    return (done_mask[dev >> 6].load(std::memory_order_acquire) >> (dev & 63) & 1ull) ? -1 : dev;
+  }
+  void done(int dev) { done_mask[dev >> 6].fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
 
 // ---------------------------------------------------------------- bf16 <-> f32
 typedef uint16_t bf16_t;  // raw storage

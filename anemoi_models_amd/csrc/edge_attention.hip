@@ -714,12 +714,13 @@ static bool launch_tiled(const EdgeTileParams& p, hipStream_t st) {
   const size_t lds = tiled_lds_bytes(LPH, UP, p.s_cap, p.e_cap);
   if (lds > 160 * 1024 || p.s_cap > 8 * TILE_DST) return false;
   auto kern = gt_edge_attention_tiled_kernel<T, VEC, LPH, UP>;
-  static bool raised = false;  // per instantiation
-  if (!raised) {
+  static PerDeviceOnce raised;  // per instantiation
+  const int raise_dev = raised.pending();
+  if (raise_dev >= 0) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return false;
-    raised = true;
+    raised.done(raise_dev);
   }
   // persistent: one workgroup per CU when LDS allows only one, else as many as fit (the chunks get shorter)
   const int64_t total = (int64_t)p.n_tiles * p.H;
@@ -819,12 +820,13 @@ static bool launch_fast(const EdgeAttnParams& p, hipStream_t st) {
   if (lds > 160 * 1024 || p.C % VEC != 0) return false;
   auto kern = gt_edge_attention_kernel<T, VEC, LPH, EDP>;
   if (lds > 64 * 1024) {
-    static bool raised = false;  // per instantiation
-    if (!raised) {
+    static PerDeviceOnce raised;  // per instantiation
+    const int raise_dev = raised.pending();
+    if (raise_dev >= 0) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024) != hipSuccess)
         return false;
-      raised = true;
+      raised.done(raise_dev);
     }
   }
   // persistent-style grid: 8 XCDs x blocks_per_xcd, 4 waves per block, waves_per_xcd % n_slices == 0

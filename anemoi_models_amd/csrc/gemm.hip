@@ -881,8 +881,9 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   // pre-activation and the result is acc * act'(it).  Whole tiles only in both modes.
   const bool dual = epi == 1, gmul = epi == 2;
   if (tail_done != nullptr) *tail_done = false;
-  static bool raised = false;
-  if (!raised) {
+  static PerDeviceOnce raised;
+  const int raise_dev = raised.pending();
+  if (raise_dev >= 0) {
 #define RAISE_W4_(A, RES, LNF)                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 8>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
@@ -943,7 +944,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4(3, true);
 #undef RAISE_W4
 #undef RAISE_W4_
-    raised = true;
+    raised.done(raise_dev);
   }
   const int64_t mt = (M + BIG_M - 1) / BIG_M;
   const int64_t nt = (N + BIG_N - 1) / BIG_N;

@@ -395,8 +395,9 @@ extern "C" int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x,
   const int64_t tiles = chunks * nt * kt;
   ANEMOI_REQUIRE(tiles < ((int64_t)1 << 31) && (int64_t)nt * kt < ((int64_t)1 << 31), ANEMOI_ERR_UNSUPPORTED,
                  "anemoi_weight_grad_tn: too many tiles");
-  static bool raised = false;
-  if (!raised) {
+  static PerDeviceOnce raised;
+  const int raise_dev = raised.pending();
+  if (raise_dev >= 0) {
     const void* kernels[4] = {reinterpret_cast<const void*>(weight_grad_tn_kernel<0>),
                               reinterpret_cast<const void*>(weight_grad_tn_kernel<1>),
                               reinterpret_cast<const void*>(weight_grad_tn_kernel<2>),
@@ -404,7 +405,7 @@ extern "C" int anemoi_weight_grad_tn(const void* dy, int64_t ldy, const void* x,
     for (const void* kp : kernels)
       if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS) != hipSuccess)
         return fail(ANEMOI_ERR_LAUNCH, "anemoi_weight_grad_tn: cannot raise the dynamic LDS limit to %d", TN_LDS);
-    raised = true;
+    raised.done(raise_dev);
   }
   int64_t blocks = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;  // one persistent workgroup per CU, whole XCD rows
   const int holders = 2 * (kt < 4 ? kt : 4);

@@ -443,11 +443,13 @@ class _HaloRows(torch.autograd.Function):
         halo, n_own = ctx.halo, ctx.n_own
         d_own = dfull[:n_own].clone()
         n_send = sum(halo.send_splits)
-        if n_send > 0 or halo.n_recv > 0:
-            back = torch.empty((n_send, dfull.shape[1]), dtype=dfull.dtype, device=dfull.device)
-            _alltoallv(back, dfull[n_own:].contiguous(), halo.send_splits, halo.recv_splits, halo.group)
-            if n_send > 0:
-                d_own.index_add_(0, halo.send_idx, back)
+        # the reverse all-to-all-v is a GROUP-WIDE collective (RCCL all_to_all_single): a rank with an empty halo enters it
+        # with zero-length splits exactly as HaloExchange.start does in the forward -- skipping it would leave its peers
+        # waiting in (or mis-pair) the collective.  Only the accumulation is conditional.
+        back = torch.empty((n_send, dfull.shape[1]), dtype=dfull.dtype, device=dfull.device)
+        _alltoallv(back, dfull[n_own:].contiguous(), halo.send_splits, halo.recv_splits, halo.group)
+        if n_send > 0:
+            d_own.index_add_(0, halo.send_idx, back)
         return d_own, None
 
 
@@ -645,6 +647,7 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
 def finish_local_rows(model, x_state: Tensor, y_local: Tensor, sp: ShardPlan) -> Tensor:
     """Prognostic residual (from the last time slice of this rank's rows of the state) and boundings on the rows this
     rank decodes: the row-local part of ``AnemoiModelEncProcDec._finish`` (reference :227-231)."""
+    assert x_state.shape[0] == 1 and x_state.shape[2] == 1, "a sharded state is batch 1, ensemble 1 (reference layers/block.py:501-504)"
     out_idx, in_idx = model._prognostic_indices(x_state.device)
     own = y_local.float().clone()
     own[:, out_idx.long()] += x_state[0, -1, 0].index_select(0, sp.dec_dst_ids)[:, in_idx.long()]
@@ -674,12 +677,15 @@ def advance_sharded_state(model, x_state: Tensor, y_local: Tensor, sp: ShardPlan
     ``anemoi_advance_input`` shifts the time axis in place.  Afterwards exactly the rows ``enc_src_ids`` /
     ``dec_dst_ids`` of ``x_state`` are valid on this rank -- all the next ``sharded_forward`` reads."""
     b, _, ens, grid, _ = x_state.shape
+    assert b == 1 and ens == 1, "a sharded state is batch 1, ensemble 1 (reference layers/block.py:501-504)"
     v_out = y_local.shape[1]
     rows = torch.cat([sp.dec_dst_ids, sp.grid_halo_ids])
     y_rows = torch.empty((rows.shape[0], v_out), dtype=torch.float32, device=x_state.device)
     n_own = sp.dec_dst_ids.shape[0]
     y_rows[:n_own].copy_(finish_local_rows(model, x_state, y_local, sp))
     sp.grid_halo.exchange(y_rows, n_own)  # predictions of the encoder-halo grid rows, from the ranks that decode them
-    y_full = torch.empty((b, ens, grid, v_out), dtype=torch.float32, device=x_state.device)
-    y_full[0, 0].index_copy_(0, rows, y_rows)  # every other row stays unspecified: it is never read on this rank
+    # rows this rank neither decodes nor reads stay ZERO (never uninitialised memory: advance_input copies every row
+    # into the state, and NaN / Inf there would reach assemble_nodes and the forcing pre-processors of rollout())
+    y_full = torch.zeros((b, ens, grid, v_out), dtype=torch.float32, device=x_state.device)
+    y_full[0, 0].index_copy_(0, rows, y_rows)
     return ops.advance_input(x_state, y_full, colmap, forcing)

@@ -271,7 +271,7 @@ class PlanCache:
         if plan is None:
             path = self._disk_path(edge_index, n_src, n_dst, batch_size, edge_inc, src_map, dst_map)
             if path is not None and os.path.exists(path):
-                plan = load_edge_plan(path, edge_index.device)
+                plan = load_edge_plan(path, edge_index.device, n_src, n_dst)
             if plan is None:
                 ei = edge_index
                 if src_map is not None or dst_map is not None:
@@ -297,19 +297,29 @@ def save_edge_plan(plan: EdgePlan, path: str) -> None:
     os.replace(tmp, path)
 
 
-def load_edge_plan(path: str, device) -> Optional[EdgePlan]:
-    """The plan stored at ``path`` on ``device``; ``None`` for a file that is not a complete, consistent plan (it is then
-    rebuilt and overwritten)."""
+def load_edge_plan(path: str, device, n_src: Optional[int] = None, n_dst: Optional[int] = None) -> Optional[EdgePlan]:
+    """The plan stored at ``path`` on ``device``; ``None`` for a file that is not a complete, consistent plan for
+    ``n_src`` x ``n_dst`` nodes (it is then rebuilt and overwritten).  A loaded plan is held to what a built one
+    guarantees -- the edge kernels gather ``col`` rows and ``perm`` attribute rows without further checks: monotone row
+    pointers ending at E, every column inside the source set, ``perm`` a permutation of the edges."""
     try:
         d = torch.load(path, map_location="cpu", weights_only=True)
-        ok = (d.get("format") == "anemoi_models_amd.EdgePlan/1" and d["rowptr"].dtype == torch.int32
-              and d["rowptr"].shape[0] == d["n_dst"] + 1 and d["col"].shape == d["perm"].shape
-              and int(d["rowptr"][-1]) == d["col"].shape[0])
+        rowptr, col, perm = d["rowptr"], d["col"], d["perm"]
+        n_edges = col.shape[0]
+        ok = (d.get("format") == "anemoi_models_amd.EdgePlan/1" and rowptr.dtype == torch.int32
+              and col.dtype == torch.int32 and perm.dtype == torch.int32
+              and rowptr.dim() == 1 and col.dim() == 1 and rowptr.shape[0] == d["n_dst"] + 1 and col.shape == perm.shape
+              and (n_src is None or int(d["n_src"]) == int(n_src)) and (n_dst is None or int(d["n_dst"]) == int(n_dst))
+              and int(rowptr[0]) == 0 and int(rowptr[-1]) == n_edges and bool((rowptr[1:] >= rowptr[:-1]).all()))
+        if ok and n_edges > 0:
+            ok = (int(col.min()) >= 0 and int(col.max()) < int(d["n_src"])
+                  and bool((torch.bincount(perm.long().clamp_(0, n_edges - 1), minlength=n_edges) == 1).all())
+                  and int(perm.min()) >= 0 and int(perm.max()) < n_edges)
     except Exception:  # noqa: BLE001  (truncated / foreign file: fall back to building)
         return None
     if not ok:
         return None
-    return EdgePlan(d["rowptr"].to(device), d["col"].to(device), d["perm"].to(device), int(d["n_src"]), int(d["n_dst"]))
+    return EdgePlan(rowptr.to(device), col.to(device), perm.to(device), int(d["n_src"]), int(d["n_dst"]))
 
 
 def locality_order(sincos_latlon: Tensor) -> Tensor:

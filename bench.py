@@ -169,7 +169,10 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
         a = agg["linear"]
         # numerator = the ALGORITHMIC flops of the reference's Linear layers for this forward, not the flops this
         # package happens to execute (folds remove some products and add others); the executed figure is given beside it
-        algo = reference_linear_flops(model) if group is None else 0.0
+        # (N > 1: this rank's share of them -- the partition splits the rows, so 1 / world of every Linear is this rank's
+        # useful work; what the rank executes on top of that, e.g. k | v of halo rows, is not credited)
+        world = 1 if group is None else group.size()
+        algo = reference_linear_flops(model) / world
         flops = algo if algo > 0 else a["flops"]
         achieved = flops / (a["ms"] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype_name]
@@ -179,7 +182,10 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
             "launches": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
             "flops_per_launch": flops / a["launches"], "bytes_per_launch": a["bytes"] / a["launches"],
             "flops_model": ("algorithmic: 2 x rows x in x out of every nn.Linear of the reference forward (SURVEY 8d)"
+                            + (f", 1/{world} of them: this rank's rows" if world > 1 else "")
                             if algo > 0 else "executed by this package's launches"),
+            # the same kernel time against the flops the launches really execute (folds remove some products, add others)
+            "frac_executed": round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / peak, 4),
             "executed_flops_per_launch": a["flops"] / a["launches"],
             "executed_tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2),
             "share_of_step": None,
@@ -241,7 +247,7 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
     return out
 
 
-def cpu_baseline(model, graph, x, idx, n_blocks: int):
+def cpu_baseline(model, graph, x, idx, n_blocks: int, hip_latent=None, hip_y=None):
     """CPU oracle (plain-PyTorch restatement of the reference algorithm, oracle/reference_path.py) timed on this host's
     cores on the SAME forward as the headline value: input assembly, encoder, processor, decoder, prognostic residual.
 
@@ -292,6 +298,19 @@ def cpu_baseline(model, graph, x, idx, n_blocks: int):
         y[..., pout] += xc[:, -1, :, :, pin]
         t_dec = tick() - t0
     t_fwd = t_enc + t_blk * n_layers / n_blocks + t_dec
+    # parity of THIS run's device results against the oracle outputs the baseline has just produced on the same input
+    # (the oracle is the checker here, never the product): the encoder output (mesh latent, 1024 ch) always; the final
+    # prediction when every processor block was run
+    def rel(a, b):
+        return float((a.float().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    parity = {}
+    if hip_latent is not None:
+        parity["encoder_out_rel_err"] = rel(hip_latent, x_latent)
+    if hip_y is not None and n_blocks == n_layers:
+        parity["output_rel_err"] = rel(hip_y, y)
+    if parity:
+        parity["vs"] = "CPU oracle (f32) on the same weights / input, max |a - b| / max |b|"
     cpu = platform.processor() or platform.machine()
     try:
         with open("/proc/cpuinfo") as f:
@@ -306,6 +325,7 @@ def cpu_baseline(model, graph, x, idx, n_blocks: int):
                   f"encoder {t_enc:.1f} s + {n_blocks} of {n_layers} processor blocks {t_blk:.1f} s{scaled} + decoder + "
                   f"residual {t_dec:.1f} s = {t_fwd:.1f} s per step ({n_grid} grid / {n_mesh} mesh nodes, "
                   f"{model.num_channels} ch, mapper chunks {mapper_chunks}); measured {t_enc + t_blk + t_dec:.1f} s",
+        **({"parity": parity} if parity else {}),
     }
 
 
@@ -462,7 +482,25 @@ def main():
             line["config"]["workload"] = line["config"]["workload"].replace("GT blocks", f"{args.processor} blocks")
         if not args.no_cpu_baseline and world == 1 and args.processor == "GraphTransformer":
             n_cpu = args.cpu_blocks if args.cpu_blocks is not None else (1 if args.workload == "cfg3" else layers)
-            line["cpu_baseline"] = cpu_baseline(model, graph, x, idx, n_cpu)
+            # the device's encoder output (mesh latent, internal Morton row order -> external node order) and prediction
+            # for the same input, for the parity figures next to the baseline
+            captured = {}
+            native = model.encoder.native
+
+            def capture(*a, **k):
+                out = native(*a, **k)
+                captured["latent"] = out[1] if isinstance(out, tuple) else out
+                return out
+
+            model.encoder.native = capture
+            try:
+                with torch.no_grad():
+                    hip_y = model(x)
+            finally:
+                del model.encoder.native  # back to the class's method
+            _, inv = model._mesh_order(x.device)
+            hip_latent = captured["latent"][: inv.numel()].index_select(0, inv)[:, : model.num_channels]
+            line["cpu_baseline"] = cpu_baseline(model, graph, x, idx, n_cpu, hip_latent, hip_y)
         print(json.dumps(line), flush=True)
     if group is not None:
         import torch.distributed as dist

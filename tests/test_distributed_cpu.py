@@ -524,3 +524,60 @@ def test_module_level_sharded_gnn_processor_and_mappers(tmp_path):
     mp.spawn(_sharded_gnn_worker, args=(2, port, result), nprocs=2, join=True)
     for r in range(2):
         assert torch.load(f"{result}.{r}") < 2e-5
+
+
+def _empty_halo_worker(rank, world, port, result_file):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from anemoi_models_amd.distributed import partition
+
+        calls = []
+        real = partition._alltoallv
+
+        def counting(out, inp, out_splits, in_splits, group, async_op=False):
+            calls.append((tuple(out_splits), tuple(in_splits)))
+            return real(out, inp, out_splits, in_splits, group, async_op=async_op)
+
+        partition._alltoallv = counting
+        # ranks 0 and 1 need two / one of each other's rows; the LAST rank owns no boundary rows at all (empty halo)
+        n_own, width = 4, 3
+        send = {0: ([1, 3], [0, 2, 0]), 1: ([2], [1, 0, 0])}.get(rank, ([], [0] * world))
+        recv = {0: [0, 1, 0], 1: [2, 0, 0]}.get(rank, [0] * world)
+        halo = partition.HaloExchange(torch.tensor(send[0], dtype=torch.int64), send[1][:world], recv[:world],
+                                      dist.group.WORLD)
+        rows = (torch.arange(n_own * width, dtype=torch.float32).view(n_own, width) + 100 * rank).requires_grad_()
+        full = partition._HaloRows.apply(rows, halo)
+        fwd_calls = len(calls)
+        weight = torch.arange(full.numel(), dtype=torch.float32).view_as(full) + 1 + rank
+        (full * weight).sum().backward()
+        # what one process computes: d rows = own-row weights + the weights of every halo copy held by the peers
+        want = weight[:n_own].clone()
+        if rank == 0:  # rank 1 holds copies of rows 1, 3 behind its 4 own rows
+            w1 = torch.arange((n_own + 2) * width, dtype=torch.float32).view(-1, width) + 2
+            want[1] += w1[n_own]
+            want[3] += w1[n_own + 1]
+        if rank == 1:  # rank 0 holds a copy of row 2
+            w0 = torch.arange((n_own + 1) * width, dtype=torch.float32).view(-1, width) + 1
+            want[2] += w0[n_own]
+        torch.save(dict(fwd=fwd_calls, bwd=len(calls) - fwd_calls, err=float((rows.grad - want).abs().max()),
+                        n_full=full.shape[0]), f"{result_file}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_backward_is_entered_by_a_rank_with_an_empty_halo(tmp_path):
+    """The reverse all-to-all-v of ``_HaloRows.backward`` is a group-wide collective: a rank that neither sends nor
+    receives boundary rows must still enter it (zero-length splits), as it does in the forward -- on RCCL a skipped call
+    hangs or mis-pairs the peers' collective.  World 3, last rank with an empty halo: one exchange per direction on EVERY
+    rank, gradients = own rows + the peers' halo copies."""
+    port = 29500 + (os.getpid() % 200)
+    result = str(tmp_path / "res")
+    mp.spawn(_empty_halo_worker, args=(3, port, result), nprocs=3, join=True)
+    for r in range(3):
+        info = torch.load(f"{result}.{r}")
+        assert info["fwd"] == 1 and info["bwd"] == 1, (r, info)
+        assert info["err"] == 0.0, (r, info)
+    assert torch.load(f"{result}.2")["n_full"] == 4

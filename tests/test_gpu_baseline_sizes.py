@@ -4,7 +4,11 @@ identical random weights and a synthetic O96 atmospheric state within 1e-3 rel f
 * config 2: O96 -> ico-5, **all 16** GraphTransformer blocks, 512 channels, 16 heads -- f32 gated at 1e-3, bf16 reported
   against the f32 oracle with a stated bound;
 * config 5: the same graph with 16 GNN blocks (pure edge-MLP message passing) -- f32 gated at 1e-3, bf16 with a bound;
-* config 4 semantics at O96: a 2-step autoregressive rollout behind the interface (normaliser + model + advance_input).
+* config 4 semantics at O96: a 2-step autoregressive rollout behind the interface (normaliser + model + advance_input);
+* config 3 AT ITS OWN SIZE (N320 -> ico-6, 542 080 grid rows, 1024 channels, 16 heads of 64, encoder in-degrees, K = 4096
+  reductions) against the oracle with 2 of the 16 identical processor blocks -- f32 gated at 1e-3 per variable, bf16
+  reported -- and config 4 at N320 (4-step rollout, 16 blocks, bf16): interface rollout == chained forward +
+  ``anemoi_advance_input``, state kept sharded over 2 ranks == unsharded.
 
 The oracle (plain-PyTorch restatement, pinned to the reference by tests/test_oracle_golden.py) runs once per module on
 the host cores (7-15 s per forward at these sizes).
@@ -189,3 +193,171 @@ def test_forward_is_bit_reproducible_under_repetition(processor, monkeypatch):
             first = y.clone()
         else:
             assert torch.equal(first, y), f"run {it} differs from run 0"
+
+
+# ------------------------------------------------------------------------------------------- config 3 / 4 at N320 size
+def test_config3_n320_ico6_1024ch_f32_and_bf16_vs_oracle(monkeypatch):
+    """BASELINE config 3 at its own size -- N320 grid (542 080 rows), ico-6 mesh (40 962), 1024 channels, 16 heads of 64
+    -- with 2 processor blocks (the 16 are the same code on the same shapes; the oracle needs ~35 s per extra block on the
+    box's cores): the whole ``AnemoiModelEncProcDec.forward`` (reference models/encoder_processor_decoder.py:168-233;
+    mapper blocks layers/block.py:508-524 with the reference's own 8 inference chunks) on the HIP kernels against
+    ``oracle.model_forward``.  f32: the north-star gate, 1e-3 per output variable.  bf16 (the headline dtype): reported
+    against the f32 oracle, bounded."""
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.models import AnemoiModelEncProcDec
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    graph = build_graph("n320_ico6")
+    idx = SimpleDataIndices(n_prognostic=80, n_forcing=10, n_diagnostic=0)
+    torch.manual_seed(1234)
+    model = AnemoiModelEncProcDec(model_config=model_config("GraphTransformer", 1024, 2, 16), data_indices=idx,
+                                  graph_data=graph)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    model.eval()
+    x = torch.randn(1, 2, 1, graph["data"].num_nodes, idx.num_input, generator=torch.Generator().manual_seed(7))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = ref.model_forward(sd, graph_tensors(graph), x, num_heads=16, num_layers=2, num_chunks=2,
+                                 prognostic_in=range(80), prognostic_out=range(80), mapper_chunks=8)
+    del sd
+    model, x = model.to(DEV), x.to(DEV)
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32")
+    with torch.no_grad():
+        got = model(x)
+    err, err_v = rel_err(got, want), per_variable_rel_err(got, want)
+    print(f"config 3 size (N320 -> ico-6, 1024 ch, 2 GT blocks) f32 vs CPU oracle: max rel {err:.3e}, per variable {err_v:.3e}")
+    assert got.dtype == torch.float32 and got.shape == want.shape == (1, 1, 542080, 80)
+    assert err < 1e-3 and err_v < 1e-3  # north-star gate at the metric's own shapes
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    with torch.no_grad():
+        got16 = model(x)
+    e16, e16_v = rel_err(got16, want), per_variable_rel_err(got16, want)
+    print(f"config 3 size bf16 storage / f32 accumulate vs f32 CPU oracle: max rel {e16:.3e}, per variable {e16_v:.3e} "
+          f"(bound {BF16_BOUND})")
+    assert torch.isfinite(got16).all() and e16 < BF16_BOUND
+
+
+def test_expand_edges_on_device_bit_exact(golden_index_ops):
+    """SURVEY section 8 a3 on DEVICE tensors: ``runtime.expand_edges`` (reference layers/mapper.py:150-171) against the
+    vectors recorded from the reference (int64, bit exact)."""
+    from anemoi_models_amd import runtime
+
+    z = golden_index_ops
+    inc = torch.tensor([[70], [31]], dtype=torch.int64, device=DEV)
+    got = runtime.expand_edges(z["expand.edge_index"].to(DEV), inc, 3)
+    assert got.is_cuda and got.dtype == torch.int64 and torch.equal(got.cpu(), z["expand.out"])
+
+
+def test_config4_n320_rollout_4_steps_16_blocks_bf16(monkeypatch):
+    """BASELINE config 4 at its own size (N320, 16 blocks, 1024 ch, bf16, 4 lead times) behind
+    ``AnemoiModelInterface.rollout`` (reference interface/__init__.py:97-123 + anemoi-training's ``advance_input``):
+    (i) the rollout loop == four chained ``pre-process -> model.forward -> post-process`` calls with
+    ``anemoi_advance_input`` in between, BIT FOR BIT (generic route on both sides); (ii) the route with the normaliser
+    fused into the first / last kernel agrees with it to bf16 rounding; (iii) every lead time is finite and the state
+    really advances (step k differs from step k - 1)."""
+    from anemoi_models_amd import ops
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.interface import AnemoiModelInterface
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    n_steps = 4
+    graph = build_graph("n320_ico6")
+    n_prog, n_forc = 80, 10
+    n_all = n_prog + n_forc
+    cfg = model_config("GraphTransformer", 1024, 16, 16)
+    cfg["data"] = {"forcing": [f"forc_{i}" for i in range(n_forc)], "diagnostic": [],
+                   "processors": {"normalizer": {"_target_": "anemoi.models.preprocessing.normalizer.InputNormalizer",
+                                                 "config": {"default": "mean-std", "min-max": ["prog_3"],
+                                                            "max": ["prog_4"], "none": ["forc_0"]}}}}
+    cfg["model"]["model"] = {"_target_": "anemoi.models.models.encoder_processor_decoder.AnemoiModelEncProcDec"}
+    gen = torch.Generator().manual_seed(11)
+    mean = (torch.randn(n_all, generator=gen) * 3.0).numpy().astype(np.float32)
+    stdev = (0.5 + torch.rand(n_all, generator=gen) * 2.0).numpy().astype(np.float32)
+    stats = {"mean": mean, "stdev": stdev, "minimum": mean - 3.0 * stdev, "maximum": mean + 3.5 * stdev}
+    idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=0)
+    torch.manual_seed(1234)
+    with torch.device(DEV):
+        iface = AnemoiModelInterface(config=type(cfg)(cfg), graph_data=graph.to(DEV), statistics=stats, data_indices=idx,
+                                     metadata={})
+    with torch.no_grad():
+        for name, p in iface.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    iface = iface.to(DEV).eval()
+    n_grid = graph["data"].num_nodes
+    in_idx = idx.data.input.full.long()
+    z = torch.randn((1, 2, n_grid, n_all), generator=torch.Generator().manual_seed(7))
+    batch = (z * torch.from_numpy(stdev)[in_idx] + torch.from_numpy(mean)[in_idx]).to(DEV)
+    f_in = idx.internal_model.input.forcing.long()
+    f_data = in_idx[f_in]
+    zf = torch.randn((n_steps, 1, n_grid, n_forc), generator=torch.Generator().manual_seed(8))
+    forcings = (zf * torch.from_numpy(stdev)[f_data] + torch.from_numpy(mean)[f_data]).to(DEV)
+
+    monkeypatch.setenv("ANEMOI_AMD_FUSE_NORMALIZER", "0")
+    got = iface.rollout(batch, n_steps, forcings)
+    # the chain, written out: reference predict_step pieces + advance_input on the normalised state
+    cmap = iface._advance_map(batch.device)
+    f_idx = f_in.to(DEV)
+    with torch.no_grad():
+        x = iface.pre_processors(batch, in_place=False)[:, 0:iface.multi_step, None, ...].float().contiguous().clone()
+        chain = []
+        for step in range(n_steps):
+            y_hat = iface.model(x)
+            chain.append(iface.post_processors(y_hat, in_place=False))
+            if step + 1 == n_steps:
+                break
+            full = x[:, -1, 0].clone()
+            full[..., f_idx] = forcings[step].to(full)
+            f_norm = iface.pre_processors(full[:, None], in_place=False)[:, 0][..., f_idx][:, None].contiguous()
+            ops.advance_input(x, y_hat.float().contiguous(), cmap, f_norm)
+        chain = torch.stack(chain)
+    assert got.shape == chain.shape == (n_steps, 1, 1, n_grid, n_prog)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, chain)  # (i)
+    for k in range(1, n_steps):  # (iii)
+        assert float((got[k] - got[k - 1]).abs().max()) > 0
+    monkeypatch.delenv("ANEMOI_AMD_FUSE_NORMALIZER")
+    fused = iface.rollout(batch, n_steps, forcings)  # (ii)
+    errs = [per_variable_rel_err(fused[k], got[k]) for k in range(n_steps)]
+    print("config 4 (N320, 16 blocks, bf16, 4 lead times): fused-normaliser vs generic route, per-variable rel err per "
+          "lead time: " + ", ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) < BF16_BOUND
+
+
+def test_config4_n320_rollout_sharded_state_ranks_sharing_one_gpu(tmp_path):
+    """BASELINE config 4 on the N > 1 route at N320 size (16 blocks, 1024 ch, bf16, 4 lead times), stepped exactly as
+    ``bench.py --rollout 4 --gpus N`` steps it: the state stays SHARDED between the lead times (grid-halo all-to-all-v, no
+    per-step all-gather), against the single-device chain.  Two ranks as processes sharing cuda:0,
+    collectives host-staged over gloo (the test box has one GPU)."""
+    import os
+    import subprocess
+    import sys
+
+    world, steps = 2, 4
+    port = 29400 + (os.getpid() % 200)
+    out = str(tmp_path / "res")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_shared_rollout.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out, "cfg3", str(steps)])
+             for r in range(world)]
+    try:
+        codes = [p.wait(timeout=1500) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    assert codes == [0] * world
+    infos = [torch.load(f"{out}.{r}") for r in range(world)]
+    assert sum(i["own"] for i in infos) == 40962
+    for i in infos:
+        print(f"config 4 sharded state, world {world}: max |sharded - unsharded| {i['err']:.3e} at output scale {i['scale']:.3e}, "
+              f"grid halo {i['grid_halo']} of {i['grid']} rows")
+        assert i["finite"] and i["shape"] == (1, 1, 542080, 80)
+        assert 0 < i["grid_halo"] < i["grid"] // 4
+        assert i["err"] <= BF16_BOUND * max(1.0, i["scale"]), i

@@ -135,6 +135,20 @@ def test_plan_cache_on_disk(tmp_path, monkeypatch):
         p3 = runtime.PlanCache().get(ei, 50, 30, dst_map=relabel)
         assert len(calls) == 3 and torch.equal(p3.col, p1.col)
         assert runtime.load_edge_plan(path, "cpu") is not None
+        # a stale / corrupt but well-formed file must not become out-of-bounds gathers: column beyond the source set,
+        # perm that is no permutation, row pointers that go backwards, a plan for another node count -> rebuilt
+        good = torch.load(path, weights_only=True)
+        for field, bad in (("col", lambda t: t.index_fill(0, torch.tensor([3]), 50)),
+                           ("col", lambda t: t.index_fill(0, torch.tensor([0]), -1)),
+                           ("perm", lambda t: t.index_fill(0, torch.tensor([5]), int(t[6]))),
+                           ("rowptr", lambda t: torch.cat([t[:2], t[1:2] - 1, t[3:]]))):
+            d = dict(good)
+            d[field] = bad(good[field].clone())
+            torch.save(d, path)
+            assert runtime.load_edge_plan(path, "cpu", 50, 30) is None, field
+        torch.save(good, path)
+        assert runtime.load_edge_plan(path, "cpu", 50, 30) is not None
+        assert runtime.load_edge_plan(path, "cpu", 51, 30) is None and runtime.load_edge_plan(path, "cpu", 50, 31) is None
     finally:
         runtime.set_plan_cache_dir(None)
     n = len(os.listdir(tmp_path))
