@@ -6,6 +6,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:  # lab builds of the kernel library (tools/micro/bin/*.so), e.g. the tail-epilogue GEMM for A/B runs
+    _i = sys.argv.index("--lib")
+    from anemoi_models_amd import _lib as _lab_lib
+
+    _lab_lib.LIB_PATH = os.path.abspath(sys.argv[_i + 1])  # ANEMOI_LAB_LIB
+    del sys.argv[_i:_i + 2]
 from anemoi_models_amd import ops  # noqa: E402
 
 SHAPES = [(40962, 4096, 1024), (40962, 1024, 4096), (40962, 1024, 1024), (542080, 4096, 1024),
