@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -69,11 +69,6 @@ SIGNATURES = {
     "anemoi_gt_conv_backward_src": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                             c_int64, c_int, c_int, c_void_p]),
-    "anemoi_gt_edge_attention_tiled_lds_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "anemoi_gt_edge_attention_tiled": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                               c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int64,
-                                               c_int64, c_int, c_int, c_void_p]),
     "anemoi_gt_edge_attention": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int64, c_int64, c_int, c_int, c_void_p]),

@@ -382,14 +382,9 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_kernel(const Edg
 template <typename T, int VEC, int LPH, int UP>
 static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   constexpr int WPB = 4;
-  static const int edges_in_flight = [] {  // tuning knobs (A/B): ANEMOI_AMD_EDGE_U in {2,4,8}, ANEMOI_AMD_EDGE_WGS per CU
-    const char* e = getenv("ANEMOI_AMD_EDGE_U");
-    return e ? atoi(e) : 4;
-  }();
-  static const int wgs_per_cu = [] {
-    const char* e = getenv("ANEMOI_AMD_EDGE_WGS");
-    return e ? atoi(e) : 5;
-  }();
+  // U = 4 edges (8 independent 16-byte gathers per lane) in flight and 5 resident workgroups per CU: the winners of the
+  // round-1 / round-2 sweeps (U in {2, 4, 8}, 2 .. 8 workgroups per CU: +-3 %; profiles/r02_edge_kernels.md)
+  constexpr int wgs_per_cu = 5;
   const int64_t units_per_xcd = ((p.n_dst + 7) / 8) * p.n_slices;
   int64_t bpx = (units_per_xcd + WPB - 1) / WPB;
   if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;  // resident workgroups per CU x 32 CUs per XCD
@@ -398,15 +393,8 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
   // (a register-double-buffered software pipeline across destinations was measured and removed: 0.30 / 1.98 / 0.79 ms
   // against 0.19 / 1.21 / 0.60 ms of this loop on the mesh / decoder / encoder graphs of config 3 -- the second
   // register set costs a wave per SIMD, which hurts more than the overlap helps)
-  if (edges_in_flight == 8)
-    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 8>), dim3((unsigned)(8 * bpx)),
-                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
-  else if (edges_in_flight == 2)
-    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 2>), dim3((unsigned)(8 * bpx)),
-                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
-  else
-    hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 4>), dim3((unsigned)(8 * bpx)),
-                       dim3(64 * WPB), 0, st, p, p.attr, p.rowptr, p.col);
+  hipLaunchKernelGGL((gt_edge_attention_folded_kernel<T, VEC, LPH, UP, 4>), dim3((unsigned)(8 * bpx)), dim3(64 * WPB), 0,
+                     st, p, p.attr, p.rowptr, p.col);
 }
 
 template <typename T, int VEC, int LPH>
@@ -430,330 +418,6 @@ static bool dispatch_folded(const EdgeFoldParams& p, int up, hipStream_t st) {
     case 4: return dispatch_folded_up<T, VEC, 4>(p, up, st);
     case 8: return dispatch_folded_up<T, VEC, 8>(p, up, st);
     case 16: return dispatch_folded_up<T, VEC, 16>(p, up, st);
-    default: return false;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Tiled path: LDS staging of the source rows of a destination tile, persistent and double buffered.
-//
-// The gather loop above pulls every k_j / v_j row slice through the CU's vector-memory path once per EDGE; on the mesh
-// graph a row is wanted by ~8 destinations, most of them neighbours in the (Morton) row order.  Measured on config 3's
-// mesh launch (profiles/r02_edge_kernels.md): the gather kernel's time follows the gathered bytes (texture addresser
-// busy 77 %), not its VALU work, not L2 locality, not the depth of its request chain.  This kernel moves each row slice
-// ONCE per tile:
-//   * tiles of TILE_DST = 64 consecutive destinations; the work list is the tile-major sequence of (tile, head) pairs,
-//     cut into one contiguous chunk per persistent workgroup (one per CU) -- perfectly balanced, and consecutive pairs of
-//     a workgroup share the tile;
-//   * once per tile the tile's CSR slice of tile-local column slots and its edge attributes go to LDS (LDS-DMA);
-//   * per (tile, head) the tile's UNIQUE source rows (k and v head slices, host-built list) and its q rows go to one of
-//     TWO LDS buffers by LDS-DMA (buffer_load ... lds: 16 bytes per lane, no registers): the requests for pair i + 1 are
-//     issued right after the barrier that publishes pair i, so they fly under pair i's arithmetic;
-//   * LPH lanes per destination (64 / LPH destinations per wave) run the gather kernel's online-softmax loop with every
-//     operand in LDS.  Destinations are assigned to the waves' slots in order of falling in-degree (host-built
-//     permutation per tile), so that the destinations that share a wave's loop have about the same trip count.
-// Same arithmetic, summation order and online-softmax batch (U = 4) per destination as the gather kernel: the results are
-// bit-identical.  Measured (profiles/r02_edge_kernels.md): it takes the load off the texture path as intended, but 160 KiB
-// of LDS per CU allow two waves per SIMD, and at that occupancy the loop's VALU stream (issue-bound, ~55 M instructions
-// per mesh launch) alone takes 0.22 ms -- the gather kernel (20 waves per CU) stays the default.
-// ---------------------------------------------------------------------------------------------
-constexpr int TILE_DST = 64;
-
-// LDS regions are sized in whole LDS-DMA instructions (64 lanes x 4 or 16 bytes): the last instruction of a region
-// writes all its lanes (zeros beyond the source array) and must not reach into the next region.
-__host__ __device__ constexpr int tiled_col_bytes(int e_cap) { return (e_cap + 63) / 64 * 256; }
-__host__ __device__ constexpr int tiled_attr_bytes(int e_cap, int up) { return (e_cap * up * 4 + 1023) / 1024 * 1024; }
-
-struct EdgeTileParams {
-  const void* q;
-  const void* k;
-  const void* v;
-  const void* xr;
-  const void* u;
-  void* out;
-  int64_t ldq, ldkv, ldr, ldu, ldo;
-  const float* attr;            // [E, UP] f32, CSR order
-  const int32_t* rowptr;        // [n_dst + 1]
-  const int32_t* tile_src_ptr;  // [n_tiles + 1]
-  const int32_t* tile_src;      // unique source rows of every tile, ascending inside a tile
-  const int32_t* col_local;     // [E] slot of the edge's source in its tile's list
-  const int32_t* tile_order;    // [n_tiles * TILE_DST] destination row of every slot of the tile (falling degree), -1 = none
-  int64_t n_dst, n_src, n_edges;
-  int n_tiles, C, D, H, s_cap, e_cap;
-  float scale;
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, int64_t bytes) {
-  const int64_t lim = bytes < (int64_t)0xffffffffll ? bytes : (int64_t)0xffffffffll;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)lim, 0x00020000);
-}
-
-template <typename T, int VEC, int LPH, int UP>
-__global__ __launch_bounds__(TILE_DST* LPH) void gt_edge_attention_tiled_kernel(const EdgeTileParams p) {
-  using Raw = typename RawVec<T, VEC>::type;
-  constexpr int APL = attrs_per_lane(UP, LPH);
-  constexpr int ROWB = LPH * 16;      // bytes of one head's slice of a row
-  constexpr int GPW = 64 / LPH;       // destinations (or staged rows) per wave instruction
-  constexpr int NW = TILE_DST / GPW;  // waves per workgroup
-  constexpr int ES = (int)sizeof(T);
-  constexpr int U = 4;     // edges per destination and loop trip: the gather kernel's batch, so the results are bit-identical
-  constexpr int MAXG = 8;  // staged row groups per wave: s_cap <= MAXG * NW * GPW = 8 * TILE_DST (launcher)
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* a_lds = smem;                                        // edge attributes of the tile
-  char* c_lds = a_lds + tiled_attr_bytes(p.e_cap, UP);       // tile-local column slots
-  char* b_lds = c_lds + tiled_col_bytes(p.e_cap);            // two buffers: k rows | v rows | q rows
-  const int buf_bytes = (2 * p.s_cap + TILE_DST) * ROWB;
-
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int g = lane / LPH, r = lane % LPH;
-  const int a0 = r * APL;
-  const bool a_own = a0 < UP;
-  const int a_ld = a_own ? a0 : 0;
-  const float amask = a_own ? 1.f : 0.f;
-  const bool has_xr = p.xr != nullptr;
-
-  // this workgroup's contiguous chunk of the tile-major (tile, head) list
-  const int64_t total = (int64_t)p.n_tiles * p.H;
-  const int64_t i0 = total * blockIdx.x / gridDim.x, i1 = total * (blockIdx.x + 1) / gridDim.x;
-  if (i0 >= i1) return;
-
-  // ---- per-tile state
-  int tile = -1, e0 = 0, n_e = 0, n_s = 0;
-  int64_t d0 = 0;
-  int64_t d = 0;       // this lane's destination row (slot wid * GPW + g of the tile's order)
-  bool valid = false;
-  int eb = 0, ee = 0;  // its edges, tile-local
-  int srcoff[MAXG];    // byte offsets of the source rows this lane stages (row groups wid, wid + NW, ...)
-  int qoff = 0;
-
-  auto tile_setup = [&](int t) {  // scalars + this lane's rows; then the tile's columns and attributes go to LDS
-    tile = t;
-    d0 = (int64_t)t * TILE_DST;
-    const int64_t d_end = d0 + TILE_DST < p.n_dst ? d0 + TILE_DST : p.n_dst;
-    e0 = p.rowptr[d0];
-    n_e = p.rowptr[d_end] - e0;
-    const int sp0 = p.tile_src_ptr[t];
-    n_s = p.tile_src_ptr[t + 1] - sp0;
-    const int slot_d = p.tile_order[(int64_t)t * TILE_DST + wid * GPW + g];
-    valid = slot_d >= 0;
-    d = valid ? (int64_t)slot_d : d0;
-    eb = p.rowptr[d] - e0;
-    ee = valid ? p.rowptr[d + 1] - e0 : eb;
-    qoff = (int)(d - d0) * (int)(p.ldq * ES) + r * 16;
-#pragma unroll
-    for (int jj = 0; jj < MAXG; ++jj) {
-      const int row = (wid + jj * NW) * GPW + g;
-      const int src = p.tile_src[sp0 + (row < n_s ? row : (n_s > 0 ? n_s - 1 : 0))];
-      srcoff[jj] = (int)((uint32_t)src * (uint32_t)(p.ldkv * ES) + (uint32_t)(r * 16));
-    }
-    const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.col_local, p.n_edges * 4);
-    for (int j = wid; j * 64 < n_e; j += NW)  // 4 bytes per lane (beyond the array: zeros)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (lds_ptr_t)(c_lds + j * 256), 4, (e0 + j * 64 + lane) * 4, 0, 0, 0);
-    const __amdgpu_buffer_rsrc_t ars = tile_rsrc(p.attr, p.n_edges * (int64_t)(UP * 4));
-    constexpr int CH = UP / 4;  // 16-byte chunks per edge
-    for (int j = wid; j * 64 < n_e * CH; j += NW)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_ptr_t)(a_lds + j * 1024), 16,
-                                               (int)(((uint32_t)e0 * CH + (uint32_t)(j * 64 + lane)) * 16u), 0, 0, 0);
-  };
-
-  auto stage_head = [&](int head, int buf) {  // k / v rows of the tile's sources and the tile's q rows, head slice
-    char* kb_ = b_lds + buf * buf_bytes;
-    char* vb_ = kb_ + p.s_cap * ROWB;
-    char* qb_ = vb_ + p.s_cap * ROWB;
-    const __amdgpu_buffer_rsrc_t krs = tile_rsrc(static_cast<const T*>(p.k) + head * p.D, p.n_src * p.ldkv * ES);
-    const __amdgpu_buffer_rsrc_t vrs = tile_rsrc(static_cast<const T*>(p.v) + head * p.D, p.n_src * p.ldkv * ES);
-    const __amdgpu_buffer_rsrc_t qrs =
-        tile_rsrc(static_cast<const T*>(p.q) + d0 * p.ldq + head * p.D, (int64_t)TILE_DST * p.ldq * ES);
-#pragma unroll
-    for (int jj = 0; jj < MAXG; ++jj) {
-      const int j = wid + jj * NW;
-      if (j * GPW < n_s) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr_t)(kb_ + j * 1024), 16, srcoff[jj], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr_t)(vb_ + j * 1024), 16, srcoff[jj], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_ptr_t)(qb_ + wid * 1024), 16, qoff, 0, 0, 2);
-  };
-
-  RawWords<T, VEC> xr_cur, xr_nxt;
-  RawWords<T, APL> u_cur, u_nxt;
-  auto load_streams = [&](int head, RawWords<T, VEC>& xr_, RawWords<T, APL>& u_) {
-    if (has_xr) xr_.load(static_cast<const char*>(p.xr) + d * p.ldr * ES, (uint32_t)((head * p.D + r * VEC) * ES), true);
-    u_.load(static_cast<const char*>(p.u) + d * p.ldu * ES, (uint32_t)((head * UP + a_ld) * ES), false);
-  };
-
-  // ---- prologue: first pair of the chunk
-  tile_setup((int)(i0 / p.H));
-  stage_head((int)(i0 % p.H), 0);
-  load_streams((int)(i0 % p.H), xr_cur, u_cur);
-
-  for (int64_t i = i0; i < i1; ++i) {
-    const int head = (int)(i % p.H);
-    const int buf = (int)((i - i0) & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of pair i has landed (and its older stores)
-    __syncthreads();                                   // ... everyone's; everyone is done with pair i - 1's buffer
-    // ---- requests for pair i + 1 (same tile: only the head changes) fly under pair i's arithmetic
-    const bool more = i + 1 < i1;
-    const bool same_tile = more && (int)((i + 1) / p.H) == tile;
-    if (same_tile) {
-      stage_head(head + 1, buf ^ 1);
-      load_streams(head + 1, xr_nxt, u_nxt);
-    }
-
-    // ---- compute pair i out of LDS
-    const char* kb_ = b_lds + buf * buf_bytes;
-    const char* vb_ = kb_ + p.s_cap * ROWB;
-    const char* qb_ = vb_ + p.s_cap * ROWB;
-    QK<T, VEC> qk;
-    float u[APL];
-    {
-      float qf[VEC];
-      const Raw qr = *reinterpret_cast<const Raw*>(qb_ + (wid * GPW + g) * ROWB + r * 16);
-      unpack<T, VEC>(qr, qf);
-      qk.set(qf);
-      u_cur.get(u);
-#pragma unroll
-      for (int a = 0; a < APL; ++a) u[a] *= amask;
-    }
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    constexpr int VP = (VEC + 1) / 2;
-    f32x2_t acc[VP];
-    float tacc[APL];
-#pragma unroll
-    for (int a = 0; a < VP; ++a) acc[a] = f32x2_t{0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    const int* cl = reinterpret_cast<const int*>(c_lds);
-    const float* al = reinterpret_cast<const float*>(a_lds) + a_ld;
-    for (int e = eb; __any(e < ee); e += U) {
-      Raw kr[U], vr[U];
-      float at[U][APL];
-      bool on[U];
-#pragma unroll
-      for (int uu = 0; uu < U; ++uu) {
-        on[uu] = e + uu < ee;
-        const int ei = on[uu] ? e + uu : 0;
-        const int slot = cl[ei];
-        kr[uu] = *reinterpret_cast<const Raw*>(kb_ + slot * ROWB + r * 16);
-        vr[uu] = *reinterpret_cast<const Raw*>(vb_ + slot * ROWB + r * 16);
-        VecIO<float, APL>::load(al + ei * UP, at[uu]);
-      }
-      float s_[U];
-      float mb = m;
-#pragma unroll
-      for (int uu = 0; uu < U; ++uu) {
-        float t = qk.dot(kr[uu]);
-#pragma unroll
-        for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[uu][a], t);
-        s_[uu] = on[uu] ? group_sum<LPH>(t) * p.scale : -INFINITY;
-        mb = fmaxf(mb, s_[uu]);
-      }
-      const float corr = m == mb ? 1.f : __expf(m - mb);  // (m == mb == -inf: nothing seen yet, nothing to rescale)
-      l *= corr;
-#pragma unroll
-      for (int a = 0; a < VP; ++a) acc[a] *= corr;
-#pragma unroll
-      for (int a = 0; a < APL; ++a) tacc[a] *= corr;
-#pragma unroll
-      for (int uu = 0; uu < U; ++uu) {
-        const float pe = on[uu] ? __expf(s_[uu] - mb) : 0.f;
-        l += pe;
-        float vv[VEC];
-        unpack<T, VEC>(vr[uu], vv);
-#pragma unroll
-        for (int a = 0; a < VP; ++a)
-          acc[a] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * a], 2 * a + 1 < VEC ? vv[2 * a + 1] : 0.f},
-                                             acc[a]);
-#pragma unroll
-        for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
-      }
-      m = mb;
-    }
-    const float inv = 1.0f / (l + 1e-16f);
-    float o[VEC];
-#pragma unroll
-    for (int a = 0; a < VEC; ++a) o[a] = acc[a >> 1][a & 1] * inv;
-    if (has_xr) {
-      float rr[VEC];
-      xr_cur.get(rr);
-#pragma unroll
-      for (int a = 0; a < VEC; ++a) o[a] += rr[a];
-    }
-    if (valid) {
-      char* on_ = static_cast<char*>(p.out) + d * p.ldo * ES;
-      store_stream<T, VEC>(reinterpret_cast<T*>(on_ + (head * p.D + r * VEC) * ES), o);
-      if (a_own) {
-        float t4[APL];
-#pragma unroll
-        for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
-        VecIO<T, APL>::store(reinterpret_cast<T*>(on_ + (p.C + head * UP + a0) * ES), t4);
-      }
-    }
-    if (same_tile) {
-      xr_cur = xr_nxt;
-      u_cur = u_nxt;
-    } else if (more) {  // tile boundary inside the chunk (at most a few per workgroup): restage from scratch
-      __syncthreads();  // nobody reads the old tile's columns / attributes any more
-      tile_setup((int)((i + 1) / p.H));
-      stage_head((int)((i + 1) % p.H), buf ^ 1);
-      load_streams((int)((i + 1) % p.H), xr_cur, u_cur);
-    }
-  }
-}
-
-static inline size_t tiled_lds_bytes(int lph, int up, int s_cap, int e_cap) {
-  return (size_t)tiled_attr_bytes(e_cap, up) + (size_t)tiled_col_bytes(e_cap) +
-         (size_t)2 * ((size_t)2 * s_cap + TILE_DST) * lph * 16;
-}
-
-template <typename T, int VEC, int LPH, int UP>
-static bool launch_tiled(const EdgeTileParams& p, hipStream_t st) {
-  const size_t lds = tiled_lds_bytes(LPH, UP, p.s_cap, p.e_cap);
-  if (lds > 160 * 1024 || p.s_cap > 8 * TILE_DST) return false;
-  auto kern = gt_edge_attention_tiled_kernel<T, VEC, LPH, UP>;
-  static PerDeviceOnce raised;  // per instantiation
-  const int raise_dev = raised.pending();
-  if (raise_dev >= 0) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return false;
-    raised.done(raise_dev);
-  }
-  // persistent: one workgroup per CU when LDS allows only one, else as many as fit (the chunks get shorter)
-  const int64_t total = (int64_t)p.n_tiles * p.H;
-  int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)lds;
-  const int64_t by_threads = 2048 / (TILE_DST * LPH);
-  if (per_cu > by_threads) per_cu = by_threads;
-  if (per_cu < 1) per_cu = 1;
-  int64_t blocks = 256 * per_cu;
-  if (blocks > total) blocks = total;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TILE_DST * LPH), lds, st, p);
-  return true;
-}
-
-template <typename T, int VEC, int LPH>
-static bool dispatch_tiled_up(const EdgeTileParams& p, int up, hipStream_t st) {
-  switch (up) {
-    case 4: return launch_tiled<T, VEC, LPH, 4>(p, st);
-    case 8: return launch_tiled<T, VEC, LPH, 8>(p, st);
-    case 12: return launch_tiled<T, VEC, LPH, 12>(p, st);
-    case 16: return launch_tiled<T, VEC, LPH, 16>(p, st);
-    default: return false;
-  }
-}
-
-template <typename T>
-static bool dispatch_tiled(const EdgeTileParams& p, int up, hipStream_t st) {
-  constexpr int VEC = 16 / sizeof(T);
-  if (p.D % VEC != 0 || p.C % VEC != 0) return false;
-  switch (p.D / VEC) {
-    case 2: return dispatch_tiled_up<T, VEC, 2>(p, up, st);
-    case 4: return dispatch_tiled_up<T, VEC, 4>(p, up, st);
-    case 8: return dispatch_tiled_up<T, VEC, 8>(p, up, st);
-    case 16: return dispatch_tiled_up<T, VEC, 16>(p, up, st);
     default: return false;
   }
 }
@@ -1102,11 +766,7 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
   p.n_dst = n_dst; p.C = C; p.D = C / H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
   p.scale = 1.0f / sqrtf((float)(C / H));
-  static const int stream_hint = [] {
-    const char* e = getenv("ANEMOI_AMD_EDGE_NT");  // A/B knob; measured -3 % on all three graphs of config 3
-    return e ? atoi(e) : 1;
-  }();
-  p.stream_hint = stream_hint;
+  p.stream_hint = 1;  // nontemporal q / x_r / out (streamed once): -3 % on all three graphs of config 3
   bool ok = false;
   if (dtype == ANEMOI_F32) ok = dispatch_folded<float>(p, up, as_stream(stream));
   else if (dtype == ANEMOI_BF16) ok = dispatch_folded<bf16_t>(p, up, as_stream(stream));
@@ -1115,65 +775,4 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
                  "anemoi_gt_edge_attention_folded: unsupported shape (D=%d, UP=%d); use anemoi_gt_edge_attention", C / H,
                  up);
   return check_launch("anemoi_gt_edge_attention_folded");
-}
-
-extern "C" int64_t anemoi_gt_edge_attention_tiled_lds_bytes(int dtype, int C, int H, int up, int s_cap, int e_cap) {
-  if (C <= 0 || H <= 0 || C % H != 0 || up <= 0 || s_cap < 0 || e_cap < 0) return -1;
-  const int vec = dtype == ANEMOI_BF16 ? 8 : 4;
-  const int d = C / H;
-  if (d % vec != 0) return -1;
-  const int lph = d / vec;
-  if (lph != 2 && lph != 4 && lph != 8 && lph != 16) return -1;
-  if (up != 4 && up != 8 && up != 12 && up != 16) return -1;
-  return (int64_t)tiled_lds_bytes(lph, up, s_cap, e_cap);
-}
-
-extern "C" int anemoi_gt_edge_attention_tiled(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
-                                              int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
-                                              const float* edge_attr, int up, const int32_t* rowptr,
-                                              const int32_t* tile_src_ptr, const int32_t* tile_src,
-                                              const int32_t* col_local, const int32_t* tile_order, int s_cap,
-                                              int e_cap, void* out, int64_t ldo, int64_t n_dst, int64_t n_src,
-                                              int64_t n_edges, int C, int H, anemoi_stream_t stream) {
-  ANEMOI_REQUIRE(q && k && v && u && out && rowptr && tile_src_ptr && tile_order, ANEMOI_ERR_INVALID,
-                 "anemoi_gt_edge_attention_tiled: null pointer");
-  ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
-                 "anemoi_gt_edge_attention_tiled: C=%d not divisible by H=%d", C, H);
-  ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
-                     (x_r == nullptr || ldr >= C),
-                 ANEMOI_ERR_INVALID, "anemoi_gt_edge_attention_tiled: leading dimension too small");
-  ANEMOI_REQUIRE(n_dst >= 0 && n_src >= 0 && n_edges >= 0 && s_cap >= 0 && e_cap >= 0, ANEMOI_ERR_INVALID,
-                 "anemoi_gt_edge_attention_tiled: negative size");
-  if (n_dst == 0) return ANEMOI_OK;
-  ANEMOI_REQUIRE(n_edges == 0 || (tile_src && col_local && edge_attr), ANEMOI_ERR_INVALID,
-                 "anemoi_gt_edge_attention_tiled: null edge arrays");
-  const int esz = dtype == ANEMOI_BF16 ? 2 : 4;
-  const int vec = 16 / esz;
-  const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
-                       ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
-                       (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % vec == 0)) && ldq % vec == 0 &&
-                       ldkv % vec == 0 && ldu % vec == 0 && ldo % vec == 0 && ((uintptr_t)edge_attr % 16 == 0) &&
-                       ((int64_t)up * esz) % 8 == 0 && ((int64_t)C * esz) % 16 == 0 && s_cap % 32 == 0 && e_cap % 4 == 0;
-  ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED,
-                 "anemoi_gt_edge_attention_tiled: operands must be 16-byte aligned, s_cap %% 32 == 0, e_cap %% 4 == 0");
-  // 32-bit byte offsets inside the buffer descriptors of k / v / q
-  ANEMOI_REQUIRE(n_src * ldkv * esz < ((int64_t)1 << 31) && (int64_t)TILE_DST * ldq * esz < ((int64_t)1 << 31),
-                 ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_tiled: k / v larger than 2 GiB");
-  EdgeTileParams p;
-  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out;
-  p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
-  p.attr = edge_attr; p.rowptr = rowptr; p.tile_src_ptr = tile_src_ptr; p.tile_src = tile_src; p.col_local = col_local;
-  p.tile_order = tile_order;
-  p.n_dst = n_dst; p.n_src = n_src; p.n_edges = n_edges;
-  p.n_tiles = (int)((n_dst + TILE_DST - 1) / TILE_DST);
-  p.C = C; p.D = C / H; p.H = H; p.s_cap = s_cap; p.e_cap = e_cap;
-  p.scale = 1.0f / sqrtf((float)(C / H));
-  bool ok = false;
-  if (dtype == ANEMOI_F32) ok = dispatch_tiled<float>(p, up, as_stream(stream));
-  else if (dtype == ANEMOI_BF16) ok = dispatch_tiled<bf16_t>(p, up, as_stream(stream));
-  else return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_tiled: dtype %d", dtype);
-  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED,
-                 "anemoi_gt_edge_attention_tiled: unsupported shape (D=%d, UP=%d, LDS for s_cap=%d e_cap=%d)", C / H, up,
-                 s_cap, e_cap);
-  return check_launch("anemoi_gt_edge_attention_tiled");
 }

@@ -1034,8 +1034,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     int64_t w4_blocks = blocks;
     // 192-row tiles for small problems: a tile stages 7/8 of the bytes of a 256-row one (the loop is bound by staging),
     // so they pay when they do not add a round -- or fill more of the chip inside one (measured in profiles/r02_gemm_small_m.txt)
-    static const bool mh6_on = [] { const char* e = getenv("ANEMOI_AMD_GEMM_MH6"); return e == nullptr || atoi(e) != 0; }();
-    if (mh6_on && !batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
+    if (!batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
       const int64_t mt6 = (M + 191) / 192, r8 = (mt * nt + max_blocks - 1) / max_blocks,
                     r6 = (mt6 * nt + max_blocks - 1) / max_blocks;
       if (r6 * 0.875 < r8 * 0.97) {

@@ -50,19 +50,11 @@ def _as_compute(x: Tensor, dtype: torch.dtype) -> Tensor:
 
 def folded_edge_phase(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr_csr: Tensor, plan,
                       num_heads: int, up: int, ld_out: Optional[int] = None) -> Tensor:
-    """The folded edge phase on the kernel that suits the edge set: source rows staged per destination tile in LDS
-    (``anemoi_gt_edge_attention_tiled``) where rows are shared by neighbouring destinations -- the mesh processor graph
-    --, the gather kernel (``anemoi_gt_edge_attention_folded``) otherwise.  Decided once per plan / shape."""
-    key = ("edge_tiles", q.dtype, q.shape[1], num_heads, up)
-    choice = plan.__dict__.setdefault("_kernel_choice", {})
-    if key not in choice:
-        choice[key] = runtime.use_edge_tiles(plan, q.dtype, q.shape[1], num_heads, up)
-    tiles = choice[key]
-    if tiles is not None:
-        return ops.gt_edge_attention_tiled(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, tiles, num_heads, up,
-                                           ld_out=ld_out)
+    """The folded edge phase (``anemoi_gt_edge_attention_folded``: one fused gather -> score -> segment softmax -> weighted
+    sum -> ``+ x_r`` pass over the destination-sorted CSR)."""
     return ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, plan.col, num_heads, up,
                                         ld_out=ld_out)
+
 
 class EmbeddedRows:
     """Node rows ``h = emb(x)`` handed to a mapper block as the raw features they are embedded from.

@@ -12,7 +12,6 @@ reference (``_run_mapper``) has no forward-pass effect and is not needed here.
 from __future__ import annotations
 
 import logging
-import os
 from typing import Optional
 
 import torch
@@ -137,7 +136,7 @@ class AnemoiModelEncProcDec(nn.Module):
         key = ("mesh_order", str(device))
         if key not in self._idx_cache:
             latlons = self.node_attributes.latlons(self._graph_name_hidden)
-            if os.environ.get("ANEMOI_AMD_MESH_REORDER", "1") == "0":
+            if not getattr(self, "mesh_locality_order", True):  # tests: the graph's own node order (an invariance check)
                 order = torch.arange(latlons.shape[0], device=device)
             else:
                 order = runtime.locality_order(latlons).to(device)

@@ -344,39 +344,6 @@ def gt_conv(q: Tensor, k: Tensor, v: Tensor, edges_csr: Tensor, rowptr: Tensor, 
     return out
 
 
-def gt_edge_attention_tiled(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
-                            rowptr: Tensor, tiles, num_heads: int, up: int, out: Optional[Tensor] = None,
-                            ld_out: Optional[int] = None) -> Tensor:
-    """:func:`gt_edge_attention_folded` with the source rows of every 64-destination tile staged in LDS
-    (``anemoi_gt_edge_attention_tiled``).  ``tiles`` = ``runtime.edge_tiles(plan)`` (built once per graph)."""
-    _dev(q, k, v, x_r, u, edge_attr, rowptr, out, tiles.tile_src_ptr, tiles.tile_src, tiles.col_local, tiles.tile_order)
-    n_dst, c = _rows(q).shape
-    if _ld(_rows(k)) != _ld(_rows(v)):
-        raise ValueError("gt_edge_attention_tiled: k and v must share their leading dimension")
-    width = c + num_heads * up
-    ld = width if ld_out is None else ld_out
-    if out is None:
-        out = torch.empty((n_dst, ld), dtype=q.dtype, device=q.device)
-        if ld > width:
-            out[:, width:].zero_()
-    n_edges = tiles.col_local.shape[0]
-    if rowptr.dtype != torch.int32 or rowptr.shape[0] != n_dst + 1 or edge_attr.shape[0] != n_edges or \
-            (n_edges > 0 and (edge_attr.shape[1] != up or not edge_attr.is_contiguous())):
-        raise ValueError("gt_edge_attention_tiled: rowptr int32 [n_dst + 1], edge_attr contiguous [E, up]")
-    if n_edges == 0:
-        edge_attr = torch.zeros((1, up), dtype=torch.float32, device=q.device)
-    alg_bytes = (2 * n_dst + 2 * k.shape[0]) * c * q.element_size() + n_edges * 52 + (n_dst + 1) * 4
-    with _Timed("gt_edge_attention", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=n_edges):
-        st = _lib.load().anemoi_gt_edge_attention_tiled(
-            dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
-            0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
-            rowptr.data_ptr(), tiles.tile_src_ptr.data_ptr(), tiles.tile_src.data_ptr(), tiles.col_local.data_ptr(),
-            tiles.tile_order.data_ptr(), tiles.s_cap, tiles.e_cap, out.data_ptr(), _ld(_rows(out)), n_dst, k.shape[0], n_edges, c, num_heads,
-            _stream())
-    _lib.check(st, "anemoi_gt_edge_attention_tiled")
-    return out
-
-
 def gather_add_act(t: Tensor, p_dst: Tensor, p_src: Tensor, dst: Tensor, src: Tensor, act: str = "Identity",
                    out: Optional[Tensor] = None) -> Tensor:
     """``act(t[e] + p_dst[dst[e]] + p_src[src[e]])`` per edge row (first edge-MLP layer of the GNN block)."""
@@ -721,13 +688,14 @@ def layer_norm_backward(x: Tensor, stats: Tensor, gamma: Tensor, dy: Tensor):
     return dx, dgamma, dbeta
 
 
-def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False):
+def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False, transposed_route: bool = False):
     """``dW [N, k] = dpre^T @ x[:, :k]`` in f32 (``dpre [M, N]``, ``x [M, >= k]`` in the compute dtype): the reduction
     over the M rows is cut into chunks -- chunked transposes, one batched GEMM on the 128 x 128 kernel, a deterministic
     sum of the partial results -- so that a small ``[N, k]`` result still fills the chip (a 1024 x 192 gradient over
     542 080 rows took 7 ms on 16 workgroups without the split).  ``want_bias``: returns ``(dW, db)`` with
     ``db = dpre.sum(0)`` (f32); for bf16 the column sums come out of the transpose of ``dpre`` (per-tile partials), not
-    out of a second pass over it."""
+    out of a second pass over it.  ``transposed_route=True`` (tests, tools/dw_bench.py) takes the transposes + NT route even
+    where the TN kernel applies (bf16, 16-byte aligned operands, M >= 128), which otherwise runs."""
     _dev(dpre, x)
     m, n = _rows(dpre).shape
     kmul = k_multiple(dpre.dtype)
@@ -736,7 +704,7 @@ def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False):
     fast = dpre.dtype == torch.bfloat16 and k % 8 == 0
     xr = _rows(x)
     if (fast and n % 8 == 0 and _ld(dpre) % 8 == 0 and _ld(xr) % 8 == 0 and dpre.data_ptr() % 16 == 0
-            and xr.data_ptr() % 16 == 0 and m >= 128 and os.environ.get("ANEMOI_AMD_DW_TN", "1") != "0"):
+            and xr.data_ptr() % 16 == 0 and m >= 128 and not transposed_route):
         # no transposed copies: the TN kernel reads dpre and x as they lie (ds_read_b64_tr_b16 fragments), f32 partials
         tiles = ((n + 255) // 256) * ((k + 255) // 256)
         chunks = max(1, min(256 // tiles if tiles <= 256 else 1, m // 2048))

@@ -103,96 +103,6 @@ def build_edge_plan(edge_index: Tensor, n_src: int, n_dst: int) -> EdgePlan:
                     n_dst)
 
 
-TILE_DST = 64  # destinations per tile of the LDS-staged edge kernel (csrc/edge_attention.hip: TILE_DST)
-
-
-@dataclass
-class EdgeTiles:
-    """Per-tile unique source lists of a destination-sorted plan (``anemoi_gt_edge_attention_tiled``)."""
-
-    tile_src_ptr: Tensor  # int32 [n_tiles + 1]
-    tile_src: Tensor  # int32 [sum of unique sources]
-    col_local: Tensor  # int32 [E]: slot of CSR edge e's source in its tile's list
-    tile_order: Tensor  # int32 [n_tiles * TILE_DST]: destination row per slot of the tile, falling in-degree, -1 = empty
-    s_cap: int  # LDS rows per tile (max unique sources, rounded up to 32)
-    e_cap: int  # LDS edge slots per tile (max edges, rounded up to 4)
-    reuse: float  # edges per unique (tile, source) pair: how many gathers one staged row replaces
-
-
-def edge_tiles(plan: EdgePlan) -> EdgeTiles:
-    """Tiling of ``plan`` for the LDS-staged edge kernel, built once per plan (torch ops on the plan's device): tiles of
-    ``TILE_DST`` consecutive destination rows; per tile the ascending unique source rows; per edge its slot."""
-    cached = getattr(plan, "_tiles", None)
-    if cached is not None:
-        return cached
-    dev = plan.rowptr.device
-    n_tiles = (plan.n_dst + TILE_DST - 1) // TILE_DST
-    e = plan.num_edges
-    if e == 0:
-        tiles = EdgeTiles(torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev),
-                          torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
-                          _tile_order(plan, n_tiles), 32, 4, 0.0)
-        plan._tiles = tiles
-        return tiles
-    tile = plan.dst.long() // TILE_DST
-    key = tile * plan.n_src + plan.col.long()
-    uniq, inverse = torch.unique(key, return_inverse=True)  # sorted: tile-major, source-ascending
-    u_tile = uniq // plan.n_src
-    counts = torch.bincount(u_tile, minlength=n_tiles)
-    ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=ptr[1:])
-    col_local = inverse - ptr[tile]
-    bounds = (torch.arange(0, n_tiles + 1, device=dev) * TILE_DST).clamp_(max=plan.n_dst)
-    e_per_tile = plan.rowptr.long()[bounds].diff()
-    tiles = EdgeTiles(ptr.to(torch.int32), (uniq % plan.n_src).to(torch.int32).contiguous(),
-                      col_local.to(torch.int32).contiguous(), _tile_order(plan, n_tiles),
-                      ops.round_up(int(counts.max()), 32),
-                      ops.round_up(int(e_per_tile.max()), 4), float(e) / float(uniq.numel()))
-    plan._tiles = tiles
-    return tiles
-
-
-def _tile_order(plan: EdgePlan, n_tiles: int) -> Tensor:
-    """Per tile the destination rows sorted by falling in-degree (stable), padded with -1: the slot -> row map of the
-    LDS-staged kernel (64 / LPH consecutive slots share a wave and its loop trip count)."""
-    dev = plan.rowptr.device
-    deg = torch.full((n_tiles * TILE_DST,), -1, dtype=torch.int64, device=dev)
-    deg[: plan.n_dst] = plan.rowptr[1:].long() - plan.rowptr[:-1].long()
-    order = torch.sort(deg.view(n_tiles, TILE_DST), dim=1, descending=True, stable=True).indices
-    rows = order + torch.arange(n_tiles, device=dev)[:, None] * TILE_DST
-    rows = torch.where(rows < plan.n_dst, rows, torch.full_like(rows, -1))
-    return rows.reshape(-1).to(torch.int32).contiguous()
-
-
-def use_edge_tiles(plan: EdgePlan, dtype: torch.dtype, channels: int, num_heads: int, up: int) -> Optional[EdgeTiles]:
-    """The tiling when the LDS-staged kernel should run this edge set, else ``None`` (-> the gather kernel).
-
-    OPT-IN (``ANEMOI_AMD_EDGE_TILED=1``: where the heuristic below says it can pay; ``=force``: wherever it fits LDS).
-    Measured on config 3's mesh graph (profiles/r02_edge_kernels.md): the staged kernel takes the load off the texture
-    path as intended (TA busy 19 % against 77 %, every row slice moved once per tile) but runs 0.26 ms against the
-    gather kernel's 0.15 ms: 160 KiB of LDS allow two waves per SIMD, and at that occupancy its loop's VALU stream is
-    issue-bound.  It stays in the library, tested and bit-identical to the gather kernel, as the base for a leaner loop.
-
-    Heuristic: staging can pay when a staged row replaces several gathers AND the per-head re-read of the tile's edge
-    attributes stays small next to it: in-degree >= 5 and >= 2.5 edges per unique (tile, source) pair -- the mesh
-    processor graph (8 / 3.0); not the decoder (in-degree 3) nor the encoder (1.3 edges per unique source)."""
-    mode = os.environ.get("ANEMOI_AMD_EDGE_TILED", "0")
-    if mode == "0" or plan.num_edges == 0 or plan.n_dst == 0:
-        return None
-    from . import _lib
-
-    if mode != "force" and plan.num_edges < 5 * plan.n_dst:
-        return None
-    tiles = edge_tiles(plan)
-    if mode != "force" and tiles.reuse < 2.5:
-        return None
-    need = _lib.load().anemoi_gt_edge_attention_tiled_lds_bytes(ops.dtype_code(dtype), channels, num_heads, up,
-                                                                tiles.s_cap, tiles.e_cap)
-    if need < 0 or need > 160 * 1024:
-        return None
-    return tiles
-
-
 _PLAN_DIR: Optional[str] = None
 
 

@@ -188,31 +188,6 @@ int anemoi_gt_conv_backward_src(int dtype, const void* q, int64_t ldq, const voi
                                 int64_t n_src, int C, int H, anemoi_stream_t stream);
 
 /*
- * The folded edge phase with LDS staging of the source rows (same inputs / outputs as anemoi_gt_edge_attention_folded,
- * same reference lines: layers/conv.py:98-142 + PyG propagate / softmax / scatter): destinations are cut into tiles of 64
- * consecutive rows; persistent workgroups walk the tile-major (tile, head) list, copy the tile's UNIQUE source rows
- * k_j / v_j (head slice) into one of two LDS buffers while the previous pair is computed, and run the per-destination
- * online softmax out of LDS.  Pays off when a source row feeds several destinations of a tile (the mesh graph: ~3.6
- * gathers per unique row and tile).  The tiling is built by the host once per graph:
- *   tile_src_ptr int32 [n_tiles + 1], tile_src int32 [tile_src_ptr[n_tiles]]: per tile the ascending list of source
- *                                      rows its edges read;
- *   col_local    int32 [E]:            for CSR slot e the position of its source row in its tile's list;
- *   tile_order   int32 [n_tiles * 64]: destination row of every slot of a tile, in order of falling in-degree (the
- *                                      destinations that share a wave get similar trip counts), -1 = empty slot;
- *   s_cap  >= max unique sources of a tile (multiple of 32, <= 512), e_cap >= max edges of a tile (multiple of 4).
- * n_tiles = ceil(n_dst / 64).  Returns ANEMOI_ERR_UNSUPPORTED when the tile does not fit LDS (see
- * anemoi_gt_edge_attention_tiled_lds_bytes: bytes of LDS per workgroup, -1 for unsupported head sizes; <= 163840) or an
- * operand exceeds 4 GiB; the caller then uses anemoi_gt_edge_attention_folded.
- */
-int64_t anemoi_gt_edge_attention_tiled_lds_bytes(int dtype, int C, int H, int up, int s_cap, int e_cap);
-int anemoi_gt_edge_attention_tiled(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
-                                   const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
-                                   int up, const int32_t* rowptr, const int32_t* tile_src_ptr, const int32_t* tile_src,
-                                   const int32_t* col_local, const int32_t* tile_order, int s_cap, int e_cap, void* out,
-                                   int64_t ldo, int64_t n_dst, int64_t n_src, int64_t n_edges, int C, int H,
-                                   anemoi_stream_t stream);
-
-/*
  * Input assembly (I/O glue K9): rows (b, ens, g) of
  *   out = [ x[b, 0..T-1, ens, g, 0..V-1] (time-major) | latlons[g, 0:n_ll] | trainable[g, 0:n_tr] | 0-pad ]
  * x is f32 [B, T, Ens, G, V] contiguous; out is `dtype` with leading dimension ldo >= T*V + n_ll + n_tr.

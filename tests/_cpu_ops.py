@@ -109,17 +109,6 @@ def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads, x_r=None, lse=None):
     return (out if x_r is None else out + x_r.float()).to(q.dtype)
 
 
-def gt_edge_attention_tiled(q, k, v, x_r, u, edge_attr, rowptr, tiles, num_heads, up, out=None, ld_out=None):
-    """CPU stand-in of anemoi_gt_edge_attention_tiled: the source of every CSR slot is rebuilt from the TILING alone
-    (tile list + local slot), so the host-logic tests exercise runtime.edge_tiles as well."""
-    from anemoi_models_amd.runtime import TILE_DST
-
-    n_dst = q.shape[0]
-    dst = torch.repeat_interleave(torch.arange(n_dst), (rowptr[1:] - rowptr[:-1]).long())
-    col = tiles.tile_src.long()[tiles.tile_src_ptr.long()[dst // TILE_DST] + tiles.col_local.long()]
-    return gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, rowptr, col, num_heads, up, out=out, ld_out=ld_out)
-
-
 def gt_edge_attention(q, k, v, x_r, edge_attr, edge_dim, w_edge, b_edge, rowptr, col, num_heads, out=None):
     n_dst, c = q.shape
     d = c // num_heads
@@ -245,7 +234,7 @@ def add(a, b, out=None):
 def install(monkeypatch):
     import anemoi_models_amd.ops as ops
 
-    for name in ("layer_norm", "layer_norm_with_stats", "row_stats", "linear", "linear_dual", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded", "gt_edge_attention_tiled",
+    for name in ("layer_norm", "layer_norm_with_stats", "row_stats", "linear", "linear_dual", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
                  "gt_conv", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                  "prognostic_residual", "finalize_output", "bound_output", "advance_input", "convert_pad", "add", "act_forward"):
         monkeypatch.setattr(ops, name, globals()[name])

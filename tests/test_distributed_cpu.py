@@ -36,7 +36,7 @@ def _worker(rank, world, port, result_file, processor="GraphTransformer", dtype=
         from anemoi_models_amd.utils.presets import model_config
 
         for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention",
-                     "gt_edge_attention_folded", "gt_edge_attention_tiled", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
+                     "gt_edge_attention_folded", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                      "prognostic_residual", "finalize_output", "convert_pad", "add", "act_forward"):
             setattr(ops, name, getattr(_cpu_ops, name))
         mappers = "GraphTransformer"
@@ -139,7 +139,7 @@ def _rollout_worker(rank, world, port, result_file):
         from test_host_logic import build_interface
 
         for name in ("layer_norm", "row_stats", "linear", "edge_attr_csr", "gt_edge_attention", "gt_edge_attention_folded",
-                     "gt_edge_attention_tiled", "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
+                     "gather_add_act", "segment_sum", "mhsa", "assemble_nodes",
                      "prognostic_residual", "finalize_output", "bound_output", "advance_input", "convert_pad", "add",
                      "act_forward"):
             setattr(ops, name, getattr(_cpu_ops, name))

@@ -262,83 +262,6 @@ def test_gt_edge_attention_folded(dtype, n_src, n_dst, e, c, h, edge_dim):
     assert rel_err(got[:, :c], want_v + xr.float()) < tol
     assert rel_err(got[:, c:c + h * up], want_t) < tol if e > 0 else torch.all(got[:, c:c + h * up] == 0)
     assert torch.all(got[:, c + h * up:] == 0)
-    # the LDS-staged kernel on the same case: same oracle, and the gather kernel's result to rounding
-    from anemoi_models_amd import _lib
-
-    tiles = runtime.edge_tiles(plan)
-    need = _lib.load().anemoi_gt_edge_attention_tiled_lds_bytes(ops.dtype_code(dtype), c, h, up, tiles.s_cap, tiles.e_cap)
-    if 0 <= need <= 160 * 1024:
-        got_t = ops.gt_edge_attention_tiled(q.to(DEV), k.to(DEV), v.to(DEV), xr.to(DEV), u.to(DEV), ea_csr, plan.rowptr,
-                                            tiles, h, up, ld_out=ld).cpu().float()
-        assert rel_err(got_t[:, :c], want_v + xr.float()) < tol
-        assert rel_err(got_t[:, c:c + h * up], want_t) < tol if e > 0 else torch.all(got_t[:, c:c + h * up] == 0)
-        assert torch.all(got_t[:, c + h * up:] == 0)
-        assert rel_err(got_t, got) < (2e-6 if dtype == torch.float32 else 1e-2)
-    else:
-        assert d // (16 // torch.empty((), dtype=dtype).element_size()) < 2 or need > 160 * 1024
-
-
-@pytest.mark.parametrize("dtype,c", [(torch.bfloat16, 1024), (torch.bfloat16, 512), (torch.float32, 1024)])
-def test_gt_edge_attention_tiled_on_the_mesh_graph(dtype, c, monkeypatch):
-    """The LDS-staged edge kernel at the processor graph of BASELINE config 2 (O96 / ico-5 mesh, Morton order): chosen
-    by the heuristic, equal to the gather kernel to rounding, deterministic, last (ragged) tile and high-degree nodes
-    included."""
-    from anemoi_models_amd import ops, runtime
-    from anemoi_models_amd.graphs.synthetic import build_graph
-
-    g = build_graph("o96_ico5")
-    n = g["hidden"].num_nodes
-    lat, lon = g["hidden"].x[:, 0].double(), g["hidden"].x[:, 1].double()
-    inv = runtime.inverse_permutation(runtime.locality_order(torch.stack([lat.sin(), lon.sin(), lat.cos(), lon.cos()], 1)))
-    ei = g[("hidden", "to", "hidden")].edge_index
-    plan = runtime.build_edge_plan(torch.stack([inv[ei[0]], inv[ei[1]]]).to(DEV), n, n)
-    h, up = 16, 12
-    assert runtime.use_edge_tiles(plan, dtype, c, h, up) is None  # opt-in: the gather kernel is the faster one today
-    monkeypatch.setenv("ANEMOI_AMD_EDGE_TILED", "1")
-    tiles = runtime.use_edge_tiles(plan, dtype, c, h, up)
-    if dtype == torch.float32 and c == 1024:
-        assert tiles is None  # f32 rows of 64 channels: two buffers of 192 source rows do not fit the 160 KiB of LDS
-        return
-    assert tiles is not None and n % runtime.TILE_DST != 0
-    dst = plan.dst.long()
-    col = tiles.tile_src.long()[tiles.tile_src_ptr.long()[dst // runtime.TILE_DST] + tiles.col_local.long()]
-    assert torch.equal(col, plan.col.long())  # integer plan: bit exact
-    gen = torch.Generator().manual_seed(3)
-    sq = (torch.randn(n, 4 * c + h * up, generator=gen) * 0.5).to(dtype).to(DEV)
-    attr = torch.randn(plan.num_edges, up, generator=gen).to(DEV)
-    ld = ops.round_up(c + h * up, ops.k_multiple(dtype))
-    args = (sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:], attr, plan.rowptr)
-    want = ops.gt_edge_attention_folded(*args, plan.col, h, up, ld_out=ld)
-    got = ops.gt_edge_attention_tiled(*args, tiles, h, up, ld_out=ld)
-    assert rel_err(got, want) < (2e-6 if dtype == torch.float32 else 1e-2)
-    assert torch.equal(got, ops.gt_edge_attention_tiled(*args, tiles, h, up, ld_out=ld))
-    assert torch.all(got[:, c + h * up:] == 0)
-
-
-def test_model_with_the_lds_staged_edge_kernel(golden_cfg1_gt, graph_o32, monkeypatch):
-    """ANEMOI_AMD_EDGE_TILED=force routes every folded edge phase that fits LDS through anemoi_gt_edge_attention_tiled:
-    the whole model against the reference golden output (bf16: 4 heads of 16 channels; f32 heads of 4 channels stay on the
-    gather kernel) and against the default route."""
-    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
-    gold = golden_cfg1_gt
-    model, _ = _build(graph_o32, 64, 4, heads=4)
-    model.load_state_dict(split_prefix(gold, "sd."))
-    model = model.to(DEV).eval()
-    with torch.no_grad():
-        y0 = model(gold["x"].to(DEV))
-    monkeypatch.setenv("ANEMOI_AMD_EDGE_TILED", "force")
-    from anemoi_models_amd import ops
-
-    calls = []
-    real = ops.gt_edge_attention_tiled
-    monkeypatch.setattr(ops, "gt_edge_attention_tiled", lambda *a, **k: calls.append(1) or real(*a, **k))
-    model2, _ = _build(graph_o32, 64, 4, heads=4)  # fresh plans: the kernel choice is cached per plan
-    model2.load_state_dict(split_prefix(gold, "sd."))
-    model2 = model2.to(DEV).eval()
-    with torch.no_grad():
-        y1 = model2(gold["x"].to(DEV))
-    assert len(calls) >= 4  # the four processor blocks at least
-    assert rel_err(y1, y0) < 2e-2
 
 
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
@@ -610,9 +533,9 @@ def test_full_size_invariants_n320_ico6_1024ch(monkeypatch):
         monkeypatch.setenv("ANEMOI_INFERENCE_NUM_CHUNKS", "4")  # (2) bf16: the chunked MLP takes its LayerNorm statistics
         assert float((model(x) - y).abs().max()) <= 1e-2 * scale  # from a separate two-pass kernel -> bf16 rounding flips
         monkeypatch.delenv("ANEMOI_INFERENCE_NUM_CHUNKS")
-        monkeypatch.setenv("ANEMOI_AMD_MESH_REORDER", "0")  # (1): a fresh model (the order is cached per model)
-        y_plain_order = make()(x)
-        monkeypatch.delenv("ANEMOI_AMD_MESH_REORDER")
+        plain = make()  # (1): a fresh model (the order is cached per model) on the graph's own mesh node order
+        plain.mesh_locality_order = False
+        y_plain_order = plain(x)
         assert float((y_plain_order - y).abs().max()) <= 3e-2 * scale  # bf16: the summation order per destination changes
         monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32")  # (3)
         y32 = model(x)
@@ -621,9 +544,9 @@ def test_full_size_invariants_n320_ico6_1024ch(monkeypatch):
         assert float((model(x) - y32).abs().max()) <= 1e-5 * scale
         monkeypatch.delenv("ANEMOI_INFERENCE_NUM_CHUNKS")
         y32_plain = None
-        monkeypatch.setenv("ANEMOI_AMD_MESH_REORDER", "0")
-        y32_plain = make()(x)
-        monkeypatch.delenv("ANEMOI_AMD_MESH_REORDER")
+        plain.mesh_locality_order = False
+        y32_plain = plain(x)
+        del plain
         assert float((y32_plain - y32).abs().max()) <= 2e-4 * scale  # f32: only rounding of a different summation order
 
 
@@ -878,7 +801,9 @@ def test_full_size_config3_invariants(monkeypatch):
 
     y_ref = run()
     assert y_ref.shape == (1, 1, graph["data"].num_nodes, 80) and torch.isfinite(y_ref).all()
-    assert rel_err(run(ANEMOI_AMD_MESH_REORDER="0"), y_ref) < 1e-4
+    model.mesh_locality_order = False  # the graph's own mesh node order (run() drops the cached order and plans)
+    assert rel_err(run(), y_ref) < 1e-4
+    model.mesh_locality_order = True
     assert rel_err(run(ANEMOI_AMD_EDGE_FOLD="0"), y_ref) < 1e-4
     y_bf16 = run(ANEMOI_AMD_DTYPE="bf16")
     assert rel_err(y_bf16, y_ref) < 5e-2
@@ -1007,11 +932,15 @@ def test_weight_grad_without_transposes(m, n, k, ld_extra):
 
 @pytest.mark.parametrize("m,n,k", [(40962, 1024, 192), (5121, 256, 1024), (2500, 96, 64)])
 def test_weight_grad_chunked_transposes(m, n, k, monkeypatch):
-    """ops.weight_grad, older route kept behind ANEMOI_AMD_DW_TN=0 and for operands the TN kernel does not take (chunked
-    transposes + batched GEMM + column sums of the partial results) == dpre^T x."""
-    from anemoi_models_amd import ops
+    """ops.weight_grad, the route for operands the TN kernel does not take -- f32, unaligned -- (chunked transposes +
+    batched GEMM + column sums of the partial results) == dpre^T x; forced here on bf16 operands."""
+    from functools import partial
 
-    monkeypatch.setenv("ANEMOI_AMD_DW_TN", "0")
+    from anemoi_models_amd import ops as ops_
+
+    class ops:  # noqa: N801  (this test's view of the module: weight_grad on the transposes route)
+        weight_grad = staticmethod(partial(ops_.weight_grad, transposed_route=True))
+
     g = torch.Generator().manual_seed(m)
     dpre, x = torch.randn(m, n, generator=g).bfloat16().to(DEV), torch.randn(m, k, generator=g).bfloat16().to(DEV)
     want = dpre.double().t() @ x.double()
@@ -1316,19 +1245,16 @@ def test_whole_model_training_step_vs_oracle_autograd(golden_cfg1_gt, graph_o32)
         if k in grads:  # (buffers such as the sin / cos coordinates have no .grad on the module)
             err = float((grads[k].grad - dsd[k].grad).abs().max())
             assert err <= 1e-5 * max(float(dsd[k].grad.abs().max()), 0.02 * scale_all), (k, err)
-    os.environ["ANEMOI_AMD_MESH_REORDER"] = "0"
-    try:
-        plain, _ = _build(graph_o32, 64, 4)
-        plain.load_state_dict(sd)
-        plain = plain.to(DEV)
-        yp = plain(x.to(DEV))
-        assert torch.equal(yp.detach(), y.detach())
-        yp.backward(dy.to(DEV))
-        for k, p in plain.named_parameters():
-            if k in used:
-                assert torch.equal(p.grad, dsd[k].grad), k
-    finally:
-        del os.environ["ANEMOI_AMD_MESH_REORDER"]
+    plain, _ = _build(graph_o32, 64, 4)  # the same step on the graph's own mesh node order
+    plain.mesh_locality_order = False
+    plain.load_state_dict(sd)
+    plain = plain.to(DEV)
+    yp = plain(x.to(DEV))
+    assert torch.equal(yp.detach(), y.detach())
+    yp.backward(dy.to(DEV))
+    for k, p in plain.named_parameters():
+        if k in used:
+            assert torch.equal(p.grad, dsd[k].grad), k
     opt = torch.optim.SGD(model.parameters(), lr=1e-3)  # and a plain optimiser step runs on them
     opt.step()
     with torch.no_grad():

@@ -488,39 +488,6 @@ def test_shard_plan_processor_edges_are_the_reference_chunks(graph_o32, world):
         assert int(idx_l[r][1].min()) >= sp.lo and int(idx_l[r][1].max()) < sp.hi
 
 
-def test_edge_tiles_reproduce_the_plan():
-    """runtime.edge_tiles: per 32-destination tile the ascending unique source rows, per CSR slot its position in that
-    list -- integer outputs, checked by rebuilding every slot's source from the tiling alone."""
-    g = torch.Generator().manual_seed(4)
-    for n_src, n_dst, e in ((50, 30, 400), (300, 97, 2000), (10, 64, 0), (5, 1, 7)):
-        ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, n_dst, (e,), generator=g)])
-        plan = runtime.build_edge_plan(ei, n_src, n_dst)
-        t = runtime.edge_tiles(plan)
-        n_tiles = (n_dst + runtime.TILE_DST - 1) // runtime.TILE_DST
-        assert t.tile_src_ptr.dtype == torch.int32 and t.tile_src_ptr.shape[0] == n_tiles + 1
-        assert t.s_cap % 32 == 0 and t.e_cap % 4 == 0
-        if e == 0:
-            continue
-        tile = plan.dst.long() // runtime.TILE_DST
-        col = t.tile_src.long()[t.tile_src_ptr.long()[tile] + t.col_local.long()]
-        assert torch.equal(col, plan.col.long())
-        for k in range(n_tiles):
-            seg = t.tile_src[int(t.tile_src_ptr[k]):int(t.tile_src_ptr[k + 1])]
-            assert torch.all(seg[1:] > seg[:-1]) and seg.numel() <= t.s_cap
-            lo, hi = k * runtime.TILE_DST, min((k + 1) * runtime.TILE_DST, n_dst)
-            assert int(plan.rowptr[hi] - plan.rowptr[lo]) <= t.e_cap
-            assert set(seg.tolist()) == set(plan.col[int(plan.rowptr[lo]):int(plan.rowptr[hi])].tolist())
-        # slot -> destination map: a permutation of the tile's rows by falling in-degree, -1 padding behind the last row
-        order = t.tile_order.view(n_tiles, runtime.TILE_DST)
-        deg = (plan.rowptr[1:] - plan.rowptr[:-1]).long()
-        for k in range(n_tiles):
-            lo, hi = k * runtime.TILE_DST, min((k + 1) * runtime.TILE_DST, n_dst)
-            rows = order[k][order[k] >= 0].long()
-            assert sorted(rows.tolist()) == list(range(lo, hi)) and torch.all(order[k][hi - lo:] == -1)
-            assert torch.all(deg[rows][1:] <= deg[rows][:-1])
-        assert runtime.edge_tiles(plan) is t  # cached on the plan
-
-
 def test_graph_transformer_conv_forward_host_wiring(monkeypatch):
     """GraphTransformerConv.forward (reference layers/conv.py:98-142 call signature): plan, CSR permutation of the edge
     features and reshapes around the kernel, on the CPU stand-in, against oracle.gt_conv."""

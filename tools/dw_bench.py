@@ -32,9 +32,9 @@ for m, n, k in shapes:
     dpre = torch.randn(m, n, device=dev).bfloat16()
     x = torch.randn(m, k, device=dev).bfloat16()
     res = {}
-    for name, env in (("tn", "1"), ("transposes", "0")):
-        os.environ["ANEMOI_AMD_DW_TN"] = env
-        res[name] = (timed(lambda: ops.weight_grad(dpre, x, k, want_bias=True)), ops.weight_grad(dpre, x, k))
+    for name, tr in (("tn", False), ("transposes", True)):
+        res[name] = (timed(lambda: ops.weight_grad(dpre, x, k, want_bias=True, transposed_route=tr)),
+                     ops.weight_grad(dpre, x, k, transposed_route=tr))
     want = dpre[:8192].double().t() @ x[:8192].double() if m <= 8192 else None
     err = float((res["tn"][1] - res["transposes"][1]).abs().max() / res["transposes"][1].abs().max())
     fl = 2.0 * m * n * k / 1e9

@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--col", default="graph", help="graph | near (sources = dst-4..dst+4: ideal locality) | random")
     ap.add_argument("--set", default="proc", choices=["proc", "enc", "dec"],
                     help="edge set: mesh processor, encoder (grid -> mesh), decoder (mesh -> grid)")
-    ap.add_argument("--tiled", action="store_true", help="the LDS-staged kernel (anemoi_gt_edge_attention_tiled)")
     ap.add_argument("--save", default=None, help="write the output tensor here (bit-compare kernel variants)")
     ap.add_argument("--compare", default=None, help="compare the output with a tensor written by --save")
     a = ap.parse_args()
@@ -57,15 +56,7 @@ def main():
     ld_out = ops.round_up(c + h * up, 64)
     out = torch.zeros(n, ld_out, dtype=torch.bfloat16, device=dev)
 
-    tiles = runtime.edge_tiles(plan) if a.tiled else None
-    if tiles is not None:
-        print(f"tiles: s_cap {tiles.s_cap} e_cap {tiles.e_cap} reuse {tiles.reuse:.2f}", flush=True)
-
     def run():
-        if tiles is not None:
-            ops.gt_edge_attention_tiled(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
-                                        attr, plan.rowptr, tiles, h, up, out=out, ld_out=ld_out)
-            return
         ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
                                      attr, plan.rowptr, plan.col, h, up, out=out, ld_out=ld_out)
 
@@ -92,15 +83,7 @@ def mapper(a):
     ld_out = ops.round_up(c + h * up, 64)
     out = torch.zeros(n_dst, ld_out, dtype=torch.bfloat16, device=dev)
 
-    tiles = runtime.edge_tiles(plan) if a.tiled else None
-    if tiles is not None:
-        print(f"tiles: s_cap {tiles.s_cap} e_cap {tiles.e_cap} reuse {tiles.reuse:.2f}", flush=True)
-
     def run():
-        if tiles is not None:
-            ops.gt_edge_attention_tiled(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], attr, plan.rowptr,
-                                        tiles, h, up, out=out, ld_out=ld_out)
-            return
         ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], attr, plan.rowptr,
                                      plan.col, h, up, out=out, ld_out=ld_out)
 
@@ -126,7 +109,7 @@ def report(a, run, out, alg, label):
         want = torch.load(a.compare)
         note = "  bit-identical to " + a.compare if torch.equal(out.cpu(), want) else \
             f"  DIFFERS from {a.compare}: max abs {float((out.cpu().float() - want.float()).abs().max()):.3e}"
-    print(f"{label} tiled={int(bool(a.tiled))} {ms:.4f} ms  {alg / ms / 1e6:.0f} GB/s "
+    print(f"{label} {ms:.4f} ms  {alg / ms / 1e6:.0f} GB/s "
           f"algorithmic ({alg / ms / 1e6 / 80:.1f} % of 8 TB/s){note}", flush=True)
 
 
