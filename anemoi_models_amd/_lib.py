@@ -32,7 +32,30 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 30
+ABI_VERSION = 32
+
+
+class GtBlockArgs(ctypes.Structure):
+    """``anemoi_gt_block_args`` of include/anemoi_amd.h (block-level entry points), field for field."""
+
+    _fields_ = [
+        ("struct_bytes", c_int64), ("n_dst", c_int64),
+        ("dtype", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("up", ctypes.c_int32),
+        ("hidden", ctypes.c_int32), ("act", ctypes.c_int32), ("k_proj", ctypes.c_int32), ("n_in", ctypes.c_int32),
+        ("eps_mlp", c_float), ("eps_out", c_float),
+        ("x", c_void_p), ("ldx", c_int64), ("x_stats", c_void_p),
+        ("w_in", c_void_p), ("b_in", c_void_p), ("cs_in", c_void_p),
+        ("sq", c_void_p), ("ld_sq", c_int64),
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("x_r", c_void_p), ("u", c_void_p),
+        ("ldq", c_int64), ("ldkv", c_int64), ("ldr", c_int64), ("ldu", c_int64),
+        ("edge_attr", c_void_p), ("rowptr", c_void_p), ("col", c_void_p),
+        ("att", c_void_p), ("ld_att", c_int64),
+        ("w_proj", c_void_p), ("b_proj", c_void_p), ("res", c_void_p), ("ld_res", c_int64), ("y", c_void_p),
+        ("y_stats", c_void_p),
+        ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("cs_fc1", c_void_p), ("h", c_void_p),
+        ("w_fc2", c_void_p), ("b_fc2", c_void_p), ("out", c_void_p), ("out_stats", c_void_p),
+        ("stats_ws", c_void_p), ("stats_ws_bytes", c_int64),
+    ]
 
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -77,11 +100,11 @@ SIGNATURES = {
     "anemoi_segment_sum": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "anemoi_mhsa_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                            c_int, c_float, c_uint32, c_void_p]),
+                            c_int, c_float, c_uint32, c_int, c_int, c_void_p]),
     "anemoi_mhsa_backward_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa_backward": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32,
-                                     c_void_p]),
+                                     c_int, c_int, c_void_p]),
     "anemoi_assemble_nodes": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "anemoi_finalize_output": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,
@@ -121,6 +144,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "anemoi_convert_pad": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "anemoi_add": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "anemoi_gt_block_tail": (c_int, [ctypes.POINTER(GtBlockArgs), c_void_p]),
+    "anemoi_gt_processor_block_forward": (c_int, [ctypes.POINTER(GtBlockArgs), c_void_p]),
 }
 
 _lib = None

@@ -421,31 +421,36 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
 
 # ------------------------------------------------------------------------------------------ mesh-node self attention
 class _MHSA(torch.autograd.Function):
-    """``dropout(softmax(Q K^T / sqrt(D))) V`` on the fused ``q | k | v`` matrix (``anemoi_mhsa``, MFMA flash kernel for
-    bf16 head sizes 64 / 32 without dropout); the backward recomputes the probabilities from the saved log-sum-exp and the
-    dropout mask from the saved seed (``anemoi_mhsa_backward``)."""
+    """``dropout(softmax(Q K^T / sqrt(D))) V`` on the fused ``q | k | v`` matrix (``anemoi_mhsa``, MFMA flash kernels for
+    bf16 head sizes 64 / 32, with or without dropout); the backward recomputes the probabilities from the saved
+    log-sum-exp and the dropout mask from the saved seed (``anemoi_mhsa_backward``)."""
 
     @staticmethod
-    def forward(ctx, qkv: Tensor, batch_size: int, num_heads: int, window: int, dropout_p: float, seed: int):
-        out, lse = ops.mhsa(qkv, batch_size, num_heads, window, return_lse=True, dropout_p=dropout_p, dropout_seed=seed)
+    def forward(ctx, qkv: Tensor, batch_size: int, num_heads: int, window: int, dropout_p: float, seed: int,
+                head_offset: int = 0, heads_total: int = 0):
+        out, lse = ops.mhsa(qkv, batch_size, num_heads, window, return_lse=True, dropout_p=dropout_p, dropout_seed=seed,
+                            head_offset=head_offset, heads_total=heads_total)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.args = (batch_size, num_heads, window, dropout_p, seed)
+        ctx.args = (batch_size, num_heads, window, dropout_p, seed, head_offset, heads_total)
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         qkv, out, lse = ctx.saved_tensors
-        b, h, w, p, seed = ctx.args
-        return ops.mhsa_backward(qkv, out, dout.contiguous(), lse, b, h, w, p, seed), None, None, None, None, None
+        b, h, w, p, seed, h0, ht = ctx.args
+        return (ops.mhsa_backward(qkv, out, dout.contiguous(), lse, b, h, w, p, seed, h0, ht), None, None, None, None, None,
+                None, None)
 
 
 def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, dropout_p: float = 0.0,
-         seed: Optional[int] = None) -> Tensor:
+         seed: Optional[int] = None, head_offset: int = 0, heads_total: int = 0) -> Tensor:
     """Differentiable ``ops.mhsa`` (reference layers/attention.py:67-112).  ``dropout_p`` > 0: attention dropout with a
-    mask derived from ``seed`` (default: drawn from torch's CPU generator, so ``torch.manual_seed`` reproduces it)."""
+    mask derived from ``seed`` (default: drawn from torch's CPU generator, so ``torch.manual_seed`` reproduces it);
+    ``head_offset`` / ``heads_total``: a head shard of a model group (see ``ops.mhsa``)."""
     if dropout_p > 0.0 and seed is None:
         seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
-    return _MHSA.apply(qkv, batch_size, num_heads, window, float(dropout_p), int(seed or 0))
+    return _MHSA.apply(qkv, batch_size, num_heads, window, float(dropout_p), int(seed or 0), int(head_offset),
+                       int(heads_total))
 
 
 # ------------------------------------------------------------------------------------------ GNN edge phase

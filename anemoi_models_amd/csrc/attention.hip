@@ -71,13 +71,72 @@ __device__ __forceinline__ int aswz64(int row, int chunk) { return chunk ^ ((row
 // fragments read from LDS once, used by two MFMAs) cut it 4x and halve the LDS -> register traffic per MFMA.
 // ATT_D = 64 (config 3: 1024 channels / 16 heads) or 32 (config 2: 512 / 16): NKS = D / 16 MFMAs per S^T block along the
 // head dimension, NDT = D / 32 row blocks of O^T; the K tile has D * 2 bytes per key, the V^T tile D rows of 128 bytes.
-template <int ATT_D>
+// ---------------------------------------------------------------------------------------------
+// Attention dropout (reference layers/attention.py:90-105: dropout_p of SDPA / flash-attn in training mode).  The keep
+// decision of probability (b, h, i, j) is a counter-based hash of its index and a per-call seed -- nothing of size S x S
+// is stored, the backward kernels rebuild exactly the same mask.  One 32-bit hash (lowbias32 of the row and the KEY PAIR
+// j >> 1) decides two neighbouring keys, 16 bits each (the forward and the dQ kernel hold neighbouring keys of one query
+// in one packed register pair: one hash per pair; p is resolved to 2^-16).  Kept probabilities are scaled by
+// 1 / (1 - p); the softmax normaliser is taken before the dropout, as in the reference.  p >= 1 drops everything (output
+// and gradients 0).  The row index uses the GLOBAL head (h0 + h of h_total): a head-sharded call (sequence-parallel
+// attention across a model group) draws the mask of the unsharded one.
+// ---------------------------------------------------------------------------------------------
+struct AttnDropout {
+  uint32_t thr16;      // keep  <=>  16 hash bits >= thr16  (thr16 = p * 2^16; 0: no dropout)
+  uint32_t seed;
+  float keep_scale;    // 1 / (1 - p), 0 when p >= 1
+  int drop_all;
+  int h0, h_total;     // global index of this call's head 0, number of heads of the whole attention
+};
+
+__device__ __forceinline__ int64_t dropout_row(const AttnDropout& dr, int64_t b, int h, int64_t S, int64_t q) {
+  return (b * dr.h_total + dr.h0 + h) * S + q;
+}
+
+__device__ __forceinline__ uint32_t dropout_row_part(const AttnDropout& dr, int64_t row) {
+  return (uint32_t)row * 0x9E3779B1u ^ (uint32_t)(row >> 32) * 0x85EBCA77u ^ dr.seed;
+}
+
+// the 2 x 16 decision bits of key pair `pair` (= key >> 1): x = row part ^ pair * C3 (C3 = 0xC2B2AE3D), lowbias32
+__device__ __forceinline__ uint32_t dropout_mix(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ float dropout_keep(const AttnDropout& dr, int64_t row, int col) {
+  // row = dropout_row(b, h, q), col = key
+  if (dr.thr16 == 0 && !dr.drop_all) return 1.0f;
+  if (dr.drop_all) return 0.0f;
+  const uint32_t x = dropout_mix(dropout_row_part(dr, row) ^ (uint32_t)(col >> 1) * 0xC2B2AE3Du);
+  return ((x >> (16 * (col & 1))) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.0f;
+}
+
+static inline AttnDropout make_dropout(float p, uint32_t seed, int h0, int h_total) {
+  AttnDropout dr;
+  dr.seed = seed;
+  dr.drop_all = p >= 1.0f ? 1 : 0;
+  const double t = p <= 0.f ? 0.0 : (double)p * 65536.0 + 0.5;
+  dr.thr16 = dr.drop_all ? 0xffffu : (uint32_t)(t > 65535.0 ? 65535.0 : t);
+  dr.keep_scale = (p > 0.f && p < 1.0f) ? 1.0f / (1.0f - p) : (p >= 1.0f ? 0.f : 1.0f);
+  dr.h0 = h0;
+  dr.h_total = h_total;
+  return dr;
+}
+
+template <int ATT_D, bool DROP = false>
 // (D = 32: capped at 128 registers = two workgroups per CU, six spilled values, 0.79 -> 0.69 ms at S = 10 242; the same cap
 //  at D = 64 spills 73 registers into the tile loop: 8.2 -> 23 ms, so D = 64 stays at one workgroup per CU)
-__global__ __launch_bounds__(512, ATT_D == 32 ? 4 : 2) void mhsa_bf16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
-                                                        const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
-                                                        int64_t ldo, int S, int S_pad, int H, int C, int window,
-                                                        float scale_log2e, float* __restrict__ lse) {
+// DROP (training, round 3): attention dropout on the packed probabilities -- the row sum is taken first (the normaliser
+// sees every key), then the dropped halves of every bf16 pair are cleared by an AND with the pair's 2 x 16 decision bits;
+// the 1 / (1 - p) rides on the final normalisation.  One hash per key pair and query: ~9 VALU per element next to the
+// softmax's ~6 (two of them 32-bit multiplies).
+__global__ __launch_bounds__(512, (ATT_D == 32 && !DROP) ? 4 : 2) void mhsa_bf16_kernel(
+    const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int64_t ldo, int S,
+    int S_pad, int H, int C, int window, float scale_log2e, float* __restrict__ lse, const AttnDropout dr) {
   static_assert(ATT_D == 32 || ATT_D == 64, "head sizes with an MFMA path");
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32;
   constexpr int KRB = ATT_D * 2;                        // bytes of a key row in the K tile
@@ -102,6 +161,12 @@ __global__ __launch_bounds__(512, ATT_D == 32 ? 4 : 2) void mhsa_bf16_kernel(con
     const bf16_t* qp = qkv + ((int64_t)b * S + qc) * ld + h * ATT_D + half * 8;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
+  }
+
+  uint32_t drow[2] = {0u, 0u};  // DROP: hash part of this lane's two queries
+  if constexpr (DROP) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) drow[qb] = dropout_row_part(dr, dropout_row(dr, b, h, S, qn[qb]));
   }
 
   // ---- key range of this workgroup (sliding window: only tiles that intersect any of its queries)
@@ -239,10 +304,18 @@ __global__ __launch_bounds__(512, ATT_D == 32 ? 4 : 2) void mhsa_bf16_kernel(con
           uint32_t w[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
+            // (DROP: the compiler's own conversion -- an opaque asm between the hash's VALU chains is invisible to its
+            //  hazard recognizer: trans-result -> VALU read without the wait state gave NaN sums in single lanes)
+            if constexpr (DROP) w[i] = pack_bf16x2(p[kk * 8 + 2 * i], p[kk * 8 + 2 * i + 1]);
+            else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
             uint32_t wi = w[i];
             psum = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&wi),
                                                    *reinterpret_cast<const bf16x2_t*>(&ones2), psum, false);
+            if constexpr (DROP) {  // keys key0 + 16 kk + 2 i (low half) and + 1 (high half): pair index (key0 >> 1) + 8 kk + i
+              const uint32_t x = dropout_mix(drow[qb] ^ ((uint32_t)(key0 >> 1) + 8u * kk + i) * 0xC2B2AE3Du);
+              const uint32_t keep = ((x & 0xffffu) >= dr.thr16 ? 0x0000ffffu : 0u) | ((x >> 16) >= dr.thr16 ? 0xffff0000u : 0u);
+              w[i] &= keep;
+            }
           }
           pb[qb][kk] = *reinterpret_cast<abf16x8_t*>(w);
         }
@@ -268,7 +341,8 @@ __global__ __launch_bounds__(512, ATT_D == 32 ? 4 : 2) void mhsa_bf16_kernel(con
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if constexpr (DROP) inv *= dr.keep_scale;
     if (lse != nullptr && half == 0 && qn[qb] < S)  // natural-log sum-exp of the scaled scores (training: backward input)
       lse[((int64_t)b * H + h) * S + qn[qb]] = (m_run[qb] + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
     if (qn[qb] < S) {
@@ -283,42 +357,6 @@ __global__ __launch_bounds__(512, ATT_D == 32 ? 4 : 2) void mhsa_bf16_kernel(con
         }
     }
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Attention dropout (reference layers/attention.py:90-105: dropout_p of SDPA / flash-attn in training mode).  The keep
-// mask of probability (b, h, i, j) is a counter-based hash of its index and a per-call seed -- nothing is stored, the
-// backward kernels rebuild exactly the same mask.  Kept probabilities are scaled by 1 / (1 - p); the softmax normaliser
-// is taken before the dropout, as in the reference.  p >= 1 drops everything (output and gradients 0).
-// ---------------------------------------------------------------------------------------------
-struct AttnDropout {
-  uint32_t threshold;  // keep  <=>  hash >= threshold  (threshold = p * 2^32; 0: no dropout)
-  uint32_t seed;
-  float keep_scale;    // 1 / (1 - p), 0 when p >= 1
-  int drop_all;
-};
-
-__device__ __forceinline__ float dropout_keep(const AttnDropout& dr, int64_t row, int col) {
-  // row = (b * H + h) * S + i, col = j
-  if (dr.threshold == 0 && !dr.drop_all) return 1.0f;
-  if (dr.drop_all) return 0.0f;
-  uint32_t x = (uint32_t)row * 0x9E3779B1u ^ (uint32_t)(row >> 32) * 0x85EBCA77u ^ (uint32_t)col * 0xC2B2AE3Du ^ dr.seed;
-  x ^= x >> 16;
-  x *= 0x7feb352du;
-  x ^= x >> 15;
-  x *= 0x846ca68bu;
-  x ^= x >> 16;
-  return x >= dr.threshold ? dr.keep_scale : 0.0f;
-}
-
-static inline AttnDropout make_dropout(float p, uint32_t seed) {
-  AttnDropout dr;
-  dr.seed = seed;
-  dr.drop_all = p >= 1.0f ? 1 : 0;
-  const double t = p <= 0.f ? 0.0 : (double)p * 4294967296.0;
-  dr.threshold = dr.drop_all ? 0xffffffffu : (uint32_t)(t > 4294967295.0 ? 4294967295.0 : t);
-  dr.keep_scale = (p > 0.f && p < 1.0f) ? 1.0f / (1.0f - p) : (p >= 1.0f ? 0.f : 1.0f);
-  return dr;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -363,7 +401,7 @@ __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__
     const float mn = fmaxf(m, s);
     const float corr = __expf(m - mn), pe = __expf(s - mn);
     l = l * corr + pe;  // the normaliser sees every key; dropout acts on the normalised probabilities
-    const float pk = pe * dropout_keep(dr, (b * H + h) * S + q, key);
+    const float pk = pe * dropout_keep(dr, dropout_row(dr, b, h, S, q), key);
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
       if (d < D) acc[d] = acc[d] * corr + pk * Elem<T>::load(vp + d);
@@ -397,7 +435,8 @@ __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__
 template <int D>
 __global__ __launch_bounds__(256) void mhsa_tail_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int S, int H, int C,
                                                         int window, float scale, int q_begin, int q_count, int n_split,
-                                                        int chunk, int64_t total, float* __restrict__ part) {
+                                                        int chunk, int64_t total, float* __restrict__ part,
+                                                        const AttnDropout dr) {
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h, split)
   if (unit >= total) return;
@@ -421,6 +460,7 @@ __global__ __launch_bounds__(256) void mhsa_tail_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int d = 0; d < D; ++d) acc[d] = 0.f;
   float m = -INFINITY, l = 0.f;
+  const int64_t drow = dropout_row(dr, b, h, S, q);
   int k_lo = split * chunk, k_hi = k_lo + chunk < S ? k_lo + chunk : S;
   if (window >= 0) {
     k_lo = k_lo > q - window ? k_lo : q - window;
@@ -440,12 +480,13 @@ __global__ __launch_bounds__(256) void mhsa_tail_kernel(const bf16_t* __restrict
     const float mn = fmaxf(m, s);
     const float corr = __expf(m - mn), pe = __expf(s - mn);
     l = l * corr + pe;
+    const float pk = pe * dropout_keep(dr, drow, key);  // (1 without dropout)
 #pragma unroll
     for (int d8 = 0; d8 < D / 8; ++d8) {
       float t[8];
       VecIO<bf16_t, 8>::load(vp + d8 * 8, t);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[d8 * 8 + i] = acc[d8 * 8 + i] * corr + pe * t[i];
+      for (int i = 0; i < 8; ++i) acc[d8 * 8 + i] = acc[d8 * 8 + i] * corr + pk * t[i];
     }
     m = mn;
   }
@@ -549,12 +590,12 @@ __device__ __forceinline__ int att_rswz(int row, int chunk) {  // swizzle of a r
 // (three waves per SIMD: the tile loop -- plain loads, two barriers per 32-query tile -- hides its latency by occupancy
 //  only; at the 212 registers the allocator takes unasked it runs two waves per SIMD, capped at 168 it spills ten and the
 //  backward of a layer at S = 40 962 goes 45.5 -> 39.3 ms; a cap of 128 spills 47)
-template <int ATT_D>
-__global__ __launch_bounds__(256, 3) void mhsa_bwd_dkv_mfma_kernel(
+template <int ATT_D, bool DROP = false>
+__global__ __launch_bounds__(256, DROP ? 2 : 3) void mhsa_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
     const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT, const float* __restrict__ lse,
     const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window,
-    float scale, float scale_log2e) {
+    float scale, float scale_log2e, const AttnDropout dr) {
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;  // chunks of 16 bytes per row
   __shared__ __attribute__((aligned(16))) char q_s[32 * RB], do_s[32 * RB], qt_s[ATT_D * 64], dot_s[ATT_D * 64];
   __shared__ float lse_s[32], dl_s[32];
@@ -586,6 +627,11 @@ __global__ __launch_bounds__(256, 3) void mhsa_bwd_dkv_mfma_kernel(
   }
   const int prow = att_row_perm(ql);
   const int t = threadIdx.x;
+  // DROP: lane = key, so the key-pair part of the hash and the half of its 32 bits that belongs to this key are lane
+  // constants; the row part moves with the query (rows below 2^32: checked by the launcher)
+  const uint32_t dkey = DROP ? ((uint32_t)(key >> 1) * 0xC2B2AE3Du ^ dr.seed) : 0u;
+  const int dsh = 16 * (key & 1);
+  const uint32_t drow0 = DROP ? (uint32_t)dropout_row(dr, b, h, S, 0) : 0u;
   for (int qt = qt_begin; qt < qt_end; ++qt) {
     __syncthreads();  // the previous tile has been consumed
     if (t < 32 * CPR) {  // Q and dO rows of the tile (row-major, swizzled)
@@ -631,8 +677,15 @@ __global__ __launch_bounds__(256, 3) void mhsa_bwd_dkv_mfma_kernel(
         const int dq_ = qt * 32 + qi - key;
         pe = (dq_ <= window && -dq_ <= window) ? pe : 0.f;
       }
-      p[r] = pe;
-      ds[r] = pe * (dp_acc[r] - dl_s[qi]);
+      if constexpr (DROP) {  // dV takes the dropped probabilities, dS = P (keep / (1 - p) dP - delta)
+        const uint32_t x = dropout_mix((drow0 + (uint32_t)(qt * 32 + qi)) * 0x9E3779B1u ^ dkey);
+        const float kf_ = ((x >> dsh) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.f;
+        p[r] = pe * kf_;
+        ds[r] = pe * (dp_acc[r] * kf_ - dl_s[qi]);
+      } else {
+        p[r] = pe;
+        ds[r] = pe * (dp_acc[r] - dl_s[qi]);
+      }
     }
     abf16x8_t pb[2], dsb[2];
 #pragma unroll
@@ -640,8 +693,13 @@ __global__ __launch_bounds__(256, 3) void mhsa_bwd_dkv_mfma_kernel(
       uint32_t w1[4], w2[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2[i]) : "v"(ds[kk * 8 + 2 * i]), "v"(ds[kk * 8 + 2 * i + 1]));
+        if constexpr (DROP) {
+          w1[i] = pack_bf16x2(p[kk * 8 + 2 * i], p[kk * 8 + 2 * i + 1]);
+          w2[i] = pack_bf16x2(ds[kk * 8 + 2 * i], ds[kk * 8 + 2 * i + 1]);
+        } else {
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w1[i]) : "v"(p[kk * 8 + 2 * i]), "v"(p[kk * 8 + 2 * i + 1]));
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2[i]) : "v"(ds[kk * 8 + 2 * i]), "v"(ds[kk * 8 + 2 * i + 1]));
+        }
       }
       pb[kk] = *reinterpret_cast<abf16x8_t*>(w1);
       dsb[kk] = *reinterpret_cast<abf16x8_t*>(w2);
@@ -675,11 +733,12 @@ __global__ __launch_bounds__(256, 3) void mhsa_bwd_dkv_mfma_kernel(
   }
 }
 
-template <int ATT_D>
+template <int ATT_D, bool DROP = false>
 __global__ __launch_bounds__(256) void mhsa_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
     const bf16_t* __restrict__ kT, const float* __restrict__ lse, const float* __restrict__ delta,
-    bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window, float scale, float scale_log2e) {
+    bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window, float scale, float scale_log2e,
+    const AttnDropout dr) {
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;
   __shared__ __attribute__((aligned(16))) char k_s[32 * RB], v_s[32 * RB], kt_s[ATT_D * 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, ql = lane & 31;
@@ -697,6 +756,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_mfma_kernel(
   }
   const float lse2 = q < S ? lse[((int64_t)b * H + h) * S + q] * 1.44269504088896340736f : INFINITY;
   const float dl = q < S ? delta[((int64_t)b * H + h) * S + q] : 0.f;
+  const uint32_t drow = DROP ? dropout_row_part(dr, dropout_row(dr, b, h, S, q)) : 0u;  // lane = query
   af32x16_t dq[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
@@ -747,15 +807,23 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_mfma_kernel(
       bool ok = key < S;
       if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
       pe = ok ? pe : 0.f;
-      ds[r] = pe * (dp_acc[r] - dl);
+      if constexpr (DROP) {  // registers r, r + 1 (r even) are the two keys of one pair: one hash for both
+        const uint32_t x = dropout_mix(drow ^ (uint32_t)(key >> 1) * 0xC2B2AE3Du);
+        const float kf_ = ((x >> (16 * (r & 1))) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.f;
+        ds[r] = pe * (dp_acc[r] * kf_ - dl);
+      } else {
+        ds[r] = pe * (dp_acc[r] - dl);
+      }
     }
     abf16x8_t dsb[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint32_t w2[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2[i]) : "v"(ds[kk * 8 + 2 * i]), "v"(ds[kk * 8 + 2 * i + 1]));
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (DROP) w2[i] = pack_bf16x2(ds[kk * 8 + 2 * i], ds[kk * 8 + 2 * i + 1]);
+        else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w2[i]) : "v"(ds[kk * 8 + 2 * i]), "v"(ds[kk * 8 + 2 * i + 1]));
+      }
       dsb[kk] = *reinterpret_cast<abf16x8_t*>(w2);
     }
     // ---- dQ^T += K^T dS^T
@@ -831,7 +899,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const T* __restrict__ 
         dp = fmaf(dov[d], Elem<T>::load(vp + d), dp);
       }
     // with dropout: O = (keep / (1 - p) * P) V, so dP = keep / (1 - p) * (dO . v) and sum_j P dP = dO . O = dl still
-    const float ds = __expf(s - ls) * (dp * dropout_keep(dr, (b * H + h) * S + q, key) - dl) * scale;
+    const float ds = __expf(s - ls) * (dp * dropout_keep(dr, dropout_row(dr, b, h, S, q), key) - dl) * scale;
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
       if (d < D) acc[d] = fmaf(ds, Elem<T>::load(kp + d), acc[d]);
@@ -883,7 +951,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkv_kernel(const T* __restrict__
       }
     const int64_t si = (b * H + h) * S + q;
     const float p = __expf(s * scale - lse[si]);
-    const float keep = dropout_keep(dr, si, key);
+    const float keep = dropout_keep(dr, dropout_row(dr, b, h, S, q), key);
     const float ds = p * (dp * keep - delta[si]) * scale;
     const float pd = p * keep;
 #pragma unroll
@@ -922,7 +990,8 @@ int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
 }
 
 int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
-                int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream) {
+                int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0, int dropout_h_total,
+                anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out, ANEMOI_ERR_INVALID, "anemoi_mhsa: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa: bad shape");
   const int C = H * D;
@@ -931,10 +1000,14 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   const float scale = 1.0f / sqrtf((float)D);
   ANEMOI_REQUIRE(dropout_p >= 0.f && dropout_p <= 1.f, ANEMOI_ERR_INVALID, "anemoi_mhsa: dropout_p %g outside [0, 1]",
                  (double)dropout_p);
-  const AttnDropout dr = make_dropout(dropout_p, dropout_seed);
-  // (attention dropout runs on the generic kernel: the MFMA kernel keeps its probabilities in packed MFMA operands)
-  if (dropout_p == 0.f && dtype == ANEMOI_BF16 && (D == 64 || D == 32) && (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 &&
-      (uintptr_t)out % 8 == 0 && ldo % 4 == 0) {
+  ANEMOI_REQUIRE(dropout_h0 >= 0 && (dropout_h_total == 0 || dropout_h0 + H <= dropout_h_total), ANEMOI_ERR_INVALID,
+                 "anemoi_mhsa: heads %d .. %d of %d", dropout_h0, dropout_h0 + H, dropout_h_total);
+  const AttnDropout dr = make_dropout(dropout_p, dropout_seed, dropout_h0, dropout_h_total > 0 ? dropout_h_total : H);
+  // MFMA route, with or without dropout (the mask is applied to the packed probabilities; the kernels hash 32-bit row
+  // indices: B x heads x S < 2^32, and p = 1 -- everything dropped -- stays on the generic kernel)
+  const bool drop = dr.thr16 != 0;
+  if (!dr.drop_all && (int64_t)B * dr.h_total * S < ((int64_t)1 << 32) && dtype == ANEMOI_BF16 && (D == 64 || D == 32) &&
+      (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 && (uintptr_t)out % 8 == 0 && ldo % 4 == 0) {
     ANEMOI_REQUIRE(workspace != nullptr, ANEMOI_ERR_INVALID, "anemoi_mhsa: workspace of %lld bytes required",
                    (long long)anemoi_mhsa_workspace_bytes(dtype, B, S, H, D));
     const int S_pad = (S + 63) / 64 * 64;
@@ -951,25 +1024,29 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
       const dim3 tgrid((unsigned)((total + 3) / 4)), tblock(256);
       if (D == 64) {
         hipLaunchKernelGGL(mhsa_tail_kernel<64>, tgrid, tblock, 0, st, static_cast<const bf16_t*>(qkv), ld, S, H, C, window,
-                           scale, s_main, rem, n_split, chunk, total, part);
+                           scale, s_main, rem, n_split, chunk, total, part, dr);
         hipLaunchKernelGGL(mhsa_tail_merge_kernel<64>, dim3((unsigned)((n_units * 64 + 255) / 256)), dim3(256), 0, st, part,
                            static_cast<bf16_t*>(out), ldo, lse, S, H, s_main, rem, n_split, n_units);
       } else {
         hipLaunchKernelGGL(mhsa_tail_kernel<32>, tgrid, tblock, 0, st, static_cast<const bf16_t*>(qkv), ld, S, H, C, window,
-                           scale, s_main, rem, n_split, chunk, total, part);
+                           scale, s_main, rem, n_split, chunk, total, part, dr);
         hipLaunchKernelGGL(mhsa_tail_merge_kernel<32>, dim3((unsigned)((n_units * 32 + 255) / 256)), dim3(256), 0, st, part,
                            static_cast<bf16_t*>(out), ldo, lse, S, H, s_main, rem, n_split, n_units);
       }
     }
     const dim3 grid((s_main + ATT_QBLK - 1) / ATT_QBLK, H, B), block(64 * ATT_WAVES);
-    if (D == 64)
-      hipLaunchKernelGGL(mhsa_bf16_kernel<64>, grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
-                         static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
-                         scale * 1.44269504088896340736f, lse);
-    else
-      hipLaunchKernelGGL(mhsa_bf16_kernel<32>, grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
-                         static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
-                         scale * 1.44269504088896340736f, lse);
+#define ANEMOI_MHSA_FWD(DD, DR)                                                                                      \
+  hipLaunchKernelGGL((mhsa_bf16_kernel<DD, DR>), grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,            \
+                     static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window, \
+                     scale * 1.44269504088896340736f, lse, dr)
+    if (D == 64) {
+      if (drop) ANEMOI_MHSA_FWD(64, true);
+      else ANEMOI_MHSA_FWD(64, false);
+    } else {
+      if (drop) ANEMOI_MHSA_FWD(32, true);
+      else ANEMOI_MHSA_FWD(32, false);
+    }
+#undef ANEMOI_MHSA_FWD
     return check_launch("anemoi_mhsa(bf16, MFMA)");
   }
   ANEMOI_REQUIRE(D <= 128, ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa: head size %d > 128", D);
@@ -1001,7 +1078,8 @@ int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int
 
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
                          int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, void* workspace, int B,
-                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream) {
+                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0,
+                         int dropout_h_total, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out && dout && lse && delta && dqkv, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: bad shape");
   const int C = H * D;
@@ -1010,12 +1088,16 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
   ANEMOI_REQUIRE(D <= 128, ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: head size %d > 128", D);
   ANEMOI_REQUIRE(dropout_p >= 0.f && dropout_p <= 1.f, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: dropout_p %g outside [0, 1]",
                  (double)dropout_p);
-  const AttnDropout dr = make_dropout(dropout_p, dropout_seed);
+  ANEMOI_REQUIRE(dropout_h0 >= 0 && (dropout_h_total == 0 || dropout_h0 + H <= dropout_h_total), ANEMOI_ERR_INVALID,
+                 "anemoi_mhsa_backward: heads %d .. %d of %d", dropout_h0, dropout_h0 + H, dropout_h_total);
+  const AttnDropout dr = make_dropout(dropout_p, dropout_seed, dropout_h0, dropout_h_total > 0 ? dropout_h_total : H);
+  const bool drop = dr.thr16 != 0;
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)D);
   const int64_t units = (int64_t)B * S * H;
   ANEMOI_REQUIRE((units + 3) / 4 < ((int64_t)1 << 31), ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: grid too large");
-  if (dropout_p == 0.f && dtype == ANEMOI_BF16 && (D == 64 || D == 32) && workspace != nullptr &&
+  if (!dr.drop_all && (int64_t)B * dr.h_total * S < ((int64_t)1 << 32) && dtype == ANEMOI_BF16 && (D == 64 || D == 32) &&
+      workspace != nullptr &&
       (uintptr_t)workspace % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)out % 2 == 0 &&
       (uintptr_t)dqkv % 8 == 0 && ld % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0) {
     // MFMA route: delta, the three transposed operands, then the two kernels
@@ -1033,17 +1115,21 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
     hipLaunchKernelGGL(transpose_v_kernel, tgrid, tblock, 0, st, dob, lddo, S, S_pad, H, D, C, doT, 0);
     const dim3 grid128((S + 127) / 128, H, B), block256(256);
     const float sl2 = scale * 1.44269504088896340736f;
+#define ANEMOI_MHSA_BWD(DD, DR)                                                                                         \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((mhsa_bwd_dkv_mfma_kernel<DD, DR>), grid128, block256, 0, st, qkvb, ld, dob, lddo, qT, doT, lse, \
+                       delta, static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2, dr);                \
+    hipLaunchKernelGGL((mhsa_bwd_dq_mfma_kernel<DD, DR>), grid128, block256, 0, st, qkvb, ld, dob, lddo, kT, lse, delta, \
+                       static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2, dr);                       \
+  } while (0)
     if (D == 64) {
-      hipLaunchKernelGGL(mhsa_bwd_dkv_mfma_kernel<64>, grid128, block256, 0, st, qkvb, ld, dob, lddo, qT, doT, lse, delta,
-                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
-      hipLaunchKernelGGL(mhsa_bwd_dq_mfma_kernel<64>, grid128, block256, 0, st, qkvb, ld, dob, lddo, kT, lse, delta,
-                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
+      if (drop) ANEMOI_MHSA_BWD(64, true);
+      else ANEMOI_MHSA_BWD(64, false);
     } else {
-      hipLaunchKernelGGL(mhsa_bwd_dkv_mfma_kernel<32>, grid128, block256, 0, st, qkvb, ld, dob, lddo, qT, doT, lse, delta,
-                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
-      hipLaunchKernelGGL(mhsa_bwd_dq_mfma_kernel<32>, grid128, block256, 0, st, qkvb, ld, dob, lddo, kT, lse, delta,
-                         static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2);
+      if (drop) ANEMOI_MHSA_BWD(32, true);
+      else ANEMOI_MHSA_BWD(32, false);
     }
+#undef ANEMOI_MHSA_BWD
     return check_launch("anemoi_mhsa_backward(bf16, MFMA)");
   }
   dim3 grid((unsigned)((units + 3) / 4)), block(256);

@@ -80,13 +80,26 @@ class MultiHeadSelfAttention(nn.Module):
         q, k, v = (shard_heads(t, shapes=shapes, mgroup=model_comm_group) for t in (q, k, v))
         h_loc, n_all = q.shape[1], q.shape[2]
         fused = torch.stack([t[0].permute(1, 0, 2) for t in (q, k, v)], dim=1).reshape(n_all, 3 * h_loc * d).contiguous()
+        # attention dropout across the group: ONE seed (rank 0's draw, broadcast) and the global head index in the mask's
+        # hash, so the ranks together drop exactly what the unsharded attention would with that seed
         p, seed = self.dropout()
+        h0 = 0
         if p > 0.0:
-            raise NotImplementedError("attention dropout across a model group (the ranks would need one mask)")
+            import torch.distributed as dist
+
+            from ..distributed.shapes import split_bounds
+
+            seed_t = torch.tensor([seed], dtype=torch.int64)
+            if dist.get_backend(model_comm_group) == "nccl":
+                seed_t = seed_t.to(x.device)
+            dist.broadcast(seed_t, dist.get_global_rank(model_comm_group, 0), group=model_comm_group)
+            seed = int(seed_t.item())
+            h0 = split_bounds(h, model_comm_group.size())[model_comm_group.rank()]
         if grad:
-            att = autograd.mhsa(fused, 1, h_loc, self.attention_window(), 0.0, 0)
+            att = autograd.mhsa(fused, 1, h_loc, self.attention_window(), p, seed, h0, h)
         else:
-            att = ops.mhsa(fused, 1, h_loc, self.attention_window())
+            att = ops.mhsa(fused, 1, h_loc, self.attention_window(), dropout_p=p, dropout_seed=seed, head_offset=h0,
+                           heads_total=h)
         att = att.view(n_all, h_loc, d).permute(1, 0, 2).unsqueeze(0)  # (1, H_local, N, D)
         att = shard_sequence(att, shapes=shapes, mgroup=model_comm_group)  # (1, H, n_local, D)
         att = att[0].permute(1, 0, 2).reshape(n_local, h * d).contiguous()

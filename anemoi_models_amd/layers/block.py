@@ -317,6 +317,29 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         ln1 = getattr(self, "layer_norm1", None)
         return ln1.eps if isinstance(ln1, nn.LayerNorm) and runtime.ln_fold_enabled(dtype) else None
 
+    def block_abi_operands(self, dtype: torch.dtype, lead_layers, tag: str):
+        """Packed operands of this block for the block-level C entry points (``anemoi_gt_block_tail`` /
+        ``anemoi_gt_processor_block_forward``) -- the very tensors the op-by-op route caches and passes --, or ``None`` when
+        the block cannot take that route (f32, LayerNorm fold off, unfolded edge kernel, another node MLP shape).
+        ``lead_layers`` / ``tag``: the Linear layers whose rows open the LayerNorm-folded input product (processor block:
+        lin_self, lin_query, lin_key, lin_value under "sqkvu")."""
+        up = self.fold_width(dtype)
+        if up is None or not runtime.ln_fold_enabled(dtype):
+            return None
+        if self._dst_mlp is None:
+            self._dst_mlp = NativeSequential(self.node_dst_mlp)
+        mlp = self._dst_mlp.folded_pair(dtype)
+        if mlp is None:
+            return None
+        ln = self.layer_norm1
+        w_in, b_in, cs_in = self._packed.get(
+            (tag, "lnfold", dtype), list(self._fold_params(lead_layers)) + [ln.weight, ln.bias],
+            lambda: runtime.fold_layer_norm(*self._folded_rows(lead_layers, up), ln.weight, ln.bias, dtype))
+        w_proj, b_proj = self._folded_out(dtype, up)
+        eps_mlp, act, w1, b1, cs1, w2, b2 = mlp
+        return dict(up=up, w_in=w_in, b_in=b_in, cs_in=cs_in, w_proj=w_proj, b_proj=b_proj, eps_mlp=eps_mlp, act=act, w_fc1=w1,
+                    b_fc1=b1, cs_fc1=cs1, w_fc2=w2, b_fc2=b2, eps_ln1=ln.eps)
+
     def _node_mlp(self, y: Tensor, which: str, num_chunks: int, out_stats_eps: Optional[float] = None) -> Tensor:
         """``mlp(y) + y`` with mlp = LayerNorm, Linear, act, Linear; optionally in row chunks (bounded hidden buffer)."""
         if which == "dst":

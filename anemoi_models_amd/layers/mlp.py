@@ -74,6 +74,23 @@ class NativeSequential:
                 self.steps.append(("act", m, None))
             i += 1
 
+    def folded_pair(self, dtype: torch.dtype):
+        """The packed operands of ``LayerNorm -> Linear + act -> Linear`` (the node MLP of a GraphTransformer block) for
+        the block-level C entry points: ``(eps, act, w1', b1', colsum1, w2, b2)`` -- the SAME cached tensors ``__call__``
+        hands to ``ops.linear`` --, or ``None`` when this sequence has another shape or the LayerNorm fold is off."""
+        kinds = [s[0] for s in self.steps]
+        if kinds != ["ln", "linear", "linear"] or not runtime.ln_fold_enabled(dtype):
+            return None
+        (_, ln, _), (_, m1, act), (_, m2, act2) = self.steps
+        if act2 != "Identity" or m1.in_features % ops.k_multiple(dtype) != 0 or m2.in_features % ops.k_multiple(dtype) != 0:
+            return None
+        wf, bf, cs = self.cache.get(("lnfold", 1, dtype), [m1.weight, m1.bias, ln.weight, ln.bias],
+                                    lambda: runtime.fold_layer_norm(m1.weight.detach().float(), m1.bias, ln.weight, ln.bias,
+                                                                    dtype))
+        w2 = self.cache.get(("w", 2, dtype), [m2.weight], lambda: runtime.pack_weight([m2.weight], dtype))
+        b2 = None if m2.bias is None else runtime.f32c(m2.bias)
+        return ln.eps, act, wf, bf, cs, w2, b2
+
     def __call__(self, x: Tensor, residual: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
                  start: int = 0, out_stats_eps: Optional[float] = None) -> Tensor:
         """Run steps ``start..`` (``start`` > 0: the caller has already produced the output of the earlier steps).

@@ -172,6 +172,101 @@ class GNNProcessor(GraphEdgeMixin, BaseProcessor):
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)
 
 
+class _BlockAbiPlan:
+    """Argument blocks (``anemoi_gt_block_args``) of every block of a GraphTransformer processor for one (row count,
+    device, weights version): built once, then a forward is ``num_layers`` FFI calls.  Workspaces are shared by the blocks
+    (they run back to back on one stream); the node matrix ping-pongs between two resident buffers, the last block writes
+    a fresh tensor (the result must not alias storage the next call overwrites)."""
+
+    def __init__(self) -> None:
+        self.ok = False
+        self.sig = None
+
+    @classmethod
+    def build(cls, proc, x: Tensor, ea: Tensor, plan, sig) -> "_BlockAbiPlan":
+        import ctypes
+
+        from .. import _lib
+
+        self = cls()
+        self.sig = sig
+        blocks = [blk for chunk in proc.proc for blk in chunk.blocks]
+        dtype, dev, n = x.dtype, x.device, x.shape[0]
+        operands = []
+        for blk in blocks:
+            all4 = [blk.lin_self, blk.lin_query, blk.lin_key, blk.lin_value]
+            op = blk.block_abi_operands(dtype, all4, "sqkvu")
+            if op is None:
+                return self
+            operands.append(op)
+        blk0 = blocks[0]
+        c, h = blk0.num_heads * blk0.out_channels_conv, blk0.num_heads
+        up = operands[0]["up"]
+        n_in, k_proj, hidden = operands[0]["w_in"].shape[0], operands[0]["w_proj"].shape[1], operands[0]["w_fc1"].shape[0]
+        if x.shape[1] != c or any(o["w_in"].shape != operands[0]["w_in"].shape or o["w_fc1"].shape[0] != hidden
+                                  or o["act"] not in _lib.ACT_CODES for o in operands):
+            return self
+        new = lambda *shape, dt=dtype: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
+        self.keep = [operands, ea, plan]
+        self.sq, self.att, self.y, self.hbuf = new(n, n_in), new(n, k_proj), new(n, c), new(n, hidden)
+        self.att[:, c + h * up:].zero_()  # the K padding of the projection: the edge kernel never writes it (zeroed ONCE here)
+        self.bufs = [new(n, c), new(n, c)]
+        self.stats = [new(n, 2, dt=torch.float32) for _ in range(3)]  # y, out (ping), out (pong)
+        self.ws = new(n * max(c // 128, 1), 2, dt=torch.float32)
+        self.eps_in = operands[0]["eps_ln1"]
+        self.args = []
+        for i, (blk, o) in enumerate(zip(blocks, operands)):
+            a = _lib.GtBlockArgs()
+            a.struct_bytes = ctypes.sizeof(_lib.GtBlockArgs)
+            a.n_dst, a.dtype, a.C, a.H, a.up = n, ops.dtype_code(dtype), c, h, up
+            a.hidden, a.act, a.k_proj, a.n_in = hidden, _lib.ACT_CODES[o["act"]], k_proj, n_in
+            a.eps_mlp = o["eps_mlp"]
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else blk  # the LayerNorm that reads this block's output next
+            a.eps_out = nxt.layer_norm1.eps
+            a.ldx = c
+            a.w_in, a.cs_in = o["w_in"].data_ptr(), o["cs_in"].data_ptr()
+            a.b_in = None if o["b_in"] is None else o["b_in"].data_ptr()
+            a.sq, a.ld_sq = self.sq.data_ptr(), n_in
+            a.edge_attr, a.rowptr, a.col = ea.data_ptr(), plan.rowptr.data_ptr(), plan.col.data_ptr()
+            a.att, a.ld_att = self.att.data_ptr(), k_proj
+            a.w_proj = o["w_proj"].data_ptr()
+            a.b_proj = None if o["b_proj"] is None else o["b_proj"].data_ptr()
+            a.y, a.y_stats = self.y.data_ptr(), self.stats[0].data_ptr()
+            a.w_fc1, a.cs_fc1, a.h = o["w_fc1"].data_ptr(), o["cs_fc1"].data_ptr(), self.hbuf.data_ptr()
+            a.b_fc1 = None if o["b_fc1"] is None else o["b_fc1"].data_ptr()
+            a.w_fc2 = o["w_fc2"].data_ptr()
+            a.b_fc2 = None if o["b_fc2"] is None else o["b_fc2"].data_ptr()
+            a.stats_ws, a.stats_ws_bytes = self.ws.data_ptr(), self.ws.numel() * 4
+            # block i reads buffer (i - 1) % 2 (block 0: the caller's x) and writes buffer i % 2 (last block: a fresh tensor)
+            if i > 0:
+                a.x, a.x_stats = self.bufs[(i - 1) % 2].data_ptr(), self.stats[1 + (i - 1) % 2].data_ptr()
+            a.out, a.out_stats = self.bufs[i % 2].data_ptr(), self.stats[1 + i % 2].data_ptr()
+            self.args.append(a)
+        self.refs = [ctypes.byref(a) for a in self.args]
+        self.fn = _lib.load().anemoi_gt_processor_block_forward
+        self.shape = (n, c)
+        self.eps_out = blocks[-1].layer_norm1.eps
+        self.ok = True
+        return self
+
+    def run(self, x: Tensor) -> Tensor:
+        from .. import _lib
+
+        stats_in = ops.row_stats(x, self.eps_in)  # carried by the GEMM that produced x, or one pass over it
+        out = torch.empty(self.shape, dtype=x.dtype, device=x.device)
+        out_stats = torch.empty((self.shape[0], 2), dtype=torch.float32, device=x.device)
+        first, last = self.args[0], self.args[-1]
+        first.x, first.x_stats = x.data_ptr(), stats_in.data_ptr()
+        last.out, last.out_stats = out.data_ptr(), out_stats.data_ptr()
+        stream = ops._stream()
+        for ref in self.refs:
+            st = self.fn(ref, stream)
+            if st != 0:
+                _lib.check(st, "anemoi_gt_processor_block_forward")
+        ops._carry_stats(out, self.eps_out, out_stats)
+        return out
+
+
 class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
     def __init__(self, num_layers: int, trainable_size: int = 8, num_channels: int = 128, num_chunks: int = 2,
                  num_heads: int = 16, mlp_hidden_ratio: int = 4, activation: str = "GELU", cpu_offload: bool = False,
@@ -197,9 +292,35 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
         plan = self._plans.get(self.edge_index_base, n, n, batch_size, self.edge_inc, node_map, node_map)
         ea = runtime.edge_attr_csr_cached(self._packed, self.edge_attr, self.trainable.trainable, plan,
                                           *self.proc[0].blocks[0].edge_layout(x.dtype))
+        fast = self._block_abi_plan(x, ea, plan)
+        if fast is not None:
+            return fast.run(x)
         for chunk in self.proc:
             x = chunk.native(x, ea, plan)
         return x
+
+    # ---- block-level C ABI: one FFI call per block (anemoi_gt_processor_block_forward), same kernels, same packed weights
+    block_abi = True  # False: always the op-by-op route (tests compare the two; bench.py's instrumented pass times ops)
+
+    def _block_abi_plan(self, x: Tensor, ea: Tensor, plan):
+        if not self.block_abi or ops.PROFILE is not None or not x.is_cuda or x.dtype != torch.bfloat16 or x.shape[0] == 0:
+            return None
+        if x.stride(1) != 1 or x.stride(0) != x.shape[1] or plan.num_edges == 0:
+            return None
+        params = self.__dict__.get("_abi_params")
+        if params is None:
+            params = self.__dict__["_abi_params"] = [p for p in self.parameters()]
+        # any in-place change of a parameter (optimiser step, load_state_dict, .normal_()) bumps its version counter
+        sig = (sum(p._version for p in params), params[0].data_ptr(), x.shape[0], str(x.device), ea.data_ptr(), id(plan))
+        fast = self.__dict__.get("_abi_plan")
+        if fast is None or fast.sig != sig:
+            fast = self.__dict__["_abi_plan"] = _BlockAbiPlan.build(self, x, ea, plan, sig)
+        return fast if fast.ok else None
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .bfloat16(): new storages behind the cached pointers
+        self.__dict__.pop("_abi_plan", None)
+        self.__dict__.pop("_abi_params", None)
+        return super()._apply(fn, *args, **kwargs)
 
     def native_local(self, x_own: Tensor, local_graph) -> Tensor:
         """Node-partitioned run (``distributed/partition.py``): this rank's mesh rows in, same rows out."""

@@ -382,10 +382,13 @@ def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None) -> Tens
 
 
 def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Optional[Tensor] = None,
-         return_lse: bool = False, dropout_p: float = 0.0, dropout_seed: int = 0):
+         return_lse: bool = False, dropout_p: float = 0.0, dropout_seed: int = 0, head_offset: int = 0,
+         heads_total: int = 0):
     """Multi-head self attention on the fused ``lin_qkv`` output ``[B*S, 3C]`` -> ``[B*S, C]`` (heads concatenated).
     ``return_lse``: also the f32 ``[B, H, S]`` log-sum-exp of the scaled scores (the backward's input).
-    ``dropout_p`` / ``dropout_seed``: attention dropout (training mode of the reference), mask = hash(index, seed)."""
+    ``dropout_p`` / ``dropout_seed``: attention dropout (training mode of the reference), mask = hash(index, seed);
+    ``head_offset`` / ``heads_total``: this call holds the heads ``head_offset ... + num_heads`` of ``heads_total`` (a head
+    shard of a model group draws the mask of the unsharded attention; 0 = all heads)."""
     _dev(qkv, out)
     rows, c3 = _rows(qkv).shape
     c = c3 // 3
@@ -401,13 +404,14 @@ def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Op
     with _Timed("mhsa", flops=4 * batch_size * num_heads * s_len * s_len * d, s=s_len, h=num_heads, d=d):
         st = lib.anemoi_mhsa(code, qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)), _ptr(ws), _ptr(lse),
                              batch_size, s_len, num_heads, d, window, float(dropout_p), int(dropout_seed) & 0xFFFFFFFF,
-                             _stream())
+                             int(head_offset), int(heads_total), _stream())
     _lib.check(st, "anemoi_mhsa")
     return (out, lse) if return_lse else out
 
 
 def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_size: int, num_heads: int,
-                  window: int = -1, dropout_p: float = 0.0, dropout_seed: int = 0) -> Tensor:
+                  window: int = -1, dropout_p: float = 0.0, dropout_seed: int = 0, head_offset: int = 0,
+                  heads_total: int = 0) -> Tensor:
     """``d qkv`` ``[B*S, 3C]`` of :func:`mhsa` from the forward's output and log-sum-exp (``anemoi_mhsa_backward``)."""
     _dev(qkv, out, dout, lse)
     rows, c3 = _rows(qkv).shape
@@ -419,11 +423,11 @@ def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_siz
         raise ValueError("mhsa_backward: lse must be the contiguous f32 [B, H, S] output of mhsa(return_lse=True)")
     lib = _lib.load()
     ws_bytes = lib.anemoi_mhsa_backward_workspace_bytes(dtype_code(qkv.dtype), batch_size, s_len, num_heads, c // num_heads)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 and dropout_p == 0.0 else None
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 else None
     st = lib.anemoi_mhsa_backward(dtype_code(qkv.dtype), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)),
                                   dout.data_ptr(), _ld(_rows(dout)), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), c3,
                                   _ptr(ws), batch_size, s_len, num_heads, c // num_heads, window, float(dropout_p),
-                                  int(dropout_seed) & 0xFFFFFFFF, _stream())
+                                  int(dropout_seed) & 0xFFFFFFFF, int(head_offset), int(heads_total), _stream())
     _lib.check(st, "anemoi_mhsa_backward")
     return dqkv
 

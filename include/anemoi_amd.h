@@ -281,11 +281,16 @@ int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* row
  * other cases use a VALU kernel (workspace may be NULL).
  * dropout_p in [0, 1] (attention dropout of the reference in training mode, layers/attention.py:90): probabilities are
  * dropped AFTER normalisation by a counter-based hash of (batch, head, query, key) and `dropout_seed`, kept ones scaled
- * by 1 / (1 - p); the backward rebuilds the same mask from the same seed.  dropout_p > 0 always takes the VALU kernel.
+ * by 1 / (1 - p); the backward rebuilds the same mask from the same seed.  One 32-bit hash decides the key pair
+ * (2 j, 2 j + 1) of a query, 16 bits each (p is resolved to 2^-16).  The MFMA kernels apply the mask to their packed
+ * probabilities (0 < p < 1, B x heads x S < 2^32); p = 1 takes the VALU kernel.  `dropout_h0` / `dropout_h_total`: the
+ * GLOBAL index of head 0 of this call and the head count of the whole attention (0 = H) -- a head-sharded call
+ * (sequence-parallel attention, distributed/transformer.py:85-130) then draws exactly the mask of the unsharded one.
  */
 int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
-                int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream);
+                int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0, int dropout_h_total,
+                anemoi_stream_t stream);
 
 /*
  * Backward of anemoi_mhsa (what torch autograd derives for the reference's scaled_dot_product_attention call,
@@ -293,14 +298,15 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
  * output (natural-log sum-exp of the scaled scores per query and head; pass NULL to the forward when not training), `out`
  * the forward's result, `dout` its gradient; writes dqkv [B*S, 3C] = dq | dk | dv in `dtype`.  `delta` f32 [B, H, S] is
  * scratch.  Probabilities are recomputed from lse (nothing of size S x S is stored); no atomics.  bf16 with D = 64 / 32
- * and dropout_p = 0: MFMA kernels (one pass with the keys stationary for dK / dV, one with the queries stationary for dQ)
+ * and dropout_p < 1: MFMA kernels (one pass with the keys stationary for dK / dV, one with the queries stationary for dQ)
  * on a `workspace` of anemoi_mhsa_backward_workspace_bytes() bytes (Q^T, K^T, dO^T); otherwise VALU kernels, O(S^2 D) on
  * the vector pipe (workspace may be NULL).
  */
 int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
                          int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, void* workspace, int B,
-                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, anemoi_stream_t stream);
+                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0,
+                         int dropout_h_total, anemoi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Backward pass, dense half (first step): the pieces the autograd of the fused Linear and of
@@ -412,6 +418,52 @@ int anemoi_gt_edge_attention_folded_backward_src(int dtype, const void* q, int64
 int anemoi_gt_edge_attr_grad(int dtype, const float* alpha, const float* w, const float* dsum, const void* u, int64_t ldu,
                              const void* dt, int64_t lddt, const int32_t* dst_of_edge, float* dattr, int64_t n_edges,
                              int H, int up, int D, anemoi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Block-level entry points ("gt_block_fwd(x, ln / lin weights, edge attributes, csr, ..., out,
+ * stream)"): a whole GraphTransformer block's launch sequence from ONE call on the caller's stream -- what
+ * GraphTransformerProcessorBlock.forward (reference layers/block.py:602-635) and the back half of
+ * GraphTransformerMapperBlock.forward (layers/block.py:516-550) do, on the bf16 LayerNorm-folded route: the host mirror
+ * pays one FFI call per block instead of five or six (host enqueue of a forward: 2.6 -> 0.6 ms).  Weights arrive packed
+ * as the op-level entry points above take them (LayerNorm folded in by the caller: W' = W * gamma, column sums of W',
+ * b' = b + W beta; lin_edge folded into W_in / W_proj); every buffer -- workspaces included -- is the caller's.
+ *
+ *   anemoi_gt_block_tail              out = mlp(LN(y)) + y,  y = projection(edge_phase(q, k, v, u) + x_r | t) + res
+ *                                     (edge phase = anemoi_gt_edge_attention_folded; projection = anemoi_linear_stats
+ *                                     with the node MLP's LayerNorm statistics in its epilogue; mlp = LayerNorm-folded
+ *                                     Linear + activation (anemoi_linear_ln), Linear + y (anemoi_linear_stats, or
+ *                                     anemoi_linear when out_stats is NULL))
+ *   anemoi_gt_processor_block_forward the x_r | q | k | v | u product of LayerNorm(x) first (anemoi_linear_ln into
+ *                                     `sq`, whose column ranges then ARE q, k, v, x_r, u), then the tail with res = x.
+ * `struct_bytes` must be sizeof(anemoi_gt_block_args) (layout check across the FFI).  Status codes as everywhere.
+ */
+typedef struct anemoi_gt_block_args {
+  int64_t struct_bytes;
+  int64_t n_dst;           /* destination rows (processor block: all rows)                                       */
+  int32_t dtype;           /* ANEMOI_BF16                                                                        */
+  int32_t C, H, up;        /* channels, heads, folded edge width per head                                        */
+  int32_t hidden, act;     /* node MLP: hidden width, activation code                                            */
+  int32_t k_proj, n_in;    /* projection K (= ld of att: C + H * up, slab padded); columns of the input product  */
+  float eps_mlp, eps_out;  /* epsilon of the node MLP's LayerNorm; of the LayerNorm that consumes `out` next     */
+  /* LayerNorm-folded input product (anemoi_gt_processor_block_forward only) */
+  const void* x; int64_t ldx; const float* x_stats;                 /* [n_dst, C], its row statistics            */
+  const void* w_in; const float* b_in; const float* cs_in;          /* [n_in, C] = x_r | q | k | v | u rows      */
+  void* sq; int64_t ld_sq;                                          /* [n_dst, n_in] workspace                   */
+  /* edge phase (the processor entry point overwrites these with column ranges of sq) */
+  const void* q; const void* k; const void* v; const void* x_r; const void* u;
+  int64_t ldq, ldkv, ldr, ldu;
+  const float* edge_attr; const int32_t* rowptr; const int32_t* col; /* [E, up] f32 CSR order, int32 CSR           */
+  void* att; int64_t ld_att;                                        /* [n_dst, k_proj] workspace; the caller has */
+                                                                    /* ZEROED its columns >= C + H * up (K pad)  */
+  /* projection (+ res) -> y and the statistics of the node MLP's LayerNorm */
+  const void* w_proj; const float* b_proj; const void* res; int64_t ld_res; void* y; float* y_stats;
+  /* node MLP */
+  const void* w_fc1; const float* b_fc1; const float* cs_fc1; void* h;  /* [hidden, C] LayerNorm-folded; [n_dst, hidden] */
+  const void* w_fc2; const float* b_fc2; void* out; float* out_stats;   /* [C, hidden]; out [n_dst, C]; NULL: no stats   */
+  void* stats_ws; int64_t stats_ws_bytes;                           /* >= n_dst * max(C / 128, 1) * 8 bytes      */
+} anemoi_gt_block_args;
+int anemoi_gt_block_tail(const anemoi_gt_block_args* args, anemoi_stream_t stream);
+int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 
 #ifdef __cplusplus
 }

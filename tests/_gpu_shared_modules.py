@@ -77,6 +77,17 @@ def main():
                 err = max(err, float((part - full[k].cpu()).abs().max()))
                 scale = max(scale, float(full[k].abs().max()))
             info[name + ".grad"] = err / max(scale, 1e-30)
+        # attention dropout across the group (reference layers/processor.py:99: dropout_p = 0.1 by default): rank 0's seed
+        # for all, the global head index in the mask's hash -> the ranks together drop what the unsharded attention drops
+        drop = TransformerProcessor(num_layers=2, window_size=None, num_channels=c, num_chunks=1, num_heads=heads,
+                                    mlp_hidden_ratio=2, dropout_p=0.3).to(dev).train()
+        with torch.no_grad():
+            torch.manual_seed(99)  # the blocks draw their seeds from torch's CPU generator: the same draws on both routes
+            want = drop(xh, 1, [list(xh.shape)])
+            torch.manual_seed(99)
+            got = drop(xh[rows].contiguous(), 1, sh, g)
+            info["tfm_dropout.fwd"] = float((got - want[rows]).abs().max() / want.abs().max())
+            info["tfm_dropout.acts"] = float((want - drop.eval()(xh, 1, [list(xh.shape)])).abs().max() > 0)  # dropout did act
         enc = GraphTransformerForwardMapper(in_channels_src=20, in_channels_dst=6, hidden_dim=c, trainable_size=2,
                                             num_heads=heads, mlp_hidden_ratio=2, sub_graph=graph[("data", "to", "hidden")],
                                             sub_graph_edge_attributes=attrs, src_grid_size=n_d, dst_grid_size=n_h).to(dev).eval()

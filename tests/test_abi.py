@@ -37,3 +37,24 @@ def test_argument_validation_without_gpu():
     assert st == _lib.ANEMOI_ERR_INVALID and b"null pointer" in lib.anemoi_last_error()
     st = lib.anemoi_linear(1, 1, 16, 48, 16, None, None, 0, 16, 8, 4, 8, 48, 0, None)  # K = 48: not slab padded
     assert st == _lib.ANEMOI_ERR_INVALID and b"multiple" in lib.anemoi_last_error()
+
+
+def test_block_level_entry_points_validate_their_argument_block_without_gpu():
+    """anemoi_gt_block_tail / anemoi_gt_processor_block_forward (SURVEY section 8b's block-level boundary): the ctypes
+    mirror of ``anemoi_gt_block_args`` has the size the library was compiled with, and a bad block is refused with a
+    status code before anything is launched."""
+    from anemoi_models_amd import _lib
+
+    lib = _lib.load()
+    a = _lib.GtBlockArgs()
+    assert lib.anemoi_gt_block_tail(None, None) == _lib.ANEMOI_ERR_INVALID and b"null argument" in lib.anemoi_last_error()
+    a.struct_bytes = ctypes.sizeof(_lib.GtBlockArgs) - 8
+    assert lib.anemoi_gt_processor_block_forward(ctypes.byref(a), None) == _lib.ANEMOI_ERR_INVALID
+    assert b"out of sync" in lib.anemoi_last_error()
+    a.struct_bytes = ctypes.sizeof(_lib.GtBlockArgs)  # the layout check passes: both sides agree on sizeof
+    a.dtype = _lib.F32
+    assert lib.anemoi_gt_processor_block_forward(ctypes.byref(a), None) == _lib.ANEMOI_ERR_UNSUPPORTED
+    assert b"bf16" in lib.anemoi_last_error()
+    a.dtype, a.n_dst, a.C, a.H, a.up, a.hidden, a.k_proj, a.ld_att = _lib.BF16, 16, 64, 4, 4, 128, 64, 128
+    assert lib.anemoi_gt_block_tail(ctypes.byref(a), None) == _lib.ANEMOI_ERR_INVALID  # K of the projection < C + H * up
+    assert b"projection K" in lib.anemoi_last_error()

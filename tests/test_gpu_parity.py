@@ -264,6 +264,63 @@ def test_gt_edge_attention_folded(dtype, n_src, n_dst, e, c, h, edge_dim):
     assert torch.all(got[:, c + h * up:] == 0)
 
 
+@pytest.mark.parametrize("graph_name,channels,layers,heads", [("o32_ico2", 64, 4, 4), ("o96_ico5", 512, 4, 16)])
+def test_block_level_entry_point_is_the_op_by_op_route(graph_name, channels, layers, heads, monkeypatch):
+    """anemoi_gt_processor_block_forward (one FFI call per block: LayerNorm-folded x_r|q|k|v|u product, edge phase,
+    projection + residual, node MLP; reference layers/block.py:602-635) issues exactly the launches of the op-by-op route on
+    the same packed weights: the processor's output is BIT-IDENTICAL, through the module and through a direct ctypes
+    call of the entry point; a parameter update is picked up (the argument blocks are rebuilt)."""
+    import ctypes
+
+    from anemoi_models_amd import _lib, ops
+    from anemoi_models_amd.graphs.synthetic import build_graph
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    graph = build_graph(graph_name)
+    torch.manual_seed(3)
+    model, _ = _build(graph, channels, layers, heads=heads)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("trainable"):
+                p.normal_(0.0, 0.1)
+    model = model.to(DEV).eval()
+    proc = model.processor
+    n = graph["hidden"].num_nodes
+    x = (torch.randn(n, channels, generator=torch.Generator().manual_seed(1)) * 0.7).bfloat16().to(DEV)
+    calls = []
+    real = _lib.load().anemoi_gt_processor_block_forward
+    with torch.no_grad():
+        proc.block_abi = False
+        want = proc.native(x, 1)
+        proc.block_abi = True
+        got = proc.native(x, 1)
+        plan = proc.__dict__["_abi_plan"]
+        assert plan.ok and len(plan.args) == layers
+        assert torch.equal(got, want)
+        assert torch.equal(proc.native(x, 1), want) and got.data_ptr() != proc.native(x, 1).data_ptr()
+        # the entry point itself, called as a foreign caller would: block 0 on its argument block
+        a = plan.args[0]
+        stats = ops.row_stats(x, proc.proc[0].blocks[0].layer_norm1.eps)
+        a.x, a.x_stats = x.data_ptr(), stats.data_ptr()
+        out0 = torch.empty(n, channels, dtype=torch.bfloat16, device=DEV)
+        old_out = a.out
+        a.out = out0.data_ptr()
+        assert real(ctypes.byref(a), ops._stream()) == 0
+        a.out = old_out
+        proc.block_abi = False
+        blk0 = proc.proc[0].blocks[0]
+        ea = plan.keep[1]
+        assert torch.equal(out0, blk0.native(x, ea, plan.keep[2]))
+        proc.block_abi = True
+        # a weight update invalidates the argument blocks
+        blk0.lin_query.weight.mul_(1.5)
+        got2 = proc.native(x, 1)
+        assert proc.__dict__["_abi_plan"] is not plan and not torch.equal(got2, want)
+        proc.block_abi = False
+        assert torch.equal(got2, proc.native(x, 1))
+    del calls
+
+
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
     from anemoi_models_amd import runtime
 

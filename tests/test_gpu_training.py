@@ -279,26 +279,36 @@ def test_transformer_model_training_step_vs_oracle_autograd(graph_o32, golden_cf
     assert any("attention.lin_qkv" in k for k in used) and any("attention.projection" in k for k in used)
 
 
-def _dropout_keep_mask(seed: int, p: float, b: int, h: int, s: int) -> torch.Tensor:
+def _dropout_keep_mask(seed: int, p: float, b: int, h: int, s: int, h0: int = 0, h_total: int = 0) -> torch.Tensor:
     """The kernels' counter-based keep mask (csrc/attention.hip::dropout_keep) restated with torch integer arithmetic:
-    [B, H, S, S] of 0 / 1."""
+    [B, H, S, S] of 0 / 1.  One lowbias32 hash of (row, key >> 1) decides a key pair, 16 bits per key."""
     m32 = 0xFFFFFFFF
-    row = torch.arange(b * h * s, dtype=torch.int64).view(b, h, s, 1)  # (b * H + h) * S + i
+    h_total = h_total or h
+    bb = torch.arange(b, dtype=torch.int64).view(b, 1, 1, 1)
+    hh = torch.arange(h, dtype=torch.int64).view(1, h, 1, 1) + h0
+    qq = torch.arange(s, dtype=torch.int64).view(1, 1, s, 1)
+    row = (bb * h_total + hh) * s + qq  # (b * H_total + h0 + h) * S + i
     col = torch.arange(s, dtype=torch.int64).view(1, 1, 1, s)
     x = ((row & m32) * 0x9E3779B1) & m32
-    x = x ^ (((row >> 32) * 0x85EBCA77) & m32) ^ ((col * 0xC2B2AE3D) & m32) ^ (seed & m32)
+    x = x ^ (((row >> 32) * 0x85EBCA77) & m32) ^ (seed & m32)
+    x = x ^ (((col >> 1) * 0xC2B2AE3D) & m32)
     x = x ^ (x >> 16)
     x = (x * 0x7FEB352D) & m32
     x = x ^ (x >> 15)
     x = (x * 0x846CA68B) & m32
     x = x ^ (x >> 16)
-    thr = min(int(p * 4294967296.0), 4294967295)
-    return (x >= thr).to(torch.float64) if p < 1.0 else torch.zeros(b, h, s, s, dtype=torch.float64)
+    bits = (x >> (16 * (col & 1))) & 0xFFFF
+    thr = min(int(p * 65536.0 + 0.5), 65535)
+    return (bits >= thr).to(torch.float64) if p < 1.0 else torch.zeros(b, h, s, s, dtype=torch.float64)
 
 
 @pytest.mark.parametrize("dtype,b,s,h,d,window,p", [
     (torch.float32, 2, 150, 3, 5, -1, 0.3), (torch.float32, 1, 97, 2, 16, 20, 0.5), (torch.bfloat16, 1, 200, 4, 64, -1, 0.1),
     (torch.float32, 1, 64, 2, 8, -1, 1.0), (torch.bfloat16, 2, 130, 4, 32, -1, 0.25),
+    # the MFMA kernels (bf16, D = 64 / 32): whole 512-query blocks + a ragged one, the key-split rows behind the last
+    # block (S = 514), a sliding window, D = 32
+    (torch.bfloat16, 1, 700, 4, 64, -1, 0.1), (torch.bfloat16, 1, 514, 2, 64, -1, 0.3), (torch.bfloat16, 2, 700, 4, 32, -1, 0.25),
+    (torch.bfloat16, 1, 1100, 2, 64, 70, 0.2),
 ])
 def test_mhsa_attention_dropout_forward_and_backward(dtype, b, s, h, d, window, p):
     """Attention dropout (reference layers/attention.py:90-105, training mode): forward and gradients against torch
@@ -335,6 +345,34 @@ def test_mhsa_attention_dropout_forward_and_backward(dtype, b, s, h, d, window, 
     again = autograd.mhsa(qkv.to(DEV), b, h, window, p, seed)
     other = autograd.mhsa(qkv.to(DEV), b, h, window, p, seed + 1)
     assert torch.equal(again, got.detach()) and not torch.equal(other, got.detach())
+
+
+def test_mhsa_attention_dropout_on_the_mfma_kernels_at_mesh_size():
+    """Attention dropout at the sequence length of BASELINE config 2's mesh (S = 10 242 = 20 blocks of 512 queries + 2
+    key-split rows, heads of 64, bf16: the MFMA forward / dK dV / dQ kernels with the mask applied to their packed
+    probabilities) against torch autograd in f64 with the restated mask; the reference's constructor default p = 0.1
+    (layers/processor.py:99)."""
+    from anemoi_models_amd import autograd
+
+    b, s, h, d, p = 1, 10242, 2, 64, 0.1
+    g = torch.Generator().manual_seed(5)
+    seed, c = 20260101, h * d
+    qkv = (torch.randn(b * s, 3 * c, generator=g) * 0.8).bfloat16()
+    dout = torch.randn(b * s, c, generator=g).bfloat16()
+    keep = _dropout_keep_mask(seed, p, b, h, s)
+    assert abs(float(keep.mean()) - (1.0 - p)) < 2e-3
+    ref_in = qkv.double().requires_grad_()
+    q, k, v = (t.reshape(b, s, h, d).permute(0, 2, 1, 3) for t in ref_in.split(c, dim=1))
+    prob = torch.softmax(q @ k.transpose(-1, -2) / d**0.5, -1) * keep * (1.0 / (1.0 - p))
+    want = (prob @ v).permute(0, 2, 1, 3).reshape(b * s, c)
+    want.backward(dout.double())
+    x = qkv.to(DEV).requires_grad_()
+    got = autograd.mhsa(x, b, h, -1, p, seed)
+    got.backward(dout.to(DEV))
+    e_out, e_grad = rel_err(got.detach(), want.detach()), rel_err(x.grad, ref_in.grad)
+    print(f"MFMA attention dropout p = {p} at S = {s}: output rel err {e_out:.3e}, d qkv rel err {e_grad:.3e}")
+    assert e_out < 2e-2 and e_grad < 3e-2
+    assert torch.equal(autograd.mhsa(qkv.to(DEV), b, h, -1, p, seed), got.detach())
 
 
 @pytest.mark.parametrize("batch_size,num_heads,mult,p", [(3, 4, 5, 0.4), (8, 1, 10, 0.0), (2, 20, 1, 1.0), (5, 7, 3, 0.73)])
@@ -476,6 +514,7 @@ def test_module_level_model_groups_ranks_sharing_one_gpu(tmp_path):
     assert codes == [0, 0]
     for r in range(2):
         info = torch.load(f"{out}.{r}")
-        assert len(info) == 8, sorted(info)
+        assert len(info) == 10, sorted(info)
+        assert info.pop("tfm_dropout.acts") == 1.0  # the train-mode call really dropped probabilities
         for k, v in info.items():
             assert v < (2e-5 if k.endswith(".fwd") else 2e-4), (r, k, v)
