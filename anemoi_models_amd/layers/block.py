@@ -340,6 +340,55 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         return dict(up=up, w_in=w_in, b_in=b_in, cs_in=cs_in, w_proj=w_proj, b_proj=b_proj, eps_mlp=eps_mlp, act=act, w_fc1=w1,
                     b_fc1=b1, cs_fc1=cs1, w_fc2=w2, b_fc2=b2, eps_ln1=ln.eps)
 
+    def _block_tail(self, q: Tensor, k: Tensor, v: Tensor, x_r: Tensor, u: Tensor, edge_attr_csr: Tensor, plan, res: Tensor,
+                    up: int, out_stats_eps: Optional[float]) -> Optional[Tensor]:
+        """Edge phase -> projection (+ ``res``) -> node MLP (+ skip) as ONE call of ``anemoi_gt_block_tail`` (the launches
+        and packed weights of ``folded_edge_phase`` + ``ops.linear`` + ``_node_mlp``; bit-identical), or ``None`` when this
+        block / call has to go op by op (f32, LayerNorm fold off, another MLP shape, bench.py's per-kernel timing pass)."""
+        import ctypes
+
+        from .. import _lib
+
+        dtype = q.dtype
+        if (ops.PROFILE is not None or dtype != torch.bfloat16 or not q.is_cuda or plan.num_edges == 0 or q.shape[0] == 0
+                or not self.block_abi or self._mlp_ln_eps("dst", dtype) is None):
+            return None
+        if self._dst_mlp is None:
+            self._dst_mlp = NativeSequential(self.node_dst_mlp)
+        mlp = self._dst_mlp.folded_pair(dtype)
+        if mlp is None or not (res.dim() == 2 and res.stride(1) == 1):
+            return None
+        eps_mlp, act, w1, b1, cs1, w2, b2 = mlp
+        wp, bp = self._folded_out(dtype, up)
+        n, c, h = q.shape[0], q.shape[1], self.num_heads
+        dev = q.device
+        att = torch.empty((n, wp.shape[1]), dtype=dtype, device=dev)
+        if wp.shape[1] > c + h * up:
+            att[:, c + h * up:].zero_()
+        y, hid, out = (torch.empty((n, w), dtype=dtype, device=dev) for w in (c, w1.shape[0], c))
+        stats = torch.empty((2 if out_stats_eps is not None else 1, n, 2), dtype=torch.float32, device=dev)
+        ws = torch.empty((n * max(c // 128, 1), 2), dtype=torch.float32, device=dev)
+        a = _lib.GtBlockArgs()
+        a.struct_bytes, a.n_dst, a.dtype = ctypes.sizeof(_lib.GtBlockArgs), n, ops.dtype_code(dtype)
+        a.C, a.H, a.up, a.hidden, a.act, a.k_proj = c, h, up, w1.shape[0], _lib.ACT_CODES[act], wp.shape[1]
+        a.eps_mlp, a.eps_out = eps_mlp, (out_stats_eps if out_stats_eps is not None else 0.0)
+        a.q, a.k, a.v, a.x_r, a.u = q.data_ptr(), k.data_ptr(), v.data_ptr(), x_r.data_ptr(), u.data_ptr()
+        a.ldq, a.ldkv, a.ldr, a.ldu = ops._ld(q), ops._ld(k), ops._ld(x_r), ops._ld(u)
+        a.edge_attr, a.rowptr, a.col = edge_attr_csr.data_ptr(), plan.rowptr.data_ptr(), plan.col.data_ptr()
+        a.att, a.ld_att = att.data_ptr(), wp.shape[1]
+        a.w_proj, a.b_proj = wp.data_ptr(), ops._ptr(bp)
+        a.res, a.ld_res, a.y, a.y_stats = res.data_ptr(), ops._ld(res), y.data_ptr(), stats[0].data_ptr()
+        a.w_fc1, a.b_fc1, a.cs_fc1, a.h = w1.data_ptr(), ops._ptr(b1), cs1.data_ptr(), hid.data_ptr()
+        a.w_fc2, a.b_fc2, a.out = w2.data_ptr(), ops._ptr(b2), out.data_ptr()
+        a.out_stats = stats[1].data_ptr() if out_stats_eps is not None else None
+        a.stats_ws, a.stats_ws_bytes = ws.data_ptr(), ws.numel() * 4
+        _lib.check(_lib.load().anemoi_gt_block_tail(ctypes.byref(a), ops._stream()), "anemoi_gt_block_tail")
+        if out_stats_eps is not None:
+            ops._carry_stats(out, out_stats_eps, stats[1])
+        return out
+
+    block_abi = True  # False: op by op (tests compare the two routes)
+
     def _node_mlp(self, y: Tensor, which: str, num_chunks: int, out_stats_eps: Optional[float] = None) -> Tensor:
         """``mlp(y) + y`` with mlp = LayerNorm, Linear, act, Linear; optionally in row chunks (bounded hidden buffer)."""
         if which == "dst":
@@ -403,6 +452,10 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
                                  lambda: self._folded_rows(sq_layers, up),
                                  self._fold_params(sq_layers))  # ... overlapped with the x_r | q | u GEMM
             halo.finish(pending)
+            done = self._block_tail(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan, x, up,
+                                    self._next_ln_eps(dtype))
+            if done is not None:
+                return done
             att = folded_edge_phase(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan,
                                     self.num_heads, up, ld_out=wpf.shape[1])
             y = ops.linear(att, wpf, bp, residual=x, stats_eps=self._mlp_ln_eps("dst", dtype))
@@ -413,6 +466,10 @@ class GraphTransformerProcessorBlock(GraphTransformerBaseBlock):
             sq = self._ln_linear(xh, "sqkvu", lambda: self._folded_in("sqkvu", all4, dtype, up),
                                  lambda: self._folded_rows(all4, up),
                                  self._fold_params(all4))  # [N, 4C + H*up] = x_r | q | k | v | u
+            done = self._block_tail(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
+                                    edge_attr_csr, plan, x, up, self._next_ln_eps(dtype))
+            if done is not None:
+                return done
             att = folded_edge_phase(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
                                     edge_attr_csr, plan, self.num_heads, up, ld_out=wpf.shape[1])
             # projection(out + x_r) + x_skip, lin_edge part via W_t; the statistics of the MLP's LayerNorm ride on the
@@ -530,6 +587,11 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
             del xd
             if halo is not None:
                 halo.finish(pending)
+            if num_chunks <= 1 and not self.update_src_nodes:
+                done = self._block_tail(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan,
+                                        h_dst, up, out_stats_eps)
+                if done is not None:
+                    return (x_src.h if isinstance(x_src, EmbeddedRows) else x_src), done
             att = folded_edge_phase(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr_csr, plan,
                                     self.num_heads, up, ld_out=wp.shape[1])
         else:

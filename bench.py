@@ -16,7 +16,8 @@ The JSON line also carries
                 from HIP events on the launch stream in a separate instrumented pass (not inside the timed region);
   roofline_edge the fused gather/scatter edge kernel against the HBM roofline (algorithmic bytes of section 8d);
   cpu_baseline  the CPU oracle (plain PyTorch, same algorithm as the reference) timed on this host's cores on the same
-                forward: encoder and decoder in full, a bounded number of the identical processor blocks, scaled.
+                forward (all of it by default; --cpu-blocks N runs N of the identical processor blocks and scales), with
+                the parity of this run's device results against the oracle's outputs beside it.
 ``value`` / ``ms_per_step`` come from the K-step bracket the driver's contract prescribes (mean); ``ms_per_step_median``
 / ``value_at_median`` are the per-step median (device events on the launch stream, rank 0) SURVEY section 8d asks for.
 """
@@ -57,8 +58,9 @@ def parse_args():
                     help="processor family (BASELINE config 5 = --workload cfg2 --processor GNN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=None,
-                    help="processor blocks the CPU-baseline sample runs (default: 1 for cfg3, all for cfg1 / cfg2); the "
-                         "encoder and decoder always run in full")
+                    help="processor blocks the CPU-baseline sample runs (default: all of them -- at config 3 the whole "
+                         "forward takes ~2.5 min on the GPU box's 128 host threads and doubles as the full-size parity check; "
+                         "fewer blocks: the sample is scaled); the encoder and decoder always run in full")
     ap.add_argument("--rollout", type=int, default=1,
                     help="autoregressive forecasts per step (BASELINE config 4 = --rollout 4): forward, then the "
                          "in-place input update anemoi_advance_input, repeated")
@@ -481,7 +483,7 @@ def main():
         if args.processor != "GraphTransformer":
             line["config"]["workload"] = line["config"]["workload"].replace("GT blocks", f"{args.processor} blocks")
         if not args.no_cpu_baseline and world == 1 and args.processor == "GraphTransformer":
-            n_cpu = args.cpu_blocks if args.cpu_blocks is not None else (1 if args.workload == "cfg3" else layers)
+            n_cpu = args.cpu_blocks if args.cpu_blocks is not None else layers
             # the device's encoder output (mesh latent, internal Morton row order -> external node order) and prediction
             # for the same input, for the parity figures next to the baseline
             captured = {}

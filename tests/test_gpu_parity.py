@@ -287,12 +287,21 @@ def test_block_level_entry_point_is_the_op_by_op_route(graph_name, channels, lay
     proc = model.processor
     n = graph["hidden"].num_nodes
     x = (torch.randn(n, channels, generator=torch.Generator().manual_seed(1)) * 0.7).bfloat16().to(DEV)
-    calls = []
+    from anemoi_models_amd.layers.block import GraphTransformerBaseBlock
+
+    def op_by_op(on: bool):  # processor-level plan AND the blocks' own anemoi_gt_block_tail calls
+        proc.block_abi = not on
+        monkeypatch.setattr(GraphTransformerBaseBlock, "block_abi", not on)
+
     real = _lib.load().anemoi_gt_processor_block_forward
     with torch.no_grad():
-        proc.block_abi = False
+        op_by_op(True)
         want = proc.native(x, 1)
-        proc.block_abi = True
+        y_model = model(torch.randn(1, 2, 1, graph["data"].num_nodes, 12, generator=torch.Generator().manual_seed(2)).to(DEV))
+        op_by_op(False)
+        # the whole model: mapper blocks through anemoi_gt_block_tail, processor blocks through the resident plan
+        assert torch.equal(model(torch.randn(1, 2, 1, graph["data"].num_nodes, 12,
+                                             generator=torch.Generator().manual_seed(2)).to(DEV)), y_model)
         got = proc.native(x, 1)
         plan = proc.__dict__["_abi_plan"]
         assert plan.ok and len(plan.args) == layers
@@ -307,18 +316,18 @@ def test_block_level_entry_point_is_the_op_by_op_route(graph_name, channels, lay
         a.out = out0.data_ptr()
         assert real(ctypes.byref(a), ops._stream()) == 0
         a.out = old_out
-        proc.block_abi = False
         blk0 = proc.proc[0].blocks[0]
         ea = plan.keep[1]
+        assert torch.equal(out0, blk0.native(x, ea, plan.keep[2]))  # the block on its own: x_r|q|k|v|u GEMM + block tail
+        op_by_op(True)
         assert torch.equal(out0, blk0.native(x, ea, plan.keep[2]))
-        proc.block_abi = True
+        op_by_op(False)
         # a weight update invalidates the argument blocks
         blk0.lin_query.weight.mul_(1.5)
         got2 = proc.native(x, 1)
         assert proc.__dict__["_abi_plan"] is not plan and not torch.equal(got2, want)
-        proc.block_abi = False
+        op_by_op(True)
         assert torch.equal(got2, proc.native(x, 1))
-    del calls
 
 
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
