@@ -446,3 +446,60 @@ class GraphedForward:
         self.static_x.copy_(x)
         self.graph.replay()
         return self.static_y
+
+
+class GraphedTrainStep:
+    """One TRAINING step -- forward, loss, backward, optionally the optimizer step -- captured in a HIP graph and replayed.
+
+    The differentiable route issues several hundred launches per step from Python and from autograd's backward thread;
+    below the N320 grid the step is bound by that host work, not by the GPU (config 2: 10 ms of forward enqueue for 10 ms
+    of GPU work).  The capture follows torch's whole-network recipe: warm-up steps on a side stream, gradients set to
+    ``None`` so that the captured backward allocates them from the graph's private pool, then every replay rewrites the
+    same ``.grad`` tensors in place.  ``loss_fn(y, target)`` must be sync-free torch code; an ``optimizer`` must be
+    capturable (``torch.optim.Adam(..., capturable=True)`` / SGD).  Without one the caller steps on ``param.grad`` after
+    each call (and must not set the gradients to ``None``).  Shapes are frozen at capture time; parameters are read in
+    place, so optimizer updates between replays are seen.
+
+    torch's capture rule applies: no autograd graph over the model's parameters may be alive when this is built (drop
+    references to the losses / outputs of earlier eager steps) -- a surviving graph keeps the parameters' gradient
+    accumulators bound to the stream it ran on, the captured backward then touches that stream and the HIP runtime
+    aborts the capture (observed as a crash in ``capture_end``).
+    """
+
+    def __init__(self, model, loss_fn, example_x: Tensor, example_target: Tensor, optimizer=None, warmup: int = 3) -> None:
+        if not example_x.is_cuda:
+            raise ValueError("GraphedTrainStep: the example input must live on the GPU")
+        self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
+        self.static_x, self.static_target = example_x.clone(), example_target.clone()
+        params = [p for p in model.parameters() if p.requires_grad]
+
+        def zero():
+            for p in params:
+                p.grad = None
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                zero()
+                loss_fn(model(self.static_x), self.static_target).backward()
+                if optimizer is not None:
+                    optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        zero()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_y = model(self.static_x)
+            self.static_loss = loss_fn(self.static_y, self.static_target)
+            self.static_loss.backward()
+            if optimizer is not None:
+                optimizer.step()
+
+    def __call__(self, x: Tensor, target: Tensor) -> Tensor:
+        if x.shape != self.static_x.shape or target.shape != self.static_target.shape:
+            raise ValueError("GraphedTrainStep: input / target shape differs from the captured one")
+        self.static_x.copy_(x)
+        self.static_target.copy_(target)
+        self.graph.replay()
+        return self.static_loss

@@ -177,6 +177,74 @@ def test_checkpointing_reproduces_the_gradients_bit_for_bit(graph_o32, golden_cf
     assert res["1"][2] < 0.6 * res["0"][2], (res["1"][2], res["0"][2])
 
 
+@pytest.mark.parametrize("checkpoint", ["1", "0"])
+def test_training_step_captured_in_a_hip_graph(graph_o32, golden_cfg1_gt, monkeypatch, checkpoint):
+    """runtime.GraphedTrainStep: forward + loss + backward captured once, replayed on new inputs -- loss and every
+    parameter gradient equal the eager step's bit for bit (the kernels are deterministic and the graph replays the same
+    launches); with a capturable optimizer inside the graph, two replays equal two eager steps."""
+    from test_gpu_parity import _build
+
+    from anemoi_models_amd.runtime import GraphedTrainStep
+
+    monkeypatch.setenv("ANEMOI_AMD_CHECKPOINT", checkpoint)
+    gold = golden_cfg1_gt
+    gen = torch.Generator().manual_seed(5)
+    xs = [gold["x"].to(DEV), (gold["x"] + 0.1 * torch.randn(gold["x"].shape, generator=gen)).to(DEV)]
+    ts = [torch.randn(gold["y"].shape, generator=gen).to(DEV) for _ in xs]
+    loss_fn = lambda y, t: ((y - t) ** 2).mean()  # noqa: E731
+
+    def fresh():
+        model, _ = _build(graph_o32, 64, 4)
+        model.load_state_dict(split_prefix(gold, "sd."))
+        return model.to(DEV).train()
+
+    # gradients only.  (The eager steps live in a function: an autograd graph of an earlier step that is still referenced --
+    # a kept ``loss`` -- pins the parameters' AccumulateGrad nodes to the stream it was built on, and a capture that
+    # reuses them touches that stream: torch's whole-network capture rule, see GraphedTrainStep.)
+    model = fresh()
+
+    def eager_step(x, t):
+        for p in model.parameters():
+            p.grad = None
+        loss = loss_fn(model(x), t)
+        loss.backward()
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    want = [eager_step(x, t) for x, t in zip(xs, ts)]
+    graphed = GraphedTrainStep(model, loss_fn, torch.zeros_like(xs[0]), torch.zeros_like(ts[0]))
+    for (x, t), (wl, wg) in zip(zip(xs, ts), want):
+        gl = graphed(x, t)
+        assert torch.equal(gl, wl)
+        got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        assert set(got) == set(wg) and len(wg) > 20
+        for k, g in wg.items():
+            assert torch.equal(got[k], g), k
+
+    # optimizer step inside the graph
+    eager, captured = fresh(), fresh()
+    opt_e = torch.optim.SGD(eager.parameters(), lr=1e-2, momentum=0.9)
+    opt_c = torch.optim.SGD(captured.parameters(), lr=1e-2, momentum=0.9)
+    graphed = GraphedTrainStep(captured, loss_fn, xs[0], ts[0], optimizer=opt_c, warmup=1)
+    # the warm-up step is a real optimizer step on the example; bring the eager model to the same state
+    opt_e.zero_grad(set_to_none=True)  # (the capture pass records, it does not run: one step, not two)
+    loss_fn(eager(xs[0]), ts[0]).backward()
+    opt_e.step()
+
+    def eager_opt_step(x, t):
+        opt_e.zero_grad(set_to_none=True)
+        le = loss_fn(eager(x), t)
+        le.backward()
+        opt_e.step()
+        return le.detach()
+
+    for x, t in zip(xs, ts):
+        le = eager_opt_step(x, t)
+        lc = graphed(x, t)
+        assert rel_err(lc.detach(), le) < 1e-6
+    for (k, pe), (_, pc) in zip(eager.named_parameters(), captured.named_parameters()):
+        assert rel_err(pc.detach(), pe.detach()) < 1e-5, k
+
+
 def test_training_with_boundings(graph_o32, golden_cfg1_gt):
     """A model with a ``bounding:`` list under autograd: the forward equals the reference golden output and the clamps
     cut the gradient where they bite."""

@@ -23,13 +23,33 @@ target = torch.zeros((1, 1, graph["data"].num_nodes, 80), device=dev)
 
 def step():
     y = model(x)
+    if os.environ.get("TRAIN_BENCH_PHASE") == "forward":  # profiling aid: the differentiable forward alone
+        return 0.0
     loss = ((y - target) ** 2).mean()
     loss.backward()
     for p in model.parameters():
         p.grad = None
-    return float(loss)
+    return float(loss.detach())
 
 
+if os.environ.get("TRAIN_BENCH_GRAPH") == "1":  # the whole step as one HIP graph (runtime.GraphedTrainStep)
+    from anemoi_models_amd.runtime import GraphedTrainStep
+
+    eager_loss = step()
+    g = GraphedTrainStep(model, lambda y, t: ((y - t) ** 2).mean(), x, target)
+    l0 = float(g(x, target))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lg = g(x, target)
+    host = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    layers = bench.WORKLOADS[workload][2]
+    print(f"{workload} {processor} (HIP graph): forward + backward {ms:.1f} ms / step (host {host:.2f} ms) = "
+          f"{graph['hidden'].num_nodes * layers / ms * 1e3:.3e} mesh-node updates/s (loss {float(lg):.6f}, eager {eager_loss:.6f})",
+          flush=True)
+    sys.exit(0)
 step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
