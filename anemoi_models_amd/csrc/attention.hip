@@ -16,6 +16,9 @@
 //
 // `window` >= 0 applies flash-attn's sliding window (key j visible from query i iff |i - j| <= window);
 // window < 0 = global attention (the reference's SDPA fallback, layers/attention.py:99-105).
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 
 namespace anemoi {
@@ -136,8 +139,10 @@ template <int ATT_D, bool DROP = false>
 // softmax's ~6 (two of them 32-bit multiplies).
 __global__ __launch_bounds__(512, (ATT_D == 32 && !DROP) ? 4 : 2) void mhsa_bf16_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int64_t ldo, int S,
-    int S_pad, int H, int C, int window, float scale_log2e, float* __restrict__ lse, const AttnDropout dr) {
+    int S_pad, int H, int C, int window, float scale_log2e, float* __restrict__ lse, const AttnDropout dr,
+    const int* __restrict__ run_flag = nullptr) {  // optional: run only if *run_flag != 0 (fallback of mhsa_bf16_w4_kernel)
   static_assert(ATT_D == 32 || ATT_D == 64, "head sizes with an MFMA path");
+  if (run_flag != nullptr && *run_flag == 0) return;
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32;
   constexpr int KRB = ATT_D * 2;                        // bytes of a key row in the K tile
   constexpr int K_TILE = ATT_KV * KRB, V_TILE = ATT_D * 128;
@@ -344,6 +349,355 @@ __global__ __launch_bounds__(512, (ATT_D == 32 && !DROP) ? 4 : 2) void mhsa_bf16
     float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if constexpr (DROP) inv *= dr.keep_scale;
     if (lse != nullptr && half == 0 && qn[qb] < S)  // natural-log sum-exp of the scaled scores (training: backward input)
+      lse[((int64_t)b * H + h) * S + qn[qb]] = (m_run[qb] + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+    if (qn[qb] < S) {
+      bf16_t* op = out + ((int64_t)b * S + qn[qb]) * ldo + h * ATT_D;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v4[4] = {o_acc[qb][dt][4 * g] * inv, o_acc[qb][dt][4 * g + 1] * inv,
+                               o_acc[qb][dt][4 * g + 2] * inv, o_acc[qb][dt][4 * g + 3] * inv};
+          VecIO<bf16_t, 4>::store(op + dt * 32 + 8 * g + 4 * half, v4);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// D = 64, FOUR waves x 128 queries per workgroup (one wave per SIMD, the 512-register budget of the GEMM kernel), software
+// pipelined by 32-key blocks: while the VALU runs the softmax of block j, the matrix pipe runs S^T of block j + 1 and the
+// P V product of block j - 1 of the SAME wave (independent accumulators), instead of two waves per SIMD taking turns in
+// the same phase (profiles/r02_mhsa_lab.md: VALU-active 55 % + MFMA-busy 34 % = 89 % of the cycles).  K / V^T fragments feed
+// four query blocks (half the LDS -> register traffic per MFMA of the 8-wave kernel).  A tile's barrier sits between its two
+// blocks: the K fragments of the next tile are first needed by the second block's matrix phase.
+// ---------------------------------------------------------------------------------------------
+constexpr int W4_WAVES = 4, W4_QB = 4, W4_QPW = 32 * W4_QB;  // 4 x 128 = the 8-wave kernel's 512 queries per workgroup
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                           const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+                                                           int64_t ldo, int S, int S_pad, int H, int C,
+                                                           float scale_log2e, float* __restrict__ lse, const AttnDropout dr,
+                                                           int* __restrict__ redo_flag) {
+  constexpr int ATT_D = 64, NKS = 4, NDT = 2, KRB = 128;
+  constexpr int K_TILE = ATT_KV * KRB, V_TILE = ATT_D * 128, ATT_STAGE = K_TILE + V_TILE;
+  constexpr int N_STAGE = 4;  // tile kt + 2 is requested behind barrier kt; the V^T half of tile kt - 1 is still read there
+  __shared__ __attribute__((aligned(16))) char smem[N_STAGE * ATT_STAGE];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qw0 = blockIdx.x * ATT_QBLK + wid * W4_QPW;  // first query of this wave
+  const int half = lane >> 5, ql = lane & 31;
+
+  abf16x8_t qf[W4_QB][NKS];
+  int qn[W4_QB];
+#pragma unroll
+  for (int qb = 0; qb < W4_QB; ++qb) {
+    qn[qb] = qw0 + qb * 32 + ql;
+    const int qc = qn[qb] < S ? qn[qb] : S - 1;
+    const bf16_t* qp = qkv + ((int64_t)b * S + qc) * ld + h * ATT_D + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[qb][ks] = *reinterpret_cast<const abf16x8_t*>(qp + ks * 16);
+    }
+  }
+  uint32_t drow[W4_QB] = {0u, 0u, 0u, 0u};
+  if constexpr (DROP) {
+#pragma unroll
+    for (int qb = 0; qb < W4_QB; ++qb) drow[qb] = dropout_row_part(dr, dropout_row(dr, b, h, S, qn[qb]));
+  }
+  const int kt_begin = 0, kt_end = (S + ATT_KV - 1) / ATT_KV;
+  // staging: wave w moves row groups 2 w and 2 w + 1 (8 rows x 128 B each) of the K tile and of the V^T tile
+  const int srow = lane >> 3, scp = lane & 7;
+  const bf16_t* kbase = qkv + (int64_t)b * S * ld + C + h * ATT_D;
+  const bf16_t* vbase = vt + ((int64_t)b * H + h) * ATT_D * S_pad;
+  auto stage = [&](int kt, int buf) {
+    char* ks_ = smem + buf * ATT_STAGE;
+    char* vs_ = ks_ + K_TILE;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int sr = (wid * 2 + g) * 8 + srow;
+      const int sc = aswz(sr, scp);
+      int key = kt * ATT_KV + sr;
+      if (key > S - 1) key = S - 1;
+      aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + sc * 16, ks_ + (wid * 2 + g) * 1024);
+      aglds16(reinterpret_cast<const char*>(vbase + (int64_t)sr * S_pad + kt * ATT_KV) + sc * 16, vs_ + (wid * 2 + g) * 1024);
+    }
+  };
+  constexpr int DMA_PER_STAGE = 4;
+  auto publish = [&](int kt) {  // barrier "kt": tile kt readable by everyone, tile kt + 2 requested
+    if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the bare barrier, not __syncthreads(): its fence makes the compiler wait for vmcnt(0) -- i.e. for the DMA of tile
+    // kt + 1 as well, the one request this loop wants to keep in flight across the barrier.  The only LDS writers are the
+    // DMAs counted above; this wave's LDS reads of the buffer refilled next were consumed by MFMAs already issued.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < kt_end) stage(kt + 2, (kt + 2 - kt_begin) % N_STAGE);
+  };
+  static_assert(DMA_PER_STAGE == 4, "the counted wait above");
+
+  af32x16_t o_acc[W4_QB][NDT];
+#pragma unroll
+  for (int qb = 0; qb < W4_QB; ++qb)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qb][dt][r] = 0.f;
+#pragma unroll
+  for (int qb = 0; qb < W4_QB; ++qb)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) asm volatile("" : "+a"(o_acc[qb][dt]));
+  float m_run[W4_QB], l_run[W4_QB];
+#pragma unroll
+  for (int qb = 0; qb < W4_QB; ++qb) m_run[qb] = -INFINITY, l_run[qb] = 0.f;
+  const int kperm = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);  // K row of MFMA row i: index bits 2 and 3 swapped
+
+  auto k_frags = [&](const char* ks_, int kb, abf16x8_t (&kf)[NKS]) {
+    const int krow = kb * 32 + kperm;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const abf16x8_t*>(ks_ + krow * KRB + (aswz(krow, ks * 2 + half) << 4));
+  };
+  auto v_frags = [&](const char* vs_, int kb, abf16x8_t (&vf)[NDT][2]) {
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int vrow = dt * 32 + ql;
+        vf[dt][kk] = *reinterpret_cast<const abf16x8_t*>(vs_ + vrow * 128 + (aswz(vrow, kb * 4 + kk * 2 + half) << 4));
+      }
+  };
+  // The wave's four query blocks go through the pipeline as two PAIRS (pr = 0: blocks 0, 1; pr = 1: blocks 2, 3): the scores
+  // of one pair are consumed by the softmax while the other pair's are produced -- 64 score registers alive, not 128.
+  // A half step = 16 MFMAs (P V of one pair: 8, S^T of one pair: 8) issued BETWEEN the slices of one pair's softmax.  The MFMAs
+  // are inline asm with fixed register classes -- scores in ordinary registers (VALU operands), O^T in the accumulation half
+  // (MFMA-only) -- because the allocator, left alone, computes the scores into AGPRs, copies them out
+  // one register at a time and spills the Q^T fragments (measured: 21 ms per layer).  Hazards the compiler cannot see
+  // behind the asm: a score is read by the VALU a whole half step after its last MFMA; the accumulators are read by the
+  // epilogue behind explicit s_nops.
+#define W4_MFMA_S0(sv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sv) : "v"(av), "a"(bv))
+#define W4_MFMA_S(sv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sv) : "v"(av), "a"(bv))
+#define W4_MFMA_O(ov, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ov) : "v"(av), "v"(bv))
+  // MFMA n (0 .. 15) of a half step: 0..7 = P V of pair PV_PR (skipped when !DO_PV), 8..15 = S^T of pair S_PR (!DO_S)
+  auto half_step = [&](auto do_pv_c, auto do_s_c, auto pv_pr_c, auto s_pr_c, auto sm_pr_c, int kt, int kb,
+                       const abf16x8_t (&vf)[NDT][2], const abf16x8_t (&pbo)[2][2], const abf16x8_t (&kf)[NKS],
+                       af32x16_t (&sb)[2], af32x16_t (&sa)[2], abf16x8_t (&pbn)[2][2]) {
+    constexpr bool DO_PV = decltype(do_pv_c)::value, DO_S = decltype(do_s_c)::value;
+    constexpr int PV_PR = decltype(pv_pr_c)::value, S_PR = decltype(s_pr_c)::value, SM_PR = decltype(sm_pr_c)::value;
+    (void)&o_acc; (void)&qf;  // (named once outside the asm operands: clang does not capture a variable it only meets there)
+#define W4_MF(n)                                                                                                     \
+  do {                                                                                                               \
+    if constexpr ((n) < 8) {                                                                                         \
+      if constexpr (DO_PV)                                                                                           \
+        W4_MFMA_O(o_acc[2 * PV_PR + ((n) & 1)][(n) >> 2], vf[(n) >> 2][((n) >> 1) & 1], pbo[(n) & 1][((n) >> 1) & 1]); \
+    } else if constexpr (DO_S) {                                                                                     \
+      if constexpr ((n) < 10) W4_MFMA_S0(sb[(n) & 1], kf[0], qf[2 * S_PR + ((n) & 1)][0]);                           \
+      else W4_MFMA_S(sb[(n) & 1], kf[((n) - 8) >> 1], qf[2 * S_PR + ((n) & 1)][((n) - 8) >> 1]);                     \
+    }                                                                                                                \
+  } while (0)
+    // ---- softmax of pair SM_PR on sa, slices of it between the MFMAs
+    const int key0 = kt * ATT_KV + kb * 32 + 8 * half, blk0 = kt * ATT_KV + kb * 32;
+    if (blk0 + 32 > S) {  // the sequence ends inside this block (global attention only: the launcher keeps windows off this kernel)
+      asm volatile("s_nop 15" ::: "memory");  // the scores' last MFMA (asm: no hazard handling by the compiler) has retired
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[i][r] = key0 + (r & 7) + 16 * (r >> 3) < S ? sa[i][r] : -INFINITY;
+    }
+    // NO running maximum in this loop: the reference of a query is the maximum of its FIRST 32-key block (taken in the
+    // prologue below), fixed for the whole pass.  Later probabilities may exceed 1 (by 2^(later maximum - first maximum)), which f32 sums and bf16
+    // operands carry without loss as long as that stays below ~2^100; the final o / l does not care which reference was
+    // used.  Nothing rescales the 128 accumulator registers, no branch splits the matrix phase.  The pathological case
+    // (a later score more than ~70 above the first block's maximum) shows as a non-finite row sum at the end and raises
+    // the call's fallback flag: the launcher's second kernel (the 8-wave kernel with the exact online maximum) then
+    // recomputes the call -- it exits at once when the flag is clear.
+    const uint32_t ones2 = 0x3f803f80u;
+    float m_neg[2], psum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) m_neg[i] = -m_run[2 * SM_PR + i];
+    uint32_t w[2][2][4];
+    // 16 slots: MFMA n, then three independent VALU stages of the softmax, software pipelined over the 16 packed pairs of
+    // the two query blocks (pair c: block i = c >> 3, fragment kk = (c >> 2) & 1, word j = c & 3):
+    //     C(n): pack + row sum      B(n + 1): the two exp2      A(n + 2): the two fma
+    // so that no instruction of a slot waits for another one of the same slot.  The VALU side is inline asm as well: pure
+    // arithmetic is not ordered against the (volatile) MFMA asm, and instruction selection moves ALL of it in front of or
+    // behind the run of MFMAs -- the scheduling fences only hold what selection already put between them; two volatile asm
+    // statements stay in source order.  Early-clobber outputs: a stage's result must not land in a register a later
+    // instruction of the same statement still reads.
+    float ta[2][2], tb[2][2];  // [slot parity][element]: fma results, exp2 results
+    const float sc = scale_log2e;
+    // the first two A stages and the first B stage (sa[0]'s last MFMA is two slots back: 8 instructions + these wait states)
+    asm volatile("s_nop 3" ::: "memory");
+    ta[0][0] = fmaf(sa[0][0], sc, m_neg[0]);
+    ta[0][1] = fmaf(sa[0][1], sc, m_neg[0]);
+    ta[1][0] = fmaf(sa[0][2], sc, m_neg[0]);
+    ta[1][1] = fmaf(sa[0][3], sc, m_neg[0]);
+    tb[0][0] = __builtin_amdgcn_exp2f(ta[0][0]);
+    tb[0][1] = __builtin_amdgcn_exp2f(ta[0][1]);
+    auto valu = [&](auto n_c) {
+      constexpr int n = decltype(n_c)::value;
+      constexpr int i = n >> 3, kk = (n >> 2) & 1, j = n & 3;
+      constexpr int c2 = n + 2, i2 = (c2 >> 3) & 1, kk2 = (c2 >> 2) & 1, j2 = c2 & 3;
+      // (slot 0 packs the exponentials the COMPILER issued just above: a transcendental's result needs a wait state before
+      //  a VALU read, and the hazard recognizer does not look into the asm -- NaN probabilities in a quarter of the lanes)
+      //  -- the wait states sit INSIDE slot 0's statement: pure instructions may be placed between two asm statements)
+#define W4_VALU_FULL(PREFIX)                                                                                              \
+  asm volatile(PREFIX "v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"                                                           \
+                      "v_exp_f32 %[f0], %[t0]\n\t"                                                                         \
+                      "v_exp_f32 %[f1], %[t1]\n\t"                                                                         \
+                      "v_fma_f32 %[u0], %[s0], %[sc], %[mn]\n\t"                                                           \
+                      "v_fma_f32 %[u1], %[s1], %[sc], %[mn]\n\t"                                                           \
+                      "v_dot2c_f32_bf16 %[ps], 0x3f803f80, %[w]"                                                           \
+               : [w] "=&v"(w[i][kk][j]), [f0] "=&v"(tb[(n + 1) & 1][0]), [f1] "=&v"(tb[(n + 1) & 1][1]),                   \
+                 [u0] "=&v"(ta[n & 1][0]), [u1] "=&v"(ta[n & 1][1]), [ps] "+v"(psum[i])                                    \
+               : [e0] "v"(tb[n & 1][0]), [e1] "v"(tb[n & 1][1]), [t0] "v"(ta[(n + 1) & 1][0]), [t1] "v"(ta[(n + 1) & 1][1]), \
+                 [s0] "v"(sa[i2][kk2 * 8 + 2 * j2]), [s1] "v"(sa[i2][kk2 * 8 + 2 * j2 + 1]), [sc] "s"(sc), [mn] "v"(m_neg[i2]))
+      if constexpr (n == 0) {
+        W4_VALU_FULL("s_nop 1\n\t");
+      } else if constexpr (n < 14) {
+        W4_VALU_FULL("");
+#undef W4_VALU_FULL
+      } else if constexpr (n == 14) {
+        asm volatile(
+            "v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"
+            "v_exp_f32 %[f0], %[t0]\n\t"
+            "v_exp_f32 %[f1], %[t1]\n\t"
+            "v_dot2c_f32_bf16 %[ps], 0x3f803f80, %[w]"
+            : [w] "=&v"(w[i][kk][j]), [f0] "=&v"(tb[(n + 1) & 1][0]), [f1] "=&v"(tb[(n + 1) & 1][1]), [ps] "+v"(psum[i])
+            : [e0] "v"(tb[n & 1][0]), [e1] "v"(tb[n & 1][1]), [t0] "v"(ta[(n + 1) & 1][0]), [t1] "v"(ta[(n + 1) & 1][1]));
+      } else {
+        asm volatile(
+            "v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"
+            "s_nop 0\n\t"
+            "v_dot2c_f32_bf16 %[ps], 0x3f803f80, %[w]\n\t"
+            "s_nop 3"  // a dot product's result is not forwarded to an ordinary VALU read right behind it (the compiler
+                       // does not see the hazard inside the asm: the row sum lost this last pair)
+            : [w] "=&v"(w[i][kk][j]), [ps] "+v"(psum[i])
+            : [e0] "v"(tb[n & 1][0]), [e1] "v"(tb[n & 1][1]));
+      }
+      if constexpr (DROP) {
+        const uint32_t x = dropout_mix(drow[2 * SM_PR + i] ^ ((uint32_t)(key0 >> 1) + 8u * kk + j) * 0xC2B2AE3Du);
+        const uint32_t keep = ((x & 0xffffu) >= dr.thr16 ? 0x0000ffffu : 0u) | ((x >> 16) >= dr.thr16 ? 0xffff0000u : 0u);
+        w[i][kk][j] &= keep;
+      }
+    };
+#define W4_SLOT(n)                                   \
+  do {                                               \
+    W4_MF(n);                                        \
+    valu(std::integral_constant<int, (n)>{});        \
+  } while (0)
+    W4_SLOT(0);
+    W4_SLOT(1);
+    W4_SLOT(2);
+    W4_SLOT(3);
+    W4_SLOT(4);
+    W4_SLOT(5);
+    W4_SLOT(6);
+    W4_SLOT(7);
+    W4_SLOT(8);
+    W4_SLOT(9);
+    W4_SLOT(10);
+    W4_SLOT(11);
+    W4_SLOT(12);
+    W4_SLOT(13);
+    W4_SLOT(14);
+    W4_SLOT(15);
+#undef W4_SLOT
+#undef W4_MF
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) pbn[i][kk] = *reinterpret_cast<abf16x8_t*>(w[i][kk]);
+      l_run[2 * SM_PR + i] += psum[i];
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  if (kt_begin < kt_end) {
+    stage(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
+    publish(kt_begin);
+    af32x16_t s0[2], s1[2];            // scores of pair 0 / pair 1
+    abf16x8_t p0[2][2], p1[2][2];      // packed probabilities of pair 0 / pair 1
+    abf16x8_t kf0[NKS], kf1[NKS], vf0[NDT][2], vf1[NDT][2];  // fragments of the tile's block 0 / block 1
+    // Half steps of block j (tile kt, kb):   A(j): matrix  P V (j - 1, pair 1), S^T (j, pair 1);      VALU  softmax (j, pair 0)
+    //                                        B(j): matrix  P V (j, pair 0),     S^T (j + 1, pair 0);  VALU  softmax (j, pair 1)
+    k_frags(smem, 0, kf0);
+    // prologue: S^T of the first block for BOTH pairs -> the queries' reference maxima (pair 1's scores are produced again
+    // by the first half step: eight MFMAs once per workgroup); pair 0's stay in s0 for the first softmax
+#pragma unroll
+    for (int pr = 1; pr >= 0; --pr) {
+      W4_MFMA_S0(s0[0], kf0[0], qf[2 * pr][0]);
+      W4_MFMA_S0(s0[1], kf0[0], qf[2 * pr + 1][0]);
+#pragma unroll
+      for (int ks = 1; ks < NKS; ++ks) {
+        W4_MFMA_S(s0[0], kf0[ks], qf[2 * pr][ks]);
+        W4_MFMA_S(s0[1], kf0[ks], qf[2 * pr + 1][ks]);
+      }
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMAs: no hazard handling by the compiler)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float m = s0[i][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, 8 * half + (r & 7) + 16 * (r >> 3) < S ? s0[i][r] : -INFINITY);
+        m_run[2 * pr + i] = fmaxf(m, __shfl_xor(m, 32, 64)) * scale_log2e;
+      }
+    }
+    // ONE loop body, no branch around a half step (a branch there makes the allocator copy accumulator tuples at the join):
+    // the P V product "of the block before the first" multiplies zeros, the S^T product "of the block behind the last"
+    // multiplies the stale K fragments into scores nobody reads.
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        p1[i][kk] = abf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        vf1[i][kk] = abf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const char* ks_ = smem + ((kt - kt_begin) % N_STAGE) * ATT_STAGE;
+      const char* vs_ = ks_ + K_TILE;
+      // ---- A(2k)      [vf1 / p1: block 2k - 1]
+      k_frags(ks_, 1, kf1);
+      v_frags(vs_, 0, vf0);
+      half_step(T_{}, T_{}, I1{}, I1{}, I0{}, kt, 0, vf1, p1, kf0, s1, s0, p0);
+      // ---- B(2k)
+      half_step(T_{}, T_{}, I0{}, I0{}, I1{}, kt, 0, vf0, p0, kf1, s0, s1, p1);
+      // ---- the next tile's K fragments are needed by B(2k + 1)
+      if (kt + 1 < kt_end) {
+        publish(kt + 1);
+        k_frags(smem + ((kt + 1 - kt_begin) % N_STAGE) * ATT_STAGE, 0, kf0);
+      }
+      v_frags(vs_, 1, vf1);
+      // ---- A(2k + 1)
+      half_step(T_{}, T_{}, I1{}, I1{}, I0{}, kt, 1, vf0, p1, kf1, s1, s0, p0);
+      // ---- B(2k + 1)
+      half_step(T_{}, T_{}, I0{}, I0{}, I1{}, kt, 1, vf1, p0, kf0, s0, s1, p1);
+    }
+    // epilogue: P V (last block, pair 1)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) W4_MFMA_O(o_acc[2 + i][dt], vf1[dt][kk], p1[i][kk]);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  }
+#undef W4_MFMA_S0
+#undef W4_MFMA_S
+#undef W4_MFMA_O
+
+#pragma unroll
+  for (int qb = 0; qb < W4_QB; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    if (!(l_tot < 1e37f) && qn[qb] < S) *redo_flag = 1;  // (also NaN) a probability left the f32 range: see the half step
+    float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if constexpr (DROP) inv *= dr.keep_scale;
+    if (lse != nullptr && half == 0 && qn[qb] < S)
       lse[((int64_t)b * H + h) * S + qn[qb]] = (m_run[qb] + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
     if (qn[qb] < S) {
       bf16_t* op = out + ((int64_t)b * S + qn[qb]) * ldo + h * ATT_D;
@@ -983,9 +1337,13 @@ static inline int64_t mhsa_vt_bytes(int B, int S, int H, int D) {
   return ((int64_t)B * H * D * ((S + 63) / 64 * 64) * 2 + 255) / 256 * 256;
 }
 
+static inline int64_t mhsa_tail_bytes(int B, int S, int H, int D) {
+  return ((int64_t)B * mhsa_tail_rows(S) * H * mhsa_tail_splits(B, S, H) * (D + 2) * 4 + 255) / 256 * 256;
+}
+
 int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
   if (dtype == ANEMOI_BF16 && (D == 64 || D == 32))  // V^T, then the partial states of the left-over rows' key chunks
-    return mhsa_vt_bytes(B, S, H, D) + (int64_t)B * mhsa_tail_rows(S) * H * mhsa_tail_splits(B, S, H) * (D + 2) * 4;
+    return mhsa_vt_bytes(B, S, H, D) + mhsa_tail_bytes(B, S, H, D) + 256;  // + the fallback flag of the 4-wave kernel
   return 0;
 }
 
@@ -1039,7 +1397,29 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   hipLaunchKernelGGL((mhsa_bf16_kernel<DD, DR>), grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,            \
                      static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window, \
                      scale * 1.44269504088896340736f, lse, dr)
-    if (D == 64) {
+    // D = 64, global attention: the 4-wave software-pipelined kernel; its fallback (a probability left the f32 range under
+    // the fixed reference maximum) is the 8-wave kernel behind a device-side flag -- no host round trip, graph capturable
+    if (D == 64 && window < 0) {
+      int* flag = reinterpret_cast<int*>(static_cast<char*>(workspace) + mhsa_vt_bytes(B, S, H, D) + mhsa_tail_bytes(B, S, H, D));
+      if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return fail(ANEMOI_ERR_LAUNCH, "anemoi_mhsa: flag reset");
+      const dim3 block4(64 * W4_WAVES);
+      if (drop)
+        hipLaunchKernelGGL((mhsa_bf16_w4_kernel<true>), grid, block4, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                           static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C,
+                           scale * 1.44269504088896340736f, lse, dr, flag);
+      else
+        hipLaunchKernelGGL((mhsa_bf16_w4_kernel<false>), grid, block4, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                           static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C,
+                           scale * 1.44269504088896340736f, lse, dr, flag);
+      if (drop)
+        hipLaunchKernelGGL((mhsa_bf16_kernel<64, true>), grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                           static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
+                           scale * 1.44269504088896340736f, lse, dr, flag);
+      else
+        hipLaunchKernelGGL((mhsa_bf16_kernel<64, false>), grid, block, 0, st, static_cast<const bf16_t*>(qkv), ld,
+                           static_cast<const bf16_t*>(workspace), static_cast<bf16_t*>(out), ldo, S, S_pad, H, C, window,
+                           scale * 1.44269504088896340736f, lse, dr, flag);
+    } else if (D == 64) {
       if (drop) ANEMOI_MHSA_FWD(64, true);
       else ANEMOI_MHSA_FWD(64, false);
     } else {

@@ -822,6 +822,27 @@ def test_mhsa(dtype, b, s, h, d, window):
     assert rel_err(got, want) < (2e-5 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("boost", [3.0, 40.0, 400.0])
+def test_mhsa_four_wave_kernel_fixed_reference_and_its_fallback(boost):
+    """The D = 64 global-attention kernel keeps each query's FIRST 32-key block maximum as the softmax reference for the
+    whole pass (no running maximum, no accumulator rescale).  Scores far above that reference: `boost` 3 stays inside the
+    kernel's range (probabilities up to ~2^40), 40 and 400 push probabilities past the f32 range -- the kernel raises its
+    device-side flag and the launcher's second kernel (exact online maximum) recomputes the call.  All three must agree
+    with the f32 reference; keys 0..31 are the reference block, the boosted key sits behind it."""
+    from anemoi_models_amd import ops
+
+    b, s, h, d = 1, 1200, 4, 64
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(b * s, 3 * h * d, generator=g)
+    qkv[700, h * d:2 * h * d] *= boost           # one key far above everything in the first block, every head
+    qkv[100:140, :h * d] *= 1.0 + boost / 10.0   # ... seen through some larger queries
+    qkv = qkv.bfloat16()
+    want = _sdpa(qkv, b, h, -1)
+    got = ops.mhsa(qkv.to(DEV), b, h, -1)
+    assert torch.isfinite(got.float()).all()
+    assert rel_err(got, want) < 2e-2
+
+
 def test_transformer_block_and_model_vs_golden(graph_o32, golden_blocks, golden_cfg1_tfm):
     from anemoi_models_amd.layers.block import TransformerProcessorBlock
 
