@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -125,6 +125,8 @@ SIGNATURES = {
                                       c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "anemoi_col_sum_workspace_floats": (c_int64, [c_int64, c_int]),
     "anemoi_col_sum": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "anemoi_row_dot": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "anemoi_row_scale": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "anemoi_act_forward": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,
                                    c_void_p]),
     "anemoi_act_backward": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int,

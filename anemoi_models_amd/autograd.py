@@ -202,6 +202,108 @@ def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Ten
     return _LayerNorm.apply(x, gamma, beta, eps)
 
 
+class _ScaledLinear(torch.autograd.Function):
+    """``y = s[:, None] * (x @ f.T) + b``: ``x [M, Kp]`` in the compute dtype (K padded), ``f [N, Kp]`` / ``b [N]`` f32,
+    ``s [M]`` f32 -- the product behind a LayerNorm whose mean has been removed algebraically (``s`` = the row's rstd).
+    Forward on ``anemoi_linear_ln`` (statistics ``{s, 0}``, zero column sums); backward: ``df = dy^T (s x)`` (TN weight
+    gradient on the scaled K-narrow rows), ``dx = s (dy f)``, ``ds = sum_n dy (y - b) / s`` (``anemoi_row_dot`` on the saved
+    output: the unscaled product is never materialised), ``db = sum_m dy``."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, f: Tensor, s: Tensor, b: Tensor):
+        dtype = x.dtype
+        fp = f.detach().to(dtype).contiguous()
+        sd = s.detach().float()
+        stats = torch.stack([sd, torch.zeros_like(sd)], dim=1).contiguous()
+        zeros = torch.zeros(f.shape[0], dtype=torch.float32, device=x.device)
+        y = ops.linear(x, fp, b.detach().float().contiguous(), ln=(stats, zeros))
+        ctx.save_for_backward(x, f, s, b, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, f, s, b, y = ctx.saved_tensors
+        dtype = x.dtype
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        n, kp = f.shape
+        sd = s.detach().float().contiguous()
+        dx = df = ds = db = None
+        if need[2]:
+            ds = ops.row_dot(dy, y, b.detach().float().contiguous()) / sd
+        if need[1]:
+            xs = ops.row_scale(x, sd)
+            if need[3]:
+                df, db = ops.weight_grad(dy, xs, kp, want_bias=True)
+            else:
+                df = ops.weight_grad(dy, xs, kp)
+            df = df.to(f.dtype)
+        if db is None and need[3]:
+            db = ops.col_sum(dy)
+        if need[0]:
+            np_ = ops.round_up(n, ops.k_multiple(dtype))
+            ft = ops.transpose(f.detach().to(dtype).contiguous(), ld_out=np_)
+            dp = dy if n == np_ else ops.convert_pad(dy, dtype, np_)
+            dx = ops.linear(dp, ft)
+            ops.row_scale(dx, sd, out=dx)
+        return dx, df, ds, (None if db is None else db.to(b.dtype))
+
+
+class _QuadForm(torch.autograd.Function):
+    """``q[i] = x_i^T M x_i`` for a SYMMETRIC ``M [K, K]`` (f32), ``x [rows, K]`` in the compute dtype: one K x K product on
+    the rows + one row dot (f32 sums of the bf16 products).  Backward: ``dx = 2 g (x M)`` (the saved product, row scaled),
+    ``dM = x^T (g x)`` (TN weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, m: Tensor):
+        z = ops.linear(x, m.detach().to(x.dtype).contiguous())
+        ctx.save_for_backward(x, z)
+        return ops.row_dot(z, x)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, z = ctx.saved_tensors
+        g = g.detach().float().contiguous()
+        dx = ops.row_scale(z, g, 2.0) if ctx.needs_input_grad[0] else None
+        dm = ops.weight_grad(ops.row_scale(x, g), x, x.shape[1]) if ctx.needs_input_grad[1] else None
+        return dx, dm
+
+
+def folded_embedding_ln_linear(x: Tensor, emb_w: Tensor, emb_b: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,
+                               w_rows: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """``Linear(LayerNorm(emb(x)))`` on the RAW node features (mapper embedding -> block LayerNorm -> k|v or x_r|q|u
+    Linear, reference layers/mapper.py:322-331 + layers/block.py:516-528), differentiable: the training form of
+    ``runtime.fold_embedded_layer_norm``.  With the channel-centred embedding ``A = [E_c | b_c]`` (the LayerNorm's mean is
+    gone algebraically) and ``x_aug = [x | 1 | 0-pad]``:
+
+        var_i = x_aug_i^T (A^T A / C) x_aug_i,   y_i = rsqrt(var_i + eps) * (x_aug_i F^T) + b',
+        F = (W * gamma) A,   b' = b + W beta
+
+    -- a K = k_in + 1 product instead of the embedding GEMM's successor at K = C, and no ``[M, C]`` LayerNorm pass.  The
+    algebra on the parameters is plain torch (autograd carries the gradients to the embedding, the LayerNorm and the
+    Linear), the two products on the rows are autograd nodes on the HIP kernels."""
+    dtype = x.dtype
+    c, k_in = emb_w.shape
+    if x.shape[1] < k_in:
+        raise ValueError(f"folded_embedding_ln_linear: x has {x.shape[1]} columns, the embedding expects {k_in}")
+    kp = ops.round_up(k_in + 1, ops.k_multiple(dtype))
+    m = x.shape[0]
+    xa = torch.cat([x[:, :k_in], torch.ones((m, 1), dtype=dtype, device=x.device),
+                    torch.zeros((m, kp - k_in - 1), dtype=dtype, device=x.device)], dim=1)
+    e_c = emb_w.float() - emb_w.float().mean(0, keepdim=True)
+    b_e = torch.zeros(c, dtype=torch.float32, device=x.device) if emb_b is None else emb_b.float()
+    b_c = b_e - b_e.mean()
+    a = torch.cat([e_c, b_c[:, None], torch.zeros((c, kp - k_in - 1), dtype=torch.float32, device=x.device)], dim=1)
+    var = _QuadForm.apply(xa, a.t() @ a / c)
+    s = torch.rsqrt(var.clamp_min(0.0) + eps)
+    w = w_rows.float()
+    f = (w * gamma.float()[None, :]) @ a
+    b2 = w @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.float()
+    return _ScaledLinear.apply(xa, f, s, b2)
+
+
 # ------------------------------------------------------------------------------------------ edge phase
 def _transposed_csr(plan):
     """(rowptr_t, eid_t, dst_t) of the source-major view of a destination-sorted plan, cached on the plan."""
@@ -577,18 +679,25 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
     return _gt_tail(att, x, sd, prefix, w_t, act, eps)
 
 
-def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, plan, num_heads: int,
-                    act: str = "GELU", eps: float = 1e-5) -> Tensor:
+def gt_mapper_block(x_src: Optional[Tensor], x_dst: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, plan, num_heads: int,
+                    act: str = "GELU", eps: float = 1e-5, kv_fn=None, sq_fn=None) -> Tensor:
     """Differentiable ``GraphTransformerMapperBlock`` (reference layers/block.py:479-550, ``update_src_nodes=False``):
     keys / values from ``LayerNorm1(x_src)``, queries / self term from ``LayerNorm2(x_dst)``, the new destination nodes
     are returned; same kernels and fold as :func:`gt_processor_block`."""
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
     c = x_dst.shape[1]
     h, up = num_heads, edge_attr_csr.shape[1]
-    xs = layer_norm(x_src, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
-    xd = layer_norm(x_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), eps)
-    kv = linear(xs, torch.cat([g("lin_key.weight"), g("lin_value.weight")], 0),
-                torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0))
+    # ``kv_fn`` / ``sq_fn`` (the mappers, training.gt_mapper): ``Linear(LayerNorm(.))`` of the source / destination rows
+    # computed on the RAW node features (folded_embedding_ln_linear) -- called with (weight rows, bias); x_src may then
+    # be None (its embedding is never formed)
+    w_kv = torch.cat([g("lin_key.weight"), g("lin_value.weight")], 0)
+    b_kv = torch.cat([g("lin_key.bias"), g("lin_value.bias")], 0)
+    if kv_fn is not None:
+        kv = kv_fn(w_kv, b_kv, g("layer_norm1.weight"), g("layer_norm1.bias"))
+    else:
+        kv = linear(layer_norm(x_src, g("layer_norm1.weight"), g("layer_norm1.bias"), eps), w_kv, b_kv)
+    if sq_fn is None or up > FOLD_MAX_UP:
+        xd = layer_norm(x_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), eps)
     if up > FOLD_MAX_UP:  # see gt_processor_block
         sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight")], 0),
                     torch.cat([g("lin_self.bias"), g("lin_query.bias")], 0))
@@ -596,8 +705,12 @@ def gt_mapper_block(x_src: Tensor, x_dst: Tensor, sd: dict, prefix: str, edge_at
                       sq[:, :c], plan, h)
         return _gt_tail(att, x_dst, sd, prefix, None, act, eps)
     w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x_dst.device)
-    sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0),
-                torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0))  # x_r | q | u
+    w_sq = torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0)
+    b_sq = torch.cat([g("lin_self.bias"), g("lin_query.bias"), b_u], 0)
+    if sq_fn is not None:
+        sq = sq_fn(w_sq, b_sq, g("layer_norm2.weight"), g("layer_norm2.bias"))  # x_r | q | u
+    else:
+        sq = linear(xd, w_sq, b_sq)  # x_r | q | u
     att = gt_edge_attention_packed(sq, kv, edge_attr_csr, plan, h, up)
     return _gt_tail(att, x_dst, sd, prefix, w_t, act, eps)
 

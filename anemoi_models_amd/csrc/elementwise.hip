@@ -341,6 +341,73 @@ __global__ __launch_bounds__(256) void convert_pad_kernel(const S* __restrict__ 
   }
 }
 
+// out[r, c] = alpha * s[r] * x[r, c]   (s f32 per row; the result in x's dtype)
+template <typename T>
+__global__ __launch_bounds__(256) void row_scale_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ s,
+                                                        float alpha, T* __restrict__ out, int64_t ldo, int64_t rows,
+                                                        int cols) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int64_t per_row = (cols + VEC - 1) / VEC;
+  const int64_t total = rows * per_row;
+  const bool vec_ok = cols % VEC == 0 && ldx % VEC == 0 && ldo % VEC == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per_row;
+    const int c = (int)(i - r * per_row) * VEC;
+    const float f = alpha * s[r];
+    if (vec_ok) {
+      float v[VEC];
+      VecIO<T, VEC>::load(x + r * ldx + c, v);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[k] *= f;
+      VecIO<T, VEC>::store(out + r * ldo + c, v);
+    } else {
+      for (int k = 0; k < VEC && c + k < cols; ++k) Elem<T>::store(out + r * ldo + c + k, Elem<T>::load(x + r * ldx + c + k) * f);
+    }
+  }
+}
+
+// out[r] = sum_c a[r, c] * (b[r, c] - shift[c])   (f32; one wave per row, 16 bytes per lane and step)
+template <typename T>
+__global__ __launch_bounds__(256) void row_dot_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b,
+                                                      int64_t ldb, const float* __restrict__ shift,
+                                                      float* __restrict__ out, int64_t rows, int cols) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const T* ar = a + r * lda;
+  const T* br = b + r * ldb;
+  float acc = 0.f;
+  const bool vec_ok = cols % VEC == 0 && lda % VEC == 0 && ldb % VEC == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0;
+  if (vec_ok) {
+    constexpr int U = 4;  // 8 independent 16-byte loads per lane in flight (a row of 2048 bf16 is one trip)
+    for (int c0 = lane * VEC; c0 < cols; c0 += U * 64 * VEC) {
+      float av[U][VEC], bv[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64 * VEC;
+        if (c < cols) {
+          VecIO<T, VEC>::load(ar + c, av[u]);
+          VecIO<T, VEC>::load(br + c, bv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64 * VEC;
+        if (c < cols) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc = fmaf(av[u][i], bv[u][i] - (shift != nullptr ? shift[c + i] : 0.f), acc);
+        }
+      }
+    }
+  } else {
+    for (int c = lane; c < cols; c += 64)
+      acc = fmaf(Elem<T>::load(ar + c), Elem<T>::load(br + c) - (shift != nullptr ? shift[c] : 0.f), acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[r] = acc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b,
                                                   int64_t ldb, T* __restrict__ y, int64_t ldy, int64_t rows,
@@ -593,6 +660,44 @@ int anemoi_convert_pad(int src_dtype, const void* src, int64_t ld_src, int dst_d
   return check_launch("anemoi_convert_pad");
 }
 
+int anemoi_row_scale(int dtype, const void* x, int64_t ldx, const float* s, float alpha, void* out, int64_t ldo,
+                     int64_t rows, int cols, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x && s && out && rows >= 0 && cols >= 0 && ldx >= cols && ldo >= cols, ANEMOI_ERR_INVALID,
+                 "anemoi_row_scale: bad argument");
+  if (rows * cols == 0) return ANEMOI_OK;
+  hipStream_t st = as_stream(stream);
+  const int vec = dtype == ANEMOI_F32 ? 4 : 8;
+  dim3 grid(flat_grid(rows * ((cols + vec - 1) / vec))), block(256);
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((row_scale_kernel<float>), grid, block, 0, st, static_cast<const float*>(x), ldx, s, alpha,
+                       static_cast<float*>(out), ldo, rows, cols);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((row_scale_kernel<bf16_t>), grid, block, 0, st, static_cast<const bf16_t*>(x), ldx, s, alpha,
+                       static_cast<bf16_t*>(out), ldo, rows, cols);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_row_scale: dtype %d", dtype);
+  return check_launch("anemoi_row_scale");
+}
+
+int anemoi_row_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, const float* shift, float* out,
+                   int64_t rows, int cols, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(a && b && out && rows >= 0 && cols >= 0 && lda >= cols && ldb >= cols, ANEMOI_ERR_INVALID,
+                 "anemoi_row_dot: bad argument");
+  if (rows == 0) return ANEMOI_OK;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  ANEMOI_REQUIRE((rows + 3) / 4 < ((int64_t)1 << 31), ANEMOI_ERR_UNSUPPORTED, "anemoi_row_dot: grid too large");
+  if (dtype == ANEMOI_F32)
+    hipLaunchKernelGGL((row_dot_kernel<float>), grid, block, 0, st, static_cast<const float*>(a), lda,
+                       static_cast<const float*>(b), ldb, shift, out, rows, cols);
+  else if (dtype == ANEMOI_BF16)
+    hipLaunchKernelGGL((row_dot_kernel<bf16_t>), grid, block, 0, st, static_cast<const bf16_t*>(a), lda,
+                       static_cast<const bf16_t*>(b), ldb, shift, out, rows, cols);
+  else
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_row_dot: dtype %d", dtype);
+  return check_launch("anemoi_row_dot");
+}
+
 int anemoi_add(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
                int cols, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(a && b && y && rows >= 0 && cols >= 0, ANEMOI_ERR_INVALID, "anemoi_add: bad argument");
@@ -662,7 +767,7 @@ int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int3
   return check_launch("anemoi_bound_output");
 }
 
-int anemoi_abi_version(void) { return 32; }
+int anemoi_abi_version(void) { return 33; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

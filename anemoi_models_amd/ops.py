@@ -599,6 +599,37 @@ def col_sum(x: Tensor) -> Tensor:
     return out
 
 
+def row_dot(a: Tensor, b: Tensor, shift: Optional[Tensor] = None) -> Tensor:
+    """``out[r] = sum_c a[r, c] * (b[r, c] - shift[c])`` in f32 (``shift``: optional f32 ``[cols]``)."""
+    _dev(a, b, shift)
+    rows, cols = _rows(a).shape
+    if tuple(_rows(b).shape) != (rows, cols) or a.dtype != b.dtype:
+        raise ValueError("row_dot: a and b must have the same shape and dtype")
+    if shift is not None and (shift.dtype != torch.float32 or shift.numel() < cols or not shift.is_contiguous()):
+        raise ValueError("row_dot: shift must be a contiguous f32 vector with one entry per column")
+    out = torch.empty(rows, dtype=torch.float32, device=a.device)
+    with _Timed("row_dot", bytes=2 * rows * cols * a.element_size()):
+        st = _lib.load().anemoi_row_dot(dtype_code(a.dtype), a.data_ptr(), _ld(_rows(a)), b.data_ptr(), _ld(_rows(b)),
+                                        _ptr(shift), out.data_ptr(), rows, cols, _stream())
+    _lib.check(st, "anemoi_row_dot")
+    return out
+
+
+def row_scale(x: Tensor, s: Tensor, alpha: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    """``alpha * s[:, None] * x`` in x's dtype (``s``: contiguous f32 ``[rows]``)."""
+    _dev(x, s, out)
+    rows, cols = _rows(x).shape
+    if s.dtype != torch.float32 or s.numel() != rows or not s.is_contiguous():
+        raise ValueError("row_scale: s must be a contiguous f32 vector with one entry per row")
+    if out is None:
+        out = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    with _Timed("row_scale", bytes=2 * rows * cols * x.element_size()):
+        st = _lib.load().anemoi_row_scale(dtype_code(x.dtype), x.data_ptr(), _ld(_rows(x)), s.data_ptr(), float(alpha),
+                                          out.data_ptr(), _ld(_rows(out)), rows, cols, _stream())
+    _lib.check(st, "anemoi_row_scale")
+    return out
+
+
 def linear_dual(x: Tensor, w: Tensor, bias: Optional[Tensor], act: str):
     """``(pre, y) = (x @ w.T + bias, act(pre))``: the training forward of Linear + activation.  One launch
     (``anemoi_linear_dual``) for the whole 256-row tiles of a bf16 product, the GEMM + activation pass pair for the rest."""

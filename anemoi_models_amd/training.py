@@ -199,10 +199,30 @@ def gt_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int, src_map: Op
     plan, ea = _set_plan_and_attrs(mapper, x_src.shape[0], x_dst.shape[0], batch_size, ops.round_up(mapper.edge_dim + 1, 4),
                                    src_map, dst_map)
     hs, hd = _cast(x_src, dtype), _cast(x_dst, dtype)
-    if hasattr(mapper, "emb_nodes_src"):
+    # the LARGER node set (the grid: sources of the encoder, destinations of the decoder) feeds its first Linear from the
+    # raw features -- embedding -> LayerNorm -> Linear folded into a K = features + 1 product (bf16, few input features:
+    # the inference path's rule, layers/mapper.py::_embedded); the decoder still forms its embedded rows (skip connection)
+    kv_fn = sq_fn = None
+    eps = blk.layer_norm1.eps
+
+    def can_fold(lin):
+        return (runtime.embed_fold_enabled(dtype) and 2 * (lin.in_features + 1) <= lin.out_features
+                and autograd.FOLD_MAX_UP >= ops.round_up(mapper.edge_dim + 1, 4))
+
+    if hasattr(mapper, "emb_nodes_src") and hs.shape[0] >= hd.shape[0] and can_fold(mapper.emb_nodes_src):
+        raw_src, emb = hs, mapper.emb_nodes_src
+        kv_fn = lambda w, b, gamma, beta: autograd.folded_embedding_ln_linear(  # noqa: E731
+            raw_src, emb.weight, emb.bias, gamma, beta, eps, w, b)
+        hs = None
+    elif hasattr(mapper, "emb_nodes_src"):
         hs = autograd.linear(hs, mapper.emb_nodes_src.weight, mapper.emb_nodes_src.bias)
+    if hd.shape[0] > (0 if hs is None else hs.shape[0]) and hs is not None and can_fold(mapper.emb_nodes_dst):
+        raw_dst, emb_d = hd, mapper.emb_nodes_dst
+        sq_fn = lambda w, b, gamma, beta: autograd.folded_embedding_ln_linear(  # noqa: E731
+            raw_dst, emb_d.weight, emb_d.bias, gamma, beta, eps, w, b)
     hd = autograd.linear(hd, mapper.emb_nodes_dst.weight, mapper.emb_nodes_dst.bias)
-    y = autograd.gt_mapper_block(hs, hd, _block_sd(blk), "b", ea, plan, blk.num_heads, blk.activation, blk.layer_norm1.eps)
+    y = autograd.gt_mapper_block(hs, hd, _block_sd(blk), "b", ea, plan, blk.num_heads, blk.activation, eps,
+                                 kv_fn=kv_fn, sq_fn=sq_fn)
     ext = getattr(mapper, "node_data_extractor", None)
     if ext is not None:
         y = sequential(ext, y)

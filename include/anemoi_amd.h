@@ -353,6 +353,17 @@ int64_t anemoi_col_sum_workspace_floats(int64_t rows, int cols);
 int anemoi_col_sum(int dtype, const void* x, int64_t ldx, int64_t rows, int cols, float* out, float* workspace,
                    int64_t workspace_floats, anemoi_stream_t stream);
 
+/* out[r] = sum_c a[r, c] * (b[r, c] - shift[c]) in f32 (shift optional: f32 [cols]).  The training route's folded
+ * "embedding -> LayerNorm -> Linear" product y = rstd * (x F^T) + b' needs d rstd[r] = sum_c dy[r, c] (y[r, c] - b'[c]) / rstd[r]
+ * (anemoi_models_amd/autograd.py::_ScaledLinear; reference layers/mapper.py:322-331 + layers/block.py:516-528 under autograd). */
+int anemoi_row_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, const float* shift, float* out,
+                   int64_t rows, int cols, anemoi_stream_t stream);
+
+/* out[r, c] = alpha * s[r] * x[r, c] (s: f32 per row; out in x's dtype, may alias x): the row scalings of the same folded
+ * product's backward (dx = rstd (dy F), dF = dy^T (rstd x)) and of its variance term x^T (A^T A / C) x. */
+int anemoi_row_scale(int dtype, const void* x, int64_t ldx, const float* s, float alpha, void* out, int64_t ldo,
+                     int64_t rows, int cols, anemoi_stream_t stream);
+
 /* out = act(pre) (+ residual): the differentiable forward keeps `pre` for act' and applies the activation in one pass. */
 int anemoi_act_forward(int dtype, int act, const void* pre, int64_t ldp, const void* residual, int64_t ldr, void* out,
                        int64_t ldo, int64_t rows, int cols, anemoi_stream_t stream);
