@@ -1054,6 +1054,62 @@ def test_col_sum_two_stages(dtype, rows, cols):
     assert torch.equal(got, ops.col_sum(x))  # fixed summation order
 
 
+@pytest.mark.parametrize("dtype,rows,cols,ld_extra", [(torch.bfloat16, 5000, 2048, 0), (torch.bfloat16, 777, 264, 8),
+                                                      (torch.float32, 300, 100, 4), (torch.bfloat16, 33, 10, 0)])
+def test_row_dot_and_row_scale(dtype, rows, cols, ld_extra):
+    """anemoi_row_dot (out[r] = sum_c a (b - shift), f32) and anemoi_row_scale (alpha s[r] x[r, :]) against torch, padded
+    leading dimensions and widths off the 16-byte granule included."""
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(rows + cols)
+    a = torch.randn(rows, cols + ld_extra, generator=g).to(dtype).to(DEV)[:, :cols]
+    b = torch.randn(rows, cols + ld_extra, generator=g).to(dtype).to(DEV)[:, :cols]
+    shift = torch.randn(cols, generator=g).to(DEV)
+    for sh in (None, shift):
+        got = ops.row_dot(a, b, sh)
+        want = (a.double() * (b.double() - (0 if sh is None else sh.double()))).sum(1)
+        assert got.dtype == torch.float32 and rel_err(got, want) < 1e-5
+    s_ = torch.randn(rows, generator=g).to(DEV)
+    got = ops.row_scale(a, s_, 2.0)
+    want = (2.0 * s_.double()[:, None] * a.double())
+    assert got.dtype == dtype and rel_err(got, want) < (1e-6 if dtype == torch.float32 else 4e-3)
+    inplace = a.clone()
+    ops.row_scale(inplace, s_, 2.0, out=inplace)
+    assert torch.equal(inplace, got)
+
+
+@pytest.mark.parametrize("m,k_in,c,n", [(3000, 100, 512, 768), (1500, 40, 256, 256)])
+def test_folded_embedding_ln_linear_matches_torch_autograd(m, k_in, c, n):
+    """autograd.folded_embedding_ln_linear -- Linear(LayerNorm(emb(x))) on the raw features, the training route's form of the
+    embedding fold (reference layers/mapper.py:322-331 + layers/block.py:516-528) -- against the unfolded chain under torch
+    autograd in f64: output and the gradients of x, the embedding, the LayerNorm and the Linear."""
+    from anemoi_models_amd import autograd
+
+    g = torch.Generator().manual_seed(m)
+    x = torch.randn(m, k_in, generator=g)
+    p = {"ew": torch.randn(c, k_in, generator=g) / k_in**0.5, "eb": 0.1 * torch.randn(c, generator=g),
+         "gamma": 1 + 0.1 * torch.randn(c, generator=g), "beta": 0.1 * torch.randn(c, generator=g),
+         "w": torch.randn(n, c, generator=g) / c**0.5, "b": 0.1 * torch.randn(n, generator=g)}
+    dy = torch.randn(m, n, generator=g)
+    xb = x.bfloat16()
+
+    def run(dev, dtype, fn):
+        xx = xb.to(dev).to(dtype).requires_grad_(True)
+        pp = {k: v.to(dev).to(torch.float64 if dtype == torch.float64 else torch.float32).requires_grad_(True) for k, v in p.items()}
+        y = fn(xx, pp)
+        y.backward(dy.to(dev).to(y.dtype))
+        return y.detach(), xx.grad, {k: v.grad for k, v in pp.items()}
+
+    ref = run("cpu", torch.float64, lambda xx, pp: torch.nn.functional.linear(torch.nn.functional.layer_norm(
+        torch.nn.functional.linear(xx, pp["ew"], pp["eb"]), (c,), pp["gamma"], pp["beta"], 1e-5), pp["w"], pp["b"]))
+    got = run(DEV, torch.bfloat16, lambda xx, pp: autograd.folded_embedding_ln_linear(
+        xx, pp["ew"], pp["eb"], pp["gamma"], pp["beta"], 1e-5, pp["w"], pp["b"]))
+    assert rel_err(got[0], ref[0]) < 2e-2
+    assert rel_err(got[1], ref[1]) < 3e-2
+    for k in p:
+        assert rel_err(got[2][k], ref[2][k]) < 3e-2, k
+
+
 @pytest.mark.parametrize("m,k,hid,n,act,res", [(2500, 256, 1024, 256, "GELU", True), (4096, 512, 2048, 512, "SiLU", False),
                                                (1100, 1024, 4096, 1024, "GELU", True), (300, 64, 256, 64, "GELU", True)])
 def test_mlp2_fused_node_matches_torch_autograd(m, k, hid, n, act, res):
