@@ -412,17 +412,32 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
   const int srow = lane >> 3, scp = lane & 7;
   const bf16_t* kbase = qkv + (int64_t)b * S * ld + C + h * ATT_D;
   const bf16_t* vbase = vt + ((int64_t)b * H + h) * ATT_D * S_pad;
+  // Buffer descriptors: the per-lane offsets are loop invariants, the tile enters as a scalar offset -- four LDS-DMA
+  // instructions and two scalar multiplies per tile instead of four 64-bit address chains.  K rows behind the sequence
+  // end lie outside the descriptor and read as zeros (their scores are masked anyway); the launcher keeps calls whose
+  // q|k|v block of one batch element exceeds the 2 GiB descriptor range on the 8-wave kernel.
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(kbase), 0, (int)(((int64_t)(S - 1) * ld + ATT_D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(vbase), 0, (int)((int64_t)ATT_D * S_pad * 2), 0x00020000);
+  int koff[2], voff[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int sr = (wid * 2 + g) * 8 + srow;
+    const int sc = aswz(sr, scp);
+    koff[g] = sr * (int)ld * 2 + sc * 16;
+    voff[g] = sr * S_pad * 2 + sc * 16;
+  }
+  const int ktile_bytes = ATT_KV * (int)ld * 2;
   auto stage = [&](int kt, int buf) {
     char* ks_ = smem + buf * ATT_STAGE;
     char* vs_ = ks_ + K_TILE;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const int sr = (wid * 2 + g) * 8 + srow;
-      const int sc = aswz(sr, scp);
-      int key = kt * ATT_KV + sr;
-      if (key > S - 1) key = S - 1;
-      aglds16(reinterpret_cast<const char*>(kbase + (int64_t)key * ld) + sc * 16, ks_ + (wid * 2 + g) * 1024);
-      aglds16(reinterpret_cast<const char*>(vbase + (int64_t)sr * S_pad + kt * ATT_KV) + sc * 16, vs_ + (wid * 2 + g) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(ks_ + (wid * 2 + g) * 1024), 16,
+                                               koff[g], kt * ktile_bytes, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(vs_ + (wid * 2 + g) * 1024), 16,
+                                               voff[g], kt * (ATT_KV * 2), 0, 0);
     }
   };
   constexpr int DMA_PER_STAGE = 4;
@@ -453,6 +468,20 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
   float m_run[W4_QB], l_run[W4_QB];
 #pragma unroll
   for (int qb = 0; qb < W4_QB; ++qb) m_run[qb] = -INFINITY, l_run[qb] = 0.f;
+  af32x16_t lacc[2];   // row sums on the matrix pipe (!DROP), one tuple per PAIR: registers 0..7 block 0, 8..15 block 1
+  abf16x8_t onesf[2];  // A fragments: ones in rows 0..15 / in rows 16..31
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint32_t one2 = ((ql >> 4) == i) ? 0x3f803f80u : 0u;
+    uint32_t ow[4] = {one2, one2, one2, one2};
+    onesf[i] = *reinterpret_cast<abf16x8_t*>(ow);
+  }
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[pr][r] = 0.f;
+    asm volatile("" : "+a"(lacc[pr]));
+  }
   const int kperm = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);  // K row of MFMA row i: index bits 2 and 3 swapped
 
   auto k_frags = [&](const char* ks_, int kb, abf16x8_t (&kf)[NKS]) {
@@ -486,15 +515,28 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
                        af32x16_t (&sb)[2], af32x16_t (&sa)[2], abf16x8_t (&pbn)[2][2]) {
     constexpr bool DO_PV = decltype(do_pv_c)::value, DO_S = decltype(do_s_c)::value;
     constexpr int PV_PR = decltype(pv_pr_c)::value, S_PR = decltype(s_pr_c)::value, SM_PR = decltype(sm_pr_c)::value;
-    (void)&o_acc; (void)&qf;  // (named once outside the asm operands: clang does not capture a variable it only meets there)
+    (void)&o_acc; (void)&qf; (void)&lacc; (void)&onesf;  // (named once outside the asm operands: clang does not capture a variable it only meets there)
+    // MFMA n of a half step: 0..7 = P V of pair PV_PR; then, interleaved, the four ROW-SUM products of the same
+    // probabilities (8, 10, 12, 14) and S^T of pair S_PR (9, 11, 13, 15..19).  Row sums: a fragment of ones times P^T -- every
+    // row of the 32 x 32 result = the column sums -- so the normaliser comes off the matrix pipe, which has slack, instead of
+    // 16 v_dot2c per half step on the VALU, which is the bound (-0.6 ms per layer without them).  The two query blocks of a
+    // pair share ONE accumulator tuple: the ones sit in rows 0..15 for block 0 and in rows 16..31 for block 1, i.e. the sums
+    // land in registers 0..7 / 8..15 (four tuples would take the last free AGPRs, and an allocator short of registers moves
+    // tuples around behind the asm MFMAs that just wrote them).  Their four accumulations are one dependency chain, hence the
+    // S^T MFMAs between them.  Not with dropout: there the normaliser must see the probabilities BEFORE the mask, so the
+    // DROP variant keeps the dot products.
 #define W4_MF(n)                                                                                                     \
   do {                                                                                                               \
     if constexpr ((n) < 8) {                                                                                         \
       if constexpr (DO_PV)                                                                                           \
         W4_MFMA_O(o_acc[2 * PV_PR + ((n) & 1)][(n) >> 2], vf[(n) >> 2][((n) >> 1) & 1], pbo[(n) & 1][((n) >> 1) & 1]); \
+    } else if constexpr ((n) < 16 && ((n) & 1) == 0) {                                                               \
+      constexpr int lj_ = ((n) - 8) >> 1; /* 0 .. 3: block i = lj & 1, fragment kk = lj >> 1 */                      \
+      if constexpr (DO_PV && !DROP) W4_MFMA_O(lacc[PV_PR], onesf[lj_ & 1], pbo[lj_ & 1][lj_ >> 1]);                  \
     } else if constexpr (DO_S) {                                                                                     \
-      if constexpr ((n) < 10) W4_MFMA_S0(sb[(n) & 1], kf[0], qf[2 * S_PR + ((n) & 1)][0]);                           \
-      else W4_MFMA_S(sb[(n) & 1], kf[((n) - 8) >> 1], qf[2 * S_PR + ((n) & 1)][((n) - 8) >> 1]);                     \
+      constexpr int st_ = (n) < 16 ? ((n) - 9) >> 1 : (n) - 12; /* 0 .. 7: block i = st & 1, k step = st >> 1 */     \
+      if constexpr (st_ < 2) W4_MFMA_S0(sb[st_ & 1], kf[0], qf[2 * S_PR + (st_ & 1)][0]);                            \
+      else W4_MFMA_S(sb[st_ & 1], kf[st_ >> 1], qf[2 * S_PR + (st_ & 1)][st_ >> 1]);                                 \
     }                                                                                                                \
   } while (0)
     // ---- softmax of pair SM_PR on sa, slices of it between the MFMAs
@@ -513,104 +555,126 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
     // (a later score more than ~70 above the first block's maximum) shows as a non-finite row sum at the end and raises
     // the call's fallback flag: the launcher's second kernel (the 8-wave kernel with the exact online maximum) then
     // recomputes the call -- it exits at once when the flag is clear.
-    const uint32_t ones2 = 0x3f803f80u;
     float m_neg[2], psum[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 2; ++i) m_neg[i] = -m_run[2 * SM_PR + i];
     uint32_t w[2][2][4];
-    // 16 slots: MFMA n, then three independent VALU stages of the softmax, software pipelined over the 16 packed pairs of
-    // the two query blocks (pair c: block i = c >> 3, fragment kk = (c >> 2) & 1, word j = c & 3):
-    //     C(n): pack + row sum      B(n + 1): the two exp2      A(n + 2): the two fma
-    // so that no instruction of a slot waits for another one of the same slot.  The VALU side is inline asm as well: pure
-    // arithmetic is not ordered against the (volatile) MFMA asm, and instruction selection moves ALL of it in front of or
-    // behind the run of MFMAs -- the scheduling fences only hold what selection already put between them; two volatile asm
-    // statements stay in source order.  Early-clobber outputs: a stage's result must not land in a register a later
+    // TWENTY slots, one MFMA each (the matrix pipe takes one MFMA of a wave at a time: an MFMA with no VALU work behind it
+    // is 32 idle issue cycles), and the softmax of the 16 packed pairs of the two query blocks (pair c: block i = c >> 3,
+    // fragment kk = (c >> 2) & 1, word j = c & 3) cut to fit them:
+    //     4 F slots: the eight fma (exp2 arguments) of the NEXT four pairs                      -- 32 cycles
+    //    16 E slots: the two exp2 of pair n, pack (+ dropout: row sum) of pair n - 1            -- 36 cycles
+    // in the order F E E E E F E E E E ...; every instruction reads what an EARLIER slot produced.  The VALU side is inline
+    // asm as well: pure arithmetic is not ordered against the (volatile) MFMA asm, and instruction selection moves ALL of it
+    // in front of or behind the run of MFMAs -- the scheduling fences only hold what selection already put between them; two
+    // volatile asm statements stay in source order.  Early-clobber outputs: a result must not land in a register a later
     // instruction of the same statement still reads.
-    float ta[2][2], tb[2][2];  // [slot parity][element]: fma results, exp2 results
+    float ta[4][2], tb[2][2];  // exp2 arguments of the current group of four pairs; exp2 results [slot parity]
     const float sc = scale_log2e;
-    // the first two A stages and the first B stage (sa[0]'s last MFMA is two slots back: 8 instructions + these wait states)
-    asm volatile("s_nop 3" ::: "memory");
-    ta[0][0] = fmaf(sa[0][0], sc, m_neg[0]);
-    ta[0][1] = fmaf(sa[0][1], sc, m_neg[0]);
-    ta[1][0] = fmaf(sa[0][2], sc, m_neg[0]);
-    ta[1][1] = fmaf(sa[0][3], sc, m_neg[0]);
-    tb[0][0] = __builtin_amdgcn_exp2f(ta[0][0]);
-    tb[0][1] = __builtin_amdgcn_exp2f(ta[0][1]);
-    auto valu = [&](auto n_c) {
+#define W4_DOT2C_DROP "v_dot2c_f32_bf16 %[ps], 0x3f803f80, %[w]"
+#define W4_DOT2C_NONE "s_nop 0"
+    auto f_slot = [&](auto g_c) {  // pairs 4 g .. 4 g + 3
+      constexpr int g = decltype(g_c)::value, i = g >> 1, e0 = (g & 1) * 8;  // elements e0 .. e0 + 7 of sa[i]
+      (void)&ta; (void)&sa; (void)&m_neg; (void)&sc;  // (clang does not capture what it only meets as an asm operand)
+      asm volatile("v_fma_f32 %[u0], %[s0], %[sc], %[mn]\n\t"
+                   "v_fma_f32 %[u1], %[s1], %[sc], %[mn]\n\t"
+                   "v_fma_f32 %[u2], %[s2], %[sc], %[mn]\n\t"
+                   "v_fma_f32 %[u3], %[s3], %[sc], %[mn]\n\t"
+                   "v_fma_f32 %[u4], %[s4], %[sc], %[mn]\n\t"
+                   "v_fma_f32 %[u5], %[s5], %[sc], %[mn]\n\t"
+                   "v_fma_f32 %[u6], %[s6], %[sc], %[mn]\n\t"
+                   "v_fma_f32 %[u7], %[s7], %[sc], %[mn]"
+                   : [u0] "=&v"(ta[0][0]), [u1] "=&v"(ta[0][1]), [u2] "=&v"(ta[1][0]), [u3] "=&v"(ta[1][1]),
+                     [u4] "=&v"(ta[2][0]), [u5] "=&v"(ta[2][1]), [u6] "=&v"(ta[3][0]), [u7] "=&v"(ta[3][1])
+                   : [s0] "v"(sa[i][e0]), [s1] "v"(sa[i][e0 + 1]), [s2] "v"(sa[i][e0 + 2]), [s3] "v"(sa[i][e0 + 3]),
+                     [s4] "v"(sa[i][e0 + 4]), [s5] "v"(sa[i][e0 + 5]), [s6] "v"(sa[i][e0 + 6]), [s7] "v"(sa[i][e0 + 7]),
+                     [sc] "s"(sc), [mn] "v"(m_neg[i]));
+    };
+    auto e_slot = [&](auto n_c) {
       constexpr int n = decltype(n_c)::value;
-      constexpr int i = n >> 3, kk = (n >> 2) & 1, j = n & 3;
-      constexpr int c2 = n + 2, i2 = (c2 >> 3) & 1, kk2 = (c2 >> 2) & 1, j2 = c2 & 3;
-      // (slot 0 packs the exponentials the COMPILER issued just above: a transcendental's result needs a wait state before
-      //  a VALU read, and the hazard recognizer does not look into the asm -- NaN probabilities in a quarter of the lanes)
-      //  -- the wait states sit INSIDE slot 0's statement: pure instructions may be placed between two asm statements)
-#define W4_VALU_FULL(PREFIX)                                                                                              \
-  asm volatile(PREFIX "v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"                                                           \
-                      "v_exp_f32 %[f0], %[t0]\n\t"                                                                         \
-                      "v_exp_f32 %[f1], %[t1]\n\t"                                                                         \
-                      "v_fma_f32 %[u0], %[s0], %[sc], %[mn]\n\t"                                                           \
-                      "v_fma_f32 %[u1], %[s1], %[sc], %[mn]\n\t"                                                           \
-                      "v_dot2c_f32_bf16 %[ps], 0x3f803f80, %[w]"                                                           \
-               : [w] "=&v"(w[i][kk][j]), [f0] "=&v"(tb[(n + 1) & 1][0]), [f1] "=&v"(tb[(n + 1) & 1][1]),                   \
-                 [u0] "=&v"(ta[n & 1][0]), [u1] "=&v"(ta[n & 1][1]), [ps] "+v"(psum[i])                                    \
-               : [e0] "v"(tb[n & 1][0]), [e1] "v"(tb[n & 1][1]), [t0] "v"(ta[(n + 1) & 1][0]), [t1] "v"(ta[(n + 1) & 1][1]), \
-                 [s0] "v"(sa[i2][kk2 * 8 + 2 * j2]), [s1] "v"(sa[i2][kk2 * 8 + 2 * j2 + 1]), [sc] "s"(sc), [mn] "v"(m_neg[i2]))
+      constexpr int pi = (n - 1) >> 3, pkk = ((n - 1) >> 2) & 1, pj = (n - 1) & 3;  // pair n - 1: pack (+ row sum)
+      (void)&ta; (void)&tb; (void)&w; (void)&psum;
+#define W4_E_FIRST                                                   \
+  asm volatile("v_exp_f32 %[f0], %[t0]\n\t"                          \
+               "v_exp_f32 %[f1], %[t1]"                              \
+               : [f0] "=&v"(tb[0][0]), [f1] "=&v"(tb[0][1])          \
+               : [t0] "v"(ta[0][0]), [t1] "v"(ta[0][1]))
+#define W4_E(DOT)                                                                                                    \
+  asm volatile("v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"                                                           \
+               "v_exp_f32 %[f0], %[t0]\n\t"                                                                         \
+               "v_exp_f32 %[f1], %[t1]\n\t" DOT                                                                     \
+               : [w] "=&v"(w[pi][pkk][pj]), [f0] "=&v"(tb[n & 1][0]), [f1] "=&v"(tb[n & 1][1]), [ps] "+v"(psum[pi]) \
+               : [e0] "v"(tb[(n - 1) & 1][0]), [e1] "v"(tb[(n - 1) & 1][1]), [t0] "v"(ta[n & 3][0]), [t1] "v"(ta[n & 3][1]))
       if constexpr (n == 0) {
-        W4_VALU_FULL("s_nop 1\n\t");
-      } else if constexpr (n < 14) {
-        W4_VALU_FULL("");
-#undef W4_VALU_FULL
-      } else if constexpr (n == 14) {
-        asm volatile(
-            "v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"
-            "v_exp_f32 %[f0], %[t0]\n\t"
-            "v_exp_f32 %[f1], %[t1]\n\t"
-            "v_dot2c_f32_bf16 %[ps], 0x3f803f80, %[w]"
-            : [w] "=&v"(w[i][kk][j]), [f0] "=&v"(tb[(n + 1) & 1][0]), [f1] "=&v"(tb[(n + 1) & 1][1]), [ps] "+v"(psum[i])
-            : [e0] "v"(tb[n & 1][0]), [e1] "v"(tb[n & 1][1]), [t0] "v"(ta[(n + 1) & 1][0]), [t1] "v"(ta[(n + 1) & 1][1]));
+        W4_E_FIRST;
       } else {
-        asm volatile(
-            "v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"
-            "s_nop 0\n\t"
-            "v_dot2c_f32_bf16 %[ps], 0x3f803f80, %[w]\n\t"
-            "s_nop 3"  // a dot product's result is not forwarded to an ordinary VALU read right behind it (the compiler
-                       // does not see the hazard inside the asm: the row sum lost this last pair)
-            : [w] "=&v"(w[i][kk][j]), [ps] "+v"(psum[i])
-            : [e0] "v"(tb[n & 1][0]), [e1] "v"(tb[n & 1][1]));
+        if constexpr (DROP) W4_E(W4_DOT2C_DROP);
+        else W4_E(W4_DOT2C_NONE);
       }
-      if constexpr (DROP) {
-        const uint32_t x = dropout_mix(drow[2 * SM_PR + i] ^ ((uint32_t)(key0 >> 1) + 8u * kk + j) * 0xC2B2AE3Du);
+#undef W4_E_FIRST
+#undef W4_E
+      if constexpr (DROP && n > 0) {
+        const uint32_t x = dropout_mix(drow[2 * SM_PR + pi] ^ ((uint32_t)(key0 >> 1) + 8u * pkk + pj) * 0xC2B2AE3Du);
         const uint32_t keep = ((x & 0xffffu) >= dr.thr16 ? 0x0000ffffu : 0u) | ((x >> 16) >= dr.thr16 ? 0xffff0000u : 0u);
-        w[i][kk][j] &= keep;
+        w[pi][pkk][pj] &= keep;
       }
     };
-#define W4_SLOT(n)                                   \
-  do {                                               \
-    W4_MF(n);                                        \
-    valu(std::integral_constant<int, (n)>{});        \
-  } while (0)
-    W4_SLOT(0);
-    W4_SLOT(1);
-    W4_SLOT(2);
-    W4_SLOT(3);
-    W4_SLOT(4);
-    W4_SLOT(5);
-    W4_SLOT(6);
-    W4_SLOT(7);
-    W4_SLOT(8);
-    W4_SLOT(9);
-    W4_SLOT(10);
-    W4_SLOT(11);
-    W4_SLOT(12);
-    W4_SLOT(13);
-    W4_SLOT(14);
-    W4_SLOT(15);
-#undef W4_SLOT
+    // the last pair's pack (+ row sum); wait states: the exponentials right above, and a dot product's result is not
+    // forwarded to an ordinary VALU read right behind it (the compiler sees neither hazard inside the asm)
+    auto tail = [&]() {
+      (void)&tb; (void)&w; (void)&psum;
+#define W4_TAIL(DOT)                                                  \
+  asm volatile("s_nop 0\n\t"                                         \
+               "v_cvt_pk_bf16_f32 %[w], %[e0], %[e1]\n\t"            \
+               "s_nop 0\n\t" DOT "\n\t"                              \
+               "s_nop 3"                                              \
+               : [w] "=&v"(w[1][1][3]), [ps] "+v"(psum[1])            \
+               : [e0] "v"(tb[1][0]), [e1] "v"(tb[1][1]))
+      if constexpr (DROP) W4_TAIL(W4_DOT2C_DROP);
+      else W4_TAIL(W4_DOT2C_NONE);
+#undef W4_TAIL
+      if constexpr (DROP) {
+        const uint32_t x = dropout_mix(drow[2 * SM_PR + 1] ^ ((uint32_t)(key0 >> 1) + 8u + 3u) * 0xC2B2AE3Du);
+        const uint32_t keep = ((x & 0xffffu) >= dr.thr16 ? 0x0000ffffu : 0u) | ((x >> 16) >= dr.thr16 ? 0xffff0000u : 0u);
+        w[1][1][3] &= keep;
+      }
+    };
+    asm volatile("s_nop 3" ::: "memory");  // (sa[0]'s last MFMA is two slots back: these wait states on top)
+#define W4_F(g) f_slot(std::integral_constant<int, (g)>{})
+#define W4_E(n) e_slot(std::integral_constant<int, (n)>{})
+    // (20 MFMAs in numeric order: two accumulations into the same block always have another MFMA between them -- back to
+    //  back, the second would read its accumulator before the first has written it, and behind asm nobody inserts the wait)
+    W4_MF(0);  W4_F(0);
+    W4_MF(1);  W4_E(0);
+    W4_MF(2);  W4_E(1);
+    W4_MF(3);  W4_E(2);
+    W4_MF(4);  W4_E(3);
+    W4_MF(5);  W4_F(1);
+    W4_MF(6);  W4_E(4);
+    W4_MF(7);  W4_E(5);
+    W4_MF(8);  W4_E(6);
+    W4_MF(9);  W4_E(7);
+    W4_MF(10); W4_F(2);
+    W4_MF(11); W4_E(8);
+    W4_MF(12); W4_E(9);
+    W4_MF(13); W4_E(10);
+    W4_MF(14); W4_E(11);
+    W4_MF(15); W4_F(3);
+    W4_MF(16); W4_E(12);
+    W4_MF(17); W4_E(13);
+    W4_MF(18); W4_E(14);
+    W4_MF(19); W4_E(15);
+    tail();
+#undef W4_F
+#undef W4_E
+#undef W4_DOT2C_DROP
+#undef W4_DOT2C_NONE
 #undef W4_MF
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) pbn[i][kk] = *reinterpret_cast<abf16x8_t*>(w[i][kk]);
-      l_run[2 * SM_PR + i] += psum[i];
+      if constexpr (DROP) l_run[2 * SM_PR + i] += psum[i];
     }
   };
   using T_ = std::true_type;
@@ -685,6 +749,15 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < 2; ++i) W4_MFMA_O(o_acc[2 + i][dt], vf1[dt][kk], p1[i][kk]);
+    if constexpr (!DROP) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (one dependency chain, nothing between its links here)
+          W4_MFMA_O(lacc[1], onesf[i], p1[i][kk]);
+        }
+    }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   }
 #undef W4_MFMA_S0
@@ -693,7 +766,8 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
 
 #pragma unroll
   for (int qb = 0; qb < W4_QB; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    // (the MFMA row sums already span both K halves of every block: no exchange between the lane halves)
+    const float l_tot = DROP ? l_run[qb] + __shfl_xor(l_run[qb], 32, 64) : lacc[qb >> 1][(qb & 1) * 8];
     if (!(l_tot < 1e37f) && qn[qb] < S) *redo_flag = 1;  // (also NaN) a probability left the f32 range: see the half step
     float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if constexpr (DROP) inv *= dr.keep_scale;
@@ -1399,7 +1473,7 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
                      scale * 1.44269504088896340736f, lse, dr)
     // D = 64, global attention: the 4-wave software-pipelined kernel; its fallback (a probability left the f32 range under
     // the fixed reference maximum) is the 8-wave kernel behind a device-side flag -- no host round trip, graph capturable
-    if (D == 64 && window < 0) {
+    if (D == 64 && window < 0 && (int64_t)S * ld * 2 < ((int64_t)1 << 31)) {
       int* flag = reinterpret_cast<int*>(static_cast<char*>(workspace) + mhsa_vt_bytes(B, S, H, D) + mhsa_tail_bytes(B, S, H, D));
       if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return fail(ANEMOI_ERR_LAUNCH, "anemoi_mhsa: flag reset");
       const dim3 block4(64 * W4_WAVES);
