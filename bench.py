@@ -206,7 +206,7 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
         achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype_name]
         out["roofline_mhsa"] = {
-            "kernel": "anemoi::mhsa_bf16_kernel<D> (anemoi_mhsa: flash attention on v_mfma_f32_32x32x16_bf16, D = 64 | 32)",
+            "kernel": "anemoi::mhsa_bf16_w4_kernel (D = 64, global) / mhsa_bf16_kernel<D> (anemoi_mhsa: flash attention on v_mfma_f32_32x32x16_bf16)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None, "launches": a["launches"],
             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "flops_per_launch": a["flops"] / a["launches"],
