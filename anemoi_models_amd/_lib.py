@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -133,7 +133,8 @@ SIGNATURES = {
                                     c_void_p]),
     "anemoi_layer_norm_backward_workspace_floats": (c_int64, [c_int64, c_int]),
     "anemoi_layer_norm_backward": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                                           c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+                                           c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_int64, c_void_p]),
     "anemoi_gt_edge_attention_folded_backward_dst": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                                              c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                                              c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -185,6 +185,34 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None
 
 
+class _LayerNormSkip(torch.autograd.Function):
+    """``(LayerNorm(x), x)``: the normalised rows for the branch AND the rows themselves for the skip connection around
+    it (``x + f(norm(x))``, reference layers/block.py:504-508, 614-635) as ONE autograd node -- the backward receives both
+    gradients and ``anemoi_layer_norm_backward`` adds the skip's into ``dx`` in its own pass, instead of autograd
+    accumulating the two contributions with a separate add over ``[N, C]`` (36 of them per config-3 training step)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+        y, stats = ops.layer_norm_with_stats(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(),
+                                             eps)
+        ctx.save_for_backward(x, stats, gamma)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor, dskip: Optional[Tensor]):
+        x, stats, gamma = ctx.saved_tensors
+        if dy is None:  # the branch is unused: only the skip carries a gradient
+            return dskip, None, None, None
+        dx, dgamma, dbeta = ops.layer_norm_backward(x, stats, gamma, dy.contiguous(),
+                                                    None if dskip is None else dskip.contiguous())
+        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None
+
+
+def layer_norm_skip(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5):
+    """``(layer_norm(x), x)`` -- use the second result for the skip connection around the normalised branch."""
+    return _LayerNormSkip.apply(x, gamma, beta, eps)
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = "Identity",
            residual: Optional[Tensor] = None) -> Tensor:
     """``act(x @ weight.T + bias) + residual`` with gradients for ``x``, ``weight``, ``bias`` and ``residual``.
@@ -647,7 +675,7 @@ def _gt_tail(y_att: Tensor, x_skip: Tensor, sd: dict, prefix: str, w_t: Optional
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
     w_p = g("projection.weight") if w_t is None else torch.cat([g("projection.weight"), w_t], dim=1)
     y = linear(y_att, w_p, g("projection.bias"), "Identity", x_skip)
-    h1 = layer_norm(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
+    h1, y = layer_norm_skip(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
     return mlp2(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), g("node_dst_mlp.3.weight"),
                 g("node_dst_mlp.3.bias"), act, y)
 
@@ -673,7 +701,7 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
     w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x.device)
     w_in = torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight"), w_u], 0)
     b_in = torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias"), b_u], 0)
-    xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
+    xh, x = layer_norm_skip(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
     sq = linear(xh, w_in, b_in)  # x_r | q | k | v | u
     att = _GTEdgeAttentionSelf.apply(sq, edge_attr_csr, plan, h, up)
     return _gt_tail(att, x, sd, prefix, w_t, act, eps)
@@ -697,7 +725,7 @@ def gt_mapper_block(x_src: Optional[Tensor], x_dst: Tensor, sd: dict, prefix: st
     else:
         kv = linear(layer_norm(x_src, g("layer_norm1.weight"), g("layer_norm1.bias"), eps), w_kv, b_kv)
     if sq_fn is None or up > FOLD_MAX_UP:
-        xd = layer_norm(x_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), eps)
+        xd, x_dst = layer_norm_skip(x_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), eps)
     if up > FOLD_MAX_UP:  # see gt_processor_block
         sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight")], 0),
                     torch.cat([g("lin_self.bias"), g("lin_query.bias")], 0))

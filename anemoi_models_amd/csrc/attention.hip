@@ -444,12 +444,11 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
   auto publish = [&](int kt) {  // barrier "kt": tile kt readable by everyone, tile kt + 2 requested
     if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the bare barrier, not __syncthreads(): its fence makes the compiler wait for vmcnt(0) -- i.e. for the DMA of tile
-    // kt + 1 as well, the one request this loop wants to keep in flight across the barrier.  The only LDS writers are the
-    // DMAs counted above; this wave's LDS reads of the buffer refilled next were consumed by MFMAs already issued.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    // __syncthreads(), fence included: here the compiler waits for vmcnt(0) in it, i.e. also for the DMA of tile kt + 1 that
+    // the counted wait above would let stay in flight.  The bare s_barrier behind the counted wait was measured -- same
+    // speed -- and is NOT safe: single keys of a tile were occasionally read stale (results differing in the last bit of a
+    // few rows between identical calls, ~8 % of the calls at S = 700; found by bit-comparing repeated calls, now a test).
+    __syncthreads();
     if (kt + 2 < kt_end) stage(kt + 2, (kt + 2 - kt_begin) % N_STAGE);
   };
   static_assert(DMA_PER_STAGE == 4, "the counted wait above");

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
                                                                   const float* __restrict__ gamma,
                                                                   const T* __restrict__ dy, int64_t ldd,
                                                                   T* __restrict__ dx, int64_t ldo, int64_t rows, int C,
-                                                                  int rows_per_wg, float* __restrict__ partial) {
+                                                                  int rows_per_wg, float* __restrict__ partial,
+                                                                  const T* __restrict__ dres, int64_t ldr) {
   extern __shared__ float lds[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float* my_dg = lds + (size_t)wid * 2 * C;
@@ -385,6 +386,12 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
             const float xh = xv[i] * st.x + st.y;
             o[i] = st.x * (dv[i] * gv[i] - sg - xh * sgx);
           }
+          if (dres != nullptr) {  // + the gradient that reaches x through the skip connection around the LayerNorm
+            float rv[V];
+            VecIO<T, V>::load(dres + r * ldr + c, rv);
+#pragma unroll
+            for (int i = 0; i < V; ++i) o[i] += rv[i];
+          }
           VecIO<T, V>::store(dx + r * ldo + c, o);
         }
       }
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
       for (int c = lane; c < C; c += 64) {
         const float xh = Elem<T>::load(x + r * ldx + c) * st.x + st.y;
         const float g = Elem<T>::load(dy + r * ldd + c) * gamma[c];
-        Elem<T>::store(dx + r * ldo + c, st.x * (g - sg - xh * sgx));
+        Elem<T>::store(dx + r * ldo + c, st.x * (g - sg - xh * sgx) + (dres != nullptr ? Elem<T>::load(dres + r * ldr + c) : 0.f));
       }
     }
   }
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(256) void layer_norm_backward_kernel(const T* __res
 template <typename T>
 static int layer_norm_backward_launch(const T* x, int64_t ldx, const float2* stats, const float* gamma, const T* dy,
                                       int64_t ldd, T* dx, int64_t ldo, int64_t rows, int C, float* dgamma, float* dbeta,
-                                      float* workspace, int64_t workspace_floats, hipStream_t st) {
+                                      float* workspace, int64_t workspace_floats, hipStream_t st, const T* dres, int64_t ldr) {
   ANEMOI_REQUIRE((size_t)C * 8 * sizeof(float) <= 160 * 1024, ANEMOI_ERR_UNSUPPORTED,
                  "anemoi_layer_norm_backward: C = %d too wide for the LDS column partials", C);
   int rows_per_wg = (int)((rows + 1023) / 1024);
@@ -431,13 +438,14 @@ static int layer_norm_backward_launch(const T* x, int64_t ldx, const float2* sta
                             (int)lds_bytes) != hipSuccess)
       return fail(ANEMOI_ERR_LAUNCH, "anemoi_layer_norm_backward: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds_bytes, st, x, ldx, stats, gamma, dy, ldd, dx, ldo, rows,
-                       C, rows_per_wg, workspace);
+                       C, rows_per_wg, workspace, dres, ldr);
     return ANEMOI_OK;
   };
   int rc;
   constexpr int V = 16 / sizeof(T);
   const bool vec_ok = C % V == 0 && ldx % V == 0 && ldd % V == 0 && ldo % V == 0 && (uintptr_t)x % 16 == 0 &&
-                      (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)gamma % 16 == 0;
+                      (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)gamma % 16 == 0 &&
+                      (dres == nullptr || (ldr % V == 0 && (uintptr_t)dres % 16 == 0));
   if (!vec_ok) rc = launch(layer_norm_backward_kernel<T, 0>);
   else if (C <= 64 * 8) rc = launch(layer_norm_backward_kernel<T, 8>);
   else if (C <= 64 * 16) rc = launch(layer_norm_backward_kernel<T, 16>);
@@ -591,21 +599,24 @@ int64_t anemoi_layer_norm_backward_workspace_floats(int64_t rows, int C) {
 }
 
 int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const float* stats, const float* gamma,
-                               const void* dy, int64_t ldd, void* dx, int64_t ldo, int64_t rows, int C, float* dgamma,
-                               float* dbeta, float* workspace, int64_t workspace_floats, anemoi_stream_t stream) {
+                               const void* dy, int64_t ldd, const void* dres, int64_t ldr, void* dx, int64_t ldo,
+                               int64_t rows, int C, float* dgamma, float* dbeta, float* workspace,
+                               int64_t workspace_floats, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(x && stats && gamma && dy && dx && dgamma && dbeta && rows > 0 && C > 0 && ldx >= C && ldd >= C &&
-                     ldo >= C,
+                     ldo >= C && (dres == nullptr || ldr >= C),
                  ANEMOI_ERR_INVALID, "anemoi_layer_norm_backward: bad argument");
   ANEMOI_REQUIRE((uintptr_t)stats % 8 == 0, ANEMOI_ERR_INVALID, "anemoi_layer_norm_backward: stats must be 8-byte aligned");
   if (dtype == ANEMOI_F32)
     return layer_norm_backward_launch<float>(static_cast<const float*>(x), ldx, reinterpret_cast<const float2*>(stats),
                                              gamma, static_cast<const float*>(dy), ldd, static_cast<float*>(dx), ldo,
-                                             rows, C, dgamma, dbeta, workspace, workspace_floats, bw_stream(stream));
+                                             rows, C, dgamma, dbeta, workspace, workspace_floats, bw_stream(stream),
+                                             static_cast<const float*>(dres), ldr);
   if (dtype == ANEMOI_BF16)
     return layer_norm_backward_launch<bf16_t>(static_cast<const bf16_t*>(x), ldx,
                                               reinterpret_cast<const float2*>(stats), gamma,
                                               static_cast<const bf16_t*>(dy), ldd, static_cast<bf16_t*>(dx), ldo, rows,
-                                              C, dgamma, dbeta, workspace, workspace_floats, bw_stream(stream));
+                                              C, dgamma, dbeta, workspace, workspace_floats, bw_stream(stream),
+                                              static_cast<const bf16_t*>(dres), ldr);
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_layer_norm_backward: dtype %d", dtype);
 }
 

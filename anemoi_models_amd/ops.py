@@ -703,9 +703,10 @@ def act_backward(pre: Tensor, dy: Tensor, act: str) -> Tensor:
     return out
 
 
-def layer_norm_backward(x: Tensor, stats: Tensor, gamma: Tensor, dy: Tensor):
-    """``(dx, dgamma, dbeta)`` of ``layer_norm(x) * gamma + beta`` from the forward's ``row_stats(x)``."""
-    _dev(x, stats, gamma, dy)
+def layer_norm_backward(x: Tensor, stats: Tensor, gamma: Tensor, dy: Tensor, dres: Optional[Tensor] = None):
+    """``(dx, dgamma, dbeta)`` of ``layer_norm(x) * gamma + beta`` from the forward's ``row_stats(x)``; ``dres`` (optional,
+    x's shape and dtype) is added to ``dx`` in the same pass (the skip connection's gradient)."""
+    _dev(x, stats, gamma, dy, dres)
     rows, c = _rows(x).shape
     if tuple(_rows(dy).shape) != (rows, c) or dy.dtype != x.dtype or stats.shape != (rows, 2):
         raise ValueError("layer_norm_backward: shapes of x, dy, stats do not match")
@@ -716,9 +717,12 @@ def layer_norm_backward(x: Tensor, stats: Tensor, gamma: Tensor, dy: Tensor):
     n_ws = lib.anemoi_layer_norm_backward_workspace_floats(rows, c)
     ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
     gamma = gamma.detach().float().contiguous()
+    if dres is not None and (tuple(_rows(dres).shape) != (rows, c) or dres.dtype != x.dtype):
+        raise ValueError("layer_norm_backward: dres must have x's shape and dtype")
     st = lib.anemoi_layer_norm_backward(dtype_code(x.dtype), x.data_ptr(), _ld(x), stats.data_ptr(), gamma.data_ptr(),
-                                        dy.data_ptr(), _ld(dy), dx.data_ptr(), c, rows, c, dgamma.data_ptr(),
-                                        dbeta.data_ptr(), ws.data_ptr(), n_ws, _stream())
+                                        dy.data_ptr(), _ld(dy), _ptr(dres), 0 if dres is None else _ld(_rows(dres)),
+                                        dx.data_ptr(), c, rows, c, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                                        n_ws, _stream())
     _lib.check(st, "anemoi_layer_norm_backward")
     return dx, dgamma, dbeta
 

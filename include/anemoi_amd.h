@@ -394,11 +394,14 @@ int anemoi_linear_actgrad(int dtype, const void* x, int64_t ldx, const void* w, 
  * LayerNorm backward from the forward's row statistics (stats [rows, 2] = { rstd, -mean * rstd }, anemoi_row_stats):
  *   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * gamma, xhat = x * rstd - mean * rstd;
  *   dgamma[c] = sum_r dy * xhat, dbeta[c] = sum_r dy (f32).  workspace: anemoi_layer_norm_backward_workspace_floats.
+ *   dres (optional, [rows, ldr] in x's dtype): added to dx before the store -- the gradient that reaches x through the skip
+ *   connection around the LayerNorm (layers/block.py:504-508, 614-635: x + mlp(norm(x))), instead of a separate add pass.
  */
 int64_t anemoi_layer_norm_backward_workspace_floats(int64_t rows, int C);
 int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const float* stats, const float* gamma,
-                               const void* dy, int64_t ldd, void* dx, int64_t ldo, int64_t rows, int C, float* dgamma,
-                               float* dbeta, float* workspace, int64_t workspace_floats, anemoi_stream_t stream);
+                               const void* dy, int64_t ldd, const void* dres, int64_t ldr, void* dx, int64_t ldo,
+                               int64_t rows, int C, float* dgamma, float* dbeta, float* workspace,
+                               int64_t workspace_floats, anemoi_stream_t stream);
 
 /*
  * Backward of anemoi_gt_edge_attention_folded (the edge half of SURVEY.md section 8f-1; what torch.autograd derives from
