@@ -234,8 +234,9 @@ class _ScaledLinear(torch.autograd.Function):
     """``y = s[:, None] * (x @ f.T) + b``: ``x [M, Kp]`` in the compute dtype (K padded), ``f [N, Kp]`` / ``b [N]`` f32,
     ``s [M]`` f32 -- the product behind a LayerNorm whose mean has been removed algebraically (``s`` = the row's rstd).
     Forward on ``anemoi_linear_ln`` (statistics ``{s, 0}``, zero column sums); backward: ``df = dy^T (s x)`` (TN weight
-    gradient on the scaled K-narrow rows), ``dx = s (dy f)``, ``ds = sum_n dy (y - b) / s`` (``anemoi_row_dot`` on the saved
-    output: the unscaled product is never materialised), ``db = sum_m dy``."""
+    gradient on the scaled K-narrow rows), ``g = dy f`` (one K = N product onto the Kp narrow columns), ``dx = s g``,
+    ``ds = sum_k g x`` (``anemoi_row_dot`` over the Kp columns: ``sum_n dy (x f^T)_n`` regrouped, so neither the wide
+    output nor the unscaled product is read again), ``db = sum_m dy``."""
 
     @staticmethod
     def forward(ctx, x: Tensor, f: Tensor, s: Tensor, b: Tensor):
@@ -245,20 +246,27 @@ class _ScaledLinear(torch.autograd.Function):
         stats = torch.stack([sd, torch.zeros_like(sd)], dim=1).contiguous()
         zeros = torch.zeros(f.shape[0], dtype=torch.float32, device=x.device)
         y = ops.linear(x, fp, b.detach().float().contiguous(), ln=(stats, zeros))
-        ctx.save_for_backward(x, f, s, b, y)
+        ctx.save_for_backward(x, f, s, b)
         return y
 
     @staticmethod
     def backward(ctx, dy: Tensor):
-        x, f, s, b, y = ctx.saved_tensors
+        x, f, s, b = ctx.saved_tensors
         dtype = x.dtype
         dy = dy.contiguous()
         need = ctx.needs_input_grad
         n, kp = f.shape
         sd = s.detach().float().contiguous()
         dx = df = ds = db = None
-        if need[2]:
-            ds = ops.row_dot(dy, y, b.detach().float().contiguous()) / sd
+        if need[0] or need[2]:
+            np_ = ops.round_up(n, ops.k_multiple(dtype))
+            ft = ops.transpose(f.detach().to(dtype).contiguous(), ld_out=np_)
+            dp = dy if n == np_ else ops.convert_pad(dy, dtype, np_)
+            g = ops.linear(dp, ft)
+            if need[2]:
+                ds = ops.row_dot(g, x)
+            if need[0]:
+                dx = ops.row_scale(g, sd, out=g)
         if need[1]:
             xs = ops.row_scale(x, sd)
             if need[3]:
@@ -268,12 +276,6 @@ class _ScaledLinear(torch.autograd.Function):
             df = df.to(f.dtype)
         if db is None and need[3]:
             db = ops.col_sum(dy)
-        if need[0]:
-            np_ = ops.round_up(n, ops.k_multiple(dtype))
-            ft = ops.transpose(f.detach().to(dtype).contiguous(), ld_out=np_)
-            dp = dy if n == np_ else ops.convert_pad(dy, dtype, np_)
-            dx = ops.linear(dp, ft)
-            ops.row_scale(dx, sd, out=dx)
         return dx, df, ds, (None if db is None else db.to(b.dtype))
 
 
