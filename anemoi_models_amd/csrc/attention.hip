@@ -31,6 +31,10 @@ __device__ __forceinline__ void aglds16(const void* gptr, void* lptr) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                    (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
 }
+__device__ __forceinline__ void aglds4(const void* gptr, void* lptr) {  // one dword per lane: LDS base + lane * 4
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lptr, 4, 0, 0);
+}
 __device__ __forceinline__ int aswz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 // ---------------------------------------------------------------------------------------------
@@ -986,14 +990,17 @@ static inline int mhsa_tail_splits(int B, int S, int H) {
 //   dQ kernel: a wave owns 32 queries; S^T = K Q^T exactly as in the forward (keys in the registers),
 //         dP^T = V dO^T,  dS^T = P^T (dP^T - delta),   dQ^T += K^T dS^T.
 //   The A operands with the reduction along the sequence (dO^T, Q^T, K^T) come from transposed copies [B, H, D, S_pad]
-//   made once per call (transpose_v_kernel), as V^T in the forward.  Tiles are staged with plain loads and a barrier; four
-//   workgroups per CU hide the latency (correctness-first structure: 16 / 12 MFMAs per 32 x 32 block pair against the
-//   forward's 8).  The VALU kernels below took 46 s per layer at S = 40 962 (config 3) -- unusable; they remain for f32,
-//   other head sizes and attention dropout.
+//   made once per call (transpose_v_kernel), as V^T in the forward.  Tiles travel through an LDS ring by LDS-DMA (16 / 12
+//   MFMAs per 32 x 32 block pair against the forward's 8).  The VALU kernels below took 46 s per layer at S = 40 962
+//   (config 3) -- unusable; they remain for f32 and other head sizes.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mhsa_delta_kernel(const bf16_t* __restrict__ o, int64_t ldo,
                                                          const bf16_t* __restrict__ dout, int64_t lddo,
-                                                         float* __restrict__ delta, int S, int H, int D, int64_t total) {
+                                                         float* __restrict__ delta, const float* __restrict__ lse,
+                                                         float* __restrict__ lse2p, float* __restrict__ deltap, int S,
+                                                         int S_pad, int H, int D, int64_t total) {
+  // lse2p / deltap (optional, [B, H, S_pad]): the log-sum-exp in log2 units and delta as the dK/dV kernel's LDS-DMA reads
+  // them, padded behind S with +inf (P = 0 for the rows of a ragged last query tile) and 0
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
   if (unit >= total) return;
@@ -1005,6 +1012,16 @@ __global__ __launch_bounds__(256) void mhsa_delta_kernel(const bf16_t* __restric
   if (lane < D) v = Elem<bf16_t>::load(o + bq * ldo + h * D + lane) * Elem<bf16_t>::load(dout + bq * lddo + h * D + lane);
   v = wave_sum(v);
   if (lane == 0) delta[(b * H + h) * S + q] = v;
+  if (lse2p != nullptr) {
+    const int64_t pr = (b * H + h) * S_pad;
+    if (lane == 0) {
+      lse2p[pr + q] = lse[(b * H + h) * S + q] * 1.44269504088896340736f;
+      deltap[pr + q] = v;
+    } else if (q == S - 1 && lane <= S_pad - S) {  // S_pad - S <= 63 pad entries
+      lse2p[pr + q + lane] = INFINITY;
+      deltap[pr + q + lane] = 0.f;
+    }
+  }
 }
 
 __device__ __forceinline__ int att_row_perm(int ql) { return (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1); }
@@ -1014,21 +1031,69 @@ __device__ __forceinline__ int att_rswz(int row, int chunk) {  // swizzle of a r
   return ATT_D == 64 ? aswz(row, chunk) : aswz64(row, chunk);
 }
 
-// (three waves per SIMD: the tile loop -- plain loads, two barriers per 32-query tile -- hides its latency by occupancy
-//  only; at the 212 registers the allocator takes unasked it runs two waves per SIMD, capped at 168 it spills ten and the
-//  backward of a layer at S = 40 962 goes 45.5 -> 39.3 ms; a cap of 128 spills 47)
-template <int ATT_D, bool DROP = false>
-__global__ __launch_bounds__(256, DROP ? 2 : 3) void mhsa_bwd_dkv_mfma_kernel(
+// The accumulating products of the two kernels (dV^T, dK^T, dQ^T) are inline-asm MFMAs on accumulators pinned to AGPRs,
+// each followed by eight wait states.  Found in round 3 with the builtin: the compiler had kept dQ^T in VGPRs across the
+// loop (32 + 32 v_accvgpr moves per tile) and re-used the A fragment's registers for the softmax arithmetic in the issue
+// slot right behind the MFMA that read them -- `v_mfma a[0:15], v[0:3], v[4:7], a[0:15]; v_sub_f32 v0, ...` -- and that
+// product came out wrong, deterministically, for exactly the 32 output rows of that accumulator (tools/micro/
+// mhsa_bwd_dbg.py; with the wait states or with a barrier's worth of other code behind the MFMA it is right).  The
+// hazard recognizer knows no write-after-read case on SrcA / SrcB; here the instruction stream guarantees one.
+#ifdef ATT_BWD_PROF
+__device__ unsigned long long att_prof[16];
+#define ATT_T(i)                                        \
+  do {                                                  \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    tacc[i] += t_ - tlast;                              \
+    tlast = t_;                                         \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+#else
+#define ATT_T(i)
+#endif
+constexpr int ATT_BWD_STAGES = 3;  // LDS ring of the backward kernels: tiles requested ATT_BWD_STAGES - 1 ahead
+constexpr int ATT_BWD_NW = 4;  // waves per workgroup of the two backward kernels: 32 keys (dK/dV) or 32 queries (dQ) each
+#define ANEMOI_BWD_MFMA_ACC(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+a"(ACC) : "v"(A), "v"(B))
+// the score-side products (S, dP) the same way, accumulators in VGPRs (the softmax arithmetic reads them in place)
+#define ANEMOI_BWD_MFMA_S0(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0\n\ts_nop 7" : "=&v"(ACC) : "v"(A), "v"(B))
+#define ANEMOI_BWD_MFMA_S(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(ACC) : "v"(A), "v"(B))
+
+// Round 3 (per layer at S = 40 962, D = 64: 40.9 -> 27.9 ms; dK/dV 25.5 -> 17.6, dQ 14.2 -> 10.9), in the order measured
+// with the s_memtime phase marks (ATT_T, tools/micro/mhsa_bwd_phase.py) and the PMC passes of tools/micro/mhsa_bwd_pmc.sh:
+// the waves sat in s_waitcnt for 65 % of their cycles, and not for HBM -- eight exposed LDS round trips per tile (every
+// A fragment read next to its MFMA), sixteen more for lse / delta read one dword at a time, 330 .. 500 clocks of 64-bit
+// address arithmetic per tile for the staging, and a 16-deep chain of taken branches around the window mask.  Now: LDS-DMA
+// ring (one barrier per tile), all fragments of a phase requested ahead of it, lse / delta as four 16-byte reads,
+// 32 x 32 -> 64-bit row addresses, the window code behind a template switch.  What remains (phase marks: 2700 clocks per
+// tile and wave, of which 1020 are the two resident waves' MFMAs and ~900 their softmax arithmetic): the MFMA and the
+// VALU phases of the two waves of a SIMD hardly overlap; the forward's answer (one wave per SIMD, both streams
+// interleaved by hand) has not been carried over.  Workgroups of eight waves (half the L2 -> LDS traffic) are slower
+// (18.3 / 13.2 ms): their wave pairs run in lockstep.
+template <int ATT_D, bool DROP = false, bool WIN = true>  // WIN: sliding-window mask code compiled in (window >= 0)
+__global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
-    const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT, const float* __restrict__ lse,
-    const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window,
+    const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT, const float* __restrict__ lse2p,
+    const float* __restrict__ deltap, bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window,
     float scale, float scale_log2e, const AttnDropout dr) {
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;  // chunks of 16 bytes per row
-  __shared__ __attribute__((aligned(16))) char q_s[32 * RB], do_s[32 * RB], qt_s[ATT_D * 64], dot_s[ATT_D * 64];
-  __shared__ float lse_s[32], dl_s[32];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, ql = lane & 31;
+  // Query tiles (32 queries: Q and dO rows, Q^T and dO^T rows of 64 bytes, lse / delta) travel through a ring of three LDS
+  // buffers by LDS-DMA: tile qt + 2 is requested while tile qt is computed, one barrier per tile (round 3; the first
+  // version staged every tile with plain loads between two barriers and hid the round trip by occupancy alone).  A tile
+  // array is PP pieces of 1 KiB (64 lanes x 16 bytes, landing linearly): the swizzle is applied on the SOURCE side (the
+  // lane of LDS position s of row r fetches chunk swz(r, s); both swizzles are involutions).
+  constexpr int NW = ATT_BWD_NW, PP = ATT_D / 16, ARR = PP * 1024, STAGE = 4 * ARR + 256, N_STAGE = 3;
+  constexpr int PRE = N_STAGE - 1;  // tiles requested ahead of the one being computed
+  constexpr int PPW = 4 * PP / NW, NDMA = PPW + 1;  // pieces per wave and tile (+ the lse / delta dwords)
+  static_assert(4 * PP % NW == 0, "every wave stages the same number of pieces");
+  __shared__ __attribute__((aligned(16))) char smem[N_STAGE * STAGE];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __builtin_assume(wid >= 0 && wid < NW);
+  const int half = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int key0 = (blockIdx.x * 4 + wid) * 32, key = key0 + ql, kc = key < S ? key : S - 1;
+  const int key0 = (blockIdx.x * NW + wid) * 32, key = key0 + ql, kc = key < S ? key : S - 1;
   // stationary B fragments: lane = key column, 8 consecutive d per k-step
   abf16x8_t kf[NKS], vf[NKS];
   {
@@ -1046,61 +1111,119 @@ __global__ __launch_bounds__(256, DROP ? 2 : 3) void mhsa_bwd_dkv_mfma_kernel(
     for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
   // query tiles that can see any key of this workgroup
   int qt_begin = 0, qt_end = (S + 31) / 32;
-  if (window >= 0) {
-    const int lo = (int)blockIdx.x * 128 - window, hi = (int)blockIdx.x * 128 + 127 + window;
+  if (WIN && window >= 0) {
+    const int lo = (int)blockIdx.x * (32 * NW) - window, hi = (int)blockIdx.x * (32 * NW) + 32 * NW - 1 + window;
     qt_begin = lo > 0 ? lo / 32 : 0;
     const int e = hi / 32 + 1;
     qt_end = e < qt_end ? e : qt_end;
   }
   const int prow = att_row_perm(ql);
-  const int t = threadIdx.x;
   // DROP: lane = key, so the key-pair part of the hash and the half of its 32 bits that belongs to this key are lane
   // constants; the row part moves with the query (rows below 2^32: checked by the launcher)
   const uint32_t dkey = DROP ? ((uint32_t)(key >> 1) * 0xC2B2AE3Du ^ dr.seed) : 0u;
   const int dsh = 16 * (key & 1);
   const uint32_t drow0 = DROP ? (uint32_t)dropout_row(dr, b, h, S, 0) : 0u;
-  for (int qt = qt_begin; qt < qt_end; ++qt) {
-    __syncthreads();  // the previous tile has been consumed
-    if (t < 32 * CPR) {  // Q and dO rows of the tile (row-major, swizzled)
-      const int r = t / CPR, ch = t % CPR;
-      int q = qt * 32 + r;
-      q = q < S ? q : S - 1;
-      const int64_t row = (int64_t)b * S + q;
-      *reinterpret_cast<uint4*>(q_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) =
-          *reinterpret_cast<const uint4*>(qkv + row * ld + h * ATT_D + ch * 8);
-      *reinterpret_cast<uint4*>(do_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) =
-          *reinterpret_cast<const uint4*>(dout + row * lddo + h * ATT_D + ch * 8);
-    }
-    if (t < ATT_D * 4) {  // Q^T and dO^T: D rows of 32 queries (64 bytes)
-      const int d = t >> 2, ch = t & 3;
-      const int64_t off = (((int64_t)b * H + h) * ATT_D + d) * S_pad + qt * 32 + ch * 8;
-      *reinterpret_cast<uint4*>(qt_s + d * 64 + (aswz64(d, ch) << 4)) = *reinterpret_cast<const uint4*>(qT + off);
-      *reinterpret_cast<uint4*>(dot_s + d * 64 + (aswz64(d, ch) << 4)) = *reinterpret_cast<const uint4*>(doT + off);
-    }
-    if (t < 32) {
-      const int q = qt * 32 + t;
-      lse_s[t] = q < S ? lse[((int64_t)b * H + h) * S + q] * 1.44269504088896340736f : INFINITY;  // q >= S: P = 0
-      dl_s[t] = q < S ? delta[((int64_t)b * H + h) * S + q] : 0.f;
-    }
-    __syncthreads();
-    // ---- S = Q K^T and dP = dO V^T: lane = key, register r <-> query 8 half + (r & 7) + 16 (r >> 3) of the tile
-    af32x16_t s_acc, dp_acc;
+  const int64_t bh = (int64_t)b * H + h;
+  auto stage = [&](int qt, int buf) {
+    char* sb = smem + buf * STAGE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_acc[r] = dp_acc[r] = 0.f;
+    for (int i = 0; i < PPW; ++i) {  // piece id = NW i + wave: array id / PP (Q, dO, Q^T, dO^T), piece id % PP of it
+      const int id = i * NW + wid, arr = id / PP, sub = id % PP;
+      const char* src;
+      if (arr < 2) {  // row-major tile: 1024 / RB rows per piece
+        const int r = sub * (1024 / RB) + lane / CPR;
+        int q = qt * 32 + r;
+        q = q < S ? q : S - 1;
+        const uint32_t row = (uint32_t)(b * S + q);  // (rows below 2^31: checked by the launcher)
+        const int col = h * ATT_D + att_rswz<ATT_D>(r, lane % CPR) * 8;
+        src = reinterpret_cast<const char*>(arr == 0 ? qkv + (uint64_t)row * (uint32_t)ld + col
+                                                     : dout + (uint64_t)row * (uint32_t)lddo + col);
+      } else {  // transposed tile: 16 rows d of 64 bytes per piece
+        const int d = sub * 16 + (lane >> 2);
+        const int64_t off = (bh * ATT_D + d) * S_pad + qt * 32 + aswz64(d, lane & 3) * 8;
+        src = reinterpret_cast<const char*>((arr == 2 ? qT : doT) + off);
+      }
+      aglds16(src, sb + id * 1024);
+    }
+    // lse (log2 units) of the tile's 32 queries in the lanes 0 .. 31, delta in 32 .. 63 (every wave: same bytes, same place)
+    aglds4((lane < 32 ? lse2p : deltap) + bh * S_pad + qt * 32 + (lane & 31), sb + 4 * ARR);
+  };
+#pragma unroll
+  for (int i = 0; i < PRE; ++i)
+    if (qt_begin + i < qt_end) stage(qt_begin + i, i);
+#ifdef ATT_BWD_PROF
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    ATT_T(0);
+    // this wave's requests of tile qt have landed (the PRE - 1 tiles behind it may stay in flight: vmcnt counts in order,
+    // NDMA per tile; the last PRE - 1 tiles simply drain); the barrier publishes the buffer and retires tile qt - 1,
+    // whose buffer is refilled next (see mhsa_bf16_kernel)
+    if (qt + PRE - 1 < qt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_T(1);
+    __syncthreads();
+    ATT_T(2);
+    if (qt + PRE < qt_end) stage(qt + PRE, (qt + PRE - qt_begin) % N_STAGE);
+    ATT_T(3);
+    const char* sb = smem + ((qt - qt_begin) % N_STAGE) * STAGE;
+    const char *q_s = sb, *do_s = sb + ARR, *qt_s = sb + 2 * ARR, *dot_s = sb + 3 * ARR;
+    const float* lse_s = reinterpret_cast<const float*>(sb + 4 * ARR);
+    const float* dl_s = lse_s + 32;
+    // ---- S = Q K^T and dP = dO V^T: lane = key, register r <-> query 8 half + (r & 7) + 16 (r >> 3) of the tile
+    // every A fragment of a phase is requested before the phase's first MFMA (one exposed LDS round trip per phase: with
+    // the loads next to their MFMAs the loop paid eight of them per tile, 65 % of the wave cycles in s_waitcnt); the
+    // fragments of the second phase are requested behind the score MFMAs and land under the softmax arithmetic
+    af32x16_t s_acc, dp_acc;
+    abf16x8_t fa[NKS], fb[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int ch = att_rswz<ATT_D>(prow, ks * 2 + half);
-      const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(q_s + prow * RB + (ch << 4));
-      const abf16x8_t a2 = *reinterpret_cast<const abf16x8_t*>(do_s + prow * RB + (ch << 4));
-      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s_acc, 0, 0, 0);
-      dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vf[ks], dp_acc, 0, 0, 0);
+      fa[ks] = *reinterpret_cast<const abf16x8_t*>(q_s + prow * RB + (ch << 4));
+      fb[ks] = *reinterpret_cast<const abf16x8_t*>(do_s + prow * RB + (ch << 4));
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (ks == 0) {
+        ANEMOI_BWD_MFMA_S0(s_acc, fa[ks], kf[ks]);
+        ANEMOI_BWD_MFMA_S0(dp_acc, fb[ks], vf[ks]);
+      } else {
+        ANEMOI_BWD_MFMA_S(s_acc, fa[ks], kf[ks]);
+        ANEMOI_BWD_MFMA_S(dp_acc, fb[ks], vf[ks]);
+      }
+    }
+    abf16x8_t fdo[NDT][2], fqt[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int drow = dt * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int off = drow * 64 + (aswz64(drow, kk * 2 + half) << 4);
+        fdo[dt][kk] = *reinterpret_cast<const abf16x8_t*>(dot_s + off);
+        fqt[dt][kk] = *reinterpret_cast<const abf16x8_t*>(qt_s + off);
+      }
+    }
+    // lse / delta of this lane's 16 queries (register r <-> query 8 half + (r & 7) + 16 (r >> 3)): four 16-byte reads each,
+    // requested here too (read one by one next to their use they were sixteen exposed LDS round trips per tile)
+    float lsev[16], dlv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q0 = 8 * half + 4 * (g & 1) + 16 * (g >> 1);
+      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);
+      const float4 d4 = *reinterpret_cast<const float4*>(dl_s + q0);
+      lsev[4 * g] = l4.x, lsev[4 * g + 1] = l4.y, lsev[4 * g + 2] = l4.z, lsev[4 * g + 3] = l4.w;
+      dlv[4 * g] = d4.x, dlv[4 * g + 1] = d4.y, dlv[4 * g + 2] = d4.z, dlv[4 * g + 3] = d4.w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");  // (with the last product's own eight: its results are read next)
+    ATT_T(4);
     float p[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = 8 * half + (r & 7) + 16 * (r >> 3);
-      float pe = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, -lse_s[qi]));
-      if (window >= 0) {
+      float pe = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, -lsev[r]));
+      if (WIN && window >= 0) {
         const int dq_ = qt * 32 + qi - key;
         pe = (dq_ <= window && -dq_ <= window) ? pe : 0.f;
       }
@@ -1108,10 +1231,10 @@ __global__ __launch_bounds__(256, DROP ? 2 : 3) void mhsa_bwd_dkv_mfma_kernel(
         const uint32_t x = dropout_mix((drow0 + (uint32_t)(qt * 32 + qi)) * 0x9E3779B1u ^ dkey);
         const float kf_ = ((x >> dsh) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.f;
         p[r] = pe * kf_;
-        ds[r] = pe * (dp_acc[r] * kf_ - dl_s[qi]);
+        ds[r] = pe * (dp_acc[r] * kf_ - dlv[r]);
       } else {
         p[r] = pe;
-        ds[r] = pe * (dp_acc[r] - dl_s[qi]);
+        ds[r] = pe * (dp_acc[r] - dlv[r]);
       }
     }
     abf16x8_t pb[2], dsb[2];
@@ -1132,19 +1255,22 @@ __global__ __launch_bounds__(256, DROP ? 2 : 3) void mhsa_bwd_dkv_mfma_kernel(
       dsb[kk] = *reinterpret_cast<abf16x8_t*>(w2);
     }
     // ---- dV^T += dO^T P,  dK^T += Q^T dS   (A rows = d, reduction over the tile's queries)
+    ATT_T(5);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      const int drow = dt * 32 + ql;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const int off = drow * 64 + (aswz64(drow, kk * 2 + half) << 4);
-        const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(dot_s + off);
-        const abf16x8_t a2 = *reinterpret_cast<const abf16x8_t*>(qt_s + off);
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[kk], dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb[kk], dk[dt], 0, 0, 0);
+        ANEMOI_BWD_MFMA_ACC(dv[dt], fdo[dt][kk], pb[kk]);
+        ANEMOI_BWD_MFMA_ACC(dk[dt], fqt[dt][kk], dsb[kk]);
       }
     }
+    ATT_T(6);
   }
+#ifdef ATT_BWD_PROF
+  if (blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 64)
+    for (int i = 0; i < 8; ++i) att_prof[i] = tacc[i];
+#endif
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> the accumulator reads below
   if (key < S) {  // lane = key; register r <-> d = dt * 32 + 8 (r >> 2) + 4 half + (r & 3)
     bf16_t* kp = dqkv + ((int64_t)b * S + key) * lddq + C + h * ATT_D;
 #pragma unroll
@@ -1160,17 +1286,26 @@ __global__ __launch_bounds__(256, DROP ? 2 : 3) void mhsa_bwd_dkv_mfma_kernel(
   }
 }
 
-template <int ATT_D, bool DROP = false>
-__global__ __launch_bounds__(256) void mhsa_bwd_dq_mfma_kernel(
+template <int ATT_D, bool DROP = false, bool WIN = true>
+__global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
     const bf16_t* __restrict__ kT, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window, float scale, float scale_log2e,
     const AttnDropout dr) {
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;
-  __shared__ __attribute__((aligned(16))) char k_s[32 * RB], v_s[32 * RB], kt_s[ATT_D * 64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, ql = lane & 31;
+  // key tiles (K and V rows, K^T rows of 64 bytes) through a ring of three LDS buffers by LDS-DMA, as in the dK/dV kernel:
+  // 3 PP pieces of 1 KiB per tile, piece i NW + wave for the waves that have one (D = 64: twelve pieces on eight waves --
+  // two for the waves 0 .. 3, one for the others; every wave waits for its own count)
+  constexpr int NW = ATT_BWD_NW, PP = ATT_D / 16, ARR = PP * 1024, NPIECE = 3 * PP, PPW = (NPIECE + NW - 1) / NW;
+  constexpr int STAGE = 3 * ARR, N_STAGE = ATT_BWD_STAGES, PRE = N_STAGE - 1;
+  static_assert(PPW <= 3, "the wait below knows the counts 0 .. 3");
+  __shared__ __attribute__((aligned(16))) char smem[N_STAGE * STAGE];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __builtin_assume(wid >= 0 && wid < NW);
+  const int half = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q = (blockIdx.x * 4 + wid) * 32 + ql, qc = q < S ? q : S - 1;
+  const int q = (blockIdx.x * NW + wid) * 32 + ql, qc = q < S ? q : S - 1;
+  const int n_mine = wid < NPIECE ? (NPIECE - wid + NW - 1) / NW : 0;  // this wave's requests per tile
   abf16x8_t qf[NKS], dof[NKS];  // B fragments: lane = query column, 8 consecutive d per k-step
   {
     const bf16_t* qp = qkv + ((int64_t)b * S + qc) * ld + h * ATT_D + half * 8;
@@ -1190,50 +1325,84 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
   int kt_begin = 0, kt_end = (S + 31) / 32;
-  if (window >= 0) {
-    const int lo = (int)blockIdx.x * 128 - window, hi = (int)blockIdx.x * 128 + 127 + window;
+  if (WIN && window >= 0) {
+    const int lo = (int)blockIdx.x * (32 * NW) - window, hi = (int)blockIdx.x * (32 * NW) + 32 * NW - 1 + window;
     kt_begin = lo > 0 ? lo / 32 : 0;
     const int e = hi / 32 + 1;
     kt_end = e < kt_end ? e : kt_end;
   }
   const int prow = att_row_perm(ql);
-  const int t = threadIdx.x;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    __syncthreads();
-    if (t < 32 * CPR) {
-      const int r = t / CPR, ch = t % CPR;
-      int key = kt * 32 + r;
-      key = key < S ? key : S - 1;
-      const bf16_t* kp = qkv + ((int64_t)b * S + key) * ld + C + h * ATT_D + ch * 8;
-      *reinterpret_cast<uint4*>(k_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) = *reinterpret_cast<const uint4*>(kp);
-      *reinterpret_cast<uint4*>(v_s + r * RB + (att_rswz<ATT_D>(r, ch) << 4)) = *reinterpret_cast<const uint4*>(kp + C);
-    }
-    if (t < ATT_D * 4) {
-      const int d = t >> 2, ch = t & 3;
-      const int64_t off = (((int64_t)b * H + h) * ATT_D + d) * S_pad + kt * 32 + ch * 8;
-      *reinterpret_cast<uint4*>(kt_s + d * 64 + (aswz64(d, ch) << 4)) = *reinterpret_cast<const uint4*>(kT + off);
-    }
-    __syncthreads();
-    // ---- S^T = K Q^T and dP^T = V dO^T: lane = query, register r <-> key 8 half + (r & 7) + 16 (r >> 3) of the tile
-    af32x16_t s_acc, dp_acc;
+  const int64_t bh = (int64_t)b * H + h;
+  auto stage = [&](int kt, int buf) {
+    char* sb = smem + buf * STAGE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_acc[r] = dp_acc[r] = 0.f;
+    for (int i = 0; i < PPW; ++i) {  // array id / PP (K, V, K^T), piece id % PP of it
+      const int id = i * NW + wid, arr = id / PP, sub = id % PP;
+      if (id >= NPIECE) break;  // (wave-uniform)
+      const char* src;
+      if (arr < 2) {
+        const int r = sub * (1024 / RB) + lane / CPR;
+        int key = kt * 32 + r;
+        key = key < S ? key : S - 1;
+        src = reinterpret_cast<const char*>(qkv + (uint64_t)(uint32_t)(b * S + key) * (uint32_t)ld + (arr + 1) * C +
+                                            h * ATT_D + att_rswz<ATT_D>(r, lane % CPR) * 8);
+      } else {
+        const int d = sub * 16 + (lane >> 2);
+        src = reinterpret_cast<const char*>(kT + (bh * ATT_D + d) * S_pad + kt * 32 + aswz64(d, lane & 3) * 8);
+      }
+      aglds16(src, sb + id * 1024);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < PRE; ++i)
+    if (kt_begin + i < kt_end) stage(kt_begin + i, i);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // this wave's requests of tile kt have landed; those of the PRE - 1 tiles behind it (n_mine each) may stay in flight
+    if (kt + PRE - 1 < kt_end && n_mine == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (PRE - 1)) : "memory");
+    else if (kt + PRE - 1 < kt_end && n_mine == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PRE - 1)) : "memory");
+    else if (kt + PRE - 1 < kt_end && n_mine == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRE - 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + PRE < kt_end) stage(kt + PRE, (kt + PRE - kt_begin) % N_STAGE);
+    const char* sb = smem + ((kt - kt_begin) % N_STAGE) * STAGE;
+    const char *k_s = sb, *v_s = sb + ARR, *kt_s = sb + 2 * ARR;
+    // ---- S^T = K Q^T and dP^T = V dO^T: lane = query, register r <-> key 8 half + (r & 7) + 16 (r >> 3) of the tile
+    af32x16_t s_acc, dp_acc;  // (fragment requests ahead of each phase: see the dK/dV kernel)
+    abf16x8_t fa[NKS], fb[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int ch = att_rswz<ATT_D>(prow, ks * 2 + half);
-      const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(k_s + prow * RB + (ch << 4));
-      const abf16x8_t a2 = *reinterpret_cast<const abf16x8_t*>(v_s + prow * RB + (ch << 4));
-      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s_acc, 0, 0, 0);
-      dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dof[ks], dp_acc, 0, 0, 0);
+      fa[ks] = *reinterpret_cast<const abf16x8_t*>(k_s + prow * RB + (ch << 4));
+      fb[ks] = *reinterpret_cast<const abf16x8_t*>(v_s + prow * RB + (ch << 4));
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (ks == 0) {
+        ANEMOI_BWD_MFMA_S0(s_acc, fa[ks], qf[ks]);
+        ANEMOI_BWD_MFMA_S0(dp_acc, fb[ks], dof[ks]);
+      } else {
+        ANEMOI_BWD_MFMA_S(s_acc, fa[ks], qf[ks]);
+        ANEMOI_BWD_MFMA_S(dp_acc, fb[ks], dof[ks]);
+      }
+    }
+    abf16x8_t fkt[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int drow = dt * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fkt[dt][kk] = *reinterpret_cast<const abf16x8_t*>(kt_s + drow * 64 + (aswz64(drow, kk * 2 + half) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");  // (with the last product's own eight: its results are read next)
     float ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kt * 32 + 8 * half + (r & 7) + 16 * (r >> 3);
       float pe = __builtin_amdgcn_exp2f(fmaf(s_acc[r], scale_log2e, -lse2));
-      bool ok = key < S;
-      if (window >= 0) ok = ok && (key - q <= window) && (q - key <= window);
-      pe = ok ? pe : 0.f;
+      // keys behind S need no mask: their K / V rows are row S - 1 again (finite dS) and their K^T columns are zero
+      if (WIN && window >= 0) pe = ((key - q <= window) && (q - key <= window)) ? pe : 0.f;
       if constexpr (DROP) {  // registers r, r + 1 (r even) are the two keys of one pair: one hash for both
         const uint32_t x = dropout_mix(drow ^ (uint32_t)(key >> 1) * 0xC2B2AE3Du);
         const float kf_ = ((x >> (16 * (r & 1))) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.f;
@@ -1253,17 +1422,14 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_mfma_kernel(
       }
       dsb[kk] = *reinterpret_cast<abf16x8_t*>(w2);
     }
-    // ---- dQ^T += K^T dS^T
+    // ---- dQ^T += K^T dS^T   (ANEMOI_BWD_MFMA_ACC: see the note above the dK/dV kernel)
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const int drow = dt * 32 + ql;
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const abf16x8_t a = *reinterpret_cast<const abf16x8_t*>(kt_s + drow * 64 + (aswz64(drow, kk * 2 + half) << 4));
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb[kk], dq[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < NDT; ++dt) ANEMOI_BWD_MFMA_ACC(dq[dt], fkt[dt][kk], dsb[kk]);
     }
   }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> the accumulator reads below
   if (q < S) {
     bf16_t* qp = dqkv + ((int64_t)b * S + q) * lddq + h * ATT_D;
 #pragma unroll
@@ -1524,8 +1690,16 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
   return check_launch("anemoi_mhsa(generic)");
 }
 
+#ifdef ATT_BWD_PROF
+int anemoi_debug_att_prof(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(att_prof), sizeof(att_prof));
+}
+#endif
+
 int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int D) {
-  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32)) return 3 * mhsa_vt_bytes(B, S, H, D);  // Q^T, K^T, dO^T
+  // Q^T, K^T, dO^T + the padded log-sum-exp (log2 units) and delta rows [B, H, S_pad] the dK/dV kernel's LDS-DMA reads
+  if (dtype == ANEMOI_BF16 && (D == 64 || D == 32))
+    return 3 * mhsa_vt_bytes(B, S, H, D) + 2 * (int64_t)B * H * ((S + 63) / 64 * 64) * 4;
   return 0;
 }
 
@@ -1550,7 +1724,7 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
   const int64_t units = (int64_t)B * S * H;
   ANEMOI_REQUIRE((units + 3) / 4 < ((int64_t)1 << 31), ANEMOI_ERR_UNSUPPORTED, "anemoi_mhsa_backward: grid too large");
   if (!dr.drop_all && (int64_t)B * dr.h_total * S < ((int64_t)1 << 32) && dtype == ANEMOI_BF16 && (D == 64 || D == 32) &&
-      workspace != nullptr &&
+      workspace != nullptr && (int64_t)B * S < ((int64_t)1 << 31) && ld < ((int64_t)1 << 31) && lddo < ((int64_t)1 << 31) &&
       (uintptr_t)workspace % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)out % 2 == 0 &&
       (uintptr_t)dqkv % 8 == 0 && ld % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0) {
     // MFMA route: delta, the three transposed operands, then the two kernels
@@ -1560,20 +1734,27 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
     bf16_t* qT = static_cast<bf16_t*>(workspace);
     bf16_t* kT = reinterpret_cast<bf16_t*>(static_cast<char*>(workspace) + mhsa_vt_bytes(B, S, H, D));
     bf16_t* doT = reinterpret_cast<bf16_t*>(static_cast<char*>(workspace) + 2 * mhsa_vt_bytes(B, S, H, D));
+    float* lse2p = reinterpret_cast<float*>(static_cast<char*>(workspace) + 3 * mhsa_vt_bytes(B, S, H, D));
+    float* deltap = lse2p + (int64_t)B * H * S_pad;
     hipLaunchKernelGGL(mhsa_delta_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st,
-                       static_cast<const bf16_t*>(out), ldo, dob, lddo, delta, S, H, D, units);
+                       static_cast<const bf16_t*>(out), ldo, dob, lddo, delta, lse, lse2p, deltap, S, S_pad, H, D, units);
     const dim3 tgrid(S_pad / 64, H, B), tblock(256);
     hipLaunchKernelGGL(transpose_v_kernel, tgrid, tblock, 0, st, qkvb, ld, S, S_pad, H, D, C, qT, 0);
     hipLaunchKernelGGL(transpose_v_kernel, tgrid, tblock, 0, st, qkvb, ld, S, S_pad, H, D, C, kT, C);
     hipLaunchKernelGGL(transpose_v_kernel, tgrid, tblock, 0, st, dob, lddo, S, S_pad, H, D, C, doT, 0);
-    const dim3 grid128((S + 127) / 128, H, B), block256(256);
+    const dim3 grid128((S + 32 * ATT_BWD_NW - 1) / (32 * ATT_BWD_NW), H, B), block256(64 * ATT_BWD_NW);
     const float sl2 = scale * 1.44269504088896340736f;
-#define ANEMOI_MHSA_BWD(DD, DR)                                                                                         \
+#define ANEMOI_MHSA_BWD_(DD, DR, WN)                                                                                     \
   do {                                                                                                                  \
-    hipLaunchKernelGGL((mhsa_bwd_dkv_mfma_kernel<DD, DR>), grid128, block256, 0, st, qkvb, ld, dob, lddo, qT, doT, lse, \
+    hipLaunchKernelGGL((mhsa_bwd_dkv_mfma_kernel<DD, DR, WN>), grid128, block256, 0, st, qkvb, ld, dob, lddo, qT, doT,  \
+                       lse2p, deltap, static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2, dr);       \
+    hipLaunchKernelGGL((mhsa_bwd_dq_mfma_kernel<DD, DR, WN>), grid128, block256, 0, st, qkvb, ld, dob, lddo, kT, lse,   \
                        delta, static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2, dr);                \
-    hipLaunchKernelGGL((mhsa_bwd_dq_mfma_kernel<DD, DR>), grid128, block256, 0, st, qkvb, ld, dob, lddo, kT, lse, delta, \
-                       static_cast<bf16_t*>(dqkv), lddq, S, S_pad, H, C, window, scale, sl2, dr);                       \
+  } while (0)
+#define ANEMOI_MHSA_BWD(DD, DR)                       \
+  do {                                                \
+    if (window >= 0) ANEMOI_MHSA_BWD_(DD, DR, true);  \
+    else ANEMOI_MHSA_BWD_(DD, DR, false);             \
   } while (0)
     if (D == 64) {
       if (drop) ANEMOI_MHSA_BWD(64, true);
@@ -1582,6 +1763,7 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
       if (drop) ANEMOI_MHSA_BWD(32, true);
       else ANEMOI_MHSA_BWD(32, false);
     }
+#undef ANEMOI_MHSA_BWD_
 #undef ANEMOI_MHSA_BWD
     return check_launch("anemoi_mhsa_backward(bf16, MFMA)");
   }
