@@ -1071,8 +1071,13 @@ constexpr int ATT_BWD_NW = 4;  // waves per workgroup of the two backward kernel
 // tile and wave, of which 1020 are the two resident waves' MFMAs and ~900 their softmax arithmetic): the MFMA and the
 // VALU phases of the two waves of a SIMD hardly overlap; the forward's answer (one wave per SIMD, both streams
 // interleaved by hand) has not been carried over.  Workgroups of eight waves (half the L2 -> LDS traffic) are slower
-// (18.3 / 13.2 ms): their wave pairs run in lockstep.
-template <int ATT_D, bool DROP = false, bool WIN = true>  // WIN: sliding-window mask code compiled in (window >= 0)
+// (18.3 / 13.2 ms): their wave pairs run in lockstep.  Making that lockstep a ping-pong (waves w and w + 4 share a SIMD --
+// tools/micro/wave_simd_map.hip -- so the waves 4 .. 7 ran one barrier behind the waves 0 .. 3: [barrier] M2(t - 1) M1(t)
+// [barrier] V(t), four stages) was built, bit-identical, and no faster either (18.0 ms): every phase is long on its own
+// (M1 ~800 clocks for 256 clocks of matrix pipe) because a wave reads ALL of the tile's fragments, 24 ds_read_b128 per
+// tile and wave for its 32 keys -- 54 % of the CU's LDS bandwidth at the present rate.  The lever is 64 keys per wave.
+// WIN: sliding-window mask code compiled in (window >= 0).
+template <int ATT_D, bool DROP, bool WIN>
 __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
     const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT, const float* __restrict__ lse2p,
@@ -1148,33 +1153,19 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
     // lse (log2 units) of the tile's 32 queries in the lanes 0 .. 31, delta in 32 .. 63 (every wave: same bytes, same place)
     aglds4((lane < 32 ? lse2p : deltap) + bh * S_pad + qt * 32 + (lane & 31), sb + 4 * ARR);
   };
-#pragma unroll
-  for (int i = 0; i < PRE; ++i)
-    if (qt_begin + i < qt_end) stage(qt_begin + i, i);
-#ifdef ATT_BWD_PROF
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
-  for (int qt = qt_begin; qt < qt_end; ++qt) {
-    ATT_T(0);
-    // this wave's requests of tile qt have landed (the PRE - 1 tiles behind it may stay in flight: vmcnt counts in order,
-    // NDMA per tile; the last PRE - 1 tiles simply drain); the barrier publishes the buffer and retires tile qt - 1,
-    // whose buffer is refilled next (see mhsa_bf16_kernel)
-    if (qt + PRE - 1 < qt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ATT_T(1);
-    __syncthreads();
-    ATT_T(2);
-    if (qt + PRE < qt_end) stage(qt + PRE, (qt + PRE - qt_begin) % N_STAGE);
-    ATT_T(3);
-    const char* sb = smem + ((qt - qt_begin) % N_STAGE) * STAGE;
+  // ---- the three phases of a tile
+  af32x16_t s_acc, dp_acc;
+  abf16x8_t fdo[NDT][2], fqt[NDT][2], pb[2], dsb[2];
+  float lsev[16], dlv[16];
+  // M1: S = Q K^T and dP = dO V^T (lane = key, register r <-> query 8 half + (r & 7) + 16 (r >> 3) of the tile).  Every A
+  // fragment of a phase is requested before the phase's first MFMA (one exposed LDS round trip per phase: with the loads
+  // next to their MFMAs the loop paid eight of them per tile, 65 % of the wave cycles in s_waitcnt); the fragments of M2
+  // and lse / delta (four 16-byte reads each: one dword at a time they were sixteen more round trips) are requested
+  // behind the score MFMAs and land under the softmax arithmetic.  Everything the tile needs from LDS is read here.
+  auto m1 = [&](const char* sb) {
     const char *q_s = sb, *do_s = sb + ARR, *qt_s = sb + 2 * ARR, *dot_s = sb + 3 * ARR;
     const float* lse_s = reinterpret_cast<const float*>(sb + 4 * ARR);
     const float* dl_s = lse_s + 32;
-    // ---- S = Q K^T and dP = dO V^T: lane = key, register r <-> query 8 half + (r & 7) + 16 (r >> 3) of the tile
-    // every A fragment of a phase is requested before the phase's first MFMA (one exposed LDS round trip per phase: with
-    // the loads next to their MFMAs the loop paid eight of them per tile, 65 % of the wave cycles in s_waitcnt); the
-    // fragments of the second phase are requested behind the score MFMAs and land under the softmax arithmetic
-    af32x16_t s_acc, dp_acc;
     abf16x8_t fa[NKS], fb[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -1193,7 +1184,6 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
         ANEMOI_BWD_MFMA_S(dp_acc, fb[ks], vf[ks]);
       }
     }
-    abf16x8_t fdo[NDT][2], fqt[NDT][2];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
       const int drow = dt * 32 + ql;
@@ -1204,9 +1194,6 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
         fqt[dt][kk] = *reinterpret_cast<const abf16x8_t*>(qt_s + off);
       }
     }
-    // lse / delta of this lane's 16 queries (register r <-> query 8 half + (r & 7) + 16 (r >> 3)): four 16-byte reads each,
-    // requested here too (read one by one next to their use they were sixteen exposed LDS round trips per tile)
-    float lsev[16], dlv[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int q0 = 8 * half + 4 * (g & 1) + 16 * (g >> 1);
@@ -1217,7 +1204,9 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 7" ::: "memory");  // (with the last product's own eight: its results are read next)
-    ATT_T(4);
+  };
+  // V: P = exp2(S c - lse), dS = P (dP - delta), both as bf16 B fragments of M2
+  auto vphase = [&](int qt) {
     float p[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1237,7 +1226,6 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
         ds[r] = pe * (dp_acc[r] - dlv[r]);
       }
     }
-    abf16x8_t pb[2], dsb[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint32_t w1[4], w2[4];
@@ -1254,8 +1242,9 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
       pb[kk] = *reinterpret_cast<abf16x8_t*>(w1);
       dsb[kk] = *reinterpret_cast<abf16x8_t*>(w2);
     }
-    // ---- dV^T += dO^T P,  dK^T += Q^T dS   (A rows = d, reduction over the tile's queries)
-    ATT_T(5);
+  };
+  // M2: dV^T += dO^T P,  dK^T += Q^T dS   (A rows = d, reduction over the tile's queries)
+  auto m2 = [&]() {
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
@@ -1264,6 +1253,30 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
         ANEMOI_BWD_MFMA_ACC(dk[dt], fqt[dt][kk], dsb[kk]);
       }
     }
+  };
+#pragma unroll
+  for (int i = 0; i < PRE; ++i)
+    if (qt_begin + i < qt_end) stage(qt_begin + i, i);
+#ifdef ATT_BWD_PROF
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    ATT_T(0);
+    // this wave's requests of tile qt have landed (the PRE - 1 tiles behind it may stay in flight: vmcnt counts in order,
+    // NDMA per tile; the last PRE - 1 tiles simply drain); the barrier publishes the buffer and retires tile qt - 1,
+    // whose buffer is refilled next (see mhsa_bf16_kernel)
+    if (qt + PRE - 1 < qt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_T(1);
+    __syncthreads();
+    ATT_T(2);
+    if (qt + PRE < qt_end) stage(qt + PRE, (qt + PRE - qt_begin) % N_STAGE);
+    ATT_T(3);
+    m1(smem + ((qt - qt_begin) % N_STAGE) * STAGE);
+    ATT_T(4);
+    vphase(qt);
+    ATT_T(5);
+    m2();
     ATT_T(6);
   }
 #ifdef ATT_BWD_PROF

@@ -1,4 +1,5 @@
-"""Shader-clock phases of one wave of the dK/dV kernel (library built with -DATT_BWD_PROF): python tools/micro/mhsa_bwd_phase.py LIB"""
+"""Shader-clock phases of one wave of the dK/dV kernel (library built with -DATT_BWD_PROF; the marks cost an lgkmcnt(0) each, so LDS latency shows up in the phase that ends at the next mark):
+   python tools/micro/mhsa_bwd_phase.py"""
 import ctypes
 import os
 import sys
@@ -21,9 +22,9 @@ out = (ctypes.c_ulonglong * 16)()
 lib.anemoi_debug_att_prof.argtypes = [ctypes.c_void_p]
 print("rc", lib.anemoi_debug_att_prof(out))
 n = (s + 31) // 32
-names = ["loop top -> wait", "vmcnt wait", "barrier", "stage issue", "frag loads + S/dP MFMAs (+nops)", "softmax VALU + cvt", "acc MFMAs"]
-v = list(out)[:7]
+names = ["(6 -> 0 wrap)", "vmcnt wait", "barrier", "stage issue", "M1 (frag loads, S/dP MFMAs)", "V (softmax, cvt)", "M2 (acc MFMAs)", "-"]
+v = list(out)[:8]
 tot = sum(v)
-for nm, t in zip(["(6 -> 0 wrap)"] + names[1:], v):
+for nm, t in zip(names, v):
     print(f"{nm:36s} {t / n:9.1f} clocks / tile ({100 * t / tot:5.1f} %)")
-print("total", tot / n, "s_memtime ticks per tile (100 MHz domain?)")
+print("total", round(tot / n, 1), "clocks per tile")
