@@ -1031,13 +1031,25 @@ __device__ __forceinline__ int att_rswz(int row, int chunk) {  // swizzle of a r
   return ATT_D == 64 ? aswz(row, chunk) : aswz64(row, chunk);
 }
 
-// The accumulating products of the two kernels (dV^T, dK^T, dQ^T) are inline-asm MFMAs on accumulators pinned to AGPRs,
-// each followed by eight wait states.  Found in round 3 with the builtin: the compiler had kept dQ^T in VGPRs across the
-// loop (32 + 32 v_accvgpr moves per tile) and re-used the A fragment's registers for the softmax arithmetic in the issue
-// slot right behind the MFMA that read them -- `v_mfma a[0:15], v[0:3], v[4:7], a[0:15]; v_sub_f32 v0, ...` -- and that
-// product came out wrong, deterministically, for exactly the 32 output rows of that accumulator (tools/micro/
-// mhsa_bwd_dbg.py; with the wait states or with a barrier's worth of other code behind the MFMA it is right).  The
-// hazard recognizer knows no write-after-read case on SrcA / SrcB; here the instruction stream guarantees one.
+// All products of the two kernels are inline-asm MFMAs -- the accumulating ones (dV^T, dK^T, dQ^T) on accumulators pinned
+// to AGPRs, the score-side ones (S, dP) on VGPR accumulators the softmax arithmetic reads in place -- each with wait
+// states around it, and products on the same accumulator never back to back.  Found in round 3: with the MFMA builtin
+// the compiler kept dQ^T in VGPRs across the tile loop (32 + 32 v_accvgpr moves per tile around the two dQ^T MFMAs of each
+// accumulator), and the dQ rows of accumulator 0 (d = 0 .. 31) came out wrong at D = 64 -- deterministically, for every
+// S, the other accumulator and dK / dV right (tools/micro/mhsa_bwd_dbg.py).  Extra barriers, s_sleep or a full vmcnt(0)
+// did not change a digit, a second __syncthreads() between the staging and the products (i.e. another local schedule)
+// did, so it is a property of that instruction sequence, not a race.  The obvious suspect -- the MFMA's A registers being
+// re-used by the softmax arithmetic in the very next issue slot, `v_mfma a[0:15], v[0:3], v[4:7], a[0:15]; v_sub_f32
+// v0, ...` -- is NOT it: the same pattern is in the forward kernels and the GEMM (13 + 72 places), whose parity tests
+// are bit-stable.  Pinned accumulators WITHOUT wait states made D = 64 right and D = 32 wrong (two dependent MFMAs back
+// to back, nothing the compiler pads inside asm); pinned accumulators with the wait states below are right for every
+// shape of the tests.  The cause of the original failure was not isolated further.
+#define ANEMOI_BWD_MFMA_ACC(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+a"(ACC) : "v"(A), "v"(B))
+#define ANEMOI_BWD_MFMA_S0(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0\n\ts_nop 7" : "=&v"(ACC) : "v"(A), "v"(B))
+#define ANEMOI_BWD_MFMA_S(ACC, A, B) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(ACC) : "v"(A), "v"(B))
 #ifdef ATT_BWD_PROF
 __device__ unsigned long long att_prof[16];
 #define ATT_T(i)                                        \
