@@ -299,8 +299,8 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
  * the forward's result, `dout` its gradient; writes dqkv [B*S, 3C] = dq | dk | dv in `dtype`.  `delta` f32 [B, H, S] is
  * scratch.  Probabilities are recomputed from lse (nothing of size S x S is stored); no atomics.  bf16 with D = 64 / 32
  * and dropout_p < 1: MFMA kernels (one pass with the keys stationary for dK / dV, one with the queries stationary for dQ)
- * on a `workspace` of anemoi_mhsa_backward_workspace_bytes() bytes (Q^T, K^T, dO^T); otherwise VALU kernels, O(S^2 D) on
- * the vector pipe (workspace may be NULL).
+ * on a `workspace` of anemoi_mhsa_backward_workspace_bytes() bytes (Q^T, K^T, dO^T and the padded lse / delta rows the
+ * dK / dV kernel streams); otherwise VALU kernels, O(S^2 D) on the vector pipe (workspace may be NULL).
  */
 int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
