@@ -1083,8 +1083,9 @@ constexpr int ATT_BWD_NW = 4;  // waves per workgroup of the two backward kernel
 // tile and wave, of which 1020 are the two resident waves' MFMAs and ~900 their softmax arithmetic): the MFMA and the
 // VALU phases of the two waves of a SIMD hardly overlap; the forward's answer (one wave per SIMD, both streams
 // interleaved by hand) has not been carried over.  Workgroups of eight waves (half the L2 -> LDS traffic) are slower
-// (18.3 / 13.2 ms): their wave pairs run in lockstep.  Making that lockstep a ping-pong (waves w and w + 4 share a SIMD --
-// tools/micro/wave_simd_map.hip -- so the waves 4 .. 7 ran one barrier behind the waves 0 .. 3: [barrier] M2(t - 1) M1(t)
+// (18.3 / 13.2 ms): their wave pairs run in lockstep; a cap of 168 registers (three waves per SIMD) spills 228 bytes:
+// 65 ms.  Making that lockstep a ping-pong (waves w and w + 4 share a SIMD -- tools/micro/wave_simd_map.hip -- so the
+// waves 4 .. 7 ran one barrier behind the waves 0 .. 3: [barrier] M2(t - 1) M1(t)
 // [barrier] V(t), four stages) was built, bit-identical, and no faster either (18.0 ms): every phase is long on its own
 // (M1 ~800 clocks for 256 clocks of matrix pipe) because a wave reads ALL of the tile's fragments, 24 ds_read_b128 per
 // tile and wave for its 32 keys -- 54 % of the CU's LDS bandwidth at the present rate.  The lever is 64 keys per wave.
