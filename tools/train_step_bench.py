@@ -18,6 +18,10 @@ os.environ.setdefault("ANEMOI_AMD_DTYPE", "bf16")
 dev = torch.device("cuda", 0)
 model, graph, x, _ = bench.build(workload, dev, processor)
 model.train()
+if os.environ.get("TRAIN_BENCH_DROPOUT"):  # attention dropout of the Transformer processor (reference default 0.1)
+    for m in model.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = float(os.environ["TRAIN_BENCH_DROPOUT"])
 target = torch.zeros((1, 1, graph["data"].num_nodes, 80), device=dev)
 
 
