@@ -300,6 +300,8 @@ def test_node_partitioned_training_step_ranks_sharing_one_gpu(world, graph_name,
 @pytest.mark.parametrize("dtype,b,s,h,d,window", [
     (torch.float32, 2, 300, 4, 64, -1), (torch.float32, 1, 257, 2, 24, 30), (torch.bfloat16, 1, 700, 8, 64, -1),
     (torch.bfloat16, 2, 333, 16, 32, -1), (torch.bfloat16, 1, 400, 2, 64, 50), (torch.bfloat16, 1, 1026, 2, 64, -1),
+    # windows that cut the tile loops of both backward kernels at both ends (LDS ring started at a tile > 0)
+    (torch.bfloat16, 1, 3000, 2, 64, 100), (torch.bfloat16, 2, 1500, 4, 32, 70),
 ])
 def test_mhsa_backward_vs_torch_autograd(dtype, b, s, h, d, window):
     """anemoi_mhsa_backward (probabilities recomputed from the forward's log-sum-exp) against torch autograd through an
