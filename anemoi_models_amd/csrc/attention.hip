@@ -681,7 +681,6 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
     }
   };
   using T_ = std::true_type;
-  using F_ = std::false_type;
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
