@@ -1087,7 +1087,12 @@ constexpr int ATT_BWD_NW = 4;  // waves per workgroup of the two backward kernel
 // waves 4 .. 7 ran one barrier behind the waves 0 .. 3: [barrier] M2(t - 1) M1(t)
 // [barrier] V(t), four stages) was built, bit-identical, and no faster either (18.0 ms): every phase is long on its own
 // (M1 ~800 clocks for 256 clocks of matrix pipe) because a wave reads ALL of the tile's fragments, 24 ds_read_b128 per
-// tile and wave for its 32 keys -- 54 % of the CU's LDS bandwidth at the present rate.  The lever is 64 keys per wave.
+// tile and wave for its 32 keys -- 54 % of the CU's LDS bandwidth at the present rate.  Two more forms, both correct at
+// once and both dropped: one wave per SIMD with the next tile's S / dP MFMAs placed between two-element chunks of the
+// softmax arithmetic by sched_barrier (23.1 ms; with every LDS request of the next tile at the top of the step and two
+// register sets: 31.6 ms -- 362 registers, and 32 ds_read_b128 per step in front of one wave's first MFMA), and lse /
+// delta read straight from global memory instead of through LDS (a third of the LDS reads gone: 17.4 ms, no change).
+// What is left to try is the forward's shape: 64 keys per wave, one wave per SIMD, both streams written out by hand.
 // WIN: sliding-window mask code compiled in (window >= 0).
 template <int ATT_D, bool DROP, bool WIN>
 __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
