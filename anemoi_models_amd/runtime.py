@@ -464,11 +464,17 @@ class GraphedTrainStep:
     references to the losses / outputs of earlier eager steps) -- a surviving graph keeps the parameters' gradient
     accumulators bound to the stream it ran on, the captured backward then touches that stream and the HIP runtime
     aborts the capture (observed as a crash in ``capture_end``).
+
+    Attention dropout (``dropout_p > 0`` of the Transformer processor in training mode) is refused: the mask's seed is a
+    host-side draw that becomes a kernel argument, so every replay would repeat the mask of the capture step.
     """
 
     def __init__(self, model, loss_fn, example_x: Tensor, example_target: Tensor, optimizer=None, warmup: int = 3) -> None:
         if not example_x.is_cuda:
             raise ValueError("GraphedTrainStep: the example input must live on the GPU")
+        if model.training and any(float(getattr(m, "dropout_p", 0.0) or 0.0) > 0.0 for m in model.modules()):
+            raise ValueError("GraphedTrainStep: attention dropout draws its seed on the host; a replayed graph would repeat "
+                             "one dropout mask every step -- train eagerly or set dropout_p = 0")
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.static_x, self.static_target = example_x.clone(), example_target.clone()
         params = [p for p in model.parameters() if p.requires_grad]

@@ -177,6 +177,23 @@ def test_checkpointing_reproduces_the_gradients_bit_for_bit(graph_o32, golden_cf
     assert res["1"][2] < 0.6 * res["0"][2], (res["1"][2], res["0"][2])
 
 
+def test_graphed_train_step_refuses_attention_dropout(graph_o32):
+    """A captured step would replay ONE dropout mask (the seed is a host-side draw baked into the launch): refused loudly."""
+    from test_gpu_parity import _build
+
+    from anemoi_models_amd.runtime import GraphedTrainStep
+
+    model, idx = _build(graph_o32, 64, 2, processor="Transformer")
+    model = model.to(DEV).train()
+    for m in model.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.1
+    x = torch.randn(1, 2, 1, graph_o32["data"].num_nodes, idx.num_input, device=DEV)
+    t = torch.zeros(1, 1, graph_o32["data"].num_nodes, model.num_output_channels, device=DEV)
+    with pytest.raises(ValueError, match="dropout"):
+        GraphedTrainStep(model, lambda y, tt: ((y - tt) ** 2).mean(), x, t)
+
+
 @pytest.mark.parametrize("checkpoint", ["1", "0"])
 def test_training_step_captured_in_a_hip_graph(graph_o32, golden_cfg1_gt, monkeypatch, checkpoint):
     """runtime.GraphedTrainStep: forward + loss + backward captured once, replayed on new inputs -- loss and every
