@@ -436,8 +436,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   constexpr int TM = MH * 32;        // tile rows
   constexpr int NS = 8 * MH;         // MFMAs per 32-deep K step
   constexpr int NRD = 8 + MH;        // fragment reads per K step = LDS-DMA instructions per slab and wave
-  constexpr int G1 = MH == 8 ? 23 : MH == 6 ? 17 : 15, SP = MH == 8 ? 5 : MH == 6 ? 4 : 3,
-                G2 = MH == 8 ? 103 : MH == 6 ? 78 : 51;  // schedule (see below)
+  constexpr int G1 = MH == 8 ? 23 : MH == 6 ? 17 : MH == 5 ? 16 : 15, SP = MH == 8 ? 5 : MH == 4 ? 3 : 4,
+                G2 = MH == 8 ? 103 : MH == 6 ? 78 : MH == 5 ? 66 : 51;  // schedule (see below)
+  static_assert(MH == 4 || MH == 5 || MH == 6 || MH == 8, "tile heights with a measured slab schedule");
   static_assert(G1 + 1 + (NRD - 1) * SP < G2 && G2 + NRD < 2 * NS, "slab schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -471,7 +472,10 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   for (int p = 0; p < 2; ++p) {
     const int r = 8 * p + srow;
     const int c = swz(r, scp);
-    vox[p] = r * (int)ldx * 2 + c * 16;
+    // odd MH: the x rows of the odd waves start 8 rows into a 16-row swizzle period (wave w stages LDS rows w * MH * 8 ...),
+    // so their two piece classes (LDS row mod 16 < 8 / >= 8) trade swizzles
+    const int cx = (MH % 2 != 0 && (wid & 1)) ? swz(r ^ 8, scp) : c;
+    vox[p] = r * (int)ldx * 2 + cx * 16;
     vow[p] = (8 * (srow >> 2) + (srow & 3)) * K * 2 + c * 16;
   }
   const int xrow16 = 16 * (int)ldx * 2;
@@ -889,6 +893,8 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
       hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 6>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 5>),  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
       hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 4>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)      \
     return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
@@ -907,6 +913,10 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4_RS(false, true, 6);
     RAISE_W4_RS(true, false, 6);
     RAISE_W4_RS(true, true, 6);
+    RAISE_W4_RS(false, false, 5);
+    RAISE_W4_RS(false, true, 5);
+    RAISE_W4_RS(true, false, 5);
+    RAISE_W4_RS(true, true, 5);
     RAISE_W4_RS(false, false, 4);
     RAISE_W4_RS(false, true, 4);
     RAISE_W4_RS(true, false, 4);
@@ -974,7 +984,8 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       // x 4096 0.314 -> 0.295 ms; at K = 1216 the second launch costs what the half tiles save)
       // (round 2: splitting EVERY remainder of <= 128 tiles off, whatever K, measured -1 ... +9 % on the per-rank shapes
       //  5121 x {4096, 2048, 2240, 1024} -- profiles/r02_gemm_small_m.txt -- so the rule stays)
-      if (rem_mt > 0 && rem_mt * nt <= 128 && (rem_mt == mt || K >= 2048)) {
+      // (the whole-problem case, rem_mt == mt, is one candidate of the tile-height model below for the plain epilogues)
+      if (rem_mt > 0 && rem_mt * nt <= 128 && ((rem_mt == mt && (dual || gmul)) || (rem_mt != mt && K >= 2048))) {
         mt_a = mt - rem_mt;
         mt_b = rem_mt;
       }
@@ -1032,15 +1043,35 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     const bf16_t* rb = static_cast<const bf16_t*>(residual);
     bf16_t* yb = static_cast<bf16_t*>(y);
     int64_t w4_blocks = blocks;
-    // 192-row tiles for small problems: a tile stages 7/8 of the bytes of a 256-row one (the loop is bound by staging),
-    // so they pay when they do not add a round -- or fill more of the chip inside one (measured in profiles/r02_gemm_small_m.txt)
+    // Small problems (fewer than four rounds of 256-row tiles -- the per-rank shapes of a node-partitioned run, BASELINE
+    // configs 2 and 5): the tile HEIGHT is chosen per launch among 256 / 192 / 160 / 128 rows by a two-term model of the
+    // persistent loop, rounds x (epilogue + slabs x staged bytes): the loop is bound by the bytes it stages, so a tile of
+    // 32 MH rows costs (32 MH + 256) / 512 of a whole one per slab (measured 0.75 for MH = 4, 0.875 for MH = 6) and
+    // MH / 8 of its 6.5 us epilogue; what decides is how the tile count quantises against the 256 CUs
+    // (5121 x 2048: 160 / 216 / 256 / 320 tiles -> 160-row tiles fill the chip exactly once;
+    //  5121 x 4096: 320 / 432 / 512 / 640 -> two balanced rounds of 160-row tiles; profiles/r04_gemm_small_m.txt).
     if (!batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
-      const int64_t mt6 = (M + 191) / 192, r8 = (mt * nt + max_blocks - 1) / max_blocks,
-                    r6 = (mt6 * nt + max_blocks - 1) / max_blocks;
-      if (r6 * 0.875 < r8 * 0.97) {
-        const int64_t tiles6 = mt6 * nt;
-        w4_blocks = tiles6 < max_blocks ? (tiles6 + 7) / 8 * 8 : max_blocks;
-        LAUNCH_W4_PLAIN(6, xb, rb, yb, ln, M, tiles6, w4_tail)
+      static const int forced_mh = [] {  // lab switch for A/B runs: ANEMOI_AMD_GEMM_MH=4|5|6|8
+        const char* e = getenv("ANEMOI_AMD_GEMM_MH");
+        return e != nullptr ? atoi(e) : 0;
+      }();
+      int best_mh = 8;
+      double best_cost = 1e30;
+      for (const int mh : {8, 6, 5, 4}) {
+        const int64_t tiles = (M + 32 * mh - 1) / (32 * mh) * nt, rounds = (tiles + max_blocks - 1) / max_blocks;
+        const double cost = (double)rounds * (0.8125 * mh + (K / 64) * 1.44 * (32 * mh + 256) / 512.0);
+        if (forced_mh == mh || (forced_mh == 0 && cost < best_cost * 0.97)) {  // (3 %: ties go to the taller tile)
+          best_cost = cost;
+          best_mh = mh;
+          if (forced_mh == mh) break;
+        }
+      }
+      if (best_mh != 8) {
+        const int64_t tiles = (M + 32 * best_mh - 1) / (32 * best_mh) * nt;
+        w4_blocks = tiles < max_blocks ? (tiles + 7) / 8 * 8 : max_blocks;
+        if (best_mh == 6) { LAUNCH_W4_PLAIN(6, xb, rb, yb, ln, M, tiles, w4_tail) }
+        else if (best_mh == 5) { LAUNCH_W4_PLAIN(5, xb, rb, yb, ln, M, tiles, w4_tail) }
+        else { LAUNCH_W4_PLAIN(4, xb, rb, yb, ln, M, tiles, w4_tail) }
         mt_a = 0;  // done
       }
     }

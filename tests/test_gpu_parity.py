@@ -1573,16 +1573,20 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
 
 @pytest.mark.parametrize("m,n,k,act,res,fold", [
     (40962, 1024, 4096, "Identity", True, False),   # 640 tiles = 2.5 rounds: remainder rows as half tiles
-    (5121, 4096, 1024, "GELU", False, True),        # 320 tiles = 1.25 rounds (LayerNorm fold)
+    (5121, 4096, 1024, "GELU", False, True),        # 320 tiles = 1.25 rounds -> 512 tiles of 160 rows (LayerNorm fold)
     (5121, 1024, 4096, "Identity", True, False),    # 80 tiles: the whole problem as half tiles
     (5121, 1024, 1216, "Identity", True, False),    # K = 19 slabs
     (2304, 1024, 512, "SiLU", False, False),        # 36 tiles: 4 or 5 per XCD
     (70000, 1024, 1024, "Identity", False, False),  # ragged last row tile
-    (5121, 2048, 1024, "Identity", True, False),    # 160 tiles -> 216 tiles of 192 rows (MH = 6), residual + row statistics
-    (5121, 2240, 1024, "Identity", False, True),    # ... ragged last column tile, LayerNorm fold
-    (10242, 2048, 512, "GELU", False, False),       # config 2's fc1: 320 tiles = 2 rounds -> 432 shorter ones
-    (5000, 4096, 1024, "Identity", True, False),    # 192-row tiles with a ragged last row tile (5000 = 26 * 192 + 8)
-    (4800, 4096, 512, "SiLU", False, False),        # 25 * 192 rows exactly
+    (5121, 2048, 1024, "Identity", True, False),    # 160 tiles -> 256 tiles of 160 rows (MH = 5), residual + row statistics
+    (5121, 2240, 1024, "Identity", False, True),    # 243 tiles of 192 rows (MH = 6), ragged last column tile, LayerNorm fold
+    (10242, 2048, 512, "GELU", False, False),       # config 2's fc1: 320 tiles = 2 rounds -> 512 of 160 rows
+    (5000, 4096, 1024, "Identity", True, False),    # 160-row tiles with a ragged last row tile (5000 = 31 * 160 + 40)
+    (4800, 4096, 512, "SiLU", False, False),        # 30 * 160 rows exactly (MH = 5: odd waves start mid swizzle period)
+    (5000, 2048, 1024, "Identity", True, True),     # 160-row tiles, ragged last row tile (31 * 160 + 40), LN fold + residual
+    (4960, 4096, 1024, "GELU", False, False),       # 31 * 160 rows: 496 tiles, two rounds of 160-row tiles
+    (5569, 2048, 1024, "Identity", False, True),    # own + halo rows of a rank's k | v product: 192-row tiles (30 x 8)
+    (10242, 2240, 512, "Identity", False, True),    # config 2's x_r | q | k | v | u product
 ])
 def test_linear_remainder_round_shapes(m, n, k, act, res, fold):
     """Shapes whose tile count leaves a short remainder round on the 256 CUs (full mesh and per-rank sizes of config 3):
