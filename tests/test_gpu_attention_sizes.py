@@ -77,12 +77,12 @@ def test_mhsa_mesh_size_vs_reference_rows(s, h, d, window):
 
     got = ops.mhsa(qkv, 1, h, window)
     assert got.shape == (s, c) and torch.isfinite(got.float()).all()
-    assert _rel(got, want) <= 2e-2
+    assert _rel(got, want) <= 1e-2  # measured 1.8e-3 ... 3.5e-3
     rows = _row_rel(got, want)
     # rows the verdict names: the first row of every 512-query workgroup, the last 512-block, the two left-over rows
     named = torch.cat([torch.arange(0, s, 512), torch.arange(s - 514, s)]).to(DEV)
-    assert float(rows[named].max()) <= 3e-2, (int(named[rows[named].argmax()]), float(rows[named].max()))
-    assert float(rows.max()) <= 3e-2, (int(rows.argmax()), float(rows.max()))
+    assert float(rows[named].max()) <= 2e-2, (int(named[rows[named].argmax()]), float(rows[named].max()))
+    assert float(rows.max()) <= 2e-2, (int(rows.argmax()), float(rows.max()))  # measured 4.4e-3 ... 6.4e-3
 
     x = qkv.clone().requires_grad_(True)
     y = autograd.mhsa(x, 1, h, window)
@@ -94,7 +94,7 @@ def test_mhsa_mesh_size_vs_reference_rows(s, h, d, window):
     errs = {"dq": _rel(dq, wq), "dk": _rel(dk, wk), "dv": _rel(dv, wv)}
     print(f"S={s} H={h} D={d} window={window}: out {_rel(got, want):.2e} (worst row {float(rows.max()):.2e}), "
           + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
-    assert max(errs.values()) <= 3e-2, errs
+    assert max(errs.values()) <= 2e-2, errs  # measured 2.6e-3 ... 6.2e-3
     assert float(_row_rel(dq, wq)[named].max()) <= 6e-2
 
 
