@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "anemoi_linear_stats": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_float, c_void_p,
                                     c_void_p]),
+    "anemoi_linear_stats_workspace_bytes": (c_int64, [c_int, c_int64, c_int, c_int]),
     "anemoi_row_stats": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "anemoi_linear_ln": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -767,7 +767,7 @@ int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int3
   return check_launch("anemoi_bound_output");
 }
 
-int anemoi_abi_version(void) { return 34; }
+int anemoi_abi_version(void) { return 35; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

@@ -762,17 +762,19 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     // partial sums (column group u: two accumulators per partner)
     const int sk_np = SK ? ln.sk_parts - 1 : 0;
     const int sk_jlo = SK ? sk_part * MH / ln.sk_parts : 0, sk_jhi = SK ? (sk_part + 1) * MH / ln.sk_parts : MH;
-    __amdgpu_buffer_rsrc_t sk_prs[3];
-    f32x4_t pv[4][3][2];
+    constexpr int SK_UNIT_BYTES = MH * 8 * 256 * 16;  // a tile's accumulators as f32: [j][i][thread] x 16 bytes
+    __amdgpu_buffer_rsrc_t sk_rs;                      // the s slots of this tile (one per part), contiguous
+    f32x4_t pv[4][2][2];
     auto sk_fetch = [&](int jr, int u) {
       if constexpr (SK) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 2; ++q)
           if (q < sk_np) {
+            const int pq = q < sk_part ? q : q + 1;  // partner q: parts 0 .. s-1 without sk_part, ascending
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(sk_prs[q], (int)threadIdx.x * 16,
-                                                                     (jr * 8 + 2 * u + h) * 4096, 0);
+              const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(sk_rs, (int)threadIdx.x * 16,
+                                                                     pq * SK_UNIT_BYTES + (jr * 8 + 2 * u + h) * 4096, 0);
               pv[u][q][h] = f32x4_t{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
             }
           }
@@ -808,19 +810,6 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
 #pragma unroll
         for (int i = 0; i < 8; ++i)  // "+a": the zeroed value keeps the accumulator's register (no copies at the loop edges)
           asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "+a"(acc[i][j]) : "v"(zfrag));
-      } else {
-        // + the partners' partial sums of this row group (requested one row group ahead), ascending part order; the ring
-        // slot of column group u is refilled with row group j + 1 as soon as it has been consumed
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            if (q < sk_np) {
-              c[2 * u] += pv[u][q][0];
-              c[2 * u + 1] += pv[u][q][1];
-            }
-          if (j + 1 < sk_jhi) sk_fetch(j + 1, u);
-        }
       }
       float rs1 = 0.f, rs2 = 0.f;  // RS: sum / sum of squares of this lane's 32 stored values of row j * 16 + fr
 #pragma unroll
@@ -908,11 +897,10 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       typedef __attribute__((address_space(1))) unsigned gu32_t;
       const int64_t unit = chunk_start + li;
       const int s_parts = ln.sk_parts;
-      constexpr int64_t UNIT_BYTES = (int64_t)MH * 8 * 256 * 16;  // a tile's accumulators as f32: [j][i][thread] x 16 bytes
-      char* const slots = ln.sk_ws + 4096;
-      const __amdgpu_buffer_rsrc_t own_rs =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(slots + unit * UNIT_BYTES), 0, (int)UNIT_BYTES, 0x00020000);
+      sk_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(ln.sk_ws + 4096 + (unit - sk_part) * (int64_t)SK_UNIT_BYTES), 0,
+                                                s_parts * SK_UNIT_BYTES, 0x00020000);
       const int tid16 = (int)threadIdx.x * 16;
+      const int own_off = sk_part * SK_UNIT_BYTES;
       static_for_seq(
           [&](auto j_tag) {
             constexpr int j = decltype(j_tag)::value;
@@ -924,7 +912,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
                 asm volatile("" : "+v"(v));
                 __builtin_amdgcn_raw_buffer_store_b128(
                     u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                    own_rs, tid16, (j * 8 + i) * 4096, 16 /* sc1: write-through */);
+                    sk_rs, tid16, own_off + (j * 8 + i) * 4096, 16 /* sc1: write-through */);
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 1" ::: "memory");  // (store-data hazard of a 16-byte store with an SGPR offset, below)
                 __builtin_amdgcn_sched_barrier(0);
@@ -948,15 +936,36 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire behind the match: drops this CU's stale lines
       }
       __syncthreads();
-      // partner q of this part: parts 0 .. s-1 without sk_part, ascending; beyond s - 1: empty descriptors (never read)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int pq = q < sk_part ? q : q + 1;
-        sk_prs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(slots + (unit - sk_part + (q < sk_np ? pq : 0)) * UNIT_BYTES), 0,
-                                                      q < sk_np ? (int)UNIT_BYTES : 0, 0x00020000);
-      }
+      // phase 1, in place: own accumulators + the partners' partial sums (ascending part order) of the row groups this part
+      // finishes.  Requests run one row group ahead: the ring slot of column group u is refilled with row group j + 1 as
+      // soon as it has been consumed.  (Its own phase, not fused into the stores below: the two together spill.)
 #pragma unroll
       for (int u = 0; u < 4; ++u) sk_fetch(sk_jlo, u);
+      static_for_seq(
+          [&](auto j_tag) {
+            constexpr int j = decltype(j_tag)::value;
+            if (j >= sk_jlo && j < sk_jhi) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  asm volatile("" : "+a"(acc[2 * u + h][j]));
+                  f32x4_t c = acc[2 * u + h][j];
+#pragma unroll
+                  for (int q = 0; q < 2; ++q)
+                    if (q < sk_np) c += pv[u][q][h];
+                  acc[2 * u + h][j] = c;
+                  asm volatile("" : "+a"(acc[2 * u + h][j]));
+                }
+                if (j + 1 < sk_jhi) sk_fetch(j + 1, u);
+              }
+            }
+          },
+          std::make_integer_sequence<int, MH>{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // phase 2: the epilogue proper on those row groups
       static_for_seq(
           [&](auto j_tag) {
             constexpr int j = decltype(j_tag)::value;
@@ -1064,7 +1073,8 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
   RAISE_W4_SK(false, true, MHV);  \
   RAISE_W4_SK(true, false, MHV);  \
   RAISE_W4_SK(true, true, MHV)
-    RAISE_W4_SK4(8);
+    RAISE_W4_SK(false, false, 8);  // (256-row tiles + residual: the exchange's registers do not fit beside 256 accumulators)
+    RAISE_W4_SK(false, true, 8);
     RAISE_W4_SK4(6);
     RAISE_W4_SK4(5);
     RAISE_W4_SK4(4);
@@ -1217,9 +1227,9 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       int sk_mh = 0, sk_s = 0;
       double sk_cost = 1e30;
       for (const int mh : {8, 6, 5, 4})
-        for (int sp = 2; sp <= 4; ++sp) {
+        for (int sp = 2; sp <= 3; ++sp) {  // (the kernel's partner ring holds two partners)
           const int64_t tiles = (M + 32 * mh - 1) / (32 * mh) * nt, units = tiles * sp;
-          if (units > max_blocks || nk / sp < 4 || tiles > 1000) continue;
+          if (units > max_blocks || nk / sp < 4 || tiles > 1000 || (mh == 8 && residual != nullptr)) continue;
           if (4096 + units * (int64_t)mh * 32768 > ln.sk_ws_bytes) continue;
           const double part_kb = (double)(sp - 1) / sp * mh * 32.0;  // KiB a part writes and reads
           const double c = 0.8125 * mh / sp + ((nk + sp - 1) / sp) * 1.44 * (32 * mh + 256) / 512.0 + 4.0 + 2.0 * part_kb / 60.0;
@@ -1253,8 +1263,10 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       else LAUNCH_W4_SK(MHV, false, false);                          \
     }                                                                \
   } while (0)
-        if (sk_mh == 8) LAUNCH_W4_SKM(8);
-        else if (sk_mh == 6) LAUNCH_W4_SKM(6);
+        if (sk_mh == 8) {
+          if (rs_on) LAUNCH_W4_SK(8, false, true);
+          else LAUNCH_W4_SK(8, false, false);
+        } else if (sk_mh == 6) LAUNCH_W4_SKM(6);
         else if (sk_mh == 5) LAUNCH_W4_SKM(5);
         else LAUNCH_W4_SKM(4);
 #undef LAUNCH_W4_SKM

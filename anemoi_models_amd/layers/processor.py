@@ -173,10 +173,13 @@ class GNNProcessor(GraphEdgeMixin, BaseProcessor):
 
 
 class _BlockAbiPlan:
-    """Argument blocks (``anemoi_gt_block_args``) of every block of a GraphTransformer processor for one (row count,
-    device, weights version): built once, then a forward is ``num_layers`` FFI calls.  Workspaces are shared by the blocks
-    (they run back to back on one stream); the node matrix ping-pongs between two resident buffers, the last block writes
-    a fresh tensor (the result must not alias storage the next call overwrites)."""
+    """Argument-block TEMPLATES (``anemoi_gt_block_args``) of every block of a GraphTransformer processor for one (row
+    count, device, weights version): the packed weights' pointers, shapes and epsilons are filled in once; a forward copies
+    the templates, points them at intermediates it allocates itself (``torch.empty``: stream-ordered, legal under stream
+    capture) and makes ``num_layers`` FFI calls.  Nothing a launch writes to is owned by the plan, so a replaced plan
+    (another row count, new weights) cannot free memory a captured HIP graph still addresses -- a graph's intermediates
+    live in ITS memory pool --, and ``run`` is re-entrant across streams.  The node matrix ping-pongs between two buffers
+    of the call, the last block writes the result tensor."""
 
     def __init__(self) -> None:
         self.ok = False
@@ -191,7 +194,7 @@ class _BlockAbiPlan:
         self = cls()
         self.sig = sig
         blocks = [blk for chunk in proc.proc for blk in chunk.blocks]
-        dtype, dev, n = x.dtype, x.device, x.shape[0]
+        dtype, n = x.dtype, x.shape[0]
         operands = []
         for blk in blocks:
             all4 = [blk.lin_self, blk.lin_query, blk.lin_key, blk.lin_value]
@@ -206,13 +209,11 @@ class _BlockAbiPlan:
         if x.shape[1] != c or any(o["w_in"].shape != operands[0]["w_in"].shape or o["w_fc1"].shape[0] != hidden
                                   or o["act"] not in _lib.ACT_CODES for o in operands):
             return self
-        new = lambda *shape, dt=dtype: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
-        self.keep = [operands, ea, plan]
-        self.sq, self.att, self.y, self.hbuf = new(n, n_in), new(n, k_proj), new(n, c), new(n, hidden)
-        self.att[:, c + h * up:].zero_()  # the K padding of the projection: the edge kernel never writes it (zeroed ONCE here)
-        self.bufs = [new(n, c), new(n, c)]
-        self.stats = [new(n, 2, dt=torch.float32) for _ in range(3)]  # y, out (ping), out (pong)
-        self.ws = new(n * max(c // 128, 1), 2, dt=torch.float32)
+        self.keep = [operands, ea, plan]  # the packed weights, edge attributes and CSR the templates point at (read-only)
+        self.dims = (n, c, h, up, n_in, k_proj, hidden)
+        lib = _lib.load()
+        self.ws_bytes = max(16, *(int(lib.anemoi_linear_stats_workspace_bytes(ops.dtype_code(dtype), n, c, kk))
+                                  for kk in (k_proj, hidden)))
         self.eps_in = operands[0]["eps_ln1"]
         self.args = []
         for i, (blk, o) in enumerate(zip(blocks, operands)):
@@ -226,41 +227,55 @@ class _BlockAbiPlan:
             a.ldx = c
             a.w_in, a.cs_in = o["w_in"].data_ptr(), o["cs_in"].data_ptr()
             a.b_in = None if o["b_in"] is None else o["b_in"].data_ptr()
-            a.sq, a.ld_sq = self.sq.data_ptr(), n_in
+            a.ld_sq = n_in
             a.edge_attr, a.rowptr, a.col = ea.data_ptr(), plan.rowptr.data_ptr(), plan.col.data_ptr()
-            a.att, a.ld_att = self.att.data_ptr(), k_proj
+            a.ld_att = k_proj
             a.w_proj = o["w_proj"].data_ptr()
             a.b_proj = None if o["b_proj"] is None else o["b_proj"].data_ptr()
-            a.y, a.y_stats = self.y.data_ptr(), self.stats[0].data_ptr()
-            a.w_fc1, a.cs_fc1, a.h = o["w_fc1"].data_ptr(), o["cs_fc1"].data_ptr(), self.hbuf.data_ptr()
+            a.w_fc1, a.cs_fc1 = o["w_fc1"].data_ptr(), o["cs_fc1"].data_ptr()
             a.b_fc1 = None if o["b_fc1"] is None else o["b_fc1"].data_ptr()
             a.w_fc2 = o["w_fc2"].data_ptr()
             a.b_fc2 = None if o["b_fc2"] is None else o["b_fc2"].data_ptr()
-            a.stats_ws, a.stats_ws_bytes = self.ws.data_ptr(), self.ws.numel() * 4
-            # block i reads buffer (i - 1) % 2 (block 0: the caller's x) and writes buffer i % 2 (last block: a fresh tensor)
-            if i > 0:
-                a.x, a.x_stats = self.bufs[(i - 1) % 2].data_ptr(), self.stats[1 + (i - 1) % 2].data_ptr()
-            a.out, a.out_stats = self.bufs[i % 2].data_ptr(), self.stats[1 + i % 2].data_ptr()
             self.args.append(a)
-        self.refs = [ctypes.byref(a) for a in self.args]
-        self.fn = _lib.load().anemoi_gt_processor_block_forward
-        self.shape = (n, c)
+        self.fn = lib.anemoi_gt_processor_block_forward
         self.eps_out = blocks[-1].layer_norm1.eps
         self.ok = True
         return self
 
     def run(self, x: Tensor) -> Tensor:
+        import ctypes
+
         from .. import _lib
 
+        n, c, h, up, n_in, k_proj, hidden = self.dims
+        dtype, dev = x.dtype, x.device
+        new = lambda *shape, dt=dtype: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
         stats_in = ops.row_stats(x, self.eps_in)  # carried by the GEMM that produced x, or one pass over it
-        out = torch.empty(self.shape, dtype=x.dtype, device=x.device)
-        out_stats = torch.empty((self.shape[0], 2), dtype=torch.float32, device=x.device)
-        first, last = self.args[0], self.args[-1]
-        first.x, first.x_stats = x.data_ptr(), stats_in.data_ptr()
-        last.out, last.out_stats = out.data_ptr(), out_stats.data_ptr()
+        # this call's intermediates (shared by its blocks: they run back to back on one stream)
+        sq, att, y, hbuf = new(n, n_in), new(n, k_proj), new(n, c), new(n, hidden)
+        if k_proj > c + h * up:
+            att[:, c + h * up:].zero_()  # the K padding of the projection: the edge kernel never writes it
+        bufs = [new(n, c), new(n, c)]
+        stats = [new(n, 2, dt=torch.float32) for _ in range(3)]  # y, out (ping), out (pong)
+        ws = new(self.ws_bytes, dt=torch.uint8)
+        out, out_stats = new(n, c), new(n, 2, dt=torch.float32)
         stream = ops._stream()
-        for ref in self.refs:
-            st = self.fn(ref, stream)
+        last = len(self.args) - 1
+        struct = _lib.GtBlockArgs
+        for i, template in enumerate(self.args):
+            a = struct.from_buffer_copy(template)
+            a.sq, a.att, a.y, a.y_stats, a.h = sq.data_ptr(), att.data_ptr(), y.data_ptr(), stats[0].data_ptr(), hbuf.data_ptr()
+            a.stats_ws, a.stats_ws_bytes = ws.data_ptr(), self.ws_bytes
+            # block i reads buffer (i - 1) % 2 (block 0: the caller's x) and writes buffer i % 2 (last block: the result)
+            if i == 0:
+                a.x, a.x_stats = x.data_ptr(), stats_in.data_ptr()
+            else:
+                a.x, a.x_stats = bufs[(i - 1) % 2].data_ptr(), stats[1 + (i - 1) % 2].data_ptr()
+            if i == last:
+                a.out, a.out_stats = out.data_ptr(), out_stats.data_ptr()
+            else:
+                a.out, a.out_stats = bufs[i % 2].data_ptr(), stats[1 + i % 2].data_ptr()
+            st = self.fn(ctypes.byref(a), stream)
             if st != 0:
                 _lib.check(st, "anemoi_gt_processor_block_forward")
         ops._carry_stats(out, self.eps_out, out_stats)

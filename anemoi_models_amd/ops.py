@@ -164,6 +164,14 @@ def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
     return out
 
 
+def linear_stats_workspace(dtype: torch.dtype, m: int, n: int, k: int, device) -> Tensor:
+    """Workspace of ``anemoi_linear_stats`` for an ``[m, k] x [n, k]^T`` product (uint8): the row-sum partials and, for the
+    small problems that run split-K, the partial-tile region (``anemoi_linear_stats_workspace_bytes``).  Uninitialised: the
+    launcher clears the few words it polls."""
+    nbytes = _lib.load().anemoi_linear_stats_workspace_bytes(dtype_code(dtype), m, n, k)
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "Identity",
            residual: Optional[Tensor] = None, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
            n_out: Optional[int] = None, ln=None, stats_eps: Optional[float] = None) -> Tensor:
@@ -198,12 +206,12 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
                 stats_in, colsum = ln
                 _dev(stats_in, colsum)
             m_rows = x.shape[0]
-            ws = torch.empty((m_rows * max(n // 128, 1), 2), dtype=torch.float32, device=x.device)
+            ws = linear_stats_workspace(x.dtype, m_rows, n, k, x.device)
             stats_out = torch.empty((m_rows, 2), dtype=torch.float32, device=x.device)
             st = _lib.load().anemoi_linear_stats(
                 dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias), _ptr(colsum), _ptr(stats_in),
                 _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)), m_rows,
-                n, k, ws.data_ptr(), ws.numel() * 4, stats_eps, stats_out.data_ptr(), _stream())
+                n, k, ws.data_ptr(), ws.numel(), stats_eps, stats_out.data_ptr(), _stream())
             _carry_stats(out, stats_eps, stats_out)
         elif ln is None:
             st = _lib.load().anemoi_linear(

@@ -886,6 +886,54 @@ def test_transformer_block_and_model_vs_golden(graph_o32, golden_blocks, golden_
     assert rel_err(out, gold["y"]) < 1e-4
 
 
+@pytest.mark.parametrize("m,n,k,res", [
+    (5121, 1024, 4096, True),     # a rank's second MLP Linear at 8 ranks: 80 tiles of 256 x 256
+    (5121, 1024, 1216, True),     # ... its projection (19 slabs: parts of 6 / 6 / 7 or 9 / 10 slabs)
+    (10242, 512, 2048, True),     # config 2's second MLP Linear
+    (5121, 1024, 4096, False),    # no residual (256-row tiles allowed)
+    (4000, 512, 1024, True),      # ragged last row tile, half-full last column group
+    (2100, 256, 8192, False),     # one column tile, 128 slabs
+])
+def test_linear_split_k_in_launch_reduce_scatter(m, n, k, res):
+    """Split-K of ``anemoi_linear_stats`` (parts of a tile's K range on different workgroups, f32 partial tiles exchanged
+    through the workspace inside the launch): against f64, against the same product WITHOUT split-K (``anemoi_linear``:
+    one workgroup per tile, the K-ordered sum), and bit-identical over 40 calls with the allocator churning and a
+    second stream keeping part of the chip busy (uneven arrival of the parts; every output word compared)."""
+    import random
+
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * 0.7 + 0.1).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=g) / k**0.5).bfloat16().to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    r = torch.randn(m, n, generator=g).bfloat16().to(DEV) if res else None
+    want = F.linear(x.double().cpu(), w.double().cpu(), b.double().cpu())
+    if res:
+        want = want + r.double().cpu()
+    plain = ops.linear(x, w, b, residual=r)                  # anemoi_linear: no workspace, no split
+    first = ops.linear(x, w, b, residual=r, stats_eps=1e-5)  # anemoi_linear_stats with the full workspace
+    assert rel_err(first, want) < 1e-2
+    # the two routes differ by the summation order of the f32 accumulators only: at most one bf16 rounding step apart
+    d = (first.float() - plain.float()).abs()
+    assert float((d / plain.float().abs().clamp_min(1e-2)).max()) < 2 ** -6
+    assert float((d > 0).float().mean()) < 0.2
+    fresh = ops.row_stats(first.clone(), 1e-5)
+    assert rel_err(ops.row_stats(first, 1e-5), fresh) < 1e-3
+    random.seed(k)
+    side = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device=DEV)
+    for it in range(40):
+        junk = [torch.full((random.randint(1, 1 << 22),), float("nan"), device=DEV) for _ in range(random.randint(0, 3))]
+        if it % 2:
+            with torch.cuda.stream(side):
+                busy = busy @ busy * 1e-3
+        del junk
+        again = ops.linear(x, w, b, residual=r, stats_eps=1e-5)
+        assert torch.equal(again, first), it
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_config3_invariants(monkeypatch):
     """BASELINE config 3 (N320 -> ico-6, 16 blocks, 1024 ch) is too large for the CPU oracle in a test, so the full

@@ -40,17 +40,20 @@ for m, n, k in SHAPES:
         ms = s.elapsed_time(e) / 10
         print(f"M={m:7d} N={n:5d} K={k:5d} hipBLASLt (torch F.linear + bias)  {ms:8.4f} ms  "
               f"{2 * m * n * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
-    for act, res in (("Identity", None), ("GELU", None), ("Identity", r)):
+    cases = [("Identity", None, None), ("GELU", None, None), ("Identity", r, None)]
+    if os.environ.get("GEMM_BENCH_STATS", "0") != "0":  # + the row-statistics epilogue (anemoi_linear_stats: split-K route)
+        cases += [("Identity", None, 1e-5), ("Identity", r, 1e-5)]
+    for act, res, eps in cases:
         for _ in range(3):
-            ops.linear(x, w, b, act=act, residual=res, out=out)
+            ops.linear(x, w, b, act=act, residual=res, out=out, stats_eps=eps)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         it = 10
         for _ in range(it):
-            ops.linear(x, w, b, act=act, residual=res, out=out)
+            ops.linear(x, w, b, act=act, residual=res, out=out, stats_eps=eps)
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / it
-        print(f"M={m:7d} N={n:5d} K={k:5d} act={act:8s} res={res is not None!s:5s} {ms:8.4f} ms  "
+        print(f"M={m:7d} N={n:5d} K={k:5d} act={act:8s} res={res is not None!s:5s} stats={eps is not None!s:5s} {ms:8.4f} ms  "
               f"{2 * m * n * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
