@@ -20,6 +20,17 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 
+def _hipcc_version(hipcc: str) -> str:
+    """One line naming the compiler (the hand-counted wait states of the inline-asm kernels were validated against it)."""
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+        hip = next((ln.strip() for ln in out.splitlines() if ln.startswith("HIP version")), "")
+        clang = next((ln.strip() for ln in out.splitlines() if "clang version" in ln), "")
+        return "; ".join(v for v in (hip, clang) if v)[:200].replace('"', "'").replace("\\", "/") or "unknown"
+    except OSError:
+        return "unknown"
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -50,13 +61,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(os.path.join(LIB_DIR, "obj"), exist_ok=True)
     hipcc = _hipcc()
+    version = _hipcc_version(hipcc)
     hdr_time = max(os.path.getmtime(f) for f in _deps() if not f.endswith(".hip"))
 
     def compile_one(src: str) -> str:
         obj = os.path.join(LIB_DIR, "obj", os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
             return obj
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, f'-DANEMOI_HIPCC_VERSION="{version}"', "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)

@@ -60,6 +60,7 @@ class GtBlockArgs(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
     "anemoi_abi_version": (c_int, []),
+    "anemoi_build_info": (ctypes.c_char_p, []),
     "anemoi_last_error": (c_char_p, []),
     "anemoi_layer_norm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                   c_float, c_void_p]),
@@ -72,7 +73,6 @@ SIGNATURES = {
     "anemoi_linear_stats": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_float, c_void_p,
                                     c_void_p]),
-    "anemoi_linear_stats_workspace_bytes": (c_int64, [c_int, c_int64, c_int, c_int]),
     "anemoi_row_stats": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "anemoi_linear_ln": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),

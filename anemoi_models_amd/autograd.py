@@ -196,10 +196,11 @@ class _LayerNormSkip(torch.autograd.Function):
         y, stats = ops.layer_norm_with_stats(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(),
                                              eps)
         ctx.save_for_backward(x, stats, gamma)
+        ctx.set_materialize_grads(False)  # an unused output arrives as None below, not as a zero matrix to normalise
         return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy: Tensor, dskip: Optional[Tensor]):
+    def backward(ctx, dy: Optional[Tensor], dskip: Optional[Tensor]):
         x, stats, gamma = ctx.saved_tensors
         if dy is None:  # the branch is unused: only the skip carries a gradient
             return dskip, None, None, None

@@ -1043,8 +1043,20 @@ __device__ __forceinline__ int att_rswz(int row, int chunk) {  // swizzle of a r
 // are bit-stable.  Pinned accumulators WITHOUT wait states made D = 64 right and D = 32 wrong (two dependent MFMAs back
 // to back, nothing the compiler pads inside asm); pinned accumulators with the wait states below are right for every
 // shape of the tests.  The cause of the original failure was not isolated further.
+// Wait states (hipcc pads nothing inside an asm statement; cdna_hip_programming.md section 5.7 item 2, ISA hazard table):
+//   * VALU write of an A / B operand -> the MFMA reading it: 2 states           -> `s_nop 1` OPENS every statement;
+//   * MFMA result -> the next MFMA taking it whole as C (accumulate chain): 0    -> nothing between the links of a chain,
+//     and two products on the SAME accumulator are never adjacent in the source anyway;
+//   * MFMA result (v_mfma_f32_32x32x16_bf16: 8 passes) -> any other reader or writer of it, compiler code included:
+//     12 states.  Every statement ENDS with `s_nop 7` (8 states); where VALU code reads the scores / dP next, the phase
+//     functions add an explicit `s_nop 7` statement behind the last product (16 states), and the accumulator reads
+//     behind the tile loop sit behind `s_nop 15; s_nop 15` -- each site says so in its comment.
+// tests/test_gpu_training.py::test_mhsa_backward_mfma_route_vs_valu_route holds this route against the VALU kernels
+// (mhsa_bwd_dq_kernel / mhsa_bwd_dkv_kernel: plain HIP, every hazard the compiler's) on a grid of shapes;
+// anemoi_build_info() records the hipcc the library was built with.
 #define ANEMOI_BWD_MFMA_ACC(ACC, A, B) \
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+a"(ACC) : "v"(A), "v"(B))
+// the score-side products (S, dP) the same way, accumulators in VGPRs (the softmax arithmetic reads them in place)
 #define ANEMOI_BWD_MFMA_S0(ACC, A, B) \
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0\n\ts_nop 7" : "=&v"(ACC) : "v"(A), "v"(B))
 #define ANEMOI_BWD_MFMA_S(ACC, A, B) \
@@ -1064,14 +1076,6 @@ __device__ unsigned long long att_prof[16];
 #endif
 constexpr int ATT_BWD_STAGES = 3;  // LDS ring of the backward kernels: tiles requested ATT_BWD_STAGES - 1 ahead
 constexpr int ATT_BWD_NW = 4;  // waves per workgroup of the two backward kernels: 32 keys (dK/dV) or 32 queries (dQ) each
-#define ANEMOI_BWD_MFMA_ACC(ACC, A, B) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+a"(ACC) : "v"(A), "v"(B))
-// the score-side products (S, dP) the same way, accumulators in VGPRs (the softmax arithmetic reads them in place)
-#define ANEMOI_BWD_MFMA_S0(ACC, A, B) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0\n\ts_nop 7" : "=&v"(ACC) : "v"(A), "v"(B))
-#define ANEMOI_BWD_MFMA_S(ACC, A, B) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(ACC) : "v"(A), "v"(B))
-
 // Round 3 (per layer at S = 40 962, D = 64: 40.9 -> 27.9 ms; dK/dV 25.5 -> 17.6, dQ 14.2 -> 10.9), in the order measured
 // with the s_memtime phase marks (ATT_T, tools/micro/mhsa_bwd_phase.py) and the PMC passes of tools/micro/mhsa_bwd_pmc.sh:
 // the waves sat in s_waitcnt for 65 % of their cycles, and not for HBM -- eight exposed LDS round trips per tile (every

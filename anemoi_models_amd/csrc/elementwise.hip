@@ -343,9 +343,9 @@ __global__ __launch_bounds__(256) void convert_pad_kernel(const S* __restrict__ 
 
 // out[r, c] = alpha * s[r] * x[r, c]   (s f32 per row; the result in x's dtype)
 template <typename T>
-__global__ __launch_bounds__(256) void row_scale_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ s,
-                                                        float alpha, T* __restrict__ out, int64_t ldo, int64_t rows,
-                                                        int cols) {
+__global__ __launch_bounds__(256) void row_scale_kernel(const T* x, int64_t ldx, const float* __restrict__ s,
+                                                        float alpha, T* out, int64_t ldo, int64_t rows,
+                                                        int cols) {  // x == out is legal (in-place scaling): no __restrict__
   constexpr int VEC = 16 / sizeof(T);
   const int64_t per_row = (cols + VEC - 1) / VEC;
   const int64_t total = rows * per_row;
@@ -768,6 +768,11 @@ int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int3
 }
 
 int anemoi_abi_version(void) { return 35; }
+
+#ifndef ANEMOI_HIPCC_VERSION
+#define ANEMOI_HIPCC_VERSION "unknown (built without anemoi_models_amd/_build.py)"
+#endif
+const char* anemoi_build_info(void) { return "gfx950; " ANEMOI_HIPCC_VERSION; }
 
 const char* anemoi_last_error(void) { return err_buf(); }
 

@@ -55,12 +55,6 @@ struct LnFold {
   // operand bases b * b_sx / b_sw / b_sy elements apart; b_tiles = 0: one problem
   int64_t b_tiles, b_sx, b_sw, b_sy;
   int b_count;
-  // split-K launch of the four-wave kernel (SK instantiation): every tile's K range is cut into sk_parts contiguous runs
-  // of slabs, one workgroup each; sk_ws = [4 KiB header: one arrival counter per tile, zeroed by the launcher |
-  // f32 partial tiles, one per (tile, part)]
-  int sk_parts;
-  char* sk_ws;
-  int64_t sk_ws_bytes;  // host side: what the caller's workspace offers (0: no split-K)
 };
 
 template <typename T, typename TO, int VEC>
@@ -420,7 +414,7 @@ __device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int6
   }
 }
 
-template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false, bool DUAL = false, bool GMUL = false, bool SK = false>
+template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false, bool DUAL = false, bool GMUL = false>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias,
@@ -435,17 +429,6 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   // GMUL (backward, anemoi_linear_actgrad): R is the saved pre-activation, the result is acc * act'(R) -- the dX GEMM of
   // the Linear BEHIND an activation delivers the gradient of the Linear IN FRONT of it, no separate act' pass.
   static_assert(!GMUL || (HAS_RES && !LN && !RS && !DUAL && ACT != 0), "GMUL: pre-activation in R, no other epilogue mode");
-  // SK (split-K with an in-launch reduce-scatter, for problems of a few tall-K tiles -- 5121 x 1024 x 4096: 80 tiles on 256
-  // CUs): the launch walks UNITS = (tile, part), part p of s multiplying the slabs [p nk / s, (p + 1) nk / s) of the tile's
-  // K range; ONE unit per workgroup (units <= CUs, all resident).  Behind its K loop a workgroup stores the accumulators
-  // of the row groups it does NOT finish as f32 (write-through, its own slot of the workspace), counts itself in at the
-  // tile's arrival counter, waits for the other s - 1 parts, adds THEIR partials of the row groups [p MH / s, (p + 1) MH / s)
-  // -- own first, then the partners in ascending part order: a fixed order, bit-reproducible -- and runs the normal
-  // epilogue on those rows.  Every part writes (s - 1) / s of a tile and reads as much: the exchange is spread over all
-  // workgroups instead of serialising in one "fix-up" workgroup per tile (round 2's split-K lost exactly there).
-  // Protocol: cdna_hip_programming.md guideline 16, form R1 (sc1 payload stores, drained by every wave, one relaxed
-  // agent-scope arrival per workgroup; consumer: one lane polls relaxed, ONE agent acquire, barrier, plain loads).
-  static_assert(!SK || (!LN && !DUAL && !GMUL && ACT == 0), "SK: plain / residual / row-sum epilogues");
   // MH = 16-row fragments per wave along M: 8 -> the 256 x 256 tile, 4 -> a 128 x 256 tile (wave tile 64 x 128) used for
   // the rows of a remainder round (640 tiles on 256 CUs: the last 128 tiles become 256 half tiles = one full round),
   // 6 -> a 192 x 256 tile for small problems whose 256-row tiles quantise badly (5121 x 4096: 320 tiles = 2 rounds, as
@@ -474,15 +457,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int64_t chunk_len = q8 + (xcd < r8 ? 1 : 0);
   if (bix >= chunk_len) return;
-  int nk = K / 64;  // >= 2 (launcher)
-  int sk_part = 0, sk_koff = 0;  // SK: this workgroup's part of its tile and the byte offset of its first slab in a row
-  if constexpr (SK) {
-    const int nk_all = nk;
-    sk_part = (int)((chunk_start + bix) % ln.sk_parts);
-    const int kbeg = sk_part * nk_all / ln.sk_parts;
-    nk = (sk_part + 1) * nk_all / ln.sk_parts - kbeg;  // >= 2 (launcher)
-    sk_koff = kbeg * ROW_BYTES;
-  }
+  const int nk = K / 64;  // >= 2 (launcher)
 
   // ---- staging side.  Wave w fills LDS rows w * 64 + 8 i + (lane >> 3), i = 0..7, of both operand panels; the
   //      source chunk is swizzled with the LDS row ((row >> 1) & 7 = (4 i + (lane >> 4)) & 7: two classes, i even/odd).
@@ -506,7 +481,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   const int xrow16 = 16 * (int)ldx * 2;
   const int xwave = wid * (MH * 8) * (int)ldx * 2, wwave = wid * 64 * K * 2;
   __amdgpu_buffer_rsrc_t xrs, wrs;  // descriptors of the tile whose slabs are being staged
-  const int64_t tiles_per_problem = SK ? n_tiles / ln.sk_parts : ln.b_tiles > 0 ? ln.b_tiles : n_tiles;
+  const int64_t tiles_per_problem = ln.b_tiles > 0 ? ln.b_tiles : n_tiles;
   auto set_tile = [&](int64_t tile) {
     int64_t mt_;
     int nt_;
@@ -526,12 +501,11 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   };
   auto dma_x = [&](int i, int kt, char* dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, vox[i & 1],
-                                             xwave + (i >> 1) * xrow16 + kt * ROW_BYTES + sk_koff, 0, 0);
+                                             xwave + (i >> 1) * xrow16 + kt * ROW_BYTES, 0, 0);
   };
   auto dma_w = [&](int i, int kt, char* dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, vow[i & 1],
-                                             wwave + (32 * (i >> 2) + 16 * (i & 1) + 4 * ((i >> 1) & 1)) * K * 2 + kt * ROW_BYTES +
-                                                 sk_koff,
+                                             wwave + (32 * (i >> 2) + 16 * (i & 1) + 4 * ((i >> 1) & 1)) * K * 2 + kt * ROW_BYTES,
                                              0, 0);
   };
   // LDS image of a slab: x panel rows 0 .. TM-1 at the stage base (wave w: rows w * MH * 8 ...), W panel at + 32 KiB
@@ -561,7 +535,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   bf16x8_t a0[8], b0[MH], a1[8], b1[MH];
 
   // prologue: slabs 0 and 1 of the first tile; fragments of (slab 0, ks 0)
-  set_tile(SK ? (chunk_start + bix) / ln.sk_parts : chunk_start + bix);
+  set_tile(chunk_start + bix);
   stage_all(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -596,8 +570,8 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   bool has_next = false;
   for (;;) {
     if (k == 0) {
-      tile = SK ? (chunk_start + li) / ln.sk_parts : chunk_start + li;
-      has_next = !SK && li + bpx < chunk_len;
+      tile = chunk_start + li;
+      has_next = li + bpx < chunk_len;
       int64_t mt_;
       int nt_;
       const int64_t pb = ln.b_tiles > 0 ? tile / ln.b_tiles : 0;
@@ -758,28 +732,6 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
       for (int j = 0; j < MH; ++j)
         rst[j] = *reinterpret_cast<const float2*>(smem + 2 * BIG_STAGE + 2048 + (wm * (MH * 16) + j * 16 + fr_e) * 8);
     }
-    // SK: the row groups this part finishes, its partners' workspace slots, and the one-row-group-deep ring of their
-    // partial sums (column group u: two accumulators per partner)
-    const int sk_np = SK ? ln.sk_parts - 1 : 0;
-    const int sk_jlo = SK ? sk_part * MH / ln.sk_parts : 0, sk_jhi = SK ? (sk_part + 1) * MH / ln.sk_parts : MH;
-    constexpr int SK_UNIT_BYTES = MH * 8 * 256 * 16;  // a tile's accumulators as f32: [j][i][thread] x 16 bytes
-    __amdgpu_buffer_rsrc_t sk_rs;                      // the s slots of this tile (one per part), contiguous
-    f32x4_t pv[4][2][2];
-    auto sk_fetch = [&](int jr, int u) {
-      if constexpr (SK) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-          if (q < sk_np) {
-            const int pq = q < sk_part ? q : q + 1;  // partner q: parts 0 .. s-1 without sk_part, ascending
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(sk_rs, (int)threadIdx.x * 16,
-                                                                     pq * SK_UNIT_BYTES + (jr * 8 + 2 * u + h) * 4096, 0);
-              pv[u][q][h] = f32x4_t{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-            }
-          }
-      }
-    };
     auto res_fetch = [&](auto j_tag, uint4 (&rv)[4]) {
       constexpr int j = decltype(j_tag)::value;
       if constexpr (HAS_RES && j < MH) {
@@ -806,11 +758,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
         asm volatile("" : "+v"(c[i]));  // the copy is IN VGPRs here, before the accumulator's register is zeroed in place
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!SK) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)  // "+a": the zeroed value keeps the accumulator's register (no copies at the loop edges)
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "+a"(acc[i][j]) : "v"(zfrag));
-      }
+      for (int i = 0; i < 8; ++i)  // "+a": the zeroed value keeps the accumulator's register (no copies at the loop edges)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "+a"(acc[i][j]) : "v"(zfrag));
       float rs1 = 0.f, rs2 = 0.f;  // RS: sum / sum of squares of this lane's 32 stored values of row j * 16 + fr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -892,98 +842,6 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     // (sched_barrier: the compiler otherwise sinks the prefetches down to their first use)
 #define ANEMOI_PIN() __builtin_amdgcn_sched_barrier(0)
     uint4 rv[3][4];
-    if constexpr (SK) {
-      // ---- split-K: publish the row groups other parts finish, arrive, wait for the tile's other parts
-      typedef __attribute__((address_space(1))) unsigned gu32_t;
-      const int64_t unit = chunk_start + li;
-      const int s_parts = ln.sk_parts;
-      sk_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(ln.sk_ws + 4096 + (unit - sk_part) * (int64_t)SK_UNIT_BYTES), 0,
-                                                s_parts * SK_UNIT_BYTES, 0x00020000);
-      const int tid16 = (int)threadIdx.x * 16;
-      const int own_off = sk_part * SK_UNIT_BYTES;
-      static_for_seq(
-          [&](auto j_tag) {
-            constexpr int j = decltype(j_tag)::value;
-            if (j < sk_jlo || j >= sk_jhi) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                asm volatile("" : "+a"(acc[i][j]));
-                f32x4_t v = acc[i][j];
-                asm volatile("" : "+v"(v));
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                    sk_rs, tid16, own_off + (j * 8 + i) * 4096, 16 /* sc1: write-through */);
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 1" ::: "memory");  // (store-data hazard of a 16-byte store with an SGPR offset, below)
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-          },
-          std::make_integer_sequence<int, MH>{});
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores ...
-      __syncthreads();                                    // ... before ONE lane counts the workgroup in
-      gu32_t* const cnt = (gu32_t*)(ln.sk_ws) + tile;
-      if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s_parts) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > (1u << 22)) {  // ~seconds: a part that never arrives (not resident) must not hang the queue
-            __hip_atomic_store((gu32_t*)(ln.sk_ws) + 1023, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire behind the match: drops this CU's stale lines
-      }
-      __syncthreads();
-      // phase 1, in place: own accumulators + the partners' partial sums (ascending part order) of the row groups this part
-      // finishes.  Requests run one row group ahead: the ring slot of column group u is refilled with row group j + 1 as
-      // soon as it has been consumed.  (Its own phase, not fused into the stores below: the two together spill.)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) sk_fetch(sk_jlo, u);
-      static_for_seq(
-          [&](auto j_tag) {
-            constexpr int j = decltype(j_tag)::value;
-            if (j >= sk_jlo && j < sk_jhi) {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                  asm volatile("" : "+a"(acc[2 * u + h][j]));
-                  f32x4_t c = acc[2 * u + h][j];
-#pragma unroll
-                  for (int q = 0; q < 2; ++q)
-                    if (q < sk_np) c += pv[u][q][h];
-                  acc[2 * u + h][j] = c;
-                  asm volatile("" : "+a"(acc[2 * u + h][j]));
-                }
-                if (j + 1 < sk_jhi) sk_fetch(j + 1, u);
-              }
-            }
-          },
-          std::make_integer_sequence<int, MH>{});
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 7" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      // phase 2: the epilogue proper on those row groups
-      static_for_seq(
-          [&](auto j_tag) {
-            constexpr int j = decltype(j_tag)::value;
-            if constexpr (j < 2)
-              if (j >= sk_jlo && j < sk_jhi) res_fetch(j_tag, rv[j]);
-          },
-          std::make_integer_sequence<int, 2>{});
-      static_for_seq(
-          [&](auto j_tag) {
-            constexpr int j = decltype(j_tag)::value;
-            if (j + 2 >= sk_jlo && j + 2 < sk_jhi) res_fetch(std::integral_constant<int, j + 2>{}, rv[(j + 2) % 3]);
-            ANEMOI_PIN();
-            if (j >= sk_jlo && j < sk_jhi) store_rows(j_tag, rv[j % 3]);
-            ANEMOI_PIN();
-          },
-          std::make_integer_sequence<int, MH>{});
-      break;  // one unit per workgroup
-    }
     res_fetch(std::integral_constant<int, 0>{}, rv[0]);
     res_fetch(std::integral_constant<int, 1>{}, rv[1]);
     ANEMOI_PIN();
@@ -1064,22 +922,6 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4_RS(true, false, 4);
     RAISE_W4_RS(true, true, 4);
 #undef RAISE_W4_RS
-#define RAISE_W4_SK(RES, RSV, MHV)                                                                                     \
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<0, RES, false, MHV, RSV, false, false, true>), \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)                            \
-    return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
-#define RAISE_W4_SK4(MHV)        \
-  RAISE_W4_SK(false, false, MHV); \
-  RAISE_W4_SK(false, true, MHV);  \
-  RAISE_W4_SK(true, false, MHV);  \
-  RAISE_W4_SK(true, true, MHV)
-    RAISE_W4_SK(false, false, 8);  // (256-row tiles + residual: the exchange's registers do not fit beside 256 accumulators)
-    RAISE_W4_SK(false, true, 8);
-    RAISE_W4_SK4(6);
-    RAISE_W4_SK4(5);
-    RAISE_W4_SK4(4);
-#undef RAISE_W4_SK4
-#undef RAISE_W4_SK
 #define RAISE_W4_DUAL(A, MHV)                                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, false, false, MHV, false, true>), \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)                      \
@@ -1208,75 +1050,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     // MH / 8 of its 6.5 us epilogue; what decides is how the tile count quantises against the 256 CUs
     // (5121 x 2048: 160 / 216 / 256 / 320 tiles -> 160-row tiles fill the chip exactly once;
     //  5121 x 4096: 320 / 432 / 512 / 640 -> two balanced rounds of 160-row tiles; profiles/r04_gemm_small_m.txt).
-    // Split-K with an in-launch reduce-scatter (SK instantiation, see the kernel): for problems of a few tall-K tiles when
-    // the caller's workspace has room for the partial tiles.  (MH, parts) by the same model + the exchange.
-    bool sk_done = false;
-    if (!batched && !dual && !gmul && act == ANEMOI_ACT_NONE && ln.stats == nullptr && ln.sk_ws != nullptr &&
-        mt * nt < 2 * max_blocks) {
-      static const int forced_sk = [] {  // lab switch: ANEMOI_AMD_GEMM_SK=<10 * MH + parts> (e.g. 83), 0 = never
-        const char* e = getenv("ANEMOI_AMD_GEMM_SK");
-        return e != nullptr ? atoi(e) : -1;
-      }();
-      const int nk = K / 64;
-      double plain_cost = 1e30;
-      for (const int mh : {8, 6, 5, 4}) {
-        const int64_t tiles = (M + 32 * mh - 1) / (32 * mh) * nt, rounds = (tiles + max_blocks - 1) / max_blocks;
-        const double c = (double)rounds * (0.8125 * mh + nk * 1.44 * (32 * mh + 256) / 512.0);
-        plain_cost = c < plain_cost ? c : plain_cost;
-      }
-      int sk_mh = 0, sk_s = 0;
-      double sk_cost = 1e30;
-      for (const int mh : {8, 6, 5, 4})
-        for (int sp = 2; sp <= 3; ++sp) {  // (the kernel's partner ring holds two partners)
-          const int64_t tiles = (M + 32 * mh - 1) / (32 * mh) * nt, units = tiles * sp;
-          if (units > max_blocks || nk / sp < 4 || tiles > 1000 || (mh == 8 && residual != nullptr)) continue;
-          if (4096 + units * (int64_t)mh * 32768 > ln.sk_ws_bytes) continue;
-          const double part_kb = (double)(sp - 1) / sp * mh * 32.0;  // KiB a part writes and reads
-          const double c = 0.8125 * mh / sp + ((nk + sp - 1) / sp) * 1.44 * (32 * mh + 256) / 512.0 + 4.0 + 2.0 * part_kb / 60.0;
-          const bool forced = forced_sk == 10 * mh + sp;
-          if (forced || (forced_sk < 0 && c < sk_cost)) {
-            sk_cost = forced ? 0.0 : c;
-            sk_mh = mh;
-            sk_s = sp;
-            if (forced) break;
-          }
-        }
-      if (forced_sk == 0) sk_mh = 0;
-      if (sk_mh != 0 && sk_cost < 0.93 * plain_cost) {
-        const int64_t tiles = (M + 32 * sk_mh - 1) / (32 * sk_mh) * nt, units = tiles * sk_s;
-        LnFold lsk = ln;
-        lsk.sk_parts = sk_s;
-        if (hipMemsetAsync(ln.sk_ws, 0, 4096, st) != hipSuccess)
-          return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot clear the split-K arrival counters");
-        w4_blocks = (units + 7) / 8 * 8;
-#define LAUNCH_W4_SK(MHV, RES, RSV)                                                                                        \
-  hipLaunchKernelGGL((linear_bf16_w4_kernel<0, RES, false, MHV, RSV, false, false, true>), dim3((unsigned)w4_blocks),     \
-                     dim3(256), W4_LDS, st, xb, ldx, static_cast<const bf16_t*>(w), bias, rb, ldr, yb, ldy, M, N, K,       \
-                     vec_ok ? 1 : 0, units, (int)nt, lsk, w4_tail)
-#define LAUNCH_W4_SKM(MHV)                                           \
-  do {                                                               \
-    if (residual != nullptr) {                                       \
-      if (rs_on) LAUNCH_W4_SK(MHV, true, true);                      \
-      else LAUNCH_W4_SK(MHV, true, false);                           \
-    } else {                                                         \
-      if (rs_on) LAUNCH_W4_SK(MHV, false, true);                     \
-      else LAUNCH_W4_SK(MHV, false, false);                          \
-    }                                                                \
-  } while (0)
-        if (sk_mh == 8) {
-          if (rs_on) LAUNCH_W4_SK(8, false, true);
-          else LAUNCH_W4_SK(8, false, false);
-        } else if (sk_mh == 6) LAUNCH_W4_SKM(6);
-        else if (sk_mh == 5) LAUNCH_W4_SKM(5);
-        else LAUNCH_W4_SKM(4);
-#undef LAUNCH_W4_SKM
-#undef LAUNCH_W4_SK
-        mt_a = 0;
-        mt_b = 0;
-        sk_done = true;
-      }
-    }
-    if (!sk_done && !batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
+    if (!batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
       static const int forced_mh = [] {  // lab switch for A/B runs: ANEMOI_AMD_GEMM_MH=4|5|6|8
         const char* e = getenv("ANEMOI_AMD_GEMM_MH");
         return e != nullptr ? atoi(e) : 0;
@@ -1550,16 +1324,6 @@ extern "C" int anemoi_linear_actgrad(int dtype, const void* x, int64_t ldx, cons
   return rc;
 }
 
-// Workspace anemoi_linear_stats can use for an [M, K] x [N, K]^T product: the row-sum partials (M x N / 128 x 8 bytes,
-// the minimum) + for small bf16 problems the split-K region (arrival counters + one f32 partial tile per (tile, part):
-// at most 256 units of 256 x 256 x 4 bytes).  A smaller workspace is legal: the launch then does without split-K.
-extern "C" int64_t anemoi_linear_stats_workspace_bytes(int dtype, int64_t M, int N, int K) {
-  const int64_t rs = (M * (N / 128 > 1 ? N / 128 : 1) * 8 + 4095) / 4096 * 4096;
-  const int64_t mt = (M + 255) / 256, nt = (N + 255) / 256;
-  if (dtype != ANEMOI_BF16 || M < 1024 || N < 256 || N % 256 != 0 || K < 512 || mt * nt >= 512) return rs;
-  return rs + 4096 + (int64_t)256 * 262144;
-}
-
 extern "C" int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const void* w, const float* bias,
                                    const float* colsum, const float* stats_in, const void* residual, int64_t ldr,
                                    void* y, int64_t ldy, int64_t M, int N, int K, void* workspace,
@@ -1577,12 +1341,6 @@ extern "C" int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const 
     ln.rs_partial = static_cast<float2*>(workspace);
     ln.rs_slots = slots;
     ln.rs_rows_done = &rows_done;
-    // what the workspace holds beyond the row-sum partials (anemoi_linear_stats_workspace_bytes) is the split-K region
-    const int64_t rs_bytes = (M * slots * 8 + 4095) / 4096 * 4096;
-    if ((uintptr_t)workspace % 16 == 0 && workspace_bytes >= rs_bytes + 4096 + 32768) {
-      ln.sk_ws = static_cast<char*>(workspace) + rs_bytes;
-      ln.sk_ws_bytes = workspace_bytes - rs_bytes;
-    }
   }
   const int rc = linear_dispatch("anemoi_linear_stats", dtype, dtype, x, ldx, w, bias, ln, residual, ldr, y, ldy, M, N,
                                  K, ANEMOI_ACT_NONE, stream);

@@ -367,7 +367,7 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
             att[:, c + h * up:].zero_()
         y, hid, out = (torch.empty((n, w), dtype=dtype, device=dev) for w in (c, w1.shape[0], c))
         stats = torch.empty((2 if out_stats_eps is not None else 1, n, 2), dtype=torch.float32, device=dev)
-        ws = max((ops.linear_stats_workspace(dtype, n, c, kk, dev) for kk in (wp.shape[1], w1.shape[0])), key=Tensor.numel)
+        ws = torch.empty((n * max(c // 128, 1), 2), dtype=torch.float32, device=dev)
         a = _lib.GtBlockArgs()
         a.struct_bytes, a.n_dst, a.dtype = ctypes.sizeof(_lib.GtBlockArgs), n, ops.dtype_code(dtype)
         a.C, a.H, a.up, a.hidden, a.act, a.k_proj = c, h, up, w1.shape[0], _lib.ACT_CODES[act], wp.shape[1]
@@ -381,7 +381,7 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         a.w_fc1, a.b_fc1, a.cs_fc1, a.h = w1.data_ptr(), ops._ptr(b1), cs1.data_ptr(), hid.data_ptr()
         a.w_fc2, a.b_fc2, a.out = w2.data_ptr(), ops._ptr(b2), out.data_ptr()
         a.out_stats = stats[1].data_ptr() if out_stats_eps is not None else None
-        a.stats_ws, a.stats_ws_bytes = ws.data_ptr(), ws.numel()
+        a.stats_ws, a.stats_ws_bytes = ws.data_ptr(), ws.numel() * 4
         _lib.check(_lib.load().anemoi_gt_block_tail(ctypes.byref(a), ops._stream()), "anemoi_gt_block_tail")
         if out_stats_eps is not None:
             ops._carry_stats(out, out_stats_eps, stats[1])

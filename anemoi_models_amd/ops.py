@@ -164,14 +164,6 @@ def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
     return out
 
 
-def linear_stats_workspace(dtype: torch.dtype, m: int, n: int, k: int, device) -> Tensor:
-    """Workspace of ``anemoi_linear_stats`` for an ``[m, k] x [n, k]^T`` product (uint8): the row-sum partials and, for the
-    small problems that run split-K, the partial-tile region (``anemoi_linear_stats_workspace_bytes``).  Uninitialised: the
-    launcher clears the few words it polls."""
-    nbytes = _lib.load().anemoi_linear_stats_workspace_bytes(dtype_code(dtype), m, n, k)
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
-
-
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "Identity",
            residual: Optional[Tensor] = None, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
            n_out: Optional[int] = None, ln=None, stats_eps: Optional[float] = None) -> Tensor:
@@ -206,12 +198,12 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
                 stats_in, colsum = ln
                 _dev(stats_in, colsum)
             m_rows = x.shape[0]
-            ws = linear_stats_workspace(x.dtype, m_rows, n, k, x.device)
+            ws = torch.empty((m_rows * max(n // 128, 1), 2), dtype=torch.float32, device=x.device)
             stats_out = torch.empty((m_rows, 2), dtype=torch.float32, device=x.device)
             st = _lib.load().anemoi_linear_stats(
                 dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias), _ptr(colsum), _ptr(stats_in),
                 _ptr(residual), 0 if residual is None else _ld(_rows(residual)), out.data_ptr(), _ld(_rows(out)), m_rows,
-                n, k, ws.data_ptr(), ws.numel(), stats_eps, stats_out.data_ptr(), _stream())
+                n, k, ws.data_ptr(), ws.numel() * 4, stats_eps, stats_out.data_ptr(), _stream())
             _carry_stats(out, stats_eps, stats_out)
         elif ln is None:
             st = _lib.load().anemoi_linear(
@@ -419,8 +411,10 @@ def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Op
 
 def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_size: int, num_heads: int,
                   window: int = -1, dropout_p: float = 0.0, dropout_seed: int = 0, head_offset: int = 0,
-                  heads_total: int = 0) -> Tensor:
-    """``d qkv`` ``[B*S, 3C]`` of :func:`mhsa` from the forward's output and log-sum-exp (``anemoi_mhsa_backward``)."""
+                  heads_total: int = 0, use_mfma: bool = True) -> Tensor:
+    """``d qkv`` ``[B*S, 3C]`` of :func:`mhsa` from the forward's output and log-sum-exp (``anemoi_mhsa_backward``).
+    ``use_mfma=False`` withholds the workspace: the call then takes the VALU kernels (plain HIP, any head size / dtype) --
+    the yardstick the MFMA route's hand-scheduled kernels are held against in the tests."""
     _dev(qkv, out, dout, lse)
     rows, c3 = _rows(qkv).shape
     c = c3 // 3
@@ -431,7 +425,7 @@ def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_siz
         raise ValueError("mhsa_backward: lse must be the contiguous f32 [B, H, S] output of mhsa(return_lse=True)")
     lib = _lib.load()
     ws_bytes = lib.anemoi_mhsa_backward_workspace_bytes(dtype_code(qkv.dtype), batch_size, s_len, num_heads, c // num_heads)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 else None
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 and use_mfma else None
     st = lib.anemoi_mhsa_backward(dtype_code(qkv.dtype), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)),
                                   dout.data_ptr(), _ld(_rows(dout)), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), c3,
                                   _ptr(ws), batch_size, s_len, num_heads, c // num_heads, window, float(dropout_p),

@@ -47,6 +47,9 @@ typedef void* anemoi_stream_t; /* hipStream_t */
 
 /* ABI version (bumped on any signature change) and last error text of this thread. */
 int anemoi_abi_version(void);
+/* Target architecture and the hipcc / clang the library was built with (static string).  The inline-asm kernels carry
+ * hand-counted wait states hipcc does not check; a report of wrong results should quote this line. */
+const char* anemoi_build_info(void);
 const char* anemoi_last_error(void);
 
 /*
@@ -114,15 +117,7 @@ int anemoi_linear_ln(int dtype, int out_dtype, const void* x, int64_t ldx, const
  * folds them -- y is not read again.  Other shapes / dtypes (or workspace == NULL): same result through
  * anemoi_row_stats on y.  colsum / stats_in: both NULL = plain Linear, both set = LayerNorm-folded input as in
  * anemoi_linear_ln.  x, y, residual in `dtype`.
- *
- * Split-K (round 4): problems of a few tall-K tiles (a node-partitioned rank's projection / second MLP Linear,
- * 5121 x 1024 x 4096: 80 tiles of 256 x 256 on 256 CUs; config 2's 10242 x 512 x 2048) run every tile as 2 or 3 workgroups
- * over disjoint K ranges that exchange f32 partial tiles THROUGH THE WORKSPACE inside the launch (reduce-scatter: each
- * part finishes 1 / parts of the tile's rows; fixed summation order, results reproducible bit for bit) -- when the
- * workspace is at least anemoi_linear_stats_workspace_bytes(dtype, M, N, K) bytes and 16-byte aligned.  With the minimum
- * size above the call runs without split-K; the two differ in the last bits of the f32 sums (another summation order).
  */
-int64_t anemoi_linear_stats_workspace_bytes(int dtype, int64_t M, int N, int K);
 int anemoi_linear_stats(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, const float* colsum,
                         const float* stats_in, const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int N,
                         int K, void* workspace, int64_t workspace_bytes, float eps, float* stats_out,

@@ -345,6 +345,34 @@ def test_mhsa_backward_vs_torch_autograd(dtype, b, s, h, d, window):
     assert rel_err(x.grad, ref_in.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("d", [64, 32])
+@pytest.mark.parametrize("b,s", [(1, 257), (1, 512), (2, 1301), (1, 2112)])   # ragged / tile-aligned / batched / 33 tiles
+@pytest.mark.parametrize("window", [-1, 100])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_mhsa_backward_mfma_route_vs_valu_route(d, b, s, window, p):
+    """The MFMA backward (inline-asm products with hand-counted wait states the compiler cannot check) against the VALU
+    backward of the same entry point (plain HIP: every hazard is the compiler's) -- same inputs, same forward statistics,
+    same dropout mask: a compiler upgrade or a schedule change that breaks a wait state shows here as a wrong gradient,
+    on a grid of head size x ragged / aligned / batched S x window x dropout."""
+    from anemoi_models_amd import _lib, ops
+
+    h = 4
+    c = h * d
+    g = torch.Generator().manual_seed(1000 * d + s + window + int(100 * p))
+    qkv = (torch.randn(b * s, 3 * c, generator=g) * 0.9).bfloat16().to(DEV)
+    dout = torch.randn(b * s, c, generator=g).bfloat16().to(DEV)
+    out, lse = ops.mhsa(qkv, b, h, window, return_lse=True, dropout_p=p, dropout_seed=77)
+    fast = ops.mhsa_backward(qkv, out, dout, lse, b, h, window, dropout_p=p, dropout_seed=77)
+    slow = ops.mhsa_backward(qkv, out, dout, lse, b, h, window, dropout_p=p, dropout_seed=77, use_mfma=False)
+    assert torch.isfinite(fast.float()).all() and torch.isfinite(slow.float()).all()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a, w = fast[:, i * c:(i + 1) * c], slow[:, i * c:(i + 1) * c]
+        assert rel_err(a, w) < 2e-2, (name, rel_err(a, w))
+        rows = (a.float() - w.float()).abs().amax(1) / w.float().abs().amax(1).clamp_min(1e-3 * float(w.float().abs().max()))
+        assert float(rows.max()) < 6e-2, (name, int(rows.argmax()), float(rows.max()))
+    assert b"clang" in _lib.load().anemoi_build_info() or b"unknown" in _lib.load().anemoi_build_info()
+
+
 @pytest.mark.parametrize("s,h,d,window,p", [(2100, 4, 64, -1, 0.0), (1300, 8, 32, -1, 0.0), (1700, 2, 64, 90, 0.1)])
 def test_mhsa_backward_repeated_calls_are_bit_identical(s, h, d, window, p):
     """The backward kernels stream their tiles through an LDS-DMA ring (round 3): 40 calls on the same inputs, with the
