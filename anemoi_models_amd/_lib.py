@@ -101,11 +101,11 @@ SIGNATURES = {
     "anemoi_segment_sum": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "anemoi_mhsa_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                            c_int, c_float, c_uint32, c_int, c_int, c_void_p]),
+                            c_int, c_float, c_uint32, c_void_p, c_int, c_int, c_void_p]),
     "anemoi_mhsa_backward_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa_backward": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32,
-                                     c_int, c_int, c_void_p]),
+                                     c_void_p, c_int, c_int, c_void_p]),
     "anemoi_assemble_nodes": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "anemoi_finalize_output": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,

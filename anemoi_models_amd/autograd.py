@@ -560,30 +560,32 @@ class _MHSA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv: Tensor, batch_size: int, num_heads: int, window: int, dropout_p: float, seed: int,
-                head_offset: int = 0, heads_total: int = 0):
+                head_offset: int = 0, heads_total: int = 0, seed_dev: Optional[Tensor] = None):
         out, lse = ops.mhsa(qkv, batch_size, num_heads, window, return_lse=True, dropout_p=dropout_p, dropout_seed=seed,
-                            head_offset=head_offset, heads_total=heads_total)
+                            head_offset=head_offset, heads_total=heads_total, seed_dev=seed_dev)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.args = (batch_size, num_heads, window, dropout_p, seed, head_offset, heads_total)
+        # (seed_dev is THIS call's word -- runtime.DeviceDropout.seed_word() makes one per call --, so the backward reads
+        #  the value the forward saw whatever the step counter has done since)
+        ctx.args = (batch_size, num_heads, window, dropout_p, seed, head_offset, heads_total, seed_dev)
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         qkv, out, lse = ctx.saved_tensors
-        b, h, w, p, seed, h0, ht = ctx.args
-        return (ops.mhsa_backward(qkv, out, dout.contiguous(), lse, b, h, w, p, seed, h0, ht), None, None, None, None, None,
-                None, None)
+        b, h, w, p, seed, h0, ht, seed_dev = ctx.args
+        return (ops.mhsa_backward(qkv, out, dout.contiguous(), lse, b, h, w, p, seed, h0, ht, seed_dev=seed_dev), None, None,
+                None, None, None, None, None, None)
 
 
 def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, dropout_p: float = 0.0,
-         seed: Optional[int] = None, head_offset: int = 0, heads_total: int = 0) -> Tensor:
+         seed: Optional[int] = None, head_offset: int = 0, heads_total: int = 0, seed_dev: Optional[Tensor] = None) -> Tensor:
     """Differentiable ``ops.mhsa`` (reference layers/attention.py:67-112).  ``dropout_p`` > 0: attention dropout with a
     mask derived from ``seed`` (default: drawn from torch's CPU generator, so ``torch.manual_seed`` reproduces it);
     ``head_offset`` / ``heads_total``: a head shard of a model group (see ``ops.mhsa``)."""
     if dropout_p > 0.0 and seed is None:
         seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
     return _MHSA.apply(qkv, batch_size, num_heads, window, float(dropout_p), int(seed or 0), int(head_offset),
-                       int(heads_total))
+                       int(heads_total), seed_dev)
 
 
 # ------------------------------------------------------------------------------------------ GNN edge phase

@@ -94,7 +94,17 @@ struct AttnDropout {
   float keep_scale;    // 1 / (1 - p), 0 when p >= 1
   int drop_all;
   int h0, h_total;     // global index of this call's head 0, number of heads of the whole attention
+  // optional DEVICE part of the seed (the low 32 bits of a word in device memory, added to `seed` by every kernel at its
+  // start): a training step captured in a HIP graph replays its kernel arguments, so what must change from step to step
+  // -- the dropout mask -- has to come from memory the graph itself advances (runtime.DeviceDropout)
+  const uint32_t* seed_dev;
 };
+
+__device__ __forceinline__ AttnDropout dropout_resolve(const AttnDropout& in) {
+  AttnDropout dr = in;
+  if (dr.thr16 != 0 && dr.seed_dev != nullptr) dr.seed += __builtin_nontemporal_load(dr.seed_dev);
+  return dr;
+}
 
 __device__ __forceinline__ int64_t dropout_row(const AttnDropout& dr, int64_t b, int h, int64_t S, int64_t q) {
   return (b * dr.h_total + dr.h0 + h) * S + q;
@@ -122,9 +132,10 @@ __device__ __forceinline__ float dropout_keep(const AttnDropout& dr, int64_t row
   return ((x >> (16 * (col & 1))) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.0f;
 }
 
-static inline AttnDropout make_dropout(float p, uint32_t seed, int h0, int h_total) {
+static inline AttnDropout make_dropout(float p, uint32_t seed, int h0, int h_total, const void* seed_dev = nullptr) {
   AttnDropout dr;
   dr.seed = seed;
+  dr.seed_dev = static_cast<const uint32_t*>(seed_dev);
   dr.drop_all = p >= 1.0f ? 1 : 0;
   const double t = p <= 0.f ? 0.0 : (double)p * 65536.0 + 0.5;
   dr.thr16 = dr.drop_all ? 0xffffu : (uint32_t)(t > 65535.0 ? 65535.0 : t);
@@ -143,10 +154,11 @@ template <int ATT_D, bool DROP = false>
 // softmax's ~6 (two of them 32-bit multiplies).
 __global__ __launch_bounds__(512, (ATT_D == 32 && !DROP) ? 4 : 2) void mhsa_bf16_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int64_t ldo, int S,
-    int S_pad, int H, int C, int window, float scale_log2e, float* __restrict__ lse, const AttnDropout dr,
+    int S_pad, int H, int C, int window, float scale_log2e, float* __restrict__ lse, const AttnDropout dr_arg,
     const int* __restrict__ run_flag = nullptr) {  // optional: run only if *run_flag != 0 (fallback of mhsa_bf16_w4_kernel)
   static_assert(ATT_D == 32 || ATT_D == 64, "head sizes with an MFMA path");
   if (run_flag != nullptr && *run_flag == 0) return;
+  const AttnDropout dr = dropout_resolve(dr_arg);
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32;
   constexpr int KRB = ATT_D * 2;                        // bytes of a key row in the K tile
   constexpr int K_TILE = ATT_KV * KRB, V_TILE = ATT_D * 128;
@@ -382,8 +394,9 @@ template <bool DROP>
 __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                            const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                            int64_t ldo, int S, int S_pad, int H, int C,
-                                                           float scale_log2e, float* __restrict__ lse, const AttnDropout dr,
+                                                           float scale_log2e, float* __restrict__ lse, const AttnDropout dr_arg,
                                                            int* __restrict__ redo_flag) {
+  const AttnDropout dr = dropout_resolve(dr_arg);
   constexpr int ATT_D = 64, NKS = 4, NDT = 2, KRB = 128;
   constexpr int K_TILE = ATT_KV * KRB, V_TILE = ATT_D * 128, ATT_STAGE = K_TILE + V_TILE;
   constexpr int N_STAGE = 4;  // tile kt + 2 is requested behind barrier kt; the V^T half of tile kt - 1 is still read there
@@ -797,7 +810,8 @@ template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void mhsa_generic_kernel(const T* __restrict__ qkv, int64_t ld, T* __restrict__ out,
                                                            int64_t ldo, int S, int H, int D, int C, int window,
                                                            float scale, int64_t total, float* __restrict__ lse,
-                                                           const AttnDropout dr, int q_begin, int q_count) {
+                                                           const AttnDropout dr_arg, int q_begin, int q_count) {
+  const AttnDropout dr = dropout_resolve(dr_arg);
   // queries [q_begin, q_begin + q_count) of every batch element (the whole sequence, or the few rows the MFMA kernel's
   // 512-query blocks leave over)
   const int lane = threadIdx.x & 63;
@@ -866,7 +880,8 @@ template <int D>
 __global__ __launch_bounds__(256) void mhsa_tail_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int S, int H, int C,
                                                         int window, float scale, int q_begin, int q_count, int n_split,
                                                         int chunk, int64_t total, float* __restrict__ part,
-                                                        const AttnDropout dr) {
+                                                        const AttnDropout dr_arg) {
+  const AttnDropout dr = dropout_resolve(dr_arg);
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h, split)
   if (unit >= total) return;
@@ -1103,7 +1118,8 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
     const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT, const float* __restrict__ lse2p,
     const float* __restrict__ deltap, bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window,
-    float scale, float scale_log2e, const AttnDropout dr) {
+    float scale, float scale_log2e, const AttnDropout dr_arg) {
+  const AttnDropout dr = dropout_resolve(dr_arg);
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;  // chunks of 16 bytes per row
   // Query tiles (32 queries: Q and dO rows, Q^T and dO^T rows of 64 bytes, lse / delta) travel through a ring of three LDS
   // buffers by LDS-DMA: tile qt + 2 is requested while tile qt is computed, one barrier per tile (round 3; the first
@@ -1325,7 +1341,8 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ dout, int64_t lddo,
     const bf16_t* __restrict__ kT, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dqkv, int64_t lddq, int S, int S_pad, int H, int C, int window, float scale, float scale_log2e,
-    const AttnDropout dr) {
+    const AttnDropout dr_arg) {
+  const AttnDropout dr = dropout_resolve(dr_arg);
   constexpr int NKS = ATT_D / 16, NDT = ATT_D / 32, RB = ATT_D * 2, CPR = RB / 16;
   // key tiles (K and V rows, K^T rows of 64 bytes) through a ring of three LDS buffers by LDS-DMA, as in the dK/dV kernel:
   // 3 PP pieces of 1 KiB per tile, piece i NW + wave for the waves that have one (D = 64: twelve pieces on eight waves --
@@ -1491,7 +1508,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const T* __restrict__ 
                                                           int64_t ldo, const T* __restrict__ dout, int64_t lddo,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           T* __restrict__ dqkv, int64_t lddq, int S, int H, int D, int C,
-                                                          int window, float scale, int64_t total, const AttnDropout dr) {
+                                                          int window, float scale, int64_t total, const AttnDropout dr_arg) {
+  const AttnDropout dr = dropout_resolve(dr_arg);
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h)
   if (unit >= total) return;
@@ -1545,7 +1563,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkv_kernel(const T* __restrict__
                                                            const T* __restrict__ dout, int64_t lddo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            T* __restrict__ dqkv, int64_t lddq, int S, int H, int D, int C,
-                                                           int window, float scale, int64_t total, const AttnDropout dr) {
+                                                           int window, float scale, int64_t total, const AttnDropout dr_arg) {
+  const AttnDropout dr = dropout_resolve(dr_arg);
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, key, h)
   if (unit >= total) return;
@@ -1621,8 +1640,8 @@ int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D) {
 }
 
 int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
-                int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0, int dropout_h_total,
-                anemoi_stream_t stream) {
+                int H, int D, int window, float dropout_p, uint32_t dropout_seed, const void* dropout_seed_dev,
+                int dropout_h0, int dropout_h_total, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out, ANEMOI_ERR_INVALID, "anemoi_mhsa: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa: bad shape");
   const int C = H * D;
@@ -1633,7 +1652,10 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
                  (double)dropout_p);
   ANEMOI_REQUIRE(dropout_h0 >= 0 && (dropout_h_total == 0 || dropout_h0 + H <= dropout_h_total), ANEMOI_ERR_INVALID,
                  "anemoi_mhsa: heads %d .. %d of %d", dropout_h0, dropout_h0 + H, dropout_h_total);
-  const AttnDropout dr = make_dropout(dropout_p, dropout_seed, dropout_h0, dropout_h_total > 0 ? dropout_h_total : H);
+  ANEMOI_REQUIRE(dropout_seed_dev == nullptr || (uintptr_t)dropout_seed_dev % 4 == 0, ANEMOI_ERR_INVALID,
+                 "anemoi_mhsa: dropout_seed_dev must be 4-byte aligned");
+  const AttnDropout dr = make_dropout(dropout_p, dropout_seed, dropout_h0, dropout_h_total > 0 ? dropout_h_total : H,
+                                      dropout_seed_dev);
   // MFMA route, with or without dropout (the mask is applied to the packed probabilities; the kernels hash 32-bit row
   // indices: B x heads x S < 2^32, and p = 1 -- everything dropped -- stays on the generic kernel)
   const bool drop = dr.thr16 != 0;
@@ -1739,8 +1761,8 @@ int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int
 
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
                          int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, void* workspace, int B,
-                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0,
-                         int dropout_h_total, anemoi_stream_t stream) {
+                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed,
+                         const void* dropout_seed_dev, int dropout_h0, int dropout_h_total, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(qkv && out && dout && lse && delta && dqkv, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: null pointer");
   ANEMOI_REQUIRE(B > 0 && S > 0 && H > 0 && D > 0, ANEMOI_ERR_INVALID, "anemoi_mhsa_backward: bad shape");
   const int C = H * D;
@@ -1751,7 +1773,10 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
                  (double)dropout_p);
   ANEMOI_REQUIRE(dropout_h0 >= 0 && (dropout_h_total == 0 || dropout_h0 + H <= dropout_h_total), ANEMOI_ERR_INVALID,
                  "anemoi_mhsa_backward: heads %d .. %d of %d", dropout_h0, dropout_h0 + H, dropout_h_total);
-  const AttnDropout dr = make_dropout(dropout_p, dropout_seed, dropout_h0, dropout_h_total > 0 ? dropout_h_total : H);
+  ANEMOI_REQUIRE(dropout_seed_dev == nullptr || (uintptr_t)dropout_seed_dev % 4 == 0, ANEMOI_ERR_INVALID,
+                 "anemoi_mhsa: dropout_seed_dev must be 4-byte aligned");
+  const AttnDropout dr = make_dropout(dropout_p, dropout_seed, dropout_h0, dropout_h_total > 0 ? dropout_h_total : H,
+                                      dropout_seed_dev);
   const bool drop = dr.thr16 != 0;
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)D);

@@ -43,19 +43,37 @@ class MultiHeadSelfAttention(nn.Module):
             return int(self.window_size[0])
         return -1
 
-    def dropout(self):
-        """``(dropout_p, seed)`` of this call: the reference drops attention probabilities in training mode only
-        (layers/attention.py:90); the seed comes from torch's CPU generator (``torch.manual_seed`` reproduces the mask)."""
-        import torch
-
+    def dropout(self, model_comm_group=None):
+        """``(dropout_p, seed, seed_dev)`` of this call: the reference drops attention probabilities in training mode only
+        (layers/attention.py:90).  Eagerly the seed is drawn per call from torch's CPU generator (``torch.manual_seed``
+        reproduces the mask) and ``seed_dev`` is ``None``; inside a ``runtime.DeviceDropout`` context the seed is a
+        per-module constant (drawn once, the same way) and the step's device word goes with it -- capturable in a HIP graph.
+        With a model group every rank must use ONE seed: rank 0's draw is broadcast -- per call eagerly, once per module
+        under ``DeviceDropout`` (the step counters of the ranks advance in lockstep)."""
         if not self.training or self.dropout_p <= 0.0:
-            return 0.0, 0
-        return float(self.dropout_p), int(torch.randint(0, 2**31 - 1, (1,)).item())
+            return 0.0, 0, None
+        dd = runtime.device_dropout()
+        if dd is not None and self.__dict__.get("_layer_seed") is not None:
+            return float(self.dropout_p), self.__dict__["_layer_seed"], dd.word
+        seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+        if model_comm_group is not None and model_comm_group.size() > 1:
+            import torch.distributed as dist
+
+            seed_t = torch.tensor([seed], dtype=torch.int64)
+            if dist.get_backend(model_comm_group) == "nccl":
+                seed_t = seed_t.to(self.lin_qkv.weight.device)
+            dist.broadcast(seed_t, dist.get_global_rank(model_comm_group, 0), group=model_comm_group)
+            seed = int(seed_t.item())
+        if dd is None:
+            return float(self.dropout_p), seed, None
+        self.__dict__["_layer_seed"] = seed
+        return float(self.dropout_p), seed, dd.word
 
     def native(self, x: Tensor, batch_size: int) -> Tensor:
         qkv = linear_native(self._packed, "lin_qkv", self.lin_qkv, x)  # [B*S, 3C] = q | k | v
-        p, seed = self.dropout()
-        att = ops.mhsa(qkv, batch_size, self.num_heads, self.attention_window(), dropout_p=p, dropout_seed=seed)
+        p, seed, seed_dev = self.dropout()
+        att = ops.mhsa(qkv, batch_size, self.num_heads, self.attention_window(), dropout_p=p, dropout_seed=seed,
+                       seed_dev=seed_dev)
         return linear_native(self._packed, "projection", self.projection, att)
 
     def _sharded(self, x: Tensor, shapes: list, model_comm_group) -> Tensor:
@@ -82,24 +100,17 @@ class MultiHeadSelfAttention(nn.Module):
         fused = torch.stack([t[0].permute(1, 0, 2) for t in (q, k, v)], dim=1).reshape(n_all, 3 * h_loc * d).contiguous()
         # attention dropout across the group: ONE seed (rank 0's draw, broadcast) and the global head index in the mask's
         # hash, so the ranks together drop exactly what the unsharded attention would with that seed
-        p, seed = self.dropout()
+        p, seed, seed_dev = self.dropout(model_comm_group)
         h0 = 0
         if p > 0.0:
-            import torch.distributed as dist
-
             from ..distributed.shapes import split_bounds
 
-            seed_t = torch.tensor([seed], dtype=torch.int64)
-            if dist.get_backend(model_comm_group) == "nccl":
-                seed_t = seed_t.to(x.device)
-            dist.broadcast(seed_t, dist.get_global_rank(model_comm_group, 0), group=model_comm_group)
-            seed = int(seed_t.item())
             h0 = split_bounds(h, model_comm_group.size())[model_comm_group.rank()]
         if grad:
-            att = autograd.mhsa(fused, 1, h_loc, self.attention_window(), p, seed, h0, h)
+            att = autograd.mhsa(fused, 1, h_loc, self.attention_window(), p, seed, h0, h, seed_dev)
         else:
             att = ops.mhsa(fused, 1, h_loc, self.attention_window(), dropout_p=p, dropout_seed=seed, head_offset=h0,
-                           heads_total=h)
+                           heads_total=h, seed_dev=seed_dev)
         att = att.view(n_all, h_loc, d).permute(1, 0, 2).unsqueeze(0)  # (1, H_local, N, D)
         att = shard_sequence(att, shapes=shapes, mgroup=model_comm_group)  # (1, H, n_local, D)
         att = att[0].permute(1, 0, 2).reshape(n_local, h * d).contiguous()
@@ -116,8 +127,8 @@ class MultiHeadSelfAttention(nn.Module):
         if training.wants_grad(self, x):  # reference layers/attention.py:67-112 with an autograd graph
             xin = training._cast(x, runtime.compute_dtype(x))
             qkv = autograd.linear(xin, self.lin_qkv.weight, self.lin_qkv.bias)
-            p, seed = self.dropout()
-            att = autograd.mhsa(qkv, batch_size, self.num_heads, self.attention_window(), p, seed)
+            p, seed, seed_dev = self.dropout()
+            att = autograd.mhsa(qkv, batch_size, self.num_heads, self.attention_window(), p, seed, seed_dev=seed_dev)
             return autograd.linear(att, self.projection.weight, self.projection.bias)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)

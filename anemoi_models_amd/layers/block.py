@@ -873,7 +873,7 @@ class TransformerProcessorBlock(BaseBlock):
         h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
         att = self.attention
         qkv = linear_native(att._packed, "lin_qkv", att.lin_qkv, h)
-        drop_p, drop_seed = att.dropout()
+        drop_p, drop_seed, drop_dev = att.dropout()
         if head_exchange is not None:
             if drop_p > 0.0:
                 raise NotImplementedError("attention dropout in the node-partitioned forward (the ranks would need one "
@@ -887,7 +887,8 @@ class TransformerProcessorBlock(BaseBlock):
                 a_heads = a_heads.index_select(0, head_exchange.to_internal)
             a = head_exchange.heads_to_rows(a_heads, att.num_heads)  # [n_own, C]
         else:
-            a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window(), dropout_p=drop_p, dropout_seed=drop_seed)
+            a = ops.mhsa(qkv, batch_size, att.num_heads, att.attention_window(), dropout_p=drop_p, dropout_seed=drop_seed,
+                         seed_dev=drop_dev)
         x = linear_native(att._packed, "projection", att.projection, a, residual=x)  # x + attention(...)
         if self._mlp is None:
             self._mlp = NativeSequential(self.mlp)

@@ -381,14 +381,24 @@ def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None) -> Tens
     return out
 
 
+def _seed_dev_ptr(seed_dev: Optional[Tensor], like: Tensor):
+    if seed_dev is None:
+        return None
+    if not seed_dev.is_cuda or seed_dev.device != like.device or seed_dev.numel() < 1 or seed_dev.element_size() < 4:
+        raise ValueError("dropout seed_dev must be an integer tensor (>= 32 bits per element) on the input's device")
+    return seed_dev.data_ptr()
+
+
 def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Optional[Tensor] = None,
          return_lse: bool = False, dropout_p: float = 0.0, dropout_seed: int = 0, head_offset: int = 0,
-         heads_total: int = 0):
+         heads_total: int = 0, seed_dev: Optional[Tensor] = None):
     """Multi-head self attention on the fused ``lin_qkv`` output ``[B*S, 3C]`` -> ``[B*S, C]`` (heads concatenated).
     ``return_lse``: also the f32 ``[B, H, S]`` log-sum-exp of the scaled scores (the backward's input).
     ``dropout_p`` / ``dropout_seed``: attention dropout (training mode of the reference), mask = hash(index, seed);
     ``head_offset`` / ``heads_total``: this call holds the heads ``head_offset ... + num_heads`` of ``heads_total`` (a head
-    shard of a model group draws the mask of the unsharded attention; 0 = all heads)."""
+    shard of a model group draws the mask of the unsharded attention; 0 = all heads).  ``seed_dev``: a device integer
+    whose low 32 bits the kernels add to ``dropout_seed`` when they run (``runtime.DeviceDropout``: the part of the seed a
+    captured HIP graph advances between replays)."""
     _dev(qkv, out)
     rows, c3 = _rows(qkv).shape
     c = c3 // 3
@@ -404,14 +414,14 @@ def mhsa(qkv: Tensor, batch_size: int, num_heads: int, window: int = -1, out: Op
     with _Timed("mhsa", flops=4 * batch_size * num_heads * s_len * s_len * d, s=s_len, h=num_heads, d=d):
         st = lib.anemoi_mhsa(code, qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)), _ptr(ws), _ptr(lse),
                              batch_size, s_len, num_heads, d, window, float(dropout_p), int(dropout_seed) & 0xFFFFFFFF,
-                             int(head_offset), int(heads_total), _stream())
+                             _seed_dev_ptr(seed_dev, qkv), int(head_offset), int(heads_total), _stream())
     _lib.check(st, "anemoi_mhsa")
     return (out, lse) if return_lse else out
 
 
 def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_size: int, num_heads: int,
                   window: int = -1, dropout_p: float = 0.0, dropout_seed: int = 0, head_offset: int = 0,
-                  heads_total: int = 0, use_mfma: bool = True) -> Tensor:
+                  heads_total: int = 0, use_mfma: bool = True, seed_dev: Optional[Tensor] = None) -> Tensor:
     """``d qkv`` ``[B*S, 3C]`` of :func:`mhsa` from the forward's output and log-sum-exp (``anemoi_mhsa_backward``).
     ``use_mfma=False`` withholds the workspace: the call then takes the VALU kernels (plain HIP, any head size / dtype) --
     the yardstick the MFMA route's hand-scheduled kernels are held against in the tests."""
@@ -429,7 +439,8 @@ def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_siz
     st = lib.anemoi_mhsa_backward(dtype_code(qkv.dtype), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(_rows(out)),
                                   dout.data_ptr(), _ld(_rows(dout)), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), c3,
                                   _ptr(ws), batch_size, s_len, num_heads, c // num_heads, window, float(dropout_p),
-                                  int(dropout_seed) & 0xFFFFFFFF, int(head_offset), int(heads_total), _stream())
+                                  int(dropout_seed) & 0xFFFFFFFF, _seed_dev_ptr(seed_dev, qkv), int(head_offset),
+                                  int(heads_total), _stream())
     _lib.check(st, "anemoi_mhsa_backward")
     return dqkv
 

@@ -448,6 +448,44 @@ class GraphedForward:
         return self.static_y
 
 
+class DeviceDropout:
+    """Attention-dropout seeds whose per-step part lives in DEVICE memory (reference ``layers/attention.py:90``: dropout of the
+    attention probabilities in training mode, ``TransformerProcessor``'s default ``dropout_p = 0.1``).
+
+    Eagerly every attention call draws its seed on the host (torch's CPU generator) and passes it as a kernel argument.  A
+    training step captured in a HIP graph replays its kernel arguments, so the mask would repeat.  Inside this context the
+    seed of a call is ``layer constant (host, drawn once per module) + word`` with ``word = step counter x odd constant``
+    read by the kernels from device memory (``anemoi_mhsa``'s ``dropout_seed_dev``); :meth:`advance` -- two one-element
+    kernels, capturable -- moves to the next step's masks.  ``GraphedTrainStep`` opens one for a model with dropout and
+    makes ``advance`` the first captured operation; the same context around an eager loop (``advance()`` once per step)
+    draws bit-identical masks, which is how the graphed step is tested against the eager one.
+
+    A step's ``word`` is a tensor of its own (not updated in place), and the autograd node keeps the one its forward saw:
+    a backward that runs after a later ``advance`` still rebuilds its own mask."""
+
+    _active = None
+
+    def __init__(self, device, start: int = 0) -> None:
+        self.counter = torch.full((1,), int(start), dtype=torch.int64, device=device)
+        self.word = self.counter * 0x9E3779B1
+
+    def advance(self) -> None:
+        self.counter.add_(1)
+        self.word = self.counter * 0x9E3779B1  # (int64 arithmetic; the kernels read the low 32 bits)
+
+    def __enter__(self) -> "DeviceDropout":
+        self._outer, DeviceDropout._active = DeviceDropout._active, self
+        return self
+
+    def __exit__(self, *exc) -> None:
+        DeviceDropout._active = self._outer
+
+
+def device_dropout() -> Optional[DeviceDropout]:
+    """The :class:`DeviceDropout` context the caller runs in, or ``None`` (host-drawn seeds)."""
+    return DeviceDropout._active
+
+
 class GraphedTrainStep:
     """One TRAINING step -- forward, loss, backward, optionally the optimizer step -- captured in a HIP graph and replayed.
 
@@ -465,47 +503,69 @@ class GraphedTrainStep:
     accumulators bound to the stream it ran on, the captured backward then touches that stream and the HIP runtime
     aborts the capture (observed as a crash in ``capture_end``).
 
-    Attention dropout (``dropout_p > 0`` of the Transformer processor in training mode) is refused: the mask's seed is a
-    host-side draw that becomes a kernel argument, so every replay would repeat the mask of the capture step.
+    Attention dropout (``dropout_p > 0`` of the Transformer processor in training mode -- the reference's constructor
+    default is 0.1, ``layers/processor.py:99``): the captured step runs inside a :class:`DeviceDropout` context
+    (``self.dropout``) whose ``advance()`` is the first captured operation, so every replay draws new masks from the step
+    counter in device memory; ``self.dropout.counter`` may be read or set between replays (reproducibility, resume).
+
+    Side effects worth knowing: the ``warmup`` eager steps are REAL steps on ``example_x`` -- with an ``optimizer`` they
+    update the parameters and the optimizer state (torch's capture recipe needs the optimizer's state initialised; pass
+    ``warmup=1`` and a throw-away batch, or snapshot ``state_dict()`` around the constructor, if that matters).  The model's
+    training / dropout configuration is frozen at capture: ``__call__`` refuses a model whose ``training`` flag or dropout
+    rates have changed since.  The returned loss is a copy; ``static_y`` / ``static_loss`` alias graph memory the next
+    replay overwrites.
     """
 
     def __init__(self, model, loss_fn, example_x: Tensor, example_target: Tensor, optimizer=None, warmup: int = 3) -> None:
         if not example_x.is_cuda:
             raise ValueError("GraphedTrainStep: the example input must live on the GPU")
-        if model.training and any(float(getattr(m, "dropout_p", 0.0) or 0.0) > 0.0 for m in model.modules()):
-            raise ValueError("GraphedTrainStep: attention dropout draws its seed on the host; a replayed graph would repeat "
-                             "one dropout mask every step -- train eagerly or set dropout_p = 0")
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.static_x, self.static_target = example_x.clone(), example_target.clone()
+        self._config = self._dropout_config()
+        self.dropout = DeviceDropout(example_x.device) if model.training and any(p > 0.0 for p in self._config[1]) else None
         params = [p for p in model.parameters() if p.requires_grad]
 
         def zero():
             for p in params:
                 p.grad = None
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                zero()
-                loss_fn(model(self.static_x), self.static_target).backward()
-                if optimizer is not None:
-                    optimizer.step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        zero()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_y = model(self.static_x)
-            self.static_loss = loss_fn(self.static_y, self.static_target)
-            self.static_loss.backward()
+        def step(capturing: bool):
+            if self.dropout is not None:
+                self.dropout.advance()
+            y = model(self.static_x)
+            loss = loss_fn(y, self.static_target)
+            loss.backward()
             if optimizer is not None:
                 optimizer.step()
+            if capturing:
+                self.static_y, self.static_loss = y, loss
+
+        import contextlib
+
+        with self.dropout if self.dropout is not None else contextlib.nullcontext():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    zero()
+                    step(False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            zero()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                step(True)
+
+    def _dropout_config(self):
+        return bool(self.model.training), tuple(float(getattr(m, "dropout_p", 0.0) or 0.0) for m in self.model.modules())
 
     def __call__(self, x: Tensor, target: Tensor) -> Tensor:
         if x.shape != self.static_x.shape or target.shape != self.static_target.shape:
             raise ValueError("GraphedTrainStep: input / target shape differs from the captured one")
+        if self._dropout_config() != self._config:
+            raise RuntimeError("GraphedTrainStep: the model's training flag or dropout rates changed after the capture; "
+                               "the graph still runs the captured configuration -- build a new GraphedTrainStep")
         self.static_x.copy_(x)
         self.static_target.copy_(target)
         self.graph.replay()
-        return self.static_loss
+        return self.static_loss.detach().clone()

@@ -342,8 +342,8 @@ def transformer_block(block, x: Tensor, batch_size: int) -> Tensor:
     x = _cast(x, dtype)
     h = autograd.layer_norm(x, block.layer_norm1.weight, block.layer_norm1.bias, block.layer_norm1.eps)
     qkv = autograd.linear(h, att.lin_qkv.weight, att.lin_qkv.bias)
-    p, seed = att.dropout()  # attention dropout in training mode (reference layers/attention.py:90)
-    a = autograd.mhsa(qkv, batch_size, att.num_heads, att.attention_window(), p, seed)
+    p, seed, seed_dev = att.dropout()  # attention dropout in training mode (reference layers/attention.py:90)
+    a = autograd.mhsa(qkv, batch_size, att.num_heads, att.attention_window(), p, seed, seed_dev=seed_dev)
     x = autograd.linear(a, att.projection.weight, att.projection.bias, "Identity", x)
     h = autograd.layer_norm(x, block.layer_norm2.weight, block.layer_norm2.bias, block.layer_norm2.eps)
     return sequential(block.mlp, h, residual=x)

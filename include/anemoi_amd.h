@@ -289,11 +289,15 @@ int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* row
  * probabilities (0 < p < 1, B x heads x S < 2^32); p = 1 takes the VALU kernel.  `dropout_h0` / `dropout_h_total`: the
  * GLOBAL index of head 0 of this call and the head count of the whole attention (0 = H) -- a head-sharded call
  * (sequence-parallel attention, distributed/transformer.py:85-130) then draws exactly the mask of the unsharded one.
+ * `dropout_seed_dev` (may be NULL): a 4-byte aligned DEVICE word whose value every kernel of the call adds to
+ * `dropout_seed` when it starts -- the part of the seed a captured HIP graph can advance between replays (kernel arguments
+ * are frozen at capture; anemoi_models_amd/runtime.py::DeviceDropout).  The backward must be given the same word, holding
+ * the value the forward saw.
  */
 int64_t anemoi_mhsa_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, void* workspace, float* lse, int B, int S,
-                int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0, int dropout_h_total,
-                anemoi_stream_t stream);
+                int H, int D, int window, float dropout_p, uint32_t dropout_seed, const void* dropout_seed_dev,
+                int dropout_h0, int dropout_h_total, anemoi_stream_t stream);
 
 /*
  * Backward of anemoi_mhsa (what torch autograd derives for the reference's scaled_dot_product_attention call,
@@ -308,8 +312,8 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
 int64_t anemoi_mhsa_backward_workspace_bytes(int dtype, int B, int S, int H, int D);
 int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
                          int64_t lddo, const float* lse, float* delta, void* dqkv, int64_t lddq, void* workspace, int B,
-                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed, int dropout_h0,
-                         int dropout_h_total, anemoi_stream_t stream);
+                         int S, int H, int D, int window, float dropout_p, uint32_t dropout_seed,
+                         const void* dropout_seed_dev, int dropout_h0, int dropout_h_total, anemoi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Backward pass, dense half (first step): the pieces the autograd of the fused Linear and of

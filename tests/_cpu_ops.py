@@ -144,7 +144,7 @@ def segment_sum(v, rowptr, out=None):
 
 
 def mhsa(qkv, batch_size, num_heads, window=-1, out=None, return_lse=False, dropout_p=0.0, dropout_seed=0, head_offset=0,
-         heads_total=None):
+         heads_total=None, seed_dev=None):
     assert dropout_p == 0.0, "the CPU stand-in has no attention dropout"
     rows, c3 = qkv.shape
     c = c3 // 3

@@ -177,21 +177,54 @@ def test_checkpointing_reproduces_the_gradients_bit_for_bit(graph_o32, golden_cf
     assert res["1"][2] < 0.6 * res["0"][2], (res["1"][2], res["0"][2])
 
 
-def test_graphed_train_step_refuses_attention_dropout(graph_o32):
-    """A captured step would replay ONE dropout mask (the seed is a host-side draw baked into the launch): refused loudly."""
+@pytest.mark.parametrize("checkpoint", ["1", "0"])
+def test_graphed_train_step_with_attention_dropout_equals_eager(graph_o32, monkeypatch, checkpoint):
+    """``TransformerProcessor``'s default attention dropout (reference layers/processor.py:99: 0.1) inside a captured step:
+    the per-step part of the mask seed is a counter in DEVICE memory the graph itself advances (runtime.DeviceDropout), so
+    replays draw new masks -- and an eager loop in the same context, started at the same counter value, draws the same
+    ones: loss and every parameter gradient bit for bit, over three steps, with and without activation checkpointing (the
+    recomputed forward must rebuild the step's mask, not the next one)."""
     from test_gpu_parity import _build
 
-    from anemoi_models_amd.runtime import GraphedTrainStep
+    from anemoi_models_amd.runtime import DeviceDropout, GraphedTrainStep
 
+    monkeypatch.setenv("ANEMOI_AMD_CHECKPOINT", checkpoint)
+    torch.manual_seed(5)
     model, idx = _build(graph_o32, 64, 2, processor="Transformer")
     model = model.to(DEV).train()
     for m in model.modules():
         if hasattr(m, "dropout_p"):
             m.dropout_p = 0.1
-    x = torch.randn(1, 2, 1, graph_o32["data"].num_nodes, idx.num_input, device=DEV)
-    t = torch.zeros(1, 1, graph_o32["data"].num_nodes, model.num_output_channels, device=DEV)
-    with pytest.raises(ValueError, match="dropout"):
-        GraphedTrainStep(model, lambda y, tt: ((y - tt) ** 2).mean(), x, t)
+    n = graph_o32["data"].num_nodes
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(1, 2, 1, n, idx.num_input, generator=g).to(DEV) for _ in range(3)]
+    ts = [torch.randn(1, 1, n, model.num_output_channels, generator=g).to(DEV) for _ in range(3)]
+    loss_fn = lambda y, tt: ((y - tt) ** 2).mean()  # noqa: E731
+    step = GraphedTrainStep(model, loss_fn, xs[0], ts[0])
+    assert step.dropout is not None
+    params = [p for p in model.parameters() if p.requires_grad]
+    step.dropout.counter.fill_(100)
+    graphed = []
+    for x, t in zip(xs, ts):
+        loss = step(x, t)
+        graphed.append((loss.clone(), [p.grad.clone() for p in params]))
+    assert int(step.dropout.counter.item()) == 103
+    assert not torch.equal(graphed[0][0], step(xs[0], ts[0]))  # the same batch again: another mask
+    # the eager loop: same modules (same per-layer seed constants), same counter start
+    with DeviceDropout(DEV, start=100) as dd:
+        for (x, t), (g_loss, g_grads) in zip(zip(xs, ts), graphed):
+            for p in params:
+                p.grad = None
+            dd.advance()
+            loss = loss_fn(model(x), t)
+            loss.backward()
+            assert torch.equal(loss.detach(), g_loss)
+            for p, gg in zip(params, g_grads):
+                assert torch.equal(p.grad, gg)
+    # the frozen configuration is checked at every call
+    model.eval()
+    with pytest.raises(RuntimeError, match="changed after the capture"):
+        step(xs[0], ts[0])
 
 
 @pytest.mark.parametrize("checkpoint", ["1", "0"])
