@@ -57,6 +57,25 @@ class GtBlockArgs(ctypes.Structure):
         ("stats_ws", c_void_p), ("stats_ws_bytes", c_int64),
     ]
 
+class TfmBlockArgs(ctypes.Structure):
+    """``anemoi_tfm_block_args`` of include/anemoi_amd.h (``anemoi_transformer_block_forward``), field for field."""
+
+    _fields_ = [
+        ("struct_bytes", c_int64), ("rows", c_int64),
+        ("dtype", ctypes.c_int32), ("B", ctypes.c_int32), ("S", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("hidden", ctypes.c_int32), ("act", ctypes.c_int32), ("window", ctypes.c_int32),
+        ("eps1", c_float), ("eps2", c_float),
+        ("dropout_p", c_float), ("dropout_seed", c_uint32), ("dropout_seed_dev", c_void_p),
+        ("dropout_h0", ctypes.c_int32), ("dropout_h_total", ctypes.c_int32),
+        ("x", c_void_p), ("ldx", c_int64),
+        ("ln1_w", c_void_p), ("ln1_b", c_void_p), ("ln2_w", c_void_p), ("ln2_b", c_void_p),
+        ("w_qkv", c_void_p), ("b_qkv", c_void_p), ("w_proj", c_void_p), ("b_proj", c_void_p),
+        ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("w_fc2", c_void_p), ("b_fc2", c_void_p),
+        ("h_ln", c_void_p), ("qkv", c_void_p), ("att", c_void_p), ("y", c_void_p), ("h", c_void_p),
+        ("mhsa_ws", c_void_p), ("out", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/anemoi_amd.h (checked by tests/test_abi.py)
 SIGNATURES = {
     "anemoi_abi_version": (c_int, []),
@@ -150,6 +169,7 @@ SIGNATURES = {
     "anemoi_add": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "anemoi_gt_block_tail": (c_int, [ctypes.POINTER(GtBlockArgs), c_void_p]),
     "anemoi_gt_processor_block_forward": (c_int, [ctypes.POINTER(GtBlockArgs), c_void_p]),
+    "anemoi_transformer_block_forward": (c_int, [ctypes.POINTER(TfmBlockArgs), c_void_p]),
 }
 
 _lib = None

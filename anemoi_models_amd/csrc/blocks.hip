@@ -90,3 +90,40 @@ extern "C" int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* arg
   a.ld_res = args->ldx;
   return run_tail(&a, stream);
 }
+
+extern "C" int anemoi_transformer_block_forward(const anemoi_tfm_block_args* a, anemoi_stream_t stream) {
+  const char* who = "anemoi_transformer_block_forward";
+  ANEMOI_REQUIRE(a != nullptr, ANEMOI_ERR_INVALID, "%s: null argument block", who);
+  ANEMOI_REQUIRE(a->struct_bytes == (int64_t)sizeof(anemoi_tfm_block_args), ANEMOI_ERR_INVALID,
+                 "%s: argument block of %lld bytes, this library expects %lld (header / binding out of sync)", who,
+                 (long long)a->struct_bytes, (long long)sizeof(anemoi_tfm_block_args));
+  ANEMOI_REQUIRE(a->dtype == ANEMOI_F32 || a->dtype == ANEMOI_BF16, ANEMOI_ERR_UNSUPPORTED, "%s: dtype %d", who, a->dtype);
+  ANEMOI_REQUIRE(a->rows >= 0 && a->B > 0 && a->S >= 0 && a->rows == (int64_t)a->B * a->S && a->C > 0 && a->H > 0 &&
+                     a->C % a->H == 0 && a->hidden > 0,
+                 ANEMOI_ERR_INVALID, "%s: bad shape (rows %lld, B %d, S %d, C %d, H %d, hidden %d)", who, (long long)a->rows,
+                 a->B, a->S, a->C, a->H, a->hidden);
+  ANEMOI_REQUIRE(a->x && a->ln1_w && a->ln1_b && a->ln2_w && a->ln2_b && a->w_qkv && a->w_proj && a->w_fc1 && a->w_fc2 &&
+                     a->h_ln && a->qkv && a->att && a->y && a->h && a->out,
+                 ANEMOI_ERR_INVALID, "%s: null pointer", who);
+  ANEMOI_REQUIRE(a->ldx >= a->C && a->out != a->x, ANEMOI_ERR_INVALID, "%s: ldx too small, or out aliases x", who);
+  if (a->rows == 0) return ANEMOI_OK;
+  const int C = a->C;
+  int st = anemoi_layer_norm(a->dtype, a->x, a->ldx, a->ln1_w, a->ln1_b, a->h_ln, C, a->rows, C, a->eps1, stream);
+  if (st != ANEMOI_OK) return st;
+  st = anemoi_linear(a->dtype, a->dtype, a->h_ln, C, a->w_qkv, a->b_qkv, nullptr, 0, a->qkv, 3 * (int64_t)C, a->rows, 3 * C, C,
+                     ANEMOI_ACT_NONE, stream);
+  if (st != ANEMOI_OK) return st;
+  st = anemoi_mhsa(a->dtype, a->qkv, 3 * (int64_t)C, a->att, C, a->mhsa_ws, nullptr, a->B, a->S, a->H, C / a->H, a->window,
+                   a->dropout_p, a->dropout_seed, a->dropout_seed_dev, a->dropout_h0, a->dropout_h_total, stream);
+  if (st != ANEMOI_OK) return st;
+  st = anemoi_linear(a->dtype, a->dtype, a->att, C, a->w_proj, a->b_proj, a->x, a->ldx, a->y, C, a->rows, C, C, ANEMOI_ACT_NONE,
+                     stream);  // x + attention(...)
+  if (st != ANEMOI_OK) return st;
+  st = anemoi_layer_norm(a->dtype, a->y, C, a->ln2_w, a->ln2_b, a->h_ln, C, a->rows, C, a->eps2, stream);
+  if (st != ANEMOI_OK) return st;
+  st = anemoi_linear(a->dtype, a->dtype, a->h_ln, C, a->w_fc1, a->b_fc1, nullptr, 0, a->h, a->hidden, a->rows, a->hidden, C,
+                     a->act, stream);
+  if (st != ANEMOI_OK) return st;
+  return anemoi_linear(a->dtype, a->dtype, a->h, a->hidden, a->w_fc2, a->b_fc2, a->y, C, a->out, C, a->rows, C, a->hidden,
+                       ANEMOI_ACT_NONE, stream);  // y + mlp(...)
+}

@@ -870,8 +870,12 @@ class TransformerProcessorBlock(BaseBlock):
         ALL rows of its share of the heads, attention runs on those heads, and a second all-to-all brings the own rows
         of all heads back."""
         ln1, ln2 = self.layer_norm1, self.layer_norm2
-        h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
         att = self.attention
+        if head_exchange is None:
+            done = self._block_abi(x, batch_size)
+            if done is not None:
+                return done
+        h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
         qkv = linear_native(att._packed, "lin_qkv", att.lin_qkv, h)
         drop_p, drop_seed, drop_dev = att.dropout()
         if head_exchange is not None:
@@ -894,6 +898,66 @@ class TransformerProcessorBlock(BaseBlock):
             self._mlp = NativeSequential(self.mlp)
         h = ops.layer_norm(x, runtime.f32c(ln2.weight), runtime.f32c(ln2.bias), ln2.eps)
         return self._mlp(h, residual=x)
+
+    block_abi = True  # False: op by op (tests compare the two routes)
+
+    def _block_abi(self, x: Tensor, batch_size: int) -> Optional[Tensor]:
+        """The whole block as ONE call of ``anemoi_transformer_block_forward`` (the launches and packed weights of the
+        op-by-op route below; bit-identical), f32 or bf16 -- or ``None`` when this call has to go op by op (bench.py's
+        per-kernel timing pass, channel widths that need K padding, an MLP of another shape)."""
+        import ctypes
+
+        from .. import _lib
+
+        dtype, att = x.dtype, self.attention
+        c, rows = x.shape[1], x.shape[0]
+        mult = ops.k_multiple(dtype)
+        if (not self.block_abi or ops.PROFILE is not None or not x.is_cuda or rows == 0 or x.stride(1) != 1
+                or c != att.embed_dim or c % mult != 0 or rows % batch_size != 0):
+            return None
+        if self._mlp is None:
+            self._mlp = NativeSequential(self.mlp)
+        steps = self._mlp.steps
+        if [k for k, _, _ in steps] != ["linear", "linear"] or steps[0][2] not in _lib.ACT_CODES or steps[1][2] != "Identity":
+            return None
+        fc1, fc2 = steps[0][1], steps[1][1]
+        hidden = fc1.out_features
+        if hidden % mult != 0 or fc1.in_features != c or fc2.out_features != c:
+            return None
+
+        def packed(cache, tag, lin):
+            w = cache.get((tag, "w", dtype), [lin.weight], lambda: runtime.pack_weight([lin.weight], dtype))
+            return w, (None if lin.bias is None else runtime.f32c(lin.bias))
+
+        w_qkv, b_qkv = packed(att._packed, "lin_qkv", att.lin_qkv)
+        w_proj, b_proj = packed(att._packed, "projection", att.projection)
+        w1 = self._mlp.cache.get(("w", 0, dtype), [fc1.weight], lambda: runtime.pack_weight([fc1.weight], dtype))
+        w2 = self._mlp.cache.get(("w", 1, dtype), [fc2.weight], lambda: runtime.pack_weight([fc2.weight], dtype))
+        b1 = None if fc1.bias is None else runtime.f32c(fc1.bias)
+        b2 = None if fc2.bias is None else runtime.f32c(fc2.bias)
+        ln1, ln2 = self.layer_norm1, self.layer_norm2
+        p, seed, seed_dev = att.dropout()
+        new = lambda *shape: torch.empty(shape, dtype=dtype, device=x.device)  # noqa: E731
+        h_ln, qkv, a_out, y, hid, out = new(rows, c), new(rows, 3 * c), new(rows, c), new(rows, c), new(rows, hidden), new(rows, c)
+        lib = _lib.load()
+        s_len, heads = rows // batch_size, att.num_heads
+        ws_bytes = lib.anemoi_mhsa_workspace_bytes(ops.dtype_code(dtype), batch_size, s_len, heads, c // heads)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
+        keep = [runtime.f32c(t) for t in (ln1.weight, ln1.bias, ln2.weight, ln2.bias)]
+        a = _lib.TfmBlockArgs()
+        a.struct_bytes, a.rows, a.dtype = ctypes.sizeof(_lib.TfmBlockArgs), rows, ops.dtype_code(dtype)
+        a.B, a.S, a.C, a.H, a.hidden, a.act = batch_size, s_len, c, heads, hidden, _lib.ACT_CODES[steps[0][2]]
+        a.window, a.eps1, a.eps2 = att.attention_window(), ln1.eps, ln2.eps
+        a.dropout_p, a.dropout_seed, a.dropout_seed_dev = float(p), int(seed) & 0xFFFFFFFF, ops._seed_dev_ptr(seed_dev, x)
+        a.dropout_h0, a.dropout_h_total = 0, 0
+        a.x, a.ldx = x.data_ptr(), ops._ld(x)
+        a.ln1_w, a.ln1_b, a.ln2_w, a.ln2_b = (t.data_ptr() for t in keep)
+        a.w_qkv, a.b_qkv, a.w_proj, a.b_proj = w_qkv.data_ptr(), ops._ptr(b_qkv), w_proj.data_ptr(), ops._ptr(b_proj)
+        a.w_fc1, a.b_fc1, a.w_fc2, a.b_fc2 = w1.data_ptr(), ops._ptr(b1), w2.data_ptr(), ops._ptr(b2)
+        a.h_ln, a.qkv, a.att, a.y, a.h = h_ln.data_ptr(), qkv.data_ptr(), a_out.data_ptr(), y.data_ptr(), hid.data_ptr()
+        a.mhsa_ws, a.out = ops._ptr(ws), out.data_ptr()
+        _lib.check(lib.anemoi_transformer_block_forward(ctypes.byref(a), ops._stream()), "anemoi_transformer_block_forward")
+        return out
 
     def _sharded(self, x: Tensor, shapes: list, batch_size: int, model_comm_group) -> Tensor:
         """Sequence-sharded call as in the reference (layers/block.py:99-105 with a model group): everything but the

@@ -486,6 +486,42 @@ typedef struct anemoi_gt_block_args {
 int anemoi_gt_block_tail(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 
+/*
+ * anemoi_transformer_block_forward: TransformerProcessorBlock.forward (reference layers/block.py:99-105 over
+ * layers/attention.py:67-112) from one call, f32 or bf16 --
+ *     y   = x + projection(attention(lin_qkv(layer_norm1(x))))
+ *     out = y + mlp(layer_norm2(y)),    mlp = Linear -> activation -> Linear
+ * as the launch sequence anemoi_layer_norm, anemoi_linear, anemoi_mhsa, anemoi_linear (+ x), anemoi_layer_norm,
+ * anemoi_linear (+ activation), anemoi_linear (+ y) on the caller's stream.  Weights [out, K] in `dtype`, K zero padded to
+ * the slab multiple as for anemoi_linear (C itself must be a multiple); LayerNorm parameters and biases f32 (biases may be
+ * NULL); `qkv` / `att` / `y` / `h_ln` / `h` are the caller's workspaces, `mhsa_ws` of anemoi_mhsa_workspace_bytes() bytes;
+ * window / dropout arguments as anemoi_mhsa.  `out` may not alias `x`.
+ */
+typedef struct anemoi_tfm_block_args {
+  int64_t struct_bytes;
+  int64_t rows;              /* B * S node rows                                                                    */
+  int32_t dtype;             /* ANEMOI_F32 or ANEMOI_BF16                                                          */
+  int32_t B, S, C, H;        /* batch, sequence length (rows = B * S), channels, heads                             */
+  int32_t hidden, act;       /* MLP hidden width, activation code                                                  */
+  int32_t window;            /* < 0: global attention                                                              */
+  float eps1, eps2;          /* epsilon of layer_norm1 / layer_norm2                                               */
+  float dropout_p; uint32_t dropout_seed; const void* dropout_seed_dev; int32_t dropout_h0, dropout_h_total;
+  const void* x; int64_t ldx;                                       /* [rows, C]                                   */
+  const float* ln1_w; const float* ln1_b; const float* ln2_w; const float* ln2_b;
+  const void* w_qkv; const float* b_qkv;                            /* [3 C, C]                                    */
+  const void* w_proj; const float* b_proj;                          /* [C, C]                                      */
+  const void* w_fc1; const float* b_fc1;                            /* [hidden, C]                                 */
+  const void* w_fc2; const float* b_fc2;                            /* [C, hidden]                                 */
+  void* h_ln;                                                       /* [rows, C]      layer_norm1 / layer_norm2 out */
+  void* qkv;                                                        /* [rows, 3 C]                                 */
+  void* att;                                                        /* [rows, C]                                   */
+  void* y;                                                          /* [rows, C]                                   */
+  void* h;                                                          /* [rows, hidden]                              */
+  void* mhsa_ws;                                                    /* anemoi_mhsa_workspace_bytes (may be NULL)   */
+  void* out;                                                        /* [rows, C]                                   */
+} anemoi_tfm_block_args;
+int anemoi_transformer_block_forward(const anemoi_tfm_block_args* args, anemoi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,3 +58,24 @@ def test_block_level_entry_points_validate_their_argument_block_without_gpu():
     a.dtype, a.n_dst, a.C, a.H, a.up, a.hidden, a.k_proj, a.ld_att = _lib.BF16, 16, 64, 4, 4, 128, 64, 128
     assert lib.anemoi_gt_block_tail(ctypes.byref(a), None) == _lib.ANEMOI_ERR_INVALID  # K of the projection < C + H * up
     assert b"projection K" in lib.anemoi_last_error()
+
+
+def test_block_level_argument_blocks_are_checked_without_gpu():
+    """The block-level entry points refuse an argument block of another layout version / with missing pointers before
+    anything is launched (struct_bytes handshake across the FFI)."""
+    import ctypes
+
+    from anemoi_models_amd import _lib
+
+    lib = _lib.load()
+    a = _lib.TfmBlockArgs()
+    a.struct_bytes = 8
+    assert lib.anemoi_transformer_block_forward(ctypes.byref(a), None) == _lib.ANEMOI_ERR_INVALID
+    assert b"out of sync" in lib.anemoi_last_error()
+    a.struct_bytes = ctypes.sizeof(_lib.TfmBlockArgs)
+    a.dtype, a.rows, a.B, a.S, a.C, a.H, a.hidden = 1, 64, 1, 64, 128, 4, 512
+    assert lib.anemoi_transformer_block_forward(ctypes.byref(a), None) == _lib.ANEMOI_ERR_INVALID
+    assert b"null pointer" in lib.anemoi_last_error()
+    g = _lib.GtBlockArgs()
+    g.struct_bytes = ctypes.sizeof(_lib.GtBlockArgs) - 8
+    assert lib.anemoi_gt_block_tail(ctypes.byref(g), None) == _lib.ANEMOI_ERR_INVALID

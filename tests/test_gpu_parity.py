@@ -336,6 +336,48 @@ def test_block_level_entry_point_is_the_op_by_op_route(graph_name, channels, lay
         assert torch.equal(got2, proc.native(x, 1))
 
 
+@pytest.mark.parametrize("dtype,channels,heads,b,s,window", [
+    (torch.bfloat16, 512, 16, 1, 1300, -1),   # config 2's block, MFMA attention (D = 32)
+    (torch.bfloat16, 1024, 16, 2, 700, -1),   # config 3's block, batch 2 (D = 64: four-wave kernel)
+    (torch.bfloat16, 256, 4, 1, 900, 64),     # sliding window
+    (torch.float32, 128, 8, 2, 300, -1),      # f32: exact-f32 MFMA Linear + generic attention
+])
+def test_transformer_block_entry_point_is_the_op_by_op_route(dtype, channels, heads, b, s, window, monkeypatch):
+    """anemoi_transformer_block_forward (TransformerProcessorBlock.forward, reference layers/block.py:99-105, from ONE FFI
+    call) issues the launches of the op-by-op route on the same packed weights: bit-identical, f32 and bf16, global and
+    windowed attention; and against the f64 restatement of the block."""
+    from anemoi_models_amd.layers.block import TransformerProcessorBlock
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16" if dtype == torch.bfloat16 else "fp32")
+    if window >= 0:
+        monkeypatch.setenv("ANEMOI_AMD_FLASH_WINDOW", "1")
+    torch.manual_seed(channels + s)
+    blk = TransformerProcessorBlock(channels, 4 * channels, heads, "GELU", window_size=window if window >= 0 else 16,
+                                    dropout_p=0.0).to(DEV).eval()
+    with torch.no_grad():
+        for ln in (blk.layer_norm1, blk.layer_norm2):
+            ln.weight.uniform_(0.8, 1.2)
+            ln.bias.uniform_(-0.1, 0.1)
+    x = (torch.randn(b * s, channels, generator=torch.Generator().manual_seed(1)) * 0.8).to(dtype).to(DEV)
+    with torch.no_grad():
+        monkeypatch.setattr(TransformerProcessorBlock, "block_abi", False)
+        want = blk.native(x, b)
+        monkeypatch.setattr(TransformerProcessorBlock, "block_abi", True)
+        got = blk.native(x, b)
+        assert blk._block_abi(x, b) is not None  # (the route was taken, not refused)
+    assert torch.equal(got, want)
+    # f64 restatement (reference layers/block.py:99-105): x + proj(attn(qkv(LN x))), then x + MLP(LN x)
+    xd = x.double().cpu()
+    sd = {k: v.double().cpu() for k, v in blk.state_dict().items()}
+    h = F.layer_norm(xd, (channels,), sd["layer_norm1.weight"], sd["layer_norm1.bias"], 1e-5)
+    qkv = F.linear(h, sd["attention.lin_qkv.weight"])
+    a = _sdpa(qkv, b, heads, window)
+    y = xd + F.linear(a, sd["attention.projection.weight"], sd["attention.projection.bias"])
+    h = F.layer_norm(y, (channels,), sd["layer_norm2.weight"], sd["layer_norm2.bias"], 1e-5)
+    ref = y + F.linear(F.gelu(F.linear(h, sd["mlp.0.weight"], sd["mlp.0.bias"])), sd["mlp.2.weight"], sd["mlp.2.bias"])
+    assert rel_err(got, ref) < (3e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
     from anemoi_models_amd import runtime
 
