@@ -55,6 +55,7 @@ class GtBlockArgs(ctypes.Structure):
         ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("cs_fc1", c_void_p), ("h", c_void_p),
         ("w_fc2", c_void_p), ("b_fc2", c_void_p), ("out", c_void_p), ("out_stats", c_void_p),
         ("stats_ws", c_void_p), ("stats_ws_bytes", c_int64),
+        ("run_ptr", c_void_p), ("run_perm", c_void_p), ("n_runs", c_int64),
     ]
 
 class TfmBlockArgs(ctypes.Structure):
@@ -100,6 +101,10 @@ SIGNATURES = {
     "anemoi_gt_edge_attention_folded": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                                 c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                                 c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "anemoi_gt_edge_attention_folded_runs": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                                     c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                                                     c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                                     c_int, c_void_p]),
     "anemoi_linear_dual": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_int, c_int, c_void_p]),
     "anemoi_linear_actgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,

@@ -397,6 +397,155 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
                      st, p, p.attr, p.rowptr, p.col);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Folded path on a graph whose destinations all have exactly THREE in-edges (the mesh -> grid decoder: every grid node
+// is fed by its three nearest mesh nodes, reference layers/mapper.py:348-418 on an anemoi-graphs KNN edge set), in RUNS:
+// consecutive destinations fed by the same three sources -- neighbouring grid points inside one mesh triangle; mean run
+// length 2.04 at N320 -> ico-6 -- share ONE gather of the three k / v rows.  The plain kernel moves 3 x 2 row slices per
+// destination through the CU's vector-memory path, and that path, not HBM, is what it saturates (~42 GB/s per CU,
+// DESIGN.md 4.2): here the gathers per destination halve, q / x_r / out stream as before.
+//   run_ptr [n_runs + 1]  first destination of every run (runs are capped at 4 destinations)
+//   perm    [n_dst]       bits 2 s .. 2 s + 1: position (0 .. 2) inside the destination's CSR segment of its edge to the
+//                         s-th source in ASCENDING source order -- the canonical order a run's rows are gathered in
+// Edge e of destination d is CSR slot 3 d + position (uniform degree: rowptr[d] = 3 d, checked by the host).  The three
+// terms of a destination are summed in canonical order (the plain kernel: CSR order): same result up to f32 rounding,
+// deterministic.  All three scores are in registers at once: exact maximum first, no online rescale.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPH, int UP>
+__global__ __launch_bounds__(256) void gt_edge_attention_folded_runs_kernel(const EdgeFoldParams p,
+                                                                        const float* __restrict__ attr_,
+                                                                        const int32_t* __restrict__ run_ptr_,
+                                                                        const int32_t* __restrict__ col_,
+                                                                        const uint8_t* __restrict__ perm_,
+                                                                        int64_t n_runs) {
+  using Raw = typename RawVec<T, VEC>::type;
+  constexpr int APL = attrs_per_lane(UP, LPH);
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
+  const int slice = wave_in_xcd % p.n_slices;
+  const int64_t run_first = wave_in_xcd / p.n_slices;
+  const int64_t run_stride = waves_per_xcd / p.n_slices;
+  const int64_t r0 = n_runs * xcd / 8, r1 = n_runs * (xcd + 1) / 8;
+
+  const int lanes_total = p.C / VEC;
+  const int gl = slice * 64 + lane;
+  const bool active = gl < lanes_total;
+  const int gls = active ? gl : 0;
+  const int c0 = gls * VEC;
+  const int head = gls / LPH;
+  const int a0 = (gls % LPH) * APL;
+  const bool a_own = a0 < UP;
+  const int a_ld = a_own ? a0 : 0;
+  const float amask = a_own ? 1.f : 0.f;
+
+  const T* qb = static_cast<const T*>(p.q) + c0;
+  const T* kb = static_cast<const T*>(p.k) + c0;
+  const T* vb = static_cast<const T*>(p.v) + c0;
+  const T* ub = static_cast<const T*>(p.u) + head * UP + a_ld;
+  const float* ab = attr_ + a_ld;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  constexpr int VP = (VEC + 1) / 2;
+
+  for (int64_t run = r0 + run_first; run < r1; run += run_stride) {
+    const int64_t d_begin = run_ptr_[run], d_end = run_ptr_[run + 1];
+    Raw kr[3], vr[3];
+    {
+      const int pf = perm_[d_begin];
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const int64_t j = col_[3 * d_begin + ((pf >> (2 * sl)) & 3)];
+        kr[sl] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
+        vr[sl] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
+      }
+    }
+    for (int64_t node = d_begin; node < d_end; ++node) {
+      const int pd = perm_[node];
+      QK<T, VEC> qk;
+      float u[APL];
+      RawWords<T, VEC> xr_raw;
+      {
+        float qf[VEC];
+        if (p.stream_hint) load_stream<T, VEC>(qb + node * p.ldq, qf);
+        else VecIO<T, VEC>::load(qb + node * p.ldq, qf);
+        qk.set(qf);
+        VecIO<T, APL>::load(ub + node * p.ldu, u);
+        if (p.xr != nullptr) xr_raw.load(static_cast<const char*>(p.xr) + node * p.ldr * (int64_t)sizeof(T),
+                                         (uint32_t)(c0 * (int)sizeof(T)), p.stream_hint != 0);
+#pragma unroll
+        for (int i = 0; i < APL; ++i) u[i] *= amask;
+      }
+      float at[3][APL], sc[3];
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) VecIO<float, APL>::load(ab + (3 * node + ((pd >> (2 * sl)) & 3)) * UP, at[sl]);
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        float t = qk.dot(kr[sl]);
+#pragma unroll
+        for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[sl][a], t);
+        sc[sl] = group_sum<LPH>(t) * p.scale;
+      }
+      const float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+      float l = 0.f;
+      f32x2_t acc[VP];
+      float tacc[APL];
+#pragma unroll
+      for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const float pe = __expf(sc[sl] - m);
+        l += pe;
+        float vv[VEC];
+        unpack<T, VEC>(vr[sl], vv);
+#pragma unroll
+        for (int i = 0; i < VP; ++i)
+          acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f}, acc[i]);
+#pragma unroll
+        for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[sl][a], tacc[a]);
+      }
+      const float inv = 1.0f / (l + 1e-16f);
+      float o[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
+      if (p.xr != nullptr) {
+        float r[VEC];
+        xr_raw.get(r);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] += r[i];
+      }
+      T* on = static_cast<T*>(p.out) + node * p.ldo;
+      if (active) {
+        if (p.stream_hint) store_stream<T, VEC>(on + c0, o);
+        else VecIO<T, VEC>::store(on + c0, o);
+      }
+      if (active && a_own) {
+        float t4[APL];
+#pragma unroll
+        for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+        VecIO<T, APL>::store(on + p.C + head * UP + a0, t4);
+      }
+      if (p.lse != nullptr && active && (gls % LPH) == 0) p.lse[node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);
+    }
+  }
+}
+
+template <typename T, int VEC, int LPH, int UP>
+static void launch_folded_runs(const EdgeFoldParams& p, const int32_t* run_ptr, const uint8_t* perm, int64_t n_runs,
+                               hipStream_t st) {
+  constexpr int WPB = 4, wgs_per_cu = 5;
+  const int64_t units_per_xcd = ((n_runs + 7) / 8) * p.n_slices;
+  int64_t bpx = (units_per_xcd + WPB - 1) / WPB;
+  if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;
+  if (bpx < 1) bpx = 1;
+  while ((bpx * WPB) % p.n_slices != 0) ++bpx;
+  hipLaunchKernelGGL((gt_edge_attention_folded_runs_kernel<T, VEC, LPH, UP>), dim3((unsigned)(8 * bpx)), dim3(64 * WPB), 0,
+                     st, p, p.attr, run_ptr, p.col, perm, n_runs);
+}
+
 template <typename T, int VEC, int LPH>
 static bool dispatch_folded_up(const EdgeFoldParams& p, int up, hipStream_t st) {
   switch (up) {
@@ -775,4 +924,53 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
                  "anemoi_gt_edge_attention_folded: unsupported shape (D=%d, UP=%d); use anemoi_gt_edge_attention", C / H,
                  up);
   return check_launch("anemoi_gt_edge_attention_folded");
+}
+
+// The folded edge phase on a uniform-degree-3 graph with its runs of destinations that share their three sources
+// (gt_edge_attention_folded_runs_kernel above).  Same arguments and result as anemoi_gt_edge_attention_folded + the run
+// list; shapes the run kernel does not cover (f32, other head sizes) take the plain kernel.
+extern "C" int anemoi_gt_edge_attention_folded_runs(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                                                    int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
+                                                    const float* edge_attr, int up, const int32_t* rowptr,
+                                                    const int32_t* col, const int32_t* run_ptr, const uint8_t* run_perm,
+                                                    int64_t n_runs, void* out, int64_t ldo, float* lse, int64_t n_dst, int C,
+                                                    int H, anemoi_stream_t stream) {
+  const bool plain = run_ptr == nullptr || run_perm == nullptr || n_runs <= 0 || dtype != ANEMOI_BF16 || H <= 0 || C % H != 0 ||
+                     !((C / H) == 64 || (C / H) == 32) || !(up == 4 || up == 8 || up == 12 || up == 16) || n_dst == 0;
+  if (plain)
+    return anemoi_gt_edge_attention_folded(dtype, q, ldq, k, v, ldkv, x_r, ldr, u, ldu, edge_attr, up, rowptr, col, out, ldo,
+                                           lse, n_dst, C, H, stream);
+  const char* who = "anemoi_gt_edge_attention_folded_runs";
+  ANEMOI_REQUIRE(q && k && v && u && out && col && edge_attr, ANEMOI_ERR_INVALID, "%s: null pointer", who);
+  ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
+                     (x_r == nullptr || ldr >= C) && n_runs <= n_dst,
+                 ANEMOI_ERR_INVALID, "%s: leading dimension too small / more runs than destinations", who);
+  const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                       ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                       (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % 8 == 0)) && ldq % 8 == 0 && ldkv % 8 == 0 &&
+                       ldu % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)edge_attr % 16 == 0) && C % 8 == 0;
+  ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED, "%s: operands must be 16-byte aligned", who);
+  EdgeFoldParams p;
+  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out; p.lse = lse;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
+  p.attr = edge_attr; p.rowptr = rowptr; p.col = col;
+  p.n_dst = n_dst; p.C = C; p.D = C / H;
+  p.n_slices = (C + 511) / 512;
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  p.stream_hint = 1;
+  hipStream_t st = as_stream(stream);
+#define ANEMOI_RUNS_UP(LPH)                                                                                     \
+  switch (up) {                                                                                                 \
+    case 4: launch_folded_runs<bf16_t, 8, LPH, 4>(p, run_ptr, run_perm, n_runs, st); break;                     \
+    case 8: launch_folded_runs<bf16_t, 8, LPH, 8>(p, run_ptr, run_perm, n_runs, st); break;                     \
+    case 12: launch_folded_runs<bf16_t, 8, LPH, 12>(p, run_ptr, run_perm, n_runs, st); break;                   \
+    default: launch_folded_runs<bf16_t, 8, LPH, 16>(p, run_ptr, run_perm, n_runs, st); break;                   \
+  }
+  if (C / H == 64) {
+    ANEMOI_RUNS_UP(8)
+  } else {
+    ANEMOI_RUNS_UP(4)
+  }
+#undef ANEMOI_RUNS_UP
+  return check_launch(who);
 }

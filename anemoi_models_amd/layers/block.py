@@ -53,7 +53,14 @@ def folded_edge_phase(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
     """The folded edge phase (``anemoi_gt_edge_attention_folded``: one fused gather -> score -> segment softmax -> weighted
     sum -> ``+ x_r`` pass over the destination-sorted CSR)."""
     return ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, plan.col, num_heads, up,
-                                        ld_out=ld_out)
+                                        ld_out=ld_out, runs=edge_runs(plan, q.dtype))
+
+
+def edge_runs(plan, dtype):
+    """The run lists of a uniform-degree-3 plan for the bf16 run kernel (``EdgePlan.runs3``), else ``None``."""
+    if dtype != torch.bfloat16 or not hasattr(plan, "runs3") or os.environ.get("ANEMOI_AMD_EDGE_RUNS", "1") == "0":
+        return None
+    return plan.runs3()
 
 
 class EmbeddedRows:
@@ -375,6 +382,9 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         a.q, a.k, a.v, a.x_r, a.u = q.data_ptr(), k.data_ptr(), v.data_ptr(), x_r.data_ptr(), u.data_ptr()
         a.ldq, a.ldkv, a.ldr, a.ldu = ops._ld(q), ops._ld(k), ops._ld(x_r), ops._ld(u)
         a.edge_attr, a.rowptr, a.col = edge_attr_csr.data_ptr(), plan.rowptr.data_ptr(), plan.col.data_ptr()
+        runs = edge_runs(plan, dtype)
+        if runs is not None:
+            a.run_ptr, a.run_perm, a.n_runs = runs[0].data_ptr(), runs[1].data_ptr(), runs[0].shape[0] - 1
         a.att, a.ld_att = att.data_ptr(), wp.shape[1]
         a.w_proj, a.b_proj = wp.data_ptr(), ops._ptr(bp)
         a.res, a.ld_res, a.y, a.y_stats = res.data_ptr(), ops._ld(res), y.data_ptr(), stats[0].data_ptr()

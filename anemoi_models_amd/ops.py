@@ -278,12 +278,14 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], ed
 
 def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
                              rowptr: Tensor, col: Tensor, num_heads: int, up: int, out: Optional[Tensor] = None,
-                             ld_out: Optional[int] = None, lse: Optional[Tensor] = None) -> Tensor:
+                             ld_out: Optional[int] = None, lse: Optional[Tensor] = None, runs=None) -> Tensor:
     """Edge phase with lin_edge folded away: returns ``[n_dst, ld_out]`` = ``[sum alpha v (+ x_r) | t (H*up) | 0-pad]``.
 
     ``u`` is ``[n_dst, H*up]`` (extra columns of the q/k/v GEMM), ``edge_attr`` ``[E, up]`` f32 in CSR order with the
     constant-1 column.  Columns beyond ``C + H*up`` (K padding for the projection GEMM) are zero filled.  ``lse``
     (optional f32 ``[n_dst, H]``, contiguous) receives the softmax normaliser per destination and head (training).
+    ``runs = (run_ptr, perm)`` (``EdgePlan.runs3()``, uniform-degree-3 graphs): destinations that share their three sources
+    share one gather of them (``anemoi_gt_edge_attention_folded_runs``).
     """
     _dev(q, k, v, x_r, u, edge_attr, rowptr, col, out, lse)
     if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous()
@@ -308,10 +310,21 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
         edge_attr = torch.zeros((1, up), dtype=torch.float32, device=q.device)
     alg_bytes = (2 * n_dst + 2 * k.shape[0]) * c * q.element_size() + col.shape[0] * 52 + (n_dst + 1) * 4
     with _Timed("gt_edge_attention", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
-        st = _lib.load().anemoi_gt_edge_attention_folded(
-            dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
-            0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
-            rowptr.data_ptr(), col.data_ptr(), out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
+        if runs is not None:
+            run_ptr, perm = runs
+            _dev(run_ptr, perm)
+            if run_ptr.dtype != torch.int32 or perm.dtype != torch.uint8 or perm.shape[0] != n_dst:
+                raise ValueError("gt_edge_attention_folded: runs = (int32 run_ptr [n_runs + 1], uint8 perm [n_dst])")
+            st = _lib.load().anemoi_gt_edge_attention_folded_runs(
+                dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
+                0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
+                rowptr.data_ptr(), col.data_ptr(), run_ptr.data_ptr(), perm.data_ptr(), run_ptr.shape[0] - 1,
+                out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
+        else:
+            st = _lib.load().anemoi_gt_edge_attention_folded(
+                dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
+                0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
+                rowptr.data_ptr(), col.data_ptr(), out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
     _lib.check(st, "anemoi_gt_edge_attention_folded")
     return out
 

@@ -69,6 +69,13 @@ class EdgePlan:
     def num_edges(self) -> int:
         return int(self.col.shape[0])
 
+    def runs3(self):
+        """``(run_ptr, perm)`` of :func:`_runs3` (cached on the plan), or ``None`` for any other graph."""
+        r = getattr(self, "_runs3_cache", 0)
+        if r == 0:
+            r = self._runs3_cache = _runs3(self) if self.col.is_cuda else None
+        return r
+
     @property
     def dst(self) -> Tensor:
         """int32 [E]: destination node of every CSR slot (row index expanded; built on first use)."""
@@ -78,6 +85,33 @@ class EdgePlan:
             d = torch.repeat_interleave(torch.arange(self.n_dst, device=self.rowptr.device), counts).to(torch.int32)
             self._dst = d
         return d
+
+
+def _runs3(plan: "EdgePlan", max_run: int = 4):
+    """Runs of consecutive destinations with the same three sources, for ``anemoi_gt_edge_attention_folded_runs``:
+    ``(run_ptr int32 [n_runs + 1], perm uint8 [n_dst])`` when every destination of ``plan`` has exactly three in-edges from
+    three different sources (the reference's mesh -> grid decoder on anemoi-graphs' 3-nearest-neighbour edges), else
+    ``None``.  ``perm[d]`` packs, for s = 0 .. 2, the position inside d's CSR segment of its edge to the s-th source in
+    ascending source order.  Built once per plan on the plan's device, no host round trip besides two scalar checks."""
+    n, e = plan.n_dst, plan.num_edges
+    if n < 1024 or e != 3 * n:
+        return None
+    rowptr = plan.rowptr
+    if not bool((rowptr == torch.arange(0, 3 * n + 1, 3, dtype=rowptr.dtype, device=rowptr.device)).all()):
+        return None
+    src = plan.col.view(n, 3).long()
+    srt, pos = torch.sort(src, dim=1, stable=True)
+    if bool((srt[:, 1:] == srt[:, :-1]).any()):
+        return None  # a destination with two edges from one source: the run kernel's canonical order would be ambiguous
+    perm = (pos[:, 0] | (pos[:, 1] << 2) | (pos[:, 2] << 4)).to(torch.uint8).contiguous()
+    start = torch.ones(n, dtype=torch.bool, device=src.device)
+    start[1:] = (srt[1:] != srt[:-1]).any(dim=1)
+    # cap the run length: position inside its run, a new run every max_run destinations
+    idx = torch.arange(n, device=src.device)
+    first = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
+    start |= ((idx - first) % max_run) == 0
+    run_ptr = torch.cat([torch.nonzero(start).flatten(), torch.tensor([n], device=src.device)]).to(torch.int32).contiguous()
+    return run_ptr, perm
 
 
 def build_edge_plan(edge_index: Tensor, n_src: int, n_dst: int) -> EdgePlan:

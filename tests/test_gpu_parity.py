@@ -378,6 +378,58 @@ def test_transformer_block_entry_point_is_the_op_by_op_route(dtype, channels, he
     assert rel_err(got, ref) < (3e-2 if dtype == torch.bfloat16 else 1e-4)
 
 
+@pytest.mark.parametrize("c,h,xr", [(1024, 16, True), (512, 16, True), (256, 4, False)])
+def test_gt_edge_attention_folded_runs_of_shared_sources(c, h, xr):
+    """The run kernel of uniform-degree-3 graphs (decoder: grid nodes fed by their three nearest mesh nodes; consecutive
+    destinations with the same three sources share one gather) against the plain folded kernel on the same CSR -- equal up to
+    the f32 rounding of another summation order -- and against the f64 formula; lse output; bit-reproducible."""
+    from anemoi_models_amd import ops, runtime
+
+    g = torch.Generator().manual_seed(c + h)
+    n, n_src, up = 20000, 3000, 12
+    base = torch.randint(0, n_src - 40, (n,), generator=g)
+    keep = torch.rand(n, generator=g) < 0.55  # a destination keeps its predecessor's triangle with probability 0.55
+    for i in range(1, n):
+        if keep[i]:
+            base[i] = base[i - 1]
+    tri = torch.stack([base, base + 7, base + 31], 1)
+    order = torch.stack([torch.randperm(3, generator=g) for _ in range(n)])
+    src = torch.gather(tri, 1, order).reshape(-1)
+    dst = torch.arange(n).repeat_interleave(3)
+    plan = runtime.build_edge_plan(torch.stack([src, dst]).to(DEV), n_src, n)
+    runs = plan.runs3()
+    assert runs is not None and runs[0].shape[0] - 1 < 0.7 * n
+    q = (torch.randn(n, c, generator=g) * 0.5).bfloat16().to(DEV)
+    kv = (torch.randn(n_src, 2 * c, generator=g) * 0.5).bfloat16().to(DEV)
+    x_r = torch.randn(n, c, generator=g).bfloat16().to(DEV) if xr else None
+    u = (torch.randn(n, h * up, generator=g) * 0.3).bfloat16().to(DEV)
+    attr = torch.randn(3 * n, up, generator=g).to(DEV)
+    attr[:, up - 1] = 1.0
+    lse_a = torch.empty(n, h, device=DEV)
+    lse_b = torch.empty(n, h, device=DEV)
+    plain = ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], x_r, u, attr, plan.rowptr, plan.col, h, up, lse=lse_a)
+    got = ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], x_r, u, attr, plan.rowptr, plan.col, h, up, lse=lse_b,
+                                       runs=runs)
+    assert rel_err(got, plain) < 8e-3 and float((got != plain).float().mean()) < 0.2  # bf16 ties only
+    assert rel_err(lse_b, lse_a) < 1e-5
+    for _ in range(3):
+        assert torch.equal(ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], x_r, u, attr, plan.rowptr, plan.col, h, up,
+                                                        runs=runs), got)
+    # f64 formula on a sample of destinations
+    d = c // h
+    sel = torch.arange(0, n, 97)
+    qd, kd, vd, ud, ad = q.double().cpu(), kv[:, :c].double().cpu(), kv[:, c:].double().cpu(), u.double().cpu(), attr.double().cpu()
+    col = plan.col.cpu().long().view(n, 3)
+    for i in sel.tolist():
+        js = col[i]
+        s = (qd[i].view(h, d)[None] * kd[js].view(3, h, d)).sum(-1) + (ud[i].view(h, up)[None] * ad[3 * i:3 * i + 3][:, None, :]).sum(-1)
+        a = torch.softmax(s / d**0.5, 0)  # [3, H]
+        o = (a[:, :, None] * vd[js].view(3, h, d)).sum(0).reshape(c)
+        if xr:
+            o = o + x_r[i].double().cpu()
+        assert float((got[i, :c].double().cpu() - o).abs().max() / o.abs().max()) < 1e-2
+
+
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
     from anemoi_models_amd import runtime
 

@@ -83,9 +83,13 @@ def mapper(a):
     ld_out = ops.round_up(c + h * up, 64)
     out = torch.zeros(n_dst, ld_out, dtype=torch.bfloat16, device=dev)
 
+    runs = plan.runs3() if os.environ.get("ANEMOI_AMD_EDGE_RUNS", "1") != "0" else None  # decoder: shared-source runs
+    if runs is not None:
+        print(f"runs: {runs[0].shape[0] - 1} for {n_dst} destinations (mean length {n_dst / (runs[0].shape[0] - 1):.2f})")
+
     def run():
         ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], attr, plan.rowptr,
-                                     plan.col, h, up, out=out, ld_out=ld_out)
+                                     plan.col, h, up, out=out, ld_out=ld_out, runs=runs)
 
     report(a, run, out, (2 * n_dst + 2 * n_src) * c * 2 + plan.col.shape[0] * 52 + (n_dst + 1) * 4,
            f"set={a.set} n_src={n_src} n_dst={n_dst} E={plan.col.shape[0]}")
