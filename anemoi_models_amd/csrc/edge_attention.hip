@@ -401,22 +401,24 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
 // Folded path on a graph whose destinations all have exactly THREE in-edges (the mesh -> grid decoder: every grid node
 // is fed by its three nearest mesh nodes, reference layers/mapper.py:348-418 on an anemoi-graphs KNN edge set), in RUNS:
 // consecutive destinations fed by the same three sources -- neighbouring grid points inside one mesh triangle; mean run
-// length 2.04 at N320 -> ico-6 -- share ONE gather of the three k / v rows.  The plain kernel moves 3 x 2 row slices per
-// destination through the CU's vector-memory path, and that path, not HBM, is what it saturates (~42 GB/s per CU,
-// DESIGN.md 4.2): here the gathers per destination halve, q / x_r / out stream as before.
-//   run_ptr [n_runs + 1]  first destination of every run (runs are capped at 4 destinations)
-//   perm    [n_dst]       bits 2 s .. 2 s + 1: position (0 .. 2) inside the destination's CSR segment of its edge to the
-//                         s-th source in ASCENDING source order -- the canonical order a run's rows are gathered in
+// length 2.04 at N320 -> ico-6, 1.52 with the cap of two -- share ONE gather of the three k / v rows AND one dependent chain
+// of index loads: { run_ptr, perm } -> the three source ids -> every load of the run in flight together.  Measured (decoder
+// launch of config 3): 0.987 -> 0.889 ms; with runs of up to four (half the gathers, but 150 VGPRs) 0.907: the launch is bound
+// by its per-destination latency chains and the q / x_r / out stream, not by the gathered bytes.
+//   run_ptr [n_runs + 1]  first destination of every run (runs are capped at EDGE_MAX_RUN = 2 destinations)
+//   perm    [n_runs]      6 bits per destination d = 0, 1 of the run; bits 6 d + 2 s .. + 1: position (0 .. 2) inside that
+//                         destination's CSR segment of its edge to the s-th source in ASCENDING source order -- the
+//                         canonical order the run's rows are gathered in
 // Edge e of destination d is CSR slot 3 d + position (uniform degree: rowptr[d] = 3 d, checked by the host).  The three
 // terms of a destination are summed in canonical order (the plain kernel: CSR order): same result up to f32 rounding,
 // deterministic.  All three scores are in registers at once: exact maximum first, no online rescale.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPH, int UP>
+template <typename T, int VEC, int LPH, int UP, int MAXRUN>
 __global__ __launch_bounds__(256) void gt_edge_attention_folded_runs_kernel(const EdgeFoldParams p,
                                                                         const float* __restrict__ attr_,
                                                                         const int32_t* __restrict__ run_ptr_,
                                                                         const int32_t* __restrict__ col_,
-                                                                        const uint8_t* __restrict__ perm_,
+                                                                        const int32_t* __restrict__ perm_,
                                                                         int64_t n_runs) {
   using Raw = typename RawVec<T, VEC>::type;
   constexpr int APL = attrs_per_lane(UP, LPH);
@@ -450,100 +452,110 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_runs_kernel(cons
   constexpr int VP = (VEC + 1) / 2;
 
   for (int64_t run = r0 + run_first; run < r1; run += run_stride) {
-    const int64_t d_begin = run_ptr_[run], d_end = run_ptr_[run + 1];
+    // one dependent chain per RUN, not per destination: { run_ptr, perm } -> the three source ids -> every load of the run
+    // (3 + 3 row gathers, q / u / x_r and the 3 attribute rows of up to four destinations) in flight together
+    const int64_t d_begin = run_ptr_[run];
+    const int len = (int)(run_ptr_[run + 1] - d_begin);  // 1 .. MAXRUN
+    const int pr = perm_[run];                             // 6 bits per destination of the run
     Raw kr[3], vr[3];
-    {
-      const int pf = perm_[d_begin];
 #pragma unroll
-      for (int sl = 0; sl < 3; ++sl) {
-        const int64_t j = col_[3 * d_begin + ((pf >> (2 * sl)) & 3)];
-        kr[sl] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
-        vr[sl] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
-      }
+    for (int sl = 0; sl < 3; ++sl) {
+      const int64_t j = col_[3 * d_begin + ((pr >> (2 * sl)) & 3)];
+      kr[sl] = *reinterpret_cast<const Raw*>(kb + j * p.ldkv);
+      vr[sl] = *reinterpret_cast<const Raw*>(vb + j * p.ldkv);
     }
-    for (int64_t node = d_begin; node < d_end; ++node) {
-      const int pd = perm_[node];
-      QK<T, VEC> qk;
-      float u[APL];
-      RawWords<T, VEC> xr_raw;
-      {
+    QK<T, VEC> qk[MAXRUN];
+    float u[MAXRUN][APL], at[MAXRUN][3][APL];
+    RawWords<T, VEC> xr_raw[MAXRUN];
+#pragma unroll
+    for (int d = 0; d < MAXRUN; ++d) {
+      if (d < len) {
+        const int64_t node = d_begin + d;
         float qf[VEC];
         if (p.stream_hint) load_stream<T, VEC>(qb + node * p.ldq, qf);
         else VecIO<T, VEC>::load(qb + node * p.ldq, qf);
-        qk.set(qf);
-        VecIO<T, APL>::load(ub + node * p.ldu, u);
-        if (p.xr != nullptr) xr_raw.load(static_cast<const char*>(p.xr) + node * p.ldr * (int64_t)sizeof(T),
-                                         (uint32_t)(c0 * (int)sizeof(T)), p.stream_hint != 0);
+        qk[d].set(qf);
+        VecIO<T, APL>::load(ub + node * p.ldu, u[d]);
+        if (p.xr != nullptr) xr_raw[d].load(static_cast<const char*>(p.xr) + node * p.ldr * (int64_t)sizeof(T),
+                                            (uint32_t)(c0 * (int)sizeof(T)), p.stream_hint != 0);
 #pragma unroll
-        for (int i = 0; i < APL; ++i) u[i] *= amask;
+        for (int sl = 0; sl < 3; ++sl)
+          VecIO<float, APL>::load(ab + (3 * node + ((pr >> (6 * d + 2 * sl)) & 3)) * UP, at[d][sl]);
       }
-      float at[3][APL], sc[3];
+    }
 #pragma unroll
-      for (int sl = 0; sl < 3; ++sl) VecIO<float, APL>::load(ab + (3 * node + ((pd >> (2 * sl)) & 3)) * UP, at[sl]);
+    for (int d = 0; d < MAXRUN; ++d) {
+      if (d < len) {
+        const int64_t node = d_begin + d;
+        float sc[3];
 #pragma unroll
-      for (int sl = 0; sl < 3; ++sl) {
-        float t = qk.dot(kr[sl]);
+        for (int sl = 0; sl < 3; ++sl) {
+          float t = qk[d].dot(kr[sl]);
 #pragma unroll
-        for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[sl][a], t);
-        sc[sl] = group_sum<LPH>(t) * p.scale;
+          for (int a = 0; a < APL; ++a) t = fmaf(u[d][a] * amask, at[d][sl][a], t);
+          sc[sl] = group_sum<LPH>(t) * p.scale;
+        }
+        const float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+        float l = 0.f;
+        f32x2_t acc[VP];
+        float tacc[APL];
+#pragma unroll
+        for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+          const float pe = __expf(sc[sl] - m);
+          l += pe;
+          float vv[VEC];
+          unpack<T, VEC>(vr[sl], vv);
+#pragma unroll
+          for (int i = 0; i < VP; ++i)
+            acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f}, acc[i]);
+#pragma unroll
+          for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[d][sl][a], tacc[a]);
+        }
+        const float inv = 1.0f / (l + 1e-16f);
+        float o[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
+        if (p.xr != nullptr) {
+          float r[VEC];
+          xr_raw[d].get(r);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] += r[i];
+        }
+        T* on = static_cast<T*>(p.out) + node * p.ldo;
+        if (active) {
+          if (p.stream_hint) store_stream<T, VEC>(on + c0, o);
+          else VecIO<T, VEC>::store(on + c0, o);
+        }
+        if (active && a_own) {
+          float t4[APL];
+#pragma unroll
+          for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+          VecIO<T, APL>::store(on + p.C + head * UP + a0, t4);
+        }
+        if (p.lse != nullptr && active && (gls % LPH) == 0) p.lse[node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);
       }
-      const float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-      float l = 0.f;
-      f32x2_t acc[VP];
-      float tacc[APL];
-#pragma unroll
-      for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
-#pragma unroll
-      for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
-#pragma unroll
-      for (int sl = 0; sl < 3; ++sl) {
-        const float pe = __expf(sc[sl] - m);
-        l += pe;
-        float vv[VEC];
-        unpack<T, VEC>(vr[sl], vv);
-#pragma unroll
-        for (int i = 0; i < VP; ++i)
-          acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f}, acc[i]);
-#pragma unroll
-        for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[sl][a], tacc[a]);
-      }
-      const float inv = 1.0f / (l + 1e-16f);
-      float o[VEC];
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
-      if (p.xr != nullptr) {
-        float r[VEC];
-        xr_raw.get(r);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) o[i] += r[i];
-      }
-      T* on = static_cast<T*>(p.out) + node * p.ldo;
-      if (active) {
-        if (p.stream_hint) store_stream<T, VEC>(on + c0, o);
-        else VecIO<T, VEC>::store(on + c0, o);
-      }
-      if (active && a_own) {
-        float t4[APL];
-#pragma unroll
-        for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
-        VecIO<T, APL>::store(on + p.C + head * UP + a0, t4);
-      }
-      if (p.lse != nullptr && active && (gls % LPH) == 0) p.lse[node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);
     }
   }
 }
 
+constexpr int EDGE_MAX_RUN = 2;  // destinations per run (measured at N320 -> ico-6, decoder launch: runs of <= 2 at 118 VGPRs /
+                                 // four workgroups per CU 0.889 ms, runs of <= 4 at 150 VGPRs / three 0.907, plain kernel 0.987)
 template <typename T, int VEC, int LPH, int UP>
-static void launch_folded_runs(const EdgeFoldParams& p, const int32_t* run_ptr, const uint8_t* perm, int64_t n_runs,
+static void launch_folded_runs(const EdgeFoldParams& p, const int32_t* run_ptr, const int32_t* perm, int64_t n_runs,
                                hipStream_t st) {
-  constexpr int WPB = 4, wgs_per_cu = 5;
+  // (more workgroups than are resident would queue behind them and run as a second, unbalanced phase)
+  constexpr int WPB = 4, wgs_per_cu = 4;
   const int64_t units_per_xcd = ((n_runs + 7) / 8) * p.n_slices;
   int64_t bpx = (units_per_xcd + WPB - 1) / WPB;
   if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;
   if (bpx < 1) bpx = 1;
   while ((bpx * WPB) % p.n_slices != 0) ++bpx;
-  hipLaunchKernelGGL((gt_edge_attention_folded_runs_kernel<T, VEC, LPH, UP>), dim3((unsigned)(8 * bpx)), dim3(64 * WPB), 0,
-                     st, p, p.attr, run_ptr, p.col, perm, n_runs);
+  hipLaunchKernelGGL((gt_edge_attention_folded_runs_kernel<T, VEC, LPH, UP, EDGE_MAX_RUN>), dim3((unsigned)(8 * bpx)),
+                     dim3(64 * WPB), 0, st, p, p.attr, run_ptr, p.col, perm, n_runs);
 }
 
 template <typename T, int VEC, int LPH>
@@ -932,7 +944,7 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
 extern "C" int anemoi_gt_edge_attention_folded_runs(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
                                                     int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
                                                     const float* edge_attr, int up, const int32_t* rowptr,
-                                                    const int32_t* col, const int32_t* run_ptr, const uint8_t* run_perm,
+                                                    const int32_t* col, const int32_t* run_ptr, const int32_t* run_perm,
                                                     int64_t n_runs, void* out, int64_t ldo, float* lse, int64_t n_dst, int C,
                                                     int H, anemoi_stream_t stream) {
   const bool plain = run_ptr == nullptr || run_perm == nullptr || n_runs <= 0 || dtype != ANEMOI_BF16 || H <= 0 || C % H != 0 ||

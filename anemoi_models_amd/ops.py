@@ -313,8 +313,8 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
         if runs is not None:
             run_ptr, perm = runs
             _dev(run_ptr, perm)
-            if run_ptr.dtype != torch.int32 or perm.dtype != torch.uint8 or perm.shape[0] != n_dst:
-                raise ValueError("gt_edge_attention_folded: runs = (int32 run_ptr [n_runs + 1], uint8 perm [n_dst])")
+            if run_ptr.dtype != torch.int32 or perm.dtype != torch.int32 or perm.shape[0] != run_ptr.shape[0] - 1:
+                raise ValueError("gt_edge_attention_folded: runs = (int32 run_ptr [n_runs + 1], int32 perm [n_runs])")
             st = _lib.load().anemoi_gt_edge_attention_folded_runs(
                 dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
                 0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,

@@ -173,15 +173,16 @@ int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t ldq, const
  * rowptr[d] = 3 d (the mesh -> grid decoder of the reference, layers/mapper.py:348-418, on anemoi-graphs' 3-nearest-neighbour
  * edges): consecutive destinations fed by the SAME three sources form a run and share one gather of the three k / v rows.
  *   run_ptr  int32 [n_runs + 1]  first destination of every run (ascending, run_ptr[n_runs] = n_dst)
- *   run_perm uint8 [n_dst]       bits 2 s .. 2 s + 1 = position (0 .. 2) inside destination d's CSR segment of its edge to the
- *                                s-th source in ascending source order; all destinations of a run have the same source set
+ *   run_perm int32 [n_runs]      6 bits per destination d = 0, 1 of the run (runs hold at most TWO); bits 6 d + 2 s .. + 1 =
+ *                                position (0 .. 2) inside that destination's CSR segment of its edge to the s-th source in
+ *                                ascending source order; all destinations of a run have the same source set
  * Same result as the plain entry point up to the f32 rounding of another summation order (deterministic).  bf16, head sizes
  * 64 / 32; other shapes, or run_ptr == NULL, run the plain kernel.  anemoi_models_amd/runtime.py::EdgePlan.runs3 builds the lists.
  */
 int anemoi_gt_edge_attention_folded_runs(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                                          const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
                                          int up, const int32_t* rowptr, const int32_t* col, const int32_t* run_ptr,
-                                         const uint8_t* run_perm, int64_t n_runs, void* out, int64_t ldo, float* lse,
+                                         const int32_t* run_perm, int64_t n_runs, void* out, int64_t ldo, float* lse,
                                          int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
@@ -499,7 +500,7 @@ typedef struct anemoi_gt_block_args {
   const void* w_fc2; const float* b_fc2; void* out; float* out_stats;   /* [C, hidden]; out [n_dst, C]; NULL: no stats   */
   void* stats_ws; int64_t stats_ws_bytes;                           /* >= n_dst * max(C / 128, 1) * 8 bytes      */
   /* optional (NULL / 0: plain edge kernel): the runs of a uniform-degree-3 graph, anemoi_gt_edge_attention_folded_runs */
-  const int32_t* run_ptr; const uint8_t* run_perm; int64_t n_runs;
+  const int32_t* run_ptr; const int32_t* run_perm; int64_t n_runs;
 } anemoi_gt_block_args;
 int anemoi_gt_block_tail(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* args, anemoi_stream_t stream);

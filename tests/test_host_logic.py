@@ -566,7 +566,7 @@ def test_mlp_leading_dimensions_and_unfused_activation(monkeypatch):
 
 def test_runs_of_destinations_sharing_three_sources():
     """runtime._runs3: the run lists of the decoder-style graphs (every destination exactly three in-edges) -- runs are
-    maximal stretches of consecutive destinations with the same source SET, capped at 4; the packed permutation maps
+    maximal stretches of consecutive destinations with the same source SET, capped at 2; the packed permutation maps
     ascending source order back to CSR positions; any other graph gives None."""
     import torch
 
@@ -586,20 +586,21 @@ def test_runs_of_destinations_sharing_three_sources():
     shuffle = torch.randperm(3 * n, generator=g)
     plan = runtime.build_edge_plan(torch.stack([src[shuffle], dst[shuffle]]), n_src, n)
     run_ptr, perm = runtime._runs3(plan)
-    assert run_ptr.dtype == torch.int32 and perm.dtype == torch.uint8 and perm.shape == (n,)
+    assert run_ptr.dtype == torch.int32 and perm.dtype == torch.int32 and perm.shape == (run_ptr.shape[0] - 1,)
     assert run_ptr[0] == 0 and run_ptr[-1] == n and bool((run_ptr[1:] > run_ptr[:-1]).all())
     lens = (run_ptr[1:] - run_ptr[:-1])
-    assert int(lens.max()) <= 4
+    assert int(lens.max()) <= 2
     col = plan.col.view(n, 3).long()
     for r in range(run_ptr.shape[0] - 1):
         d0, d1 = int(run_ptr[r]), int(run_ptr[r + 1])
         sets = {tuple(sorted(col[d].tolist())) for d in range(d0, d1)}
         assert len(sets) == 1
-        if d1 < n and d1 - d0 < 4:  # a run ends where the source set changes (or at the cap)
+        if d1 < n and d1 - d0 < 2:  # a run ends where the source set changes (or at the cap)
             assert tuple(sorted(col[d1].tolist())) not in sets
-    for d in range(0, n, 37):
-        pos = [(int(perm[d]) >> (2 * s)) & 3 for s in range(3)]
-        assert sorted(pos) == [0, 1, 2] and [int(col[d, q]) for q in pos] == sorted(col[d].tolist())
+    for r in range(0, run_ptr.shape[0] - 1, 11):
+        for k, d in enumerate(range(int(run_ptr[r]), int(run_ptr[r + 1]))):
+            pos = [(int(perm[r]) >> (6 * k + 2 * s)) & 3 for s in range(3)]
+            assert sorted(pos) == [0, 1, 2] and [int(col[d, q]) for q in pos] == sorted(col[d].tolist())
     # degree not uniformly three / duplicate sources: no runs
     assert runtime._runs3(runtime.build_edge_plan(torch.stack([src[:-3], dst[:-3]]), n_src, n)) is None
     dup = src.clone().view(n, 3)
