@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
 N_PROG, N_FORC, N_DIAG = 20, 4, 2
-BF16_BOUND = 5e-2  # bf16 storage / f32 accumulate over 16 residual blocks vs the f32 oracle (measured value is printed)
+BF16_BOUND = 1e-2  # bf16 storage / f32 accumulate over 16 residual blocks vs the f32 oracle (measured 2.2e-3 ... 3.0e-3, printed)
 
 
 def rel_err(got, want):

@@ -515,7 +515,7 @@ def test_model_cfg1_bf16_report(graph_o32, golden_cfg1_gt, monkeypatch):
         y = model(gold["x"].to(DEV))
     err = rel_err(y, gold["y"])
     print(f"bf16 storage / f32 accumulate vs f32 reference, cfg1: max rel err {err:.3e}")
-    assert err < 5e-2
+    assert err < 1e-2  # measured 2.7e-3
 
 
 def _build_hier(graph, channels=64, heads=16):
@@ -551,7 +551,7 @@ def test_hierarchical_model_bf16_report(graph_hier, golden_hier_gt, monkeypatch)
         y = model(gold["x"].to(DEV))
     err = rel_err(y, gold["y"])
     print(f"hierarchical, bf16 storage / f32 accumulate vs f32 reference: max rel err {err:.3e}")
-    assert err < 5e-2
+    assert err < 1e-2  # measured 2.5e-3
 
 
 def test_interface_predict_step_vs_golden(graph_o32, golden_interface):
@@ -1017,7 +1017,7 @@ def test_full_size_config3_invariants(monkeypatch):
     model.mesh_locality_order = True
     assert rel_err(run(ANEMOI_AMD_EDGE_FOLD="0"), y_ref) < 1e-4
     y_bf16 = run(ANEMOI_AMD_DTYPE="bf16")
-    assert rel_err(y_bf16, y_ref) < 5e-2
+    assert rel_err(y_bf16, y_ref) < 1e-2
     # prognostic residual: y - x_last on the prognostic variables equals the decoder output, which does not change
     # when x_last is shifted by a constant on a variable the network never sees ... simpler, exact check:
     with torch.no_grad():
