@@ -885,12 +885,16 @@ __global__ __launch_bounds__(256) void mhsa_tail_kernel(const bf16_t* __restrict
   const int lane = threadIdx.x & 63;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h, split)
   if (unit >= total) return;
-  const int split = (int)(unit % n_split);
-  const int64_t u2 = unit / n_split;
+  // unit = ((b H + h) n_split + split) q_count + query: the left-over queries of one (head, key chunk) sit in neighbouring
+  // waves, so the chunk's K / V rows are fetched from HBM once and hit the caches for the others (query-slowest order read
+  // the whole K / V of every head once PER left-over query: 670 MB at S = 40 962 for two queries)
+  const int qi = (int)(unit % q_count);
+  const int64_t u1 = unit / q_count;
+  const int split = (int)(u1 % n_split);
+  const int64_t u2 = u1 / n_split;
   const int h = (int)(u2 % H);
-  const int64_t bql = u2 / H;
-  const int q = q_begin + (int)(bql % q_count);
-  const int64_t b = bql / q_count;
+  const int64_t b = u2 / H;
+  const int q = q_begin + qi;
   float qv[D], acc[D];
   {
     const bf16_t* qp = qkv + (b * S + q) * ld + h * D;
@@ -956,27 +960,42 @@ template <int D>
 __global__ __launch_bounds__(256) void mhsa_tail_merge_kernel(const float* __restrict__ part, bf16_t* __restrict__ out,
                                                               int64_t ldo, float* __restrict__ lse, int S, int H,
                                                               int q_begin, int q_count, int n_split, int64_t n_units) {
-  // one thread per (unit, d): n_split partial states -> the normalised output row slice
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_units * D) return;
-  const int d = (int)(idx % D);
-  const int64_t u2 = idx / D;  // (b, q, h)
-  const int h = (int)(u2 % H);
-  const int64_t bql = u2 / H;
-  const int q = q_begin + (int)(bql % q_count);
-  const int64_t b = bql / q_count;
-  const float* pp = part + u2 * n_split * (D + 2);
-  float mt = -INFINITY;
-  for (int sidx = 0; sidx < n_split; ++sidx) mt = fmaxf(mt, pp[sidx * (D + 2)]);
-  float lt = 0.f, o = 0.f;
-  for (int sidx = 0; sidx < n_split; ++sidx) {
-    const float mi = pp[sidx * (D + 2)];
-    const float w = mi == -INFINITY ? 0.f : __expf(mi - mt);
-    lt = fmaf(pp[sidx * (D + 2) + 1], w, lt);
-    o = fmaf(pp[sidx * (D + 2) + 2 + d], w, o);
+  // one WAVE per (b, h, query): the lanes hold the n_split <= 128 partial states (two per lane), the merge is a handful of
+  // wave reductions (the first version walked the splits one after the other in every thread: 67 us for 32 rows)
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_units) return;
+  const int qi = (int)(w % q_count);
+  const int64_t bh = w / q_count;  // b H + h
+  const int h = (int)(bh % H);
+  const int64_t b = bh / H;
+  const int q = q_begin + qi;
+  // state of (split s): part[((bh n_split + s) q_count + qi) (D + 2) ...]
+  const float* p0 = lane < n_split ? part + ((bh * n_split + lane) * q_count + qi) * (D + 2) : nullptr;
+  const float* p1 = lane + 64 < n_split ? part + ((bh * n_split + lane + 64) * q_count + qi) * (D + 2) : nullptr;
+  const float m0 = p0 != nullptr ? p0[0] : -INFINITY, m1 = p1 != nullptr ? p1[0] : -INFINITY;
+  float mt = fmaxf(m0, m1);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mt = fmaxf(mt, __shfl_xor(mt, off, 64));
+  const float w0 = m0 == -INFINITY ? 0.f : __expf(m0 - mt), w1 = m1 == -INFINITY ? 0.f : __expf(m1 - mt);
+  const float lt = wave_sum((p0 != nullptr ? p0[1] * w0 : 0.f) + (p1 != nullptr ? p1[1] * w1 : 0.f));
+  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  float mine = 0.f;  // lane d keeps output channel d
+  const float* r0 = p0 != nullptr ? p0 + 2 : part;  // (lanes without a state: any valid address, weight 0)
+  const float* r1 = p1 != nullptr ? p1 + 2 : part;
+  const float g0 = p0 != nullptr ? w0 : 0.f, g1 = p1 != nullptr ? w1 : 0.f;
+  for (int d0 = 0; d0 < D; d0 += 8) {  // eight channels' loads in flight per round trip
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = r0[d0 + i] * g0 + r1[d0 + i] * g1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float o = wave_sum(t[i]);
+      if (lane == d0 + i) mine = o;
+    }
   }
-  Elem<bf16_t>::store(out + (b * S + q) * ldo + h * D + d, lt > 0.f ? o / lt : 0.f);
-  if (lse != nullptr && d == 0) lse[(b * H + h) * S + q] = mt + __logf(lt);
+  if (lane < D) Elem<bf16_t>::store(out + (b * S + q) * ldo + h * D + lane, mine * inv);
+  if (lse != nullptr && lane == 0) lse[(b * H + h) * S + q] = mt + __logf(lt);
 }
 
 // left-over rows of the MFMA path and the split of their key range (0 rows: the MFMA kernel takes everything)
@@ -990,6 +1009,7 @@ static inline int mhsa_tail_splits(int B, int S, int H) {
   int64_t n = 4096 / ((int64_t)B * rem * H);
   const int64_t max_split = (S + 255) / 256;  // at least 256 keys per wave
   if (n > max_split) n = max_split;
+  if (n > 128) n = 128;  // the merge kernel holds two partial states per lane
   return (int)(n < 1 ? 1 : n);
 }
 
@@ -1678,12 +1698,12 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
       if (D == 64) {
         hipLaunchKernelGGL(mhsa_tail_kernel<64>, tgrid, tblock, 0, st, static_cast<const bf16_t*>(qkv), ld, S, H, C, window,
                            scale, s_main, rem, n_split, chunk, total, part, dr);
-        hipLaunchKernelGGL(mhsa_tail_merge_kernel<64>, dim3((unsigned)((n_units * 64 + 255) / 256)), dim3(256), 0, st, part,
+        hipLaunchKernelGGL(mhsa_tail_merge_kernel<64>, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, st, part,
                            static_cast<bf16_t*>(out), ldo, lse, S, H, s_main, rem, n_split, n_units);
       } else {
         hipLaunchKernelGGL(mhsa_tail_kernel<32>, tgrid, tblock, 0, st, static_cast<const bf16_t*>(qkv), ld, S, H, C, window,
                            scale, s_main, rem, n_split, chunk, total, part, dr);
-        hipLaunchKernelGGL(mhsa_tail_merge_kernel<32>, dim3((unsigned)((n_units * 32 + 255) / 256)), dim3(256), 0, st, part,
+        hipLaunchKernelGGL(mhsa_tail_merge_kernel<32>, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, st, part,
                            static_cast<bf16_t*>(out), ldo, lse, S, H, s_main, rem, n_split, n_units);
       }
     }
