@@ -981,13 +981,15 @@ __global__ __launch_bounds__(256) void mhsa_tail_merge_kernel(const float* __res
   const float lt = wave_sum((p0 != nullptr ? p0[1] * w0 : 0.f) + (p1 != nullptr ? p1[1] * w1 : 0.f));
   const float inv = lt > 0.f ? 1.0f / lt : 0.f;
   float mine = 0.f;  // lane d keeps output channel d
-  const float* r0 = p0 != nullptr ? p0 + 2 : part;  // (lanes without a state: any valid address, weight 0)
+  const float* r0 = p0 != nullptr ? p0 + 2 : part;  // (lanes without a state: any valid address, the value is discarded)
   const float* r1 = p1 != nullptr ? p1 + 2 : part;
-  const float g0 = p0 != nullptr ? w0 : 0.f, g1 = p1 != nullptr ? w1 : 0.f;
   for (int d0 = 0; d0 < D; d0 += 8) {  // eight channels' loads in flight per round trip
     float t[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = r0[d0 + i] * g0 + r1[d0 + i] * g1;
+    for (int i = 0; i < 8; ++i) {
+      const float a0 = r0[d0 + i], a1 = r1[d0 + i];
+      t[i] = (p0 != nullptr ? a0 * w0 : 0.f) + (p1 != nullptr ? a1 * w1 : 0.f);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float o = wave_sum(t[i]);
