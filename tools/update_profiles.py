@@ -77,7 +77,7 @@ out = {
     "calibration": {"add_kernel": dict(known_read_kb=163848, known_write_kb=81924, **(one("add_kernel") or {})),
                     "layer_norm_kernel": dict(known_read_kb=184800, known_write_kb=184800,
                                               **(one("layer_norm_kernel") or {}))},
-    "kernels": {"linear": merged("linear_bf16_w4_kernel"), "gt_edge_attention": merged("gt_edge_attention_folded_kernel")},
+    "kernels": {"linear": merged("linear_bf16_w4_kernel"), "gt_edge_attention": merged("gt_edge_attention_folded_")},
 }
 with open(os.path.join(dst, f"{tag}_traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
