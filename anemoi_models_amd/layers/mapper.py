@@ -42,8 +42,18 @@ class BaseMapper(nn.Module, ABC):
         self.offload_layers(cpu_offload)
 
     def offload_layers(self, cpu_offload: bool) -> None:
-        if cpu_offload:
-            raise NotImplementedError("cpu_offload is not supported on the MI355X path (288 GB HBM per GPU)")
+        """``cpu_offload=True`` (reference: ``offload_wrapper`` around the layers, layers/mapper.py:64-66 /
+        layers/processor.py:65-67 -- torch's ``OffloadWrapper`` = ``save_on_cpu``): the tensors the differentiable route saves
+        for its backward live in pinned host memory between forward and backward.  Inference is unaffected.  Not under HIP
+        graph capture (the copies synchronise)."""
+        self.cpu_offload = bool(cpu_offload)
+
+    def _offloaded(self):
+        import contextlib
+
+        if getattr(self, "cpu_offload", False):
+            return torch.autograd.graph.save_on_cpu(pin_memory=True)
+        return contextlib.nullcontext()
 
     # ---- the reference's pre / post processing hooks (layers/mapper.py:68-116, 412-418, 690-694) --------------------
     # ``forward`` runs fused launch sequences and does not come through these; they are kept, with the reference's
@@ -246,7 +256,8 @@ class GraphTransformerBaseMapper(GraphEdgeMixin, BaseMapper):
             if size != (x_src.shape[0], x_dst.shape[0]):
                 raise ValueError(f"shard_shapes describe {size} nodes, inputs have {(x_src.shape[0], x_dst.shape[0])}")
         if training.wants_grad(self, x_src, x_dst):
-            return training.gt_mapper(self, x_src, x_dst, batch_size)
+            with self._offloaded():
+                return training.gt_mapper(self, x_src, x_dst, batch_size)
         dtype = runtime.compute_dtype(x_dst)
 
         def prep(t):
@@ -426,7 +437,8 @@ class GNNBaseMapper(GraphEdgeMixin, BaseMapper):
             return x_src, self.post_process(x_dst, shapes_dst, model_comm_group)
         x_src, x_dst = x
         if training.wants_grad(self, x_src, x_dst):
-            return training.gnn_mapper(self, x_src, x_dst, batch_size)
+            with self._offloaded():
+                return training.gnn_mapper(self, x_src, x_dst, batch_size)
         dtype = runtime.compute_dtype(x_dst)
 
         def prep(t):

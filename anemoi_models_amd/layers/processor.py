@@ -36,8 +36,18 @@ class BaseProcessor(nn.Module, ABC):
         ), f"Number of processor layers ({num_layers}) has to be divisible by the number of processor chunks ({num_chunks})."
 
     def offload_layers(self, cpu_offload: bool) -> None:
-        if cpu_offload:
-            raise NotImplementedError("cpu_offload is not supported on the MI355X path (288 GB HBM per GPU)")
+        """``cpu_offload=True`` (reference: ``offload_wrapper`` around the layers, layers/mapper.py:64-66 /
+        layers/processor.py:65-67 -- torch's ``OffloadWrapper`` = ``save_on_cpu``): the tensors the differentiable route saves
+        for its backward live in pinned host memory between forward and backward.  Inference is unaffected.  Not under HIP
+        graph capture (the copies synchronise)."""
+        self.cpu_offload = bool(cpu_offload)
+
+    def _offloaded(self):
+        import contextlib
+
+        if getattr(self, "cpu_offload", False):
+            return torch.autograd.graph.save_on_cpu(pin_memory=True)
+        return contextlib.nullcontext()
 
     def build_layers(self, processor_chunk_class, *args, **kwargs) -> None:
         self.proc = nn.ModuleList([processor_chunk_class(*args, **kwargs) for _ in range(self.num_chunks)])
@@ -101,7 +111,8 @@ class TransformerProcessor(BaseProcessor):
                         x = blk(x, shard_shapes, batch_size, model_comm_group)
                 return x
         if training.wants_grad(self, x):
-            return training.transformer_processor(self, x, batch_size)
+            with self._offloaded():
+                return training.transformer_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)
@@ -166,7 +177,8 @@ class GNNProcessor(GraphEdgeMixin, BaseProcessor):
                                      size=(target_nodes, target_nodes))
             return x
         if training.wants_grad(self, x):
-            return training.gnn_processor(self, x, batch_size)
+            with self._offloaded():
+                return training.gnn_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)
@@ -364,7 +376,8 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
                                        model_comm_group, size=(n_all, n_all))
             return x
         if training.wants_grad(self, x):
-            return training.gt_processor(self, x, batch_size)
+            with self._offloaded():
+                return training.gt_processor(self, x, batch_size)
         dtype = runtime.compute_dtype(x)
         xin = x if x.dtype == dtype else x.to(dtype)
         return self.native(xin if xin.stride(-1) == 1 else xin.contiguous(), batch_size)

@@ -177,6 +177,34 @@ def test_checkpointing_reproduces_the_gradients_bit_for_bit(graph_o32, golden_cf
     assert res["1"][2] < 0.6 * res["0"][2], (res["1"][2], res["0"][2])
 
 
+def test_cpu_offload_keeps_the_gradients(graph_o32, golden_cfg1_gt):
+    """``cpu_offload=True`` of the mappers / processor (reference layers/mapper.py:64-66, layers/processor.py:65-67:
+    ``offload_wrapper``): the tensors saved for the backward travel through pinned host memory; loss and every parameter
+    gradient are bit-identical to the run without it."""
+    from test_gpu_parity import _build, split_prefix
+
+    model, _ = _build(graph_o32, 64, 4)
+    model.load_state_dict(split_prefix(golden_cfg1_gt, "sd."))
+    model = model.to(DEV).train()
+    x = golden_cfg1_gt["x"].to(DEV)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = (model(x) ** 2).mean()
+        loss.backward()
+        return loss.detach().clone(), [p.grad.clone() for p in params]
+
+    base_loss, base_grads = step()
+    for m in (model.encoder, model.processor, model.decoder):
+        m.offload_layers(True)
+    off_loss, off_grads = step()
+    assert torch.equal(off_loss, base_loss)
+    for a, b in zip(off_grads, base_grads):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("checkpoint", ["1", "0"])
 def test_graphed_train_step_with_attention_dropout_equals_eager(graph_o32, monkeypatch, checkpoint):
     """``TransformerProcessor``'s default attention dropout (reference layers/processor.py:99: 0.1) inside a captured step:
