@@ -21,6 +21,15 @@
 
 #include "common.hpp"
 
+// Lab switches (tools/micro/ab_gemm.sh): cache-policy bits of the slab DMAs (buffer_load ... lds aux: 1 = sc0, 2 = nt,
+// 16 = sc1).  The product builds with 0 / 0.
+#ifndef ANEMOI_LAB_X_AUX
+#define ANEMOI_LAB_X_AUX 0
+#endif
+#ifndef ANEMOI_LAB_W_AUX
+#define ANEMOI_LAB_W_AUX 0
+#endif
+
 namespace anemoi {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -501,12 +510,12 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   };
   auto dma_x = [&](int i, int kt, char* dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, vox[i & 1],
-                                             xwave + (i >> 1) * xrow16 + kt * ROW_BYTES, 0, 0);
+                                             xwave + (i >> 1) * xrow16 + kt * ROW_BYTES, 0, ANEMOI_LAB_X_AUX);
   };
   auto dma_w = [&](int i, int kt, char* dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, vow[i & 1],
                                              wwave + (32 * (i >> 2) + 16 * (i & 1) + 4 * ((i >> 1) & 1)) * K * 2 + kt * ROW_BYTES,
-                                             0, 0);
+                                             0, ANEMOI_LAB_W_AUX);
   };
   // LDS image of a slab: x panel rows 0 .. TM-1 at the stage base (wave w: rows w * MH * 8 ...), W panel at + 32 KiB
   auto stage_all = [&](int kt, int buf) {
