@@ -631,8 +631,6 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         (see ``GraphTransformerProcessorBlock._sharded``)."""
         from .. import autograd
 
-        if self.update_src_nodes:
-            raise NotImplementedError("update_src_nodes=True across a model group (the reference's mappers use False)")
         x_src, x_dst = x
         dtype = runtime.compute_dtype(x_dst)
         x_src, x_dst = _as_compute(x_src, dtype), _as_compute(x_dst, dtype)
@@ -648,7 +646,9 @@ class GraphTransformerMapperBlock(GraphTransformerBaseBlock):
         out = self.conv(q, k, v, e, edge_index, size=size)
         out = self.shard_output_seq(out, shapes, batch_size, model_comm_group)
         out = autograd.linear(out + x_r, self.projection.weight, self.projection.bias, "Identity", x_dst)
-        return x_src, training.sequential(self.node_dst_mlp, out, residual=out)
+        # update_src_nodes: row-local on whatever source rows this rank holds (reference layers/block.py:540-546)
+        new_src = training.sequential(self.node_src_mlp, x_src, residual=x_src) if self.update_src_nodes else x_src
+        return new_src, training.sequential(self.node_dst_mlp, out, residual=out)
 
     def forward(
         self,

@@ -116,7 +116,12 @@ class AnemoiModelEncProcDecHierarchical(AnemoiModelEncProcDec):
 
     def forward(self, x: Tensor, model_comm_group=None) -> Tensor:
         if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("the hierarchical model has no node-partitioned forward yet")
+            # The reference's own composition does not run there either: ``downscale`` is a forward mapper, whose
+            # pre-processing splits its source by the FULL shard shapes (layers/mapper.py:108-111 -> torch.split in
+            # distributed/primitives.py:49) although the level input is already a shard (models/hierarchical.py:236-244),
+            # and the gathered output of ``upscale`` (layers/mapper.py:99-102) is added to the sharded skip (:272).
+            raise NotImplementedError("the hierarchical model does not run across a model group (neither does the "
+                                      "reference's: its level mappers split already-sharded rows)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .. import training
 

@@ -141,8 +141,6 @@ def gt_processor_block(block, x: Tensor, edge_attr: Tensor, edge_index: Tensor, 
 
 def gt_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None):
     """``GraphTransformerMapperBlock.forward`` (reference layers/block.py:479-550)."""
-    if block.update_src_nodes:
-        raise NotImplementedError("update_src_nodes=True has no differentiable route (the reference's mappers use False)")
     x_src, x_dst = x
     dtype = runtime.compute_dtype(x_dst)
     n_src, n_dst = x_src.shape[0], x_dst.shape[0]
@@ -152,6 +150,9 @@ def gt_mapper_block(block, x, edge_attr: Tensor, edge_index: Tensor, size=None):
     plan, ea = _gt_edge_inputs(block, edge_attr, edge_index, n_src, n_dst)
     y = autograd.gt_mapper_block(_cast(x_src, dtype), _cast(x_dst, dtype), _block_sd(block), "b", ea, plan, block.num_heads,
                                  block.activation, block.layer_norm1.eps)
+    if block.update_src_nodes:  # row-local MLP of the source rows (reference layers/block.py:540-546)
+        xs = _cast(x_src, dtype)
+        return (sequential(block.node_src_mlp, xs, residual=xs), y), edge_attr
     return (x_src, y), edge_attr
 
 

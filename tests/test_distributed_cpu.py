@@ -397,6 +397,22 @@ def _sharded_gt_worker(rank, world, port, result_file):
             want, _ = blk(x, ea, ei, (None, None, None), 1)
             got, _ = blk(x[rows].contiguous(), ea[edges].contiguous(), ei, (sx, sx, se), 1, g, size=(n, n))
         err = float((got - want[rows]).abs().max())
+        # the mapper block with update_src_nodes (reference layers/block.py:540-546: the source MLP runs on the source rows a
+        # rank holds): 30 sources -> 45 destinations
+        from anemoi_models_amd.layers.block import GraphTransformerMapperBlock
+
+        n_s = 30
+        xs_ = torch.randn(n_s, c, generator=gen)
+        ei2 = torch.stack([torch.randint(0, n_s, (n_e,), generator=gen), torch.randint(0, n, (n_e,), generator=gen)])
+        mblk = GraphTransformerMapperBlock(c, 2 * c, c, edge_dim=edge_dim, num_heads=heads, update_src_nodes=True).eval()
+        ss = get_shape_shards(xs_, 0, g)
+        srows = slice(sum(s[0] for s in ss[:rank]), sum(s[0] for s in ss[:rank + 1]))
+        with torch.no_grad():
+            (want_s, want_d), _ = mblk((xs_, x), ea, ei2, (None, None, None), 1, size=(n_s, n))
+            (got_s, got_d), _ = mblk((xs_[srows].contiguous(), x[rows].contiguous()), ea[edges].contiguous(), ei2,
+                                     (ss, sx, se), 1, g, size=(n_s, n))
+        err = max(err, float((got_d - want_d[rows]).abs().max()), float((got_s - want_s[srows]).abs().max()),
+                  0.0 if float((want_s - xs_).abs().max()) > 1e-3 else 1e9)  # (the source rows really were updated)
         # the processor on a real sub-graph (its own edge buffers and trainable edge tensor)
         graph = build_graph("o32_ico2")
         sub = graph[("hidden", "to", "hidden")]

@@ -152,6 +152,45 @@ def test_block_level_backward_like_the_reference_tests(golden_blocks):
     _compare_block_grads(blk, rsd)
 
 
+def test_mapper_block_update_src_nodes_trains(golden_blocks):
+    """``GraphTransformerMapperBlock(update_src_nodes=True)`` (reference layers/block.py:540-546: ``node_src_mlp(x_src) +
+    x_src``, row-local): the differentiable route returns the updated sources -- same values as the inference route, the
+    gradients of the source MLP against torch's own autograd of that stack in f64."""
+    from anemoi_models_amd.layers.block import GraphTransformerMapperBlock
+
+    b = golden_blocks
+    torch.manual_seed(11)
+    blk = GraphTransformerMapperBlock(64, 256, 64, edge_dim=b["gtm.edge_attr"].shape[1], num_heads=16,
+                                      update_src_nodes=True).to(DEV)
+    ea, ei = b["gtm.edge_attr"].to(DEV), b["gtm.edge_index"].to(DEV)
+    xs, xd = b["gtm.x_src"].to(DEV), b["gtm.x_dst"].to(DEV)
+    size = (xs.shape[0], xd.shape[0])
+    with torch.no_grad():
+        (want_s, want_d), _ = blk.eval()((xs, xd), ea, ei, None, 1, size=size)
+    blk.train()
+    xs_g, xd_g = xs.clone().requires_grad_(), xd.clone().requires_grad_()
+    (got_s, got_d), _ = blk((xs_g, xd_g), ea, ei, None, 1, size=size)
+    assert rel_err(got_s.detach(), want_s) < 1e-5 and rel_err(got_d.detach(), want_d) < 1e-5
+    assert rel_err(got_s.detach(), xs) > 1e-3  # (really updated)
+    w = torch.randn_like(got_s)
+    ((got_s * w).sum() + got_d.sum()).backward()
+    import copy
+
+    mlp64 = copy.deepcopy(blk.node_src_mlp).double()
+    for q in mlp64.parameters():
+        q.grad = None
+    xr = xs.double().requires_grad_()
+    ((mlp64(xr) + xr) * w.double()).sum().backward()
+    for (name, p_), q in zip(blk.node_src_mlp.named_parameters(), mlp64.parameters()):
+        assert p_.grad is not None and rel_err(p_.grad, q.grad) < 2e-3, name
+    # d x_src = the source MLP's path + the k / v path of the attention: the former alone when the destination loss is dropped
+    blk.zero_grad()
+    xs_g2 = xs.clone().requires_grad_()
+    (got_s2, _), _ = blk((xs_g2, xd), ea, ei, None, 1, size=size)
+    (got_s2 * w).sum().backward()
+    assert rel_err(xs_g2.grad, xr.grad) < 2e-3
+
+
 def test_checkpointing_reproduces_the_gradients_bit_for_bit(graph_o32, golden_cfg1_gt, monkeypatch):
     """Mapper calls and processor chunks are recomputed in the backward (as the reference checkpoints them); all kernels
     are deterministic, so the gradients equal those of the run that kept every activation -- and less memory is held."""
