@@ -536,12 +536,26 @@ class _GTConv(torch.autograd.Function):
 def gt_conv(q: Tensor, k: Tensor, v: Tensor, e_csr: Tensor, x_r: Optional[Tensor], plan, num_heads: int) -> Tensor:
     """Differentiable ``ops.gt_conv``: gradients for ``q, k, v`` (``k`` / ``v`` slices of one buffer), the per-edge
     features ``e_csr [E, C]`` and ``x_r``."""
+    if _edge_phase_in_f32(q.dtype, q.shape[1], num_heads):
+        kv, c = torch.cat([k, v], dim=1).float(), q.shape[1]
+        return _GTConv.apply(q.float(), kv[:, :c], kv[:, c:], e_csr.float(), None if x_r is None else x_r.float(), plan,
+                             num_heads).to(q.dtype)
     return _GTConv.apply(q, k, v, e_csr, x_r, plan, num_heads)
+
+
+def _edge_phase_in_f32(dtype: torch.dtype, c: int, num_heads: int) -> bool:
+    """bf16 head sizes that are a multiple of 4 but not of 8 (BASELINE config 1: 64 channels / 16 heads): the bf16 edge
+    kernels move 8 channels per lane, so the edge phase of such a block runs on the f32 kernels (4 channels per lane) between
+    two casts -- the GEMMs around it stay bf16.  Tiny heads mean a tiny model: the casts cost nothing that matters."""
+    d = c // num_heads
+    return dtype == torch.bfloat16 and d % 8 != 0 and d % 4 == 0
 
 
 def gt_edge_attention_packed(sq: Tensor, kv: Tensor, edge_attr: Tensor, plan, num_heads: int, up: int) -> Tensor:
     """:func:`gt_edge_attention` on the packed GEMM results ``sq = x_r | q | u`` ``[n_dst, 2C + H*up]`` and
     ``kv = k | v`` ``[n_src, 2C]`` (the mapper blocks' layout): gradients arrive as one ``d sq`` and one ``d kv``."""
+    if _edge_phase_in_f32(sq.dtype, kv.shape[1] // 2, num_heads):
+        return _GTEdgeAttentionMapper.apply(sq.float(), kv.float(), edge_attr, plan, num_heads, up).to(sq.dtype)
     return _GTEdgeAttentionMapper.apply(sq, kv, edge_attr, plan, num_heads, up)
 
 
@@ -549,6 +563,11 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
                       num_heads: int, up: int) -> Tensor:
     """Differentiable ``ops.gt_edge_attention_folded``: ``[n_dst, C + H*up] = [sum alpha v (+ x_r) | sum alpha a]`` with
     gradients for ``q, k, v, x_r, u`` (compute dtype) and ``edge_attr`` (f32 ``[E, up]``, CSR order of ``plan``)."""
+    if _edge_phase_in_f32(q.dtype, q.shape[1], num_heads):
+        kv = torch.cat([k, v], dim=1).float()  # (the kernels want k and v as column ranges of one buffer)
+        c = q.shape[1]
+        return _GTEdgeAttention.apply(q.float(), kv[:, :c], kv[:, c:], None if x_r is None else x_r.float(), u.float(),
+                                      edge_attr, plan, num_heads, up).to(q.dtype)
     return _GTEdgeAttention.apply(q, k, v, x_r, u, edge_attr, plan, num_heads, up)
 
 
@@ -708,7 +727,10 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
     b_in = torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias"), b_u], 0)
     xh, x = layer_norm_skip(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
     sq = linear(xh, w_in, b_in)  # x_r | q | k | v | u
-    att = _GTEdgeAttentionSelf.apply(sq, edge_attr_csr, plan, h, up)
+    if _edge_phase_in_f32(sq.dtype, (sq.shape[1] - h * up) // 4, h):
+        att = _GTEdgeAttentionSelf.apply(sq.float(), edge_attr_csr, plan, h, up).to(sq.dtype)
+    else:
+        att = _GTEdgeAttentionSelf.apply(sq, edge_attr_csr, plan, h, up)
     return _gt_tail(att, x, sd, prefix, w_t, act, eps)
 
 

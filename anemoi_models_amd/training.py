@@ -114,7 +114,7 @@ def _block_sd(block: nn.Module) -> dict:
 
 
 def _check_heads(channels: int, num_heads: int, dtype: torch.dtype) -> None:
-    vec = 16 // torch.empty((), dtype=dtype).element_size()
+    vec = 4  # f32: 4 channels per lane; bf16: 8, head sizes 4 (mod 8) take the f32 edge kernels (autograd._edge_phase_in_f32)
     if (channels // num_heads) % vec != 0:
         raise NotImplementedError(f"graph-transformer training needs a head size that is a multiple of {vec} for {dtype} "
                                   f"(got {channels} channels / {num_heads} heads)")

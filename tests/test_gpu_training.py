@@ -216,6 +216,54 @@ def test_checkpointing_reproduces_the_gradients_bit_for_bit(graph_o32, golden_cf
     assert res["1"][2] < 0.6 * res["0"][2], (res["1"][2], res["0"][2])
 
 
+def test_bf16_training_at_head_size_4(graph_o32, golden_cfg1_gt, monkeypatch):
+    """BASELINE config 1 (64 channels, 16 heads: head size 4) trains in bf16: the bf16 edge kernels move 8 channels per lane,
+    so the edge phases of its blocks run on the f32 kernels between two casts (``autograd._edge_phase_in_f32``), every GEMM
+    stays bf16.  Loss and gradients against the f32 training step of the same weights (itself held to the oracle's autograd
+    by the tests above); blocks with the explicit-edge conv (edge_dim 39) against the oracle directly."""
+    from test_gpu_parity import _build, split_prefix
+    from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
+
+    gold = golden_cfg1_gt
+    x = gold["x"].to(DEV)
+    dy = torch.randn(gold["y"].shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        monkeypatch.setenv("ANEMOI_AMD_DTYPE", mode)
+        model, _ = _build(graph_o32, 64, 4)
+        model.load_state_dict(split_prefix(gold, "sd."))
+        model = model.to(DEV).train()
+        y = model(x)
+        y.backward(dy)
+        res[mode] = (y.detach().float().clone(), {k: p.grad.float().clone() for k, p in model.named_parameters()
+                                                   if p.grad is not None})
+    assert rel_err(res["fp32"][0], gold["y"]) < 1e-4
+    assert rel_err(res["bf16"][0], gold["y"]) < 5e-2
+    assert set(res["bf16"][1]) == set(res["fp32"][1])
+    scale_all = max(float(g.abs().max()) for g in res["fp32"][1].values())
+    for k, g32 in res["fp32"][1].items():
+        err = float((res["bf16"][1][k] - g32).abs().max())
+        assert err <= 8e-2 * max(float(g32.abs().max()), 0.05 * scale_all), (k, err, float(g32.abs().max()))
+    # explicit per-edge features (edge_dim beyond the fold), head size 4, bf16
+    g = torch.Generator().manual_seed(40)
+    c, h, edge_dim, n, e = 64, 16, 39, 120, 900
+    torch.manual_seed(6)
+    blk = GraphTransformerProcessorBlock(c, 2 * c, c, edge_dim=edge_dim, num_heads=h)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n - 1, (e,), generator=g)])
+    x0, ea0 = torch.randn(n, c, generator=g), torch.randn(e, edge_dim, generator=g)
+    rsd = {"x." + k: v.detach().double().requires_grad_() for k, v in blk.named_parameters()}
+    xr = x0.double().requires_grad_()
+    want = ref.gt_processor_block(rsd, "x", xr, ea0.double(), ei, h)
+    want.sum().backward()
+    blk = blk.to(DEV)
+    xg = x0.to(DEV).requires_grad_()
+    yb, _ = blk(xg, ea0.to(DEV), ei.to(DEV), None, 1)
+    assert rel_err(yb.detach(), want.detach()) < 8e-2
+    yb.sum().backward()
+    assert rel_err(xg.grad, xr.grad) < 8e-2
+    _compare_block_grads(blk, rsd, tol=8e-2)
+
+
 def test_cpu_offload_keeps_the_gradients(graph_o32, golden_cfg1_gt):
     """``cpu_offload=True`` of the mappers / processor (reference layers/mapper.py:64-66, layers/processor.py:65-67:
     ``offload_wrapper``): the tensors saved for the backward travel through pinned host memory; loss and every parameter
