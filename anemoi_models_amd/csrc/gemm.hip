@@ -445,9 +445,10 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   constexpr int TM = MH * 32;        // tile rows
   constexpr int NS = 8 * MH;         // MFMAs per 32-deep K step
   constexpr int NRD = 8 + MH;        // fragment reads per K step = LDS-DMA instructions per slab and wave
-  constexpr int G1 = MH == 8 ? 23 : MH == 6 ? 17 : MH == 5 ? 16 : 15, SP = MH == 8 ? 5 : MH == 4 ? 3 : 4,
-                G2 = MH == 8 ? 103 : MH == 6 ? 78 : MH == 5 ? 66 : 51;  // schedule (see below)
-  static_assert(MH == 4 || MH == 5 || MH == 6 || MH == 8, "tile heights with a measured slab schedule");
+  constexpr int G1 = MH == 8 ? 23 : MH == 6 ? 17 : MH == 5 ? 16 : MH == 4 ? 15 : 13,
+                SP = MH == 8 ? 5 : MH == 4 ? 3 : MH == 3 ? 2 : 4,
+                G2 = MH == 8 ? 103 : MH == 6 ? 78 : MH == 5 ? 66 : MH == 4 ? 51 : 36;  // schedule (see below)
+  static_assert(MH == 3 || MH == 4 || MH == 5 || MH == 6 || MH == 8, "tile heights with a measured slab schedule");
   static_assert(G1 + 1 + (NRD - 1) * SP < G2 && G2 + NRD < 2 * NS, "slab schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -905,6 +906,8 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 5>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
       hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 4>),  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess ||    \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, RES, LNF, 3>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)      \
     return fail(ANEMOI_ERR_LAUNCH, "anemoi_linear: cannot raise the dynamic LDS limit to %d", W4_LDS)
 #define RAISE_W4(A, RES) \
@@ -930,6 +933,10 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     RAISE_W4_RS(false, true, 4);
     RAISE_W4_RS(true, false, 4);
     RAISE_W4_RS(true, true, 4);
+    RAISE_W4_RS(false, false, 3);
+    RAISE_W4_RS(false, true, 3);
+    RAISE_W4_RS(true, false, 3);
+    RAISE_W4_RS(true, true, 3);
 #undef RAISE_W4_RS
 #define RAISE_W4_DUAL(A, MHV)                                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_w4_kernel<A, false, false, MHV, false, true>), \
@@ -1060,13 +1067,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     // (5121 x 2048: 160 / 216 / 256 / 320 tiles -> 160-row tiles fill the chip exactly once;
     //  5121 x 4096: 320 / 432 / 512 / 640 -> two balanced rounds of 160-row tiles; profiles/r04_gemm_small_m.txt).
     if (!batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
-      static const int forced_mh = [] {  // lab switch for A/B runs: ANEMOI_AMD_GEMM_MH=4|5|6|8
+      static const int forced_mh = [] {  // lab switch for A/B runs: ANEMOI_AMD_GEMM_MH=3|4|5|6|8
         const char* e = getenv("ANEMOI_AMD_GEMM_MH");
         return e != nullptr ? atoi(e) : 0;
       }();
       int best_mh = 8;
       double best_cost = 1e30;
-      for (const int mh : {8, 6, 5, 4}) {
+      for (const int mh : {8, 6, 5, 4, 3}) {
         const int64_t tiles = (M + 32 * mh - 1) / (32 * mh) * nt, rounds = (tiles + max_blocks - 1) / max_blocks;
         const double cost = (double)rounds * (0.8125 * mh + (K / 64) * 1.44 * (32 * mh + 256) / 512.0);
         if (forced_mh == mh || (forced_mh == 0 && cost < best_cost * 0.97)) {  // (3 %: ties go to the taller tile)
@@ -1080,6 +1087,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
         w4_blocks = tiles < max_blocks ? (tiles + 7) / 8 * 8 : max_blocks;
         if (best_mh == 6) { LAUNCH_W4_PLAIN(6, xb, rb, yb, ln, M, tiles, w4_tail) }
         else if (best_mh == 5) { LAUNCH_W4_PLAIN(5, xb, rb, yb, ln, M, tiles, w4_tail) }
+        else if (best_mh == 3) { LAUNCH_W4_PLAIN(3, xb, rb, yb, ln, M, tiles, w4_tail) }
         else { LAUNCH_W4_PLAIN(4, xb, rb, yb, ln, M, tiles, w4_tail) }
         mt_a = 0;  // done
       }

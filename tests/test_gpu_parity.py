@@ -1674,8 +1674,8 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
 @pytest.mark.parametrize("m,n,k,act,res,fold", [
     (40962, 1024, 4096, "Identity", True, False),   # 640 tiles = 2.5 rounds: remainder rows as half tiles
     (5121, 4096, 1024, "GELU", False, True),        # 320 tiles = 1.25 rounds -> 512 tiles of 160 rows (LayerNorm fold)
-    (5121, 1024, 4096, "Identity", True, False),    # 80 tiles: the whole problem as half tiles
-    (5121, 1024, 1216, "Identity", True, False),    # K = 19 slabs
+    (5121, 1024, 4096, "Identity", True, False),    # 80 tiles -> 216 tiles of 96 rows (MH = 3), ragged last row tile
+    (5121, 1024, 1216, "Identity", True, False),    # K = 19 slabs, 96-row tiles
     (2304, 1024, 512, "SiLU", False, False),        # 36 tiles: 4 or 5 per XCD
     (70000, 1024, 1024, "Identity", False, False),  # ragged last row tile
     (5121, 2048, 1024, "Identity", True, False),    # 160 tiles -> 256 tiles of 160 rows (MH = 5), residual + row statistics
@@ -1687,6 +1687,10 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
     (4960, 4096, 1024, "GELU", False, False),       # 31 * 160 rows: 496 tiles, two rounds of 160-row tiles
     (5569, 2048, 1024, "Identity", False, True),    # own + halo rows of a rank's k | v product: 192-row tiles (30 x 8)
     (10242, 2240, 512, "Identity", False, True),    # config 2's x_r | q | k | v | u product
+    (10242, 512, 2048, "Identity", True, False),    # config 2's fc2: 80 tiles -> 214 of 96 rows (MH = 3), residual + row statistics
+    (10242, 512, 640, "Identity", True, False),     # config 2's projection (K = 10 slabs), 96-row tiles
+    (4608, 1024, 2048, "GELU", False, True),        # 48 * 96 rows exactly (MH = 3: odd waves start mid swizzle period), LN fold
+    (5121, 1024, 2048, "SiLU", True, False),        # 96-row tiles, activation + residual
 ])
 def test_linear_remainder_round_shapes(m, n, k, act, res, fold):
     """Shapes whose tile count leaves a short remainder round on the 256 CUs (full mesh and per-rank sizes of config 3):
