@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -134,6 +134,10 @@ SIGNATURES = {
                                       c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "anemoi_finalize_output": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anemoi_assemble_node_rows": (c_int, [c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_int,
+                                          c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "anemoi_finalize_output_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anemoi_bound_output": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "anemoi_prognostic_residual": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p,

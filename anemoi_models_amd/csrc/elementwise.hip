@@ -239,17 +239,18 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(const float* __rest
                                                              int n_ll, const float* __restrict__ trainable, int n_tr,
                                                              T* __restrict__ out, int64_t ldo,
                                                              const float* __restrict__ in_mul,
-                                                             const float* __restrict__ in_add) {
-  const int64_t total = (int64_t)B * Ens * G * ldo;
+                                                             const float* __restrict__ in_add,
+                                                             const int64_t* __restrict__ rows, int64_t n_rows) {
+  const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * ldo;
   const int tv = T_ * V;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = idx / ldo;
     const int c = (int)(idx - row * ldo);
-    const int64_t g = row % G;
+    const int64_t g = rows != nullptr ? rows[row] : row % G;
     float val = 0.f;
     if (c < tv) {
-      const int64_t be = row / G;
+      const int64_t be = rows != nullptr ? 0 : row / G;
       const int e = (int)(be % Ens);
       const int64_t b = be / Ens;
       const int t = c / V, v = c - t * V;
@@ -273,15 +274,17 @@ __global__ __launch_bounds__(256) void assemble_nodes8_kernel(const float* __res
                                                               int n_ll, const float* __restrict__ trainable, int n_tr,
                                                               T* __restrict__ out, int ldo8,
                                                               const float* __restrict__ in_mul,
-                                                              const float* __restrict__ in_add) {
-  const int64_t total = (int64_t)B * Ens * G * ldo8;
+                                                              const float* __restrict__ in_add,
+                                                              const int64_t* __restrict__ rows, int64_t n_rows) {
+  // rows != nullptr (anemoi_assemble_node_rows, B = Ens = 1): output row i is grid node rows[i]
+  const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * ldo8;
   const int tv = T_ * V;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = idx / ldo8;
     const int c0 = (int)(idx - row * ldo8) * 8;
-    const int64_t g = row % G;
-    const int64_t be = row / G;
+    const int64_t g = rows != nullptr ? rows[row] : row % G;
+    const int64_t be = rows != nullptr ? 0 : row / G;
     const int e = (int)(be % Ens);
     const int64_t b = be / Ens;
     float val[8];
@@ -471,8 +474,10 @@ __global__ __launch_bounds__(256) void finalize_output_kernel(float* __restrict_
                                                               const float* __restrict__ in_mul,
                                                               const float* __restrict__ in_add,
                                                               const float* __restrict__ out_mul,
-                                                              const float* __restrict__ out_add) {
-  const int64_t total = (int64_t)B * Ens * G * V_out;
+                                                              const float* __restrict__ out_add,
+                                                              const int64_t* __restrict__ rows, int64_t n_rows) {
+  // rows != nullptr (anemoi_finalize_output_rows, B = Ens = 1): y holds n_rows rows, row i is grid node rows[i]
+  const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * V_out;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = idx / V_out;  // (b, ens, g)
@@ -480,8 +485,8 @@ __global__ __launch_bounds__(256) void finalize_output_kernel(float* __restrict_
     float val = y[idx];
     const int sv = src[c];
     if (sv >= 0) {
-      const int64_t g = row % G;
-      const int64_t be = row / G;
+      const int64_t g = rows != nullptr ? rows[row] : row % G;
+      const int64_t be = rows != nullptr ? 0 : row / G;
       const int e = (int)(be % Ens);
       const int64_t b = be / Ens;
       float xv = x[((((b * T_ + (T_ - 1)) * Ens + e) * G) + g) * V_in + sv];
@@ -592,9 +597,9 @@ int anemoi_row_stats(int dtype, const void* x, int64_t ldx, float* stats, int64_
   return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_row_stats: dtype %d", dtype);
 }
 
-int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
-                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo, const float* in_mul,
-                          const float* in_add, anemoi_stream_t stream) {
+static int assemble_nodes_impl(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
+                               int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo, const float* in_mul,
+                               const float* in_add, const int64_t* rows, int64_t n_rows, anemoi_stream_t stream) {
   ANEMOI_REQUIRE((in_mul == nullptr) == (in_add == nullptr), ANEMOI_ERR_INVALID,
                  "anemoi_assemble_nodes: in_mul and in_add come together");
   ANEMOI_REQUIRE(out && B > 0 && Ens > 0 && G >= 0 && T >= 0 && V >= 0 && n_ll >= 0 && n_tr >= 0, ANEMOI_ERR_INVALID,
@@ -603,28 +608,45 @@ int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int6
   ANEMOI_REQUIRE((latlons != nullptr) || n_ll == 0, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: latlons is null");
   ANEMOI_REQUIRE((trainable != nullptr) || n_tr == 0, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: trainable is null");
   ANEMOI_REQUIRE(ldo >= (int64_t)T * V + n_ll + n_tr, ANEMOI_ERR_INVALID, "anemoi_assemble_nodes: ldo too small");
-  const int64_t total = (int64_t)B * Ens * G * ldo;
+  const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * ldo;
   if (total == 0) return ANEMOI_OK;
   hipStream_t st = as_stream(stream);
   if (ldo % 8 == 0 && ldo < ((int64_t)1 << 31) && (uintptr_t)out % 16 == 0 && (dtype == ANEMOI_F32 || dtype == ANEMOI_BF16)) {
     const int ldo8 = (int)(ldo / 8);
     if (dtype == ANEMOI_F32)
       hipLaunchKernelGGL((assemble_nodes8_kernel<float>), dim3(flat_grid(total / 8)), dim3(256), 0, st, x, B, T, Ens, G,
-                         V, latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo8, in_mul, in_add);
+                         V, latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo8, in_mul, in_add, rows, n_rows);
     else
       hipLaunchKernelGGL((assemble_nodes8_kernel<bf16_t>), dim3(flat_grid(total / 8)), dim3(256), 0, st, x, B, T, Ens, G,
-                         V, latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo8, in_mul, in_add);
+                         V, latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo8, in_mul, in_add, rows, n_rows);
     return check_launch("anemoi_assemble_nodes");
   }
   if (dtype == ANEMOI_F32)
     hipLaunchKernelGGL((assemble_nodes_kernel<float>), dim3(flat_grid(total)), dim3(256), 0, st, x, B, T, Ens, G, V,
-                       latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo, in_mul, in_add);
+                       latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo, in_mul, in_add, rows, n_rows);
   else if (dtype == ANEMOI_BF16)
     hipLaunchKernelGGL((assemble_nodes_kernel<bf16_t>), dim3(flat_grid(total)), dim3(256), 0, st, x, B, T, Ens, G, V,
-                       latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo, in_mul, in_add);
+                       latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo, in_mul, in_add, rows, n_rows);
   else
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_assemble_nodes: dtype %d", dtype);
   return check_launch("anemoi_assemble_nodes");
+}
+
+int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int64_t G, int V, const float* latlons,
+                          int n_ll, const float* trainable, int n_tr, void* out, int64_t ldo, const float* in_mul,
+                          const float* in_add, anemoi_stream_t stream) {
+  return assemble_nodes_impl(dtype, x, B, T, Ens, G, V, latlons, n_ll, trainable, n_tr, out, ldo, in_mul, in_add, nullptr, 0,
+                             stream);
+}
+
+int anemoi_assemble_node_rows(int dtype, const float* x, int T, int64_t G, int V, const float* latlons, int n_ll,
+                              const float* trainable, int n_tr, const int64_t* rows, int64_t n_rows, void* out,
+                              int64_t ldo, const float* in_mul, const float* in_add, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && (rows != nullptr || n_rows == 0), ANEMOI_ERR_INVALID,
+                 "anemoi_assemble_node_rows: null row list");
+  if (n_rows == 0) return ANEMOI_OK;
+  return assemble_nodes_impl(dtype, x, 1, T, 1, G, V, latlons, n_ll, trainable, n_tr, out, ldo, in_mul, in_add, rows, n_rows,
+                             stream);
 }
 
 int anemoi_edge_attr_csr(const float* a0, int d0, const float* a1, int d1, int64_t rows0, const int32_t* perm,
@@ -738,18 +760,33 @@ int anemoi_advance_input(float* x, int B, int T, int Ens, int64_t G, int V_in, c
   return check_launch("anemoi_advance_input");
 }
 
-int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
-                           const int32_t* src, const float* in_mul, const float* in_add, const float* out_mul,
-                           const float* out_add, anemoi_stream_t stream) {
+static int finalize_output_impl(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
+                                const int32_t* src, const float* in_mul, const float* in_add, const float* out_mul,
+                                const float* out_add, const int64_t* rows, int64_t n_rows, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(y && x && src && B > 0 && T > 0 && Ens > 0 && G >= 0 && V_in > 0 && V_out > 0, ANEMOI_ERR_INVALID,
                  "anemoi_finalize_output: bad argument");
   ANEMOI_REQUIRE((in_mul == nullptr) == (in_add == nullptr) && (out_mul == nullptr) == (out_add == nullptr),
                  ANEMOI_ERR_INVALID, "anemoi_finalize_output: mul and add come together");
-  const int64_t total = (int64_t)B * Ens * G * V_out;
+  const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * V_out;
   if (total == 0) return ANEMOI_OK;
   hipLaunchKernelGGL(finalize_output_kernel, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), y, V_out, x, B, T,
-                     Ens, G, V_in, src, in_mul, in_add, out_mul, out_add);
+                     Ens, G, V_in, src, in_mul, in_add, out_mul, out_add, rows, n_rows);
   return check_launch("anemoi_finalize_output");
+}
+
+int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
+                           const int32_t* src, const float* in_mul, const float* in_add, const float* out_mul,
+                           const float* out_add, anemoi_stream_t stream) {
+  return finalize_output_impl(y, V_out, x, B, T, Ens, G, V_in, src, in_mul, in_add, out_mul, out_add, nullptr, 0, stream);
+}
+
+int anemoi_finalize_output_rows(float* y, int V_out, const float* x, int T, int64_t G, int V_in, const int32_t* src,
+                                const int64_t* rows, int64_t n_rows, const float* in_mul, const float* in_add,
+                                const float* out_mul, const float* out_add, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(n_rows >= 0 && (rows != nullptr || n_rows == 0), ANEMOI_ERR_INVALID,
+                 "anemoi_finalize_output_rows: null row list");
+  if (n_rows == 0) return ANEMOI_OK;
+  return finalize_output_impl(y, V_out, x, 1, T, 1, G, V_in, src, in_mul, in_add, out_mul, out_add, rows, n_rows, stream);
 }
 
 int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int32_t* op_col, const float* op_lo,
@@ -767,7 +804,7 @@ int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int3
   return check_launch("anemoi_bound_output");
 }
 
-int anemoi_abi_version(void) { return 35; }
+int anemoi_abi_version(void) { return 36; }
 
 #ifndef ANEMOI_HIPCC_VERSION
 #define ANEMOI_HIPCC_VERSION "unknown (built without anemoi_models_amd/_build.py)"

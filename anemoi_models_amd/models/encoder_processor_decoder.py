@@ -177,20 +177,22 @@ class AnemoiModelEncProcDec(nn.Module):
 
         return {"one_cols": (src, dst)} if isinstance(mapper, GraphTransformerBaseMapper) else {}
 
-    def _finish(self, y: Tensor, x: Tensor, input_affine=None, output_affine=None) -> Tensor:
+    def _finish(self, y: Tensor, x: Tensor, input_affine=None, output_affine=None, rows: Optional[Tensor] = None) -> Tensor:
         """Prognostic residual, boundings, optional de-normalisation (reference :223-233 + the interface's
-        post-processor when it is a plain InputNormalizer)."""
+        post-processor when it is a plain InputNormalizer).  ``rows`` (int64 grid ids, batch 1 / ensemble 1): ``y`` holds
+        only those nodes' rows ``[1, 1, len(rows), V_out]`` -- every step here is row-local, so a rank of a node-partitioned
+        run finishes the rows it decoded before they are all-gathered."""
         key = ("residual_src", str(y.device))
         if key not in self._idx_cache:
             src = torch.full((self.num_output_channels,), -1, dtype=torch.int32)
             src[torch.as_tensor(self._internal_output_idx).long()] = torch.as_tensor(self._internal_input_idx).to(torch.int32)
             self._idx_cache[key] = src.to(y.device)
         if len(self.boundings) == 0:
-            ops.finalize_output(y, x, self._idx_cache[key], input_affine, output_affine)
+            ops.finalize_output(y, x, self._idx_cache[key], input_affine, output_affine, rows=rows)
             return y if y.dtype == x.dtype else y.to(x.dtype)
         plan = self._bounding_plan(y.device, output_affine)
         if plan is None:  # a bounding class this package does not know: call the modules, as the reference does
-            ops.finalize_output(y, x, self._idx_cache[key], input_affine, None)
+            ops.finalize_output(y, x, self._idx_cache[key], input_affine, None, rows=rows)
             if y.dtype != x.dtype:
                 y = y.to(x.dtype)
             for bounding in self.boundings:
@@ -201,7 +203,7 @@ class AnemoiModelEncProcDec(nn.Module):
         # known boundings: the columns they touch stay normalised through finalize_output (mul 1 / add 0 there) and
         # are bounded, then de-normalised, by ONE kernel; every other column is finished by finalize_output
         op_lists, masked_affine, fin = plan
-        ops.finalize_output(y, x, self._idx_cache[key], input_affine, masked_affine)
+        ops.finalize_output(y, x, self._idx_cache[key], input_affine, masked_affine, rows=rows)
         ops.bound_output(y, *op_lists, fin=fin)
         return y if y.dtype == x.dtype else y.to(x.dtype)
 

@@ -459,10 +459,12 @@ def mhsa_backward(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, batch_siz
 
 
 def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Tensor], batch_size: int,
-                   dtype: torch.dtype, ld_out: Optional[int] = None, ensemble: int = 1, in_affine=None) -> Tensor:
+                   dtype: torch.dtype, ld_out: Optional[int] = None, ensemble: int = 1, in_affine=None,
+                   rows: Optional[Tensor] = None) -> Tensor:
     """Rows ``(b, ens, g)`` of ``[x (time-major) | latlons | trainable | 0-pad]`` in ``dtype``.  ``in_affine`` =
-    ``(mul, add)`` f32 ``[V]``: ``x`` is the raw state, normalised as ``x * mul + add`` while it is read."""
-    _dev(x, latlons, trainable)
+    ``(mul, add)`` f32 ``[V]``: ``x`` is the raw state, normalised as ``x * mul + add`` while it is read.
+    ``rows`` (int64 node ids; batch 1, ensemble 1): only those nodes' rows, in that order (``anemoi_assemble_node_rows``)."""
+    _dev(x, latlons, trainable, rows)
     mul = add = None
     if in_affine is not None and x is not None:
         mul, add = (t.contiguous().float() for t in in_affine)
@@ -481,20 +483,32 @@ def assemble_nodes(x: Optional[Tensor], latlons: Tensor, trainable: Optional[Ten
         b, t, ens, v = batch_size, 0, ensemble, 0
     width = t * v + n_ll + n_tr
     ld = width if ld_out is None else ld_out
-    out = torch.empty((b * ens * g, ld), dtype=dtype, device=latlons.device)
     latlons = latlons.contiguous().float()
     trainable = None if trainable is None else trainable.contiguous().float()
+    if rows is not None:
+        if b != 1 or ens != 1 or rows.dtype != torch.int64 or rows.dim() != 1:
+            raise ValueError("assemble_nodes: rows needs batch 1, ensemble 1 and a 1-d int64 id list")
+        rows = rows.contiguous()
+        out = torch.empty((rows.shape[0], ld), dtype=dtype, device=latlons.device)
+        st = _lib.load().anemoi_assemble_node_rows(dtype_code(dtype), _ptr(x), t, g, v, latlons.data_ptr(), n_ll,
+                                                   _ptr(trainable), n_tr, rows.data_ptr(), rows.shape[0], out.data_ptr(),
+                                                   ld, _ptr(mul), _ptr(add), _stream())
+        _lib.check(st, "anemoi_assemble_node_rows")
+        return out
+    out = torch.empty((b * ens * g, ld), dtype=dtype, device=latlons.device)
     st = _lib.load().anemoi_assemble_nodes(dtype_code(dtype), _ptr(x), b, t, ens, g, v, latlons.data_ptr(), n_ll,
                                            _ptr(trainable), n_tr, out.data_ptr(), ld, _ptr(mul), _ptr(add), _stream())
     _lib.check(st, "anemoi_assemble_nodes")
     return out
 
 
-def finalize_output(y: Tensor, x: Tensor, src: Tensor, in_affine=None, out_affine=None) -> Tensor:
+def finalize_output(y: Tensor, x: Tensor, src: Tensor, in_affine=None, out_affine=None,
+                    rows: Optional[Tensor] = None) -> Tensor:
     """In place on the f32 output ``y`` ``[B, Ens, G, V_out]``: prognostic residual from the last time slice of ``x``
     (``src`` int32 ``[V_out]``: input column per output column, -1 = none; ``in_affine`` normalises a raw ``x`` on the
-    fly) and, with ``out_affine = (mul, add)``, the de-normalisation ``(y - add) / mul``."""
-    _dev(y, x, src)
+    fly) and, with ``out_affine = (mul, add)``, the de-normalisation ``(y - add) / mul``.  ``rows`` (int64 node ids; batch
+    1, ensemble 1): ``y`` holds only those nodes' rows ``[..., len(rows), V_out]`` (``anemoi_finalize_output_rows``)."""
+    _dev(y, x, src, rows)
     if y.dtype != torch.float32 or not y.is_contiguous():
         raise ValueError("finalize_output: y must be contiguous float32")
     x = x.contiguous().float()
@@ -507,6 +521,15 @@ def finalize_output(y: Tensor, x: Tensor, src: Tensor, in_affine=None, out_affin
     if out_affine is not None:
         om, oa = (t_.contiguous().float() for t_ in out_affine)
     _dev(im, ia, om, oa)
+    if rows is not None:
+        if b != 1 or ens != 1 or rows.dtype != torch.int64 or rows.dim() != 1 or y.numel() != rows.shape[0] * y.shape[-1]:
+            raise ValueError("finalize_output: rows needs batch 1, ensemble 1, a 1-d int64 id list and one y row per id")
+        rows = rows.contiguous()
+        st = _lib.load().anemoi_finalize_output_rows(y.data_ptr(), y.shape[-1], x.data_ptr(), t, g, v_in, src.data_ptr(),
+                                                     rows.data_ptr(), rows.shape[0], _ptr(im), _ptr(ia), _ptr(om), _ptr(oa),
+                                                     _stream())
+        _lib.check(st, "anemoi_finalize_output_rows")
+        return y
     st = _lib.load().anemoi_finalize_output(y.data_ptr(), y.shape[-1], x.data_ptr(), b, t, ens, g, v_in, src.data_ptr(),
                                             _ptr(im), _ptr(ia), _ptr(om), _ptr(oa), _stream())
     _lib.check(st, "anemoi_finalize_output")

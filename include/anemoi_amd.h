@@ -221,6 +221,15 @@ int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int6
                           const float* in_add, anemoi_stream_t stream);
 
 /*
+ * The same for a LIST of grid nodes (batch 1, ensemble 1): out row i is the row of node rows[i] (int64 [n_rows], any order,
+ * repeats allowed).  A rank of a node-partitioned run (models/encoder_processor_decoder.py:168-181 under a model group)
+ * assembles only the grid rows its encoder reads and its decoder writes instead of the whole grid.
+ */
+int anemoi_assemble_node_rows(int dtype, const float* x, int T, int64_t G, int V, const float* latlons, int n_ll,
+                              const float* trainable, int n_tr, const int64_t* rows, int64_t n_rows, void* out,
+                              int64_t ldo, const float* in_mul, const float* in_add, anemoi_stream_t stream);
+
+/*
  * One pass over the f32 output [B, Ens, G, V_out] that ends AnemoiModelInterface.predict_step on a raw input state:
  *   y[.., c] += normalised x[b, T-1, ens, g, src[c]]      where src[c] >= 0 (prognostic residual,
  *                                                          models/encoder_processor_decoder.py:227; src int32 [V_out])
@@ -231,6 +240,15 @@ int anemoi_assemble_nodes(int dtype, const float* x, int B, int T, int Ens, int6
 int anemoi_finalize_output(float* y, int V_out, const float* x, int B, int T, int Ens, int64_t G, int V_in,
                            const int32_t* src, const float* in_mul, const float* in_add, const float* out_mul,
                            const float* out_add, anemoi_stream_t stream);
+
+/*
+ * The same on the rows a rank decodes (batch 1, ensemble 1): y is [n_rows, V_out], row i belongs to grid node rows[i]
+ * (int64 [n_rows]) -- the residual and the de-normalisation are row-local, so a node-partitioned run finishes its own rows
+ * BEFORE the final all-gather (models/encoder_processor_decoder.py:223-233, layers/mapper.py:99-102).
+ */
+int anemoi_finalize_output_rows(float* y, int V_out, const float* x, int T, int64_t G, int V_in, const int32_t* src,
+                                const int64_t* rows, int64_t n_rows, const float* in_mul, const float* in_add,
+                                const float* out_mul, const float* out_add, anemoi_stream_t stream);
 
 /*
  * Output boundings, in place on the f32 output rows [rows, V_out] (rows = B * Ens * G) after the prognostic residual:

@@ -158,7 +158,9 @@ def mhsa(qkv, batch_size, num_heads, window=-1, out=None, return_lse=False, drop
     return (o, torch.logsumexp(sc, -1)) if return_lse else o
 
 
-def assemble_nodes(x, latlons, trainable, batch_size, dtype, ld_out=None, ensemble=1, in_affine=None):
+def assemble_nodes(x, latlons, trainable, batch_size, dtype, ld_out=None, ensemble=1, in_affine=None, rows=None):
+    if rows is not None:  # (batch 1, ensemble 1: the node rows of the full matrix)
+        return assemble_nodes(x, latlons, trainable, batch_size, dtype, ld_out, ensemble, in_affine).index_select(0, rows)
     parts = []
     if x is not None and in_affine is not None:
         x = x * in_affine[0] + in_affine[1]
@@ -186,8 +188,10 @@ def act_forward(pre, act, residual=None):
     return y if residual is None else y + residual
 
 
-def finalize_output(y, x, src, in_affine=None, out_affine=None):
+def finalize_output(y, x, src, in_affine=None, out_affine=None, rows=None):
     last = x[:, -1]
+    if rows is not None:  # y holds the rows of these grid nodes only (batch 1, ensemble 1)
+        last = last.index_select(2, rows).reshape(y.shape[:-1] + (x.shape[-1],))
     if in_affine is not None:
         last = last * in_affine[0] + in_affine[1]
     cols = torch.nonzero(src >= 0).flatten()

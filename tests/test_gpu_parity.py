@@ -462,6 +462,36 @@ def test_glue_kernels():
     assert torch.equal(ops.add(a.to(DEV), b.to(DEV)).cpu(), a + b)
 
 
+def test_glue_kernels_on_a_row_list():
+    """``anemoi_assemble_node_rows`` / ``anemoi_finalize_output_rows`` (a rank of a node-partitioned run assembles and
+    finishes only its own grid rows): bit-identical to the rows of the full-grid calls, for any order / repeats of the ids,
+    with the input / output affines, both storage types, the 8-columns-per-thread and the element-wise kernels."""
+    from anemoi_models_amd import ops
+
+    g = torch.Generator().manual_seed(12)
+    n = 700
+    x = torch.randn(1, 2, 1, n, 9, generator=g).to(DEV)
+    ll, tr = torch.randn(n, 4, generator=g).to(DEV), torch.randn(n, 5, generator=g).to(DEV)
+    aff = (torch.rand(9, generator=g).to(DEV) + 0.5, torch.randn(9, generator=g).to(DEV))
+    rows = torch.cat([torch.randperm(n, generator=g)[:333], torch.tensor([5, 5, n - 1, 0])]).to(DEV)
+    for dtype in (torch.float32, torch.bfloat16):
+        for ld in (64, 30):  # (30: not a multiple of 8 -> the element-wise kernel)
+            for affine in (None, aff):
+                full = ops.assemble_nodes(x, ll, tr, 1, dtype, ld_out=ld, in_affine=affine)
+                part = ops.assemble_nodes(x, ll, tr, 1, dtype, ld_out=ld, in_affine=affine, rows=rows)
+                assert part.shape == (rows.shape[0], ld) and torch.equal(part, full.index_select(0, rows))
+    assert ops.assemble_nodes(x, ll, tr, 1, torch.float32, ld_out=32, rows=rows[:0]).shape == (0, 32)
+    src = torch.tensor([1, -1, 3, 8, -1, 0], dtype=torch.int32, device=DEV)
+    out_aff = (torch.rand(6, generator=g).to(DEV) + 0.5, torch.randn(6, generator=g).to(DEV))
+    y = torch.randn(1, 1, n, 6, generator=g).to(DEV)
+    for ia, oa in ((None, None), (aff, None), (aff, out_aff)):
+        full = ops.finalize_output(y.clone(), x, src, ia, oa)
+        part = ops.finalize_output(y[:, :, rows].contiguous(), x, src, ia, oa, rows=rows)
+        assert torch.equal(part, full[:, :, rows])
+    with pytest.raises(ValueError):
+        ops.assemble_nodes(x.repeat(2, 1, 1, 1, 1), ll, tr, 2, torch.float32, rows=rows)
+
+
 # ------------------------------------------------------------------------------------------- blocks + model
 def test_gt_blocks_vs_golden(golden_blocks):
     from anemoi_models_amd.layers.block import GraphTransformerMapperBlock, GraphTransformerProcessorBlock
