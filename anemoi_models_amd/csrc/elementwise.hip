@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(const float* __rest
 // The same with EIGHT consecutive output columns per thread (ldo % 8 == 0): one 16-byte (bf16) / two 16-byte (f32) stores
 // instead of eight 2-byte ones, one row / column division per eight elements (the element-wise form above reached 1.2 TB/s
 // on the 542 080 x 256 data-grid matrix of config 3, this one is bound by the reads of x).
-template <typename T>
+// IDX32: every flat index fits 31 bits -- 32-bit divisions (a 64-bit division is ~200 instructions on this ISA; with three
+// of them per thread the kernel was bound by integer ALU work, not by memory: 2.3 TB/s on the data-grid matrix).
+template <typename T, bool IDX32>
 __global__ __launch_bounds__(256) void assemble_nodes8_kernel(const float* __restrict__ x, int B, int T_, int Ens,
                                                               int64_t G, int V, const float* __restrict__ latlons,
                                                               int n_ll, const float* __restrict__ trainable, int n_tr,
@@ -279,16 +281,45 @@ __global__ __launch_bounds__(256) void assemble_nodes8_kernel(const float* __res
   // rows != nullptr (anemoi_assemble_node_rows, B = Ens = 1): output row i is grid node rows[i]
   const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * ldo8;
   const int tv = T_ * V;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = idx / ldo8;
-    const int c0 = (int)(idx - row * ldo8) * 8;
-    const int64_t g = rows != nullptr ? rows[row] : row % G;
-    const int64_t be = rows != nullptr ? 0 : row / G;
-    const int e = (int)(be % Ens);
-    const int64_t b = be / Ens;
+  const bool pairs = x != nullptr && V % 2 == 0 && ((uintptr_t)x & 7) == 0;
+  using I = typename std::conditional<IDX32, unsigned, int64_t>::type;
+  const bool one_be = B * Ens == 1;
+  for (I idx = (I)blockIdx.x * blockDim.x + threadIdx.x; idx < (I)total; idx += (I)gridDim.x * blockDim.x) {
+    const I row = idx / (I)ldo8;
+    const int c0 = (int)(idx - row * (I)ldo8) * 8;
+    int64_t g, b = 0;
+    int e = 0;
+    if (rows != nullptr) g = rows[row];
+    else if (one_be) g = (int64_t)row;
+    else {
+      const I be = row / (I)G;
+      g = (int64_t)(row - be * (I)G);
+      e = (int)(be % (I)Ens);
+      b = (int64_t)(be / (I)Ens);
+    }
     float val[8];
     int t = c0 / V, v = c0 - t * V;  // (time, variable) of column c0; advanced without further divisions
+    if (pairs && c0 + 8 <= tv) {
+      // V even, x 8-byte aligned: the eight columns are four (v, v + 1) pairs that never straddle a time slice -- four
+      // 8-byte loads instead of eight 4-byte ones (same values)
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const float2 p = *reinterpret_cast<const float2*>(x + ((((b * T_ + t) * Ens + e) * G) + g) * V + v);
+        val[i] = p.x;
+        val[i + 1] = p.y;
+        if (in_mul != nullptr) {
+          val[i] = val[i] * in_mul[v] + in_add[v];
+          val[i + 1] = val[i + 1] * in_mul[v + 1] + in_add[v + 1];
+        }
+        v += 2;
+        if (v == V) {
+          v = 0;
+          ++t;
+        }
+      }
+      VecIO<T, 8>::store(out + ((int64_t)row * ldo8 + (c0 >> 3)) * 8, val);
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = c0 + i;
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(256) void assemble_nodes8_kernel(const float* __res
       }
       val[i] = r;
     }
-    VecIO<T, 8>::store(out + (row * ldo8 + (c0 >> 3)) * 8, val);
+    VecIO<T, 8>::store(out + ((int64_t)row * ldo8 + (c0 >> 3)) * 8, val);
   }
 }
 
@@ -468,6 +499,7 @@ __global__ __launch_bounds__(256) void advance_input_kernel(float* __restrict__ 
 
 // y[row, c] <- ((y[row, c] + [c prognostic] normalised x[b, T-1, ens, g, src[c]]) - out_add[c]) / out_mul[c]: prognostic
 // residual and InputNormalizer.inverse_transform in one pass over the output
+template <bool IDX32>
 __global__ __launch_bounds__(256) void finalize_output_kernel(float* __restrict__ y, int V_out,
                                                               const float* __restrict__ x, int B, int T_, int Ens,
                                                               int64_t G, int V_in, const int32_t* __restrict__ src,
@@ -478,17 +510,24 @@ __global__ __launch_bounds__(256) void finalize_output_kernel(float* __restrict_
                                                               const int64_t* __restrict__ rows, int64_t n_rows) {
   // rows != nullptr (anemoi_finalize_output_rows, B = Ens = 1): y holds n_rows rows, row i is grid node rows[i]
   const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * V_out;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = idx / V_out;  // (b, ens, g)
-    const int c = (int)(idx - row * V_out);
+  using I = typename std::conditional<IDX32, unsigned, int64_t>::type;  // (see assemble_nodes8_kernel)
+  const bool one_be = B * Ens == 1;
+  for (I idx = (I)blockIdx.x * blockDim.x + threadIdx.x; idx < (I)total; idx += (I)gridDim.x * blockDim.x) {
+    const I row = idx / (I)V_out;  // (b, ens, g)
+    const int c = (int)(idx - row * (I)V_out);
     float val = y[idx];
     const int sv = src[c];
     if (sv >= 0) {
-      const int64_t g = rows != nullptr ? rows[row] : row % G;
-      const int64_t be = rows != nullptr ? 0 : row / G;
-      const int e = (int)(be % Ens);
-      const int64_t b = be / Ens;
+      int64_t g, b = 0;
+      int e = 0;
+      if (rows != nullptr) g = rows[row];
+      else if (one_be) g = (int64_t)row;
+      else {
+        const I be = row / (I)G;
+        g = (int64_t)(row - be * (I)G);
+        e = (int)(be % (I)Ens);
+        b = (int64_t)(be / (I)Ens);
+      }
       float xv = x[((((b * T_ + (T_ - 1)) * Ens + e) * G) + g) * V_in + sv];
       if (in_mul != nullptr) xv = xv * in_mul[sv] + in_add[sv];
       val += xv;
@@ -613,12 +652,18 @@ static int assemble_nodes_impl(int dtype, const float* x, int B, int T, int Ens,
   hipStream_t st = as_stream(stream);
   if (ldo % 8 == 0 && ldo < ((int64_t)1 << 31) && (uintptr_t)out % 16 == 0 && (dtype == ANEMOI_F32 || dtype == ANEMOI_BF16)) {
     const int ldo8 = (int)(ldo / 8);
-    if (dtype == ANEMOI_F32)
-      hipLaunchKernelGGL((assemble_nodes8_kernel<float>), dim3(flat_grid(total / 8)), dim3(256), 0, st, x, B, T, Ens, G,
-                         V, latlons, n_ll, trainable, n_tr, static_cast<float*>(out), ldo8, in_mul, in_add, rows, n_rows);
-    else
-      hipLaunchKernelGGL((assemble_nodes8_kernel<bf16_t>), dim3(flat_grid(total / 8)), dim3(256), 0, st, x, B, T, Ens, G,
-                         V, latlons, n_ll, trainable, n_tr, static_cast<bf16_t*>(out), ldo8, in_mul, in_add, rows, n_rows);
+#define ANEMOI_ASM8(TT, I32)                                                                                          \
+  hipLaunchKernelGGL((assemble_nodes8_kernel<TT, I32>), dim3(flat_grid(total / 8)), dim3(256), 0, st, x, B, T, Ens, G, V, \
+                     latlons, n_ll, trainable, n_tr, static_cast<TT*>(out), ldo8, in_mul, in_add, rows, n_rows)
+    const bool idx32 = total / 8 < ((int64_t)1 << 31) - ((int64_t)1 << 24);  // (+ one grid stride stays below 2^31)
+    if (dtype == ANEMOI_F32) {
+      if (idx32) ANEMOI_ASM8(float, true);
+      else ANEMOI_ASM8(float, false);
+    } else {
+      if (idx32) ANEMOI_ASM8(bf16_t, true);
+      else ANEMOI_ASM8(bf16_t, false);
+    }
+#undef ANEMOI_ASM8
     return check_launch("anemoi_assemble_nodes");
   }
   if (dtype == ANEMOI_F32)
@@ -769,8 +814,12 @@ static int finalize_output_impl(float* y, int V_out, const float* x, int B, int 
                  ANEMOI_ERR_INVALID, "anemoi_finalize_output: mul and add come together");
   const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * V_out;
   if (total == 0) return ANEMOI_OK;
-  hipLaunchKernelGGL(finalize_output_kernel, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), y, V_out, x, B, T,
-                     Ens, G, V_in, src, in_mul, in_add, out_mul, out_add, rows, n_rows);
+  if (total < ((int64_t)1 << 31) - ((int64_t)1 << 24))
+    hipLaunchKernelGGL(finalize_output_kernel<true>, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), y, V_out, x, B,
+                       T, Ens, G, V_in, src, in_mul, in_add, out_mul, out_add, rows, n_rows);
+  else
+    hipLaunchKernelGGL(finalize_output_kernel<false>, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), y, V_out, x, B,
+                       T, Ens, G, V_in, src, in_mul, in_add, out_mul, out_add, rows, n_rows);
   return check_launch("anemoi_finalize_output");
 }
 

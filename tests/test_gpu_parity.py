@@ -460,6 +460,25 @@ def test_glue_kernels():
     assert torch.equal(got, want)
     a, b = torch.randn(33, 64, generator=g), torch.randn(33, 64, generator=g)
     assert torch.equal(ops.add(a.to(DEV), b.to(DEV)).cpu(), a + b)
+    # wide rows of a whole grid: the LDS-staged kernel (groups of 32 nodes, ragged last group, batch x ensemble > 1)
+    for (bb, tt, ee, gg, vv, ld) in ((2, 2, 2, 333, 45, 128), (1, 3, 1, 1000, 31, 104), (1, 2, 1, 4097, 90, 256)):
+        x = torch.randn(bb, tt, ee, gg, vv, generator=g)
+        ll, tr = torch.randn(gg, 4, generator=g), torch.randn(gg, 3, generator=g)
+        aff = (torch.rand(vv, generator=g) + 0.5, torch.randn(vv, generator=g))
+        for dtype in (torch.float32, torch.bfloat16):
+            for affine in (None, aff):
+                got = ops.assemble_nodes(x.to(DEV), ll.to(DEV), tr.to(DEV), bb, dtype, ld_out=ld,
+                                         in_affine=None if affine is None else tuple(t_.to(DEV) for t_ in affine)).cpu()
+                xs = x if affine is None else torch.addcmul(affine[1], x, affine[0])  # (one fused multiply-add, as the kernel)
+                want = torch.cat([xs.permute(0, 2, 3, 1, 4).reshape(bb * ee * gg, tt * vv), ll.repeat(bb * ee, 1),
+                                  tr.repeat(bb * ee, 1)], 1)
+                w = tt * vv + 7
+                if affine is None:
+                    assert torch.equal(got[:, :w], want.to(dtype))
+                else:
+                    assert torch.allclose(got[:, :w].float(), want.to(dtype).float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6,
+                                          atol=1e-6)
+                assert torch.all(got[:, w:] == 0)
 
 
 def test_glue_kernels_on_a_row_list():
