@@ -157,6 +157,20 @@ struct VecIO<bf16_t, VEC> {
 };
 
 // ---------------------------------------------------------------- wave64 reductions
+// idx = q * d + rem for a launch-uniform divisor d: a 32-bit division when the flat index space fits 31 bits (`fits32` =
+// total < 2^31, so idx, d, q and rem all do) -- a 64-bit division is ~200 instructions on this ISA, and element-wise kernels
+// with several of them per thread are bound by that integer work, not by memory.
+__device__ __forceinline__ void fast_divmod(int64_t idx, int64_t d, bool fits32, int64_t& q, int64_t& rem) {
+  if (fits32) {
+    const unsigned a = (unsigned)idx, b = (unsigned)d, qq = a / b;
+    q = qq;
+    rem = a - qq * b;
+  } else {
+    q = idx / d;
+    rem = idx - q * d;
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -269,10 +269,12 @@ __global__ __launch_bounds__(256) void edge_attr_grad_kernel(const float* __rest
                                                              float* __restrict__ dattr, int64_t n_edges, int H, int UP,
                                                              float scale) {
   const int64_t total = n_edges * UP;
+  const bool fits32 = total < ((int64_t)1 << 31);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = idx / UP;
-    const int a = (int)(idx - e * UP);
+    int64_t e, a64;
+    fast_divmod(idx, UP, fits32, e, a64);
+    const int a = (int)a64;
     const int64_t i = dst_of_edge[e];
     float acc = 0.f;
     for (int h = 0; h < H; ++h) {

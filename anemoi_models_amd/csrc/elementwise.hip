@@ -384,9 +384,11 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const T* x, int64_t ldx,
   const int64_t per_row = (cols + VEC - 1) / VEC;
   const int64_t total = rows * per_row;
   const bool vec_ok = cols % VEC == 0 && ldx % VEC == 0 && ldo % VEC == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0;
+  const bool fits32 = total < ((int64_t)1 << 31);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / per_row;
-    const int c = (int)(i - r * per_row) * VEC;
+    int64_t r, piece;
+    fast_divmod(i, per_row, fits32, r, piece);
+    const int c = (int)piece * VEC;
     const float f = alpha * s[r];
     if (vec_ok) {
       float v[VEC];
@@ -480,14 +482,14 @@ __global__ __launch_bounds__(256) void advance_input_kernel(float* __restrict__ 
                                                             const float* __restrict__ forcing, int F,
                                                             const int32_t* __restrict__ colmap) {
   const int64_t total = (int64_t)B * Ens * G * V_in;
+  const bool fits32 = total < ((int64_t)1 << 31);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = idx / V_in;  // (b, ens, g)
-    const int v = (int)(idx - row * V_in);
-    const int64_t g = row % G;
-    const int64_t be = row / G;
-    const int e = (int)(be % Ens);
-    const int64_t b = be / Ens;
+    int64_t row, v64, g, be, e64, b;  // row = (b, ens, g)
+    fast_divmod(idx, V_in, fits32, row, v64);
+    fast_divmod(row, G, fits32, be, g);
+    fast_divmod(be, Ens, fits32, b, e64);
+    const int v = (int)v64, e = (int)e64;
     const int64_t t_stride = (int64_t)Ens * G * V_in;
     float* xp = x + (((b * T_) * Ens + e) * G + g) * V_in + v;  // time slice 0 of this element
     for (int t = 0; t + 1 < T_; ++t) xp[t * t_stride] = xp[(t + 1) * t_stride];
