@@ -441,7 +441,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   // MH = 16-row fragments per wave along M: 8 -> the 256 x 256 tile, 4 -> a 128 x 256 tile (wave tile 64 x 128) used for
   // the rows of a remainder round (640 tiles on 256 CUs: the last 128 tiles become 256 half tiles = one full round),
   // 6 -> a 192 x 256 tile for small problems whose 256-row tiles quantise badly (5121 x 4096: 320 tiles = 2 rounds, as
-  // 432 tiles of 7/8 the staged bytes = 2 shorter rounds; 5121 x 2048: 160 -> 216 of the 256 CUs busy, shorter tiles).
+  // 432 tiles of 7/8 the staged bytes = 2 shorter rounds; 5121 x 2048: 160 -> 216 of the 256 CUs busy, shorter tiles),
+  // 5 -> 160 x 256 (5121 x 2048: 256 tiles fill the chip exactly once), 3 -> 96 x 256 (N = 512 / 1024 at M = 10 242 / 5 121:
+  // 214 / 216 tiles in one round instead of 160).  The launcher's cost model picks the height per launch.
   constexpr int TM = MH * 32;        // tile rows
   constexpr int NS = 8 * MH;         // MFMAs per 32-deep K step
   constexpr int NRD = 8 + MH;        // fragment reads per K step = LDS-DMA instructions per slab and wave
