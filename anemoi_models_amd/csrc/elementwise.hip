@@ -3,6 +3,8 @@
 //
 // All of them are streaming kernels: one pass over the data, 16-byte accesses per lane where the
 // layout allows, one wave64 per row (LayerNorm) or a flat grid-stride mapping.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace anemoi {
@@ -571,6 +573,15 @@ __global__ __launch_bounds__(256) void bound_output_kernel(float* __restrict__ y
   }
 }
 
+// ANEMOI_AMD_IDX64=1 forces the 64-bit index instantiations of the glue kernels (tests: no tensor of 2^31 elements needed)
+static bool force_idx64() {
+  static const bool v = [] {
+    const char* e = getenv("ANEMOI_AMD_IDX64");
+    return e != nullptr && atoi(e) != 0;
+  }();
+  return v;
+}
+
 static inline unsigned flat_grid(int64_t total) {
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
@@ -657,7 +668,7 @@ static int assemble_nodes_impl(int dtype, const float* x, int B, int T, int Ens,
 #define ANEMOI_ASM8(TT, I32)                                                                                          \
   hipLaunchKernelGGL((assemble_nodes8_kernel<TT, I32>), dim3(flat_grid(total / 8)), dim3(256), 0, st, x, B, T, Ens, G, V, \
                      latlons, n_ll, trainable, n_tr, static_cast<TT*>(out), ldo8, in_mul, in_add, rows, n_rows)
-    const bool idx32 = total / 8 < ((int64_t)1 << 31) - ((int64_t)1 << 24);  // (+ one grid stride stays below 2^31)
+    const bool idx32 = !force_idx64() && total / 8 < ((int64_t)1 << 31) - ((int64_t)1 << 24);  // (+ one grid stride stays below 2^31)
     if (dtype == ANEMOI_F32) {
       if (idx32) ANEMOI_ASM8(float, true);
       else ANEMOI_ASM8(float, false);
@@ -816,7 +827,7 @@ static int finalize_output_impl(float* y, int V_out, const float* x, int B, int 
                  ANEMOI_ERR_INVALID, "anemoi_finalize_output: mul and add come together");
   const int64_t total = (rows != nullptr ? n_rows : (int64_t)B * Ens * G) * V_out;
   if (total == 0) return ANEMOI_OK;
-  if (total < ((int64_t)1 << 31) - ((int64_t)1 << 24))
+  if (!force_idx64() && total < ((int64_t)1 << 31) - ((int64_t)1 << 24))
     hipLaunchKernelGGL(finalize_output_kernel<true>, dim3(flat_grid(total)), dim3(256), 0, as_stream(stream), y, V_out, x, B,
                        T, Ens, G, V_in, src, in_mul, in_add, out_mul, out_add, rows, n_rows);
   else

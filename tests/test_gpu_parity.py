@@ -511,6 +511,41 @@ def test_glue_kernels_on_a_row_list():
         ops.assemble_nodes(x.repeat(2, 1, 1, 1, 1), ll, tr, 2, torch.float32, rows=rows)
 
 
+def test_glue_kernels_64_bit_index_instantiations(tmp_path):
+    """The glue kernels pick 32-bit index arithmetic when the flat index fits 31 bits -- always, at the sizes a test can hold.
+    ``ANEMOI_AMD_IDX64=1`` (read once per process) forces the 64-bit instantiations: a fresh process computes the same
+    assembly / finish calls (batch x ensemble > 1, row lists, affines) and the results are compared bit for bit."""
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from anemoi_models_amd import ops\n"
+        "g = torch.Generator().manual_seed(21)\n"
+        "x = torch.randn(2, 2, 2, 300, 10, generator=g).cuda()\n"
+        "ll, tr = torch.randn(300, 4, generator=g).cuda(), torch.randn(300, 3, generator=g).cuda()\n"
+        "aff = (torch.rand(10, generator=g).cuda() + 0.5, torch.randn(10, generator=g).cuda())\n"
+        "rows = torch.randperm(300, generator=g)[:77].cuda()\n"
+        "src = torch.tensor([1, -1, 3, 9, -1, 0], dtype=torch.int32).cuda()\n"
+        "y = torch.randn(2, 2, 300, 6, generator=g).cuda()\n"
+        "out = {}\n"
+        "out['a'] = ops.assemble_nodes(x, ll, tr, 2, torch.bfloat16, ld_out=32, in_affine=aff).cpu()\n"
+        "out['b'] = ops.assemble_nodes(x[:1, :, :1], ll, tr, 1, torch.float32, ld_out=40, rows=rows).cpu()\n"
+        "out['c'] = ops.finalize_output(y.clone(), x, src, aff, None).cpu()\n"
+        "out['d'] = ops.finalize_output(y[:1, :1, rows].contiguous(), x[:1, :, :1], src, None, None, rows=rows).cpu()\n"
+        "torch.save(out, sys.argv[1])\n")
+    res = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"out{mode}.pt")
+        subprocess.run([sys.executable, str(script), path], check=True, env=dict(os.environ, ANEMOI_AMD_IDX64=mode), timeout=600)
+        res[mode] = torch.load(path)
+    for k in res["0"]:
+        assert torch.equal(res["0"][k], res["1"][k]), k
+
+
 # ------------------------------------------------------------------------------------------- blocks + model
 def test_gt_blocks_vs_golden(golden_blocks):
     from anemoi_models_amd.layers.block import GraphTransformerMapperBlock, GraphTransformerProcessorBlock
