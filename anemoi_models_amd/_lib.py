@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -123,6 +123,8 @@ SIGNATURES = {
     "anemoi_gather_add_act": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "anemoi_segment_sum": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "anemoi_segment_sum_cat": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                       c_int, c_void_p]),
     "anemoi_mhsa_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "anemoi_mhsa": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_float, c_uint32, c_void_p, c_int, c_int, c_void_p]),

@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void gather_add_act_kernel(const T* __restrict
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const T* __restrict__ v, int64_t ldv,
                                                           const int32_t* __restrict__ rowptr, T* __restrict__ out,
-                                                          int64_t ldo, int64_t n_dst, int C) {
+                                                          int64_t ldo, int64_t n_dst, int C,
+                                                          const T* __restrict__ x, int64_t ldx) {
+  // x != nullptr (anemoi_segment_sum_cat): out is [n_dst, >= 2C] = [x | sums]: the lane also copies its piece of row i of x
   const int lane = threadIdx.x & 63;
   const int slices = (C + 64 * VEC - 1) / (64 * VEC);
   const int64_t units = n_dst * slices;
@@ -59,7 +61,14 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const T* __restrict__ 
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] += r[k];
     }
-    VecIO<T, VEC>::store(out + i * ldo + c, acc);
+    if (x != nullptr) {
+      float r[VEC];
+      VecIO<T, VEC>::load(x + i * ldx + c, r);
+      VecIO<T, VEC>::store(out + i * ldo + c, r);
+      VecIO<T, VEC>::store(out + i * ldo + C + c, acc);
+    } else {
+      VecIO<T, VEC>::store(out + i * ldo + c, acc);
+    }
   }
 }
 
@@ -114,27 +123,40 @@ int anemoi_gather_add_act(int dtype, const void* t, int64_t ldt, const void* p_d
   return check_launch("anemoi_gather_add_act");
 }
 
-int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* rowptr, void* out, int64_t ldo,
-                       int64_t n_dst, int C, anemoi_stream_t stream) {
-  ANEMOI_REQUIRE(n_dst >= 0 && C > 0, ANEMOI_ERR_INVALID, "anemoi_segment_sum: bad shape");
+static int segment_sum_impl(const char* who, int dtype, const void* v, int64_t ldv, const int32_t* rowptr, const void* x,
+                            int64_t ldx, void* out, int64_t ldo, int64_t n_dst, int C, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(n_dst >= 0 && C > 0, ANEMOI_ERR_INVALID, "%s: bad shape", who);
   if (n_dst == 0) return ANEMOI_OK;
-  ANEMOI_REQUIRE(v && rowptr && out, ANEMOI_ERR_INVALID, "anemoi_segment_sum: null pointer");
-  ANEMOI_REQUIRE(ldv >= C && ldo >= C, ANEMOI_ERR_INVALID, "anemoi_segment_sum: leading dimension smaller than C");
+  ANEMOI_REQUIRE(v && rowptr && out, ANEMOI_ERR_INVALID, "%s: null pointer", who);
+  ANEMOI_REQUIRE(ldv >= C && ldo >= (x != nullptr ? 2 : 1) * (int64_t)C && (x == nullptr || ldx >= C), ANEMOI_ERR_INVALID,
+                 "%s: leading dimension too small", who);
   hipStream_t st = as_stream(stream);
 #define SEG(T, V)                                                                                                   \
   hipLaunchKernelGGL((segment_sum_kernel<T, V>), dim3(wave_grid(n_dst * ((C + 64 * V - 1) / (64 * V)))), dim3(256), \
-                     0, st, static_cast<const T*>(v), ldv, rowptr, static_cast<T*>(out), ldo, n_dst, C)
+                     0, st, static_cast<const T*>(v), ldv, rowptr, static_cast<T*>(out), ldo, n_dst, C,             \
+                     static_cast<const T*>(x), ldx)
   if (dtype == ANEMOI_F32) {
-    if (vec_ok<float>(C, {ldv, ldo}, {v, out})) SEG(float, 4);
+    if (vec_ok<float>(C, {ldv, ldo, x != nullptr ? ldx : 0}, {v, out, x})) SEG(float, 4);
     else SEG(float, 1);
   } else if (dtype == ANEMOI_BF16) {
-    if (vec_ok<bf16_t>(C, {ldv, ldo}, {v, out})) SEG(bf16_t, 8);
+    if (vec_ok<bf16_t>(C, {ldv, ldo, x != nullptr ? ldx : 0}, {v, out, x})) SEG(bf16_t, 8);
     else SEG(bf16_t, 1);
   } else {
-    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_segment_sum: dtype %d", dtype);
+    return fail(ANEMOI_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
   }
 #undef SEG
-  return check_launch("anemoi_segment_sum");
+  return check_launch(who);
+}
+
+int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* rowptr, void* out, int64_t ldo,
+                       int64_t n_dst, int C, anemoi_stream_t stream) {
+  return segment_sum_impl("anemoi_segment_sum", dtype, v, ldv, rowptr, nullptr, 0, out, ldo, n_dst, C, stream);
+}
+
+int anemoi_segment_sum_cat(int dtype, const void* v, int64_t ldv, const int32_t* rowptr, const void* x, int64_t ldx,
+                           void* out, int64_t ldo, int64_t n_dst, int C, anemoi_stream_t stream) {
+  ANEMOI_REQUIRE(x != nullptr || n_dst == 0, ANEMOI_ERR_INVALID, "anemoi_segment_sum_cat: null pointer");
+  return segment_sum_impl("anemoi_segment_sum_cat", dtype, v, ldv, rowptr, x, ldx, out, ldo, n_dst, C, stream);
 }
 
 }  // extern "C"

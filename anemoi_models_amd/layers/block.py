@@ -742,9 +742,7 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
         h = ops.gather_add_act(t, p_dst, p_src, plan.dst, plan.col, act=act1, out=t)
         e_new = edge_mlp(h, residual=e_csr, start=1)  # remaining Linear/act pairs, LayerNorm, "+ e"
         del h, t, p, p_dst, p_src
-        xcat = torch.empty((x.shape[0], 2 * c), dtype=dtype, device=x.device)
-        xcat[:, :c].copy_(x)
-        ops.segment_sum(e_new, plan.rowptr, out=xcat[:, c:])  # scatter-sum over destinations
+        xcat = ops.segment_sum(e_new, plan.rowptr, cat_with=x)  # [x | scatter-sum over destinations]: the node MLP's input
         return node_mlp(xcat, residual=x), e_new
 
     def _sharded(self, x, edge_attr, edge_index, shapes, model_comm_group, size=None):
@@ -809,12 +807,11 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         del h, t, p_dst, p_src
 
         def update(x, agg):  # node_mlp(cat[x, agg]) + x
+            if agg is not None:
+                return node_mlp(ops.segment_sum(agg, plan.rowptr, cat_with=x), residual=x)
             xcat = torch.empty((x.shape[0], 2 * c), dtype=dtype, device=x.device)
             xcat[:, :c].copy_(x)
-            if agg is None:
-                xcat[:, c:].copy_(x)
-            else:
-                ops.segment_sum(agg, plan.rowptr, out=xcat[:, c:])
+            xcat[:, c:].copy_(x)
             return node_mlp(xcat, residual=x)
 
         new_dst = update(x_dst, e_new)

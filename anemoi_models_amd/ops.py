@@ -378,11 +378,26 @@ def gather_add_act(t: Tensor, p_dst: Tensor, p_src: Tensor, dst: Tensor, src: Te
     return out
 
 
-def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """Sum of the rows of every CSR segment: ``out[i] = v[rowptr[i]:rowptr[i+1]].sum(0)`` (scatter-sum over dst)."""
-    _dev(v, rowptr, out)
+def segment_sum(v: Tensor, rowptr: Tensor, out: Optional[Tensor] = None, cat_with: Optional[Tensor] = None) -> Tensor:
+    """Sum of the rows of every CSR segment: ``out[i] = v[rowptr[i]:rowptr[i+1]].sum(0)`` (scatter-sum over dst).
+    ``cat_with`` = ``x [n_dst, C]``: returns ``[n_dst, 2C] = [x | sums]`` -- the node MLP's input -- from the same pass."""
+    _dev(v, rowptr, out, cat_with)
     n_dst = rowptr.shape[0] - 1
     c = _rows(v).shape[1]
+    if cat_with is not None:
+        x = _rows(cat_with)
+        if x.shape != (n_dst, c) or x.dtype != v.dtype or out is not None:
+            raise ValueError("segment_sum: cat_with must be [n_dst, C] of v's dtype (and no out=)")
+        out = torch.empty((n_dst, 2 * c), dtype=v.dtype, device=v.device)
+        if v.shape[0] == 0:
+            out[:, :c].copy_(x)
+            out[:, c:].zero_()
+            return out
+        with _Timed("segment_sum", bytes=(v.shape[0] + 3 * n_dst) * c * v.element_size()):
+            st = _lib.load().anemoi_segment_sum_cat(dtype_code(v.dtype), v.data_ptr(), _ld(v), rowptr.data_ptr(),
+                                                    x.data_ptr(), _ld(x), out.data_ptr(), 2 * c, n_dst, c, _stream())
+        _lib.check(st, "anemoi_segment_sum_cat")
+        return out
     if out is None:
         out = torch.empty((n_dst, c), dtype=v.dtype, device=v.device)
     if v.shape[0] == 0:

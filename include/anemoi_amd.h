@@ -311,6 +311,13 @@ int anemoi_segment_sum(int dtype, const void* v, int64_t ldv, const int32_t* row
                        int64_t n_dst, int C, anemoi_stream_t stream);
 
 /*
+ * The same pass producing the node MLP's input of a GNN block, out[i, :] = [ x[i, 0:C] | sum of v[e, :] over CSR row i ]
+ * (out is [n_dst, ldo >= 2C]): torch.cat([x, aggregated], dim=1) at layers/block.py:217, 276 without a separate copy of x.
+ */
+int anemoi_segment_sum_cat(int dtype, const void* v, int64_t ldv, const int32_t* rowptr, const void* x, int64_t ldx,
+                           void* out, int64_t ldo, int64_t n_dst, int C, anemoi_stream_t stream);
+
+/*
  * Mesh-node multi-head self attention (K7): out[b*S + i, h*D:(h+1)*D] = softmax_j(q_i . k_j / sqrt(D)) v_j per head,
  * flash style, on the fused lin_qkv output qkv [B*S, 3C] = q | k | v (leading dimension ld), C = H*D.
  * Replaces the rearranges + flash_attn_func / scaled_dot_product_attention of layers/attention.py:76-108.

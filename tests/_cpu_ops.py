@@ -133,10 +133,12 @@ def gather_add_act(t, p_dst, p_src, dst, src, act="Identity", out=None):
     return y
 
 
-def segment_sum(v, rowptr, out=None):
+def segment_sum(v, rowptr, out=None, cat_with=None):
     n = rowptr.shape[0] - 1
     dst = torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).long())
     y = scatter_sum(v.float(), dst, n).to(v.dtype)
+    if cat_with is not None:
+        return torch.cat([cat_with, y], dim=1)
     if out is not None:
         out.copy_(y)
         return out

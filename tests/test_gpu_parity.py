@@ -924,6 +924,13 @@ def test_gnn_edge_ops(dtype):
     got = ops.segment_sum(v.to(DEV), plan.rowptr)
     assert rel_err(got, want) < (1e-6 if dtype == torch.float32 else 1e-2)
     assert torch.all(got[n - 1] == 0)  # destination without edges
+    # [x | sums] in one pass (anemoi_segment_sum_cat: the node MLP's input): the same bits as the two-step form, also for a
+    # strided x (a column range of a wider buffer) and a width the 16-byte path does not take
+    for width, xs in ((c, pd.to(DEV)), (c, torch.cat([ps, pd], 1).to(DEV)[:, c:]), (c - 2, pd.to(DEV)[:, : c - 2])):
+        vv = v.to(DEV)[:, :width]
+        cat = ops.segment_sum(vv, plan.rowptr, cat_with=xs)
+        assert cat.shape == (n, 2 * width)
+        assert torch.equal(cat[:, :width], xs) and torch.equal(cat[:, width:], ops.segment_sum(vv, plan.rowptr))
 
 
 def test_gnn_block_and_model_vs_golden(graph_o32, golden_blocks, golden_cfg1_gnn):
