@@ -39,13 +39,12 @@ def compute_dtype(x: Tensor) -> torch.dtype:
 
 
 def require_inference(*modules: torch.nn.Module) -> None:
-    """Refuse to run where autograd would need a backward that does not exist: only the flat GraphTransformer model has a
-    differentiable route (``autograd.model_forward``, single device)."""
+    """Guard of the inference-only entry points (``native`` routes on packed weights): refuse to run where autograd would
+    expect a graph.  The modules' ``forward`` methods take their differentiable routes (``training.py``) before they get here."""
     if torch.is_grad_enabled() and any(p.requires_grad for m in modules for p in m.parameters()):
         raise NotImplementedError(
-            "anemoi_models_amd: this model / call has no backward on the MI355X kernels (only the flat GraphTransformer "
-            "model on a single device has: autograd.model_forward); run under torch.no_grad() / "
-            "torch.inference_mode()"
+            "anemoi_models_amd: this entry point is inference-only (packed weights, no autograd graph); call the module's "
+            "forward, or run under torch.no_grad() / torch.inference_mode()"
         )
 
 
