@@ -59,11 +59,6 @@ class BaseMapper(nn.Module, ABC):
     # ``forward`` runs fused launch sequences and does not come through these; they are kept, with the reference's
     # signatures and return values, for callers (and the reference's own tests) that use a mapper piecewise.
     @staticmethod
-    def _single_group(model_comm_group) -> None:
-        if model_comm_group is not None and model_comm_group.size() > 1:
-            raise NotImplementedError("mapper-level model sharding: use the node-partitioned model forward")
-
-    @staticmethod
     def _apply_module(module: nn.Module, x: Tensor) -> Tensor:
         """An embedding / extraction sub-module on node rows, on the HIP kernels with or without an autograd graph."""
         from .mlp import MLP, NativeSequential

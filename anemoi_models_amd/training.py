@@ -55,12 +55,6 @@ def _cast(x: Tensor, dtype: torch.dtype) -> Tensor:
     return x if x.stride(-1) == 1 else x.contiguous()
 
 
-def _no_group(model_comm_group) -> None:
-    if model_comm_group is not None and model_comm_group.size() > 1:
-        raise NotImplementedError("training across a model communication group goes through the model root "
-                                  "(distributed.partition.sharded_training_forward)")
-
-
 # ------------------------------------------------------------------------------------------------ MLP / Sequential
 def sequential(seq: nn.Sequential, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
     """Linear / activation / LayerNorm stack with each Linear fused with the activation behind it."""
