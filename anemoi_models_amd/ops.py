@@ -9,7 +9,6 @@ them with CPU tensors raises.  (CPU tests of the host logic substitute this modu
 
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
