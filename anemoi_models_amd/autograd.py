@@ -809,3 +809,72 @@ def _edge_attr_csr(edge_attr_buf: Tensor, trainable: Optional[Tensor], plan, up:
     tail = torch.zeros((e, up - dim), dtype=torch.float32, device=attr.device)
     tail[:, 0] = 1.0
     return torch.cat([attr, tail], dim=1).contiguous()
+
+
+def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layers: int, num_chunks: int,
+                  prognostic_in, prognostic_out, dtype: torch.dtype = torch.float32, act: str = "GELU",
+                  data: str = "data", hidden: str = "hidden", plan_cache=None) -> Tensor:
+    """Differentiable forward of the flat GraphTransformer ``AnemoiModelEncProcDec`` (reference
+    models/encoder_processor_decoder.py:168-233; batch size 1, no boundings) for TRAINING on the HIP kernels.
+
+    ``sd``: the model's ``state_dict`` as f32 tensors on the device (``requires_grad`` where gradients are wanted, the
+    trainable node / edge tensors included); ``graph``: ``{enc,proc,dec}_edge_index`` (int64 ``[2, E]``) and
+    ``{enc,proc,dec}_edge_attr`` (f32 ``[E, k]``) as in ``oracle.reference_path.model_forward``.  Heavy ops are the
+    autograd Functions above; concatenations / index maps are torch glue.  ``plan_cache`` (a ``runtime.PlanCache``, the
+    model passes its own) keeps the CSR plans -- and the transposed CSR the backward hangs on them -- across steps: without
+    it every step pays the range-check host syncs and two sorts per edge set."""
+    from . import runtime
+
+    b, t, ens, g_, v = x.shape
+    if ens != 1 and b != 1:
+        raise NotImplementedError("autograd.model_forward: an ensemble dimension > 1 only with batch size 1 (the "
+                                  "reference repeats the node attributes per batch element only)")
+    bs = b * ens  # rows are ordered (batch, ensemble, grid) as in the reference's rearrange (:173-177)
+    head_dim = sd["processor.proc.0.blocks.0.lin_query.weight"].shape[0] // num_heads
+    if head_dim % 4 != 0:
+        raise NotImplementedError(f"autograd.model_forward: head size {head_dim} must be a multiple of 4 "
+                                  "(the folded edge kernels own whole 16-byte channel groups per lane)")
+
+    def node_attrs(name):
+        parts = [sd[f"node_attributes.latlons_{name}"]]
+        tr = sd.get(f"node_attributes.trainable_tensors.{name}.trainable")
+        return torch.cat(parts + ([] if tr is None else [tr]), dim=1).repeat(bs, 1)
+
+    x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(bs * g_, t * v), node_attrs(data)], dim=1).to(dtype)
+    x_hidden = node_attrs(hidden).to(dtype)
+    n_data, n_hidden = x_data.shape[0], x_hidden.shape[0]
+    plans, attrs = {}, {}
+    for key, mod, (ns, nd) in (("enc", "encoder", (n_data, n_hidden)), ("proc", "processor", (n_hidden, n_hidden)),
+                               ("dec", "decoder", (n_hidden, n_data))):
+        ei = graph[f"{key}_edge_index"]
+        if ei.device != x.device:
+            ei = ei.to(x.device)
+        inc = torch.tensor([[ns // bs], [nd // bs]], dtype=ei.dtype, device=ei.device) if bs > 1 else None
+        if plan_cache is not None:  # keyed on the edge-index tensor's identity / version and the batch size
+            plans[key] = plan_cache.get(ei, ns, nd, bs, inc)
+        else:  # batched graph: sample i's edges are shifted by i * (nodes per sample) (layers/mapper.py:150-171)
+            plans[key] = runtime.build_edge_plan(runtime.expand_edges(ei, inc, bs) if bs > 1 else ei, ns, nd)
+        # every edge set has its own attribute width (its trainable tensor may be absent or of another size): the
+        # folded width ``up`` = attributes + the constant-1 column, rounded to the kernel's 4-float granule
+        trainable = sd.get(f"{mod}.trainable.trainable")
+        width = graph[f"{key}_edge_attr"].shape[1] + (0 if trainable is None else trainable.shape[1])
+        attrs[key] = _edge_attr_csr(graph[f"{key}_edge_attr"].to(x.device), trainable, plans[key],
+                                    ops.round_up(width + 1, 4), bs)
+
+    xs = linear(x_data, sd["encoder.emb_nodes_src.weight"], sd["encoder.emb_nodes_src.bias"])
+    xd = linear(x_hidden, sd["encoder.emb_nodes_dst.weight"], sd["encoder.emb_nodes_dst.bias"])
+    x_latent = gt_mapper_block(xs, xd, sd, "encoder.proc", attrs["enc"], plans["enc"], num_heads, act)
+    x_proc = x_latent
+    per_chunk = num_layers // num_chunks
+    for ci in range(num_chunks):
+        for bi in range(per_chunk):
+            x_proc = gt_processor_block(x_proc, sd, f"processor.proc.{ci}.blocks.{bi}", attrs["proc"], plans["proc"],
+                                        num_heads, act)
+    x_latent_proc = x_proc + x_latent
+    xg = linear(x_data, sd["decoder.emb_nodes_dst.weight"], sd["decoder.emb_nodes_dst.bias"])
+    out = gt_mapper_block(x_latent_proc, xg, sd, "decoder.proc", attrs["dec"], plans["dec"], num_heads, act)
+    out = layer_norm(out, sd["decoder.node_data_extractor.0.weight"], sd["decoder.node_data_extractor.0.bias"])
+    out = linear(out, sd["decoder.node_data_extractor.1.weight"], sd["decoder.node_data_extractor.1.bias"])
+    y = out.float().reshape(b, ens, g_, -1).clone()
+    y[..., list(prognostic_out)] = y[..., list(prognostic_out)] + x[:, -1, :, :, list(prognostic_in)]
+    return y
