@@ -423,6 +423,71 @@ __device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int6
   }
 }
 
+// The tail rows of a tiled launch (M % 256 in 1..8), FOUR output columns per wave at a time: the x rows are loaded once for
+// the four columns and all loads of a K chunk are independent, so a wave pays ONE memory latency chain for its columns
+// instead of one per column (5121 x 4096 x 1024: the column-at-a-time pass cost 14 us of a 58-us launch, every launch of a
+// 40 962- / 10 242- / 5 121-row problem 3 - 14 us).  Per column the arithmetic is skinny_column's, operation for operation
+// (k order per lane, wave_sum, epilogue): the same bits.
+template <int ROWS>
+__device__ __forceinline__ void skinny_columns(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W,
+                                               const float* __restrict__ bias, const bf16_t* __restrict__ R, int64_t ldr,
+                                               bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K, int act, LnFold ln,
+                                               int lane, int gw, int total_waves) {
+  constexpr int CG = 4;
+  const int groups = (N + CG - 1) / CG;
+  for (int g = gw; g < groups; g += total_waves) {
+    const int n0 = g * CG;
+    float acc[ROWS][CG];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[r][c] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float xv[ROWS][8], wv[CG][8];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const int n = n0 + c < N ? n0 + c : N - 1;  // (a ragged last group recomputes the last column; not stored)
+        VecIO<bf16_t, 8>::load(W + (int64_t)n * K + k, wv[c]);
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        if (r < M) VecIO<bf16_t, 8>::load(X + r * ldx + k, xv[r]);
+#pragma unroll
+      for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+          if (r < M) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[r][c] = fmaf(xv[r][i], wv[c][i], acc[r][c]);
+          }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[r][c] = wave_sum(acc[r][c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const int n = n0 + c;
+        if (n < N) {
+          const float b = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            if (r < M) {
+              float a = acc[r][c];
+              if (ln.stats != nullptr) a = fmaf(a, ln.stats[r].x, ln.stats[r].y * ln.colsum[n]);
+              float o = act_apply(a + b, act);
+              o = bf16_to_f32(f32_to_bf16(o));  // bf16 result, then + residual
+              if (R != nullptr) o += bf16_to_f32(R[r * ldr + n]);
+              Y[r * ldy + n] = f32_to_bf16(o);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int ACT, bool HAS_RES, bool LN, int MH, bool RS = false, bool DUAL = false, bool GMUL = false>
 __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W,
@@ -455,20 +520,11 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // The up to 8 rows behind the last full row tile (M here is the 256-row multiple): every wave of the launch takes
-  // some output columns of them first -- a few microseconds in parallel instead of a separate launch behind this one.
-  if (m_tail > 0) {
-    LnFold lt = ln;
-    if (LN) lt.stats += M;
-    for (int n = (int)blockIdx.x * 4 + wid; n < N; n += (int)gridDim.x * 4)
-      skinny_column<8>(X + M * ldx, ldx, W, bias, HAS_RES ? R + M * ldr : nullptr, ldr, Y + M * ldy, ldy, m_tail, n, K,
-                       ACT, lt, lane);
-  }
   const int64_t xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = gridDim.x >> 3;
   const int64_t q8 = n_tiles / 8, r8 = n_tiles % 8;
   const int64_t chunk_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int64_t chunk_len = q8 + (xcd < r8 ? 1 : 0);
-  if (bix >= chunk_len) return;
+  const bool has_tiles = bix < chunk_len;  // (a workgroup without tiles still takes its share of the tail rows below)
   const int nk = K / 64;  // >= 2 (launcher)
 
   // ---- staging side.  Wave w fills LDS rows w * 64 + 8 i + (lane >> 3), i = 0..7, of both operand panels; the
@@ -549,8 +605,28 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   // prologue: slabs 0 and 1 of the first tile; fragments of (slab 0, ks 0)
   // (issuing slab 1 together with slab 0 and waiting for slab 0 alone -- vmcnt(NRD) -- measured no difference on any shape:
   //  back to back in a stream the operands come out of the L2 / MALL, there is no cold-miss latency to overlap)
-  set_tile(chunk_start + bix);
-  stage_all(0, 0);
+  if (has_tiles) {
+    set_tile(chunk_start + bix);
+    stage_all(0, 0);
+  }
+  // The up to 8 rows behind the last full row tile (M here is the 256-row multiple): every wave of the launch takes
+  // some output columns of them first -- in parallel instead of a separate launch behind this one, and BEHIND the first
+  // slab's DMAs, so that its loads share the latency the prologue waits for anyway.
+  if (m_tail > 0) {
+    LnFold lt = ln;
+    if (LN) lt.stats += M;
+    // groups of four columns, wave 0 of every workgroup first (a launch's workgroups stay balanced: N = 1024 gives one group
+    // to one wave of each of the 256 workgroups, not four to 64 of them)
+    const int gw = wid * (int)gridDim.x + (int)blockIdx.x, tw = (int)gridDim.x * 4;
+    const bf16_t* xt = X + M * ldx;
+    const bf16_t* rt = HAS_RES ? R + M * ldr : nullptr;
+    bf16_t* yt = Y + M * ldy;
+    if (m_tail == 1) skinny_columns<1>(xt, ldx, W, bias, rt, ldr, yt, ldy, 1, N, K, ACT, lt, lane, gw, tw);
+    else if (m_tail == 2) skinny_columns<2>(xt, ldx, W, bias, rt, ldr, yt, ldy, 2, N, K, ACT, lt, lane, gw, tw);
+    else if (m_tail <= 4) skinny_columns<4>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
+    else skinny_columns<8>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
+  }
+  if (!has_tiles) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
