@@ -1782,6 +1782,11 @@ def test_training_with_unequal_and_absent_trainable_edge_tensors(graph_o32):
     (10242, 512, 640, "Identity", True, False),     # config 2's projection (K = 10 slabs), 96-row tiles
     (4608, 1024, 2048, "GELU", False, True),        # 48 * 96 rows exactly (MH = 3: odd waves start mid swizzle period), LN fold
     (5121, 1024, 2048, "SiLU", True, False),        # 96-row tiles, activation + residual
+    # the tail rows behind the last tile (four columns per wave, row count as a template: 1 / 2 / 4 / 8 rows)
+    (4100, 4096, 1024, "GELU", False, True),        # 4 tail rows, LayerNorm fold, one column group per wave
+    (4101, 1032, 640, "Identity", True, False),     # 5 tail rows (template of 8), ragged last column group + column tile
+    (4104, 2048, 4096, "SiLU", True, False),        # 8 tail rows, K = 8 chunks
+    (40961, 1024, 1024, "Identity", False, False),  # 1 tail row behind 160 tiles
 ])
 def test_linear_remainder_round_shapes(m, n, k, act, res, fold):
     """Shapes whose tile count leaves a short remainder round on the 256 CUs (full mesh and per-rank sizes of config 3):
