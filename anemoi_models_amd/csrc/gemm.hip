@@ -1146,7 +1146,11 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     // MH / 8 of its 6.5 us epilogue; what decides is how the tile count quantises against the 256 CUs
     // (5121 x 2048: 160 / 216 / 256 / 320 tiles -> 160-row tiles fill the chip exactly once;
     //  5121 x 4096: 320 / 432 / 512 / 640 -> two balanced rounds of 160-row tiles; profiles/r04_gemm_small_m.txt).
-    if (!batched && !dual && !gmul && mt_b == 0 && mt * nt < 4 * max_blocks) {
+    // (a half-tile split chosen above competes with the single-launch candidates: its cost by the same model = whole rounds of
+    //  256-row tiles + the rounds of half tiles at 0.75 of the slab cost + ~6 us for the second launch.  20 481 x 1024 x 4096,
+    //  one rank of two: 256 + 128 half tiles = 177 against 158 for two rounds of 160-row tiles)
+    const bool split_chosen = mt_b > 0 && !dual && !gmul;
+    if (!batched && !dual && !gmul && (mt_b == 0 || split_chosen) && mt * nt < 4 * max_blocks) {
       static const int forced_mh = [] {  // lab switch for A/B runs: ANEMOI_AMD_GEMM_MH=3|4|5|6|8
         const char* e = getenv("ANEMOI_AMD_GEMM_MH");
         return e != nullptr ? atoi(e) : 0;
@@ -1162,7 +1166,18 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
           if (forced_mh == mh) break;
         }
       }
-      if (best_mh != 8) {
+      bool single = best_mh != 8;
+      if (split_chosen) {
+        const int64_t rounds_a = (mt_a * nt + max_blocks - 1) / max_blocks, rounds_b = (mt_b * 2 * nt + max_blocks - 1) / max_blocks;
+        const double split_cost = (double)rounds_a * (0.8125 * 8 + (K / 64) * 1.44) +
+                                  (double)rounds_b * (0.8125 * 4 + (K / 64) * 1.44 * 0.75) + 6.0;
+        single = forced_mh != 0 || best_cost < split_cost * 0.97;  // (a forced height means ONE launch of that height)
+        if (single) {  // one launch of best_mh-row tiles (8 included) instead of the split
+          mt_a = mt;
+          mt_b = 0;
+        }
+      }
+      if (single && best_mh != 8) {
         const int64_t tiles = (M + 32 * best_mh - 1) / (32 * best_mh) * nt;
         w4_blocks = tiles < max_blocks ? (tiles + 7) / 8 * 8 : max_blocks;
         if (best_mh == 6) { LAUNCH_W4_PLAIN(6, xb, rb, yb, ln, M, tiles, w4_tail) }
