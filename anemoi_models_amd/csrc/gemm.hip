@@ -605,13 +605,16 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
   // prologue: slabs 0 and 1 of the first tile; fragments of (slab 0, ks 0)
   // (issuing slab 1 together with slab 0 and waiting for slab 0 alone -- vmcnt(NRD) -- measured no difference on any shape:
   //  back to back in a stream the operands come out of the L2 / MALL, there is no cold-miss latency to overlap)
+  // The up to 8 rows behind the last full row tile (M here is the 256-row multiple): every wave of the launch takes
+  // some output columns of them first -- in parallel instead of a separate launch behind this one.  (Issued BEHIND the
+  // first slab's DMAs, to share the latency the prologue waits for anyway, the pass measured slower on every configuration:
+  // config 3 35.8 vs 35.6 ms, config 2 3.36 vs 3.28 ms, same boxes -- ANEMOI_LAB_TAIL_BEHIND_DMA keeps that order for A/B builds.)
+#ifdef ANEMOI_LAB_TAIL_BEHIND_DMA
   if (has_tiles) {
     set_tile(chunk_start + bix);
     stage_all(0, 0);
   }
-  // The up to 8 rows behind the last full row tile (M here is the 256-row multiple): every wave of the launch takes
-  // some output columns of them first -- in parallel instead of a separate launch behind this one, and BEHIND the first
-  // slab's DMAs, so that its loads share the latency the prologue waits for anyway.
+#endif
   if (m_tail > 0) {
     LnFold lt = ln;
     if (LN) lt.stats += M;
@@ -627,6 +630,10 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     else skinny_columns<8>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
   }
   if (!has_tiles) return;
+#ifndef ANEMOI_LAB_TAIL_BEHIND_DMA
+  set_tile(chunk_start + bix);
+  stage_all(0, 0);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
