@@ -398,6 +398,325 @@ static void launch_folded(const EdgeFoldParams& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Folded path, SCHEDULED (round 5).  Same arithmetic, same per-destination summation order, bit-identical results; what
+// changes is who walks which destination and when the index chain is resolved:
+//  * a static schedule ``sched [8 XCDs][slots][steps]`` (host-built, runtime.EdgePlan.schedule) names the destinations
+//    of every wave slot.  At step i the slots of an XCD still work on one contiguous group of destinations (the L2
+//    window is unchanged), but inside the group the heavy destinations go to the slots with the least work so far: on
+//    the ico-6 multi-scale mesh (in-degree 6 ... 36, mean 8) the plain round-robin leaves the busiest wave with 204
+//    edges against a mean of 128, and a launch of resident waves lasts as long as its busiest wave;
+//  * the chain  schedule entry -> row pointers -> source ids  is resolved by SCALAR loads one destination ahead each
+//    (entry i + 3, row pointers i + 2, the first NPF source ids of destination i + 1 while destination i is processed):
+//    SGPRs only, no vector register is spent on it, and the first 2 x U row gathers of a destination leave as soon as
+//    the previous destination's registers are free instead of two dependent round trips later.
+// The entries of a slot end with >= 3 times -1.
+// ---------------------------------------------------------------------------------------------
+// W consecutive 32-bit words through a buffer descriptor (W = 1, 2, 4, 6, 8: b32 / b64 / b128 pieces)
+template <int W>
+__device__ __forceinline__ void buffer_load_words(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint32_t (&w)[W]) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  static_assert(W == 1 || W % 2 == 0, "one word or whole 8-byte pieces");
+  if constexpr (W == 1) {
+    w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i + 4 <= W; i += 4) {
+      const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 4, soff, 0);
+      w[i] = t.x; w[i + 1] = t.y; w[i + 2] = t.z; w[i + 3] = t.w;
+    }
+    if constexpr (W % 4 == 2) {
+      const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (W - 2) * 4, soff, 0);
+      w[W - 2] = t.x; w[W - 1] = t.y;
+    }
+  }
+}
+template <int W>
+__device__ __forceinline__ void buffer_store_words(__amdgpu_buffer_rsrc_t rs, int voff, int soff, const uint32_t (&w)[W]) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  static_assert(W == 1 || W % 2 == 0, "one word or whole 8-byte pieces");
+  if constexpr (W == 1) {
+    __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, voff, soff, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i + 4 <= W; i += 4)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[i], w[i + 1], w[i + 2], w[i + 3]}, rs, voff + i * 4, soff, 0);
+    if constexpr (W % 4 == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w[W - 2], w[W - 1]}, rs, voff + (W - 2) * 4, soff, 0);
+  }
+}
+
+// N consecutive floats through a buffer descriptor (voffset = the lane's byte offset, soffset = the row's, scalar)
+template <int N>
+__device__ __forceinline__ void buffer_load_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float (&r)[N]) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  static_assert(N % 2 == 0, "whole 8-byte pieces");
+#pragma unroll
+  for (int i = 0; i + 4 <= N; i += 4) {
+    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 4, soff, 0);
+    r[i] = __uint_as_float(t.x); r[i + 1] = __uint_as_float(t.y); r[i + 2] = __uint_as_float(t.z); r[i + 3] = __uint_as_float(t.w);
+  }
+  if constexpr (N % 4 == 2) {
+    const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (N - 2) * 4, soff, 0);
+    r[N - 2] = __uint_as_float(t.x); r[N - 1] = __uint_as_float(t.y);
+  }
+}
+
+template <typename T, int VEC, int LPH, int UP, int U, int NPF>
+__global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(const EdgeFoldParams p,
+                                                                         const float* __restrict__ attr_,
+                                                                         const int32_t* __restrict__ rowptr_,
+                                                                         const int32_t* __restrict__ col_,
+                                                                         const int32_t* __restrict__ sched_,
+                                                                         int slots, int steps) {
+  using Raw = typename RawVec<T, VEC>::type;
+  constexpr int APL = attrs_per_lane(UP, LPH);
+  static_assert(UP % APL == 0 && APL * LPH >= UP, "a lane owns APL whole attributes or none");
+  static_assert(NPF % U == 0, "whole chunks of prefetched source ids");
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
+  const int slice = wave_in_xcd % p.n_slices;
+  const int slot = wave_in_xcd / p.n_slices;
+  if (slot >= slots) return;
+  const int32_t* my = sched_ + ((int64_t)xcd * slots + slot) * steps;
+  const int n_edges = rowptr_[p.n_dst];
+
+  const int lanes_total = p.C / VEC;
+  const int gl = slice * 64 + lane;
+  const bool active = gl < lanes_total;
+  const int gls = active ? gl : 0;
+  const int c0 = gls * VEC;
+  const int head = gls / LPH;
+  const int a0 = (gls % LPH) * APL;
+  const bool a_own = a0 < UP;
+  const int a_ld = a_own ? a0 : 0;
+  const float amask = a_own ? 1.f : 0.f;
+
+  static_assert(sizeof(Raw) == 16, "one 16-byte row slice per lane");
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const int lane_off = c0 * (int)sizeof(T);  // the lane's byte offset inside a node row
+  const int attr_off = a_ld * 4;             // ... inside an attribute row
+  const uint32_t row_bytes = (uint32_t)(p.ldkv * (int64_t)sizeof(T));
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.k), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.v), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ars =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(attr_), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.q), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.u), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xr), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, -1, 0x00020000);
+  const uint32_t q_row_bytes = (uint32_t)(p.ldq * (int64_t)sizeof(T)), u_row_bytes = (uint32_t)(p.ldu * (int64_t)sizeof(T));
+  const uint32_t xr_row_bytes = (uint32_t)(p.ldr * (int64_t)sizeof(T)), o_row_bytes = (uint32_t)(p.ldo * (int64_t)sizeof(T));
+  const int u_off = (head * UP + a_ld) * (int)sizeof(T);
+  const int t_off = (p.C + head * UP + a0) * (int)sizeof(T);
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  constexpr int VP = (VEC + 1) / 2;
+
+  // the first NPF source ids of a destination whose segment starts at rb (clamped reads at the very end of the array)
+  auto load_cols = [&](int rb, int (&c)[NPF]) __attribute__((always_inline)) {
+    if (rb + NPF <= n_edges) {
+#pragma unroll
+      for (int kk = 0; kk < NPF; ++kk) c[kk] = col_[rb + kk];
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < NPF; ++kk) c[kk] = col_[rb + kk < n_edges ? rb + kk : n_edges - 1];
+    }
+  };
+
+  // scalar pipeline: destination 0 complete, destination 1 with its row pointers, destination 2 by id
+  int node0 = my[0], node1 = my[1], node2 = my[2];
+  if (node0 < 0) return;
+  int rb0 = rowptr_[node0], re0 = rowptr_[node0 + 1];
+  int rb1 = rowptr_[node1 < 0 ? 0 : node1], re1 = rowptr_[(node1 < 0 ? 0 : node1) + 1];
+  int cols0[NPF];
+  load_cols(rb0, cols0);
+
+  for (int step = 0; node0 >= 0; ++step) {
+    // ---- the index chain of the destinations behind this one (scalar loads, consumed at the end of this iteration)
+    int cols1[NPF];
+    load_cols(rb1, cols1);
+    const int n2 = node2 < 0 ? 0 : node2;
+    const int rb2 = rowptr_[n2], re2 = rowptr_[n2 + 1];
+    const int node3 = my[step + 3];
+
+    const int64_t node = node0;
+    const int e_begin = rb0, e_end = re0;
+    float m = -INFINITY, l = 0.f;
+    f32x2_t acc[VP];
+    float tacc[APL];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
+    QK<T, VEC> qk;
+    float u[APL];
+    Raw kr[U], vr[U];
+    float at[U][APL];
+
+    // U edges starting at CSR slot e, their source ids in j[]: request the k / v row slices and the attribute rows ...
+    auto issue = [&](int e, const int (&j)[U]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          // buffer loads: descriptor of the whole k / v / attribute matrix, the row's byte offset as the (scalar) soffset,
+          // the lane's byte offset as the one shared 32-bit voffset -- no 64-bit per-lane address is formed or kept
+          // (twelve of them cost this kernel its fifth wave per SIMD); the host guarantees matrices below 4 GiB
+          const int row = (int)((uint32_t)j[uu] * (uint32_t)row_bytes);
+          const u32x4_t kw = __builtin_amdgcn_raw_buffer_load_b128(krs, lane_off, row, 0);
+          const u32x4_t vw = __builtin_amdgcn_raw_buffer_load_b128(vrs, lane_off, row, 0);
+          kr[uu] = __builtin_bit_cast(Raw, kw);
+          vr[uu] = __builtin_bit_cast(Raw, vw);
+          buffer_load_f32<APL>(ars, attr_off, (int)((uint32_t)(e + uu) * (uint32_t)(UP * 4)), at[uu]);
+        }
+      }
+    };
+    // ... and the online-softmax update of the plain folded kernel on them
+    auto consume = [&](int e) __attribute__((always_inline)) {
+      float s[U];
+      float mb = m;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        s[uu] = -INFINITY;
+        if (e + uu < e_end) {
+          float t = qk.dot(kr[uu]);
+#pragma unroll
+          for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[uu][a], t);
+          s[uu] = group_sum<LPH>(t) * p.scale;
+          mb = fmaxf(mb, s[uu]);
+        }
+      }
+      const float corr = __expf(m - mb);
+      l *= corr;
+#pragma unroll
+      for (int i = 0; i < VP; ++i) acc[i] *= corr;
+#pragma unroll
+      for (int a = 0; a < APL; ++a) tacc[a] *= corr;
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (e + uu < e_end) {
+          const float pe = __expf(s[uu] - mb);
+          l += pe;
+          float vv[VEC];
+          unpack<T, VEC>(vr[uu], vv);
+#pragma unroll
+          for (int i = 0; i < VP; ++i)
+            acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f},
+                                               acc[i]);
+#pragma unroll
+          for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
+        }
+      }
+      m = mb;
+    };
+
+    // the first chunk's gathers leave FIRST (their ids are already in SGPRs); q, u and x_r of the destination follow as raw
+    // words, so that one s_waitcnt covers all of a destination's first loads (q / u requested ahead of the gathers put a
+    // dependent round trip in front of them: the compiler converts u where it is loaded)
+    {
+      int j[U];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) j[uu] = cols0[uu];
+      issue(e_begin, j);
+    }
+    const u32x4_t q_raw = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane_off, (int)((uint32_t)node * q_row_bytes), 2);
+    RawWords<T, APL> u_raw;
+    buffer_load_words<RawWords<T, APL>::W>(urs, u_off, (int)((uint32_t)node * u_row_bytes), u_raw.w);
+    u32x4_t xr_raw = {0u, 0u, 0u, 0u};
+    if (p.xr != nullptr) xr_raw = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, (int)((uint32_t)node * xr_row_bytes), 2);
+    {
+      const uint32_t qw[4] = {q_raw.x, q_raw.y, q_raw.z, q_raw.w};
+      qk.set_raw(qw);
+    }
+    u_raw.get(u);
+#pragma unroll
+    for (int i = 0; i < APL; ++i) u[i] *= amask;
+    if (e_begin < e_end) consume(e_begin);
+#pragma unroll
+    for (int c = 1; c < NPF / U; ++c) {
+      if (e_begin + c * U < e_end) {
+        int j[U];
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) j[uu] = cols0[c * U + uu];
+        issue(e_begin + c * U, j);
+        consume(e_begin + c * U);
+      }
+    }
+    for (int e = e_begin + NPF; e < e_end; e += U) {  // in-degree > NPF: the rest of the ids as they are needed
+      int j[U];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) j[uu] = col_[e + uu < e_end ? e + uu : e_end - 1];
+      issue(e, j);
+      consume(e);
+    }
+
+    const float inv = 1.0f / (l + 1e-16f);
+    float o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
+    {
+      RawWords<T, VEC> xw;  // (zeros without x_r: + 0.0f leaves the sums as they are)
+      xw.w[0] = xr_raw.x; xw.w[1] = xr_raw.y; xw.w[2] = xr_raw.z; xw.w[3] = xr_raw.w;
+      float r[VEC];
+      xw.get(r);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] += r[i];
+    }
+    const int out_row = (int)((uint32_t)node * o_row_bytes);
+    if (active) {
+      u32x4_t ow;
+      VecIO<T, VEC>::store(reinterpret_cast<T*>(&ow), o);
+      __builtin_amdgcn_raw_buffer_store_b128(ow, ors, lane_off, out_row, 2);
+    }
+    if (active && a_own) {  // this lane's APL values of t~_i,h
+      float t4[APL];
+#pragma unroll
+      for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+      uint32_t tw[RawWords<T, APL>::W];
+      VecIO<T, APL>::store(reinterpret_cast<T*>(tw), t4);
+      buffer_store_words<RawWords<T, APL>::W>(ors, t_off, out_row, tw);
+    }
+    if (p.lse != nullptr && active && (gls % LPH) == 0) p.lse[node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);
+
+    // ---- rotate the scalar pipeline
+    node0 = node1; rb0 = rb1; re0 = re1;
+#pragma unroll
+    for (int kk = 0; kk < NPF; ++kk) cols0[kk] = cols1[kk];
+    node1 = node2; rb1 = rb2; re1 = re2;
+    node2 = node3;
+  }
+}
+
+// geometry of the scheduled launch: wave slots per XCD (every slot is n_slices waves, one per 512-channel slice)
+static void sched_shape(int64_t n_dst, int n_slices, int* slots, int* steps) {
+  constexpr int WPB = 4, wgs_per_cu = 5;
+  const int64_t per_xcd = (n_dst + 7) / 8;
+  int64_t bpx = (per_xcd * n_slices + WPB - 1) / WPB;
+  if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;
+  if (bpx < 1) bpx = 1;
+  while ((bpx * WPB) % n_slices != 0) ++bpx;
+  *slots = (int)(bpx * WPB / n_slices);
+  *steps = (int)((per_xcd + *slots - 1) / *slots) + 3;
+}
+
+template <typename T, int VEC, int LPH, int UP>
+static void launch_folded_sched(const EdgeFoldParams& p, const int32_t* sched, int slots, int steps, hipStream_t st) {
+  const unsigned blocks = (unsigned)(8 * ((int64_t)slots * p.n_slices / 4));
+  static const int u_env = getenv("ANEMOI_AMD_EDGE_U") ? atoi(getenv("ANEMOI_AMD_EDGE_U")) : 4;  // lab switch
+  if (u_env == 6)
+    hipLaunchKernelGGL((gt_edge_attention_folded_sched_kernel<T, VEC, LPH, UP, 6, 12>), dim3(blocks), dim3(256), 0, st, p,
+                       p.attr, p.rowptr, p.col, sched, slots, steps);
+  else if (u_env == 3)
+    hipLaunchKernelGGL((gt_edge_attention_folded_sched_kernel<T, VEC, LPH, UP, 3, 12>), dim3(blocks), dim3(256), 0, st, p,
+                       p.attr, p.rowptr, p.col, sched, slots, steps);
+  else
+    hipLaunchKernelGGL((gt_edge_attention_folded_sched_kernel<T, VEC, LPH, UP, 4, 8>), dim3(blocks), dim3(256), 0, st, p,
+                       p.attr, p.rowptr, p.col, sched, slots, steps);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Folded path on a graph whose destinations all have exactly THREE in-edges (the mesh -> grid decoder: every grid node
 // is fed by its three nearest mesh nodes, reference layers/mapper.py:348-418 on an anemoi-graphs KNN edge set), in RUNS:
 // consecutive destinations fed by the same three sources -- neighbouring grid points inside one mesh triangle; mean run
@@ -936,6 +1255,72 @@ extern "C" int anemoi_gt_edge_attention_folded(int dtype, const void* q, int64_t
                  "anemoi_gt_edge_attention_folded: unsupported shape (D=%d, UP=%d); use anemoi_gt_edge_attention", C / H,
                  up);
   return check_launch("anemoi_gt_edge_attention_folded");
+}
+
+// Launch geometry of anemoi_gt_edge_attention_folded_sched for a destination count / channel width / dtype: wave slots
+// per XCD and entries per slot of the schedule the caller builds (layout [8][slots][steps] int32; XCD x owns the
+// destinations [n_dst x / 8, n_dst (x + 1) / 8); every slot's list ends with at least three -1).
+extern "C" int anemoi_edge_schedule_shape(int dtype, int64_t n_dst, int C, int* slots, int* steps) {
+  ANEMOI_REQUIRE(slots && steps && n_dst >= 0 && C > 0 && (dtype == ANEMOI_F32 || dtype == ANEMOI_BF16), ANEMOI_ERR_INVALID,
+                 "anemoi_edge_schedule_shape: bad argument");
+  const int vec = dtype == ANEMOI_BF16 ? 8 : 4;
+  sched_shape(n_dst, (C + 64 * vec - 1) / (64 * vec), slots, steps);
+  return ANEMOI_OK;
+}
+
+// anemoi_gt_edge_attention_folded with a destination schedule (gt_edge_attention_folded_sched_kernel above): the same
+// result bit for bit.  ``sched`` int32 [8][slots][steps] as anemoi_edge_schedule_shape prescribes; every destination of
+// XCD x's range exactly once in XCD x's lists (the host builds it: runtime.EdgePlan.schedule); bf16 with 32- or 64-channel
+// heads -- every other shape takes the plain kernel.
+extern "C" int anemoi_gt_edge_attention_folded_sched(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                                                     int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
+                                                     const float* edge_attr, int up, const int32_t* rowptr,
+                                                     const int32_t* col, const int32_t* sched, int slots, int steps,
+                                                     void* out, int64_t ldo, float* lse, int64_t n_dst, int C, int H,
+                                                     anemoi_stream_t stream) {
+  const bool plain = sched == nullptr || dtype != ANEMOI_BF16 || H <= 0 || C % H != 0 || !((C / H) == 64 || (C / H) == 32) ||
+                     !(up == 4 || up == 8 || up == 12 || up == 16) || n_dst == 0;
+  if (plain)
+    return anemoi_gt_edge_attention_folded(dtype, q, ldq, k, v, ldkv, x_r, ldr, u, ldu, edge_attr, up, rowptr, col, out, ldo,
+                                           lse, n_dst, C, H, stream);
+  const char* who = "anemoi_gt_edge_attention_folded_sched";
+  ANEMOI_REQUIRE(q && k && v && u && out && col && edge_attr && rowptr, ANEMOI_ERR_INVALID, "%s: null pointer", who);
+  ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
+                     (x_r == nullptr || ldr >= C),
+                 ANEMOI_ERR_INVALID, "%s: leading dimension too small", who);
+  int want_slots = 0, want_steps = 0;
+  sched_shape(n_dst, (C + 511) / 512, &want_slots, &want_steps);
+  ANEMOI_REQUIRE(slots == want_slots && steps >= want_steps, ANEMOI_ERR_INVALID,
+                 "%s: schedule of %d slots x %d steps, this launch needs %d x >= %d (anemoi_edge_schedule_shape)", who, slots,
+                 steps, want_slots, want_steps);
+  const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                       ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                       (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % 8 == 0)) && ldq % 8 == 0 && ldkv % 8 == 0 &&
+                       ldu % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)edge_attr % 16 == 0) && C % 8 == 0;
+  ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED, "%s: operands must be 16-byte aligned", who);
+  EdgeFoldParams p;
+  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out; p.lse = lse;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
+  p.attr = edge_attr; p.rowptr = rowptr; p.col = col;
+  p.n_dst = n_dst; p.C = C; p.D = C / H;
+  p.n_slices = (C + 511) / 512;
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  p.stream_hint = 1;
+  hipStream_t st = as_stream(stream);
+#define ANEMOI_SCHED_UP(LPH)                                                                                   \
+  switch (up) {                                                                                                \
+    case 4: launch_folded_sched<bf16_t, 8, LPH, 4>(p, sched, slots, steps, st); break;                         \
+    case 8: launch_folded_sched<bf16_t, 8, LPH, 8>(p, sched, slots, steps, st); break;                         \
+    case 12: launch_folded_sched<bf16_t, 8, LPH, 12>(p, sched, slots, steps, st); break;                       \
+    default: launch_folded_sched<bf16_t, 8, LPH, 16>(p, sched, slots, steps, st); break;                       \
+  }
+  if (C / H == 64) {
+    ANEMOI_SCHED_UP(8)
+  } else {
+    ANEMOI_SCHED_UP(4)
+  }
+#undef ANEMOI_SCHED_UP
+  return check_launch(who);
 }
 
 // The folded edge phase on a uniform-degree-3 graph with its runs of destinations that share their three sources

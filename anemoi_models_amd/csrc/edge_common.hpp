@@ -39,6 +39,10 @@ struct QK<float, VEC> {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) q[i] = qf[i];
   }
+  __device__ __forceinline__ void set_raw(const uint32_t (&w)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) q[i] = __uint_as_float(w[i]);
+  }
   __device__ __forceinline__ float dot(const Raw& kr) const {
     float kk[VEC];
     unpack<float, VEC>(kr, kk);
@@ -59,6 +63,11 @@ struct QK<bf16_t, VEC> {
   __device__ __forceinline__ void set(const float (&qf)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC / 2; ++i) q[i] = pack_bf16x2(qf[2 * i], qf[2 * i + 1]);
+  }
+  // the packed words as they sit in memory: no conversion, so the load's s_waitcnt lands at the first dot product
+  __device__ __forceinline__ void set_raw(const uint32_t (&w)[VEC / 2]) {
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) q[i] = w[i];
   }
   __device__ __forceinline__ float dot(const Raw& kr) const {
     const uint32_t* kw = reinterpret_cast<const uint32_t*>(&kr);

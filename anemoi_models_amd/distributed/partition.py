@@ -116,6 +116,9 @@ class HaloExchange:
     # send buffers by (dtype, width), allocated once: the same exchange runs in every block of every step, and a block's
     # pack is ordered behind the previous block's transfer (``finish`` lets the stream wait for it) -- one buffer is enough
     _send: dict = field(default_factory=dict, repr=False, compare=False)
+    # measurement hook (bench.py ``exchanges``): a list collects, per exchange, four device events on the launch stream --
+    # before / after ``start`` (pack + enqueue) and before / after ``finish`` (the stream waiting for the transfer)
+    TIMING = None
 
     @property
     def n_recv(self) -> int:
@@ -135,17 +138,29 @@ class HaloExchange:
 
         Returns a handle for :meth:`finish`; between the two the caller may launch work that does not touch the halo
         rows (the x_r | q | u GEMM), which overlaps with the xGMI transfer."""
+        marks = None
+        if HaloExchange.TIMING is not None and rows.is_cuda:
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            marks[0].record()
         send = self._pack(rows, n_own) if not (torch.is_grad_enabled() and rows.requires_grad) else \
             rows[:n_own].index_select(0, self.send_idx)
         work = _alltoallv(rows[n_own:n_own + self.n_recv], send, self.recv_splits, self.send_splits, self.group,
                           async_op=True)
-        return (work, send)  # keep the send buffer alive until the transfer has been waited for
+        if marks is not None:
+            marks[1].record()
+        return (work, send, marks)  # keep the send buffer alive until the transfer has been waited for
 
     @staticmethod
     def finish(handle) -> None:
-        work = handle[0]
+        work, marks = handle[0], handle[2]
+        if marks is not None:
+            marks[2].record()
         if work is not None:
             work.wait()  # the current stream waits for RCCL's stream; the host does not block
+        if marks is not None:
+            marks[3].record()
+            if HaloExchange.TIMING is not None:
+                HaloExchange.TIMING.append(tuple(marks))
 
     def exchange(self, rows: Tensor, n_own: int) -> None:
         self.finish(self.start(rows, n_own))

@@ -41,6 +41,10 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks (bf16 / e
 # parity bounds of the run itself (max |a - b| / max |b| of the prediction): north_star's 1e-3 for f32; bf16 storage is
 # reported against the f32 oracle, measured 2.9e-3 at config 3 -- beyond 1e-2 the line is an error, not a result
 PARITY_BOUND = {"bf16": 1e-2, "fp32": 1e-3}
+# the encoder output (mesh latent, 1024 channels, BEFORE the processor) is gated as well: bf16 measured 9.8e-3 at config 3
+# -- the largest entries of a 1024-channel latent carry one bf16 rounding of the residual stream (attribution:
+# profiles/r05_latent_error.txt) --, f32 2e-6
+LATENT_BOUND = {"bf16": 2e-2, "fp32": 1e-3}
 
 WORKLOADS = {
     # name: (graph, channels, processor blocks, heads, description)
@@ -252,7 +256,61 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
     return out
 
 
-def cpu_baseline(model, graph, x, idx, n_blocks: int, hip_latent=None, hip_y=None):
+def _rel(a, b) -> float:
+    return float((a.float().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _per_variable_rel(a, b):
+    """SURVEY 8d parity gate: per output variable ``||a - b||_inf / ||b||_inf``."""
+    a, b = a.float().cpu().flatten(0, -2), b.flatten(0, -2)
+    return ((a - b).abs().max(dim=0).values / b.abs().max(dim=0).values.clamp_min(1e-30)).tolist()
+
+
+def device_forward_with_latent(model, x):
+    """One forward on the device that also hands back the encoder output (mesh latent) in the EXTERNAL node order."""
+    captured = {}
+    native = model.encoder.native
+
+    def capture(*a, **k):
+        out = native(*a, **k)
+        captured["latent"] = out[1] if isinstance(out, tuple) else out
+        return out
+
+    model.encoder.native = capture
+    try:
+        with torch.no_grad():
+            y = model(x)
+    finally:
+        del model.encoder.native  # back to the class's method
+    _, inv = model._mesh_order(x.device)
+    return y, captured["latent"][: inv.numel()].index_select(0, inv)[:, : model.num_channels]
+
+
+def f32_leg(model, x, steps: int = 5):
+    """The north star's own parity statement (1e-3 rel fp32) needs an f32 forward of the SAME model / input: the exact-f32
+    MFMA route of this package (``ANEMOI_AMD_DTYPE=fp32``), timed over ``steps`` forwards after one warm-up."""
+    before = os.environ.get("ANEMOI_AMD_DTYPE")
+    os.environ["ANEMOI_AMD_DTYPE"] = "fp32"
+    try:
+        y, latent = device_forward_with_latent(model, x)
+        y, latent = y.float().cpu(), latent.float().cpu()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(steps):
+                model(x)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        if before is None:
+            del os.environ["ANEMOI_AMD_DTYPE"]
+        else:
+            os.environ["ANEMOI_AMD_DTYPE"] = before
+    torch.cuda.empty_cache()
+    return y, latent, ms, steps
+
+
+def cpu_baseline(model, graph, x, idx, n_blocks: int, hip_latent=None, hip_y=None, f32=None):
     """CPU oracle (plain-PyTorch restatement of the reference algorithm, oracle/reference_path.py) timed on this host's
     cores on the SAME forward as the headline value: input assembly, encoder, processor, decoder, prognostic residual.
 
@@ -306,16 +364,27 @@ def cpu_baseline(model, graph, x, idx, n_blocks: int, hip_latent=None, hip_y=Non
     # parity of THIS run's device results against the oracle outputs the baseline has just produced on the same input
     # (the oracle is the checker here, never the product): the encoder output (mesh latent, 1024 ch) always; the final
     # prediction when every processor block was run
-    def rel(a, b):
-        return float((a.float().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
-
-    parity = {}
+    rel = _rel
+    parity, parity_fp32 = {}, None
     if hip_latent is not None:
         parity["encoder_out_rel_err"] = rel(hip_latent, x_latent)
     if hip_y is not None and n_blocks == n_layers:
         parity["output_rel_err"] = rel(hip_y, y)
+        pv = _per_variable_rel(hip_y, y)
+        parity["per_variable_rel_err_max"] = max(pv)
     if parity:
         parity["vs"] = "CPU oracle (f32) on the same weights / input, max |a - b| / max |b|"
+    if f32 is not None:  # the exact-f32 route of the same model on the same input: north_star's "within 1e-3 rel fp32"
+        y32, latent32, ms32, steps32 = f32
+        parity_fp32 = {"encoder_out_rel_err": rel(latent32, x_latent), "ms_per_step_f32": round(ms32, 3), "steps": steps32,
+                       "bound": PARITY_BOUND["fp32"], "processor_blocks_compared": n_blocks,
+                       "vs": "CPU oracle (f32), the device on its exact-f32 MFMA route (ANEMOI_AMD_DTYPE=fp32), same "
+                             "weights / input; per variable: ||a - b||_inf / ||b||_inf of every output column"}
+        if n_blocks == n_layers:
+            pv = _per_variable_rel(y32, y)
+            parity_fp32["output_rel_err"] = rel(y32, y)
+            parity_fp32["per_variable_rel_err_max"] = max(pv)
+            parity_fp32["per_variable_rel_err"] = [float(f"{v:.3e}") for v in pv]
     cpu = platform.processor() or platform.machine()
     try:
         with open("/proc/cpuinfo") as f:
@@ -331,18 +400,96 @@ def cpu_baseline(model, graph, x, idx, n_blocks: int, hip_latent=None, hip_y=Non
                   f"residual {t_dec:.1f} s = {t_fwd:.1f} s per step ({n_grid} grid / {n_mesh} mesh nodes, "
                   f"{model.num_channels} ch, mapper chunks {mapper_chunks}); measured {t_enc + t_blk + t_dec:.1f} s",
         **({"parity": parity} if parity else {}),
+        **({"parity_fp32": parity_fp32} if parity_fp32 else {}),
     }
 
 
-def _run(stage) -> int:
-    args = parse_args()
+class Stage:
+    """Where the run is, for the error line -- and for the watchdog: a stage with a time limit (process-group init, the
+    first collective, the partitioned-vs-single comparison: the places where a rank whose peer never arrives would block
+    for ever) that overruns ends the process with ONE JSON error line and exit code 4.  No restart, no retry."""
+
+    LIMITS_S = {"init_process_group": 300.0, "first all_reduce": 180.0, "parity_vs_single": 900.0,
+                "exchange timing": 300.0}
+
+    def __init__(self) -> None:
+        self.name, self.since = "start", time.monotonic()
+        scale = float(os.environ.get("ANEMOI_AMD_BENCH_WATCHDOG_SCALE", "1"))
+        self.limits = {k: v * scale for k, v in self.LIMITS_S.items()}
+        self._printed = False
+
+    def __getitem__(self, i):  # stage[0] / stage[0] = "...": the list protocol the code below uses
+        return self.name
+
+    def __setitem__(self, i, name) -> None:
+        self.name, self.since = name, time.monotonic()
+
+    def watch(self) -> None:
+        import threading
+
+        def loop():
+            while True:
+                time.sleep(0.5)
+                limit = self.limits.get(self.name)
+                if limit is not None and time.monotonic() - self.since > limit:
+                    print(json.dumps({"error": f"watchdog: stage '{self.name}' exceeded {limit:.0f} s (a peer rank missing "
+                                               "or a collective that never completes)", "stage": self.name,
+                                      "rank": int(os.environ.get("RANK", "0"))}), flush=True)
+                    os._exit(4)
+
+        threading.Thread(target=loop, daemon=True, name="bench-watchdog").start()
+
+
+def self_launch(n: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher: BEFORE this process has touched the GPU, start the N ranks as
+    children (``python -m torch.distributed.run --nproc-per-node N bench.py ...``, rendezvous on 127.0.0.1), relay rank
+    0's JSON line -- exactly one line on stdout -- and return the worst exit code.  (A process that has initialised the
+    GPU never re-launches or replaces itself; this one only imports torch.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)  # the children's stderr passes through
+    results, errors = [], []
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            try:
+                obj = json.loads(ln)
+            except ValueError:
+                obj = None
+            if isinstance(obj, dict):
+                (errors if "error" in obj else results).append(ln.rstrip("\n"))
+                continue
+        sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and results and not errors:
+        print(results[-1], flush=True)
+        return 0
+    if errors:
+        print(errors[0], flush=True)
+    else:
+        print(json.dumps({"error": f"torch.distributed.run exited with {rc} and no JSON line", "stage": "self-launch",
+                          "rank": 0}), flush=True)
+    return rc if rc != 0 else 3
+
+
+def _run(stage, args) -> int:
     failure = None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise RuntimeError(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (one process per GPU: "
+                           "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N, or plain "
+                           "python bench.py --gpus N, which launches them itself)")
+    stage.watch()
     from anemoi_models_amd import _lib
 
     _lib.load()  # fail loudly if the HIP library is missing
@@ -455,6 +602,14 @@ def _run(stage) -> int:
                   "worst rank", "bound": PARITY_BOUND[args.dtype],
         }
         del y_part, y_one
+        if not (parity_vs_single["finite"] and parity_vs_single["max_rel_err"] <= PARITY_BOUND[args.dtype]):
+            # every rank holds the all-reduced figure: nothing is timed on a partition that computes something else
+            dist.destroy_process_group()
+            if rank == 0:
+                print(json.dumps({"error": f"parity: partitioned forward differs from the single-GPU forward by "
+                                           f"{parity_vs_single['max_rel_err']:.3e} (bound {PARITY_BOUND[args.dtype]:g})",
+                                  "parity_vs_single": parity_vs_single, "stage": "parity_vs_single", "rank": 0}), flush=True)
+            return 3
     stage[0] = "warmup"
 
     for _ in range(args.warmup):
@@ -493,6 +648,8 @@ def _run(stage) -> int:
         dist.all_gather(every, t)
         rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
         elapsed = max(float(e.item()) for e in every)  # the contract's MAX over ranks
+    stage[0] = "exchange timing"
+    exchanges = exchange_timing(model, x, group, elapsed / args.steps * 1e3, share_gpu) if group is not None else None
     stage[0] = "profile pass"
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -525,6 +682,8 @@ def _run(stage) -> int:
             line["ms_per_step_ranks"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
                                          "all": [round(v, 3) for v in rank_ms]}
             line["parity_vs_single"] = parity_vs_single
+            if exchanges is not None:
+                line["exchanges"] = exchanges
         if group is not None:  # what this rank puts on the wire per forward step (rank 0's numbers; xGMI all-to-all-v)
             sp = next((v for k, v in model._idx_cache.items() if isinstance(k, tuple) and k[0] == "shard_plan"), None)
             if sp is not None:
@@ -545,43 +704,119 @@ def _run(stage) -> int:
         if args.processor != "GraphTransformer":
             line["config"]["workload"] = line["config"]["workload"].replace("GT blocks", f"{args.processor} blocks")
         if not args.no_cpu_baseline and world == 1 and args.processor == "GraphTransformer":
+            stage[0] = "cpu baseline"
             n_cpu = args.cpu_blocks if args.cpu_blocks is not None else layers
             # the device's encoder output (mesh latent, internal Morton row order -> external node order) and prediction
-            # for the same input, for the parity figures next to the baseline
-            captured = {}
-            native = model.encoder.native
-
-            def capture(*a, **k):
-                out = native(*a, **k)
-                captured["latent"] = out[1] if isinstance(out, tuple) else out
-                return out
-
-            model.encoder.native = capture
-            try:
-                with torch.no_grad():
-                    hip_y = model(x)
-            finally:
-                del model.encoder.native  # back to the class's method
-            _, inv = model._mesh_order(x.device)
-            hip_latent = captured["latent"][: inv.numel()].index_select(0, inv)[:, : model.num_channels]
-            line["cpu_baseline"] = cpu_baseline(model, graph, x, idx, n_cpu, hip_latent, hip_y)
-        print(json.dumps(line), flush=True)
+            # for the same input, for the parity figures next to the baseline; on a bf16 run the exact-f32 route of the same
+            # model as well (north_star: "within 1e-3 rel fp32" -- the f32 leg is what that sentence is checked on)
+            hip_y, hip_latent = device_forward_with_latent(model, x)
+            f32 = f32_leg(model, x) if args.dtype == "bf16" else None
+            line["cpu_baseline"] = cpu_baseline(model, graph, x, idx, n_cpu, hip_latent, hip_y, f32)
+        # every bound is evaluated BEFORE anything is printed: a run whose output failed its comparison prints the error
+        # line only (with the measured errors), never a result line a reader of the first "{" would take for a number
         bound = PARITY_BOUND[args.dtype]
-        out_err = line.get("cpu_baseline", {}).get("parity", {}).get("output_rel_err")
-        if out_err is not None and not out_err <= bound:
-            failure = f"parity: output_rel_err {out_err:.3e} against the CPU oracle exceeds {bound:g}"
+        base = line.get("cpu_baseline", {})
+        par, par32 = base.get("parity", {}), base.get("parity_fp32", {})
+        checks = [("output_rel_err", par.get("output_rel_err"), bound),
+                  ("encoder_out_rel_err", par.get("encoder_out_rel_err"), LATENT_BOUND[args.dtype]),
+                  ("parity_fp32.output_rel_err", par32.get("output_rel_err"), PARITY_BOUND["fp32"]),
+                  ("parity_fp32.per_variable_rel_err_max", par32.get("per_variable_rel_err_max"), PARITY_BOUND["fp32"]),
+                  ("parity_fp32.encoder_out_rel_err", par32.get("encoder_out_rel_err"), LATENT_BOUND["fp32"])]
+        bad = [f"{name} {val:.3e} > {lim:g}" for name, val, lim in checks if val is not None and not val <= lim]
+        if bad:
+            failure = {"error": "parity against the CPU oracle: " + "; ".join(bad), "parity": par, "parity_fp32":
+                       {k: v for k, v in par32.items() if k != "per_variable_rel_err"}}
         if parity_vs_single is not None and not (parity_vs_single["finite"] and parity_vs_single["max_rel_err"] <= bound):
-            failure = (f"parity: partitioned forward differs from the single-GPU forward by "
-                       f"{parity_vs_single['max_rel_err']:.3e} (bound {bound:g})")
+            failure = {"error": f"parity: partitioned forward differs from the single-GPU forward by "
+                                f"{parity_vs_single['max_rel_err']:.3e} (bound {bound:g})", "parity_vs_single": parity_vs_single}
+        if failure is None:
+            print(json.dumps(line), flush=True)
     stage[0] = "teardown"
     if group is not None:
         import torch.distributed as dist
 
         dist.destroy_process_group()
     if failure is not None:
-        print(json.dumps({"error": failure, "stage": "parity", "rank": rank}), flush=True)
+        print(json.dumps({**failure, "stage": "parity", "rank": rank}), flush=True)
         return 3
     return 0
+
+
+def exchange_timing(model, x, group, step_ms: float, share_gpu: bool):
+    """N > 1: what the halo exchanges cost and how much of it the step sees.
+
+    * ``alone_us``: every all-to-all-v of the step's plans (processor k|v halo, decoder halo) issued ALONE, device idle on
+      both sides, 20 repetitions -- the collective's own latency at this world size (min / median / max over the
+      repetitions, worst rank);
+    * ``in_step``: one instrumented forward with device events on the launch stream around ``HaloExchange.start`` (pack
+      + enqueue) and ``HaloExchange.finish`` (the stream waiting for the transfer): ``exposed_us`` is the time the
+      compute stream stood still in ``finish`` -- 0 when the transfer hides behind the GEMM launched in between --,
+      ``window_us`` start to finish.  ``exposed_fraction_of_step`` = sum of the exposed waits / the measured step.
+    """
+    import statistics
+
+    import torch.distributed as dist
+
+    from anemoi_models_amd.distributed.partition import HaloExchange
+
+    sp = next((v for k, v in model._idx_cache.items() if isinstance(k, tuple) and k[0] == "shard_plan"), None)
+    if sp is None:
+        return None
+    dtype = torch.bfloat16 if os.environ.get("ANEMOI_AMD_DTYPE") == "bf16" else torch.float32
+    width = 2 * model.num_channels
+    out = {}
+
+    def reduce_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if share_gpu else x.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return [float(v) for v in t.tolist()]
+
+    alone = {}
+    for name, lg in (("processor", sp.proc), ("decoder", sp.dec)):
+        halo = getattr(lg, "halo", None)
+        if halo is None:
+            continue
+        n_own = lg.n_own_src
+        rows = torch.zeros((n_own + halo.n_recv, width), dtype=dtype, device=x.device)
+        us = []
+        for it in range(23):
+            torch.cuda.synchronize()
+            dist.barrier(group=group)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            halo.exchange(rows, n_own)
+            torch.cuda.synchronize()
+            if it >= 3:
+                us.append((time.perf_counter() - t0) * 1e6)
+        lo, med, hi = reduce_max([min(us), statistics.median(us), max(us)])
+        alone[name] = {"min": round(lo, 1), "median": round(med, 1), "max": round(hi, 1),
+                       "rows_sent": int(sum(halo.send_splits)), "rows_received": int(halo.n_recv),
+                       "bytes_received": int(halo.n_recv) * width * rows.element_size()}
+        del rows
+    out["alone_us"] = alone
+    HaloExchange.TIMING = []
+    try:
+        with torch.no_grad():
+            model(x, group)
+        torch.cuda.synchronize()
+        rec = HaloExchange.TIMING
+    finally:
+        HaloExchange.TIMING = None
+    if rec:
+        start = [e0.elapsed_time(e1) * 1e3 for e0, e1, e2, e3 in rec]
+        exposed = [e2.elapsed_time(e3) * 1e3 for e0, e1, e2, e3 in rec]
+        window = [e0.elapsed_time(e3) * 1e3 for e0, e1, e2, e3 in rec]
+
+        def mmm(v):
+            return {"min": round(min(v), 1), "median": round(statistics.median(v), 1), "max": round(max(v), 1)}
+
+        tot = reduce_max([sum(exposed), sum(start)])
+        out["in_step"] = {"exchanges": len(rec), "start_us": mmm(start), "exposed_us": mmm(exposed), "window_us": mmm(window),
+                          "exposed_us_per_step_worst_rank": round(tot[0], 1), "pack_us_per_step_worst_rank": round(tot[1], 1),
+                          "exposed_fraction_of_step": round(tot[0] * 1e-3 / step_ms, 4), "rank": 0}
+    out["note"] = ("device events on the launch stream around HaloExchange.start / finish; 'exposed' = the compute stream "
+                   "waiting inside finish" + (" [DEBUG: host-staged gloo on a shared GPU -- not RCCL timings]" if share_gpu else ""))
+    return out
 
 
 def _backend_name(group) -> str:
@@ -594,9 +829,12 @@ def main() -> int:
     """Runs the benchmark; any failure (process-group init, a collective, a kernel status, parity beyond its bound) ends in
     ONE JSON error line on stdout and a non-zero exit code -- never a bare traceback the driver would have to parse, never
     a number printed for an output nobody compared with anything."""
-    stage = ["start"]
+    stage = Stage()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, sys.argv[1:])  # nothing has touched the GPU yet
     try:
-        return _run(stage)
+        return _run(stage, args)
     except SystemExit:
         raise
     except BaseException as exc:  # noqa: BLE001  (KeyboardInterrupt included: the driver's timeout)

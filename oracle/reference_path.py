@@ -240,7 +240,7 @@ def mlp(sd: SD, p: str, x: Tensor, act: str = "SiLU", n_extra_layers: int = 0, l
         x = a(x)
         idx += 1
     if layer_norm:
-        x = _ln(sd, f"{p}.model.{idx}", x)
+        x = _ln(sd, f"{p}.model.{idx}", x).type_as(x)  # layers/utils.py:27-39 AutocastLayerNorm: cast back to the input type
     return x
 
 

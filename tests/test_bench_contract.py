@@ -36,9 +36,69 @@ def test_bench_failure_is_one_json_error_line():
 
 
 def test_bench_gpus_mismatch_refused():
+    """``--gpus`` must be the launcher's WORLD_SIZE: a mismatch is one JSON error line, not a silently smaller run."""
     res = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
-    assert res.returncode != 0 and "torch.distributed.run" in (res.stderr + res.stdout)
+                         env=dict(os.environ, WORLD_SIZE="2", RANK="0"))
+    assert res.returncode != 0
+    out = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, res.stdout
+    line = json.loads(out[0])
+    assert "error" in line and "WORLD_SIZE=2" in line["error"] and "metric" not in line
+
+
+def _env_without_launcher(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bench_self_launch_relays_one_error_line_without_a_gpu():
+    """``python bench.py --gpus 2`` with no launcher starts its two ranks itself (before touching the GPU) and relays ONE
+    JSON line.  In the CPU container both ranks fail (no device): the parent prints one error line, exit code != 0."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU (the GPU boxes run test_bench_self_launch_on_a_shared_gpu)")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "cfg1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=_env_without_launcher())
+    assert res.returncode != 0
+    out = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, res.stdout
+    line = json.loads(out[0])
+    assert "error" in line and "stage" in line and "metric" not in line
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_on_a_shared_gpu():
+    """The same command on a GPU box (the two ranks share cuda:0 over host-staged gloo): one result line, exit code 0, with
+    the N > 1 self-checks and the per-exchange timing block."""
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg1",
+                          "--dtype", "fp32", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200,
+                         env=_env_without_launcher(ANEMOI_AMD_BENCH_SHARE_GPU="1"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, res.stdout
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["parity_vs_single"]["finite"]
+    ex = line["exchanges"]
+    assert ex["alone_us"]["processor"]["median"] > 0 and ex["in_step"]["exchanges"] >= 4  # 4 blocks (+ the decoder's)
+    assert 0.0 <= ex["in_step"]["exposed_fraction_of_step"]
+
+
+@pytest.mark.gpu
+def test_bench_watchdog_ends_a_rank_whose_peer_never_arrives():
+    """World 2 with only rank 0 started: process-group init can never complete.  The watchdog prints ONE JSON error line
+    naming the stage and ends the process with exit code 4 -- bounded, no restart."""
+    port = 29600 + (os.getpid() % 300)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               ANEMOI_AMD_BENCH_SHARE_GPU="1", ANEMOI_AMD_BENCH_WATCHDOG_SCALE="0.05")  # init limit 300 s -> 15 s
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "cfg1",
+                          "--dtype", "fp32", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 4, (res.returncode, res.stderr[-2000:])
+    out = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, res.stdout
+    line = json.loads(out[0])
+    assert "watchdog" in line["error"] and line["stage"] == "init_process_group"
 
 
 @pytest.mark.gpu
@@ -79,3 +139,5 @@ def test_bench_main_world_n_ranks_sharing_one_gpu(world, workload, extra):
     assert len(ranks["all"]) == world and ranks["min"] <= ranks["max"]
     assert abs(ranks["max"] - line["ms_per_step"]) < 1e-2 * line["ms_per_step"] + 1e-3  # value = MAX over ranks
     assert line["halo"]["own_mesh_rows"] > 0 and "DEBUG" in line["config"]["parallelism"]
+    ex = line["exchanges"]  # per-exchange timing: every halo all-to-all-v alone, and start / exposed wait inside a step
+    assert set(ex["alone_us"]) >= {"processor"} and ex["in_step"]["exchanges"] > 0
