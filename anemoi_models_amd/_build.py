@@ -52,7 +52,13 @@ def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(f) > t for f in _deps())
+    if any(os.path.getmtime(f) > t for f in _deps()):
+        return True
+    try:  # built by another hipcc than the one on this box?
+        with open(os.path.join(LIB_DIR, "obj", ".hipcc_version")) as f:
+            return f.read() != _hipcc_version(_hipcc())
+    except (OSError, RuntimeError):
+        return False  # (no stamp / no compiler here: a shipped library is used as it is)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -62,6 +68,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.join(LIB_DIR, "obj"), exist_ok=True)
     hipcc = _hipcc()
     version = _hipcc_version(hipcc)
+    # objects of another compiler are never reused: anemoi_build_info() names ONE hipcc (the one the hand-counted wait
+    # states of the inline-asm kernels were validated against), so a compiler upgrade rebuilds everything
+    stamp = os.path.join(LIB_DIR, "obj", ".hipcc_version")
+    try:
+        with open(stamp) as f:
+            same_compiler = f.read() == version
+    except OSError:
+        same_compiler = False
+    if not same_compiler:
+        force = True
     hdr_time = max(os.path.getmtime(f) for f in _deps() if not f.endswith(".hip"))
 
     def compile_one(src: str) -> str:
@@ -84,6 +100,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{res.stderr}")
+    with open(stamp, "w") as f:
+        f.write(version)
     return LIB_PATH
 
 

@@ -40,9 +40,15 @@ int check_args(const anemoi_gt_block_args* a, const char* who, bool with_input) 
 }
 
 int run_tail(const anemoi_gt_block_args* a, anemoi_stream_t stream) {
-  int st = anemoi_gt_edge_attention_folded_runs(a->dtype, a->q, a->ldq, a->k, a->v, a->ldkv, a->x_r, a->ldr, a->u, a->ldu,
-                                                a->edge_attr, a->up, a->rowptr, a->col, a->run_ptr, a->run_perm, a->n_runs,
-                                                a->att, a->ld_att, nullptr, a->n_dst, a->C, a->H, stream);
+  int st;
+  if (a->sched != nullptr && a->run_ptr == nullptr)
+    st = anemoi_gt_edge_attention_folded_sched(a->dtype, a->q, a->ldq, a->k, a->v, a->ldkv, a->x_r, a->ldr, a->u, a->ldu,
+                                               a->edge_attr, a->up, a->rowptr, a->col, a->sched, a->sched_slots, a->sched_steps,
+                                               a->n_src, a->att, a->ld_att, nullptr, a->n_dst, a->C, a->H, stream);
+  else
+    st = anemoi_gt_edge_attention_folded_runs(a->dtype, a->q, a->ldq, a->k, a->v, a->ldkv, a->x_r, a->ldr, a->u, a->ldu,
+                                              a->edge_attr, a->up, a->rowptr, a->col, a->run_ptr, a->run_perm, a->n_runs,
+                                              a->att, a->ld_att, nullptr, a->n_dst, a->C, a->H, stream);
   if (st != ANEMOI_OK) return st;
   // y = projection(att) + res, with { rstd, -mean rstd } of y's rows for the node MLP's LayerNorm
   st = anemoi_linear_stats(a->dtype, a->att, a->ld_att, a->w_proj, a->b_proj, nullptr, nullptr, a->res, a->ld_res, a->y,

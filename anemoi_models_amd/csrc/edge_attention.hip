@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(con
   const int slot = wave_in_xcd / p.n_slices;
   if (slot >= slots) return;
   const int32_t* my = sched_ + ((int64_t)xcd * slots + slot) * steps;
-  const int n_edges = rowptr_[p.n_dst];
+  const int n_edges = max(rowptr_[p.n_dst], 1);  // (the caller's col / attribute arrays hold at least one entry)
 
   const int lanes_total = p.C / VEC;
   const int gl = slice * 64 + lane;
@@ -655,14 +655,14 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(con
     const float inv = 1.0f / (l + 1e-16f);
     float o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = acc[i >> 1][i & 1] * inv;
+    for (int i = 0; i < VEC; ++i) o[i] = __fmul_rn(acc[i >> 1][i & 1], inv);
     {
       RawWords<T, VEC> xw;  // (zeros without x_r: + 0.0f leaves the sums as they are)
       xw.w[0] = xr_raw.x; xw.w[1] = xr_raw.y; xw.w[2] = xr_raw.z; xw.w[3] = xr_raw.w;
       float r[VEC];
       xw.get(r);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] += r[i];
+      for (int i = 0; i < VEC; ++i) o[i] = __fadd_rn(o[i], r[i]);  // (no contraction with the * inv above: the plain kernel's rounding)
     }
     const int out_row = (int)((uint32_t)node * o_row_bytes);
     if (active) {
@@ -691,7 +691,8 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(con
 
 // geometry of the scheduled launch: wave slots per XCD (every slot is n_slices waves, one per 512-channel slice)
 static void sched_shape(int64_t n_dst, int n_slices, int* slots, int* steps) {
-  constexpr int WPB = 4, wgs_per_cu = 5;
+  constexpr int WPB = 4;
+  static const int wgs_per_cu = getenv("ANEMOI_AMD_EDGE_WGS") ? atoi(getenv("ANEMOI_AMD_EDGE_WGS")) : 5;  // lab switch
   const int64_t per_xcd = (n_dst + 7) / 8;
   int64_t bpx = (per_xcd * n_slices + WPB - 1) / WPB;
   if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;
@@ -1276,10 +1277,14 @@ extern "C" int anemoi_gt_edge_attention_folded_sched(int dtype, const void* q, i
                                                      int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
                                                      const float* edge_attr, int up, const int32_t* rowptr,
                                                      const int32_t* col, const int32_t* sched, int slots, int steps,
-                                                     void* out, int64_t ldo, float* lse, int64_t n_dst, int C, int H,
-                                                     anemoi_stream_t stream) {
+                                                     int64_t n_src, void* out, int64_t ldo, float* lse, int64_t n_dst, int C,
+                                                     int H, anemoi_stream_t stream) {
+  // the kernel addresses rows as 32-bit byte offsets from the matrix bases (buffer loads): every matrix below 4 GiB
+  const int64_t lim = (int64_t)1 << 32;
+  const bool fits = n_src > 0 && n_src * ldkv * 2 < lim && n_dst * ldq * 2 < lim && n_dst * ldu * 2 < lim && n_dst * ldo * 2 < lim &&
+                    (x_r == nullptr || n_dst * ldr * 2 < lim);
   const bool plain = sched == nullptr || dtype != ANEMOI_BF16 || H <= 0 || C % H != 0 || !((C / H) == 64 || (C / H) == 32) ||
-                     !(up == 4 || up == 8 || up == 12 || up == 16) || n_dst == 0;
+                     !(up == 4 || up == 8 || up == 12 || up == 16) || n_dst == 0 || !fits;
   if (plain)
     return anemoi_gt_edge_attention_folded(dtype, q, ldq, k, v, ldkv, x_r, ldr, u, ldu, edge_attr, up, rowptr, col, out, ldo,
                                            lse, n_dst, C, H, stream);
@@ -1340,8 +1345,11 @@ extern "C" int anemoi_gt_edge_attention_folded_runs(int dtype, const void* q, in
   const char* who = "anemoi_gt_edge_attention_folded_runs";
   ANEMOI_REQUIRE(q && k && v && u && out && col && edge_attr, ANEMOI_ERR_INVALID, "%s: null pointer", who);
   ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
-                     (x_r == nullptr || ldr >= C) && n_runs <= n_dst,
-                 ANEMOI_ERR_INVALID, "%s: leading dimension too small / more runs than destinations", who);
+                     (x_r == nullptr || ldr >= C) && n_runs <= n_dst && 2 * n_runs >= n_dst,
+                 ANEMOI_ERR_INVALID,
+                 "%s: leading dimension too small, or %lld runs cannot cover %lld destinations with runs of 1 or 2 (the kernel "
+                 "handles runs of at most two; rowptr[d] = 3 d is the caller's contract)", who, (long long)n_runs,
+                 (long long)n_dst);
   const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
                        ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                        (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % 8 == 0)) && ldq % 8 == 0 && ldkv % 8 == 0 &&

@@ -378,6 +378,10 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
         return sharded_training_forward(model, x, group)
     batch_size, _, ensemble_size, grid, _ = x.shape
     assert batch_size == 1, "Only batch size of 1 is supported when model is sharded across GPUs"
+    if ensemble_size != 1:
+        # (the reference shards the '(batch ensemble grid)' rows, models/encoder_processor_decoder.py:173-186, so ensembles
+        # run there; here the plan's grid-row ids address ONE member -- tracked as a gap, refused before any plan is built)
+        raise NotImplementedError("the node-partitioned forward runs ensemble size 1 (batch 1 per model group, as the reference)")
     dtype = runtime.compute_dtype(x)
     from ..layers.mapper import GNNBaseMapper
 
@@ -407,8 +411,6 @@ def sharded_forward(model, x: Tensor, group, input_affine=None, output_affine=No
     if sp.io_rows is None:
         sp.io_rows = torch.cat([sp.enc_src_ids, sp.dec_dst_ids])
     n_enc = sp.enc_src_ids.shape[0]
-    if ensemble_size != 1:
-        raise NotImplementedError("the node-partitioned forward runs ensemble size 1 (batch 1 per model group, as the reference)")
     x_rows = ops.assemble_nodes(x, na.latlons(data), model._with_ones(na.trainable_tensors[data].trainable, grid, fold),
                                 1, dtype, ld_out=model._feature_ld(width + int(fold), dtype, fold), in_affine=input_affine,
                                 rows=sp.io_rows)

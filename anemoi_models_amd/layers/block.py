@@ -52,8 +52,17 @@ def folded_edge_phase(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
                       num_heads: int, up: int, ld_out: Optional[int] = None) -> Tensor:
     """The folded edge phase (``anemoi_gt_edge_attention_folded``: one fused gather -> score -> segment softmax -> weighted
     sum -> ``+ x_r`` pass over the destination-sorted CSR)."""
+    runs = edge_runs(plan, q.dtype)
     return ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, plan.col, num_heads, up,
-                                        ld_out=ld_out, runs=edge_runs(plan, q.dtype))
+                                        ld_out=ld_out, runs=runs, sched=None if runs is not None else edge_schedule(plan, q))
+
+
+def edge_schedule(plan, q: Tensor):
+    """The destination schedule of a plan for the scheduled bf16 edge kernel (``EdgePlan.schedule``), else ``None``
+    (``ANEMOI_AMD_EDGE_SCHED=0``: the round-robin kernel, A/B)."""
+    if q.dtype != torch.bfloat16 or not hasattr(plan, "schedule") or os.environ.get("ANEMOI_AMD_EDGE_SCHED", "1") == "0":
+        return None
+    return plan.schedule(q.dtype, q.shape[-1])
 
 
 def edge_runs(plan, dtype):
@@ -385,6 +394,10 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         runs = edge_runs(plan, dtype)
         if runs is not None:
             a.run_ptr, a.run_perm, a.n_runs = runs[0].data_ptr(), runs[1].data_ptr(), runs[0].shape[0] - 1
+        elif edge_attr_csr.shape[0] * up * 4 < 2**32:
+            sched = edge_schedule(plan, q)
+            if sched is not None:
+                a.sched, a.sched_slots, a.sched_steps, a.n_src = sched.data_ptr(), sched.shape[1], sched.shape[2], k.shape[0]
         a.att, a.ld_att = att.data_ptr(), wp.shape[1]
         a.w_proj, a.b_proj = wp.data_ptr(), ops._ptr(bp)
         a.res, a.ld_res, a.y, a.y_stats = res.data_ptr(), ops._ld(res), y.data_ptr(), stats[0].data_ptr()

@@ -221,7 +221,10 @@ class _BlockAbiPlan:
         if x.shape[1] != c or any(o["w_in"].shape != operands[0]["w_in"].shape or o["w_fc1"].shape[0] != hidden
                                   or o["act"] not in _lib.ACT_CODES for o in operands):
             return self
-        self.keep = [operands, ea, plan]  # the packed weights, edge attributes and CSR the templates point at (read-only)
+        from .block import edge_schedule
+
+        sched = edge_schedule(plan, x) if ea.shape[0] * up * 4 < 2**32 else None
+        self.keep = [operands, ea, plan, sched]  # the packed weights, edge attributes, CSR and schedule the templates point at
         self.dims = (n, c, h, up, n_in, k_proj, hidden)
         lib = _lib.load()
         self.ws_bytes = n * max(c // 128, 1) * 8  # row-sum partials of anemoi_linear_stats
@@ -240,6 +243,8 @@ class _BlockAbiPlan:
             a.b_in = None if o["b_in"] is None else o["b_in"].data_ptr()
             a.ld_sq = n_in
             a.edge_attr, a.rowptr, a.col = ea.data_ptr(), plan.rowptr.data_ptr(), plan.col.data_ptr()
+            if sched is not None:
+                a.sched, a.sched_slots, a.sched_steps, a.n_src = sched.data_ptr(), sched.shape[1], sched.shape[2], plan.n_src
             a.ld_att = k_proj
             a.w_proj = o["w_proj"].data_ptr()
             a.b_proj = None if o["b_proj"] is None else o["b_proj"].data_ptr()

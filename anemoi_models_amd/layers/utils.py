@@ -15,7 +15,18 @@ class CheckpointWrapper(nn.Module):
         self.module = module
 
     def forward(self, *args, **kwargs):
-        return checkpoint(self.module, *args, **kwargs, use_reentrant=False)
+        from .. import runtime
+
+        dd = runtime.device_dropout()
+        if dd is None:
+            return checkpoint(self.module, *args, **kwargs, use_reentrant=False)
+        frozen = dd.pinned()  # the recomputation re-enters the forward's dropout step (training._checkpoint)
+
+        def pinned(*a, **k):
+            with frozen:
+                return self.module(*a, **k)
+
+        return checkpoint(pinned, *args, **kwargs, use_reentrant=False)
 
 
 class AutocastLayerNorm(nn.LayerNorm):

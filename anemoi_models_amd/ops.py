@@ -277,14 +277,16 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], ed
 
 def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
                              rowptr: Tensor, col: Tensor, num_heads: int, up: int, out: Optional[Tensor] = None,
-                             ld_out: Optional[int] = None, lse: Optional[Tensor] = None, runs=None) -> Tensor:
+                             ld_out: Optional[int] = None, lse: Optional[Tensor] = None, runs=None, sched=None) -> Tensor:
     """Edge phase with lin_edge folded away: returns ``[n_dst, ld_out]`` = ``[sum alpha v (+ x_r) | t (H*up) | 0-pad]``.
 
     ``u`` is ``[n_dst, H*up]`` (extra columns of the q/k/v GEMM), ``edge_attr`` ``[E, up]`` f32 in CSR order with the
     constant-1 column.  Columns beyond ``C + H*up`` (K padding for the projection GEMM) are zero filled.  ``lse``
     (optional f32 ``[n_dst, H]``, contiguous) receives the softmax normaliser per destination and head (training).
     ``runs = (run_ptr, perm)`` (``EdgePlan.runs3()``, uniform-degree-3 graphs): destinations that share their three sources
-    share one gather of them (``anemoi_gt_edge_attention_folded_runs``).
+    share one gather of them (``anemoi_gt_edge_attention_folded_runs``).  ``sched`` (``EdgePlan.schedule()``: int32
+    ``[8, slots, steps]``): the destination schedule of ``anemoi_gt_edge_attention_folded_sched`` -- balanced wave slots, index
+    chain resolved one destination ahead; bit-identical to the plain kernel.  ``runs`` wins when both are given.
     """
     _dev(q, k, v, x_r, u, edge_attr, rowptr, col, out, lse)
     if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous()
@@ -318,6 +320,15 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
                 dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
                 0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
                 rowptr.data_ptr(), col.data_ptr(), run_ptr.data_ptr(), perm.data_ptr(), run_ptr.shape[0] - 1,
+                out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
+        elif sched is not None and col.shape[0] * up * 4 < 2**32:
+            _dev(sched)
+            if sched.dtype != torch.int32 or sched.dim() != 3 or sched.shape[0] != 8 or not sched.is_contiguous():
+                raise ValueError("gt_edge_attention_folded: sched = contiguous int32 [8, slots, steps]")
+            st = _lib.load().anemoi_gt_edge_attention_folded_sched(
+                dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
+                0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
+                rowptr.data_ptr(), col.data_ptr(), sched.data_ptr(), sched.shape[1], sched.shape[2], _rows(k).shape[0],
                 out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
         else:
             st = _lib.load().anemoi_gt_edge_attention_folded(

@@ -75,6 +75,18 @@ class EdgePlan:
             r = self._runs3_cache = _runs3(self) if self.col.is_cuda else None
         return r
 
+    def schedule(self, dtype: torch.dtype, channels: int):
+        """Destination schedule of ``anemoi_gt_edge_attention_folded_sched`` for this plan at ``channels`` / ``dtype``
+        (cached on the plan): int32 ``[8, slots, steps]`` on the plan's device, or ``None`` where the scheduled kernel has
+        nothing to offer (f32; graphs of uniform in-degree 3, which take the run kernel)."""
+        if dtype != torch.bfloat16 or not self.col.is_cuda or self.n_dst == 0:
+            return None
+        cache = self.__dict__.setdefault("_sched_cache", {})
+        key = (dtype, channels)
+        if key not in cache:
+            cache[key] = _edge_schedule(self, dtype, channels)
+        return cache[key]
+
     @property
     def dst(self) -> Tensor:
         """int32 [E]: destination node of every CSR slot (row index expanded; built on first use)."""
@@ -84,6 +96,52 @@ class EdgePlan:
             d = torch.repeat_interleave(torch.arange(self.n_dst, device=self.rowptr.device), counts).to(torch.int32)
             self._dst = d
         return d
+
+
+# relative cost of a destination for the schedule: a fixed part (q / u / x_r / out streams, epilogue) + one unit per chunk of
+# SCHED_U in-edges (the kernel's gather batch)
+SCHED_U, SCHED_UNIT_COST = 4, 1.5
+
+
+def edge_schedule_lists(degree: Tensor, slots: int, steps: int, chunk: int = SCHED_U, unit_cost: float = SCHED_UNIT_COST) -> Tensor:
+    """The static destination schedule of the scheduled edge kernel (host logic, CPU tensors): int32 ``[8, slots, steps]``.
+
+    XCD ``x`` owns the destinations ``[n x / 8, n (x + 1) / 8)``; at step ``i`` its ``slots`` wave slots take the ``i``-th
+    group of ``slots`` consecutive destinations (so that what is in flight at any time is one contiguous window of the
+    CSR, as in the round-robin kernel), the most expensive destination of the group going to the slot with the least work so
+    far.  Cost of a destination = ``unit_cost + ceil(degree / chunk)``.  Unused entries are -1; every list ends with >= 3."""
+    n = int(degree.shape[0])
+    cost = unit_cost + torch.div(degree.to(torch.float64) + (chunk - 1), chunk, rounding_mode="floor")
+    sched = torch.full((8, slots, steps), -1, dtype=torch.int32)
+    uniform = n == 0 or bool((degree == degree[0]).all()) or os.environ.get("ANEMOI_AMD_EDGE_BALANCE", "1") == "0"  # (lab: A/B)
+    for x in range(8):
+        n0, n1 = n * x // 8, n * (x + 1) // 8
+        load = torch.zeros(slots, dtype=torch.float64)
+        for i, g0 in enumerate(range(n0, n1, slots)):
+            ids = torch.arange(g0, min(g0 + slots, n1), dtype=torch.int32)
+            k = ids.shape[0]
+            if uniform:
+                sched[x, :k, i] = ids
+                continue
+            c = cost[g0:g0 + k]
+            by_cost = torch.argsort(c, descending=True, stable=True)
+            by_load = torch.argsort(load, stable=True)[:k]
+            sched[x, by_load, i] = ids[by_cost]
+            load[by_load] += c[by_cost]
+    return sched
+
+
+def _edge_schedule(plan: "EdgePlan", dtype: torch.dtype, channels: int):
+    import ctypes
+
+    from . import _lib
+
+    slots, steps = ctypes.c_int(0), ctypes.c_int(0)
+    st = _lib.load().anemoi_edge_schedule_shape(ops.dtype_code(dtype), plan.n_dst, channels, ctypes.byref(slots),
+                                                ctypes.byref(steps))
+    _lib.check(st, "anemoi_edge_schedule_shape")
+    degree = (plan.rowptr[1:] - plan.rowptr[:-1]).cpu()
+    return edge_schedule_lists(degree, slots.value, steps.value).to(plan.col.device).contiguous()
 
 
 def _runs3(plan: "EdgePlan", max_run: int = 2):
@@ -516,6 +574,14 @@ class DeviceDropout:
     def advance(self) -> None:
         self.counter.add_(1)
         self.word = self.counter * 0x9E3779B1  # (int64 arithmetic; the kernels read the low 32 bits)
+
+    def pinned(self) -> "DeviceDropout":
+        """A context with THIS step's ``word`` frozen: what a checkpointed region re-enters when it is recomputed -- inside or
+        outside the original ``with`` block, before or after a later :meth:`advance` -- so that the recomputed forward draws
+        the masks its first run drew (``training._checkpoint``)."""
+        frozen = object.__new__(DeviceDropout)
+        frozen.counter, frozen.word = self.counter, self.word
+        return frozen
 
     def __enter__(self) -> "DeviceDropout":
         self._outer, DeviceDropout._active = DeviceDropout._active, self

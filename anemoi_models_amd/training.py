@@ -47,7 +47,19 @@ def wants_grad(module: nn.Module, *tensors) -> bool:
 def _checkpoint(fn, *args):
     if os.environ.get("ANEMOI_AMD_CHECKPOINT", "1") == "0":
         return fn(*args)
-    return _torch_checkpoint(fn, *args, use_reentrant=False)
+    dd = runtime.device_dropout()
+    if dd is None:  # host-drawn dropout seeds: torch's checkpoint restores the CPU generator for the recomputation
+        return _torch_checkpoint(fn, *args, use_reentrant=False)
+    # device-side dropout seeds: the recomputation has to see the step word of ITS forward, wherever and whenever the
+    # backward runs (outside the ``with DeviceDropout`` block the modules would draw fresh host seeds, after a later
+    # ``advance()`` the next step's word: either way another mask than the forward's, i.e. silently wrong gradients)
+    frozen = dd.pinned()
+
+    def pinned(*a):
+        with frozen:
+            return fn(*a)
+
+    return _torch_checkpoint(pinned, *args, use_reentrant=False)
 
 
 def _cast(x: Tensor, dtype: torch.dtype) -> Tensor:

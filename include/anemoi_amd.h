@@ -186,6 +186,27 @@ int anemoi_gt_edge_attention_folded_runs(int dtype, const void* q, int64_t ldq, 
                                          int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
+ * anemoi_gt_edge_attention_folded with a DESTINATION SCHEDULE (round 5): the same result bit for bit -- same arithmetic,
+ * same per-destination summation order -- from a launch in which
+ *   - a host-built static schedule names the destinations every wave slot walks.  At any step the slots of an XCD work on
+ *     one contiguous group of destinations (same L2 window as the plain kernel), but inside the group the destinations
+ *     with many in-edges go to the slots with the least work so far: on a multi-scale icosahedral mesh (in-degree 6 ... 36)
+ *     the plain round-robin leaves the busiest wave with 1.6 x the mean work, and the launch lasts as long as that wave;
+ *   - schedule entry -> row pointers -> source ids are resolved by scalar loads one destination AHEAD each, and all of a
+ *     destination's first loads (2 U row gathers, attribute rows, q / u / x_r) are in flight under one wait.
+ * sched: int32 [8][slots][steps], XCD x's lists hold every destination of [n_dst x / 8, n_dst (x + 1) / 8) exactly once,
+ * each list ends with at least three -1; slots / steps as anemoi_edge_schedule_shape returns them for (dtype, n_dst, C).
+ * bf16 with 32- or 64-channel heads and every operand matrix below 4 GiB; other cases (or sched == NULL) run the plain kernel.
+ * anemoi_models_amd/runtime.py::EdgePlan.schedule builds the lists.
+ */
+int anemoi_edge_schedule_shape(int dtype, int64_t n_dst, int C, int* slots, int* steps);
+int anemoi_gt_edge_attention_folded_sched(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                          const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
+                                          int up, const int32_t* rowptr, const int32_t* col, const int32_t* sched, int slots,
+                                          int steps, int64_t n_src, void* out, int64_t ldo, float* lse, int64_t n_dst, int C,
+                                          int H, anemoi_stream_t stream);
+
+/*
  * GraphTransformerConv with explicit per-edge features (the callable the reference exposes, layers/conv.py:98-142):
  *   s_ij = q_i . (k_j + e_ij) / sqrt(D),  alpha = softmax over the in-edges of i (+1e-16),  out_i = sum_j alpha (v_j + e_ij)
  * q [n_dst, C], k / v [n_src, C], edges [E, C] in the CSR order of (rowptr, col) (= lin_edge(edge_attr)[perm]), all in
@@ -526,6 +547,8 @@ typedef struct anemoi_gt_block_args {
   void* stats_ws; int64_t stats_ws_bytes;                           /* >= n_dst * max(C / 128, 1) * 8 bytes      */
   /* optional (NULL / 0: plain edge kernel): the runs of a uniform-degree-3 graph, anemoi_gt_edge_attention_folded_runs */
   const int32_t* run_ptr; const int32_t* run_perm; int64_t n_runs;
+  /* optional (NULL: none; ignored when runs are given): the destination schedule of anemoi_gt_edge_attention_folded_sched */
+  const int32_t* sched; int32_t sched_slots, sched_steps; int64_t n_src;
 } anemoi_gt_block_args;
 int anemoi_gt_block_tail(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* args, anemoi_stream_t stream);

@@ -430,6 +430,65 @@ def test_gt_edge_attention_folded_runs_of_shared_sources(c, h, xr):
         assert float((got[i, :c].double().cpu() - o).abs().max() / o.abs().max()) < 1e-2
 
 
+@pytest.mark.parametrize("n_src,n_dst,c,h,up,kind", [
+    (5000, 5121, 1024, 16, 12, "mesh"),     # a rank-of-8 mesh shard: in-degrees 6 ... 36 as on the multi-scale icosahedron
+    (40962, 40962, 1024, 16, 12, "mesh"),   # the ico-6 mesh launch of config 3
+    (3000, 2500, 512, 16, 12, "ragged"),    # D = 32; empty destinations, one of in-degree 70, the last ones empty
+    (9000, 700, 1024, 16, 16, "encoder"),   # in-degrees 16 ... 40 (beyond the prefetched ids), up = 16
+    (64, 5, 1024, 16, 12, "ragged"),        # fewer destinations than XCDs
+])
+def test_gt_edge_attention_folded_scheduled_is_the_plain_kernel_bit_for_bit(n_src, n_dst, c, h, up, kind, monkeypatch):
+    """``anemoi_gt_edge_attention_folded_sched`` (balanced static destination schedule, index chain resolved one destination
+    ahead by scalar loads, buffer-load gathers) against the round-robin kernel on the same CSR: the same arithmetic in the
+    same order -- outputs, the t columns and lse are BIT-IDENTICAL, for every gather-batch width the kernel is built with;
+    every destination is written exactly once (poisoned output)."""
+    from anemoi_models_amd import ops, runtime
+
+    g = torch.Generator().manual_seed(n_dst + c)
+    if kind == "mesh":
+        deg = torch.tensor([6, 12, 18, 24, 30, 36])[torch.multinomial(torch.tensor([.75, .1875, .047, .012, .003, .001]),
+                                                                        n_dst, replacement=True, generator=g)]
+    elif kind == "encoder":
+        deg = torch.randint(16, 41, (n_dst,), generator=g)
+    else:
+        deg = torch.randint(0, 9, (n_dst,), generator=g)
+        deg[n_dst // 2] = 70
+        deg[-2:] = 0
+    dst = torch.repeat_interleave(torch.arange(n_dst), deg)
+    src = torch.randint(0, n_src, (int(deg.sum()),), generator=g)
+    perm = torch.randperm(dst.shape[0], generator=g)  # the CSR sort has to be stable over a shuffled edge list
+    plan = runtime.build_edge_plan(torch.stack([src[perm], dst[perm]]).to(DEV), n_src, n_dst)
+    sched = plan.schedule(torch.bfloat16, c)
+    assert sched is not None and sched.shape[0] == 8
+    listed = sched[sched >= 0].sort().values.cpu()
+    assert torch.equal(listed, torch.arange(n_dst, dtype=torch.int32))  # every destination exactly once
+    e = plan.num_edges
+    q = (torch.randn(n_dst, c, generator=g) * 0.5).bfloat16().to(DEV)
+    kv = (torch.randn(n_src, 2 * c, generator=g) * 0.5).bfloat16().to(DEV)
+    x_r = torch.randn(n_dst, c, generator=g).bfloat16().to(DEV)
+    u = (torch.randn(n_dst, h * up, generator=g) * 0.3).bfloat16().to(DEV)
+    attr = torch.randn(e, up, generator=g).to(DEV)
+    ld = ops.round_up(c + h * up, 64)
+
+    def run(**kw):
+        out = torch.full((n_dst, ld), float("nan"), dtype=torch.bfloat16, device=DEV)
+        out[:, c + h * up:] = 0
+        lse = torch.full((n_dst, h), float("nan"), device=DEV)
+        ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], kw.pop("x_r", x_r), u, attr, plan.rowptr, plan.col, h, up,
+                                     out=out, ld_out=ld, lse=lse, **kw)
+        return out, lse
+
+    plain, lse_plain = run()
+    assert torch.isfinite(plain.float()).all()
+    got, lse = run(sched=sched)
+    assert torch.equal(got, plain) and torch.equal(lse, lse_plain)
+    got, _ = run(sched=sched, x_r=None)
+    want, _ = run(x_r=None)
+    assert torch.equal(got, want)
+    for _ in range(2):
+        assert torch.equal(run(sched=sched)[0], plain)  # reproducible
+
+
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
     from anemoi_models_amd import runtime
 

@@ -56,9 +56,11 @@ def main():
     ld_out = ops.round_up(c + h * up, 64)
     out = torch.zeros(n, ld_out, dtype=torch.bfloat16, device=dev)
 
+    sched = plan.schedule(torch.bfloat16, c) if os.environ.get("ANEMOI_AMD_EDGE_SCHED", "1") != "0" else None
+
     def run():
         ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
-                                     attr, plan.rowptr, plan.col, h, up, out=out, ld_out=ld_out)
+                                     attr, plan.rowptr, plan.col, h, up, out=out, ld_out=ld_out, sched=sched)
 
     e = plan.col.shape[0]
     report(a, run, out, 4 * n * c * 2 + e * 52 + (n + 1) * 4, f"set=proc order={a.order} col={a.col} n={n} E={e}")
@@ -87,9 +89,11 @@ def mapper(a):
     if runs is not None:
         print(f"runs: {runs[0].shape[0] - 1} for {n_dst} destinations (mean length {n_dst / (runs[0].shape[0] - 1):.2f})")
 
+    sched = plan.schedule(torch.bfloat16, c) if os.environ.get("ANEMOI_AMD_EDGE_SCHED", "1") != "0" and runs is None else None
+
     def run():
         ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], attr, plan.rowptr,
-                                     plan.col, h, up, out=out, ld_out=ld_out, runs=runs)
+                                     plan.col, h, up, out=out, ld_out=ld_out, runs=runs, sched=sched)
 
     report(a, run, out, (2 * n_dst + 2 * n_src) * c * 2 + plan.col.shape[0] * 52 + (n_dst + 1) * 4,
            f"set={a.set} n_src={n_src} n_dst={n_dst} E={plan.col.shape[0]}")
@@ -113,6 +117,7 @@ def report(a, run, out, alg, label):
         want = torch.load(a.compare)
         note = "  bit-identical to " + a.compare if torch.equal(out.cpu(), want) else \
             f"  DIFFERS from {a.compare}: max abs {float((out.cpu().float() - want.float()).abs().max()):.3e}"
+    label += f" sched={os.environ.get('ANEMOI_AMD_EDGE_SCHED', '1')} U={os.environ.get('ANEMOI_AMD_EDGE_U', '4')}"
     print(f"{label} {ms:.4f} ms  {alg / ms / 1e6:.0f} GB/s "
           f"algorithmic ({alg / ms / 1e6 / 80:.1f} % of 8 TB/s){note}", flush=True)
 
