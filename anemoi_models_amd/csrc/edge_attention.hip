@@ -654,15 +654,19 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(con
 
     const float inv = 1.0f / (l + 1e-16f);
     float o[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = __fmul_rn(acc[i >> 1][i & 1], inv);
     {
+      // (acc * inv) + x_r as TWO roundings: the plain kernel's arithmetic, whose + x_r sits behind a branch and is therefore
+      // never contracted into an fma with the scaling in front of it -- bit identity between the two kernels is a test
+#pragma clang fp contract(off)
       RawWords<T, VEC> xw;  // (zeros without x_r: + 0.0f leaves the sums as they are)
       xw.w[0] = xr_raw.x; xw.w[1] = xr_raw.y; xw.w[2] = xr_raw.z; xw.w[3] = xr_raw.w;
       float r[VEC];
       xw.get(r);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] = __fadd_rn(o[i], r[i]);  // (no contraction with the * inv above: the plain kernel's rounding)
+      for (int i = 0; i < VEC; ++i) {
+        const float scaled = acc[i >> 1][i & 1] * inv;
+        o[i] = scaled + r[i];
+      }
     }
     const int out_row = (int)((uint32_t)node * o_row_bytes);
     if (active) {
@@ -692,8 +696,14 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(con
 // geometry of the scheduled launch: wave slots per XCD (every slot is n_slices waves, one per 512-channel slice)
 static void sched_shape(int64_t n_dst, int n_slices, int* slots, int* steps) {
   constexpr int WPB = 4;
-  static const int wgs_per_cu = getenv("ANEMOI_AMD_EDGE_WGS") ? atoi(getenv("ANEMOI_AMD_EDGE_WGS")) : 5;  // lab switch
+  // Resident workgroups per CU.  A long launch (the ico-6 mesh: 5 120 destinations x 2 slices per XCD) is bound by the CU's
+  // texture-address unit -- its busy time is the same for every form of this kernel (PMC: 229 k cycles per launch and CU,
+  // 32 cycles per 16-byte-per-lane wave load) -- and runs FASTER with fewer waves contending for it: 3 / 4 / 5 workgroups
+  // per CU 0.136 / 0.138 / 0.141 ms.  A short launch (O96 -> ico-5: 1 280 destinations per XCD, a handful of steps per
+  // wave) is bound by its few dependent round trips and wants every wave it can get: 0.0239 / 0.0232 / 0.0205 ms.
+  static const int wgs_env = getenv("ANEMOI_AMD_EDGE_WGS") ? atoi(getenv("ANEMOI_AMD_EDGE_WGS")) : 0;  // lab switch
   const int64_t per_xcd = (n_dst + 7) / 8;
+  const int wgs_per_cu = wgs_env > 0 ? wgs_env : (per_xcd * n_slices >= 12 * 32 * 5 * WPB ? 3 : 5);
   int64_t bpx = (per_xcd * n_slices + WPB - 1) / WPB;
   if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;
   if (bpx < 1) bpx = 1;
