@@ -389,11 +389,21 @@ def _edge_backward(q, k, v, dout, u, dt, lse, edge_attr, plan, h: int, up: int, 
     return dattr
 
 
+def _edge_forward_lists(plan, q: Tensor) -> dict:
+    """The plan's run lists (uniform-degree-3 decoder graphs) or destination schedule (mesh graphs) for the forward edge
+    kernel -- what the inference route hands it (``layers/block.py::folded_edge_phase``); results equal the plain kernel's."""
+    from .layers.block import edge_runs, edge_schedule
+
+    runs = edge_runs(plan, q.dtype)
+    return {"runs": runs, "sched": None if runs is not None else edge_schedule(plan, q)}
+
+
 class _GTEdgeAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, x_r, u, edge_attr, plan, num_heads: int, up: int):
         lse = torch.empty((q.shape[0], num_heads), dtype=torch.float32, device=q.device)
-        out = ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, plan.rowptr, plan.col, num_heads, up, lse=lse)
+        out = ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, plan.rowptr, plan.col, num_heads, up, lse=lse,
+                                           **_edge_forward_lists(plan, q))
         ctx.save_for_backward(q, k, v, u, edge_attr, lse)  # the backward needs neither the result nor x_r
         ctx.plan, ctx.h, ctx.up, ctx.has_xr = plan, num_heads, up, x_r is not None
         return out
@@ -426,7 +436,8 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
         c = (sq.shape[1] - num_heads * up) // 4
         lse = torch.empty((sq.shape[0], num_heads), dtype=torch.float32, device=sq.device)
         out = ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
-                                           edge_attr, plan.rowptr, plan.col, num_heads, up, lse=lse)
+                                           edge_attr, plan.rowptr, plan.col, num_heads, up, lse=lse,
+                                           **_edge_forward_lists(plan, sq[:, :c]))
         ctx.save_for_backward(sq, edge_attr, lse)
         ctx.plan, ctx.h, ctx.up, ctx.c = plan, num_heads, up, c
         return out
@@ -459,7 +470,7 @@ class _GTEdgeAttentionMapper(torch.autograd.Function):
         c = kv.shape[1] // 2
         lse = torch.empty((sq.shape[0], num_heads), dtype=torch.float32, device=sq.device)
         out = ops.gt_edge_attention_folded(sq[:, c:2 * c], kv[:, :c], kv[:, c:], sq[:, :c], sq[:, 2 * c:], edge_attr,
-                                           plan.rowptr, plan.col, num_heads, up, lse=lse)
+                                           plan.rowptr, plan.col, num_heads, up, lse=lse, **_edge_forward_lists(plan, sq[:, :c]))
         ctx.save_for_backward(sq, kv, edge_attr, lse)
         ctx.plan, ctx.h, ctx.up, ctx.c = plan, num_heads, up, c
         return out

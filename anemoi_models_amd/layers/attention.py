@@ -56,8 +56,8 @@ class MultiHeadSelfAttention(nn.Module):
         if dd is not None and self.__dict__.get("_layer_seed") is not None:
             return float(self.dropout_p), self.__dict__["_layer_seed"], dd.word
         seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
-        if model_comm_group is not None and model_comm_group.size() > 1:
-            import torch.distributed as dist
+        if model_comm_group is not None and model_comm_group.size() > 1 and not hasattr(model_comm_group, "rank_"):
+            import torch.distributed as dist  # (``rank_``: partition.SimulatedRank, the one-rank-alone timing stand-in)
 
             seed_t = torch.tensor([seed], dtype=torch.int64)
             if dist.get_backend(model_comm_group) == "nccl":

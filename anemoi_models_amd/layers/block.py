@@ -897,16 +897,18 @@ class TransformerProcessorBlock(BaseBlock):
                 return done
         h = ops.layer_norm(x, runtime.f32c(ln1.weight), runtime.f32c(ln1.bias), ln1.eps)
         qkv = linear_native(att._packed, "lin_qkv", att.lin_qkv, h)
-        drop_p, drop_seed, drop_dev = att.dropout()
+        # attention dropout (training mode, reference layers/attention.py:90) across a model group: ONE seed -- rank 0's draw,
+        # broadcast -- and the GLOBAL head index in the mask's hash, so the ranks together drop exactly what the unsharded
+        # attention drops with that seed (every rank sees the whole sequence of its heads in the unsharded row order)
+        drop_p, drop_seed, drop_dev = att.dropout(None if head_exchange is None else head_exchange.group)
         if head_exchange is not None:
-            if drop_p > 0.0:
-                raise NotImplementedError("attention dropout in the node-partitioned forward (the ranks would need one "
-                                          "mask over the gathered sequence)")
             window = att.attention_window()
             qkv_heads = head_exchange.rows_to_heads(qkv, att.num_heads)  # [S, 3 * C_local], internal row order
             if window >= 0:  # the window slides over the EXTERNAL node order
                 qkv_heads = qkv_heads.index_select(0, head_exchange.to_external)
-            a_heads = ops.mhsa(qkv_heads, batch_size, head_exchange.local_heads(att.num_heads), window)
+            a_heads = ops.mhsa(qkv_heads, batch_size, head_exchange.local_heads(att.num_heads), window, dropout_p=drop_p,
+                               dropout_seed=drop_seed, head_offset=head_exchange._head_bounds(att.num_heads)[head_exchange.rank],
+                               heads_total=att.num_heads, seed_dev=drop_dev)
             if window >= 0:
                 a_heads = a_heads.index_select(0, head_exchange.to_internal)
             a = head_exchange.heads_to_rows(a_heads, att.num_heads)  # [n_own, C]

@@ -101,6 +101,10 @@ class EdgePlan:
 # relative cost of a destination for the schedule: a fixed part (q / u / x_r / out streams, epilogue) + one unit per chunk of
 # SCHED_U in-edges (the kernel's gather batch)
 SCHED_U, SCHED_UNIT_COST = 4, 1.5
+# graphs of a higher mean in-degree stay on the round-robin kernel: the N320 -> ico-6 encoder (mean 21, 16 ... 104) measured
+# 0.588 ms there, 0.585 with an identity schedule and 0.630 with the balanced one (the prefetched ids cover 8 of its edges, and
+# re-dealing its destinations costs more L2 locality than the balance returns)
+SCHED_MAX_MEAN_DEGREE = 12
 
 
 def edge_schedule_lists(degree: Tensor, slots: int, steps: int, chunk: int = SCHED_U, unit_cost: float = SCHED_UNIT_COST) -> Tensor:
@@ -141,6 +145,8 @@ def _edge_schedule(plan: "EdgePlan", dtype: torch.dtype, channels: int):
                                                 ctypes.byref(steps))
     _lib.check(st, "anemoi_edge_schedule_shape")
     degree = (plan.rowptr[1:] - plan.rowptr[:-1]).cpu()
+    if plan.num_edges > SCHED_MAX_MEAN_DEGREE * plan.n_dst:
+        return None
     return edge_schedule_lists(degree, slots.value, steps.value).to(plan.col.device).contiguous()
 
 

@@ -50,6 +50,21 @@ def main():
         sp = [v for k, v in model._idx_cache.items() if k[0] == "shard_plan"][0]
         info = dict(err=float((got - want).abs().max()), rerun=float((again - got).abs().max()),
                     scale=float(want.abs().max()), own=sp.hi - sp.lo, finite=bool(torch.isfinite(got).all()))
+        if family == "Transformer":
+            # attention dropout (training mode, no autograd: the inference route with the rows <-> heads exchange): the same
+            # CPU-generator draws on both routes -> rank 0's seed for all, global head index in the mask's hash -> the ranks
+            # together drop what the unsharded attention drops
+            for m in model.modules():
+                if hasattr(m, "dropout_p"):
+                    m.dropout_p = 0.3
+            model.train()
+            with torch.no_grad():
+                torch.manual_seed(99)
+                want_d = model(x)
+                torch.manual_seed(99)
+                got_d = model(x, dist.group.WORLD)
+            info.update(drop_err=float((got_d - want_d).abs().max()), drop_acts=float((want_d - want).abs().max()))
+            model.eval()
         if len(sys.argv) > 10 and sys.argv[10] == "train":
             model.train()
             dy = torch.randn(want.shape, generator=torch.Generator().manual_seed(5)).to(device)
