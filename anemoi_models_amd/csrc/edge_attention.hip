@@ -443,6 +443,10 @@ __device__ __forceinline__ void buffer_store_words(__amdgpu_buffer_rsrc_t rs, in
     for (int i = 0; i + 4 <= W; i += 4)
       __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[i], w[i + 1], w[i + 2], w[i + 3]}, rs, voff + i * 4, soff, 0);
     if constexpr (W % 4 == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w[W - 2], w[W - 1]}, rs, voff + (W - 2) * 4, soff, 0);
+    // (wide store with an SGPR soffset: the compiler does not pad the data-register hazard, see the scheduled kernel)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -670,16 +674,23 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(con
     }
     const int out_row = (int)((uint32_t)node * o_row_bytes);
     if (active) {
-      u32x4_t ow;
-      VecIO<T, VEC>::store(reinterpret_cast<T*>(&ow), o);
-      __builtin_amdgcn_raw_buffer_store_b128(ow, ors, lane_off, out_row, 2);
+      uint32_t ow[4];
+      pack_words<T, VEC>(o, ow);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ow[0], ow[1], ow[2], ow[3]}, ors, lane_off, out_row, 2);
+      // gfx950: a 16-byte buffer store whose data registers the very next VALU instruction overwrites stores the NEW value in
+      // part of dword 1 (lanes 12 .. 15 of every 16); the compiler pads that hazard except when soffset is an SGPR, as here
+      // (csrc/gemm.hip's epilogue met it in round 2).  Seen in the UP = 16 instantiation, where the t words are computed
+      // right behind the store: pad by hand.
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (active && a_own) {  // this lane's APL values of t~_i,h
       float t4[APL];
 #pragma unroll
       for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
       uint32_t tw[RawWords<T, APL>::W];
-      VecIO<T, APL>::store(reinterpret_cast<T*>(tw), t4);
+      pack_words<T, APL>(t4, tw);
       buffer_store_words<RawWords<T, APL>::W>(ors, t_off, out_row, tw);
     }
     if (p.lse != nullptr && active && (gls % LPH) == 0) p.lse[node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);

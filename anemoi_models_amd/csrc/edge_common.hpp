@@ -158,4 +158,20 @@ struct RawWords {
   }
 };
 
+// N values -> the 32-bit words they occupy in memory (bf16: round-to-nearest-even pairs, low half first), built in
+// registers.  (Not VecIO::store through a reinterpret_cast of a local: that writes the local through another type, and the
+// optimizer is free to order such a store behind the read that hands the local to a buffer-store builtin -- observed in the
+// scheduled edge kernel's UP = 16 instantiation as stale words in single lanes.)
+template <typename T, int N>
+__device__ __forceinline__ void pack_words(const float (&r)[N], uint32_t (&w)[RawWords<T, N>::W]) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = __float_as_uint(r[i]);
+  } else {
+    static_assert(N % 2 == 0, "bf16 values are packed in pairs");
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) w[i] = pack_bf16x2(r[2 * i], r[2 * i + 1]);
+  }
+}
+
 }  // namespace anemoi

@@ -310,7 +310,10 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
         col = torch.zeros(1, dtype=torch.int32, device=q.device)
         edge_attr = torch.zeros((1, up), dtype=torch.float32, device=q.device)
     alg_bytes = (2 * n_dst + 2 * k.shape[0]) * c * q.element_size() + col.shape[0] * 52 + (n_dst + 1) * 4
-    with _Timed("gt_edge_attention", bytes=alg_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
+    # (+ the operands this kernel moves because of its fusions -- x_r read, u read, t written -- which SURVEY 8d's figure does
+    #  not count: reported beside the roofline fraction, never instead of it)
+    fused_bytes = alg_bytes + n_dst * ((0 if x_r is None else c) + 2 * num_heads * up) * q.element_size()
+    with _Timed("gt_edge_attention", bytes=alg_bytes, fused_bytes=fused_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
         if runs is not None:
             run_ptr, perm = runs
             _dev(run_ptr, perm)

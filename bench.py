@@ -104,7 +104,7 @@ def detail_table(records, dtype_name: str) -> None:
 
     agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     for name, start, end, work in records:
-        key = (name,) + tuple(sorted((k, v) for k, v in work.items() if k not in ("flops", "bytes")))
+        key = (name,) + tuple(sorted((k, v) for k, v in work.items() if k not in ("flops", "bytes", "fused_bytes")))
         a = agg[key]
         a[0] += 1
         a[1] += start.elapsed_time(end)
@@ -168,11 +168,12 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
         detail_table(records, dtype_name)
     agg = {}
     for name, start, end, work in records:
-        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "fused_bytes": 0.0})
         a["launches"] += 1
         a["ms"] += start.elapsed_time(end)
         a["flops"] += work.get("flops", 0)
         a["bytes"] += work.get("bytes", 0)
+        a["fused_bytes"] += work.get("fused_bytes", 0)
     out = {}
     if "linear" in agg and agg["linear"]["ms"] > 0:
         a = agg["linear"]
@@ -203,10 +204,14 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
         a = agg["gt_edge_attention"]
         achieved = a["bytes"] / (a["ms"] * 1e-3) / 1e9
         out["roofline_edge"] = {
-            "kernel": "anemoi::gt_edge_attention_kernel (fused gather/lin_edge/softmax/scatter)", "bound": "hbm",
+            "kernel": "anemoi::gt_edge_attention_folded_{sched,runs,}_kernel (fused gather / score / segment softmax / scatter)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": a["launches"],
             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "bytes_per_launch": a["bytes"] / a["launches"],
+            # the same launches against the bytes INCLUDING the operands of the kernel's fusions (x_r read, u read, t written:
+            # not in SURVEY 8d's figure); beside frac, not instead of it
+            "frac_fused_operands": round(a["fused_bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "fused_operand_bytes_per_launch": a["fused_bytes"] / a["launches"],
         }
     if "mhsa" in agg and agg["mhsa"]["ms"] > 0:  # Transformer processor: mesh-node self attention (MFMA-bound)
         a = agg["mhsa"]

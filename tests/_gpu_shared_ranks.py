@@ -54,9 +54,9 @@ def main():
             # attention dropout (training mode, no autograd: the inference route with the rows <-> heads exchange): the same
             # CPU-generator draws on both routes -> rank 0's seed for all, global head index in the mask's hash -> the ranks
             # together drop what the unsharded attention drops
-            for m in model.modules():
-                if hasattr(m, "dropout_p"):
-                    m.dropout_p = 0.3
+            rates = {m: m.dropout_p for m in model.modules() if hasattr(m, "dropout_p")}
+            for m in rates:
+                m.dropout_p = 0.3
             model.train()
             with torch.no_grad():
                 torch.manual_seed(99)
@@ -64,6 +64,8 @@ def main():
                 torch.manual_seed(99)
                 got_d = model(x, dist.group.WORLD)
             info.update(drop_err=float((got_d - want_d).abs().max()), drop_acts=float((want_d - want).abs().max()))
+            for m, rate in rates.items():
+                m.dropout_p = rate
             model.eval()
         if len(sys.argv) > 10 and sys.argv[10] == "train":
             model.train()

@@ -452,7 +452,8 @@ def test_gt_edge_attention_folded_scheduled_is_the_plain_kernel_bit_for_bit(n_sr
         deg = torch.randint(6, 15, (n_dst,), generator=g)
     else:
         deg = torch.randint(0, 9, (n_dst,), generator=g)
-        deg[n_dst // 2] = 70
+        if n_dst > 100:
+            deg[n_dst // 2] = 70
         deg[-2:] = 0
     dst = torch.repeat_interleave(torch.arange(n_dst), deg)
     src = torch.randint(0, n_src, (int(deg.sum()),), generator=g)

@@ -3,8 +3,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from anemoi_models_amd import ops, runtime
 DEV="cuda"
 g = torch.Generator().manual_seed(1)
-n_src, n_dst, c, h, up = 5000, 5121, 1024, 16, 12
-deg = torch.tensor([6, 12, 18, 24, 30, 36])[torch.multinomial(torch.tensor([.75, .1875, .047, .012, .003, .001]), n_dst, replacement=True, generator=g)]
+n_src, n_dst, c, h, up = 9000, 700, 1024, 16, int(os.environ.get("DBG_UP", "16"))
+deg = torch.randint(6, 15, (n_dst,), generator=g)
 dst = torch.repeat_interleave(torch.arange(n_dst), deg)
 src = torch.randint(0, n_src, (int(deg.sum()),), generator=g)
 plan = runtime.build_edge_plan(torch.stack([src, dst]).to(DEV), n_src, n_dst)
@@ -15,7 +15,10 @@ kv = (torch.randn(n_src, 2 * c, generator=g) * 0.5).bfloat16().to(DEV)
 x_r = torch.randn(n_dst, c, generator=g).bfloat16().to(DEV)
 u = (torch.randn(n_dst, h * up, generator=g) * 0.3).bfloat16().to(DEV)
 attr = torch.randn(e, up, generator=g).to(DEV)
-for xr in (x_r, None):
+if os.environ.get("DBG_ZERO_U"): u.zero_()
+if os.environ.get("DBG_ZERO_ATTR"): attr.zero_()
+if os.environ.get("DBG_XR_ONLY"): pass
+for xr in (x_r,):
     la, lb = torch.empty(n_dst, h, device=DEV), torch.empty(n_dst, h, device=DEV)
     a = ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], xr, u, attr, plan.rowptr, plan.col, h, up, lse=la)
     b = ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], xr, u, attr, plan.rowptr, plan.col, h, up, lse=lb, sched=sched)
@@ -27,3 +30,6 @@ for xr in (x_r, None):
     if d.any():
         i = int(torch.nonzero(d.any(1))[0]); cols = torch.nonzero(d[i]).flatten()[:8].tolist()
         print(" row", i, "deg", int(deg[i]), "cols", cols, a[i, cols].float().tolist(), b[i, cols].float().tolist())
+        dc = d.any(0).nonzero().flatten()
+        print(" differing columns: min", int(dc.min()), "max", int(dc.max()), "count", dc.numel(), "t-col diffs per (col % up):",
+              torch.bincount((dc[dc >= c] - c) % up, minlength=up).tolist() if (dc >= c).any() else None)
