@@ -68,6 +68,20 @@ def test_bench_self_launch_relays_one_error_line_without_a_gpu():
     assert "error" in line and "stage" in line and "metric" not in line
 
 
+def test_bench_watchdog_thread_prints_one_error_line_and_exits_4():
+    """``bench.Stage`` alone, no GPU: a stage with a time limit that overruns ends the process with exit code 4 and ONE
+    JSON error line naming the stage; stages without a limit (build, timed steps, cpu baseline) are never interrupted."""
+    code = ("import os, sys, time; sys.path.insert(0, %r); import bench; "
+            "os.environ['ANEMOI_AMD_BENCH_WATCHDOG_SCALE'] = '0.005'; s = bench.Stage(); s.watch(); "
+            "s[0] = 'build'; time.sleep(2.5); s[0] = 'first all_reduce'; time.sleep(30); print('not reached')" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 4, (res.returncode, res.stderr[-1500:])
+    out = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1 and "not reached" not in res.stdout
+    line = json.loads(out[0])
+    assert line["stage"] == "first all_reduce" and "watchdog" in line["error"]
+
+
 @pytest.mark.gpu
 def test_bench_self_launch_on_a_shared_gpu():
     """The same command on a GPU box (the two ranks share cuda:0 over host-staged gloo): one result line, exit code 0, with
