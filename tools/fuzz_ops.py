@@ -113,6 +113,50 @@ def fuzz_edge_attention():
     print(f"gt_edge_attention: {bad} bad of {n_cases // 3}", flush=True)
 
 
+def fuzz_edge_scheduled():
+    """The scheduled folded kernel (static destination schedule, scalar index pipeline, buffer loads) against the round-robin
+    folded kernel on the same operands: BIT identity (outputs incl. the t columns, lse) over random graphs -- destination
+    counts below / around / above the launch-shape thresholds, in-degrees 0 ... 40 incl. empty destinations, head sizes 64 / 32,
+    every folded width, with and without x_r, strided operands (column ranges of one GEMM result)."""
+    bad = tried = 0
+    for case in range(n_cases // 3):
+        h = rng.choice([8, 16])
+        d = rng.choice([32, 64])
+        c = h * d
+        up = rng.choice([4, 8, 12, 16])
+        n_dst = rng.choice([rng.randint(1, 40), rng.randint(41, 3000), rng.randint(3000, 30000)])
+        n_src = rng.choice([rng.randint(1, 50), rng.randint(51, 5000)])
+        g = torch.Generator().manual_seed(seed * 104729 + case)
+        deg = torch.randint(0, rng.choice([4, 9, 13]), (n_dst,), generator=g)
+        if n_dst > 10:
+            deg[rng.randrange(n_dst)] = rng.choice([17, 40])
+        dst = torch.repeat_interleave(torch.arange(n_dst), deg)
+        e = int(dst.shape[0])
+        src = torch.randint(0, n_src, (e,), generator=g)
+        perm = torch.randperm(e, generator=g)
+        plan = runtime.build_edge_plan(torch.stack([src[perm], dst[perm]]).to(dev), n_src, n_dst)
+        sched = plan.schedule(torch.bfloat16, c)
+        if sched is None:
+            continue
+        tried += 1
+        wide = torch.randn(n_dst, 2 * c + h * up, generator=g).bfloat16().to(dev)  # x_r | q | u as one GEMM result
+        kv = torch.randn(n_src, 2 * c, generator=g).bfloat16().to(dev)
+        attr = torch.randn(max(e, 0), up, generator=g).to(dev)
+        xr = wide[:, :c] if rng.random() < 0.7 else None
+        outs = []
+        for sc in (None, sched):
+            lse = torch.full((n_dst, h), float("nan"), device=dev)
+            out = ops.gt_edge_attention_folded(wide[:, c:2 * c], kv[:, :c], kv[:, c:], xr, wide[:, 2 * c:], attr, plan.rowptr,
+                                               plan.col, h, up, lse=lse, sched=sc)
+            outs.append((out, lse))
+        same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        if not same or not bool(torch.isfinite(outs[1][0].float()).all()):
+            bad += 1
+            print(f"  scheduled edge kernel case {case}: n_src={n_src} n_dst={n_dst} e={e} h={h} d={d} up={up} x_r={xr is not None}",
+                  flush=True)
+    print(f"gt_edge_attention_folded scheduled vs round-robin (bit identity): {bad} bad of {tried}", flush=True)
+
+
 def fuzz_rows():
     bad = 0
     for case in range(n_cases // 3):
@@ -159,5 +203,6 @@ def fuzz_weight_grad():
 
 fuzz_linear()
 fuzz_edge_attention()
+fuzz_edge_scheduled()
 fuzz_rows()
 fuzz_weight_grad()
