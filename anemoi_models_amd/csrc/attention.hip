@@ -81,15 +81,20 @@ __device__ __forceinline__ int aswz64(int row, int chunk) { return chunk ^ ((row
 // ---------------------------------------------------------------------------------------------
 // Attention dropout (reference layers/attention.py:90-105: dropout_p of SDPA / flash-attn in training mode).  The keep
 // decision of probability (b, h, i, j) is a counter-based hash of its index and a per-call seed -- nothing of size S x S
-// is stored, the backward kernels rebuild exactly the same mask.  One 32-bit hash (lowbias32 of the row and the KEY PAIR
-// j >> 1) decides two neighbouring keys, 16 bits each (the forward and the dQ kernel hold neighbouring keys of one query
-// in one packed register pair: one hash per pair; p is resolved to 2^-16).  Kept probabilities are scaled by
-// 1 / (1 - p); the softmax normaliser is taken before the dropout, as in the reference.  p >= 1 drops everything (output
-// and gradients 0).  The row index uses the GLOBAL head (h0 + h of h_total): a head-sharded call (sequence-parallel
-// attention across a model group) draws the mask of the unsharded one.
+// is stored, the backward kernels rebuild exactly the same mask.  One 32-bit hash of the row and the KEY PAIR j >> 1
+// decides two neighbouring keys, 15 bits each (the forward and the dQ kernel hold neighbouring keys of one query in one
+// packed register pair: one hash per pair; p is resolved to 2^-15).  Kept probabilities are scaled by 1 / (1 - p); the
+// softmax normaliser is taken before the dropout, as in the reference.  p >= 1 drops everything (output and gradients 0).
+// The row index uses the GLOBAL head (h0 + h of h_total): a head-sharded call (sequence-parallel attention across a model
+// group) draws the mask of the unsharded one.
+// Round 5: the mask generator is cut to what a keep decision needs -- ONE multiply in the mixer (x ^= x >> 16; x *= M;
+// x ^= x >> 15: every decision bit depends on all 32 input bits through the product's upper half and its fold-down) and
+// 15-bit thresholds, so that a pair's and-mask is three packed 16-bit operations (mask, subtract, arithmetic shift).  With
+// the two-multiply mixer and 16-bit compares the mask cost more VALU cycles than the softmax it masks: the dropout
+// variants of the kernels ran 1.7 x (forward) / 1.9 x (backward) the plain ones (profiles/r05_train_step_bench.txt).
 // ---------------------------------------------------------------------------------------------
 struct AttnDropout {
-  uint32_t thr16;      // keep  <=>  16 hash bits >= thr16  (thr16 = p * 2^16; 0: no dropout)
+  uint32_t thr15;      // keep  <=>  15 hash bits >= thr15  (thr15 = p * 2^15; 0: no dropout)
   uint32_t seed;
   float keep_scale;    // 1 / (1 - p), 0 when p >= 1
   int drop_all;
@@ -102,7 +107,7 @@ struct AttnDropout {
 
 __device__ __forceinline__ AttnDropout dropout_resolve(const AttnDropout& in) {
   AttnDropout dr = in;
-  if (dr.thr16 != 0 && dr.seed_dev != nullptr) dr.seed += __builtin_nontemporal_load(dr.seed_dev);
+  if (dr.thr15 != 0 && dr.seed_dev != nullptr) dr.seed += __builtin_nontemporal_load(dr.seed_dev);
   return dr;
 }
 
@@ -114,22 +119,29 @@ __device__ __forceinline__ uint32_t dropout_row_part(const AttnDropout& dr, int6
   return (uint32_t)row * 0x9E3779B1u ^ (uint32_t)(row >> 32) * 0x85EBCA77u ^ dr.seed;
 }
 
-// the 2 x 16 decision bits of key pair `pair` (= key >> 1): x = row part ^ pair * C3 (C3 = 0xC2B2AE3D), lowbias32
+// the 2 x 15 decision bits of key pair `pair` (= key >> 1): x = row part ^ pair * C3 (C3 = 0xC2B2AE3D), mixed once
 __device__ __forceinline__ uint32_t dropout_mix(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352du;
   x ^= x >> 15;
-  x *= 0x846ca68bu;
-  x ^= x >> 16;
   return x;
+}
+
+// and-mask of a packed bf16 pair from the pair's hash: 0xffff in the half whose 15 bits are >= thr15.  `cthr2` = thr15 - 1 in
+// both halves (dropout_cthr2): (thr15 - 1) - x15 is negative exactly for the kept halves, its sign fills the half.
+typedef short att_s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dropout_cthr2(const uint32_t thr15) { return ((thr15 - 1u) & 0xffffu) * 0x00010001u; }
+__device__ __forceinline__ uint32_t dropout_pair_mask(uint32_t x, uint32_t cthr2) {
+  const att_s16x2_t d = __builtin_bit_cast(att_s16x2_t, cthr2) - __builtin_bit_cast(att_s16x2_t, x & 0x7fff7fffu);
+  return __builtin_bit_cast(uint32_t, d >> 15);
 }
 
 __device__ __forceinline__ float dropout_keep(const AttnDropout& dr, int64_t row, int col) {
   // row = dropout_row(b, h, q), col = key
-  if (dr.thr16 == 0 && !dr.drop_all) return 1.0f;
+  if (dr.thr15 == 0 && !dr.drop_all) return 1.0f;
   if (dr.drop_all) return 0.0f;
   const uint32_t x = dropout_mix(dropout_row_part(dr, row) ^ (uint32_t)(col >> 1) * 0xC2B2AE3Du);
-  return ((x >> (16 * (col & 1))) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.0f;
+  return ((x >> (16 * (col & 1))) & 0x7fffu) >= dr.thr15 ? dr.keep_scale : 0.0f;
 }
 
 static inline AttnDropout make_dropout(float p, uint32_t seed, int h0, int h_total, const void* seed_dev = nullptr) {
@@ -137,8 +149,8 @@ static inline AttnDropout make_dropout(float p, uint32_t seed, int h0, int h_tot
   dr.seed = seed;
   dr.seed_dev = static_cast<const uint32_t*>(seed_dev);
   dr.drop_all = p >= 1.0f ? 1 : 0;
-  const double t = p <= 0.f ? 0.0 : (double)p * 65536.0 + 0.5;
-  dr.thr16 = dr.drop_all ? 0xffffu : (uint32_t)(t > 65535.0 ? 65535.0 : t);
+  const double t = p <= 0.f ? 0.0 : (double)p * 32768.0 + 0.5;
+  dr.thr15 = dr.drop_all ? 0x8000u : (uint32_t)(t > 32768.0 ? 32768.0 : t);
   dr.keep_scale = (p > 0.f && p < 1.0f) ? 1.0f / (1.0f - p) : (p >= 1.0f ? 0.f : 1.0f);
   dr.h0 = h0;
   dr.h_total = h_total;
@@ -334,8 +346,7 @@ __global__ __launch_bounds__(512, (ATT_D == 32 && !DROP) ? 4 : 2) void mhsa_bf16
                                                    *reinterpret_cast<const bf16x2_t*>(&ones2), psum, false);
             if constexpr (DROP) {  // keys key0 + 16 kk + 2 i (low half) and + 1 (high half): pair index (key0 >> 1) + 8 kk + i
               const uint32_t x = dropout_mix(drow[qb] ^ ((uint32_t)(key0 >> 1) + 8u * kk + i) * 0xC2B2AE3Du);
-              const uint32_t keep = ((x & 0xffffu) >= dr.thr16 ? 0x0000ffffu : 0u) | ((x >> 16) >= dr.thr16 ? 0xffff0000u : 0u);
-              w[i] &= keep;
+              w[i] &= dropout_pair_mask(x, dropout_cthr2(dr.thr15));
             }
           }
           pb[qb][kk] = *reinterpret_cast<abf16x8_t*>(w);
@@ -631,8 +642,7 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
 #undef W4_E
       if constexpr (DROP && n > 0) {
         const uint32_t x = dropout_mix(drow[2 * SM_PR + pi] ^ ((uint32_t)(key0 >> 1) + 8u * pkk + pj) * 0xC2B2AE3Du);
-        const uint32_t keep = ((x & 0xffffu) >= dr.thr16 ? 0x0000ffffu : 0u) | ((x >> 16) >= dr.thr16 ? 0xffff0000u : 0u);
-        w[pi][pkk][pj] &= keep;
+        w[pi][pkk][pj] &= dropout_pair_mask(x, dropout_cthr2(dr.thr15));
       }
     };
     // the last pair's pack (+ row sum); wait states: the exponentials right above, and a dot product's result is not
@@ -651,8 +661,7 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
 #undef W4_TAIL
       if constexpr (DROP) {
         const uint32_t x = dropout_mix(drow[2 * SM_PR + 1] ^ ((uint32_t)(key0 >> 1) + 8u + 3u) * 0xC2B2AE3Du);
-        const uint32_t keep = ((x & 0xffffu) >= dr.thr16 ? 0x0000ffffu : 0u) | ((x >> 16) >= dr.thr16 ? 0xffff0000u : 0u);
-        w[1][1][3] &= keep;
+        w[1][1][3] &= dropout_pair_mask(x, dropout_cthr2(dr.thr15));
       }
     };
     asm volatile("s_nop 3" ::: "memory");  // (sa[0]'s last MFMA is two slots back: these wait states on top)
@@ -1267,6 +1276,8 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
   // V: P = exp2(S c - lse), dS = P (dP - delta), both as bf16 B fragments of M2
   auto vphase = [&](int qt) {
     float p[16], ds[16];
+    const uint32_t drow_tile = (drow0 + (uint32_t)(qt * 32)) * 0x9E3779B1u;
+    (void)drow_tile;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = 8 * half + (r & 7) + 16 * (r >> 3);
@@ -1276,8 +1287,10 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
         pe = (dq_ <= window && -dq_ <= window) ? pe : 0.f;
       }
       if constexpr (DROP) {  // dV takes the dropped probabilities, dS = P (keep / (1 - p) dP - delta)
-        const uint32_t x = dropout_mix((drow0 + (uint32_t)(qt * 32 + qi)) * 0x9E3779B1u ^ dkey);
-        const float kf_ = ((x >> dsh) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.f;
+        // (row part = (row0 + q) G with q = 32 qt + qi: the tile's base once, the register's share a constant -- no
+        //  per-element multiply in front of the mixer's own)
+        const uint32_t x = dropout_mix((drow_tile + (uint32_t)qi * 0x9E3779B1u) ^ dkey);
+        const float kf_ = ((x >> dsh) & 0x7fffu) >= dr.thr15 ? dr.keep_scale : 0.f;
         p[r] = pe * kf_;
         ds[r] = pe * (dp_acc[r] * kf_ - dlv[r]);
       } else {
@@ -1478,7 +1491,7 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dq_mfma_kernel(
       if (WIN && window >= 0) pe = ((key - q <= window) && (q - key <= window)) ? pe : 0.f;
       if constexpr (DROP) {  // registers r, r + 1 (r even) are the two keys of one pair: one hash for both
         const uint32_t x = dropout_mix(drow ^ (uint32_t)(key >> 1) * 0xC2B2AE3Du);
-        const float kf_ = ((x >> (16 * (r & 1))) & 0xffffu) >= dr.thr16 ? dr.keep_scale : 0.f;
+        const float kf_ = ((x >> (16 * (r & 1))) & 0x7fffu) >= dr.thr15 ? dr.keep_scale : 0.f;
         ds[r] = pe * (dp_acc[r] * kf_ - dl);
       } else {
         ds[r] = pe * (dp_acc[r] - dl);
@@ -1680,7 +1693,7 @@ int anemoi_mhsa(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, 
                                       dropout_seed_dev);
   // MFMA route, with or without dropout (the mask is applied to the packed probabilities; the kernels hash 32-bit row
   // indices: B x heads x S < 2^32, and p = 1 -- everything dropped -- stays on the generic kernel)
-  const bool drop = dr.thr16 != 0;
+  const bool drop = dr.thr15 != 0;
   if (!dr.drop_all && (int64_t)B * dr.h_total * S < ((int64_t)1 << 32) && dtype == ANEMOI_BF16 && (D == 64 || D == 32) &&
       (uintptr_t)qkv % 16 == 0 && ld % 8 == 0 && (uintptr_t)out % 8 == 0 && ldo % 4 == 0) {
     ANEMOI_REQUIRE(workspace != nullptr, ANEMOI_ERR_INVALID, "anemoi_mhsa: workspace of %lld bytes required",
@@ -1799,7 +1812,7 @@ int anemoi_mhsa_backward(int dtype, const void* qkv, int64_t ld, const void* out
                  "anemoi_mhsa: dropout_seed_dev must be 4-byte aligned");
   const AttnDropout dr = make_dropout(dropout_p, dropout_seed, dropout_h0, dropout_h_total > 0 ? dropout_h_total : H,
                                       dropout_seed_dev);
-  const bool drop = dr.thr16 != 0;
+  const bool drop = dr.thr15 != 0;
   hipStream_t st = as_stream(stream);
   const float scale = 1.0f / sqrtf((float)D);
   const int64_t units = (int64_t)B * S * H;

@@ -572,7 +572,8 @@ def test_transformer_model_training_step_vs_oracle_autograd(graph_o32, golden_cf
 
 def _dropout_keep_mask(seed: int, p: float, b: int, h: int, s: int, h0: int = 0, h_total: int = 0) -> torch.Tensor:
     """The kernels' counter-based keep mask (csrc/attention.hip::dropout_keep) restated with torch integer arithmetic:
-    [B, H, S, S] of 0 / 1.  One lowbias32 hash of (row, key >> 1) decides a key pair, 16 bits per key."""
+    [B, H, S, S] of 0 / 1.  One 32-bit hash of (row, key >> 1) -- one multiply, two fold-downs -- decides a key pair, 15 bits
+    per key."""
     m32 = 0xFFFFFFFF
     h_total = h_total or h
     bb = torch.arange(b, dtype=torch.int64).view(b, 1, 1, 1)
@@ -586,10 +587,8 @@ def _dropout_keep_mask(seed: int, p: float, b: int, h: int, s: int, h0: int = 0,
     x = x ^ (x >> 16)
     x = (x * 0x7FEB352D) & m32
     x = x ^ (x >> 15)
-    x = (x * 0x846CA68B) & m32
-    x = x ^ (x >> 16)
-    bits = (x >> (16 * (col & 1))) & 0xFFFF
-    thr = min(int(p * 65536.0 + 0.5), 65535)
+    bits = (x >> (16 * (col & 1))) & 0x7FFF
+    thr = min(int(p * 32768.0 + 0.5), 32768)
     return (bits >= thr).to(torch.float64) if p < 1.0 else torch.zeros(b, h, s, s, dtype=torch.float64)
 
 

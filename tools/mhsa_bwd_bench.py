@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anemoi_models_amd import autograd  # noqa: E402
 
 shapes = [(10242, 16, 32), (40962, 16, 64)]
+P_DROP = float(os.environ.get("MHSA_BENCH_DROPOUT", "0"))  # attention dropout (training mode of the reference; its default: 0.1)
 if len(sys.argv) > 1:  # S,H,D triples
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for (s, h, d) in shapes:
@@ -19,10 +20,10 @@ for (s, h, d) in shapes:
 
     def fwd():
         with torch.no_grad():
-            autograd.mhsa(x.detach(), 1, h, -1)
+            autograd.mhsa(x.detach(), 1, h, -1, P_DROP, 12345)
 
     def step():
-        autograd.mhsa(x, 1, h, -1).backward(dy)
+        autograd.mhsa(x, 1, h, -1, P_DROP, 12345).backward(dy)
         x.grad = None
 
     res = []
@@ -37,5 +38,5 @@ for (s, h, d) in shapes:
         torch.cuda.synchronize()
         res.append(a.elapsed_time(b) / 3)
     flops = 4 * h * s * s * d
-    print(f"S={s} H={h} D={d}: forward {res[0]:.2f} ms, forward + backward {res[1]:.2f} ms -> backward {res[1] - res[0]:.2f} ms "
+    print(f"dropout {P_DROP}: S={s} H={h} D={d}: forward {res[0]:.2f} ms, forward + backward {res[1]:.2f} ms -> backward {res[1] - res[0]:.2f} ms "
           f"({3.5 * flops / (res[1] - res[0]) / 1e9:.0f} TFLOP/s over its 7 S x S x D products)", flush=True)
