@@ -45,6 +45,12 @@ PARITY_BOUND = {"bf16": 1e-2, "fp32": 1e-3}
 # -- the largest entries of a 1024-channel latent carry one bf16 rounding of the residual stream (attribution:
 # profiles/r05_latent_error.txt) --, f32 2e-6
 LATENT_BOUND = {"bf16": 2e-2, "fp32": 1e-3}
+# test hook (tests/test_bench_contract.py): scales every parity bound, so that the "a failed comparison prints ONE error line
+# and no result line" contract can be exercised on a healthy build
+_BOUND_SCALE = float(os.environ.get("ANEMOI_AMD_BENCH_PARITY_BOUND_SCALE", "1"))
+if _BOUND_SCALE != 1.0:
+    PARITY_BOUND = {k: v * _BOUND_SCALE for k, v in PARITY_BOUND.items()}
+    LATENT_BOUND = {k: v * _BOUND_SCALE for k, v in LATENT_BOUND.items()}
 
 WORKLOADS = {
     # name: (graph, channels, processor blocks, heads, description)

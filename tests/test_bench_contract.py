@@ -100,6 +100,22 @@ def test_bench_self_launch_on_a_shared_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_parity_failure_prints_the_error_line_only():
+    """A run whose output fails its comparison with the CPU oracle must not print a result line: with every parity bound scaled
+    to 1e-6 of its value (test hook) a healthy config-2 run ends with exit code 3 and ONE JSON line that carries the error and
+    the measured errors -- no "metric", no "value"."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", ANEMOI_AMD_BENCH_PARITY_BOUND_SCALE="1e-6")
+    res = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--workload", "cfg2"], capture_output=True,
+                         text=True, timeout=900, env=env)
+    assert res.returncode == 3, (res.returncode, res.stderr[-2000:])
+    out = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, res.stdout[-3000:]
+    line = json.loads(out[0])
+    assert "error" in line and line["stage"] == "parity" and "metric" not in line and "value" not in line
+    assert line["parity"]["output_rel_err"] > 0 and line["parity_fp32"]["output_rel_err"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_watchdog_ends_a_rank_whose_peer_never_arrives():
     """World 2 with only rank 0 started: process-group init can never complete.  The watchdog prints ONE JSON error line
     naming the stage and ends the process with exit code 4 -- bounded, no restart."""
