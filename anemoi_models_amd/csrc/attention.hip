@@ -1332,7 +1332,11 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
 #ifdef ATT_BWD_PROF
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
-  for (int qt = qt_begin; qt < qt_end; ++qt) {
+  // One tile.  The ring position is a COMPILE-TIME constant (the loop below is unrolled by the ring's three buffers): with a
+  // run-time buffer index every one of the tile's 24 fragment reads paid a v_add for its LDS address -- 40 of the loop's ~130
+  // VALU instructions per tile in a kernel that is bound by its VALU stream (round 5) -- now they are immediate offsets.
+  auto tile = [&](int qt, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
     ATT_T(0);
     // this wave's requests of tile qt have landed (the PRE - 1 tiles behind it may stay in flight: vmcnt counts in order,
     // NDMA per tile; the last PRE - 1 tiles simply drain); the barrier publishes the buffer and retires tile qt - 1,
@@ -1342,14 +1346,28 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
     ATT_T(1);
     __syncthreads();
     ATT_T(2);
-    if (qt + PRE < qt_end) stage(qt + PRE, (qt + PRE - qt_begin) % N_STAGE);
+    if (qt + PRE < qt_end) stage(qt + PRE, (BUF + PRE) % N_STAGE);
     ATT_T(3);
-    m1(smem + ((qt - qt_begin) % N_STAGE) * STAGE);
+    m1(smem + BUF * STAGE);
     ATT_T(4);
     vphase(qt);
     ATT_T(5);
     m2();
     ATT_T(6);
+  };
+  {
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    static_assert(N_STAGE == 3, "the tile loop is unrolled by the ring");
+    int qt = qt_begin;
+    for (; qt + 2 < qt_end; qt += 3) {
+      tile(qt, B0{});
+      tile(qt + 1, B1{});
+      tile(qt + 2, B2{});
+    }
+    if (qt < qt_end) tile(qt, B0{});
+    if (qt + 1 < qt_end) tile(qt + 1, B1{});
   }
 #ifdef ATT_BWD_PROF
   if (blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 64)
@@ -1442,15 +1460,19 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dq_mfma_kernel(
 #pragma unroll
   for (int i = 0; i < PRE; ++i)
     if (kt_begin + i < kt_end) stage(kt_begin + i, i);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  // One tile; the ring position is a compile-time constant (the loop is unrolled by the ring's buffers, see the dK/dV kernel:
+  // immediate LDS offsets instead of a v_add per fragment read)
+  auto tile = [&](int kt, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    (void)&dq;  // (an asm operand alone does not capture in a generic lambda)
     // this wave's requests of tile kt have landed; those of the PRE - 1 tiles behind it (n_mine each) may stay in flight
     if (kt + PRE - 1 < kt_end && n_mine == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (PRE - 1)) : "memory");
     else if (kt + PRE - 1 < kt_end && n_mine == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PRE - 1)) : "memory");
     else if (kt + PRE - 1 < kt_end && n_mine == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRE - 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + PRE < kt_end) stage(kt + PRE, (kt + PRE - kt_begin) % N_STAGE);
-    const char* sb = smem + ((kt - kt_begin) % N_STAGE) * STAGE;
+    if (kt + PRE < kt_end) stage(kt + PRE, (BUF + PRE) % N_STAGE);
+    const char* sb = smem + BUF * STAGE;
     const char *k_s = sb, *v_s = sb + ARR, *kt_s = sb + 2 * ARR;
     // ---- S^T = K Q^T and dP^T = V dO^T: lane = query, register r <-> key 8 half + (r & 7) + 16 (r >> 3) of the tile
     af32x16_t s_acc, dp_acc;  // (fragment requests ahead of each phase: see the dK/dV kernel)
@@ -1514,6 +1536,20 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dq_mfma_kernel(
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) ANEMOI_BWD_MFMA_ACC(dq[dt], fkt[dt][kk], dsb[kk]);
     }
+  };
+  {
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    static_assert(N_STAGE == 3, "the tile loop is unrolled by the ring");
+    int kt = kt_begin;
+    for (; kt + 2 < kt_end; kt += 3) {
+      tile(kt, B0{});
+      tile(kt + 1, B1{});
+      tile(kt + 2, B2{});
+    }
+    if (kt < kt_end) tile(kt, B0{});
+    if (kt + 1 < kt_end) tile(kt + 1, B1{});
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> the accumulator reads below
   if (q < S) {
