@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -176,7 +176,7 @@ SIGNATURES = {
                                                              c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                                              c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                              c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                                             c_int64, c_int, c_int, c_void_p]),
+                                                             c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "anemoi_gt_edge_attention_folded_backward_src": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                              c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),

@@ -34,11 +34,87 @@ def _pack(w: Tensor, dtype: torch.dtype) -> Tensor:
     """``[N, K]`` f32 parameter -> compute dtype with K zero-padded to the GEMM's slab multiple."""
     n, k = w.shape
     kp = ops.round_up(k, ops.k_multiple(dtype))
-    if kp == k and w.dtype == dtype and w.is_contiguous():
-        return w
+    if kp == k:  # no padding: the cast alone (one launch; nothing for a contiguous weight in the compute dtype)
+        return w.detach().to(dtype).contiguous()
     out = torch.zeros((n, kp), dtype=dtype, device=w.device)
     out[:, :k] = w.detach().to(dtype)
     return out
+
+
+class GradSink:
+    """``[count, N * K (+ N)]`` f32: where the weight (and bias) gradients of the SAME Linear of ``count`` equally shaped
+    blocks land -- slot ``i`` is the ``out`` of block i's weight-gradient reduction (``ops.weight_grad``), so the gradient of
+    the stacked weight ``[count, N, K]`` is complete without a copy when the last block has run (:class:`_Unstack`).
+    Allocated on first use in a backward, released when every part has been handed to autograd."""
+
+    def __init__(self, count: int, n: int, k: int, bias: bool, device, stacked_parts: int = 1) -> None:
+        self.count, self.n, self.k, self.bias, self.device = count, n, k, bias, device
+        self.width = n * k + (n if bias else 0)
+        self.buf: Optional[Tensor] = None
+        self.stacked_parts = stacked_parts  # how many parts ("w", "b") an _Unstack collects before the buffer is let go
+        self._pending = 0
+
+    def slot(self, i: int) -> Tensor:
+        if self.buf is None:
+            self.buf = torch.empty((self.count, self.width), dtype=torch.float32, device=self.device)
+            self._pending = self.stacked_parts
+        return self.buf[i]
+
+    def stacked(self, part: str, grads) -> Optional[Tensor]:
+        """The stacked gradient of ``part`` ("w" / "b") if every block's gradient IS its slot of the buffer, else None."""
+        buf = self.buf
+        if buf is None or len(grads) != self.count:
+            return None
+        off = 0 if part == "w" else self.n * self.k
+        size = self.n * self.k if part == "w" else self.n
+        esz = buf.element_size()
+        for i, g in enumerate(grads):
+            if (g is None or g.dtype != buf.dtype or g.numel() != size or not g.is_contiguous()
+                    or g.data_ptr() != buf.data_ptr() + (i * self.width + off) * esz):
+                return None
+        out = buf[:, off:off + size]
+        self._pending -= 1
+        if self._pending <= 0:
+            self.buf = None
+        return out.view(self.count, self.n, self.k) if part == "w" else out
+
+
+class WeightPrep:
+    """One Linear of one block, prepared by its processor for a whole forward + backward: ``w`` the weight in the compute
+    dtype (K padded), ``wt`` its transpose ``[K, N]`` (the dX GEMM's operand) or None, ``sink`` / ``index`` the slot of a
+    :class:`GradSink` its weight gradient is reduced into (or None)."""
+
+    __slots__ = ("w", "wt", "sink", "index")
+
+    def __init__(self, w: Tensor, wt: Optional[Tensor] = None, sink: Optional[GradSink] = None, index: int = 0) -> None:
+        self.w, self.wt, self.sink, self.index = w, wt, sink, index
+
+    def grad_out(self, has_bias: bool, want_w: bool, want_b: bool) -> Optional[Tensor]:
+        s = self.sink
+        if s is None or not want_w or s.bias != (has_bias and want_b):
+            return None
+        return s.slot(self.index)
+
+
+class _Unstack(torch.autograd.Function):
+    """``stacked [L, ...] -> L`` tensors (``unbind``).  Backward: when the L gradients are the slots of ``sink`` they ARE the
+    stacked gradient already -- no ``torch.stack`` over ``L x N x K`` floats (config 3: 0.9 GB per step)."""
+
+    @staticmethod
+    def forward(ctx, stacked: Tensor, sink: Optional[GradSink], part: str):
+        ctx.sink, ctx.part, ctx.shape = sink, part, stacked.shape
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for t in stacked.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            return None, None, None
+        got = ctx.sink.stacked(ctx.part, grads) if ctx.sink is not None else None
+        if got is None:
+            ref = next(g for g in grads if g is not None)
+            got = torch.stack([torch.zeros_like(ref) if g is None else g for g in grads])
+        return got.reshape(ctx.shape), None, None
 
 
 _TORCH_ACT = {"GELU": torch.nn.functional.gelu, "SiLU": torch.nn.functional.silu, "ReLU": torch.relu}
@@ -46,14 +122,16 @@ _TORCH_ACT = {"GELU": torch.nn.functional.gelu, "SiLU": torch.nn.functional.silu
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: str, residual: Optional[Tensor]):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: str, residual: Optional[Tensor],
+                prep: Optional[WeightPrep] = None):
         dtype = x.dtype
         k = weight.shape[1]
         kp = ops.round_up(k, ops.k_multiple(dtype))
         if x.shape[1] not in (k, kp):
             raise ValueError(f"linear: x has {x.shape[1]} columns, weight expects {k}")
         xk = x if x.shape[1] == kp else ops.convert_pad(x, dtype, kp)
-        w = _pack(weight, dtype)
+        w = _pack(weight, dtype) if prep is None else prep.w
+        ctx.prep = prep
         b = None if bias is None else bias.detach().float().contiguous()
         if act == "Identity":
             pre = None
@@ -85,27 +163,33 @@ class _Linear(torch.autograd.Function):
         dpre = dy if ctx.act == "Identity" else ops.act_backward(pre, dy, ctx.act)
         n, k = weight.shape
         kmul = ops.k_multiple(dtype)
+        prep = ctx.prep
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             # dX [M, K] = dpre [M, N] @ W [N, K]: a Linear whose weight is W^T [K, N] (N is the reduction dimension)
             np_ = ops.round_up(n, kmul)
-            wt = ops.transpose(weight.detach().to(dtype).contiguous(), ld_out=np_)
+            if prep is not None and prep.wt is not None:
+                wt = prep.wt
+            else:
+                wt = ops.transpose(weight.detach().to(dtype).contiguous(), ld_out=np_)
             dp = dpre if n == np_ else ops.convert_pad(dpre, dtype, np_)
             dx = ops.linear(dp, wt)
             if ctx.x_cols != k:
                 dx = ops.convert_pad(dx, dtype, ctx.x_cols)
         if ctx.needs_input_grad[1]:
             # dW [N, K] = dpre^T [N, M] @ X [M, K]: a Linear with x' = dpre^T, weight' = X^T, reduction over the M rows
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                dw, db = ops.weight_grad(dpre, xk, k, want_bias=True)  # the bias gradient rides on dpre's transpose
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            out = None if prep is None or weight.dtype != torch.float32 else prep.grad_out(ctx.has_bias, True, want_b)
+            if want_b:
+                dw, db = ops.weight_grad(dpre, xk, k, want_bias=True, out=out)  # the bias gradient rides on dpre's transpose
                 dw = dw.to(weight.dtype)
             else:
-                dw = ops.weight_grad(dpre, xk, k).to(weight.dtype)
+                dw = ops.weight_grad(dpre, xk, k, out=out).to(weight.dtype)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_sum(dpre)
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dw, db, None, dres
+        return dx, dw, db, None, dres, None
 
 
 class _MLP2(torch.autograd.Function):
@@ -117,9 +201,12 @@ class _MLP2(torch.autograd.Function):
     :func:`mlp2` composes two :class:`_Linear` nodes otherwise."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act: str, residual):
+    def forward(ctx, x, w1, b1, w2, b2, act: str, residual, prep1: Optional[WeightPrep] = None,
+                prep2: Optional[WeightPrep] = None):
         dtype = x.dtype
-        w1p, w2p = _pack(w1, dtype), _pack(w2, dtype)
+        w1p = _pack(w1, dtype) if prep1 is None else prep1.w
+        w2p = _pack(w2, dtype) if prep2 is None else prep2.w
+        ctx.prep1, ctx.prep2 = prep1, prep2
         pre, h = ops.linear_dual(x, w1p, None if b1 is None else b1.detach().float().contiguous(), act)
         y = ops.linear(h, w2p, None if b2 is None else b2.detach().float().contiguous(), residual=residual)
         ctx.save_for_backward(x, w1, w2, pre, h)
@@ -132,33 +219,46 @@ class _MLP2(torch.autograd.Function):
         dtype = x.dtype
         dy = dy.contiguous()
         need = ctx.needs_input_grad
+        prep1, prep2 = ctx.prep1, ctx.prep2
+
+        def sink_out(prep, w, has_b, want_b):
+            return None if prep is None or w.dtype != torch.float32 else prep.grad_out(has_b, True, want_b)
+
+        def transposed(prep, w):
+            return prep.wt if prep is not None and prep.wt is not None else ops.transpose(w.detach().to(dtype).contiguous())
+
         dx = dw1 = db1 = dw2 = db2 = None
         if need[3]:
-            if ctx.has_b2 and need[4]:
-                dw2, db2 = ops.weight_grad(dy, h, w2.shape[1], want_bias=True)
+            want_b2 = ctx.has_b2 and need[4]
+            out2 = sink_out(prep2, w2, ctx.has_b2, want_b2)
+            if want_b2:
+                dw2, db2 = ops.weight_grad(dy, h, w2.shape[1], want_bias=True, out=out2)
             else:
-                dw2 = ops.weight_grad(dy, h, w2.shape[1])
+                dw2 = ops.weight_grad(dy, h, w2.shape[1], out=out2)
             dw2 = dw2.to(w2.dtype)
         if db2 is None and ctx.has_b2 and need[4]:
             db2 = ops.col_sum(dy)
         if need[0] or need[1] or (ctx.has_b1 and need[2]):
             # d pre = (dy W2) * act'(pre): Linear2's dX GEMM with the activation's derivative in its epilogue
-            dpre = ops.linear_actgrad(dy, ops.transpose(w2.detach().to(dtype).contiguous()), pre, ctx.act)
+            dpre = ops.linear_actgrad(dy, transposed(prep2, w2), pre, ctx.act)
             if need[1]:
-                if ctx.has_b1 and need[2]:
-                    dw1, db1 = ops.weight_grad(dpre, x, w1.shape[1], want_bias=True)
+                want_b1 = ctx.has_b1 and need[2]
+                out1 = sink_out(prep1, w1, ctx.has_b1, want_b1)
+                if want_b1:
+                    dw1, db1 = ops.weight_grad(dpre, x, w1.shape[1], want_bias=True, out=out1)
                 else:
-                    dw1 = ops.weight_grad(dpre, x, w1.shape[1])
+                    dw1 = ops.weight_grad(dpre, x, w1.shape[1], out=out1)
                 dw1 = dw1.to(w1.dtype)
             if db1 is None and ctx.has_b1 and need[2]:
                 db1 = ops.col_sum(dpre)
             if need[0]:
-                dx = ops.linear(dpre, ops.transpose(w1.detach().to(dtype).contiguous()))
-        return dx, dw1, db1, dw2, db2, None, (dy if ctx.has_res and need[6] else None)
+                dx = ops.linear(dpre, transposed(prep1, w1))
+        return dx, dw1, db1, dw2, db2, None, (dy if ctx.has_res and need[6] else None), None, None
 
 
 def mlp2(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], act: str,
-         residual: Optional[Tensor] = None) -> Tensor:
+         residual: Optional[Tensor] = None, prep1: Optional[WeightPrep] = None,
+         prep2: Optional[WeightPrep] = None) -> Tensor:
     """``linear(linear(x, w1, b1, act), w2, b2, residual=residual)`` -- fused into one autograd node (:class:`_MLP2`) when
     the shapes allow the fused GEMM epilogues (bf16, every width a multiple of the 64-element K slab)."""
     km = ops.k_multiple(x.dtype)
@@ -166,8 +266,8 @@ def mlp2(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[T
              and w1.shape[1] % km == 0 and w1.shape[0] % km == 0 and w2.shape[0] % km == 0 and w2.shape[1] == w1.shape[0]
              and x.shape[0] >= 1024 and w1.shape[0] >= 256 and w2.shape[0] >= 256 and x.is_contiguous())
     if not fused:
-        return linear(linear(x, w1, b1, act), w2, b2, "Identity", residual)
-    return _MLP2.apply(x, w1, b1, w2, b2, act, residual)
+        return linear(linear(x, w1, b1, act, prep=prep1), w2, b2, "Identity", residual, prep=prep2)
+    return _MLP2.apply(x, w1, b1, w2, b2, act, residual, prep1, prep2)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -215,15 +315,15 @@ def layer_norm_skip(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5):
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = "Identity",
-           residual: Optional[Tensor] = None) -> Tensor:
+           residual: Optional[Tensor] = None, prep: Optional[WeightPrep] = None) -> Tensor:
     """``act(x @ weight.T + bias) + residual`` with gradients for ``x``, ``weight``, ``bias`` and ``residual``.
     ``x`` / ``residual`` in the compute dtype (f32 or bf16), ``weight [N, K]`` / ``bias [N]`` f32 parameters.  ``act``
     outside the kernel's epilogues (Identity / GELU / SiLU / ReLU; the reference takes any ``torch.nn`` activation by
     name): the product runs here, the activation as a torch module behind it."""
     if act not in ("Identity", "GELU", "SiLU", "ReLU"):
-        y = getattr(torch.nn, act)()(_Linear.apply(x, weight, bias, "Identity", None))
+        y = getattr(torch.nn, act)()(_Linear.apply(x, weight, bias, "Identity", None, prep))
         return y if residual is None else y + residual
-    return _Linear.apply(x, weight, bias, act, residual)
+    return _Linear.apply(x, weight, bias, act, residual, prep)
 
 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tensor:
@@ -352,10 +452,12 @@ def _transposed_csr(plan):
     return cached
 
 
-def _edge_backward(q, k, v, dout, u, dt, lse, edge_attr, plan, h: int, up: int, dq, dk, dv, du, want_dattr: bool):
+def _edge_backward(q, k, v, dout, u, dt, lse, edge_attr, plan, h: int, up: int, dq, dk, dv, du, want_dattr: bool,
+                   dxr: Optional[Tensor] = None):
     """The three backward kernels of the folded edge phase (csrc/edge_backward.hip) on column views: ``q, dout, u, dt``
     ``[n_dst, .]``, ``k, v`` ``[n_src, C]`` in, ``dq, du`` ``[n_dst, .]`` and ``dk, dv`` ``[n_src, C]`` out (any row
-    pitch: the processor block hands in the column ranges of ONE ``d(x_r|q|k|v|u)`` buffer).  Returns d edge_attr."""
+    pitch: the processor block hands in the column ranges of ONE ``d(x_r|q|k|v|u)`` buffer).  ``dxr`` (optional,
+    ``[n_dst, C]`` view): receives ``dout`` (the self term's gradient) in the destination sweep.  Returns d edge_attr."""
     from . import _lib
 
     n_dst, c = q.shape
@@ -372,7 +474,8 @@ def _edge_backward(q, k, v, dout, u, dt, lse, edge_attr, plan, h: int, up: int, 
     st = lib.anemoi_gt_edge_attention_folded_backward_dst(
         code, q.data_ptr(), ld(q), k.data_ptr(), v.data_ptr(), ld(k), dout.data_ptr(), ld(dout), u.data_ptr(), ld(u),
         dt.data_ptr(), ld(dt), lse.data_ptr(), edge_attr.data_ptr(), up, plan.rowptr.data_ptr(), plan.col.data_ptr(),
-        alpha.data_ptr(), w.data_ptr(), dsum.data_ptr(), dq.data_ptr(), ld(dq), du.data_ptr(), ld(du), n_dst, c, h, stream)
+        alpha.data_ptr(), w.data_ptr(), dsum.data_ptr(), dq.data_ptr(), ld(dq), du.data_ptr(), ld(du),
+        None if dxr is None else dxr.data_ptr(), 0 if dxr is None else ld(dxr), n_dst, c, h, stream)
     _lib.check(st, "anemoi_gt_edge_attention_folded_backward_dst")
     rowptr_t, eid_t, dst_t, dst_of_edge = _transposed_csr(plan)
     st = lib.anemoi_gt_edge_attention_folded_backward_src(
@@ -449,13 +552,13 @@ class _GTEdgeAttentionSelf(torch.autograd.Function):
         dfull = dfull.contiguous()
         dout = dfull[:, :c]
         dsq = torch.empty_like(sq)
-        dsq[:, :c].copy_(dout)  # d x_r
         if plan.col.shape[0] == 0:
+            dsq[:, :c].copy_(dout)  # d x_r
             dsq[:, c:].zero_()
             return dsq, torch.zeros_like(edge_attr), None, None, None
         dattr = _edge_backward(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], dout, sq[:, 4 * c:],
                                dfull[:, c:c + h * up], lse, edge_attr, plan, h, up, dsq[:, c:2 * c], dsq[:, 2 * c:3 * c],
-                               dsq[:, 3 * c:4 * c], dsq[:, 4 * c:], ctx.needs_input_grad[1])
+                               dsq[:, 3 * c:4 * c], dsq[:, 4 * c:], ctx.needs_input_grad[1], dxr=dsq[:, :c])  # d x_r = dout
         return dsq, dattr, None, None, None
 
 
@@ -482,14 +585,14 @@ class _GTEdgeAttentionMapper(torch.autograd.Function):
         dfull = dfull.contiguous()
         dout = dfull[:, :c]
         dsq = torch.empty_like(sq)
-        dsq[:, :c].copy_(dout)  # d x_r
         if plan.col.shape[0] == 0:
+            dsq[:, :c].copy_(dout)  # d x_r
             dsq[:, c:].zero_()
             return dsq, torch.zeros_like(kv), torch.zeros_like(edge_attr), None, None, None
         dkv = torch.empty_like(kv)
         dattr = _edge_backward(sq[:, c:2 * c], kv[:, :c], kv[:, c:], dout, sq[:, 2 * c:], dfull[:, c:c + h * up], lse,
                                edge_attr, plan, h, up, dsq[:, c:2 * c], dkv[:, :c], dkv[:, c:], dsq[:, 2 * c:],
-                               ctx.needs_input_grad[2])
+                               ctx.needs_input_grad[2], dxr=dsq[:, :c])  # d x_r = dout
         return dsq, dkv, dattr, None, None, None
 
 
@@ -697,6 +800,110 @@ def _lin_edge_fold(sd: dict, prefix: str, c: int, h: int, up: int, device):
 FOLD_MAX_UP = 16  # widest per-head edge representation of the folded edge kernels (edge_dim + 1 rounded up to 4)
 
 
+class GTBlockWeights:
+    """The operands of ONE processor block out of :func:`gt_processor_weights`: f32 ``w_in`` / ``b_in`` / ``w_p`` (results
+    of the batched fold algebra -- autograd carries their gradients back to every block's parameters in one batched
+    backward) and the :class:`WeightPrep` of the block's four GEMMs."""
+
+    __slots__ = ("w_in", "b_in", "w_p", "p_in", "p_p", "p_1", "p_2")
+
+
+def _stacked_cast_and_transpose(stacked: Tensor, dtype: torch.dtype):
+    """``[L, N, K]`` f32 -> (``[L, N, K]``, ``[L, K, N]``) in the compute dtype: one cast + one chunked transpose launch."""
+    from . import _lib
+
+    count, n, k = stacked.shape
+    w = stacked.detach().to(dtype)
+    wt = torch.empty((count, k, n), dtype=dtype, device=w.device)
+    st = _lib.load().anemoi_transpose_chunked(ops.dtype_code(dtype), w.data_ptr(), k, wt.data_ptr(), n, count * n, k, n, None,
+                                              ops._stream())
+    _lib.check(st, "anemoi_transpose_chunked")
+    return w, wt
+
+
+def _params_cast_and_transpose(params, dtype: torch.dtype):
+    """The same for L separate ``[N, K]`` f32 parameters: a multi-tensor cast into one buffer + one chunked transpose."""
+    from . import _lib
+
+    count = len(params)
+    n, k = params[0].shape
+    w = torch.empty((count, n, k), dtype=dtype, device=params[0].device)
+    torch._foreach_copy_(list(w.unbind(0)), [p.detach() for p in params])
+    wt = torch.empty((count, k, n), dtype=dtype, device=w.device)
+    st = _lib.load().anemoi_transpose_chunked(ops.dtype_code(dtype), w.data_ptr(), k, wt.data_ptr(), n, count * n, k, n, None,
+                                              ops._stream())
+    _lib.check(st, "anemoi_transpose_chunked")
+    return w, wt
+
+
+def gt_processor_weights(sds: list, prefix: str, c: int, h: int, up: int, dtype: torch.dtype, device):
+    """Everything the blocks of a GraphTransformer processor derive from their PARAMETERS, for all blocks at once: the
+    lin_edge fold (three batched einsums instead of three per block), ``x_r|q|k|v|u`` / ``projection|t`` weight assembly,
+    the casts to the compute dtype and the transposes the dX GEMMs read.  Per block and step the per-block route spends
+    ~50 launches of a few microseconds on this (a third of the launches of a config-3 training step); here it is ~40
+    launches per processor.  Returns a list of :class:`GTBlockWeights`, or None when the blocks do not qualify (other dtype
+    than bf16, widths off the GEMM's 64-element slab, differing shapes) -- the caller then takes the per-block route.
+    ``ANEMOI_AMD_TRAIN_BATCHED_PARAMS=0`` switches it off (A/B runs)."""
+    import os
+
+    count = len(sds)
+    km = ops.k_multiple(dtype)
+    if (os.environ.get("ANEMOI_AMD_TRAIN_BATCHED_PARAMS", "1") == "0" or dtype != torch.bfloat16 or count < 2
+            or up > FOLD_MAX_UP or c % km != 0 or (h * up) % km != 0):
+        return None
+    names = ("lin_self", "lin_query", "lin_key", "lin_value", "lin_edge", "projection", "node_dst_mlp.1", "node_dst_mlp.3")
+    key = lambda sd, n, part: sd.get(f"{prefix}.{n}.{part}")  # noqa: E731
+    for n in names:
+        ws, bs = [key(sd, n, "weight") for sd in sds], [key(sd, n, "bias") for sd in sds]
+        if any(w is None or b is None or w.dtype != torch.float32 or b.dtype != torch.float32 or w.shape != ws[0].shape
+               or not w.is_contiguous() for w, b in zip(ws, bs)):
+            return None
+    hidden = key(sds[0], "node_dst_mlp.1", "weight").shape[0]
+    if hidden % km != 0 or key(sds[0], "node_dst_mlp.3", "weight").shape != (c, hidden):
+        return None
+    col = lambda n, part: [key(sd, n, part) for sd in sds]  # noqa: E731
+    d = c // h
+    we, be = torch.stack(col("lin_edge", "weight")), torch.stack(col("lin_edge", "bias"))
+    edge_dim = we.shape[2]
+    pad = torch.zeros((count, c, up - edge_dim - 1), dtype=torch.float32, device=device)
+    weh = torch.cat([we, be[:, :, None], pad], dim=2).view(count, h, d, up)
+    wq, bq = torch.stack(col("lin_query", "weight")), torch.stack(col("lin_query", "bias"))
+    wp = torch.stack(col("projection", "weight"))
+    w_u = torch.einsum("lhda,lhdc->lhac", weh, wq.view(count, h, d, c)).reshape(count, h * up, c)
+    b_u = torch.einsum("lhda,lhd->lha", weh, bq.view(count, h, d)).reshape(count, h * up)
+    w_t = torch.einsum("lohd,lhda->loha", wp.view(count, c, h, d), weh).reshape(count, c, h * up)
+    n_in = 4 * c + h * up
+    rows, vecs = [], []
+    w_u_i, b_u_i = w_u.unbind(0), b_u.unbind(0)  # (unbind: ONE backward node that stacks the L gradients)
+    for i, sd in enumerate(sds):  # one cat over 5 L matrices: block i's rows are x_r | q | k | v | u
+        rows += [key(sd, "lin_self", "weight"), key(sd, "lin_query", "weight"), key(sd, "lin_key", "weight"),
+                 key(sd, "lin_value", "weight"), w_u_i[i]]
+        vecs += [key(sd, "lin_self", "bias"), key(sd, "lin_query", "bias"), key(sd, "lin_key", "bias"),
+                 key(sd, "lin_value", "bias"), b_u_i[i]]
+    w_in = torch.cat(rows, dim=0).view(count, n_in, c)
+    b_in = torch.cat(vecs, dim=0).view(count, n_in)
+    w_p = torch.cat([wp, w_t], dim=2)  # [L, C, C + H * up]
+    sink_in = GradSink(count, n_in, c, True, device, stacked_parts=2)
+    sink_p = GradSink(count, c, c + h * up, True, device, stacked_parts=1)  # (the projection's bias is a leaf: its slot goes to it)
+    w_in_c, w_in_t = _stacked_cast_and_transpose(w_in, dtype)
+    w_p_c, w_p_t = _stacked_cast_and_transpose(w_p, dtype)
+    w1_c, w1_t = _params_cast_and_transpose(col("node_dst_mlp.1", "weight"), dtype)
+    w2_c, w2_t = _params_cast_and_transpose(col("node_dst_mlp.3", "weight"), dtype)
+    w_in_i = _Unstack.apply(w_in, sink_in, "w")
+    b_in_i = _Unstack.apply(b_in, sink_in, "b")
+    w_p_i = _Unstack.apply(w_p, sink_p, "w")
+    out = []
+    for i in range(count):
+        bw = GTBlockWeights()
+        bw.w_in, bw.b_in, bw.w_p = w_in_i[i], b_in_i[i], w_p_i[i]
+        bw.p_in = WeightPrep(w_in_c[i], w_in_t[i], sink_in, i)
+        bw.p_p = WeightPrep(w_p_c[i], w_p_t[i], sink_p, i)
+        bw.p_1 = WeightPrep(w1_c[i], w1_t[i])
+        bw.p_2 = WeightPrep(w2_c[i], w2_t[i])
+        out.append(bw)
+    return out
+
+
 def _explicit_edge_features(sd: dict, prefix: str, edge_attr_csr: Tensor, dtype: torch.dtype) -> Tensor:
     """``lin_edge(a)`` as an explicit ``[E, C]`` matrix in CSR order (the route for ``up > FOLD_MAX_UP``): the attribute
     matrix carries a constant 1 behind the ``edge_dim`` real columns, so ``[W_e | b_e | 0]`` is the whole Linear."""
@@ -706,26 +913,40 @@ def _explicit_edge_features(sd: dict, prefix: str, edge_attr_csr: Tensor, dtype:
     return linear(edge_attr_csr.to(dtype), torch.cat([w_e, b_e[:, None], pad], dim=1), None)
 
 
-def _gt_tail(y_att: Tensor, x_skip: Tensor, sd: dict, prefix: str, w_t: Optional[Tensor], act: str, eps: float) -> Tensor:
+def _gt_tail(y_att: Tensor, x_skip: Tensor, sd: dict, prefix: str, w_t: Optional[Tensor], act: str, eps: float,
+             prepared: Optional[GTBlockWeights] = None) -> Tensor:
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
-    w_p = g("projection.weight") if w_t is None else torch.cat([g("projection.weight"), w_t], dim=1)
-    y = linear(y_att, w_p, g("projection.bias"), "Identity", x_skip)
+    if prepared is not None:
+        y = linear(y_att, prepared.w_p, g("projection.bias"), "Identity", x_skip, prep=prepared.p_p)
+    else:
+        w_p = g("projection.weight") if w_t is None else torch.cat([g("projection.weight"), w_t], dim=1)
+        y = linear(y_att, w_p, g("projection.bias"), "Identity", x_skip)
     h1, y = layer_norm_skip(y, g("node_dst_mlp.0.weight"), g("node_dst_mlp.0.bias"), eps)
     return mlp2(h1, g("node_dst_mlp.1.weight"), g("node_dst_mlp.1.bias"), g("node_dst_mlp.3.weight"),
-                g("node_dst_mlp.3.bias"), act, y)
+                g("node_dst_mlp.3.bias"), act, y, None if prepared is None else prepared.p_1,
+                None if prepared is None else prepared.p_2)
 
 
 def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, plan, num_heads: int,
-                       act: str = "GELU", eps: float = 1e-5) -> Tensor:
+                       act: str = "GELU", eps: float = 1e-5, prepared: Optional[GTBlockWeights] = None) -> Tensor:
     """Differentiable ``GraphTransformerProcessorBlock`` (reference layers/block.py:602-635) on the HIP kernels:
     ``sd[prefix + ".lin_query.weight"]`` etc. are the block's f32 parameters (``requires_grad`` as wanted),
     ``edge_attr_csr`` ``[E, up]`` f32 the edge attributes in the plan's CSR order with the constant-1 column behind the
     ``edge_dim`` real ones (``ops.edge_attr_csr``).  ``lin_edge`` is folded into the q GEMM and the projection exactly
     as in the inference path; the fold itself is ordinary torch algebra on the parameters, so autograd carries the
-    gradients back to ``lin_edge`` / ``lin_query`` / ``projection``."""
+    gradients back to ``lin_edge`` / ``lin_query`` / ``projection``.  ``prepared``: this block's entry of
+    :func:`gt_processor_weights` (the fold algebra, casts and transposes done for all blocks of the processor at once)."""
     g = lambda name: sd[prefix + "." + name]  # noqa: E731
     c = x.shape[1]
     h, up = num_heads, edge_attr_csr.shape[1]
+    if prepared is not None:
+        xh, x = layer_norm_skip(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
+        sq = linear(xh, prepared.w_in, prepared.b_in, prep=prepared.p_in)  # x_r | q | k | v | u
+        if _edge_phase_in_f32(sq.dtype, (sq.shape[1] - h * up) // 4, h):
+            att = _GTEdgeAttentionSelf.apply(sq.float(), edge_attr_csr, plan, h, up).to(sq.dtype)
+        else:
+            att = _GTEdgeAttentionSelf.apply(sq, edge_attr_csr, plan, h, up)
+        return _gt_tail(att, x, sd, prefix, None, act, eps, prepared)
     if up > FOLD_MAX_UP:  # many edge attributes: lin_edge as a GEMM, the conv on explicit per-edge features
         xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
         sq = linear(xh, torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight")], 0),

@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void transpose_b16_kernel(const uint16_t* __re
 // every 16th partial each (four chains), LDS folds the 16 groups in a fixed order (deterministic).  The one-block-per-256
 // columns form of the stage kernel below ran 4 .. 17 workgroups for 56 us, 121 times per training step.
 // ---------------------------------------------------------------------------------------------
+// (out_hi / split: columns >= split go to out_hi[c - split] -- d gamma | d beta of the LayerNorm backward land in their
+//  two result vectors without device copies behind this kernel)
 __global__ __launch_bounds__(256) void col_sum_final_kernel(const float* __restrict__ partial, int64_t n_part, int cols,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, float* __restrict__ out_hi, int split) {
   __shared__ float fold[16][17];
   const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void col_sum_final_kernel(const float* __restr
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += fold[i][cl];
-    out[c] = t;
+    if (out_hi != nullptr && c >= split) out_hi[c - split] = t;
+    else out[c] = t;
   }
 }
 
@@ -218,7 +221,7 @@ static int col_sum_launch(const T* x, int64_t ldx, int64_t rows, int cols, float
   hipLaunchKernelGGL((col_sum_stage_kernel<T>), dim3((unsigned)blocks, cblocks), dim3(256), 0, st, x, ldx, rows, cols,
                      chunk, workspace);
   hipLaunchKernelGGL(col_sum_final_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, st, workspace, blocks, cols,
-                     out);
+                     out, static_cast<float*>(nullptr), 0);
   return check_launch("anemoi_col_sum");
 }
 
@@ -453,12 +456,8 @@ static int layer_norm_backward_launch(const T* x, int64_t ldx, const float2* sta
   else rc = launch(layer_norm_backward_kernel<T, 0>);
   if (rc != ANEMOI_OK) return rc;
   // [wgs, 2C] partials -> d gamma | d beta
-  float* both = workspace + wgs * 2 * C;
   hipLaunchKernelGGL(col_sum_final_kernel, dim3((unsigned)((2 * C + 15) / 16)), dim3(256), 0, st, workspace, (int64_t)wgs,
-                     2 * C, both);
-  if (hipMemcpyAsync(dgamma, both, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(dbeta, both + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return fail(ANEMOI_ERR_LAUNCH, "anemoi_layer_norm_backward: device copy failed");
+                     2 * C, dgamma, dbeta, C);
   return check_launch("anemoi_layer_norm_backward");
 }
 

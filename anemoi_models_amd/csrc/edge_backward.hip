@@ -38,7 +38,8 @@ struct EdgeBwdParams {
   float* dsum;       // [n_dst, H]
   void* dq;          // [n_dst, lddq]
   void* du;          // [n_dst, lddu]  (H * UP columns)
-  int64_t ldq, ldkv, ldd, ldu, lddt, lddq, lddu;
+  void* dxr;         // optional [n_dst, lddxr]: a copy of dout (the gradient of the self term x_r, out = sum alpha v + x_r)
+  int64_t ldq, ldkv, ldd, ldu, lddt, lddq, lddu, lddxr;
   int64_t n_dst;
   int C, H, n_slices;
   float scale;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(256) void gt_edge_bwd_dst_kernel(const EdgeBwdParam
       qk.set(f);
       VecIO<T, VEC>::load(dob + node * p.ldd, f);
       dok.set(f);
+      if (p.dxr != nullptr && active) VecIO<T, VEC>::store(static_cast<T*>(p.dxr) + node * p.lddxr + c0, f);
       VecIO<T, APL>::load(ub + node * p.ldu, u);
       VecIO<T, APL>::load(dtb + node * p.lddt, dtl);
 #pragma unroll
@@ -553,7 +555,8 @@ int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64
                                                  const void* dt, int64_t lddt, const float* lse, const float* edge_attr,
                                                  int up, const int32_t* rowptr, const int32_t* col, float* alpha,
                                                  float* w, float* dsum, void* dq, int64_t lddq, void* du, int64_t lddu,
-                                                 int64_t n_dst, int C, int H, anemoi_stream_t stream) {
+                                                 void* dxr, int64_t lddxr, int64_t n_dst, int C, int H,
+                                                 anemoi_stream_t stream) {
   ANEMOI_REQUIRE(q && k && v && dout && u && dt && lse && edge_attr && rowptr && col && alpha && w && dsum && dq && du,
                  ANEMOI_ERR_INVALID, "anemoi_gt_edge_attention_folded_backward_dst: null pointer");
   ANEMOI_REQUIRE(n_dst >= 0 && C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID,
@@ -564,12 +567,13 @@ int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64
                      ldu % vec == 0 && lddt % vec == 0 && lddu % vec == 0 && ((int64_t)up * esz) % 8 == 0 &&
                      (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
                      (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 16 == 0 && (uintptr_t)u % 16 == 0 &&
-                     (uintptr_t)dt % 16 == 0 && (uintptr_t)du % 16 == 0 && (uintptr_t)edge_attr % 16 == 0,
+                     (uintptr_t)dt % 16 == 0 && (uintptr_t)du % 16 == 0 && (uintptr_t)edge_attr % 16 == 0 &&
+                     (dxr == nullptr || ((uintptr_t)dxr % 16 == 0 && lddxr % vec == 0 && lddxr >= C)),
                  ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_edge_attention_folded_backward_dst: operands must be 16-byte aligned");
   EdgeBwdParams p;
   p.q = q; p.k = k; p.v = v; p.dout = dout; p.u = u; p.dt = dt; p.lse = lse;
-  p.alpha = alpha; p.w = w; p.dsum = dsum; p.dq = dq; p.du = du;
-  p.ldq = ldq; p.ldkv = ldkv; p.ldd = ldd; p.ldu = ldu; p.lddt = lddt; p.lddq = lddq; p.lddu = lddu;
+  p.alpha = alpha; p.w = w; p.dsum = dsum; p.dq = dq; p.du = du; p.dxr = dxr;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldd = ldd; p.ldu = ldu; p.lddt = lddt; p.lddq = lddq; p.lddu = lddu; p.lddxr = lddxr;
   p.n_dst = n_dst; p.C = C; p.H = H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
   p.scale = 1.0f / sqrtf((float)(C / H));

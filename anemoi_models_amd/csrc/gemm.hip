@@ -428,7 +428,8 @@ __device__ __forceinline__ void skinny_column(const bf16_t* __restrict__ X, int6
 // instead of one per column (5121 x 4096 x 1024: the column-at-a-time pass cost 14 us of a 58-us launch, every launch of a
 // 40 962- / 10 242- / 5 121-row problem 3 - 14 us).  Per column the arithmetic is skinny_column's, operation for operation
 // (k order per lane, wave_sum, epilogue): the same bits.
-template <int ROWS>
+// EPI 1 / 2: the DUAL / GMUL epilogues of the four-wave kernel (R = second output / saved pre-activation), ACT_T = its ACT.
+template <int ROWS, int EPI = 0, int ACT_T = 0>
 __device__ __forceinline__ void skinny_columns(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W,
                                                const float* __restrict__ bias, const bf16_t* __restrict__ R, int64_t ldr,
                                                bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K, int act, LnFold ln,
@@ -475,6 +476,15 @@ __device__ __forceinline__ void skinny_columns(const bf16_t* __restrict__ X, int
           for (int r = 0; r < ROWS; ++r) {
             if (r < M) {
               float a = acc[r][c];
+              if constexpr (EPI == 1) {  // pre-activation (as the backward will read it) next to the activation of the f32 sum
+                const_cast<bf16_t*>(R)[r * ldr + n] = f32_to_bf16(a + b);
+                Y[r * ldy + n] = f32_to_bf16(act_apply(a + b, act));
+                continue;
+              } else if constexpr (EPI == 2) {  // (x W^T) * act'(pre)
+                const float pv = bf16_to_f32(R[r * ldr + n]);
+                Y[r * ldy + n] = f32_to_bf16((a + b) * act_grad2<ACT_T>(f32x2_t{pv, pv}).x);
+                continue;
+              }
               if (ln.stats != nullptr) a = fmaf(a, ln.stats[r].x, ln.stats[r].y * ln.colsum[n]);
               float o = act_apply(a + b, act);
               o = bf16_to_f32(f32_to_bf16(o));  // bf16 result, then + residual
@@ -622,12 +632,13 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     // to one wave of each of the 256 workgroups, not four to 64 of them)
     const int gw = wid * (int)gridDim.x + (int)blockIdx.x, tw = (int)gridDim.x * 4;
     const bf16_t* xt = X + M * ldx;
-    const bf16_t* rt = HAS_RES ? R + M * ldr : nullptr;
+    const bf16_t* rt = (HAS_RES || DUAL) ? R + M * ldr : nullptr;
     bf16_t* yt = Y + M * ldy;
-    if (m_tail == 1) skinny_columns<1>(xt, ldx, W, bias, rt, ldr, yt, ldy, 1, N, K, ACT, lt, lane, gw, tw);
-    else if (m_tail == 2) skinny_columns<2>(xt, ldx, W, bias, rt, ldr, yt, ldy, 2, N, K, ACT, lt, lane, gw, tw);
-    else if (m_tail <= 4) skinny_columns<4>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
-    else skinny_columns<8>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
+    constexpr int EPI = DUAL ? 1 : GMUL ? 2 : 0;
+    if (m_tail == 1) skinny_columns<1, EPI, ACT>(xt, ldx, W, bias, rt, ldr, yt, ldy, 1, N, K, ACT, lt, lane, gw, tw);
+    else if (m_tail == 2) skinny_columns<2, EPI, ACT>(xt, ldx, W, bias, rt, ldr, yt, ldy, 2, N, K, ACT, lt, lane, gw, tw);
+    else if (m_tail <= 4) skinny_columns<4, EPI, ACT>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
+    else skinny_columns<8, EPI, ACT>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
   }
   if (!has_tiles) return;
 #ifndef ANEMOI_LAB_TAIL_BEHIND_DMA
@@ -1107,14 +1118,14 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     if (residual != nullptr) LAUNCH_W4_(A, true, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL);   \
     else LAUNCH_W4_(A, false, MHV, RSV, XP, RP, YP, LNV, MV, TILES, TAIL);                      \
   } while (0)
-#define LAUNCH_W4_DUAL(A, MHV, XP, RP, YP, LNV, MV, TILES)                                                            \
+#define LAUNCH_W4_DUAL(A, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                                      \
   hipLaunchKernelGGL((linear_bf16_w4_kernel<A, false, false, MHV, false, true>), dim3((unsigned)w4_blocks), dim3(256), \
                      W4_LDS, st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,             \
-                     vec_ok ? 1 : 0, TILES, (int)nt, LNV, 0)
-#define LAUNCH_W4_GMUL(A, MHV, XP, RP, YP, LNV, MV, TILES)                                                                  \
+                     vec_ok ? 1 : 0, TILES, (int)nt, LNV, TAIL)
+#define LAUNCH_W4_GMUL(A, MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                                            \
   hipLaunchKernelGGL((linear_bf16_w4_kernel<A, true, false, MHV, false, false, true>), dim3((unsigned)w4_blocks), dim3(256), \
                      W4_LDS, st, XP, ldx, static_cast<const bf16_t*>(w), bias, RP, ldr, YP, ldy, MV, N, K,                   \
-                     vec_ok ? 1 : 0, TILES, (int)nt, LNV, 0)
+                     vec_ok ? 1 : 0, TILES, (int)nt, LNV, TAIL)
 #define LAUNCH_W4_PLAIN(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                      \
   switch (act) {                                                                                    \
     case ANEMOI_ACT_GELU: LAUNCH_W4(ANEMOI_ACT_GELU, MHV, false, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
@@ -1128,15 +1139,15 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
 #define LAUNCH_W4_ACT(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)                                        \
   if (gmul) {                                                                                       \
     switch (act) {                                                                                  \
-      case ANEMOI_ACT_GELU: LAUNCH_W4_GMUL(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
-      case ANEMOI_ACT_SILU: LAUNCH_W4_GMUL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
-      default: LAUNCH_W4_GMUL(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES); break;               \
+      case ANEMOI_ACT_GELU: LAUNCH_W4_GMUL(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+      case ANEMOI_ACT_SILU: LAUNCH_W4_GMUL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+      default: LAUNCH_W4_GMUL(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break;         \
     }                                                                                               \
   } else if (dual) {                                                                                \
     switch (act) {                                                                                  \
-      case ANEMOI_ACT_GELU: LAUNCH_W4_DUAL(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
-      case ANEMOI_ACT_SILU: LAUNCH_W4_DUAL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES); break; \
-      default: LAUNCH_W4_DUAL(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES); break;               \
+      case ANEMOI_ACT_GELU: LAUNCH_W4_DUAL(ANEMOI_ACT_GELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+      case ANEMOI_ACT_SILU: LAUNCH_W4_DUAL(ANEMOI_ACT_SILU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break; \
+      default: LAUNCH_W4_DUAL(ANEMOI_ACT_RELU, MHV, XP, RP, YP, LNV, MV, TILES, TAIL); break;         \
     }                                                                                               \
   } else LAUNCH_W4_PLAIN(MHV, XP, RP, YP, LNV, MV, TILES, TAIL)
     // row-sum partials (LnFold::rs_partial): plain epilogue only, whole 256-column tiles only
@@ -1409,13 +1420,18 @@ extern "C" int anemoi_linear_dual(int dtype, const void* x, int64_t ldx, const v
   ANEMOI_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && ldp >= N, ANEMOI_ERR_INVALID,
                  "anemoi_linear_dual: bad shape");
   ANEMOI_REQUIRE(act > ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_linear_dual: act %d", act);
-  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 && M % BIG_M == 0 && N >= 256 && N % 8 == 0 && K >= 128 && K % 64 == 0 &&
-                     (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)pre % 16 == 0 &&
+  // (up to 8 rows behind the last whole 256-row tile are computed by the same launch: the skinny pass of the kernel)
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 && M % BIG_M <= 8 && (M >= BIG_M || M == 0) && N >= 256 && N % 8 == 0 && K >= 128 &&
+                     K % 64 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)pre % 16 == 0 &&
                      (uintptr_t)y % 16 == 0 && ldx % 8 == 0 && ldp % 8 == 0 && ldy % 8 == 0,
-                 ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_dual: bf16, M a multiple of 256, N >= 256, K >= 128, 16-byte aligned");
+                 ANEMOI_ERR_UNSUPPORTED,
+                 "anemoi_linear_dual: bf16, M = a multiple of 256 (+ at most 8 rows), N >= 256, K >= 128, 16-byte aligned");
   if (M == 0) return ANEMOI_OK;
-  const int rc = linear_bf16_256_launch(x, ldx, w, bias, pre, ldp, y, ldy, M, N, K, act, as_stream(stream),
-                                        LnFold{nullptr, nullptr}, 0, nullptr, 1);
+  bool tail_done = false;
+  const int rc = linear_bf16_256_launch(x, ldx, w, bias, pre, ldp, y, ldy, M / BIG_M * BIG_M, N, K, act, as_stream(stream),
+                                        LnFold{nullptr, nullptr}, (int)(M % BIG_M), &tail_done, 1);
+  if (rc == ANEMOI_OK && M % BIG_M != 0 && !tail_done)
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_dual: the ragged rows were not taken by the fast path");
   if (rc == W4_NEEDS_WHOLE_TILES) return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_dual: shape not taken by the fast path");
   return rc;
 }
@@ -1430,14 +1446,17 @@ extern "C" int anemoi_linear_actgrad(int dtype, const void* x, int64_t ldx, cons
   ANEMOI_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && ldp >= N, ANEMOI_ERR_INVALID,
                  "anemoi_linear_actgrad: bad shape");
   ANEMOI_REQUIRE(act > ANEMOI_ACT_NONE && act <= ANEMOI_ACT_RELU, ANEMOI_ERR_INVALID, "anemoi_linear_actgrad: act %d", act);
-  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 && M % BIG_M == 0 && N >= 256 && N % 8 == 0 && K >= 128 && K % 64 == 0 &&
-                     (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)pre % 16 == 0 &&
+  ANEMOI_REQUIRE(dtype == ANEMOI_BF16 && M % BIG_M <= 8 && (M >= BIG_M || M == 0) && N >= 256 && N % 8 == 0 && K >= 128 &&
+                     K % 64 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)pre % 16 == 0 &&
                      (uintptr_t)y % 16 == 0 && ldx % 8 == 0 && ldp % 8 == 0 && ldy % 8 == 0,
                  ANEMOI_ERR_UNSUPPORTED,
-                 "anemoi_linear_actgrad: bf16, M a multiple of 256, N >= 256, K >= 128, 16-byte aligned");
+                 "anemoi_linear_actgrad: bf16, M = a multiple of 256 (+ at most 8 rows), N >= 256, K >= 128, 16-byte aligned");
   if (M == 0) return ANEMOI_OK;
-  const int rc = linear_bf16_256_launch(x, ldx, w, nullptr, pre, ldp, y, ldy, M, N, K, act, as_stream(stream),
-                                        LnFold{nullptr, nullptr}, 0, nullptr, 2);
+  bool tail_done = false;
+  const int rc = linear_bf16_256_launch(x, ldx, w, nullptr, pre, ldp, y, ldy, M / BIG_M * BIG_M, N, K, act, as_stream(stream),
+                                        LnFold{nullptr, nullptr}, (int)(M % BIG_M), &tail_done, 2);
+  if (rc == ANEMOI_OK && M % BIG_M != 0 && !tail_done)
+    return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_actgrad: the ragged rows were not taken by the fast path");
   if (rc == W4_NEEDS_WHOLE_TILES)
     return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_linear_actgrad: shape not taken by the fast path");
   return rc;

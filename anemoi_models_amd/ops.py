@@ -662,12 +662,15 @@ def transpose(x: Tensor, ld_out: Optional[int] = None) -> Tensor:
     return out
 
 
-def col_sum(x: Tensor) -> Tensor:
+def col_sum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """f32 column sums of a row-major matrix (bias gradient), deterministic two-stage reduction."""
     _dev(x)
     rows, cols = _rows(x).shape
     lib = _lib.load()
-    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    elif out.dtype != torch.float32 or out.numel() != cols or not out.is_contiguous():
+        raise ValueError("col_sum: out must be a contiguous f32 vector of the column count")
     n_ws = lib.anemoi_col_sum_workspace_floats(rows, cols)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
     st = lib.anemoi_col_sum(dtype_code(x.dtype), x.data_ptr(), _ld(x), rows, cols, out.data_ptr(), ws.data_ptr(), n_ws,
@@ -709,7 +712,8 @@ def row_scale(x: Tensor, s: Tensor, alpha: float = 1.0, out: Optional[Tensor] = 
 
 def linear_dual(x: Tensor, w: Tensor, bias: Optional[Tensor], act: str):
     """``(pre, y) = (x @ w.T + bias, act(pre))``: the training forward of Linear + activation.  One launch
-    (``anemoi_linear_dual``) for the whole 256-row tiles of a bf16 product, the GEMM + activation pass pair for the rest."""
+    (``anemoi_linear_dual``) for the whole 256-row tiles of a bf16 product and up to 8 rows behind them, the GEMM +
+    activation pass pair for a longer remainder."""
     _dev(x, w, bias)
     m, k = _rows(x).shape
     n = w.shape[0]
@@ -722,6 +726,8 @@ def linear_dual(x: Tensor, w: Tensor, bias: Optional[Tensor], act: str):
         return pre, act_forward(pre, act)
     pre = torch.empty((m, n), dtype=x.dtype, device=x.device)
     y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    if m - m_main <= 8:  # the launch computes up to 8 ragged rows itself (its skinny pass)
+        m_main = m
     with _Timed("linear", flops=2 * m_main * n * k, bytes=(m_main * k + n * k + 2 * m_main * n) * 2, m=m_main, n=n, k=k):
         st = _lib.load().anemoi_linear_dual(dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), _ptr(bias),
                                             pre.data_ptr(), n, y.data_ptr(), n, m_main, n, k, _lib.ACT_CODES[act], _stream())
@@ -745,6 +751,8 @@ def linear_actgrad(x: Tensor, w: Tensor, pre: Tensor, act: str) -> Tensor:
     if m_main < 1024:
         return act_backward(pre, linear(x, w), act)
     out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    if m - m_main <= 8:  # (as linear_dual)
+        m_main = m
     with _Timed("linear", flops=2 * m_main * n * k, bytes=(m_main * k + n * k + 2 * m_main * n) * 2, m=m_main, n=n, k=k):
         st = _lib.load().anemoi_linear_actgrad(dtype_code(x.dtype), x.data_ptr(), _ld(x), w.data_ptr(), pre.data_ptr(),
                                                _ld(_rows(pre)), out.data_ptr(), n, m_main, n, k, _lib.ACT_CODES[act],
@@ -804,14 +812,17 @@ def layer_norm_backward(x: Tensor, stats: Tensor, gamma: Tensor, dy: Tensor, dre
     return dx, dgamma, dbeta
 
 
-def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False, transposed_route: bool = False):
+def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False, transposed_route: bool = False,
+                out: Optional[Tensor] = None):
     """``dW [N, k] = dpre^T @ x[:, :k]`` in f32 (``dpre [M, N]``, ``x [M, >= k]`` in the compute dtype): the reduction
     over the M rows is cut into chunks -- chunked transposes, one batched GEMM on the 128 x 128 kernel, a deterministic
     sum of the partial results -- so that a small ``[N, k]`` result still fills the chip (a 1024 x 192 gradient over
     542 080 rows took 7 ms on 16 workgroups without the split).  ``want_bias``: returns ``(dW, db)`` with
     ``db = dpre.sum(0)`` (f32); for bf16 the column sums come out of the transpose of ``dpre`` (per-tile partials), not
     out of a second pass over it.  ``transposed_route=True`` (tests, tools/dw_bench.py) takes the transposes + NT route even
-    where the TN kernel applies (bf16, 16-byte aligned operands, M >= 128), which otherwise runs."""
+    where the TN kernel applies (bf16, 16-byte aligned operands, M >= 128), which otherwise runs.  ``out`` (optional, f32
+    ``[N * k (+ N)]`` contiguous): where the TN route leaves ``dW`` (and ``db`` behind it) -- the results are then views of
+    it (a caller's stacked gradient buffer, autograd.GradSink); ignored by the other route."""
     _dev(dpre, x)
     m, n = _rows(dpre).shape
     kmul = k_multiple(dpre.dtype)
@@ -831,12 +842,17 @@ def weight_grad(dpre: Tensor, x: Tensor, k: int, want_bias: bool = False, transp
         # one buffer [chunks, n * k (+ n)]: the weight partials and, behind them, the bias partials of a chunk -- ONE column
         # sum over the chunks finishes both
         width = n * k + (n if want_bias else 0)
-        part = torch.empty((chunks, width), dtype=torch.float32, device=dpre.device)
+        if out is not None and (out.dtype != torch.float32 or out.numel() != width or not out.is_contiguous()):
+            raise ValueError(f"weight_grad: out must be a contiguous f32 vector of {width} elements")
+        if out is not None and chunks == 1:
+            part = out.view(1, width)
+        else:
+            part = torch.empty((chunks, width), dtype=torch.float32, device=dpre.device)
         st = _lib.load().anemoi_weight_grad_tn(dpre.data_ptr(), _ld(dpre), xr.data_ptr(), _ld(xr), part.data_ptr(), width,
                                                part[:, n * k:].data_ptr() if want_bias else None, width, m, n, k, chunk_rows,
                                                _stream())
         _lib.check(st, "anemoi_weight_grad_tn")
-        total = part[0] if chunks == 1 else col_sum(part)
+        total = part[0] if chunks == 1 else col_sum(part, out=None if out is None else out.view(width))
         dw = total[: n * k].view(n, k)
         return (dw, total[n * k:]) if want_bias else dw
     tile = 256 if fast else 128

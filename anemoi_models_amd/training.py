@@ -184,10 +184,19 @@ def gt_processor(proc, x: Tensor, batch_size: int, node_map: Optional[Tensor] = 
     n = x.shape[0]
     plan, ea = _set_plan_and_attrs(proc, n, n, batch_size, ops.round_up(proc.edge_dim + 1, 4), node_map, node_map)
 
+    # what the blocks derive from their parameters alone (lin_edge fold, weight assembly, casts, transposes): once for
+    # all blocks of the processor, outside the checkpointed chunks
+    blocks = [blk for chunk in proc.proc for blk in chunk.blocks]
+    sds = [_block_sd(blk) for blk in blocks]
+    same = all(b.num_heads == blk0.num_heads and b.activation == blk0.activation for b in blocks)
+    prepared = autograd.gt_processor_weights(sds, "b", x.shape[1], blk0.num_heads, ea.shape[1], dtype, x.device) if same else None
+    index = {id(blk): i for i, blk in enumerate(blocks)}
+
     def run_chunk(chunk, h, attrs):
         for blk in chunk.blocks:
-            h = autograd.gt_processor_block(h, _block_sd(blk), "b", attrs, plan, blk.num_heads, blk.activation,
-                                            blk.layer_norm1.eps)
+            i = index[id(blk)]
+            h = autograd.gt_processor_block(h, sds[i], "b", attrs, plan, blk.num_heads, blk.activation,
+                                            blk.layer_norm1.eps, None if prepared is None else prepared[i])
         return h
 
     h = _cast(x, dtype)

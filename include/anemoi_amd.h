@@ -445,8 +445,9 @@ int anemoi_act_backward(int dtype, int act, const void* pre, int64_t ldp, const 
 /*
  * Training forward of Linear + activation: y = act(x W^T + b) and pre = x W^T + b (rounded to the activation dtype) from
  * ONE launch (the backward multiplies by act'(pre); nn.Linear + nn.GELU of layers/mlp.py:74-84, layers/block.py:504-508
- * under autograd).  bf16 only, M a multiple of 256, N >= 256, K >= 128 (multiple of 64), 16-byte aligned operands;
- * ANEMOI_ERR_UNSUPPORTED otherwise -- the caller then runs anemoi_linear followed by anemoi_act_forward.
+ * under autograd).  bf16 only, M = a multiple of 256 plus at most 8 rows (the mesh sizes 10 * 4^k + 2: the last rows are
+ * computed by the same launch), N >= 256, K >= 128 (multiple of 64), 16-byte aligned operands; ANEMOI_ERR_UNSUPPORTED
+ * otherwise -- the caller then runs anemoi_linear followed by anemoi_act_forward.
  */
 int anemoi_linear_dual(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* pre, int64_t ldp,
                        void* y, int64_t ldy, int64_t M, int N, int K, int act, anemoi_stream_t stream);
@@ -487,13 +488,16 @@ int anemoi_layer_norm_backward(int dtype, const void* x, int64_t ldx, const floa
  * (rowptr_t [n_src+1], eid_t [E] = position of the edge in the forward CSR, dst_t [E] = its destination; u / dt / du are
  * [n_dst, H*up] column ranges in the activation dtype, dst_of_edge [E] the destination of every CSR slot).  dsum is
  * accumulated in f32 over the edges, never rebuilt from the forward's rounded output.  No atomics.
+ * dxr (optional, [n_dst, lddxr]): _dst also leaves a copy of dout there -- the gradient of the self term x_r of
+ * out = sum alpha v + x_r -- so that a caller who keeps x_r | q | k | v | u in one matrix fills d x_r without a pass of its own.
  */
 int anemoi_gt_edge_attention_folded_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
                                                  int64_t ldkv, const void* dout, int64_t ldd, const void* u, int64_t ldu,
                                                  const void* dt, int64_t lddt, const float* lse, const float* edge_attr,
                                                  int up, const int32_t* rowptr, const int32_t* col, float* alpha,
                                                  float* w, float* dsum, void* dq, int64_t lddq, void* du, int64_t lddu,
-                                                 int64_t n_dst, int C, int H, anemoi_stream_t stream);
+                                                 void* dxr, int64_t lddxr, int64_t n_dst, int C, int H,
+                                                 anemoi_stream_t stream);
 int anemoi_gt_edge_attention_folded_backward_src(int dtype, const void* q, int64_t ldq, const void* dout, int64_t ldd,
                                                  const float* alpha, const float* w, const float* dsum,
                                                  const int32_t* rowptr_t, const int32_t* eid_t, const int32_t* dst_t,

@@ -36,6 +36,7 @@ def rows_from_csv(path):
 
 def main():
     path = sys.argv[1]
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 45  # rows printed (0: all)
     dbs = [path] if path.endswith(".db") else glob.glob(path + "/**/*_results.db", recursive=True)
     csvs = [path] if path.endswith(".csv") else glob.glob(path + "/**/*kernel_trace.csv", recursive=True)
     agg = defaultdict(lambda: [0, 0.0])
@@ -52,7 +53,7 @@ def main():
                 agg[k][1] += dur
     tot = sum(v[1] for v in agg.values())
     print(f"{'kernel':102s} {'blocks':>8s} {'vgpr':>5s} {'lds':>6s} {'n':>6s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}")
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[: top or None]:
         print(f"{k[0]:102s} {k[1]:8d} {k[2]:5d} {k[3]:6d} {v[0]:6d} {v[1]:12.1f} {v[1]/v[0]:10.1f} {100*v[1]/tot:6.2f}")
     print(f"total kernel time {tot/1e3:.3f} ms over {sum(v[0] for v in agg.values())} launches")
 
