@@ -664,10 +664,10 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
         # decoder: own grid rows as destinations, own + halo mesh rows as sources
         if gt_maps:
             hd = autograd.linear(x_data.index_select(0, sp.dec_dst_ids), dec.emb_nodes_dst.weight, dec.emb_nodes_dst.bias)
-            y_local = training._checkpoint(lambda a, c_: mapper_block(dec, a, c_, sp.dec), x_latent_proc, hd)
+            y_local = training._checkpoint(lambda a, c_: mapper_block(dec, a, c_, sp.dec), x_latent_proc, hd, last=True)
             y_local = training.sequential(dec.node_data_extractor, y_local).float()
         else:
-            y_local = training._checkpoint(gnn_decoder, x_latent_proc, x_dec_dst).float()
+            y_local = training._checkpoint(gnn_decoder, x_latent_proc, x_dec_dst, last=True).float()
         y = _GatherOutput.apply(y_local, sp, group, grid)
         return training._finish(model, y, x, 1, 1, grid)
 

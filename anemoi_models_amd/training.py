@@ -16,7 +16,8 @@ processor (bf16 head sizes 64 / 32: MFMA attention forward and backward; other c
 
 Activation checkpointing follows the reference: every mapper call and every processor chunk is wrapped in
 ``torch.utils.checkpoint`` (reference models/encoder_processor_decoder.py:159-166, layers/processor.py:73-77); all
-kernels are deterministic, so the recomputation reproduces the forward bit for bit.  ``ANEMOI_AMD_CHECKPOINT=0``
+kernels are deterministic, so the recomputation reproduces the forward bit for bit.  The decoder -- the last region, whose
+recomputation could free nothing at the memory peak -- keeps its activations (:func:`_checkpoint`).  ``ANEMOI_AMD_CHECKPOINT=0``
 keeps every activation instead (faster, config 3 then needs ~58 GiB per sample).
 """
 
@@ -44,8 +45,14 @@ def wants_grad(module: nn.Module, *tensors) -> bool:
     return any(p.requires_grad for p in module.parameters())
 
 
-def _checkpoint(fn, *args):
+def _checkpoint(fn, *args, last: bool = False):
+    """``last``: the region is the LAST one of the forward (the decoder).  Its recomputation would run at the very start of
+    the backward, while every other region's checkpoint is still held: it frees nothing at the peak and costs a second
+    decoder forward (13 ms of a 153 ms config-3 step) -- so it keeps its activations instead
+    (``ANEMOI_AMD_CHECKPOINT_LAST=1`` wraps it like the reference does, models/encoder_processor_decoder.py:223-231)."""
     if os.environ.get("ANEMOI_AMD_CHECKPOINT", "1") == "0":
+        return fn(*args)
+    if last and os.environ.get("ANEMOI_AMD_CHECKPOINT_LAST", "0") != "1":
         return fn(*args)
     dd = runtime.device_dropout()
     if dd is None:  # host-drawn dropout seeds: torch's checkpoint restores the CPU generator for the recomputation
@@ -452,7 +459,7 @@ def model_forward(model, x: Tensor) -> Tensor:
         else:
             x_proc = gnn_processor(model.processor, x_latent, rows, inv)
         x_latent_proc = x_proc + x_latent
-        out = _checkpoint(lambda a, c: run_mapper(model.decoder, a, c, inv, None), x_latent_proc, x_data_latent)
+        out = _checkpoint(lambda a, c: run_mapper(model.decoder, a, c, inv, None), x_latent_proc, x_data_latent, last=True)
         return _finish(model, out, x, b, ens, g)
 
 
@@ -469,8 +476,8 @@ def hierarchical_forward(model, x: Tensor) -> Tensor:
     def first(out):  # GraphTransformer backward mappers return the destination nodes; forward / GNN mappers (src, dst)
         return out[1] if isinstance(out, tuple) else out
 
-    def run(mapper, a, c):
-        return _checkpoint(lambda p, q: mapper((p, q), rows, None), a, c)
+    def run(mapper, a, c, last=False):
+        return _checkpoint(lambda p, q: mapper((p, q), rows, None), a, c, last=last)
 
     with torch.autocast(device_type=x.device.type, enabled=False):
         x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(rows * g, -1), _node_rows(model, data, rows)], dim=1).to(dtype)
@@ -489,5 +496,5 @@ def hierarchical_forward(model, x: Tensor) -> Tensor:
             curr = first(run(model.upscale[src], curr, x_encoded[dst])) + x_skip[dst]
             if model.level_process:
                 curr = model.up_level_processor[dst](curr, rows, None)
-        out = first(run(model.decoder, curr, x_data))
+        out = first(run(model.decoder, curr, x_data, last=True))
         return _finish(model, out, x, b, ens, g)
