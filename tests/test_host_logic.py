@@ -642,3 +642,65 @@ def test_edge_schedule_lists_cover_every_destination_once_and_balance_the_slots(
         assert float(load.max() / load.mean()) < 1.10 < 1.15 < float(rr.max() / rr.mean()), (load.max() / load.mean(), rr.max() / rr.mean())
     uniform = edge_schedule_lists(torch.full((1000,), 3), 125, 4)
     assert torch.equal(uniform[0, :, 0], torch.arange(125, dtype=torch.int32)) and int((uniform >= 0).sum()) == 1000
+
+
+def test_grad_sink_hands_out_the_stacked_gradient_without_a_copy():
+    """``autograd.GradSink`` / ``_Unstack`` (training route of a processor): when the gradient of block i's weight IS slot i of
+    the sink, the gradient of the stacked weight is the sink's buffer itself (no ``torch.stack``); anything else -- a missing
+    gradient, a tensor that lives elsewhere -- falls back to stacking, with the same values."""
+    from anemoi_models_amd import autograd
+
+    count, n, k = 3, 4, 5
+
+    class _FromSlot(torch.autograd.Function):  # stands for _Linear: its weight gradient is written into the sink's slot
+        @staticmethod
+        def forward(ctx, w, b, sink, i, elsewhere):
+            ctx.sink, ctx.i, ctx.elsewhere = sink, i, elsewhere
+            return (w.sum() + b.sum()).reshape(1)
+
+        @staticmethod
+        def backward(ctx, g):
+            slot = ctx.sink.slot(ctx.i)
+            slot[: n * k] = float(ctx.i + 1)
+            slot[n * k:] = float(-ctx.i - 1)
+            dw, db = slot[: n * k].view(n, k), slot[n * k:]
+            if ctx.elsewhere:
+                dw = dw.clone()
+            return dw, db, None, None, None
+
+    for elsewhere in (False, True):
+        w_leaf = torch.randn(count, n, k, requires_grad=True)
+        b_leaf = torch.randn(count, n, requires_grad=True)
+        w, b = w_leaf * 1.0, b_leaf * 1.0  # (the stacked operands are results of the fold algebra, not leaves)
+        seen = {}
+        w.register_hook(lambda g: seen.__setitem__("w", g))
+        b.register_hook(lambda g: seen.__setitem__("b", g))
+        sink = autograd.GradSink(count, n, k, True, "cpu", stacked_parts=2)
+        ws = autograd._Unstack.apply(w, sink, "w")
+        bs = autograd._Unstack.apply(b, sink, "b")
+        total = sum(_FromSlot.apply(ws[i], bs[i], sink, i, elsewhere and i == 1) for i in range(count))
+        buf_ptr = []
+        real_slot = sink.slot
+
+        def slot(i, _real=real_slot):
+            t = _real(i)
+            buf_ptr.append(sink.buf.data_ptr())
+            return t
+
+        sink.slot = slot
+        total.sum().backward()
+        want_w = torch.arange(1.0, count + 1)[:, None, None].expand(count, n, k)
+        want_b = -torch.arange(1.0, count + 1)[:, None].expand(count, n)
+        assert torch.equal(w_leaf.grad, want_w) and torch.equal(b_leaf.grad, want_b)
+        assert sink.buf is None or elsewhere  # handed over (both parts collected) -- or kept: the "w" part was stacked instead
+        assert seen["b"].data_ptr() == buf_ptr[0] + n * k * 4
+        if not elsewhere:  # zero-copy: the stacked gradient IS the sink's buffer
+            assert seen["w"].data_ptr() == buf_ptr[0] and seen["w"].stride() == (n * k + n, k, 1)
+        else:
+            assert seen["w"].data_ptr() != buf_ptr[0]
+    # a block without a gradient: zeros for it, the others stacked
+    w = torch.randn(count, n, k, requires_grad=True)
+    ws = autograd._Unstack.apply(w, None, "w")
+    (ws[0].sum() * 2.0 + ws[2].sum() * 3.0).backward()
+    assert torch.equal(w.grad[0], torch.full((n, k), 2.0)) and torch.equal(w.grad[1], torch.zeros(n, k))
+    assert torch.equal(w.grad[2], torch.full((n, k), 3.0))
