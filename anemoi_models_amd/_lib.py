@@ -57,6 +57,7 @@ class GtBlockArgs(ctypes.Structure):
         ("stats_ws", c_void_p), ("stats_ws_bytes", c_int64),
         ("run_ptr", c_void_p), ("run_perm", c_void_p), ("n_runs", c_int64),
         ("sched", c_void_p), ("sched_slots", ctypes.c_int32), ("sched_steps", ctypes.c_int32), ("n_src", c_int64),
+        ("run_dst", c_void_p),
     ]
 
 class TfmBlockArgs(ctypes.Structure):
@@ -106,6 +107,10 @@ SIGNATURES = {
                                                      c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                                      c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                                      c_int, c_void_p]),
+    "anemoi_gt_edge_attention_folded_groups": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                                       c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                                       c_void_p, c_int64, c_int, c_int, c_void_p]),
     "anemoi_edge_schedule_shape": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p]),
     "anemoi_gt_edge_attention_folded_sched": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                                       c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,

@@ -899,6 +899,220 @@ static void launch_folded_runs(const EdgeFoldParams& p, const int32_t* run_ptr, 
                      dim3(64 * WPB), 0, st, p, p.attr, run_ptr, p.col, perm, n_runs);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The uniform-degree-3 decoder in GROUPS (round 5): all destinations fed by the same three sources -- the grid points of
+// one mesh triangle, 5.4 on average at N320 -> ico-6, wherever they lie in the grid's own order -- are walked by ONE wave
+// behind ONE gather of the three k / v row slices.  The run kernel above only sees the neighbours that happen to be
+// consecutive in the grid order (mean 1.5 with its cap of two) and spends 3.75 of its 9.9 loads per destination and slice
+// on k / v; here it is 6 / (group length), and the launch is bound by the CU's texture-address unit (81 % busy, PMC).
+//   grp_ptr  [n_groups + 1]  group g = entries grp_ptr[g] .. grp_ptr[g + 1] - 1 (1 .. EDGE_MAX_GROUP of them) of
+//   grp_dst  [n_dst]         the destinations, every one exactly once, sorted by source triple (runtime.EdgePlan.groups3)
+//   grp_perm [n_dst]         6 bits per entry: the CSR position of the edge to the s-th source in ascending source order
+// The index chain (group bounds -> first destination -> its three sources; every destination's id and permutation) is
+// scalar and resolved one group / one destination ahead; the per-destination arithmetic is the run kernel's, operation for
+// operation (canonical source order, exact maximum, no online rescale): bit-identical results.
+// ---------------------------------------------------------------------------------------------
+constexpr int EDGE_MAX_GROUP = 8;
+template <typename T, int VEC, int LPH, int UP>
+__global__ __launch_bounds__(256) void gt_edge_attention_folded_groups3_kernel(const EdgeFoldParams p,
+                                                                           const float* __restrict__ attr_,
+                                                                           const int32_t* __restrict__ col_,
+                                                                           const int32_t* __restrict__ grp_ptr_,
+                                                                           const int32_t* __restrict__ grp_dst_,
+                                                                           const int32_t* __restrict__ grp_perm_,
+                                                                           int64_t n_groups) {
+  using Raw = typename RawVec<T, VEC>::type;
+  constexpr int APL = attrs_per_lane(UP, LPH);
+  static_assert(sizeof(Raw) == 16, "one 16-byte row slice per lane");
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  constexpr int VP = (VEC + 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wave_in_xcd = (int)(blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (int)(gridDim.x >> 3) * 4;
+  const int slice = wave_in_xcd % p.n_slices;
+  const int64_t g_first = wave_in_xcd / p.n_slices;
+  const int64_t g_stride = waves_per_xcd / p.n_slices;
+  const int64_t g0 = n_groups * xcd / 8, g1 = n_groups * (xcd + 1) / 8;
+
+  const int lanes_total = p.C / VEC;
+  const int gl = slice * 64 + lane;
+  const bool active = gl < lanes_total;
+  const int gls = active ? gl : 0;
+  const int c0 = gls * VEC;
+  const int head = gls / LPH;
+  const int a0 = (gls % LPH) * APL;
+  const bool a_own = a0 < UP;
+  const int a_ld = a_own ? a0 : 0;
+  const float amask = a_own ? 1.f : 0.f;
+
+  const int lane_off = c0 * (int)sizeof(T);
+  const int attr_off = a_ld * 4;
+  const uint32_t kv_row_bytes = (uint32_t)(p.ldkv * (int64_t)sizeof(T));
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.k), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.v), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(attr_), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.q), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.u), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xr), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, -1, 0x00020000);
+  const uint32_t q_row_bytes = (uint32_t)(p.ldq * (int64_t)sizeof(T)), u_row_bytes = (uint32_t)(p.ldu * (int64_t)sizeof(T));
+  const uint32_t xr_row_bytes = (uint32_t)(p.ldr * (int64_t)sizeof(T)), o_row_bytes = (uint32_t)(p.ldo * (int64_t)sizeof(T));
+  const int u_off = (head * UP + a_ld) * (int)sizeof(T);
+  const int t_off = (p.C + head * UP + a0) * (int)sizeof(T);
+
+  struct DstRegs {  // everything of one destination that travels through vector registers before its arithmetic
+    u32x4_t q, xr;
+    RawWords<T, APL> u;
+    float at[3][APL];
+  };
+  // node / pm are wave-uniform (scalar loads of grp_dst / grp_perm): row offsets go out as scalar soffsets
+  auto issue = [&](DstRegs& r, int node, int pm) __attribute__((always_inline)) {
+    r.q = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane_off, (int)((uint32_t)node * q_row_bytes), 2);
+    buffer_load_words<RawWords<T, APL>::W>(urs, u_off, (int)((uint32_t)node * u_row_bytes), r.u.w);
+    r.xr = u32x4_t{0u, 0u, 0u, 0u};
+    if (p.xr != nullptr) r.xr = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, (int)((uint32_t)node * xr_row_bytes), 2);
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+      buffer_load_f32<APL>(ars, attr_off, (int)((uint32_t)(3 * node + ((pm >> (2 * sl)) & 3)) * (uint32_t)(UP * 4)), r.at[sl]);
+  };
+
+  // scalar pipeline, one group ahead: bounds, the first TWO destinations with their permutations, the three source ids
+  auto group_head = [&](int64_t g, int& begin, int& len, int (&src)[3], int (&nd)[2], int (&pd)[2]) __attribute__((always_inline)) {
+    const int64_t gc = g < g1 ? g : g1 - 1;  // (past the end: a harmless repeat of the last group, never consumed)
+    begin = grp_ptr_[gc];
+    len = grp_ptr_[gc + 1] - begin;
+    const int second = begin + (len > 1 ? 1 : 0);
+    nd[0] = grp_dst_[begin];
+    pd[0] = grp_perm_[begin];
+    nd[1] = grp_dst_[second];
+    pd[1] = grp_perm_[second];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) src[sl] = col_[3 * nd[0] + ((pd[0] >> (2 * sl)) & 3)];
+  };
+  if (g0 + g_first >= g1) return;
+  int nb, nl, nsrc[3], nnd[2], npd[2];
+  group_head(g0 + g_first, nb, nl, nsrc, nnd, npd);
+
+  for (int64_t g = g0 + g_first; g < g1; g += g_stride) {
+    const int begin = nb, len = nl;
+    Raw kr[3], vr[3];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      const int row = (int)((uint32_t)nsrc[sl] * kv_row_bytes);
+      kr[sl] = __builtin_bit_cast(Raw, __builtin_amdgcn_raw_buffer_load_b128(krs, lane_off, row, 0));
+      vr[sl] = __builtin_bit_cast(Raw, __builtin_amdgcn_raw_buffer_load_b128(vrs, lane_off, row, 0));
+    }
+    int node = nnd[0], node_n = nnd[1], pm_n = npd[1];
+    DstRegs cur;
+    issue(cur, node, npd[0]);
+    group_head(g + g_stride, nb, nl, nsrc, nnd, npd);  // the next group's chain, behind this group's first loads
+
+    for (int d = 0; d < len; ++d) {
+      // The next destination of the group: its rows are requested before this one's arithmetic (its id and permutation were
+      // fetched one iteration earlier; the ones of the destination after it leave now).  The last destination of a group
+      // requests nothing: the next group's k / v gathers come first.
+      const bool more = d + 1 < len;
+      const int third = begin + (d + 2 < len ? d + 2 : d);
+      const int node_nn = grp_dst_[third], pm_nn = grp_perm_[third];
+      DstRegs nxt = cur;
+      if (more) issue(nxt, node_n, pm_n);
+
+      QK<T, VEC> qk;
+      {
+        const uint32_t qw[4] = {cur.q.x, cur.q.y, cur.q.z, cur.q.w};
+        qk.set_raw(qw);
+      }
+      float u[APL];
+      cur.u.get(u);
+      float sc[3];
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        float t = qk.dot(kr[sl]);
+#pragma unroll
+        for (int a = 0; a < APL; ++a) t = fmaf(u[a] * amask, cur.at[sl][a], t);
+        sc[sl] = group_sum<LPH>(t) * p.scale;
+      }
+      const float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+      float l = 0.f;
+      f32x2_t acc[VP];
+      float tacc[APL];
+#pragma unroll
+      for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const float pe = __expf(sc[sl] - m);
+        l += pe;
+        float vv[VEC];
+        unpack<T, VEC>(vr[sl], vv);
+#pragma unroll
+        for (int i = 0; i < VP; ++i)
+          acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], 2 * i + 1 < VEC ? vv[2 * i + 1] : 0.f}, acc[i]);
+#pragma unroll
+        for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, cur.at[sl][a], tacc[a]);
+      }
+      const float inv = 1.0f / (l + 1e-16f);
+      float o[VEC];
+      {
+        // (acc * inv) + x_r as TWO roundings, like the run kernel (whose + x_r sits behind a branch)
+#pragma clang fp contract(off)
+        RawWords<T, VEC> xw;
+        xw.w[0] = cur.xr.x; xw.w[1] = cur.xr.y; xw.w[2] = cur.xr.z; xw.w[3] = cur.xr.w;
+        float r[VEC];
+        xw.get(r);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float scaled = acc[i >> 1][i & 1] * inv;
+          o[i] = p.xr != nullptr ? scaled + r[i] : scaled;
+        }
+      }
+      const int out_row = (int)((uint32_t)node * o_row_bytes);
+      if (active) {
+        uint32_t ow[4];
+        pack_words<T, VEC>(o, ow);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ow[0], ow[1], ow[2], ow[3]}, ors, lane_off, out_row, 2);
+        __builtin_amdgcn_sched_barrier(0);  // (store-data hazard with an SGPR soffset: see the scheduled kernel)
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (active && a_own) {
+        float t4[APL];
+#pragma unroll
+        for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+        uint32_t tw[RawWords<T, APL>::W];
+        pack_words<T, APL>(t4, tw);
+        buffer_store_words<RawWords<T, APL>::W>(ors, t_off, out_row, tw);
+      }
+      if (p.lse != nullptr && active && (gls % LPH) == 0) p.lse[(int64_t)node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);
+      cur = nxt;
+      node = node_n;
+      node_n = node_nn;
+      pm_n = pm_nn;
+    }
+  }
+}
+
+template <typename T, int VEC, int LPH, int UP>
+static void launch_folded_groups3(const EdgeFoldParams& p, const int32_t* grp_ptr, const int32_t* grp_dst,
+                                  const int32_t* grp_perm, int64_t n_groups, hipStream_t st) {
+  static const int wgs_env = getenv("ANEMOI_AMD_EDGE_GROUP_WGS") ? atoi(getenv("ANEMOI_AMD_EDGE_GROUP_WGS")) : 0;  // lab switch
+  constexpr int WPB = 4;
+  // (N320 -> ico-6 decoder launch, 3 / 4 / 5 / 6 workgroups per CU: 0.826 / 0.833 / 0.838 / 0.888 ms -- the launch moves 3.8 GB
+  //  of x_r | q | u rows in and out | t rows out, 4.6 TB/s: more waves only contend)
+  const int wgs_per_cu = wgs_env > 0 ? wgs_env : 3;
+  const int64_t units_per_xcd = ((n_groups + 7) / 8) * p.n_slices;
+  int64_t bpx = (units_per_xcd + WPB - 1) / WPB;
+  if (bpx > 32 * wgs_per_cu) bpx = 32 * wgs_per_cu;
+  if (bpx < 1) bpx = 1;
+  while ((bpx * WPB) % p.n_slices != 0) ++bpx;
+  hipLaunchKernelGGL((gt_edge_attention_folded_groups3_kernel<T, VEC, LPH, UP>), dim3((unsigned)(8 * bpx)), dim3(64 * WPB), 0,
+                     st, p, p.attr, p.col, grp_ptr, grp_dst, grp_perm, n_groups);
+}
+
 template <typename T, int VEC, int LPH>
 static bool dispatch_folded_up(const EdgeFoldParams& p, int up, hipStream_t st) {
   switch (up) {
@@ -1288,6 +1502,63 @@ extern "C" int anemoi_edge_schedule_shape(int dtype, int64_t n_dst, int C, int* 
   const int vec = dtype == ANEMOI_BF16 ? 8 : 4;
   sched_shape(n_dst, (C + 64 * vec - 1) / (64 * vec), slots, steps);
   return ANEMOI_OK;
+}
+
+// The uniform-degree-3 decoder in groups of destinations that share their three sources (gt_edge_attention_folded_groups3_kernel
+// above): same arguments and result as anemoi_gt_edge_attention_folded_runs with the group lists in place of the run lists
+// (rowptr[d] = 3 d is the caller's contract; groups of 1 .. 8 destinations, every destination exactly once).  Shapes the kernel
+// does not cover (f32, other head sizes, matrices of 4 GiB and more) take the plain kernel.
+extern "C" int anemoi_gt_edge_attention_folded_groups(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                                                      int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
+                                                      const float* edge_attr, int up, const int32_t* rowptr,
+                                                      const int32_t* col, const int32_t* grp_ptr, const int32_t* grp_dst,
+                                                      const int32_t* grp_perm, int64_t n_groups, int64_t n_src, void* out,
+                                                      int64_t ldo, float* lse, int64_t n_dst, int C, int H,
+                                                      anemoi_stream_t stream) {
+  const int64_t gib4 = (int64_t)1 << 32;
+  const bool small = n_dst * ldq * 2 < gib4 && n_dst * ldu * 2 < gib4 && n_dst * ldo * 2 < gib4 && n_src * ldkv * 2 < gib4 &&
+                     (x_r == nullptr || n_dst * ldr * 2 < gib4) && 3 * n_dst * (int64_t)up * 4 < gib4;
+  const bool plain = grp_ptr == nullptr || grp_dst == nullptr || grp_perm == nullptr || n_groups <= 0 || dtype != ANEMOI_BF16 ||
+                     H <= 0 || C % H != 0 || !((C / H) == 64 || (C / H) == 32) ||
+                     !(up == 4 || up == 8 || up == 12 || up == 16) || n_dst == 0 || !small;
+  if (plain)
+    return anemoi_gt_edge_attention_folded(dtype, q, ldq, k, v, ldkv, x_r, ldr, u, ldu, edge_attr, up, rowptr, col, out, ldo,
+                                           lse, n_dst, C, H, stream);
+  const char* who = "anemoi_gt_edge_attention_folded_groups";
+  ANEMOI_REQUIRE(q && k && v && u && out && col && edge_attr, ANEMOI_ERR_INVALID, "%s: null pointer", who);
+  ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
+                     (x_r == nullptr || ldr >= C) && n_groups <= n_dst && EDGE_MAX_GROUP * n_groups >= n_dst && n_src > 0,
+                 ANEMOI_ERR_INVALID,
+                 "%s: leading dimension too small, or %lld groups cannot cover %lld destinations with groups of 1 .. %d", who,
+                 (long long)n_groups, (long long)n_dst, EDGE_MAX_GROUP);
+  const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                       ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                       (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % 8 == 0)) && ldq % 8 == 0 && ldkv % 8 == 0 &&
+                       ldu % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)edge_attr % 16 == 0) && C % 8 == 0;
+  ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED, "%s: operands must be 16-byte aligned", who);
+  EdgeFoldParams p;
+  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out; p.lse = lse;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
+  p.attr = edge_attr; p.rowptr = rowptr; p.col = col;
+  p.n_dst = n_dst; p.C = C; p.D = C / H;
+  p.n_slices = (C + 511) / 512;
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  p.stream_hint = 1;
+  hipStream_t st = as_stream(stream);
+#define ANEMOI_GROUPS_UP(LPH)                                                                                       \
+  switch (up) {                                                                                                     \
+    case 4: launch_folded_groups3<bf16_t, 8, LPH, 4>(p, grp_ptr, grp_dst, grp_perm, n_groups, st); break;           \
+    case 8: launch_folded_groups3<bf16_t, 8, LPH, 8>(p, grp_ptr, grp_dst, grp_perm, n_groups, st); break;           \
+    case 12: launch_folded_groups3<bf16_t, 8, LPH, 12>(p, grp_ptr, grp_dst, grp_perm, n_groups, st); break;         \
+    default: launch_folded_groups3<bf16_t, 8, LPH, 16>(p, grp_ptr, grp_dst, grp_perm, n_groups, st); break;         \
+  }
+  if (C / H == 64) {
+    ANEMOI_GROUPS_UP(8)
+  } else {
+    ANEMOI_GROUPS_UP(4)
+  }
+#undef ANEMOI_GROUPS_UP
+  return check_launch(who);
 }
 
 // anemoi_gt_edge_attention_folded with a destination schedule (gt_edge_attention_folded_sched_kernel above): the same

@@ -66,7 +66,8 @@ def edge_schedule(plan, q: Tensor):
 
 
 def edge_runs(plan, dtype):
-    """The run lists of a uniform-degree-3 plan for the bf16 run kernel (``EdgePlan.runs3``), else ``None``."""
+    """The group (or run) lists of a uniform-degree-3 plan for the bf16 kernels that share source gathers between
+    destinations (``EdgePlan.runs3``), else ``None``."""
     if dtype != torch.bfloat16 or not hasattr(plan, "runs3") or os.environ.get("ANEMOI_AMD_EDGE_RUNS", "1") == "0":
         return None
     return plan.runs3()
@@ -394,6 +395,8 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
         runs = edge_runs(plan, dtype)
         if runs is not None:
             a.run_ptr, a.run_perm, a.n_runs = runs[0].data_ptr(), runs[1].data_ptr(), runs[0].shape[0] - 1
+            if len(runs) == 3:  # groups: the destination list, and the row count of k / v for the 4-GiB check
+                a.run_dst, a.n_src = runs[2].data_ptr(), k.shape[0]
         elif edge_attr_csr.shape[0] * up * 4 < 2**32:
             sched = edge_schedule(plan, q)
             if sched is not None:

@@ -283,8 +283,9 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     ``u`` is ``[n_dst, H*up]`` (extra columns of the q/k/v GEMM), ``edge_attr`` ``[E, up]`` f32 in CSR order with the
     constant-1 column.  Columns beyond ``C + H*up`` (K padding for the projection GEMM) are zero filled.  ``lse``
     (optional f32 ``[n_dst, H]``, contiguous) receives the softmax normaliser per destination and head (training).
-    ``runs = (run_ptr, perm)`` (``EdgePlan.runs3()``, uniform-degree-3 graphs): destinations that share their three sources
-    share one gather of them (``anemoi_gt_edge_attention_folded_runs``).  ``sched`` (``EdgePlan.schedule()``: int32
+    ``runs`` (``EdgePlan.runs3()``, uniform-degree-3 graphs): destinations that share their three sources share one gather
+    of them -- ``(grp_ptr, grp_perm, grp_dst)``: all destinations of a source triple (``anemoi_gt_edge_attention_folded_groups``),
+    ``(run_ptr, perm)``: the consecutive ones (``anemoi_gt_edge_attention_folded_runs``).  ``sched`` (``EdgePlan.schedule()``: int32
     ``[8, slots, steps]``): the destination schedule of ``anemoi_gt_edge_attention_folded_sched`` -- balanced wave slots, index
     chain resolved one destination ahead; bit-identical to the plain kernel.  ``runs`` wins when both are given.
     """
@@ -314,7 +315,20 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     #  not count: reported beside the roofline fraction, never instead of it)
     fused_bytes = alg_bytes + n_dst * ((0 if x_r is None else c) + 2 * num_heads * up) * q.element_size()
     with _Timed("gt_edge_attention", bytes=alg_bytes, fused_bytes=fused_bytes, n_dst=n_dst, n_src=k.shape[0], edges=col.shape[0]):
-        if runs is not None:
+        if runs is not None and len(runs) == 3:  # groups of destinations that share their three sources
+            grp_ptr, grp_perm, grp_dst = runs
+            _dev(grp_ptr, grp_perm, grp_dst)
+            if (grp_ptr.dtype != torch.int32 or grp_perm.dtype != torch.int32 or grp_dst.dtype != torch.int32
+                    or grp_perm.shape[0] != n_dst or grp_dst.shape[0] != n_dst):
+                raise ValueError("gt_edge_attention_folded: runs = (int32 grp_ptr [n_groups + 1], int32 grp_perm [n_dst], "
+                                 "int32 grp_dst [n_dst])")
+            st = _lib.load().anemoi_gt_edge_attention_folded_groups(
+                dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
+                0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
+                rowptr.data_ptr(), col.data_ptr(), grp_ptr.data_ptr(), grp_dst.data_ptr(), grp_perm.data_ptr(),
+                grp_ptr.shape[0] - 1, _rows(k).shape[0], out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads,
+                _stream())
+        elif runs is not None:
             run_ptr, perm = runs
             _dev(run_ptr, perm)
             if run_ptr.dtype != torch.int32 or perm.dtype != torch.int32 or perm.shape[0] != run_ptr.shape[0] - 1:

@@ -69,10 +69,19 @@ class EdgePlan:
         return int(self.col.shape[0])
 
     def runs3(self):
-        """``(run_ptr, perm)`` of :func:`_runs3` (cached on the plan), or ``None`` for any other graph."""
+        """The shared-source lists of a uniform-degree-3 graph for the edge kernel (cached on the plan), or ``None`` for any
+        other graph: the GROUPS ``(grp_ptr, grp_perm, grp_dst)`` of :func:`_groups3` (all destinations of a source triple,
+        ``anemoi_gt_edge_attention_folded_groups``), or -- with ``ANEMOI_AMD_EDGE_GROUPS=0`` -- the consecutive RUNS
+        ``(run_ptr, perm)`` of :func:`_runs3`."""
         r = getattr(self, "_runs3_cache", 0)
         if r == 0:
-            r = self._runs3_cache = _runs3(self) if self.col.is_cuda else None
+            r = None
+            if self.col.is_cuda:
+                if os.environ.get("ANEMOI_AMD_EDGE_GROUPS", "1") != "0":
+                    r = _groups3(self)
+                if r is None:
+                    r = _runs3(self)
+            self._runs3_cache = r
         return r
 
     def schedule(self, dtype: torch.dtype, channels: int):
@@ -186,6 +195,41 @@ def _runs3(plan: "EdgePlan", max_run: int = 2):
         has = lens > d
         packed[has] |= perm[(begin + d)[has]] << (6 * d)
     return run_ptr.to(torch.int32).contiguous(), packed.to(torch.int32).contiguous()
+
+
+def _groups3(plan: "EdgePlan", max_group: int = 8):
+    """Groups of destinations with the same three sources, wherever they lie in the destination order, for
+    ``anemoi_gt_edge_attention_folded_groups``: ``(grp_ptr int32 [n_groups + 1], grp_perm int32 [n_dst], grp_dst int32
+    [n_dst])`` under the conditions of :func:`_runs3` (exactly three in-edges from three different sources per destination),
+    else ``None`` -- also when the groups are too short to pay (mean below 1.5).  ``grp_dst`` lists every destination once,
+    sorted by (ascending) source triple and, inside a triple, by destination; a triple's destinations are cut into groups of
+    at most ``max_group`` (the kernel's ``EDGE_MAX_GROUP``).  ``grp_perm[i]``: 6 bits, for s = 0 .. 2 the position inside the
+    CSR segment of ``grp_dst[i]`` of its edge to the s-th source in ascending source order.  Built on the plan's device."""
+    n, e = plan.n_dst, plan.num_edges
+    if n < 1024 or e != 3 * n or plan.n_src >= 2**21:  # (the triple is packed into one 63-bit key)
+        return None
+    rowptr = plan.rowptr
+    if not bool((rowptr == torch.arange(0, 3 * n + 1, 3, dtype=rowptr.dtype, device=rowptr.device)).all()):
+        return None
+    src = plan.col.view(n, 3).long()
+    srt, pos = torch.sort(src, dim=1, stable=True)
+    if bool((srt[:, 1:] == srt[:, :-1]).any()):
+        return None
+    perm = pos[:, 0] | (pos[:, 1] << 2) | (pos[:, 2] << 4)
+    key = (srt[:, 0] * plan.n_src + srt[:, 1]) * plan.n_src + srt[:, 2]
+    order = torch.argsort(key, stable=True)
+    sk = key[order]
+    start = torch.ones(n, dtype=torch.bool, device=src.device)
+    start[1:] = sk[1:] != sk[:-1]
+    idx = torch.arange(n, device=src.device)
+    first = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
+    start |= ((idx - first) % max_group) == 0
+    begin = torch.nonzero(start).flatten()
+    if n < 1.5 * begin.shape[0]:
+        return None
+    grp_ptr = torch.cat([begin, torch.tensor([n], device=src.device)])
+    return (grp_ptr.to(torch.int32).contiguous(), perm[order].to(torch.int32).contiguous(),
+            order.to(torch.int32).contiguous())
 
 
 def build_edge_plan(edge_index: Tensor, n_src: int, n_dst: int) -> EdgePlan:

@@ -186,6 +186,24 @@ int anemoi_gt_edge_attention_folded_runs(int dtype, const void* q, int64_t ldq, 
                                          int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
+ * The same launch on GROUPS: every destination fed by the same three sources -- the grid points of one mesh triangle, wherever
+ * they lie in the grid's own order (5.4 per triangle at N320 -> ico-6, against runs of 1.5 consecutive ones) -- is walked
+ * by one wave behind one gather of the three k / v row slices:
+ *   grp_ptr  int32 [n_groups + 1]  group g = entries grp_ptr[g] .. grp_ptr[g + 1] - 1 (1 .. 8 of them) of
+ *   grp_dst  int32 [n_dst]         the destinations, each exactly once (sorted by source triple)
+ *   grp_perm int32 [n_dst]         per entry, bits 2 s .. 2 s + 1 = CSR position of its edge to the s-th source, ascending
+ * n_src = rows of k / v.  Results equal anemoi_gt_edge_attention_folded_runs bit for bit (same per-destination arithmetic).
+ * bf16, head size 64 / 32, every matrix below 4 GiB; anything else, or grp_ptr == NULL, runs the plain kernel.
+ * anemoi_models_amd/runtime.py::EdgePlan.runs3 builds the lists (reference layers/mapper.py:348-418 on 3-NN decoder edges).
+ */
+int anemoi_gt_edge_attention_folded_groups(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                           const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
+                                           int up, const int32_t* rowptr, const int32_t* col, const int32_t* grp_ptr,
+                                           const int32_t* grp_dst, const int32_t* grp_perm, int64_t n_groups, int64_t n_src,
+                                           void* out, int64_t ldo, float* lse, int64_t n_dst, int C, int H,
+                                           anemoi_stream_t stream);
+
+/*
  * anemoi_gt_edge_attention_folded with a DESTINATION SCHEDULE (round 5): the same result bit for bit -- same arithmetic,
  * same per-destination summation order -- from a launch in which
  *   - a host-built static schedule names the destinations every wave slot walks.  At any step the slots of an XCD work on
@@ -553,6 +571,9 @@ typedef struct anemoi_gt_block_args {
   const int32_t* run_ptr; const int32_t* run_perm; int64_t n_runs;
   /* optional (NULL: none; ignored when runs are given): the destination schedule of anemoi_gt_edge_attention_folded_sched */
   const int32_t* sched; int32_t sched_slots, sched_steps; int64_t n_src;
+  /* optional (NULL: run_ptr / run_perm are the consecutive runs above): run_ptr / run_perm / run_dst are the GROUP lists of
+   * anemoi_gt_edge_attention_folded_groups (groups of 1 .. 8 destinations out of run_dst, run_perm per destination; n_src set) */
+  const int32_t* run_dst;
 } anemoi_gt_block_args;
 int anemoi_gt_block_tail(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* args, anemoi_stream_t stream);

@@ -397,8 +397,10 @@ def test_gt_edge_attention_folded_runs_of_shared_sources(c, h, xr):
     src = torch.gather(tri, 1, order).reshape(-1)
     dst = torch.arange(n).repeat_interleave(3)
     plan = runtime.build_edge_plan(torch.stack([src, dst]).to(DEV), n_src, n)
-    runs = plan.runs3()
-    assert runs is not None and runs[0].shape[0] - 1 < 0.72 * n
+    runs = plan.runs3()  # the GROUPS of a source triple (round 5); the consecutive runs below
+    assert runs is not None and len(runs) == 3 and runs[0].shape[0] - 1 < 0.72 * n
+    runs2 = runtime._runs3(plan)
+    assert runs2 is not None and len(runs2) == 2
     q = (torch.randn(n, c, generator=g) * 0.5).bfloat16().to(DEV)
     kv = (torch.randn(n_src, 2 * c, generator=g) * 0.5).bfloat16().to(DEV)
     x_r = torch.randn(n, c, generator=g).bfloat16().to(DEV) if xr else None
@@ -412,6 +414,11 @@ def test_gt_edge_attention_folded_runs_of_shared_sources(c, h, xr):
                                        runs=runs)
     assert rel_err(got, plain) < 8e-3 and float((got != plain).float().mean()) < 0.2  # bf16 ties only
     assert rel_err(lse_b, lse_a) < 1e-5
+    # the group kernel and the run kernel: the same per-destination arithmetic in the same (canonical) order -- the same bits
+    lse_c = torch.empty(n, h, device=DEV)
+    got2 = ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], x_r, u, attr, plan.rowptr, plan.col, h, up, lse=lse_c,
+                                        runs=runs2)
+    assert torch.equal(got, got2) and torch.equal(lse_b, lse_c)
     for _ in range(3):
         assert torch.equal(ops.gt_edge_attention_folded(q, kv[:, :c], kv[:, c:], x_r, u, attr, plan.rowptr, plan.col, h, up,
                                                         runs=runs), got)

@@ -608,6 +608,49 @@ def test_runs_of_destinations_sharing_three_sources():
     assert runtime._runs3(runtime.build_edge_plan(torch.stack([dup.reshape(-1), dst]), n_src, n)) is None
 
 
+def test_groups_of_destinations_sharing_three_sources():
+    """runtime._groups3: every destination exactly once, sorted by source triple, a triple's destinations cut into groups of at
+    most 8 wherever they lie in the destination order; the per-destination permutation maps ascending source order back to
+    CSR positions; graphs that are not uniformly of degree three (or too short-grouped to pay) give None."""
+    from anemoi_models_amd import runtime
+
+    g = torch.Generator().manual_seed(5)
+    n, n_src, n_tri = 4000, 700, 400
+    base = torch.randint(0, n_src - 40, (n_tri,), generator=g)
+    tri_of = torch.randint(0, n_tri, (n,), generator=g)  # ~10 destinations per triangle, scattered over the order
+    tri_of[:30] = 7                                      # one triangle with > 8 + 8 destinations
+    tri = torch.stack([base, base + 7, base + 31], 1)[tri_of]
+    order = torch.stack([torch.randperm(3, generator=g) for _ in range(n)])
+    src = torch.gather(tri, 1, order).reshape(-1)
+    dst = torch.arange(n).repeat_interleave(3)
+    shuffle = torch.randperm(3 * n, generator=g)
+    plan = runtime.build_edge_plan(torch.stack([src[shuffle], dst[shuffle]]), n_src, n)
+    grp_ptr, grp_perm, grp_dst = runtime._groups3(plan)
+    assert grp_ptr.dtype == grp_perm.dtype == grp_dst.dtype == torch.int32
+    assert grp_perm.shape == (n,) and torch.equal(torch.sort(grp_dst.long()).values, torch.arange(n))
+    assert grp_ptr[0] == 0 and grp_ptr[-1] == n
+    lens = grp_ptr[1:] - grp_ptr[:-1]
+    assert int(lens.min()) >= 1 and int(lens.max()) <= 8 and n / lens.shape[0] > 4
+    col = plan.col.view(n, 3).long()
+    key = [tuple(sorted(col[d].tolist())) for d in range(n)]
+    seen = []
+    for r in range(grp_ptr.shape[0] - 1):
+        ds = grp_dst[int(grp_ptr[r]):int(grp_ptr[r + 1])].tolist()
+        assert len({key[d] for d in ds}) == 1 and ds == sorted(ds)
+        seen.append(key[ds[0]])
+    assert seen == sorted(seen)  # groups in ascending triple order; a triple's groups adjacent ...
+    for a, b, la in zip(seen[:-1], seen[1:], lens[:-1].tolist()):
+        assert a != b or la == 8  # ... and only a full group is followed by another one of the same triple
+    for i in range(0, n, 13):
+        d = int(grp_dst[i])
+        pos = [(int(grp_perm[i]) >> (2 * s)) & 3 for s in range(3)]
+        assert sorted(pos) == [0, 1, 2] and [int(col[d, q]) for q in pos] == sorted(col[d].tolist())
+    assert runtime._groups3(runtime.build_edge_plan(torch.stack([src[:-3], dst[:-3]]), n_src, n)) is None
+    i = torch.arange(n)
+    lone = torch.stack([i % 690, 690 + i // 690, torch.full((n,), 699)], 1)  # every destination its own triple
+    assert runtime._groups3(runtime.build_edge_plan(torch.stack([lone.reshape(-1), dst]), n_src, n)) is None
+
+
 def test_edge_schedule_lists_cover_every_destination_once_and_balance_the_slots():
     """Host logic of the scheduled edge kernel (runtime.edge_schedule_lists): per XCD every destination of its range exactly
     once, at step i the i-th group of `slots` consecutive destinations (the L2 window of the round-robin kernel), lists end
