@@ -836,6 +836,38 @@ def _params_cast_and_transpose(params, dtype: torch.dtype):
     return w, wt
 
 
+def _gt_stacked_fold(sds: list, prefix: str, c: int, h: int, up: int, device):
+    """``(w_in [L, 4C + H*up, C], b_in [L, 4C + H*up], w_p [L, C, C + H*up])`` in f32 for the L blocks ``sds``: per block the
+    rows ``lin_self | lin_query | lin_key | lin_value | W_u`` (+ biases, ``b_u`` last) and the columns ``projection | W_t`` with
+    ``(W_u, b_u, W_t)`` the lin_edge fold of :func:`_lin_edge_fold` -- the same values, from three batched einsums and three
+    concatenations for all blocks (plain torch on the parameters: autograd carries the gradients back)."""
+    count = len(sds)
+    key = lambda sd, n, part: sd[f"{prefix}.{n}.{part}"]  # noqa: E731
+    col = lambda n, part: [key(sd, n, part) for sd in sds]  # noqa: E731
+    d = c // h
+    we, be = torch.stack(col("lin_edge", "weight")), torch.stack(col("lin_edge", "bias"))
+    edge_dim = we.shape[2]
+    pad = torch.zeros((count, c, up - edge_dim - 1), dtype=torch.float32, device=device)
+    weh = torch.cat([we, be[:, :, None], pad], dim=2).view(count, h, d, up)
+    wq, bq = torch.stack(col("lin_query", "weight")), torch.stack(col("lin_query", "bias"))
+    wp = torch.stack(col("projection", "weight"))
+    w_u = torch.einsum("lhda,lhdc->lhac", weh, wq.view(count, h, d, c)).reshape(count, h * up, c)
+    b_u = torch.einsum("lhda,lhd->lha", weh, bq.view(count, h, d)).reshape(count, h * up)
+    w_t = torch.einsum("lohd,lhda->loha", wp.view(count, c, h, d), weh).reshape(count, c, h * up)
+    n_in = 4 * c + h * up
+    rows, vecs = [], []
+    w_u_i, b_u_i = w_u.unbind(0), b_u.unbind(0)  # (unbind: ONE backward node that stacks the L gradients)
+    for i, sd in enumerate(sds):  # one cat over 5 L matrices: block i's rows are x_r | q | k | v | u
+        rows += [key(sd, "lin_self", "weight"), key(sd, "lin_query", "weight"), key(sd, "lin_key", "weight"),
+                 key(sd, "lin_value", "weight"), w_u_i[i]]
+        vecs += [key(sd, "lin_self", "bias"), key(sd, "lin_query", "bias"), key(sd, "lin_key", "bias"),
+                 key(sd, "lin_value", "bias"), b_u_i[i]]
+    w_in = torch.cat(rows, dim=0).view(count, n_in, c)
+    b_in = torch.cat(vecs, dim=0).view(count, n_in)
+    w_p = torch.cat([wp, w_t], dim=2)  # [L, C, C + H * up]
+    return w_in, b_in, w_p
+
+
 def gt_processor_weights(sds: list, prefix: str, c: int, h: int, up: int, dtype: torch.dtype, device):
     """Everything the blocks of a GraphTransformer processor derive from their PARAMETERS, for all blocks at once: the
     lin_edge fold (three batched einsums instead of three per block), ``x_r|q|k|v|u`` / ``projection|t`` weight assembly,
@@ -862,27 +894,8 @@ def gt_processor_weights(sds: list, prefix: str, c: int, h: int, up: int, dtype:
     if hidden % km != 0 or key(sds[0], "node_dst_mlp.3", "weight").shape != (c, hidden):
         return None
     col = lambda n, part: [key(sd, n, part) for sd in sds]  # noqa: E731
-    d = c // h
-    we, be = torch.stack(col("lin_edge", "weight")), torch.stack(col("lin_edge", "bias"))
-    edge_dim = we.shape[2]
-    pad = torch.zeros((count, c, up - edge_dim - 1), dtype=torch.float32, device=device)
-    weh = torch.cat([we, be[:, :, None], pad], dim=2).view(count, h, d, up)
-    wq, bq = torch.stack(col("lin_query", "weight")), torch.stack(col("lin_query", "bias"))
-    wp = torch.stack(col("projection", "weight"))
-    w_u = torch.einsum("lhda,lhdc->lhac", weh, wq.view(count, h, d, c)).reshape(count, h * up, c)
-    b_u = torch.einsum("lhda,lhd->lha", weh, bq.view(count, h, d)).reshape(count, h * up)
-    w_t = torch.einsum("lohd,lhda->loha", wp.view(count, c, h, d), weh).reshape(count, c, h * up)
+    w_in, b_in, w_p = _gt_stacked_fold(sds, prefix, c, h, up, device)
     n_in = 4 * c + h * up
-    rows, vecs = [], []
-    w_u_i, b_u_i = w_u.unbind(0), b_u.unbind(0)  # (unbind: ONE backward node that stacks the L gradients)
-    for i, sd in enumerate(sds):  # one cat over 5 L matrices: block i's rows are x_r | q | k | v | u
-        rows += [key(sd, "lin_self", "weight"), key(sd, "lin_query", "weight"), key(sd, "lin_key", "weight"),
-                 key(sd, "lin_value", "weight"), w_u_i[i]]
-        vecs += [key(sd, "lin_self", "bias"), key(sd, "lin_query", "bias"), key(sd, "lin_key", "bias"),
-                 key(sd, "lin_value", "bias"), b_u_i[i]]
-    w_in = torch.cat(rows, dim=0).view(count, n_in, c)
-    b_in = torch.cat(vecs, dim=0).view(count, n_in)
-    w_p = torch.cat([wp, w_t], dim=2)  # [L, C, C + H * up]
     sink_in = GradSink(count, n_in, c, True, device, stacked_parts=2)
     sink_p = GradSink(count, c, c + h * up, True, device, stacked_parts=1)  # (the projection's bias is a leaf: its slot goes to it)
     w_in_c, w_in_t = _stacked_cast_and_transpose(w_in, dtype)

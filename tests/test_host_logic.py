@@ -747,3 +747,47 @@ def test_grad_sink_hands_out_the_stacked_gradient_without_a_copy():
     (ws[0].sum() * 2.0 + ws[2].sum() * 3.0).backward()
     assert torch.equal(w.grad[0], torch.full((n, k), 2.0)) and torch.equal(w.grad[1], torch.zeros(n, k))
     assert torch.equal(w.grad[2], torch.full((n, k), 3.0))
+
+
+def test_stacked_fold_of_a_processor_equals_the_per_block_fold():
+    """``autograd._gt_stacked_fold`` (the lin_edge fold and the ``x_r|q|k|v|u`` / ``projection|t`` weight assembly of ALL blocks
+    of a processor from three batched einsums, training route) against the per-block algebra it replaces
+    (``autograd._lin_edge_fold`` + the concatenations of ``gt_processor_block``): same matrices, and the same gradients for
+    every parameter under a random cotangent."""
+    from anemoi_models_amd import autograd
+
+    c, h, edge_dim, up, count = 64, 8, 3, 4, 3
+    g = torch.Generator().manual_seed(9)
+
+    def block():
+        names = {"lin_self": (c, c), "lin_query": (c, c), "lin_key": (c, c), "lin_value": (c, c), "lin_edge": (c, edge_dim),
+                 "projection": (c, c)}
+        sd = {}
+        for n, shape in names.items():
+            sd[f"b.{n}.weight"] = torch.randn(*shape, generator=g).requires_grad_()
+            sd[f"b.{n}.bias"] = torch.randn(shape[0], generator=g).requires_grad_()
+        return sd
+
+    sds = [block() for _ in range(count)]
+    w_in, b_in, w_p = autograd._gt_stacked_fold(sds, "b", c, h, up, "cpu")
+    assert w_in.shape == (count, 4 * c + h * up, c) and b_in.shape == (count, 4 * c + h * up) and w_p.shape == (count, c, c + h * up)
+    cot = [torch.randn(t.shape, generator=g) for t in (w_in, b_in, w_p)]
+    (w_in * cot[0]).sum().add((b_in * cot[1]).sum()).add((w_p * cot[2]).sum()).backward()
+    got = [{k: v.grad.clone() for k, v in sd.items() if v.grad is not None} for sd in sds]
+    for sd in sds:
+        for v in sd.values():
+            v.grad = None
+    for i, sd in enumerate(sds):
+        w_u, b_u, w_t = autograd._lin_edge_fold(sd, "b", c, h, up, "cpu")
+        gp = lambda n: sd["b." + n]  # noqa: E731
+        wi = torch.cat([gp("lin_self.weight"), gp("lin_query.weight"), gp("lin_key.weight"), gp("lin_value.weight"), w_u], 0)
+        bi = torch.cat([gp("lin_self.bias"), gp("lin_query.bias"), gp("lin_key.bias"), gp("lin_value.bias"), b_u], 0)
+        wp = torch.cat([gp("projection.weight"), w_t], 1)
+        assert torch.allclose(w_in[i], wi, rtol=1e-6, atol=1e-6) and torch.allclose(b_in[i], bi, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(w_p[i], wp, rtol=1e-6, atol=1e-6)
+        (wi * cot[0][i]).sum().add((bi * cot[1][i]).sum()).add((wp * cot[2][i]).sum()).backward()
+        for k, v in sd.items():
+            if k == "b.projection.bias":  # (never enters the fold: the GEMM takes it as it is)
+                assert v.grad is None and k not in got[i]
+                continue
+            assert torch.allclose(got[i][k], v.grad, rtol=1e-5, atol=1e-5), (i, k)
