@@ -22,6 +22,7 @@ are in the compute dtype.  No atomics anywhere: gradients are reproducible bit f
 
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -173,7 +174,16 @@ class _Linear(torch.autograd.Function):
             else:
                 wt = ops.transpose(weight.detach().to(dtype).contiguous(), ld_out=np_)
             dp = dpre if n == np_ else ops.convert_pad(dpre, dtype, np_)
-            dx = ops.linear(dp, wt)
+            if (dtype == torch.bfloat16 and wt.shape[0] < 256 and dp.shape[0] >= 65536 and np_ >= 128
+                    and os.environ.get("ANEMOI_AMD_TRAIN_WIDE_DX", "1") != "0"):
+                # few input features on very many rows (the mappers' embeddings of the grid nodes: 542 080 x 1024 -> 192 at
+                # config 3): fewer than 256 output columns would take the 128 x 128 kernel (0.49 ms, 2.3 TB/s of the dpre
+                # it reads); with the transposed weight padded to 256 zero rows the persistent kernel runs it
+                wide = torch.zeros((256, np_), dtype=dtype, device=wt.device)
+                wide[: wt.shape[0]] = wt
+                dx = ops.linear(dp, wide)[:, : wt.shape[0]]
+            else:
+                dx = ops.linear(dp, wt)
             if ctx.x_cols != k:
                 dx = ops.convert_pad(dx, dtype, ctx.x_cols)
         if ctx.needs_input_grad[1]:

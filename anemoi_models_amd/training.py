@@ -395,7 +395,37 @@ def _node_rows(model, name: str, rows: int) -> Tensor:
     return torch.cat(parts, dim=1).repeat(rows, 1)
 
 
+class _PrognosticResidual(torch.autograd.Function):
+    """``y = float(out)`` with ``y[..., prognostic] += x[:, -1, ..., prognostic_in]`` (reference
+    models/encoder_processor_decoder.py:223-228) in the ONE pass of ``anemoi_finalize_output`` -- the inference route's
+    kernel -- instead of zeros / index_select / index_put / add over the ``[grid, V_out]`` output (five passes over 173 MB at
+    config 3).  ``x`` carries no gradient on this route (the caller checks); the gradient of ``out`` is the incoming one."""
+
+    @staticmethod
+    def forward(ctx, out: Tensor, x: Tensor, src: Tensor, shape):
+        y = torch.empty(shape, dtype=torch.float32, device=out.device)  # (a tensor of its own, not a view: boundings write in place)
+        y.view(out.shape).copy_(out)
+        ops.finalize_output(y, x, src, None, None)
+        ctx.out_shape, ctx.out_dtype = out.shape, out.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return g.reshape(ctx.out_shape).to(ctx.out_dtype), None, None, None
+
+
 def _finish(model, out: Tensor, x: Tensor, b: int, ens: int, g: int) -> Tensor:
+    if (out.is_cuda and not x.requires_grad and x.dtype == torch.float32 and x.dim() == 5
+            and os.environ.get("ANEMOI_AMD_TRAIN_FUSED_FINISH", "1") != "0"):
+        key = ("residual_src", str(x.device))  # (the inference route's column map, models/encoder_processor_decoder.py::_finish)
+        if key not in model._idx_cache:
+            src = torch.full((model.num_output_channels,), -1, dtype=torch.int32)
+            src[torch.as_tensor(model._internal_output_idx).long()] = torch.as_tensor(model._internal_input_idx).to(torch.int32)
+            model._idx_cache[key] = src.to(x.device)
+        y = _PrognosticResidual.apply(out, x, model._idx_cache[key], (b, ens, g, out.shape[-1]))
+        for bounding in model.boundings:
+            y = bounding(y)
+        return y
     y = out.float().reshape(b, ens, g, -1).to(x.dtype).clone()
     key = ("prognostic_long", str(x.device))  # index tensors resident on the device: a Python list here costs an upload
     if key not in model._idx_cache:           # and a device synchronisation per step

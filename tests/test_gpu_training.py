@@ -268,6 +268,50 @@ def test_batched_processor_weights_equal_the_per_block_route(graph_o32, monkeypa
     assert y_err <= 2e-3 and worst <= 2e-2, (y_err, worst)
 
 
+def test_wide_dx_and_fused_finish_equal_the_plain_routes(graph_o32, golden_cfg1_gt, monkeypatch):
+    """Two training-step shortcuts against the routes they replace: (a) the dX GEMM of a Linear with few input features on very
+    many rows runs on the persistent kernel through a transposed weight padded to 256 zero rows (``ANEMOI_AMD_TRAIN_WIDE_DX``);
+    (b) the prognostic residual of the model output is ONE pass of ``anemoi_finalize_output`` under autograd
+    (``ANEMOI_AMD_TRAIN_FUSED_FINISH``)."""
+    from test_gpu_parity import _build
+    from anemoi_models_amd import autograd
+
+    g = torch.Generator().manual_seed(4)
+    m, k_in, n = 70001, 192, 1024
+    x = torch.randn(m, k_in, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(n, k_in, generator=g) / k_in**0.5).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    dy = torch.randn(m, n, generator=g).bfloat16().to(DEV)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ANEMOI_AMD_TRAIN_WIDE_DX", mode)
+        xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        y = autograd.linear(xr, wr, br)
+        y.backward(dy)
+        res[mode] = (y.detach().clone(), xr.grad.clone(), wr.grad.clone(), br.grad.clone())
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][2], res["0"][2]) and torch.equal(res["1"][3], res["0"][3])
+    want = dy.float() @ w
+    assert res["1"][1].shape == (m, k_in) and rel_err(res["1"][1], want) < 1e-2 and rel_err(res["0"][1], want) < 1e-2
+    assert rel_err(res["1"][1], res["0"][1]) < 1e-2
+
+    gold = golden_cfg1_gt
+    dyo = torch.randn(gold["y"].shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ANEMOI_AMD_TRAIN_FUSED_FINISH", mode)
+        model, _ = _build(graph_o32, 64, 4)
+        model.load_state_dict(split_prefix(gold, "sd."))
+        model = model.to(DEV).train()
+        y = model(gold["x"].to(DEV))
+        y.backward(dyo)
+        out[mode] = (y.detach().clone(), {k_: p.grad.clone() for k_, p in model.named_parameters() if p.grad is not None})
+    assert out["1"][0].dtype == out["0"][0].dtype == torch.float32 and rel_err(out["1"][0], gold["y"]) < 1e-4
+    assert torch.allclose(out["1"][0], out["0"][0], rtol=0, atol=1e-6)
+    assert set(out["1"][1]) == set(out["0"][1])
+    for k_, g1 in out["1"][1].items():
+        assert torch.equal(g1, out["0"][1][k_]), k_
+
+
 def test_bf16_training_at_head_size_4(graph_o32, golden_cfg1_gt, monkeypatch):
     """BASELINE config 1 (64 channels, 16 heads: head size 4) trains in bf16: the bf16 edge kernels move 8 channels per lane,
     so the edge phases of its blocks run on the f32 kernels between two casts (``autograd._edge_phase_in_f32``), every GEMM
