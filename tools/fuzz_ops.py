@@ -157,6 +157,63 @@ def fuzz_edge_scheduled():
     print(f"gt_edge_attention_folded scheduled vs round-robin (bit identity): {bad} bad of {tried}", flush=True)
 
 
+def fuzz_edge_groups():
+    """The group kernel of uniform-degree-3 graphs (all destinations of a source triple behind one gather; scalar index chain,
+    buffer loads) against the run kernel where the plan has runs (BIT identity: same per-destination arithmetic) and against
+    the plain folded kernel (f32 rounding of another summation order): random triangle assignments -- scattered, clustered,
+    groups longer than the cap of eight --, head sizes 64 / 32, every folded width, with and without x_r, strided operands."""
+    bad = tried = with_runs = 0
+    for case in range(n_cases // 3):
+        h = rng.choice([8, 16])
+        d = rng.choice([32, 64])
+        c = h * d
+        up = rng.choice([4, 8, 12, 16])
+        n_dst = rng.choice([rng.randint(1024, 3000), rng.randint(3000, 40000)])
+        n_src = rng.randint(40, 6000)
+        g = torch.Generator().manual_seed(seed * 7919 + case)
+        n_tri = max(1, n_dst // rng.choice([2, 5, 12]))
+        base = torch.randint(0, max(1, n_src - 33), (n_tri,), generator=g)
+        tri_of = torch.randint(0, n_tri, (n_dst,), generator=g)
+        if rng.random() < 0.5:  # clustered: consecutive destinations often share their triangle (the run kernel's case)
+            keep = torch.rand(n_dst, generator=g) < 0.6
+            for i in range(1, n_dst):
+                if keep[i]:
+                    tri_of[i] = tri_of[i - 1]
+        tri = torch.stack([base, base + 7, base + 31], 1)[tri_of]
+        order = torch.stack([torch.randperm(3, generator=g) for _ in range(n_dst)])
+        src = torch.gather(tri, 1, order).reshape(-1)
+        dst = torch.arange(n_dst).repeat_interleave(3)
+        plan = runtime.build_edge_plan(torch.stack([src, dst]).to(dev), n_src, n_dst)
+        groups = runtime._groups3(plan)
+        if groups is None:
+            continue
+        tried += 1
+        runs = runtime._runs3(plan)
+        wide = torch.randn(n_dst, 2 * c + h * up, generator=g).bfloat16().to(dev)  # x_r | q | u as one GEMM result
+        kv = torch.randn(n_src, 2 * c, generator=g).bfloat16().to(dev)
+        attr = torch.randn(3 * n_dst, up, generator=g).to(dev)
+        xr = wide[:, :c] if rng.random() < 0.7 else None
+        res = {}
+        for name, lists in (("plain", None), ("groups", groups), ("runs", runs)):
+            if name == "runs" and runs is None:
+                continue
+            lse = torch.full((n_dst, h), float("nan"), device=dev)
+            out = ops.gt_edge_attention_folded(wide[:, c:2 * c], kv[:, :c], kv[:, c:], xr, wide[:, 2 * c:], attr, plan.rowptr,
+                                               plan.col, h, up, lse=lse, runs=lists)
+            res[name] = (out, lse)
+        ok = bool(torch.isfinite(res["groups"][0].float()).all()) and rel(res["groups"][0], res["plain"][0].float()) < 1e-2 \
+            and rel(res["groups"][1], res["plain"][1]) < 1e-5
+        if "runs" in res:
+            with_runs += 1
+            ok = ok and torch.equal(res["groups"][0], res["runs"][0]) and torch.equal(res["groups"][1], res["runs"][1])
+        if not ok:
+            bad += 1
+            print(f"  group edge kernel case {case}: n_src={n_src} n_dst={n_dst} h={h} d={d} up={up} x_r={xr is not None} "
+                  f"groups={groups[0].shape[0] - 1} runs={'-' if runs is None else runs[0].shape[0] - 1}", flush=True)
+    print(f"gt_edge_attention_folded groups vs plain (and bit identity with the run kernel in {with_runs} cases): {bad} bad of {tried}",
+          flush=True)
+
+
 def fuzz_rows():
     bad = 0
     for case in range(n_cases // 3):
@@ -204,5 +261,6 @@ def fuzz_weight_grad():
 fuzz_linear()
 fuzz_edge_attention()
 fuzz_edge_scheduled()
+fuzz_edge_groups()
 fuzz_rows()
 fuzz_weight_grad()
