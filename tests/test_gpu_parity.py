@@ -365,6 +365,19 @@ def test_transformer_block_entry_point_is_the_op_by_op_route(dtype, channels, he
         monkeypatch.setattr(TransformerProcessorBlock, "block_abi", True)
         got = blk.native(x, b)
         assert blk._block_abi(x, b) is not None  # (the route was taken, not refused)
+        if not torch.equal(got, want):
+            # (this comparison failed ONCE in the ~15 whole-suite runs of round 5 and never in 20 000 repeats on its own --
+            #  profiles/r05_verdict_items.md, tools/micro/tfm_block_repeat.py: say which route moved, and where)
+            got2 = blk.native(x, b)
+            monkeypatch.setattr(TransformerProcessorBlock, "block_abi", False)
+            want2 = blk.native(x, b)
+            d = (got.float() - want.float()).abs()
+            r, c_ = [int(v) for v in torch.nonzero(d == d.max())[0]]
+            pytest.fail(f"block entry point != op-by-op route: {int((got != want).sum())} elements differ, max |diff| "
+                        f"{float(d.max()):.3e} at row {r} column {c_}; repeated: entry point "
+                        f"{'reproduces itself' if torch.equal(got, got2) else 'CHANGED'}, op-by-op route "
+                        f"{'reproduces itself' if torch.equal(want, want2) else 'CHANGED'}, second pair "
+                        f"{'equal' if torch.equal(got2, want2) else 'different'}")
     assert torch.equal(got, want)
     # f64 restatement (reference layers/block.py:99-105): x + proj(attn(qkv(LN x))), then x + MLP(LN x)
     xd = x.double().cpu()
