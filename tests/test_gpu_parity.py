@@ -366,7 +366,7 @@ def test_transformer_block_entry_point_is_the_op_by_op_route(dtype, channels, he
         got = blk.native(x, b)
         assert blk._block_abi(x, b) is not None  # (the route was taken, not refused)
         if not torch.equal(got, want):
-            # (this comparison failed ONCE in the ~15 whole-suite runs of round 5 and never in 20 000 repeats on its own --
+            # (this comparison failed ONCE in six whole-suite runs of round 5 and never in 20 000 repeats on its own --
             #  profiles/r05_verdict_items.md, tools/micro/tfm_block_repeat.py: say which route moved, and where)
             got2 = blk.native(x, b)
             monkeypatch.setattr(TransformerProcessorBlock, "block_abi", False)
