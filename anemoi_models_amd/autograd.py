@@ -31,10 +31,10 @@ from torch import Tensor
 from . import ops
 
 
-def _pack(w: Tensor, dtype: torch.dtype) -> Tensor:
-    """``[N, K]`` f32 parameter -> compute dtype with K zero-padded to the GEMM's slab multiple."""
+def _pack(w: Tensor, dtype: torch.dtype, k_pad: Optional[int] = None) -> Tensor:
+    """``[N, K]`` f32 parameter -> compute dtype with K zero-padded to the GEMM's slab multiple (or to ``k_pad`` columns)."""
     n, k = w.shape
-    kp = ops.round_up(k, ops.k_multiple(dtype))
+    kp = ops.round_up(k, ops.k_multiple(dtype)) if k_pad is None else k_pad
     if kp == k:  # no padding: the cast alone (one launch; nothing for a contiguous weight in the compute dtype)
         return w.detach().to(dtype).contiguous()
     out = torch.zeros((n, kp), dtype=dtype, device=w.device)
@@ -128,10 +128,12 @@ class _Linear(torch.autograd.Function):
         dtype = x.dtype
         k = weight.shape[1]
         kp = ops.round_up(k, ops.k_multiple(dtype))
+        if x.shape[1] > kp and x.shape[1] % ops.k_multiple(dtype) == 0 and prep is None:
+            kp = x.shape[1]  # rows that carry more (zero / constant) padding columns than the weight needs: zero weights meet them
         if x.shape[1] not in (k, kp):
             raise ValueError(f"linear: x has {x.shape[1]} columns, weight expects {k}")
         xk = x if x.shape[1] == kp else ops.convert_pad(x, dtype, kp)
-        w = _pack(weight, dtype) if prep is None else prep.w
+        w = _pack(weight, dtype, kp) if prep is None else prep.w
         ctx.prep = prep
         b = None if bias is None else bias.detach().float().contiguous()
         if act == "Identity":
@@ -411,7 +413,7 @@ class _QuadForm(torch.autograd.Function):
 
 
 def folded_embedding_ln_linear(x: Tensor, emb_w: Tensor, emb_b: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,
-                               w_rows: Tensor, bias: Optional[Tensor]) -> Tensor:
+                               w_rows: Tensor, bias: Optional[Tensor], augmented: bool = False) -> Tensor:
     """``Linear(LayerNorm(emb(x)))`` on the RAW node features (mapper embedding -> block LayerNorm -> k|v or x_r|q|u
     Linear, reference layers/mapper.py:322-331 + layers/block.py:516-528), differentiable: the training form of
     ``runtime.fold_embedded_layer_norm``.  With the channel-centred embedding ``A = [E_c | b_c]`` (the LayerNorm's mean is
@@ -422,15 +424,22 @@ def folded_embedding_ln_linear(x: Tensor, emb_w: Tensor, emb_b: Optional[Tensor]
 
     -- a K = k_in + 1 product instead of the embedding GEMM's successor at K = C, and no ``[M, C]`` LayerNorm pass.  The
     algebra on the parameters is plain torch (autograd carries the gradients to the embedding, the LayerNorm and the
-    Linear), the two products on the rows are autograd nodes on the HIP kernels."""
+    Linear), the two products on the rows are autograd nodes on the HIP kernels.  ``augmented``: ``x`` IS ``x_aug`` already
+    (``[M, kp]`` with the constant 1 in column ``k_in`` and zeros behind it: ``training._AssembleNodes`` writes the model
+    input that way), so no concatenation pass over the rows."""
     dtype = x.dtype
     c, k_in = emb_w.shape
     if x.shape[1] < k_in:
         raise ValueError(f"folded_embedding_ln_linear: x has {x.shape[1]} columns, the embedding expects {k_in}")
     kp = ops.round_up(k_in + 1, ops.k_multiple(dtype))
     m = x.shape[0]
-    xa = torch.cat([x[:, :k_in], torch.ones((m, 1), dtype=dtype, device=x.device),
-                    torch.zeros((m, kp - k_in - 1), dtype=dtype, device=x.device)], dim=1)
+    if augmented:
+        if x.shape[1] != kp:
+            raise ValueError(f"folded_embedding_ln_linear: augmented rows need {kp} columns, got {x.shape[1]}")
+        xa = x
+    else:
+        xa = torch.cat([x[:, :k_in], torch.ones((m, 1), dtype=dtype, device=x.device),
+                        torch.zeros((m, kp - k_in - 1), dtype=dtype, device=x.device)], dim=1)
     e_c = emb_w.float() - emb_w.float().mean(0, keepdim=True)
     b_e = torch.zeros(c, dtype=torch.float32, device=x.device) if emb_b is None else emb_b.float()
     b_c = b_e - b_e.mean()

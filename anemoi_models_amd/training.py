@@ -213,9 +213,10 @@ def gt_processor(proc, x: Tensor, batch_size: int, node_map: Optional[Tensor] = 
 
 
 def gt_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int, src_map: Optional[Tensor] = None,
-              dst_map: Optional[Tensor] = None) -> Tensor:
+              dst_map: Optional[Tensor] = None, augmented: bool = False) -> Tensor:
     """``GraphTransformerForwardMapper`` / ``GraphTransformerBackwardMapper`` (reference layers/mapper.py:275-418): returns
-    the mapped (and, for the backward mapper, extracted) destination nodes."""
+    the mapped (and, for the backward mapper, extracted) destination nodes.  ``augmented``: the rows of the LARGER node set (the
+    grid) are ``[features | 1 | 0-pad]`` already (:class:`_AssembleNodes`)."""
     dtype = runtime.compute_dtype(x_dst)
     blk = mapper.proc
     _check_heads(mapper.hidden_dim, blk.num_heads, dtype)
@@ -235,14 +236,14 @@ def gt_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int, src_map: Op
     if hasattr(mapper, "emb_nodes_src") and hs.shape[0] >= hd.shape[0] and can_fold(mapper.emb_nodes_src):
         raw_src, emb = hs, mapper.emb_nodes_src
         kv_fn = lambda w, b, gamma, beta: autograd.folded_embedding_ln_linear(  # noqa: E731
-            raw_src, emb.weight, emb.bias, gamma, beta, eps, w, b)
+            raw_src, emb.weight, emb.bias, gamma, beta, eps, w, b, augmented=augmented)
         hs = None
     elif hasattr(mapper, "emb_nodes_src"):
         hs = autograd.linear(hs, mapper.emb_nodes_src.weight, mapper.emb_nodes_src.bias)
     if hd.shape[0] > (0 if hs is None else hs.shape[0]) and hs is not None and can_fold(mapper.emb_nodes_dst):
         raw_dst, emb_d = hd, mapper.emb_nodes_dst
         sq_fn = lambda w, b, gamma, beta: autograd.folded_embedding_ln_linear(  # noqa: E731
-            raw_dst, emb_d.weight, emb_d.bias, gamma, beta, eps, w, b)
+            raw_dst, emb_d.weight, emb_d.bias, gamma, beta, eps, w, b, augmented=augmented)
     hd = autograd.linear(hd, mapper.emb_nodes_dst.weight, mapper.emb_nodes_dst.bias)
     y = autograd.gt_mapper_block(hs, hd, _block_sd(blk), "b", ea, plan, blk.num_heads, blk.activation, eps,
                                  kv_fn=kv_fn, sq_fn=sq_fn)
@@ -395,6 +396,33 @@ def _node_rows(model, name: str, rows: int) -> Tensor:
     return torch.cat(parts, dim=1).repeat(rows, 1)
 
 
+class _AssembleNodes(torch.autograd.Function):
+    """The model input as the mappers' GEMMs read it -- rows ``(b, ens, g)`` of ``[x (time-major) | sin/cos latlon | trainable |
+    1 | 0-pad]`` in the compute dtype, ``ld`` columns -- from ONE kernel (``anemoi_assemble_nodes``, the inference route's)
+    instead of permute / cat / cast here and one more concatenation per folded embedding (four passes over the 542 080 grid rows
+    of config 3).  The constant 1 behind the features carries the embedding bias of the folded products
+    (``autograd.folded_embedding_ln_linear(augmented=True)``) and meets zero weights everywhere else.  Backward: the columns of
+    the trainable tensor, summed over the batch; ``x`` carries no gradient on this route (the caller checks)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, latlons: Tensor, trainable: Optional[Tensor], dtype: torch.dtype, ld: int):
+        g = latlons.shape[0]
+        ones = torch.ones((g, 1), dtype=torch.float32, device=latlons.device)
+        tr1 = ones if trainable is None else torch.cat([trainable.detach().float(), ones], dim=1)
+        out = ops.assemble_nodes(x, latlons, tr1, x.shape[0], dtype, ld_out=ld)
+        ctx.off = x.shape[1] * x.shape[4] + latlons.shape[1]
+        ctx.n_tr = 0 if trainable is None else trainable.shape[1]
+        ctx.g, ctx.tr_dtype = g, (None if trainable is None else trainable.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        if ctx.n_tr == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None, None
+        gt = grad[:, ctx.off:ctx.off + ctx.n_tr].float().reshape(-1, ctx.g, ctx.n_tr).sum(0)
+        return None, None, gt.to(ctx.tr_dtype), None, None
+
+
 class _PrognosticResidual(torch.autograd.Function):
     """``y = float(out)`` with ``y[..., prognostic] += x[:, -1, ..., prognostic_in]`` (reference
     models/encoder_processor_decoder.py:223-228) in the ONE pass of ``anemoi_finalize_output`` -- the inference route's
@@ -454,7 +482,21 @@ def model_forward(model, x: Tensor) -> Tensor:
     dtype = runtime.compute_dtype(x)  # under torch.autocast: the autocast dtype
     with torch.autocast(device_type=x.device.type, enabled=False):  # this route picks its precisions itself: the
         # activations are cast once here and every sub-module follows the dtype of what it is handed
-        x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(rows * g, -1), _node_rows(model, data, rows)], dim=1).to(dtype)
+        from .layers.mapper import GraphTransformerBaseMapper as _GTMapper
+
+        na = model.node_attributes
+        width = x.shape[1] * x.shape[4] + na.attr_ndims[data]
+        # bf16 GraphTransformer mappers that fold their embedding: the input is written ONCE, in the layout of their first GEMMs
+        augmented = (x.is_cuda and not x.requires_grad and x.dtype == torch.float32 and dtype == torch.bfloat16
+                     and isinstance(model.encoder, _GTMapper) and isinstance(model.decoder, _GTMapper)
+                     and runtime.embed_fold_enabled(dtype) and hasattr(model.encoder, "emb_nodes_src")
+                     and model.encoder.emb_nodes_src.in_features == width
+                     and os.environ.get("ANEMOI_AMD_TRAIN_ASSEMBLE", "1") != "0")
+        if augmented:
+            x_data = _AssembleNodes.apply(x, na.latlons(data), na.trainable_tensors[data].trainable, dtype,
+                                          ops.round_up(width + 1, ops.k_multiple(dtype)))
+        else:
+            x_data = torch.cat([x.permute(0, 2, 3, 1, 4).reshape(rows * g, -1), _node_rows(model, data, rows)], dim=1).to(dtype)
         x_hidden = _node_rows(model, hidden, rows)
         shapes = None  # (single device: the modules ignore shard shapes on this route)
         # As in inference, the mesh rows live in the internal Morton order between encoder and decoder (gather locality of
@@ -476,7 +518,7 @@ def model_forward(model, x: Tensor) -> Tensor:
             if inv is None:
                 return mapper((a, c), rows, shapes)
             if isinstance(mapper, GraphTransformerBaseMapper):
-                y = gt_mapper(mapper, a, c, rows, src_map, dst_map)
+                y = gt_mapper(mapper, a, c, rows, src_map, dst_map, augmented=augmented)
                 return (a, y) if hasattr(mapper, "emb_nodes_src") else y  # forward mapper: raw source handed on
             hs, hd = gnn_mapper(mapper, a, c, rows, src_map, dst_map)
             return (hs, hd) if hasattr(mapper, "emb_nodes_src") else hd

@@ -311,6 +311,31 @@ def test_wide_dx_and_fused_finish_equal_the_plain_routes(graph_o32, golden_cfg1_
     for k_, g1 in out["1"][1].items():
         assert torch.equal(g1, out["0"][1][k_]), k_
 
+    # (c) bf16: the model input written once in the layout of the mappers' first GEMMs ([x | latlon | trainable | 1 | 0-pad],
+    # training._AssembleNodes, ANEMOI_AMD_TRAIN_ASSEMBLE) against permute / cat / cast + one concatenation per folded embedding:
+    # with the fold (128 channels) and without it (64 channels: the embeddings stay GEMMs on the wider rows)
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    for channels in (128, 64):
+        torch.manual_seed(12)
+        model, _ = _build(graph_o32, channels, 2)
+        model = model.to(DEV).train()
+        xin = gold["x"].to(DEV)
+        res_c = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ANEMOI_AMD_TRAIN_ASSEMBLE", mode)
+            for p_ in model.parameters():
+                p_.grad = None
+            y = model(xin)
+            y.backward(dyo)
+            res_c[mode] = (y.detach().clone(), {k_: p_.grad.float().clone() for k_, p_ in model.named_parameters()
+                                                 if p_.grad is not None})
+        assert rel_err(res_c["1"][0], res_c["0"][0]) < 2e-3, channels
+        assert set(res_c["1"][1]) == set(res_c["0"][1])
+        scale_all = max(float(g0.abs().max()) for g0 in res_c["0"][1].values())
+        for k_, g0 in res_c["0"][1].items():
+            err = float((res_c["1"][1][k_] - g0).abs().max())
+            assert err <= 2e-2 * max(float(g0.abs().max()), 0.05 * scale_all), (channels, k_, err, float(g0.abs().max()))
+
 
 def test_bf16_training_at_head_size_4(graph_o32, golden_cfg1_gt, monkeypatch):
     """BASELINE config 1 (64 channels, 16 heads: head size 4) trains in bf16: the bf16 edge kernels move 8 channels per lane,
