@@ -583,7 +583,9 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
     // ---- softmax of pair SM_PR on sa, slices of it between the MFMAs
     const int key0 = kt * ATT_KV + kb * 32 + 8 * half, blk0 = kt * ATT_KV + kb * 32;
     if (blk0 + 32 > S) {  // the sequence ends inside this block (global attention only: the launcher keeps windows off this kernel)
-      asm volatile("s_nop 15" ::: "memory");  // the scores' last MFMA (asm: no hazard handling by the compiler) has retired
+      // the scores' last MFMA (asm: no hazard handling by the compiler) has retired.  The scores are OPERANDS of the wait:
+      // a bare asm statement does not order the register reads below against itself (see the prologue)
+      asm volatile("s_nop 15" : "+v"(sa[0]), "+v"(sa[1]));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -741,7 +743,14 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
         W4_MFMA_S(s0[0], kf0[ks], qf[2 * pr][ks]);
         W4_MFMA_S(s0[1], kf0[ks], qf[2 * pr + 1][ks]);
       }
-      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMAs: no hazard handling by the compiler)
+      // asm MFMAs: no hazard handling by the compiler, and the wait states must take the scores as OPERANDS.  Behind a bare
+      // `asm volatile("s_nop ..." ::: "memory")` the compiler hoisted the maxima in FRONT of the wait (pure register
+      // arithmetic is not ordered against a volatile asm, "memory" or not): v_max read a score register right behind the MFMA
+      // that writes it, i.e. the reference maximum was taken from whatever the register held at that cycle.  Any reference
+      // gives the same softmax up to rounding -- no parity test can see it -- but WHICH value was read depended on the
+      // wave's timing (instruction fetch under contention): results differing in the last bit between identical calls
+      // (round 5, found by bit-comparing repeated calls with a second process on the GPU, tools/micro/mhsa_repeat_diag.py).
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0[0]), "+v"(s0[1]));
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float m = s0[i][0];
@@ -796,7 +805,10 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
           W4_MFMA_O(lacc[1], onesf[i], p1[i][kk]);
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // (last asm MFMAs -> the accumulator reads of the epilogue: the accumulators are operands of the wait, see the prologue)
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(o_acc[0][0]), "+a"(o_acc[0][1]), "+a"(o_acc[1][0]), "+a"(o_acc[1][1]), "+a"(o_acc[2][0]),
+                   "+a"(o_acc[2][1]), "+a"(o_acc[3][0]), "+a"(o_acc[3][1]), "+a"(lacc[0]), "+a"(lacc[1]));
   }
 #undef W4_MFMA_S0
 #undef W4_MFMA_S
@@ -1285,7 +1297,7 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
       dlv[4 * g] = d4.x, dlv[4 * g + 1] = d4.y, dlv[4 * g + 2] = d4.z, dlv[4 * g + 3] = d4.w;
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7" ::: "memory");  // (with the last product's own eight: its results are read next)
+    asm volatile("s_nop 7" : "+v"(s_acc), "+v"(dp_acc));  // (with the last product's own eight: its results -- operands of the wait, so no read of them can be placed in front of it -- are read next)
   };
   // V: P = exp2(S c - lse), dS = P (dP - delta), both as bf16 B fragments of M2
   auto vphase = [&](int qt) {
@@ -1387,7 +1399,9 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dkv_mfma_kernel(
   if (blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 64)
     for (int i = 0; i < 8; ++i) att_prof[i] = tacc[i];
 #endif
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> the accumulator reads below
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> the accumulator reads below ...
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) asm volatile("" : "+a"(dk[dt]), "+a"(dv[dt]));  // ... which depend on THIS statement (volatile asm statements keep their order; plain register reads are not ordered against one)
   if (key < S) {  // lane = key; register r <-> d = dt * 32 + 8 (r >> 2) + 4 half + (r & 3)
     bf16_t* kp = dqkv + ((int64_t)b * S + key) * lddq + C + h * ATT_D;
 #pragma unroll
@@ -1517,7 +1531,7 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dq_mfma_kernel(
         fkt[dt][kk] = *reinterpret_cast<const abf16x8_t*>(kt_s + drow * 64 + (aswz64(drow, kk * 2 + half) << 4));
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7" ::: "memory");  // (with the last product's own eight: its results are read next)
+    asm volatile("s_nop 7" : "+v"(s_acc), "+v"(dp_acc));  // (with the last product's own eight: its results -- operands of the wait, so no read of them can be placed in front of it -- are read next)
     float ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1565,7 +1579,9 @@ __global__ __launch_bounds__(64 * ATT_BWD_NW) void mhsa_bwd_dq_mfma_kernel(
     if (kt < kt_end) tile(kt, B0{});
     if (kt + 1 < kt_end) tile(kt + 1, B1{});
   }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> the accumulator reads below
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> the accumulator reads below ...
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) asm volatile("" : "+a"(dq[dt]));  // ... which depend on THIS statement (see the dK/dV kernel)
   if (q < S) {
     bf16_t* qp = dqkv + ((int64_t)b * S + q) * lddq + h * ATT_D;
 #pragma unroll

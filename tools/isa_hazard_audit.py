@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Audit a gfx950 assembly listing (hipcc -save-temps: *-hip-amdgcn-amd-amdhsa-gfx950.s) for MFMA results touched too early.
+
+hipcc pads nothing around an inline-asm MFMA and does not order plain register arithmetic against a bare
+`asm volatile("s_nop ..." ::: "memory")`: a compiler-placed VALU read of a score register can end up directly behind the
+MFMA that writes it (round 5: the reference maxima of the four-wave attention forward -- valid results, but differing in
+the last bit between identical calls under contention).  This walks the instruction stream behind every v_mfma and
+reports any instruction that reads or writes a register of its destination before the required wait states have passed
+(8-pass product: 12 states, 4-pass: 8; cdna_hip_programming.md section 5.7 item 2), except the next MFMA taking the
+destination whole as its C operand (accumulate chain: 0 states).  States are counted conservatively: one per
+instruction, n + 1 per `s_nop n`, PASSES per intervening MFMA (the matrix pipe takes one product of a wave at a time).
+
+  python tools/isa_hazard_audit.py file.s [kernel-name-substring]      exit code 1 if anything is reported
+"""
+import re
+import sys
+
+REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+
+
+def regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        lo = int(m.group(2) if m.group(2) is not None else m.group(3))
+        hi = int(m.group(2) if m.group(2) is not None else m.group(4))
+        out.update((m.group(1), r) for r in range(lo, hi + 1))
+    return out
+
+
+def passes(op):
+    return 8 if "32x32" in op else 4
+
+
+def audit(path, only=None):
+    lines = open(path).read().split("\n")
+    found = []
+    fn = None
+    insts = []  # (function, line number, text)
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            fn = m.group(1)
+        t = l.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":") or fn is None:
+            continue
+        insts.append((fn, i + 1, t))
+    for k, (fn, ln, t) in enumerate(insts):
+        if not t.startswith("v_mfma") or (only and only not in fn):
+            continue
+        ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+        dst = regs(ops[0])
+        need = 12 if passes(t) == 8 else 8
+        states = 0
+        for fn2, ln2, t2 in insts[k + 1:]:
+            if fn2 != fn or states >= need:
+                break
+            op = t2.split()[0]
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                break
+            if op == "s_nop":
+                states += int(t2.split()[1]) + 1
+                continue
+            if op.startswith("v_mfma"):
+                o2 = [o.strip() for o in t2.split(None, 1)[1].split(",")]
+                chain = regs(o2[0]) == dst and regs(o2[3]) == dst and not (regs(o2[1]) | regs(o2[2])) & dst
+                if not chain and regs(t2) & dst:
+                    found.append((fn, ln, t, ln2, t2, states))
+                if chain:
+                    break  # the chain's next link is audited on its own
+                states += passes(t2)
+                continue
+            if op.startswith(("v_", "ds_", "buffer_", "global_", "flat_", "scratch_")) and regs(t2) & dst:
+                found.append((fn, ln, t, ln2, t2, states))
+                break
+            states += 1
+    return found
+
+
+if __name__ == "__main__":
+    res = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    for fn, ln, t, ln2, t2, st in res[:40]:
+        print(f"{fn[:60]}: line {ln}: {t}\n    touched after {st} wait state(s) by line {ln2}: {t2}")
+    print(f"{len(res)} early touches of an MFMA destination in {sys.argv[1]}")
+    sys.exit(1 if res else 0)
