@@ -18,6 +18,19 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libanemoi_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# Sources with inline-asm MFMAs: their device listing is kept next to the object (lib/obj/<name>-hip-amdgcn-amd-amdhsa-gfx950.s,
+# not shipped, not committed) so that tools/isa_hazard_audit.py -- and tests/test_host_logic.py -- can check that nothing
+# touches an MFMA result before its wait states have passed (hipcc pads nothing around such a statement).
+ASM_SOURCES = ("attention", "gemm", "weight_grad")
+
+
+def device_listing(name: str):
+    """Path of the gfx950 listing of ``csrc/<name>.hip`` written by the last build, or None if absent / older than the source."""
+    path = os.path.join(LIB_DIR, "obj", f"{name}-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+    src = os.path.join(CSRC, name + ".hip")
+    if os.path.exists(path) and os.path.getmtime(path) >= os.path.getmtime(src):
+        return path
+    return None
 
 
 def _hipcc_version(hipcc: str) -> str:
@@ -85,6 +98,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
             return obj
         cmd = [hipcc, *FLAGS, f'-DANEMOI_HIPCC_VERSION="{version}"', "-c", src, "-o", obj]
+        if os.path.basename(src)[:-4] in ASM_SOURCES:
+            cmd.insert(1, "-save-temps=obj")
         if verbose:
             print(" ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)

@@ -464,32 +464,20 @@ __global__ __launch_bounds__(256) void mhsa_bf16_w4_kernel(const bf16_t* __restr
     for (int g = 0; g < 2; ++g) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(ks_ + (wid * 2 + g) * 1024), 16,
                                                koff[g], kt * ktile_bytes, 0, 0);
-#if defined(ANEMOI_LAB_ATT) && ANEMOI_LAB_ATT == 2
-      asm volatile("s_nop 7" ::: "memory");
-#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(vs_ + (wid * 2 + g) * 1024), 16,
                                                voff[g], kt * (ATT_KV * 2), 0, 0);
-#if defined(ANEMOI_LAB_ATT) && ANEMOI_LAB_ATT == 2
-      asm volatile("s_nop 7" ::: "memory");
-#endif
     }
-#if defined(ANEMOI_LAB_ATT) && ANEMOI_LAB_ATT == 3
-    __syncthreads();
-#endif
   };
   constexpr int DMA_PER_STAGE = 4;
   auto publish = [&](int kt) {  // barrier "kt": tile kt readable by everyone, tile kt + 2 requested
-#if defined(ANEMOI_LAB_ATT) && ANEMOI_LAB_ATT == 1
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif defined(ANEMOI_LAB_ATT) && ANEMOI_LAB_ATT == 4
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
     if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // __syncthreads(), fence included: here the compiler waits for vmcnt(0) in it, i.e. also for the DMA of tile kt + 1 that
     // the counted wait above would let stay in flight.  The bare s_barrier behind the counted wait was measured -- same
-    // speed -- and is NOT safe: single keys of a tile were occasionally read stale (results differing in the last bit of a
-    // few rows between identical calls, ~8 % of the calls at S = 700; found by bit-comparing repeated calls, now a test).
+    // speed.  (Round 3 blamed it for results differing in the last bit of a few rows between identical calls and read that
+    // as stale keys; round 5 found the cause in the prologue below -- maxima read in front of their wait states -- and four
+    // variants of this synchronisation made no difference to it.  The ring's accounting was right all along; the stronger
+    // barrier stays because it costs nothing.)
     __syncthreads();
     if (kt + 2 < kt_end) stage(kt + 2, (kt + 2 - kt_begin) % N_STAGE);
   };

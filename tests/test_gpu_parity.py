@@ -367,8 +367,9 @@ def test_transformer_block_entry_point_is_the_op_by_op_route(dtype, channels, he
         got = blk.native(x, b)
         assert blk._block_abi(x, b) is not None  # (the route was taken, not refused)
         if not torch.equal(got, want):
-            # (this comparison failed ONCE in six whole-suite runs of round 5 and never in 20 000 repeats on its own --
-            #  profiles/r05_verdict_items.md, tools/micro/tfm_block_repeat.py: say which route moved, and where)
+            # (this comparison failed ONCE in six whole-suite runs of round 5: the attention forward's reference maxima were
+            #  read in front of their wait states, DESIGN.md section 4.3 -- fixed; if it ever fails again, say which route
+            #  moved, and where)
             got2 = blk.native(x, b)
             monkeypatch.setattr(TransformerProcessorBlock, "block_abi", False)
             want2 = blk.native(x, b)
@@ -379,7 +380,6 @@ def test_transformer_block_entry_point_is_the_op_by_op_route(dtype, channels, he
                                        f"{'reproduces itself' if torch.equal(got, got2) else 'CHANGED'}, op-by-op route "
                                        f"{'reproduces itself' if torch.equal(want, want2) else 'CHANGED'}, second pair "
                                        f"{'equal' if torch.equal(got2, want2) else 'different'})")
-            got = want  # (reported as a warning: the comparison against the f64 restatement below goes on)
     assert torch.equal(got, want)
     # f64 restatement (reference layers/block.py:99-105): x + proj(attn(qkv(LN x))), then x + MLP(LN x)
     xd = x.double().cpu()

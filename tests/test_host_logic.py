@@ -791,3 +791,56 @@ def test_stacked_fold_of_a_processor_equals_the_per_block_fold():
                 assert v.grad is None and k not in got[i]
                 continue
             assert torch.allclose(got[i][k], v.grad, rtol=1e-5, atol=1e-5), (i, k)
+
+
+# ---------------------------------------------------------------------------------------------
+# The listings of the inline-asm kernels: nothing touches an MFMA result before its wait states have passed
+# ---------------------------------------------------------------------------------------------
+def _audit_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "isa_hazard_audit", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_hazard_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_isa_hazard_audit_reports_a_read_right_behind_its_mfma(tmp_path):
+    """The auditor itself, on a hand-written listing: the round-5 bug pattern (a v_max on a score register directly behind the
+    MFMA writing it), a wait that is long enough, an accumulate chain (exempt) and a short wait."""
+    audit = _audit_module()
+    listing = tmp_path / "k.s"
+    listing.write_text("\n".join([
+        "_Z1kv:",
+        "\tv_mfma_f32_32x32x16_bf16 v[16:31], v[56:59], a[0:3], v[16:31]",   # chain link: exempt ...
+        "\tv_mfma_f32_32x32x16_bf16 v[16:31], v[60:63], a[4:7], v[16:31]",   # ... and this one is read too early
+        "\tv_max_f32_e32 v16, v16, v16",
+        "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[56:59], a[0:3], 0",
+        "\ts_nop 15",
+        "\tv_max_f32_e32 v0, v0, v0",                                          # behind 16 states: fine
+        "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[56:59], v[60:63], a[0:3]",
+        "\ts_nop 3",
+        "\tv_accvgpr_read_b32 v1, a2",                                         # 4 states of 8: too early
+        "\ts_endpgm",
+    ]) + "\n")
+    found = audit.audit(str(listing))
+    assert [(f[1], f[3]) for f in found] == [(3, 4), (8, 10)], found
+
+
+def test_no_mfma_result_is_touched_before_its_wait_states_in_the_built_kernels():
+    """Every listing the build kept (anemoi_models_amd/_build.py::ASM_SOURCES): zero early touches.  Skipped only where the
+    library was not built from source in this tree (no listing to read)."""
+    from anemoi_models_amd import _build
+
+    audit = _audit_module()
+    seen = 0
+    for name in _build.ASM_SOURCES:
+        path = _build.device_listing(name)
+        if path is None:
+            continue
+        seen += 1
+        found = audit.audit(path)
+        assert not found, f"{name}.hip: {len(found)} early touches of an MFMA destination, first: {found[0]}"
+    if seen == 0:
+        pytest.skip("no device listing in anemoi_models_amd/lib/obj (run __graft_entry__.build() from source)")

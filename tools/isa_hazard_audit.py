@@ -51,7 +51,8 @@ def audit(path, only=None):
         dst = regs(ops[0])
         need = 12 if passes(t) == 8 else 8
         states = 0
-        for fn2, ln2, t2 in insts[k + 1:]:
+        for j in range(k + 1, len(insts)):
+            fn2, ln2, t2 = insts[j]
             if fn2 != fn or states >= need:
                 break
             op = t2.split()[0]
