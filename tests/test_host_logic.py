@@ -826,6 +826,21 @@ def test_isa_hazard_audit_reports_a_read_right_behind_its_mfma(tmp_path):
     ]) + "\n")
     found = audit.audit(str(listing))
     assert [(f[1], f[3]) for f in found] == [(3, 4), (8, 10)], found
+    # second rule: a vector write needs 2 wait states before an MFMA reads it as an operand
+    listing.write_text("\n".join([
+        "_Z1kv:",
+        "\tv_mov_b32_e32 v56, 0",
+        "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[56:59], v[60:63], a[0:15]",   # right behind the write: reported
+        "\tv_mov_b32_e32 v60, 0",
+        "\ts_nop 1",
+        "\tv_mfma_f32_32x32x16_bf16 a[16:31], v[56:59], v[60:63], a[16:31]",  # behind 2 states: fine
+        "\tv_accvgpr_write_b32 a3, v1",
+        "\ts_add_i32 s0, s0, 1",
+        "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[56:59], v[60:63], a[0:15]",   # one state only: reported
+        "\ts_endpgm",
+    ]) + "\n")
+    found = audit.audit_operands(str(listing))
+    assert [(f[1], f[3]) for f in found] == [(3, 2), (9, 7)], found
 
 
 def test_no_mfma_result_is_touched_before_its_wait_states_in_the_built_kernels():
@@ -842,5 +857,7 @@ def test_no_mfma_result_is_touched_before_its_wait_states_in_the_built_kernels()
         seen += 1
         found = audit.audit(path)
         assert not found, f"{name}.hip: {len(found)} early touches of an MFMA destination, first: {found[0]}"
+        found = audit.audit_operands(path)
+        assert not found, f"{name}.hip: {len(found)} MFMA operands written fewer than 2 wait states ahead, first: {found[0]}"
     if seen == 0:
         pytest.skip("no device listing in anemoi_models_amd/lib/obj (run __graft_entry__.build() from source)")

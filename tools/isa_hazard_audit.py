@@ -77,9 +77,52 @@ def audit(path, only=None):
     return found
 
 
+def audit_operands(path, only=None):
+    """Second rule of the same section: a VALU (or v_accvgpr_write) result needs 2 wait states before an MFMA reads it as an
+    A / B / C operand.  Reports MFMAs whose operand register was written by a vector instruction fewer than 2 states earlier."""
+    lines = open(path).read().split("\n")
+    found = []
+    fn = None
+    window = []  # the last instructions of the current function: (line number, text, states it accounts for)
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            fn = m.group(1)
+            window = []
+        t = l.split(";")[0].strip()
+        if not t or t.startswith(".") or fn is None:
+            continue
+        if t.endswith(":"):
+            window = []  # a label: predecessors unknown, the straight-line rule ends here
+            continue
+        op = t.split()[0]
+        if op.startswith("v_mfma") and not (only and only not in fn):
+            ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+            src = regs(ops[1]) | regs(ops[2]) | regs(ops[3])
+            states = 0
+            for ln2, t2, st2 in reversed(window):
+                if states >= 2:
+                    break
+                op2 = t2.split()[0]
+                if op2.startswith("v_") and not op2.startswith(("v_mfma", "v_cmp", "v_nop")):
+                    dst2 = regs(t2.split(None, 1)[1].split(",")[0])
+                    if dst2 & src:
+                        found.append((fn, i + 1, t, ln2, t2, states))
+                        break
+                states += st2
+        window.append((i + 1, t, int(t.split()[1]) + 1 if op == "s_nop" else 1))
+        del window[:-4]
+    return found
+
+
 if __name__ == "__main__":
-    res = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    only = sys.argv[2] if len(sys.argv) > 2 else None
+    res = audit(sys.argv[1], only)
     for fn, ln, t, ln2, t2, st in res[:40]:
         print(f"{fn[:60]}: line {ln}: {t}\n    touched after {st} wait state(s) by line {ln2}: {t2}")
     print(f"{len(res)} early touches of an MFMA destination in {sys.argv[1]}")
-    sys.exit(1 if res else 0)
+    res2 = audit_operands(sys.argv[1], only)
+    for fn, ln, t, ln2, t2, st in res2[:40]:
+        print(f"{fn[:60]}: line {ln}: {t}\n    operand written {st} wait state(s) earlier by line {ln2}: {t2}")
+    print(f"{len(res2)} MFMA operands written fewer than 2 wait states ahead in {sys.argv[1]}")
+    sys.exit(1 if res or res2 else 0)
