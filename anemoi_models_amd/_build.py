@@ -107,6 +107,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr}")
         if verbose and res.stderr.strip():
             print(res.stderr)
+        base = os.path.basename(src)[:-4]
+        if base in ASM_SOURCES:  # keep the device listing only (the other intermediates are ~100 MB)
+            keep = {base + ".o", f"{base}-hip-amdgcn-amd-amdhsa-{ARCH}.s"}
+            for f in glob.glob(os.path.join(LIB_DIR, "obj", base + "[-.]*")):
+                if os.path.basename(f) not in keep:
+                    os.remove(f)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(4, len(sources()) or 1)) as pool:

@@ -118,3 +118,65 @@ def test_mhsa_mesh_size_fixed_reference_fallback():
     assert torch.isfinite(got.float()).all()
     assert _rel(got, want) <= 2e-2
     assert float(_row_rel(got, want).max()) <= 3e-2
+
+
+def test_attention_forward_and_backward_repeat_bit_for_bit_with_a_second_process_on_the_gpu():
+    """Round 5: the D = 64 four-wave forward took its softmax reference from a register read in front of the wait states
+    behind the MFMAs writing it -- every result valid to rounding, so no parity test saw it, but WHICH value was read
+    depended on the wave's timing: with a second process computing on the same GPU 537-800 of 800 identical calls differed
+    in the last bit (alone: 0 of 60 000 on most boxes).  This is that experiment as a test: a child process runs a GEMM loop
+    on the GPU while identical calls of the attention forward (inference and training entry), its backward and a whole
+    Transformer block are compared bit for bit."""
+    import os
+    import select
+    import subprocess
+    import sys
+    import time
+
+    from anemoi_models_amd import autograd, ops
+    from anemoi_models_amd.layers.block import TransformerProcessorBlock
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = subprocess.Popen([sys.executable, os.path.join(root, "tools", "micro", "ops_repeat.py"), "linear", "200000"],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        deadline = time.time() + 240  # (the first import of torch on a fresh box takes minutes)
+        started = False
+        while time.time() < deadline and child.poll() is None:
+            ready, _, _ = select.select([child.stdout], [], [], 1.0)
+            if ready and "started" in child.stdout.readline():
+                started = True
+                break
+        assert started, "the contending process did not start computing"
+
+        s, h, d = 40962, 16, 64
+        c = h * d
+        g = torch.Generator().manual_seed(7)
+        qkv = torch.randn(s, 3 * c, generator=g)
+        qkv[:, :c] *= 1.6
+        qkv = qkv.bfloat16().to(DEV)
+        dout = torch.randn(s, c, generator=g).bfloat16().to(DEV)
+        first = ops.mhsa(qkv, 1, h, -1).clone()
+        x = qkv.clone().requires_grad_(True)
+        autograd.mhsa(x, 1, h, -1).backward(dout)
+        first_grad = x.grad.clone()
+        for it in range(150):
+            same_bits_or_last_bit_rows(ops.mhsa(qkv, 1, h, -1), first, f"inference forward, call {it}")
+            if it % 10 == 0:
+                x = qkv.clone().requires_grad_(True)
+                y = autograd.mhsa(x, 1, h, -1)
+                same_bits_or_last_bit_rows(y.detach(), first, f"training forward, call {it}")
+                y.backward(dout)
+                same_bits_or_last_bit_rows(x.grad, first_grad, f"backward, call {it}")
+
+        torch.manual_seed(3)
+        blk = TransformerProcessorBlock(1024, 4096, 16, "GELU", window_size=16, dropout_p=0.0).to(DEV).eval()
+        xb = (torch.randn(2 * 700, 1024, generator=g) * 0.8).bfloat16().to(DEV)
+        with torch.no_grad():
+            firstb = blk.native(xb, 2).clone()
+            for it in range(150):
+                same_bits_or_last_bit_rows(blk.native(xb, 2), firstb, f"Transformer block, call {it}")
+        assert child.poll() is None, "the contending process ended before the comparison did: no contention was applied"
+    finally:
+        child.kill()
+        child.wait()

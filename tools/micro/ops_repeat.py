@@ -30,6 +30,8 @@ else:                     # edge kernel: plain loads, no LDS
     f = lambda: ops.gt_edge_attention_folded(wide[:, c:2 * c], kv[:, :c], kv[:, c:], wide[:, :c], wide[:, 2 * c:], attr, plan.rowptr, plan.col, h, up,
                                              sched=plan.schedule(torch.bfloat16, c))
 ref = f().clone()
+torch.cuda.synchronize()
+print("started", flush=True)
 bad = 0
 worst = 0.0
 for it in range(iters):
