@@ -18,10 +18,10 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libanemoi_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
-# Sources with inline-asm MFMAs: their device listing is kept next to the object (lib/obj/<name>-hip-amdgcn-amd-amdhsa-gfx950.s,
+# Sources with inline-asm MFMAs or hand-padded wide stores: their device listing is kept next to the object (lib/obj/<name>-hip-amdgcn-amd-amdhsa-gfx950.s,
 # not shipped, not committed) so that tools/isa_hazard_audit.py -- and tests/test_host_logic.py -- can check that nothing
 # touches an MFMA result before its wait states have passed (hipcc pads nothing around such a statement).
-ASM_SOURCES = ("attention", "gemm", "weight_grad")
+ASM_SOURCES = ("attention", "gemm", "weight_grad", "edge_attention")
 
 
 def device_listing(name: str):
@@ -95,7 +95,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(LIB_DIR, "obj", os.path.basename(src)[:-4] + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
+        listed = os.path.basename(src)[:-4] not in ASM_SOURCES or device_listing(os.path.basename(src)[:-4]) is not None
+        if not force and listed and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
             return obj
         cmd = [hipcc, *FLAGS, f'-DANEMOI_HIPCC_VERSION="{version}"', "-c", src, "-o", obj]
         if os.path.basename(src)[:-4] in ASM_SOURCES:

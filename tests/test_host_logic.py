@@ -841,6 +841,22 @@ def test_isa_hazard_audit_reports_a_read_right_behind_its_mfma(tmp_path):
     ]) + "\n")
     found = audit.audit_operands(str(listing))
     assert [(f[1], f[3]) for f in found] == [(3, 2), (9, 7)], found
+    # third rule: the data registers of a wide buffer store with an SGPR soffset stay untouched for 2 wait states
+    listing.write_text("\n".join([
+        "_Z1kv:",
+        "\tbuffer_store_dwordx4 v[106:109], v104, s[0:3], s93 offen",
+        "\tv_mov_b32_e32 v107, 0",                                             # the very next instruction: reported
+        "\tbuffer_store_dwordx4 v[110:113], v104, s[0:3], s93 offen",
+        "\ts_nop 1",
+        "\tv_mov_b32_e32 v110, 0",                                             # behind 2 states: fine
+        "\tbuffer_store_dwordx4 v[114:117], v104, s[0:3], 0 offen",
+        "\tv_mov_b32_e32 v114, 0",                                             # no SGPR soffset: hipcc's own padding applies
+        "\tbuffer_store_dwordx2 v[118:119], v104, s[0:3], s93 offen",
+        "\tv_mov_b32_e32 v118, 0",                                             # 8 bytes: no hazard
+        "\ts_endpgm",
+    ]) + "\n")
+    found = audit.audit_stores(str(listing))
+    assert [(f[1], f[3]) for f in found] == [(2, 3)], found
 
 
 def test_no_mfma_result_is_touched_before_its_wait_states_in_the_built_kernels():
@@ -859,5 +875,7 @@ def test_no_mfma_result_is_touched_before_its_wait_states_in_the_built_kernels()
         assert not found, f"{name}.hip: {len(found)} early touches of an MFMA destination, first: {found[0]}"
         found = audit.audit_operands(path)
         assert not found, f"{name}.hip: {len(found)} MFMA operands written fewer than 2 wait states ahead, first: {found[0]}"
+        found = audit.audit_stores(path)
+        assert not found, f"{name}.hip: {len(found)} wide buffer stores whose data is overwritten too early, first: {found[0]}"
     if seen == 0:
         pytest.skip("no device listing in anemoi_models_amd/lib/obj (run __graft_entry__.build() from source)")
