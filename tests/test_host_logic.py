@@ -812,20 +812,40 @@ def test_isa_hazard_audit_reports_a_read_right_behind_its_mfma(tmp_path):
     audit = _audit_module()
     listing = tmp_path / "k.s"
     listing.write_text("\n".join([
-        "_Z1kv:",
-        "\tv_mfma_f32_32x32x16_bf16 v[16:31], v[56:59], a[0:3], v[16:31]",   # chain link: exempt ...
-        "\tv_mfma_f32_32x32x16_bf16 v[16:31], v[60:63], a[4:7], v[16:31]",   # ... and this one is read too early
-        "\tv_max_f32_e32 v16, v16, v16",
-        "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[56:59], a[0:3], 0",
+        "_Z1kv:",                                                               # line 1
+        "\t;;#ASMSTART",
+        "\tv_mfma_f32_32x32x16_bf16 v[16:31], v[56:59], a[0:3], v[16:31]",   # 3: chain link: exempt ...
+        "\t;;#ASMEND",
+        "\t;;#ASMSTART",
+        "\tv_mfma_f32_32x32x16_bf16 v[16:31], v[60:63], a[4:7], v[16:31]",   # 6: ... and this one is read too early
+        "\t;;#ASMEND",
+        "\tv_max_f32_e32 v16, v16, v16",                                      # 8
+        "\t;;#ASMSTART",
+        "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[56:59], a[0:3], 0",           # 10
+        "\t;;#ASMEND",
         "\ts_nop 15",
-        "\tv_max_f32_e32 v0, v0, v0",                                          # behind 16 states: fine
-        "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[56:59], v[60:63], a[0:3]",
+        "\tv_max_f32_e32 v0, v0, v0",                                         # 13: behind 16 states: fine
+        "\t;;#ASMSTART",
+        "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[56:59], v[60:63], a[0:3]",     # 15
+        "\t;;#ASMEND",
         "\ts_nop 3",
-        "\tv_accvgpr_read_b32 v1, a2",                                         # 4 states of 8: too early
+        "\tv_accvgpr_read_b32 v1, a2",                                        # 18: 4 states of 8: too early
+        "\ts_nop 15",
+        ".LBB0_1:",                                                             # a loop whose last product is read at its top
+        "\tv_add_f32_e32 v2, v40, v40",                                       # 21: read of v[32:47] through the back edge
+        "\ts_nop 15",
+        "\t;;#ASMSTART",
+        "\tv_mfma_f32_32x32x16_bf16 v[32:47], v[56:59], a[0:3], 0",          # 24
+        "\t;;#ASMEND",
+        "\ts_cbranch_scc1 .LBB0_1",
+        "\ts_nop 15",
+        "\tv_mfma_f32_32x32x16_bf16 v[48:63], v[56:59], v[60:63], v[48:63]",  # 28: compiler-generated on both sides:
+        "\tv_max_f32_e32 v3, v48, v48",                                       # 29: reported only with everything=True
         "\ts_endpgm",
     ]) + "\n")
     found = audit.audit(str(listing))
-    assert [(f[1], f[3]) for f in found] == [(3, 4), (8, 10)], found
+    assert [(f[1], f[3]) for f in found] == [(6, 8), (15, 18), (24, 21)], found
+    assert (28, 29) in [(f[1], f[3]) for f in audit.audit(str(listing), everything=True)]
     # second rule: a vector write needs 2 wait states before an MFMA reads it as an operand
     listing.write_text("\n".join([
         "_Z1kv:",

@@ -13,7 +13,11 @@ instruction, n + 1 per `s_nop n`, PASSES per intervening MFMA (the matrix pipe t
 Two more rules of the same kind are checked: a vector write fewer than 2 wait states ahead of an MFMA reading it as an
 operand, and a wide buffer store with an SGPR soffset whose data registers are overwritten within 2 wait states.
 
-  python tools/isa_hazard_audit.py file.s [kernel-name-substring]      exit code 1 if anything is reported
+Rule 1 follows branches (a product at the end of a loop body is read at the loop's top) and reports pairs with an inline-asm
+instruction on either side; `--all` adds the pairs of two compiler-generated instructions (hipcc pads those itself and, across
+taken branches, relies on the refetch time that a count of instructions does not see).
+
+  python tools/isa_hazard_audit.py file.s [kernel-name-substring] [--all]      exit code 1 if anything is reported
 """
 import re
 import sys
@@ -34,17 +38,31 @@ def passes(op):
     return 8 if "32x32" in op else 4
 
 
-def audit(path, only=None):
+def audit(path, only=None, everything=False):
     lines = open(path).read().split("\n")
     found = []
     fn = None
-    insts = []  # (function, line number, text)
+    insts = []   # (function, line number, text)
+    in_asm = set()  # line numbers of instructions inside an inline-asm statement
+    labels = {}  # (function, label) -> index of the first instruction behind it
+    asm = False
     for i, l in enumerate(lines):
         m = re.match(r"^(_Z\w+):", l)
         if m:
             fn = m.group(1)
+        if ";;#ASMSTART" in l:
+            asm = True
+        elif ";;#ASMEND" in l:
+            asm = False
+        elif asm:
+            in_asm.add(i + 1)
         t = l.split(";")[0].strip()
-        if not t or t.startswith(".") or t.endswith(":") or fn is None:
+        if not t or fn is None:
+            continue
+        if t.endswith(":"):
+            labels[(fn, t[:-1])] = len(insts)
+            continue
+        if t.startswith("."):
             continue
         insts.append((fn, i + 1, t))
     for k, (fn, ln, t) in enumerate(insts):
@@ -53,31 +71,52 @@ def audit(path, only=None):
         ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
         dst = regs(ops[0])
         need = 12 if passes(t) == 8 else 8
-        states = 0
-        for j in range(k + 1, len(insts)):
-            fn2, ln2, t2 = insts[j]
-            if fn2 != fn or states >= need:
-                break
-            op = t2.split()[0]
-            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
-                break
-            if op == "s_nop":
-                states += int(t2.split()[1]) + 1
-                continue
-            if op.startswith("v_mfma"):
-                o2 = [o.strip() for o in t2.split(None, 1)[1].split(",")]
-                chain = regs(o2[0]) == dst and regs(o2[3]) == dst and not (regs(o2[1]) | regs(o2[2])) & dst
-                if not chain and regs(t2) & dst:
+        # every path behind the MFMA, branches followed (a product at the end of a loop body is read at the loop's top)
+        work, seen = [(k + 1, 0)], set()
+        while work:
+            j, states = work.pop()
+            while j < len(insts) and states < need and (j, states) not in seen:
+                seen.add((j, states))
+                fn2, ln2, t2 = insts[j]
+                if fn2 != fn:
+                    break
+                op = t2.split()[0]
+                if op in ("s_endpgm", "s_setpc_b64"):
+                    break
+                if op == "s_branch" or op.startswith("s_cbranch"):
+                    target = labels.get((fn, t2.split()[1]))
+                    if target is not None:
+                        work.append((target, states + 1))
+                    if op == "s_branch":
+                        break
+                    states += 1
+                    j += 1
+                    continue
+                if op == "s_nop":
+                    states += int(t2.split()[1]) + 1
+                    j += 1
+                    continue
+                if op.startswith("v_mfma"):
+                    o2 = [o.strip() for o in t2.split(None, 1)[1].split(",")]
+                    chain = regs(o2[0]) == dst and regs(o2[3]) == dst and not (regs(o2[1]) | regs(o2[2])) & dst
+                    if not chain and regs(t2) & dst:
+                        found.append((fn, ln, t, ln2, t2, states))
+                    if chain:
+                        break  # the chain's next link is audited on its own
+                    states += passes(t2)
+                    j += 1
+                    continue
+                if op.startswith(("v_", "ds_", "buffer_", "global_", "flat_", "scratch_")) and regs(t2) & dst:
                     found.append((fn, ln, t, ln2, t2, states))
-                if chain:
-                    break  # the chain's next link is audited on its own
-                states += passes(t2)
-                continue
-            if op.startswith(("v_", "ds_", "buffer_", "global_", "flat_", "scratch_")) and regs(t2) & dst:
-                found.append((fn, ln, t, ln2, t2, states))
-                break
-            states += 1
-    return found
+                    break
+                states += 1
+                j += 1
+    # Pairs of two compiler-generated instructions are the compiler's business (its hazard recognizer pads them; across
+    # taken branches it relies on the refetch time, which this count of states does not see): only pairs with an inline-asm
+    # instruction on either side are reported unless everything is asked for.
+    if not everything:
+        found = [f for f in found if f[1] in in_asm or f[3] in in_asm]
+    return sorted(set(found), key=lambda f: (f[1], f[3]))
 
 
 def audit_operands(path, only=None):
@@ -151,8 +190,11 @@ def audit_stores(path, only=None):
 
 
 if __name__ == "__main__":
+    everything = "--all" in sys.argv
+    args = [a for a in sys.argv[1:] if a != "--all"]
+    sys.argv[1:] = args
     only = sys.argv[2] if len(sys.argv) > 2 else None
-    res = audit(sys.argv[1], only)
+    res = audit(sys.argv[1], only, everything)
     for fn, ln, t, ln2, t2, st in res[:40]:
         print(f"{fn[:60]}: line {ln}: {t}\n    touched after {st} wait state(s) by line {ln2}: {t2}")
     print(f"{len(res)} early touches of an MFMA destination in {sys.argv[1]}")
