@@ -94,6 +94,7 @@ def test_bench_self_launch_on_a_shared_gpu():
     assert len(out) == 1, res.stdout
     line = json.loads(out[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["parity_vs_single"]["finite"]
+    assert line["run_to_run_identical"] is True  # (the last timed output against two more steps)
     ex = line["exchanges"]
     assert ex["alone_us"]["processor"]["median"] > 0 and ex["in_step"]["exchanges"] >= 4  # 4 blocks (+ the decoder's)
     assert 0.0 <= ex["in_step"]["exposed_fraction_of_step"]
@@ -162,6 +163,7 @@ def test_bench_main_world_n_ranks_sharing_one_gpu(world, workload, extra):
     line = _last_json(outs[0][0])
     assert all(not [ln for ln in o[0].splitlines() if ln.startswith("{")] for o in outs[1:])  # rank 0 alone prints
     assert line["n_gpus"] == world and line["rccl_ranks"] == world and line["scaling"] == "strong"
+    assert line["run_to_run_identical"] is True
     pv = line["parity_vs_single"]
     assert pv["finite"] and pv["ranks_checked"] == world and pv["rows_checked"] > 0
     assert pv["max_rel_err"] <= pv["bound"], pv
