@@ -75,10 +75,28 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every ``csrc/*.hip`` for gfx950 and link the shared library.  Returns its path."""
+    """Compile every ``csrc/*.hip`` for gfx950 and link the shared library.  Returns its path.
+
+    One builder at a time: an exclusive ``flock`` on ``lib/.build.lock`` is held around the whole build and staleness is
+    re-checked under it, so the N ranks of ``bench.py --gpus N`` (or parallel test workers) that find the library stale at
+    once compile it once -- the others wait and then use it.  The link goes to a temporary name and is moved into place
+    atomically: no rank ever dlopens a half-written library."""
     if not force and not is_stale():
         return LIB_PATH
+    import fcntl
+
     os.makedirs(os.path.join(LIB_DIR, "obj"), exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():  # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
     version = _hipcc_version(hipcc)
     # objects of another compiler are never reused: anemoi_build_info() names ONE hipcc (the one the hand-counted wait
@@ -118,10 +136,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, len(sources()) or 1)) as pool:
         objs = list(pool.map(compile_one, sources()))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError(f"hipcc link failed:\n{res.stderr}")
+    os.replace(tmp, LIB_PATH)
     with open(stamp, "w") as f:
         f.write(version)
     return LIB_PATH

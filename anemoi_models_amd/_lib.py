@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -57,7 +57,7 @@ class GtBlockArgs(ctypes.Structure):
         ("stats_ws", c_void_p), ("stats_ws_bytes", c_int64),
         ("run_ptr", c_void_p), ("run_perm", c_void_p), ("n_runs", c_int64),
         ("sched", c_void_p), ("sched_slots", ctypes.c_int32), ("sched_steps", ctypes.c_int32), ("n_src", c_int64),
-        ("run_dst", c_void_p),
+        ("run_dst", c_void_p), ("n_edges", c_int64),
     ]
 
 class TfmBlockArgs(ctypes.Structure):
@@ -114,8 +114,8 @@ SIGNATURES = {
     "anemoi_edge_schedule_shape": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p]),
     "anemoi_gt_edge_attention_folded_sched": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                                       c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
-                                                      c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                                      c_int, c_int, c_void_p]),
+                                                      c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                                      c_int64, c_int, c_int, c_void_p]),
     "anemoi_linear_dual": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_int, c_int, c_void_p]),
     "anemoi_linear_actgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,

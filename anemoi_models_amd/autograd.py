@@ -53,6 +53,9 @@ class GradSink:
         self.width = n * k + (n if bias else 0)
         self.buf: Optional[Tensor] = None
         self.stacked_parts = stacked_parts  # how many parts ("w", "b") an _Unstack collects before the buffer is let go
+        # a bias part that no _Unstack collects goes to a LEAF parameter, whose AccumulateGrad would keep the 1-D view -- and
+        # with it the whole [count, N * K + N] buffer -- alive as ``.grad``: such a bias gradient is handed out as a copy
+        self.copy_bias = bias and stacked_parts < 2
         self._pending = 0
 
     def slot(self, i: int) -> Tensor:
@@ -64,7 +67,14 @@ class GradSink:
     def stacked(self, part: str, grads) -> Optional[Tensor]:
         """The stacked gradient of ``part`` ("w" / "b") if every block's gradient IS its slot of the buffer, else None."""
         buf = self.buf
-        if buf is None or len(grads) != self.count:
+        if buf is None:
+            return None
+        # this part is collected now, whichever way: when the last one is, the sink lets go of its buffer, so that a second
+        # backward over a retained graph gets fresh storage instead of slots that gradients already handed out still alias
+        self._pending -= 1
+        if self._pending <= 0:
+            self.buf = None
+        if len(grads) != self.count:
             return None
         off = 0 if part == "w" else self.n * self.k
         size = self.n * self.k if part == "w" else self.n
@@ -74,9 +84,6 @@ class GradSink:
                     or g.data_ptr() != buf.data_ptr() + (i * self.width + off) * esz):
                 return None
         out = buf[:, off:off + size]
-        self._pending -= 1
-        if self._pending <= 0:
-            self.buf = None
         return out.view(self.count, self.n, self.k) if part == "w" else out
 
 
@@ -124,12 +131,14 @@ _TORCH_ACT = {"GELU": torch.nn.functional.gelu, "SiLU": torch.nn.functional.silu
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: str, residual: Optional[Tensor],
-                prep: Optional[WeightPrep] = None):
+                prep: Optional[WeightPrep] = None, padded_input: bool = False):
         dtype = x.dtype
         k = weight.shape[1]
         kp = ops.round_up(k, ops.k_multiple(dtype))
-        if x.shape[1] > kp and x.shape[1] % ops.k_multiple(dtype) == 0 and prep is None:
-            kp = x.shape[1]  # rows that carry more (zero / constant) padding columns than the weight needs: zero weights meet them
+        if padded_input and prep is None and x.shape[1] == ops.round_up(k + 1, ops.k_multiple(dtype)):
+            # ``[features | 1 | 0-pad]`` rows (training._AssembleNodes): the constant column and the padding behind it meet
+            # zero weights.  Opt-in and for exactly that width -- any other width is a mis-wired call and raises below
+            kp = x.shape[1]
         if x.shape[1] not in (k, kp):
             raise ValueError(f"linear: x has {x.shape[1]} columns, weight expects {k}")
         xk = x if x.shape[1] == kp else ops.convert_pad(x, dtype, kp)
@@ -195,13 +204,15 @@ class _Linear(torch.autograd.Function):
             if want_b:
                 dw, db = ops.weight_grad(dpre, xk, k, want_bias=True, out=out)  # the bias gradient rides on dpre's transpose
                 dw = dw.to(weight.dtype)
+                if out is not None and prep.sink.copy_bias:
+                    db = db.clone()  # N floats; see GradSink.copy_bias
             else:
                 dw = ops.weight_grad(dpre, xk, k, out=out).to(weight.dtype)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_sum(dpre)
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dw, db, None, dres, None
+        return dx, dw, db, None, dres, None, None
 
 
 class _MLP2(torch.autograd.Function):
@@ -327,15 +338,17 @@ def layer_norm_skip(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5):
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: str = "Identity",
-           residual: Optional[Tensor] = None, prep: Optional[WeightPrep] = None) -> Tensor:
+           residual: Optional[Tensor] = None, prep: Optional[WeightPrep] = None, padded_input: bool = False) -> Tensor:
     """``act(x @ weight.T + bias) + residual`` with gradients for ``x``, ``weight``, ``bias`` and ``residual``.
     ``x`` / ``residual`` in the compute dtype (f32 or bf16), ``weight [N, K]`` / ``bias [N]`` f32 parameters.  ``act``
     outside the kernel's epilogues (Identity / GELU / SiLU / ReLU; the reference takes any ``torch.nn`` activation by
-    name): the product runs here, the activation as a torch module behind it."""
+    name): the product runs here, the activation as a torch module behind it.  ``x`` must have K columns (or K rounded up
+    to the slab); ``padded_input=True`` additionally admits ``[features | 1 | 0-pad]`` rows of exactly
+    ``round_up(K + 1, slab)`` columns (``training._AssembleNodes``); every other width raises ``ValueError``."""
     if act not in ("Identity", "GELU", "SiLU", "ReLU"):
-        y = getattr(torch.nn, act)()(_Linear.apply(x, weight, bias, "Identity", None, prep))
+        y = getattr(torch.nn, act)()(_Linear.apply(x, weight, bias, "Identity", None, prep, padded_input))
         return y if residual is None else y + residual
-    return _Linear.apply(x, weight, bias, act, residual, prep)
+    return _Linear.apply(x, weight, bias, act, residual, prep, padded_input)
 
 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tensor:

@@ -44,7 +44,7 @@ int run_tail(const anemoi_gt_block_args* a, anemoi_stream_t stream) {
   if (a->sched != nullptr && a->run_ptr == nullptr)
     st = anemoi_gt_edge_attention_folded_sched(a->dtype, a->q, a->ldq, a->k, a->v, a->ldkv, a->x_r, a->ldr, a->u, a->ldu,
                                                a->edge_attr, a->up, a->rowptr, a->col, a->sched, a->sched_slots, a->sched_steps,
-                                               a->n_src, a->att, a->ld_att, nullptr, a->n_dst, a->C, a->H, stream);
+                                               a->n_src, a->n_edges, a->att, a->ld_att, nullptr, a->n_dst, a->C, a->H, stream);
   else if (a->run_ptr != nullptr && a->run_dst != nullptr)
     st = anemoi_gt_edge_attention_folded_groups(a->dtype, a->q, a->ldq, a->k, a->v, a->ldkv, a->x_r, a->ldr, a->u, a->ldu,
                                                 a->edge_attr, a->up, a->rowptr, a->col, a->run_ptr, a->run_dst, a->run_perm,

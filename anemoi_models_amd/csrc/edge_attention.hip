@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void gt_edge_attention_folded_sched_kernel(con
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float scaled = acc[i >> 1][i & 1] * inv;
-        o[i] = scaled + r[i];
+        o[i] = p.xr != nullptr ? scaled + r[i] : scaled;  // (no x_r: no add at all -- a -0.0 sum stays -0.0, as in the plain kernel)
       }
     }
     const int out_row = (int)((uint32_t)node * o_row_bytes);
@@ -1569,12 +1569,13 @@ extern "C" int anemoi_gt_edge_attention_folded_sched(int dtype, const void* q, i
                                                      int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
                                                      const float* edge_attr, int up, const int32_t* rowptr,
                                                      const int32_t* col, const int32_t* sched, int slots, int steps,
-                                                     int64_t n_src, void* out, int64_t ldo, float* lse, int64_t n_dst, int C,
-                                                     int H, anemoi_stream_t stream) {
-  // the kernel addresses rows as 32-bit byte offsets from the matrix bases (buffer loads): every matrix below 4 GiB
+                                                     int64_t n_src, int64_t n_edges, void* out, int64_t ldo, float* lse,
+                                                     int64_t n_dst, int C, int H, anemoi_stream_t stream) {
+  // the kernel addresses rows as 32-bit byte offsets from the matrix bases (buffer loads): every matrix below 4 GiB, the
+  // attribute matrix [n_edges, up] f32 included (n_edges = rowptr[n_dst] lives on the device: the caller states it)
   const int64_t lim = (int64_t)1 << 32;
   const bool fits = n_src > 0 && n_src * ldkv * 2 < lim && n_dst * ldq * 2 < lim && n_dst * ldu * 2 < lim && n_dst * ldo * 2 < lim &&
-                    (x_r == nullptr || n_dst * ldr * 2 < lim);
+                    (x_r == nullptr || n_dst * ldr * 2 < lim) && n_edges > 0 && n_edges * (int64_t)up * 4 < lim;
   const bool plain = sched == nullptr || dtype != ANEMOI_BF16 || H <= 0 || C % H != 0 || !((C / H) == 64 || (C / H) == 32) ||
                      !(up == 4 || up == 8 || up == 12 || up == 16) || n_dst == 0 || !fits;
   if (plain)

@@ -397,10 +397,11 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
             a.run_ptr, a.run_perm, a.n_runs = runs[0].data_ptr(), runs[1].data_ptr(), runs[0].shape[0] - 1
             if len(runs) == 3:  # groups: the destination list, and the row count of k / v for the 4-GiB check
                 a.run_dst, a.n_src = runs[2].data_ptr(), k.shape[0]
-        elif edge_attr_csr.shape[0] * up * 4 < 2**32:
+        else:  # (beyond 32-bit attribute-row offsets the entry point takes the plain kernel by itself: n_edges states the size)
             sched = edge_schedule(plan, q)
             if sched is not None:
                 a.sched, a.sched_slots, a.sched_steps, a.n_src = sched.data_ptr(), sched.shape[1], sched.shape[2], k.shape[0]
+                a.n_edges = edge_attr_csr.shape[0]
         a.att, a.ld_att = att.data_ptr(), wp.shape[1]
         a.w_proj, a.b_proj = wp.data_ptr(), ops._ptr(bp)
         a.res, a.ld_res, a.y, a.y_stats = res.data_ptr(), ops._ld(res), y.data_ptr(), stats[0].data_ptr()

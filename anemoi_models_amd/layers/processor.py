@@ -223,7 +223,7 @@ class _BlockAbiPlan:
             return self
         from .block import edge_schedule
 
-        sched = edge_schedule(plan, x) if ea.shape[0] * up * 4 < 2**32 else None
+        sched = edge_schedule(plan, x)  # (n_edges below: the entry point declines it beyond 32-bit attribute-row offsets)
         self.keep = [operands, ea, plan, sched]  # the packed weights, edge attributes, CSR and schedule the templates point at
         self.dims = (n, c, h, up, n_in, k_proj, hidden)
         lib = _lib.load()
@@ -245,6 +245,7 @@ class _BlockAbiPlan:
             a.edge_attr, a.rowptr, a.col = ea.data_ptr(), plan.rowptr.data_ptr(), plan.col.data_ptr()
             if sched is not None:
                 a.sched, a.sched_slots, a.sched_steps, a.n_src = sched.data_ptr(), sched.shape[1], sched.shape[2], plan.n_src
+                a.n_edges = ea.shape[0]
             a.ld_att = k_proj
             a.w_proj = o["w_proj"].data_ptr()
             a.b_proj = None if o["b_proj"] is None else o["b_proj"].data_ptr()

@@ -338,7 +338,7 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
                 0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
                 rowptr.data_ptr(), col.data_ptr(), run_ptr.data_ptr(), perm.data_ptr(), run_ptr.shape[0] - 1,
                 out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
-        elif sched is not None and col.shape[0] * up * 4 < 2**32:
+        elif sched is not None:  # (the entry point itself falls back to the plain kernel beyond 32-bit row offsets)
             _dev(sched)
             if sched.dtype != torch.int32 or sched.dim() != 3 or sched.shape[0] != 8 or not sched.is_contiguous():
                 raise ValueError("gt_edge_attention_folded: sched = contiguous int32 [8, slots, steps]")
@@ -346,7 +346,7 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
                 dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
                 0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
                 rowptr.data_ptr(), col.data_ptr(), sched.data_ptr(), sched.shape[1], sched.shape[2], _rows(k).shape[0],
-                out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
+                col.shape[0], out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
         else:
             st = _lib.load().anemoi_gt_edge_attention_folded(
                 dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),

@@ -239,12 +239,12 @@ def gt_mapper(mapper, x_src: Tensor, x_dst: Tensor, batch_size: int, src_map: Op
             raw_src, emb.weight, emb.bias, gamma, beta, eps, w, b, augmented=augmented)
         hs = None
     elif hasattr(mapper, "emb_nodes_src"):
-        hs = autograd.linear(hs, mapper.emb_nodes_src.weight, mapper.emb_nodes_src.bias)
+        hs = autograd.linear(hs, mapper.emb_nodes_src.weight, mapper.emb_nodes_src.bias, padded_input=augmented)
     if hd.shape[0] > (0 if hs is None else hs.shape[0]) and hs is not None and can_fold(mapper.emb_nodes_dst):
         raw_dst, emb_d = hd, mapper.emb_nodes_dst
         sq_fn = lambda w, b, gamma, beta: autograd.folded_embedding_ln_linear(  # noqa: E731
             raw_dst, emb_d.weight, emb_d.bias, gamma, beta, eps, w, b, augmented=augmented)
-    hd = autograd.linear(hd, mapper.emb_nodes_dst.weight, mapper.emb_nodes_dst.bias)
+    hd = autograd.linear(hd, mapper.emb_nodes_dst.weight, mapper.emb_nodes_dst.bias, padded_input=augmented)
     y = autograd.gt_mapper_block(hs, hd, _block_sd(blk), "b", ea, plan, blk.num_heads, blk.activation, eps,
                                  kv_fn=kv_fn, sq_fn=sq_fn)
     ext = getattr(mapper, "node_data_extractor", None)

@@ -48,9 +48,26 @@ LATENT_BOUND = {"bf16": 2e-2, "fp32": 1e-3}
 # test hook (tests/test_bench_contract.py): scales every parity bound, so that the "a failed comparison prints ONE error line
 # and no result line" contract can be exercised on a healthy build
 _BOUND_SCALE = float(os.environ.get("ANEMOI_AMD_BENCH_PARITY_BOUND_SCALE", "1"))
+if not 0.0 < _BOUND_SCALE <= 1.0:  # the hook can only TIGHTEN the gates: a relaxed gate must never print a normal line
+    raise SystemExit(f"ANEMOI_AMD_BENCH_PARITY_BOUND_SCALE={_BOUND_SCALE}: only factors in (0, 1] are accepted")
 if _BOUND_SCALE != 1.0:
     PARITY_BOUND = {k: v * _BOUND_SCALE for k, v in PARITY_BOUND.items()}
     LATENT_BOUND = {k: v * _BOUND_SCALE for k, v in LATENT_BOUND.items()}
+
+def host_threads() -> int:
+    """Threads the CPU oracle may use: the affinity mask, cut by a cgroup CPU quota when the box has one (the GPU boxes of
+    this pool show 256 logical CPUs and a quota of 16: 128 torch threads on them are slower than 16, and "cores": 128 would
+    misstate what the baseline ran on)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
 
 WORKLOADS = {
     # name: (graph, channels, processor blocks, heads, description)
@@ -80,17 +97,21 @@ def parse_args():
     ap.add_argument("--detail", action="store_true", help="print a per-shape kernel table to stderr")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay the forward as one captured HIP graph (single GPU; pays off on the small workloads)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the 'secondary' block of the default line (Transformer processor @ config 3 with the mesh "
+                         "attention's MFMA roofline, config 2, config 5: 5 steps each, behind the timed region)")
     return ap.parse_args()
 
 
-def build(workload: str, device, processor: str = "GraphTransformer"):
+def build(workload: str, device, processor: str = "GraphTransformer", graph=None):
     from anemoi_models_amd.graphs.synthetic import build_graph
     from anemoi_models_amd.models import AnemoiModelEncProcDec
     from anemoi_models_amd.utils.indices import SimpleDataIndices
     from anemoi_models_amd.utils.presets import model_config
 
     graph_name, channels, layers, heads, _ = WORKLOADS[workload]
-    graph = build_graph(graph_name)
+    if graph is None:
+        graph = build_graph(graph_name)
     idx = SimpleDataIndices(n_prognostic=80, n_forcing=10, n_diagnostic=0)
     torch.manual_seed(1234)
     with torch.device(device):  # random-init the weights directly in HBM
@@ -334,6 +355,9 @@ def cpu_baseline(model, graph, x, idx, n_blocks: int, hip_latent=None, hip_y=Non
 
     from oracle import reference_path as ref  # checker / baseline only
 
+    if "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(host_threads())
+
     sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in model.state_dict().items()}
     data, hidden = model._graph_name_data, model._graph_name_hidden
 
@@ -413,6 +437,69 @@ def cpu_baseline(model, graph, x, idx, n_blocks: int, hip_latent=None, hip_y=Non
         **({"parity": parity} if parity else {}),
         **({"parity_fp32": parity_fp32} if parity_fp32 else {}),
     }
+
+
+SECONDARY_LEGS = (
+    # name, workload, processor, (steps, warm-ups): the north star's MHSA clause and BASELINE configs 2 / 5 inside the
+    # driver's own line (the O96-sized legs are 3 - 7 ms per step: 20 of them, so that the figure is not launch jitter)
+    ("transformer_cfg3", "cfg3", "Transformer", (5, 2)),
+    ("cfg2", "cfg2", "GraphTransformer", (20, 5)),
+    ("cfg5_gnn", "cfg2", "GNN", (20, 5)),
+)
+
+
+def secondary_leg(workload: str, processor: str, device, dtype_name: str, graph=None, steps: int = 5, warmup: int = 2):
+    """One secondary workload of the default line: ``warmup`` + ``steps`` forwards bracketed by device syncs, then one
+    instrumented forward for its roofline objects (same definitions as the headline's).  Reference for the Transformer leg:
+    layers/attention.py:67-112 (mesh-node MultiHeadSelfAttention), 4 * S^2 * C flops per layer against the bf16 MFMA peak."""
+    model, graph, x, _ = build(workload, device, processor, graph)
+    n_mesh, layers = graph["hidden"].num_nodes, WORKLOADS[workload][2]
+    with torch.no_grad():
+        for _ in range(warmup):
+            y = model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = model(x)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    if not bool(torch.isfinite(y).all()):
+        raise RuntimeError("non-finite output")
+    extra = profile_pass(model, x, None, dtype_name, traffic_ok=False)
+    keep = ("frac", "achieved", "unit", "bound", "avg_launch_ms", "launches", "frac_executed")
+    out = {"workload": WORKLOADS[workload][4].replace("GT blocks", f"{processor} blocks") if processor != "GraphTransformer"
+           else WORKLOADS[workload][4], "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+           "value": round(n_mesh * layers / (ms * 1e-3), 1), "unit": "mesh-node updates/s"}
+    for key, val in extra.items():
+        if key.startswith("roofline"):
+            out[key] = {k: v for k, v in val.items() if k in keep}
+    out["kernel_time_ms"] = dict(list(extra.get("kernel_time_ms", {}).items())[:4])
+    del model, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_block(device, dtype_name: str, graph_cfg3=None):
+    """``secondary`` of the default line.  A leg that fails reports ``{"error": ...}`` under its own name and never removes
+    the headline; ``ANEMOI_AMD_BENCH_SECONDARY`` (comma-separated leg names) restricts the legs (tests)."""
+    only = os.environ.get("ANEMOI_AMD_BENCH_SECONDARY")
+    only = None if only is None else {n.strip() for n in only.split(",") if n.strip()}
+    out = {}
+    for name, workload, processor, (steps, warmup) in SECONDARY_LEGS:
+        if only is not None and name not in only:
+            continue
+        try:
+            out[name] = secondary_leg(workload, processor, device, dtype_name, graph_cfg3 if workload == "cfg3" else None,
+                                      steps, warmup)
+        except BaseException as exc:  # noqa: BLE001 -- a secondary leg must never cost the headline
+            if isinstance(exc, (KeyboardInterrupt, SystemExit)):
+                raise
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.empty_cache()
+    out["note"] = ("each leg: warm-ups, then `steps` timed forwards (device-synchronised wall time) and one instrumented forward "
+                   "for its roofline objects, run AFTER the headline's timed region and its CPU baseline, the config-3 model "
+                   "freed first")
+    return out
 
 
 class Stage:
@@ -753,6 +840,13 @@ def _run(stage, args) -> int:
         if parity_vs_single is not None and not (parity_vs_single["finite"] and parity_vs_single["max_rel_err"] <= bound):
             failure = {"error": f"parity: partitioned forward differs from the single-GPU forward by "
                                 f"{parity_vs_single['max_rel_err']:.3e} (bound {bound:g})", "parity_vs_single": parity_vs_single}
+        if (failure is None and world == 1 and not args.no_secondary and args.workload == "cfg3" and args.dtype == "bf16"
+                and args.processor == "GraphTransformer" and args.rollout == 1 and not args.hipgraph):
+            stage[0] = "secondary"
+            graph_cfg3 = graph
+            del model, x, graphed, y_timed
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_block(device, args.dtype, graph_cfg3)
         if failure is None:
             print(json.dumps(line), flush=True)
     stage[0] = "teardown"

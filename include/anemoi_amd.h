@@ -214,15 +214,16 @@ int anemoi_gt_edge_attention_folded_groups(int dtype, const void* q, int64_t ldq
  *     destination's first loads (2 U row gathers, attribute rows, q / u / x_r) are in flight under one wait.
  * sched: int32 [8][slots][steps], XCD x's lists hold every destination of [n_dst x / 8, n_dst (x + 1) / 8) exactly once,
  * each list ends with at least three -1; slots / steps as anemoi_edge_schedule_shape returns them for (dtype, n_dst, C).
- * bf16 with 32- or 64-channel heads and every operand matrix below 4 GiB; other cases (or sched == NULL) run the plain kernel.
+ * bf16 with 32- or 64-channel heads and every operand matrix -- the attribute matrix [n_edges, up] f32 included, n_edges =
+ * rowptr[n_dst] stated by the caller -- below 4 GiB; other cases (or sched == NULL, or n_edges <= 0) run the plain kernel.
  * anemoi_models_amd/runtime.py::EdgePlan.schedule builds the lists.
  */
 int anemoi_edge_schedule_shape(int dtype, int64_t n_dst, int C, int* slots, int* steps);
 int anemoi_gt_edge_attention_folded_sched(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                                           const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
                                           int up, const int32_t* rowptr, const int32_t* col, const int32_t* sched, int slots,
-                                          int steps, int64_t n_src, void* out, int64_t ldo, float* lse, int64_t n_dst, int C,
-                                          int H, anemoi_stream_t stream);
+                                          int steps, int64_t n_src, int64_t n_edges, void* out, int64_t ldo, float* lse,
+                                          int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
  * GraphTransformerConv with explicit per-edge features (the callable the reference exposes, layers/conv.py:98-142):
@@ -574,6 +575,9 @@ typedef struct anemoi_gt_block_args {
   /* optional (NULL: run_ptr / run_perm are the consecutive runs above): run_ptr / run_perm / run_dst are the GROUP lists of
    * anemoi_gt_edge_attention_folded_groups (groups of 1 .. 8 destinations out of run_dst, run_perm per destination; n_src set) */
   const int32_t* run_dst;
+  /* rowptr[n_dst], stated by the caller: the scheduled kernel addresses attribute rows by 32-bit byte offsets and is taken
+   * only when n_edges * up * 4 < 2^32 (<= 0: not stated, plain kernel) */
+  int64_t n_edges;
 } anemoi_gt_block_args;
 int anemoi_gt_block_tail(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* args, anemoi_stream_t stream);

@@ -18,6 +18,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+from bench import host_threads  # noqa: E402  (affinity mask cut by the cgroup CPU quota)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    torch.set_num_threads(host_threads())
+    yield
+
+
 def load_npz(name):
     with np.load(os.path.join(GOLDEN, name)) as z:
         return {k: torch.from_numpy(z[k]) for k in z.files}

@@ -173,3 +173,55 @@ def test_bench_main_world_n_ranks_sharing_one_gpu(world, workload, extra):
     assert line["halo"]["own_mesh_rows"] > 0 and "DEBUG" in line["config"]["parallelism"]
     ex = line["exchanges"]  # per-exchange timing: every halo all-to-all-v alone, and start / exposed wait inside a step
     assert set(ex["alone_us"]) >= {"processor"} and ex["in_step"]["exchanges"] > 0
+
+
+def test_bench_refuses_a_relaxed_parity_gate():
+    """``ANEMOI_AMD_BENCH_PARITY_BOUND_SCALE`` exists for the test above and can only TIGHTEN the gates: a factor above 1
+    ends the run before anything is measured -- a line printed under a relaxed gate would look like any other line."""
+    res = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0", "--workload", "cfg1"], capture_output=True,
+                         text=True, timeout=600, env=dict(os.environ, ANEMOI_AMD_BENCH_PARITY_BOUND_SCALE="10"))
+    assert res.returncode != 0 and "only factors in (0, 1]" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_secondary_legs_never_raise():
+    """``secondary`` (round 6: the Transformer processor @ config 3 with the mesh attention's roofline, config 2, config 5
+    inside the default line): a leg that fails -- here every leg, the CPU container has no device -- reports its error under
+    its own name; the block itself never raises, so it can never cost the headline."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU (the GPU boxes run test_bench_secondary_block_on_the_gpu)")
+    sys.path.insert(0, ROOT)
+    import bench
+
+    os.environ["ANEMOI_AMD_BENCH_SECONDARY"] = "cfg2"
+    try:
+        out = bench.secondary_block(torch.device("cuda", 0), "bf16")
+    finally:
+        del os.environ["ANEMOI_AMD_BENCH_SECONDARY"]
+    assert set(out) == {"cfg2", "note"} and "error" in out["cfg2"]
+    assert [leg[0] for leg in bench.SECONDARY_LEGS] == ["transformer_cfg3", "cfg2", "cfg5_gnn"]
+
+
+@pytest.mark.gpu
+def test_bench_secondary_block_on_the_gpu(monkeypatch):
+    """The two O96-sized legs of ``secondary`` as the default line runs them (config 2 and config 5; the Transformer leg at
+    config 3 is the same function on the larger graph and rides in the driver's own bench run): step time, value and the
+    roofline objects of each leg -- the fused Linear's MFMA fraction for both, the edge kernel's HBM fraction for config 2."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    monkeypatch.setenv("ANEMOI_AMD_BENCH_SECONDARY", "cfg2,cfg5_gnn")
+    out = bench.secondary_block(torch.device("cuda", 0), "bf16")
+    assert set(out) == {"cfg2", "cfg5_gnn", "note"}
+    for name in ("cfg2", "cfg5_gnn"):
+        leg = out[name]
+        assert "error" not in leg, leg
+        assert 0.5 < leg["ms_per_step"] < 100.0 and leg["value"] > 0 and leg["steps"] == 20
+        assert 0.0 < leg["roofline"]["frac"] < 1.0 and leg["roofline"]["bound"] == "mfma"
+    assert 0.0 < out["cfg2"]["roofline_edge"]["frac"] < 1.0 and out["cfg2"]["roofline_edge"]["bound"] == "hbm"
+    json.dumps(out)  # serialisable as it is
