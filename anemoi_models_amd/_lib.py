@@ -58,6 +58,9 @@ class GtBlockArgs(ctypes.Structure):
         ("run_ptr", c_void_p), ("run_perm", c_void_p), ("n_runs", c_int64),
         ("sched", c_void_p), ("sched_slots", ctypes.c_int32), ("sched_steps", ctypes.c_int32), ("n_src", c_int64),
         ("run_dst", c_void_p), ("n_edges", c_int64),
+        ("tile_hdr", c_void_p), ("tile_dst", c_void_p), ("tile_src", c_void_p), ("tile_slot", c_void_p), ("tile_xcd", c_void_p),
+        ("tile_max_per_xcd", ctypes.c_int32), ("tile_src_cap", ctypes.c_int32), ("tile_edge_cap", ctypes.c_int32),
+        ("tile_pad", ctypes.c_int32),
     ]
 
 class TfmBlockArgs(ctypes.Structure):
@@ -116,6 +119,11 @@ SIGNATURES = {
                                                       c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                                       c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p,
                                                       c_int64, c_int, c_int, c_void_p]),
+    "anemoi_gt_edge_attention_folded_tiles": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                                      c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                      c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                                      c_void_p]),
     "anemoi_linear_dual": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_int, c_int, c_void_p]),
     "anemoi_linear_actgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,

@@ -530,7 +530,7 @@ def _edge_forward_lists(plan, q: Tensor) -> dict:
     from .layers.block import edge_runs, edge_schedule
 
     runs = edge_runs(plan, q.dtype)
-    return {"runs": runs, "sched": None if runs is not None else edge_schedule(plan, q)}
+    return {"runs": runs, "sched": None if runs is not None else edge_schedule(plan, q)}  # (the tile kernel: inference route)
 
 
 class _GTEdgeAttention(torch.autograd.Function):

@@ -21,6 +21,10 @@
 
 #include "common.hpp"
 
+#ifndef ANEMOI_LAB_MHSA8_PAD
+#define ANEMOI_LAB_MHSA8_PAD 0  // lab switch: full wait states behind the eight-wave kernel's S^T products (see there)
+#endif
+
 namespace anemoi {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8_t;
@@ -292,6 +296,13 @@ __global__ __launch_bounds__(512, (ATT_D == 32 && !DROP) ? 4 : 2) void mhsa_bf16
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
           s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[qb][ks], s_acc, 0, 0, 0);
+#if ANEMOI_LAB_MHSA8_PAD
+        // lab (round 6, tools/isa_hazard_audit.py --all): hipcc leaves 5 ... 9 counted states between this product and its
+        // first reader on the paths that cross taken branches (the unmasked fast path); padded here to the full 12
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 3" : "+v"(s_acc));  // (s_acc an operand: its readers stay below)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- online softmax in the log2 domain; register r <-> key key0 + (r & 7) + 16 (r >> 3).
         //      VALU budget per element: max, fma, exp2, add (the scale rides in the fma); masking only on tiles that
         //      touch the sequence end / window edge (wave-uniform test); O is rescaled only when the max grew.

@@ -41,7 +41,13 @@ int check_args(const anemoi_gt_block_args* a, const char* who, bool with_input) 
 
 int run_tail(const anemoi_gt_block_args* a, anemoi_stream_t stream) {
   int st;
-  if (a->sched != nullptr && a->run_ptr == nullptr)
+  if (a->tile_hdr != nullptr && a->run_ptr == nullptr)
+    st = anemoi_gt_edge_attention_folded_tiles(a->dtype, a->q, a->ldq, a->k, a->v, a->ldkv, a->x_r, a->ldr, a->u, a->ldu,
+                                               a->edge_attr, a->up, a->rowptr, a->col, a->tile_hdr, a->tile_dst, a->tile_src,
+                                               a->tile_slot, a->tile_xcd, a->tile_max_per_xcd, a->tile_src_cap,
+                                               a->tile_edge_cap, a->n_src, a->n_edges, a->att, a->ld_att, nullptr, a->n_dst,
+                                               a->C, a->H, stream);
+  else if (a->sched != nullptr && a->run_ptr == nullptr)
     st = anemoi_gt_edge_attention_folded_sched(a->dtype, a->q, a->ldq, a->k, a->v, a->ldkv, a->x_r, a->ldr, a->u, a->ldu,
                                                a->edge_attr, a->up, a->rowptr, a->col, a->sched, a->sched_slots, a->sched_steps,
                                                a->n_src, a->n_edges, a->att, a->ld_att, nullptr, a->n_dst, a->C, a->H, stream);

@@ -739,6 +739,293 @@ static void launch_folded_sched(const EdgeFoldParams& p, const int32_t* sched, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Folded path, LDS TILES (round 6).  The scheduled kernel above is bound by the CU's texture-address unit: every edge
+// gathers its k and v row slices again (32 cycles of that unit per 16-byte-per-lane wave load), although on a mesh in
+// Morton order ~25 consecutive destinations name only ~70 distinct sources for their ~200 edges.  Here a workgroup takes one
+// TILE -- a run of <= 32 consecutive destinations, host-built (runtime.EdgeTiles) -- and one 128-channel slice, stages the
+// k|v slices of the tile's distinct sources ONCE in LDS by LDS-DMA (4 sources per 1-KiB piece), the tile's attribute rows
+// (one contiguous block of the CSR-ordered matrix), the LDS slot byte of every edge and the destination list behind them,
+// and then computes: a wave walks a PASS of four destinations at once, one per 16-lane row (16 lanes x 8 channels = the
+// slice), each row with its own edge range; per edge the scheduled kernel's arithmetic with ds_read_b128 in place of the
+// gathers.  Per destination the edge order, the batches of U = 4 and every operation are those of the plain kernel: the
+// results are bit-identical (test_gt_edge_attention_folded_tiles_is_the_plain_kernel_bit_for_bit).  Passes (heavy
+// destinations first) are dealt to the four waves by an LDS ticket; which wave computes a destination changes nothing.
+//   hdr  [n_tiles][8]     e0, n_edges, src_off, n_src, slot_off (16-byte aligned), n_dst of the tile
+//   dst  [n_tiles][32][2] per (pass, row): destination (-1: none), (first edge - e0) << 8 | in-degree
+//   LDS: k slices [src_cap][256 B] | v slices [src_cap][256 B] | attribute rows [edge_cap][UP x 4 B] | slots [edge_cap] |
+//        destination list [256 B] | ticket
+// ---------------------------------------------------------------------------------------------
+struct EdgeTileLists {
+  const int32_t* hdr;
+  const int32_t* dst;
+  const int32_t* src;
+  const uint8_t* slot;
+  const int32_t* xcd;
+  int src_cap, edge_cap;
+  int64_t n_src;
+};
+
+template <typename T, int LPH, int UP>
+__global__ __launch_bounds__(256) void gt_edge_attention_folded_tiles_kernel(const EdgeFoldParams p,
+                                                                         const float* __restrict__ attr_,
+                                                                         const EdgeTileLists tl) {
+  constexpr int VEC = 8, U = 4;
+  using Raw = typename RawVec<T, VEC>::type;
+  constexpr int APL = attrs_per_lane(UP, LPH);
+  static_assert(sizeof(T) == 2 && UP % APL == 0 && APL * LPH >= UP, "bf16; a lane owns APL whole attributes or none");
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  constexpr int VP = VEC / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int idx = (int)(blockIdx.x >> 3);
+  const int slice = idx % p.n_slices;
+  const int ti = tl.xcd[xcd] + idx / p.n_slices;
+  if (ti >= tl.xcd[xcd + 1]) return;
+  const int32_t* hd = tl.hdr + (int64_t)ti * 8;
+  const int e0 = hd[0], ne = hd[1], so = hd[2], ns = hd[3], slot_off = hd[4], nd = hd[5];
+  const int n_pass = (nd + 3) >> 2;
+
+  char* const ks = smem;
+  char* const vs = ks + tl.src_cap * 256;
+  char* const as = vs + tl.src_cap * 256;
+  char* const ss = as + tl.edge_cap * (UP * 4);
+  char* const ds = ss + tl.edge_cap;  // (edge_cap is a multiple of 16)
+  int* const ticket = reinterpret_cast<int*>(ds + 256);
+
+  const int row = lane >> 4, l16 = lane & 15;
+  const int gls = slice * 16 + l16;  // the lane's channel group in the whole row
+  const int head = gls / LPH;
+  const int a0 = (gls % LPH) * APL;
+  const bool a_own = a0 < UP;
+  const int a_ld = a_own ? a0 : 0;
+  const float amask = a_own ? 1.f : 0.f;
+  const int lane_off = gls * VEC * (int)sizeof(T);  // the lane's byte offset inside a node row
+  const uint32_t row_bytes = (uint32_t)(p.ldkv * (int64_t)sizeof(T));
+  const uint32_t q_row_bytes = (uint32_t)(p.ldq * (int64_t)sizeof(T)), u_row_bytes = (uint32_t)(p.ldu * (int64_t)sizeof(T));
+  const uint32_t xr_row_bytes = (uint32_t)(p.ldr * (int64_t)sizeof(T)), o_row_bytes = (uint32_t)(p.ldo * (int64_t)sizeof(T));
+  const int u_off = (head * UP + a_ld) * (int)sizeof(T);
+  const int t_off = (p.C + head * UP + a0) * (int)sizeof(T);
+
+  // ---- staging: everything the tile's edges read, once
+  {
+    const __amdgpu_buffer_rsrc_t krs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.k), 0, (int)(tl.n_src * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.v), 0, (int)(tl.n_src * row_bytes), 0x00020000);
+    for (int i = wid; 4 * i < ns; i += 4) {  // piece i: the slices of sources 4 i .. 4 i + 3, one per 16-lane row
+      const int sidx = 4 * i + row;
+      const int id = sidx < ns ? tl.src[so + sidx] : -1;
+      const int voff = id >= 0 ? (int)((uint32_t)id * row_bytes) + lane_off : (int)0x7ffffff0;  // (no source: out of range, zeros)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(ks + i * 1024), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(vs + i * 1024), 16, voff, 0, 0, 0);
+    }
+    const int abytes = ne * (UP * 4);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(attr_) + (int64_t)e0 * UP, 0, abytes, 0x00020000);
+    for (int j = wid; j * 1024 < abytes; j += 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(as + j * 1024), 16, lane * 16,
+                                               j * 1024, 0, 0);
+    if (wid == 0) {
+      const __amdgpu_buffer_rsrc_t srs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tl.slot) + slot_off, 0, (ne + 3) & ~3, 0x00020000);
+      for (int j = 0; j * 256 < ne; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (__attribute__((address_space(3))) void*)(ss + j * 256), 4, lane * 4,
+                                                 j * 256, 0, 0);
+    }
+    if (wid == 1) {
+      const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<int32_t*>(tl.dst) + (int64_t)ti * 64, 0, 256, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (__attribute__((address_space(3))) void*)ds, 4, lane * 4, 0, 0, 0);
+    }
+    if (threadIdx.x == 0) *ticket = 4;  // passes 0 .. 3 are the waves' first ones
+  }
+
+  const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.q), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.u), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xr), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, -1, 0x00020000);
+
+  // a pass's per-destination operands, requested as raw words (converted at first use)
+  struct PassIn {
+    int node, pk;
+    u32x4_t q, xr;
+    RawWords<T, APL> u;
+  };
+  auto fetch = [&](int node, int pk, PassIn& in) __attribute__((always_inline)) {
+    in.node = node;
+    in.pk = pk;
+    in.q = u32x4_t{0u, 0u, 0u, 0u};
+    in.xr = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < RawWords<T, APL>::W; ++i) in.u.w[i] = 0u;
+    if (node >= 0) {
+      in.q = __builtin_amdgcn_raw_buffer_load_b128(qrs, (int)((uint32_t)node * q_row_bytes) + lane_off, 0, 2);
+      buffer_load_words<RawWords<T, APL>::W>(urs, (int)((uint32_t)node * u_row_bytes) + u_off, 0, in.u.w);
+      if (p.xr != nullptr)
+        in.xr = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((uint32_t)node * xr_row_bytes) + lane_off, 0, 2);
+    }
+  };
+
+  PassIn cur;
+  {
+    int node = -1, pk = 0;
+    if (wid < n_pass) {  // the wave's first pass, straight from the list in memory (the LDS copy is still on its way)
+      const int2 e = *reinterpret_cast<const int2*>(tl.dst + (int64_t)ti * 64 + (wid * 4 + row) * 2);
+      node = e.x;
+      pk = e.y;
+    }
+    fetch(node, pk, cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int ps = wid;
+  while (ps < n_pass) {
+    // the next pass of this wave: ticket, list entry, operands -- all in flight under this pass's edges
+    int nps = 0;
+    if (lane == 0) nps = atomicAdd(ticket, 1);
+    nps = __builtin_amdgcn_readfirstlane(nps);
+    PassIn nxt;
+    {
+      int node = -1, pk = 0;
+      if (nps < n_pass) {
+        const int2 e = *reinterpret_cast<const int2*>(ds + (nps * 4 + row) * 8);
+        node = e.x;
+        pk = e.y;
+      }
+      fetch(node, pk, nxt);
+    }
+
+    const int node = cur.node;
+    const int deg = cur.pk & 255;
+    const int er = cur.pk >> 8;  // first edge of the destination, relative to the tile's
+    int nchunk = (deg + U - 1) / U;
+    nchunk = max(max(__builtin_amdgcn_readlane(nchunk, 0), __builtin_amdgcn_readlane(nchunk, 16)),
+                 max(__builtin_amdgcn_readlane(nchunk, 32), __builtin_amdgcn_readlane(nchunk, 48)));
+
+    float m = -INFINITY, l = 0.f;
+    f32x2_t acc[VP];
+    float tacc[APL];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) acc[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < APL; ++a) tacc[a] = 0.f;
+    QK<T, VEC> qk;
+    float u[APL];
+    {
+      const uint32_t qw[4] = {cur.q.x, cur.q.y, cur.q.z, cur.q.w};
+      qk.set_raw(qw);
+    }
+    cur.u.get(u);
+#pragma unroll
+    for (int i = 0; i < APL; ++i) u[i] *= amask;
+
+    for (int ci = 0; ci < nchunk; ++ci) {
+      const int rem = deg - ci * U;  // this row's edges left (<= 0: the row is done, its lanes idle)
+      if (rem > 0) {
+        const int eb = er + ci * U;
+        Raw kr[U], vr[U];
+        float at[U][APL];
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) {
+          if (uu < rem) {
+            const int sl = *reinterpret_cast<const uint8_t*>(ss + eb + uu);
+            kr[uu] = *reinterpret_cast<const Raw*>(ks + sl * 256 + l16 * 16);
+            vr[uu] = *reinterpret_cast<const Raw*>(vs + sl * 256 + l16 * 16);
+            VecIO<float, APL>::load(reinterpret_cast<const float*>(as + (eb + uu) * (UP * 4)) + a_ld, at[uu]);
+          }
+        }
+        // the online-softmax update of the plain folded kernel, operation for operation
+        float s[U];
+        float mb = m;
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) {
+          s[uu] = -INFINITY;
+          if (uu < rem) {
+            float t = qk.dot(kr[uu]);
+#pragma unroll
+            for (int a = 0; a < APL; ++a) t = fmaf(u[a], at[uu][a], t);
+            s[uu] = group_sum<LPH>(t) * p.scale;
+            mb = fmaxf(mb, s[uu]);
+          }
+        }
+        const float corr = __expf(m - mb);
+        l *= corr;
+#pragma unroll
+        for (int i = 0; i < VP; ++i) acc[i] *= corr;
+#pragma unroll
+        for (int a = 0; a < APL; ++a) tacc[a] *= corr;
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) {
+          if (uu < rem) {
+            const float pe = __expf(s[uu] - mb);
+            l += pe;
+            float vv[VEC];
+            unpack<T, VEC>(vr[uu], vv);
+#pragma unroll
+            for (int i = 0; i < VP; ++i)
+              acc[i] = __builtin_elementwise_fma(f32x2_t{pe, pe}, f32x2_t{vv[2 * i], vv[2 * i + 1]}, acc[i]);
+#pragma unroll
+            for (int a = 0; a < APL; ++a) tacc[a] = fmaf(pe, at[uu][a], tacc[a]);
+          }
+        }
+        m = mb;
+      }
+    }
+
+    if (node >= 0) {
+      const float inv = 1.0f / (l + 1e-16f);
+      float o[VEC];
+      {
+        // (acc * inv) + x_r as TWO roundings, as in the plain kernel (see the scheduled kernel)
+#pragma clang fp contract(off)
+        RawWords<T, VEC> xw;
+        xw.w[0] = cur.xr.x; xw.w[1] = cur.xr.y; xw.w[2] = cur.xr.z; xw.w[3] = cur.xr.w;
+        float r[VEC];
+        xw.get(r);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float scaled = acc[i >> 1][i & 1] * inv;
+          o[i] = p.xr != nullptr ? scaled + r[i] : scaled;
+        }
+      }
+      const int out_row = (int)((uint32_t)node * o_row_bytes);
+      uint32_t ow[4];
+      pack_words<T, VEC>(o, ow);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ow[0], ow[1], ow[2], ow[3]}, ors, out_row + lane_off, 0, 2);
+      if (a_own) {  // this lane's APL values of t~_i,h
+        float t4[APL];
+#pragma unroll
+        for (int a = 0; a < APL; ++a) t4[a] = tacc[a] * inv;
+        uint32_t tw[RawWords<T, APL>::W];
+        pack_words<T, APL>(t4, tw);
+        buffer_store_words<RawWords<T, APL>::W>(ors, out_row + t_off, 0, tw);
+      }
+      if (p.lse != nullptr && (gls % LPH) == 0) p.lse[(int64_t)node * (p.C / p.D) + head] = m + __logf(l + 1e-16f);
+    }
+    cur = nxt;
+    ps = nps;
+  }
+}
+
+static size_t tiles_lds_bytes(int src_cap, int edge_cap, int up) {
+  return (size_t)src_cap * 512 + (size_t)edge_cap * (up * 4) + (size_t)edge_cap + 256 + 16;
+}
+
+template <typename T, int LPH, int UP>
+static int launch_folded_tiles(const EdgeFoldParams& p, const EdgeTileLists& tl, int max_tiles_per_xcd, hipStream_t st) {
+  const size_t lds = tiles_lds_bytes(tl.src_cap, tl.edge_cap, UP);  // <= 64 KiB (entry point): no attribute to raise
+  auto kernel = gt_edge_attention_folded_tiles_kernel<T, LPH, UP>;
+  const unsigned blocks = (unsigned)(8 * (int64_t)max_tiles_per_xcd * p.n_slices);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, st, p, p.attr, tl);
+  return ANEMOI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Folded path on a graph whose destinations all have exactly THREE in-edges (the mesh -> grid decoder: every grid node
 // is fed by its three nearest mesh nodes, reference layers/mapper.py:348-418 on an anemoi-graphs KNN edge set), in RUNS:
 // consecutive destinations fed by the same three sources -- neighbouring grid points inside one mesh triangle; mean run
@@ -1618,6 +1905,71 @@ extern "C" int anemoi_gt_edge_attention_folded_sched(int dtype, const void* q, i
     ANEMOI_SCHED_UP(4)
   }
 #undef ANEMOI_SCHED_UP
+  return check_launch(who);
+}
+
+// anemoi_gt_edge_attention_folded on LDS TILES (gt_edge_attention_folded_tiles_kernel above): the same result bit for bit.
+// The tile lists are the host's (anemoi_models_amd/runtime.py::EdgeTiles); bf16, 32- or 64-channel heads, C a multiple of 128,
+// every operand matrix below 4 GiB -- every other case (or tile_hdr == NULL) runs the plain kernel.
+extern "C" int anemoi_gt_edge_attention_folded_tiles(int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                                                     int64_t ldkv, const void* x_r, int64_t ldr, const void* u, int64_t ldu,
+                                                     const float* edge_attr, int up, const int32_t* rowptr,
+                                                     const int32_t* col, const int32_t* tile_hdr, const int32_t* tile_dst,
+                                                     const int32_t* tile_src, const uint8_t* tile_slot,
+                                                     const int32_t* tile_xcd, int max_tiles_per_xcd, int src_cap,
+                                                     int edge_cap, int64_t n_src, int64_t n_edges, void* out, int64_t ldo,
+                                                     float* lse, int64_t n_dst, int C, int H, anemoi_stream_t stream) {
+  const int64_t lim = (int64_t)1 << 31;  // (row offsets + lane offsets are formed as signed 32-bit voffsets)
+  const bool fits = n_src > 0 && n_src * ldkv * 2 < lim && n_dst * ldq * 2 < lim && n_dst * ldu * 2 < lim && n_dst * ldo * 2 < lim &&
+                    (x_r == nullptr || n_dst * ldr * 2 < lim) && n_edges > 0;
+  const bool plain = tile_hdr == nullptr || dtype != ANEMOI_BF16 || H <= 0 || C % H != 0 || !((C / H) == 64 || (C / H) == 32) ||
+                     C % 128 != 0 || !(up == 4 || up == 8 || up == 12 || up == 16) || n_dst == 0 || !fits ||
+                     max_tiles_per_xcd <= 0;
+  if (plain)
+    return anemoi_gt_edge_attention_folded(dtype, q, ldq, k, v, ldkv, x_r, ldr, u, ldu, edge_attr, up, rowptr, col, out, ldo,
+                                           lse, n_dst, C, H, stream);
+  const char* who = "anemoi_gt_edge_attention_folded_tiles";
+  ANEMOI_REQUIRE(q && k && v && u && out && edge_attr && tile_dst && tile_src && tile_slot && tile_xcd, ANEMOI_ERR_INVALID,
+                 "%s: null pointer", who);
+  ANEMOI_REQUIRE(ldq >= C && ldkv >= C && ldu >= (int64_t)H * up && ldo >= (int64_t)C + (int64_t)H * up &&
+                     (x_r == nullptr || ldr >= C),
+                 ANEMOI_ERR_INVALID, "%s: leading dimension too small", who);
+  ANEMOI_REQUIRE(src_cap > 0 && src_cap <= 255 && edge_cap > 0 && edge_cap % 16 == 0 &&
+                     tiles_lds_bytes(src_cap, edge_cap, up) <= 64 * 1024,
+                 ANEMOI_ERR_INVALID, "%s: tile caps %d sources / %d edges (<= 255, a multiple of 16, LDS <= 64 KiB)", who, src_cap,
+                 edge_cap);
+  const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                       ((uintptr_t)u % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                       (x_r == nullptr || ((uintptr_t)x_r % 16 == 0 && ldr % 8 == 0)) && ldq % 8 == 0 && ldkv % 8 == 0 &&
+                       ldu % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)edge_attr % 16 == 0) && ((uintptr_t)tile_slot % 16 == 0);
+  ANEMOI_REQUIRE(aligned, ANEMOI_ERR_UNSUPPORTED, "%s: operands must be 16-byte aligned", who);
+  EdgeFoldParams p;
+  p.q = q; p.k = k; p.v = v; p.xr = x_r; p.u = u; p.out = out; p.lse = lse;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldr = ldr; p.ldu = ldu; p.ldo = ldo;
+  p.attr = edge_attr; p.rowptr = rowptr; p.col = col;
+  p.n_dst = n_dst; p.C = C; p.D = C / H;
+  p.n_slices = C / 128;
+  p.scale = 1.0f / sqrtf((float)(C / H));
+  p.stream_hint = 1;
+  EdgeTileLists tl;
+  tl.hdr = tile_hdr; tl.dst = tile_dst; tl.src = tile_src; tl.slot = tile_slot; tl.xcd = tile_xcd;
+  tl.src_cap = src_cap; tl.edge_cap = edge_cap; tl.n_src = n_src;
+  hipStream_t st = as_stream(stream);
+  int rc = ANEMOI_OK;
+#define ANEMOI_TILES_UP(LPH)                                                                        \
+  switch (up) {                                                                                     \
+    case 4: rc = launch_folded_tiles<bf16_t, LPH, 4>(p, tl, max_tiles_per_xcd, st); break;          \
+    case 8: rc = launch_folded_tiles<bf16_t, LPH, 8>(p, tl, max_tiles_per_xcd, st); break;          \
+    case 12: rc = launch_folded_tiles<bf16_t, LPH, 12>(p, tl, max_tiles_per_xcd, st); break;        \
+    default: rc = launch_folded_tiles<bf16_t, LPH, 16>(p, tl, max_tiles_per_xcd, st); break;        \
+  }
+  if (C / H == 64) {
+    ANEMOI_TILES_UP(8)
+  } else {
+    ANEMOI_TILES_UP(4)
+  }
+#undef ANEMOI_TILES_UP
+  if (rc != ANEMOI_OK) return rc;
   return check_launch(who);
 }
 

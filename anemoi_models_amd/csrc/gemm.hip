@@ -29,6 +29,16 @@
 #ifndef ANEMOI_LAB_W_AUX
 #define ANEMOI_LAB_W_AUX 0
 #endif
+// Lab switch (round 6): start the workgroups of a launch in ANEMOI_LAB_STAGGER_PHASES groups, group g delayed by
+// g x ANEMOI_LAB_STAGGER x 8128 cycles -- every tile of a launch takes the same time, so the 256 workgroups run in lockstep
+// and their epilogues store 128 KiB each AT ONCE (6.4 us per tile instead of the 3.7 us a CU's own store path takes:
+// profiles/r05_gemm_store_path.md); out of phase the bursts would interleave with other workgroups' K loops.  0 = off.
+#ifndef ANEMOI_LAB_STAGGER
+#define ANEMOI_LAB_STAGGER 0
+#endif
+#ifndef ANEMOI_LAB_STAGGER_PHASES
+#define ANEMOI_LAB_STAGGER_PHASES 2
+#endif
 
 namespace anemoi {
 
@@ -641,6 +651,9 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     else skinny_columns<8, EPI, ACT>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
   }
   if (!has_tiles) return;
+#if ANEMOI_LAB_STAGGER
+  for (int i = 0, n = (int)(bix % ANEMOI_LAB_STAGGER_PHASES) * ANEMOI_LAB_STAGGER; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 #ifndef ANEMOI_LAB_TAIL_BEHIND_DMA
   set_tile(chunk_start + bix);
   stage_all(0, 0);

@@ -53,8 +53,21 @@ def folded_edge_phase(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u:
     """The folded edge phase (``anemoi_gt_edge_attention_folded``: one fused gather -> score -> segment softmax -> weighted
     sum -> ``+ x_r`` pass over the destination-sorted CSR)."""
     runs = edge_runs(plan, q.dtype)
+    tiles = None if runs is not None else edge_tiles(plan, q, num_heads, up)
     return ops.gt_edge_attention_folded(q, k, v, x_r, u, edge_attr_csr, plan.rowptr, plan.col, num_heads, up,
-                                        ld_out=ld_out, runs=runs, sched=None if runs is not None else edge_schedule(plan, q))
+                                        ld_out=ld_out, runs=runs, tiles=tiles,
+                                        sched=None if runs is not None or tiles is not None else edge_schedule(plan, q))
+
+
+TILES_DEFAULT = "0"  # ANEMOI_AMD_EDGE_TILES: the LDS-tile edge kernel for mesh graphs (A/B switch; DESIGN 4.2 for the numbers)
+
+
+def edge_tiles(plan, q: Tensor, num_heads: int, up: int):
+    """The tile lists of a plan for the LDS-tile bf16 edge kernel (``EdgePlan.tiles``), else ``None``."""
+    if (q.dtype != torch.bfloat16 or not hasattr(plan, "tiles")
+            or os.environ.get("ANEMOI_AMD_EDGE_TILES", TILES_DEFAULT) == "0"):
+        return None
+    return plan.tiles(q.dtype, q.shape[-1], num_heads, up)
 
 
 def edge_schedule(plan, q: Tensor):
@@ -63,6 +76,14 @@ def edge_schedule(plan, q: Tensor):
     if q.dtype != torch.bfloat16 or not hasattr(plan, "schedule") or os.environ.get("ANEMOI_AMD_EDGE_SCHED", "1") == "0":
         return None
     return plan.schedule(q.dtype, q.shape[-1])
+
+
+def set_tile_args(a, tiles, n_src: int, n_edges: int) -> None:
+    """The tile fields of an ``anemoi_gt_block_args`` block."""
+    a.tile_hdr, a.tile_dst, a.tile_src = tiles.hdr.data_ptr(), tiles.dst.data_ptr(), tiles.src.data_ptr()
+    a.tile_slot, a.tile_xcd = tiles.slot.data_ptr(), tiles.xcd.data_ptr()
+    a.tile_max_per_xcd, a.tile_src_cap, a.tile_edge_cap = tiles.max_tiles_per_xcd, tiles.src_cap, tiles.edge_cap
+    a.n_src, a.n_edges = n_src, n_edges
 
 
 def edge_runs(plan, dtype):
@@ -398,7 +419,10 @@ class GraphTransformerBaseBlock(BaseBlock, ABC):
             if len(runs) == 3:  # groups: the destination list, and the row count of k / v for the 4-GiB check
                 a.run_dst, a.n_src = runs[2].data_ptr(), k.shape[0]
         else:  # (beyond 32-bit attribute-row offsets the entry point takes the plain kernel by itself: n_edges states the size)
-            sched = edge_schedule(plan, q)
+            tiles = edge_tiles(plan, q, h, up)
+            if tiles is not None:
+                set_tile_args(a, tiles, k.shape[0], edge_attr_csr.shape[0])
+            sched = None if tiles is not None else edge_schedule(plan, q)
             if sched is not None:
                 a.sched, a.sched_slots, a.sched_steps, a.n_src = sched.data_ptr(), sched.shape[1], sched.shape[2], k.shape[0]
                 a.n_edges = edge_attr_csr.shape[0]

@@ -7,6 +7,8 @@ plan and gathers ``[edge_attr | trainable]`` into CSR order, then every block ru
 
 from __future__ import annotations
 
+import os
+
 from abc import ABC
 from typing import Optional
 
@@ -221,10 +223,11 @@ class _BlockAbiPlan:
         if x.shape[1] != c or any(o["w_in"].shape != operands[0]["w_in"].shape or o["w_fc1"].shape[0] != hidden
                                   or o["act"] not in _lib.ACT_CODES for o in operands):
             return self
-        from .block import edge_schedule
+        from .block import edge_schedule, edge_tiles, set_tile_args
 
-        sched = edge_schedule(plan, x)  # (n_edges below: the entry point declines it beyond 32-bit attribute-row offsets)
-        self.keep = [operands, ea, plan, sched]  # the packed weights, edge attributes, CSR and schedule the templates point at
+        tiles = edge_tiles(plan, x, h, up)
+        sched = None if tiles is not None else edge_schedule(plan, x)  # (n_edges below: the entry point declines it beyond 32-bit attribute-row offsets)
+        self.keep = [operands, ea, plan, sched, tiles]  # the packed weights, edge attributes, CSR and schedule the templates point at
         self.dims = (n, c, h, up, n_in, k_proj, hidden)
         lib = _lib.load()
         self.ws_bytes = n * max(c // 128, 1) * 8  # row-sum partials of anemoi_linear_stats
@@ -243,6 +246,8 @@ class _BlockAbiPlan:
             a.b_in = None if o["b_in"] is None else o["b_in"].data_ptr()
             a.ld_sq = n_in
             a.edge_attr, a.rowptr, a.col = ea.data_ptr(), plan.rowptr.data_ptr(), plan.col.data_ptr()
+            if tiles is not None:
+                set_tile_args(a, tiles, plan.n_src, ea.shape[0])
             if sched is not None:
                 a.sched, a.sched_slots, a.sched_steps, a.n_src = sched.data_ptr(), sched.shape[1], sched.shape[2], plan.n_src
                 a.n_edges = ea.shape[0]
@@ -343,7 +348,8 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
         if params is None:
             params = self.__dict__["_abi_params"] = [p for p in self.parameters()]
         # any in-place change of a parameter (optimiser step, load_state_dict, .normal_()) bumps its version counter
-        sig = (sum(p._version for p in params), params[0].data_ptr(), x.shape[0], str(x.device), ea.data_ptr(), id(plan))
+        sig = (sum(p._version for p in params), params[0].data_ptr(), x.shape[0], str(x.device), ea.data_ptr(), id(plan),
+               os.environ.get("ANEMOI_AMD_EDGE_TILES"), os.environ.get("ANEMOI_AMD_EDGE_SCHED"))  # (A/B switches of the edge kernel)
         fast = self.__dict__.get("_abi_plan")
         if fast is None or fast.sig != sig:
             fast = self.__dict__["_abi_plan"] = _BlockAbiPlan.build(self, x, ea, plan, sig)

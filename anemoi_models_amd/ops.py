@@ -277,7 +277,8 @@ def gt_edge_attention(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], ed
 
 def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tensor], u: Tensor, edge_attr: Tensor,
                              rowptr: Tensor, col: Tensor, num_heads: int, up: int, out: Optional[Tensor] = None,
-                             ld_out: Optional[int] = None, lse: Optional[Tensor] = None, runs=None, sched=None) -> Tensor:
+                             ld_out: Optional[int] = None, lse: Optional[Tensor] = None, runs=None, sched=None,
+                             tiles=None) -> Tensor:
     """Edge phase with lin_edge folded away: returns ``[n_dst, ld_out]`` = ``[sum alpha v (+ x_r) | t (H*up) | 0-pad]``.
 
     ``u`` is ``[n_dst, H*up]`` (extra columns of the q/k/v GEMM), ``edge_attr`` ``[E, up]`` f32 in CSR order with the
@@ -287,7 +288,9 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
     of them -- ``(grp_ptr, grp_perm, grp_dst)``: all destinations of a source triple (``anemoi_gt_edge_attention_folded_groups``),
     ``(run_ptr, perm)``: the consecutive ones (``anemoi_gt_edge_attention_folded_runs``).  ``sched`` (``EdgePlan.schedule()``: int32
     ``[8, slots, steps]``): the destination schedule of ``anemoi_gt_edge_attention_folded_sched`` -- balanced wave slots, index
-    chain resolved one destination ahead; bit-identical to the plain kernel.  ``runs`` wins when both are given.
+    chain resolved one destination ahead; bit-identical to the plain kernel.  ``tiles`` (``EdgePlan.tiles()``: a
+    ``runtime.EdgeTiles``): the LDS-tile kernel ``anemoi_gt_edge_attention_folded_tiles`` -- every source row staged once per
+    tile of <= 32 destinations; bit-identical to the plain kernel.  ``runs`` wins over ``tiles`` wins over ``sched``.
     """
     _dev(q, k, v, x_r, u, edge_attr, rowptr, col, out, lse)
     if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous()
@@ -338,6 +341,14 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
                 0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
                 rowptr.data_ptr(), col.data_ptr(), run_ptr.data_ptr(), perm.data_ptr(), run_ptr.shape[0] - 1,
                 out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
+        elif tiles is not None:
+            _dev(tiles.hdr, tiles.dst, tiles.src, tiles.slot, tiles.xcd)
+            st = _lib.load().anemoi_gt_edge_attention_folded_tiles(
+                dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)), _ptr(x_r),
+                0 if x_r is None else _ld(_rows(x_r)), u.data_ptr(), _ld(_rows(u)), edge_attr.data_ptr(), up,
+                rowptr.data_ptr(), col.data_ptr(), tiles.hdr.data_ptr(), tiles.dst.data_ptr(), tiles.src.data_ptr(),
+                tiles.slot.data_ptr(), tiles.xcd.data_ptr(), tiles.max_tiles_per_xcd, tiles.src_cap, tiles.edge_cap,
+                _rows(k).shape[0], col.shape[0], out.data_ptr(), _ld(_rows(out)), _ptr(lse), n_dst, c, num_heads, _stream())
         elif sched is not None:  # (the entry point itself falls back to the plain kernel beyond 32-bit row offsets)
             _dev(sched)
             if sched.dtype != torch.int32 or sched.dim() != 3 or sched.shape[0] != 8 or not sched.is_contiguous():

@@ -32,10 +32,27 @@ def compute_dtype(x: Tensor) -> torch.dtype:
         return _FORCED_DTYPE[forced.lower()]
     if torch.is_autocast_enabled():
         dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.float16:
+            # anemoi-training's ``precision: 16-mixed``: the reference's AutocastLayerNorm exists for "(b)float16" mixed
+            # precision (layers/utils.py:33-39).  gfx950's MFMA rate is the same for fp16 and bf16 and this package has ONE
+            # 16-bit kernel family, bf16 (8 exponent bits: no loss scaling needed, the f32 range of the residual stream
+            # survives): a float16 autocast region runs on it.  Said once, loudly -- the results differ from fp16 arithmetic
+            # in the last bits of the 16-bit roundings, the f32 accumulation is the same.
+            global _FP16_NOTICE
+            if not _FP16_NOTICE:
+                _FP16_NOTICE = True
+                import warnings
+
+                warnings.warn("anemoi_models_amd: torch.autocast(float16) runs on the bf16 kernels of the MI355X path "
+                              "(same 16-bit storage and MFMA rate, f32 accumulation; no fp16 kernels exist)", stacklevel=2)
+            return torch.bfloat16
         if dt not in (torch.bfloat16, torch.float32):
             raise NotImplementedError(f"autocast dtype {dt} is not supported on the MI355X path (use bfloat16)")
         return dt
     return torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+
+
+_FP16_NOTICE = False
 
 
 def require_inference(*modules: torch.nn.Module) -> None:
@@ -94,6 +111,17 @@ class EdgePlan:
         key = (dtype, channels)
         if key not in cache:
             cache[key] = _edge_schedule(self, dtype, channels)
+        return cache[key]
+
+    def tiles(self, dtype: torch.dtype, channels: int, heads: int, up: int):
+        """:class:`EdgeTiles` of this plan for the LDS-tile edge kernel (``anemoi_gt_edge_attention_folded_tiles``; cached on
+        the plan), or ``None`` where that kernel does not apply."""
+        if dtype != torch.bfloat16 or not self.col.is_cuda:
+            return None
+        cache = self.__dict__.setdefault("_tiles_cache", {})
+        key = (channels, heads, up)
+        if key not in cache:
+            cache[key] = _edge_tiles(self, channels, heads, up)
         return cache[key]
 
     @property
@@ -157,6 +185,114 @@ def _edge_schedule(plan: "EdgePlan", dtype: torch.dtype, channels: int):
     if plan.num_edges > SCHED_MAX_MEAN_DEGREE * plan.n_dst:
         return None
     return edge_schedule_lists(degree, slots.value, steps.value).to(plan.col.device).contiguous()
+
+
+# ---- destination TILES whose source rows are staged in LDS (round 6: anemoi_gt_edge_attention_folded_tiles) ------------
+TILE_MAX_DST = 32        # destinations per tile: 4 waves x 2 passes x 4 destinations (one per 16-lane row of a wave)
+TILE_SLICE = 128         # channels per workgroup: 16 lanes x 8 channels per destination, 256 bytes of a bf16 k (v) row
+TILE_SRC_CAP = 72        # distinct sources a tile stages: 72 x 512 bytes of k|v slices ...
+TILE_EDGE_CAP = 256      # ... next to the tile's attribute rows (256 x up x 4 bytes) and slot bytes: 3 workgroups per CU
+
+
+@dataclass
+class EdgeTiles:
+    """Host-built lists of the LDS-tile edge kernel (``anemoi_gt_edge_attention_folded_tiles``; int32 / uint8, on the plan's device).
+
+    A TILE is a run of <= ``TILE_MAX_DST`` consecutive destinations (Morton order: neighbours in space) of one XCD's
+    range whose in-edges name <= ``src_cap`` distinct sources and <= ``edge_cap`` edges.  The kernel stages the k|v slices of
+    the tile's sources ONCE in LDS; every edge then reads its source by LDS slot instead of gathering the row again -- on the
+    ico-6 multi-scale mesh a staged row serves 2.8 edges.
+      hdr   [n_tiles, 8]        first CSR slot of the tile, its edge count, offset of its source list, source count, offset of
+                                its slot bytes (a multiple of 16), destination count, 0, 0
+      dst   [n_tiles, 32, 2]    per (pass, lane row): destination id (-1: none), (first edge - tile's first edge) << 8 | degree;
+                                pass p = the p-th four of the tile's destinations by descending in-degree (rows of one pass
+                                run in lockstep: similar degrees waste the fewest lanes; heavy passes are started first)
+      src   [sum of counts]     the tiles' distinct sources, ascending per tile
+      slot  [...]               uint8 per tile and edge (CSR order inside the tile): index of the edge's source in the tile's list
+      xcd   [9]                 tile index ranges of the 8 XCDs (XCD x: destinations [n x / 8, n (x + 1) / 8))"""
+
+    hdr: Tensor
+    dst: Tensor
+    src: Tensor
+    slot: Tensor
+    xcd: Tensor
+    src_cap: int
+    edge_cap: int
+    max_tiles_per_xcd: int
+
+    @property
+    def n_tiles(self) -> int:
+        return int(self.hdr.shape[0])
+
+    def to(self, device) -> "EdgeTiles":
+        return EdgeTiles(self.hdr.to(device), self.dst.to(device), self.src.to(device), self.slot.to(device),
+                         self.xcd.to(device), self.src_cap, self.edge_cap, self.max_tiles_per_xcd)
+
+
+def edge_tile_lists(rowptr: Tensor, col: Tensor, src_cap: int = TILE_SRC_CAP, edge_cap: int = TILE_EDGE_CAP,
+                    max_dst: int = TILE_MAX_DST):
+    """The tile lists of :class:`EdgeTiles` for a destination-sorted CSR (host logic, CPU tensors), or ``None`` when one
+    destination alone exceeds a cap (in-degree > ``edge_cap`` / 255, more than ``src_cap`` distinct sources)."""
+    import numpy as np
+
+    rp = rowptr.cpu().numpy().astype(np.int64)
+    cl = col.cpu().numpy().astype(np.int64)
+    n = rp.shape[0] - 1
+    deg = rp[1:] - rp[:-1]
+    if (n == 0 or not 0 < src_cap <= 255 or edge_cap % 16 != 0 or max_dst > TILE_MAX_DST
+            or deg.max(initial=0) > min(edge_cap, 255)):
+        return None
+    hdr, dst, srcs, slots, xcd = [], [], [], [], [0]
+    src_off = slot_off = 0
+    for x in range(8):
+        n0, n1 = n * x // 8, n * (x + 1) // 8
+        d = n0
+        while d < n1:
+            first, cur, edges = d, set(), 0
+            while d < n1 and d - first < max_dst:
+                mine = set(cl[rp[d]:rp[d + 1]].tolist())
+                if len(cur | mine) > src_cap or edges + int(deg[d]) > edge_cap:
+                    break
+                cur |= mine
+                edges += int(deg[d])
+                d += 1
+            if d == first:
+                return None  # (one destination alone does not fit)
+            ids = np.array(sorted(cur), dtype=np.int64)
+            e0, e1 = int(rp[first]), int(rp[d])
+            sl = np.zeros((e1 - e0 + 15) // 16 * 16, dtype=np.uint8)
+            sl[:e1 - e0] = np.searchsorted(ids, cl[e0:e1])
+            hdr.append((e0, e1 - e0, src_off, ids.shape[0], slot_off, d - first, 0, 0))
+            srcs.append(ids)
+            slots.append(sl)
+            src_off += ids.shape[0]
+            slot_off += sl.shape[0]
+            order = np.argsort(-deg[first:d], kind="stable") + first  # heavy destinations first
+            info = np.zeros((TILE_MAX_DST, 2), dtype=np.int64)
+            info[:, 0] = -1
+            info[:order.shape[0], 0] = order
+            info[:order.shape[0], 1] = ((rp[order] - e0) << 8) | deg[order]
+            dst.append(info)
+        xcd.append(len(hdr))
+    as_i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32))  # noqa: E731
+    per_xcd = max(xcd[i + 1] - xcd[i] for i in range(8))
+    slot = np.concatenate(slots) if slots else np.zeros(16, dtype=np.uint8)
+    return EdgeTiles(as_i32(np.array(hdr)), as_i32(np.stack(dst)), as_i32(np.concatenate(srcs)),
+                     torch.from_numpy(np.concatenate([slot, np.zeros(16, dtype=np.uint8)])), as_i32(np.array(xcd)), src_cap,
+                     edge_cap, per_xcd)
+
+
+def _edge_tiles(plan: "EdgePlan", channels: int, heads: int, up: int):
+    """:class:`EdgeTiles` of a plan on its device, or ``None`` where the tile kernel does not apply: channel counts off the
+    128-channel slice, head sizes other than 32 / 64, graphs of a mean in-degree above ``SCHED_MAX_MEAN_DEGREE`` (the
+    encoder: its tiles would hold 3 destinations) or uniform degree 3 (the decoder: the group kernel)."""
+    if (channels % TILE_SLICE != 0 or heads <= 0 or channels % heads != 0 or channels // heads not in (32, 64)
+            or up not in (4, 8, 12, 16) or plan.n_dst == 0 or plan.num_edges > SCHED_MAX_MEAN_DEGREE * plan.n_dst):
+        return None
+    src_cap = int(os.environ.get("ANEMOI_AMD_EDGE_TILE_SRC", TILE_SRC_CAP))      # lab switches (A/B of the LDS budget)
+    edge_cap = int(os.environ.get("ANEMOI_AMD_EDGE_TILE_EDGES", TILE_EDGE_CAP))
+    t = edge_tile_lists(plan.rowptr, plan.col, src_cap, edge_cap)
+    return None if t is None else t.to(plan.col.device)
 
 
 def _runs3(plan: "EdgePlan", max_run: int = 2):

@@ -226,6 +226,31 @@ int anemoi_gt_edge_attention_folded_sched(int dtype, const void* q, int64_t ldq,
                                           int64_t n_dst, int C, int H, anemoi_stream_t stream);
 
 /*
+ * anemoi_gt_edge_attention_folded on LDS TILES (round 6): the same result bit for bit -- same arithmetic, same
+ * per-destination summation order -- from a launch that stages every source row ONCE per tile instead of gathering it once
+ * per edge.  A tile is a run of <= 32 consecutive destinations (an internal order that keeps graph neighbours together is
+ * what makes it pay: the mesh's Morton order) whose in-edges name <= src_cap distinct sources and <= edge_cap edges; a
+ * workgroup takes one tile x one 128-channel slice, copies the k | v slices of the tile's sources, the tile's attribute rows
+ * and the per-edge LDS slot bytes into LDS, and a wave then walks four destinations at a time (one per 16-lane row) reading
+ * its sources from LDS.  Lists (host-built, anemoi_models_amd/runtime.py::EdgeTiles; all on the device):
+ *   tile_hdr  int32 [n_tiles][8]      first CSR slot e0, edge count, offset into tile_src, source count, offset into
+ *                                     tile_slot (a multiple of 16), destination count, 0, 0
+ *   tile_dst  int32 [n_tiles][32][2]  per (pass of four, row): destination id (-1: none), (first edge - e0) << 8 | in-degree
+ *   tile_src  int32 [...]             the tiles' distinct sources
+ *   tile_slot uint8 [...]             per tile, per edge in CSR order: index of its source in the tile's list
+ *   tile_xcd  int32 [9]               tile index range of each of the 8 XCDs (destinations [n_dst x / 8, n_dst (x + 1) / 8))
+ * bf16, 32- or 64-channel heads, C a multiple of 128, up in {4, 8, 12, 16}, every operand matrix below 2 GiB; other cases
+ * (or tile_hdr == NULL) run the plain kernel.  Reference: layers/conv.py:98-142 (+ PyG propagate / softmax / scatter).
+ */
+int anemoi_gt_edge_attention_folded_tiles(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                          const void* x_r, int64_t ldr, const void* u, int64_t ldu, const float* edge_attr,
+                                          int up, const int32_t* rowptr, const int32_t* col, const int32_t* tile_hdr,
+                                          const int32_t* tile_dst, const int32_t* tile_src, const uint8_t* tile_slot,
+                                          const int32_t* tile_xcd, int max_tiles_per_xcd, int src_cap, int edge_cap,
+                                          int64_t n_src, int64_t n_edges, void* out, int64_t ldo, float* lse, int64_t n_dst,
+                                          int C, int H, anemoi_stream_t stream);
+
+/*
  * GraphTransformerConv with explicit per-edge features (the callable the reference exposes, layers/conv.py:98-142):
  *   s_ij = q_i . (k_j + e_ij) / sqrt(D),  alpha = softmax over the in-edges of i (+1e-16),  out_i = sum_j alpha (v_j + e_ij)
  * q [n_dst, C], k / v [n_src, C], edges [E, C] in the CSR order of (rowptr, col) (= lin_edge(edge_attr)[perm]), all in
@@ -578,6 +603,10 @@ typedef struct anemoi_gt_block_args {
   /* rowptr[n_dst], stated by the caller: the scheduled kernel addresses attribute rows by 32-bit byte offsets and is taken
    * only when n_edges * up * 4 < 2^32 (<= 0: not stated, plain kernel) */
   int64_t n_edges;
+  /* optional (NULL: none; taken before the schedule, ignored when runs are given): the tile lists of
+   * anemoi_gt_edge_attention_folded_tiles (n_src, n_edges set) */
+  const int32_t* tile_hdr; const int32_t* tile_dst; const int32_t* tile_src; const uint8_t* tile_slot; const int32_t* tile_xcd;
+  int32_t tile_max_per_xcd, tile_src_cap, tile_edge_cap, tile_pad;
 } anemoi_gt_block_args;
 int anemoi_gt_block_tail(const anemoi_gt_block_args* args, anemoi_stream_t stream);
 int anemoi_gt_processor_block_forward(const anemoi_gt_block_args* args, anemoi_stream_t stream);

@@ -687,6 +687,42 @@ def test_edge_schedule_lists_cover_every_destination_once_and_balance_the_slots(
     assert torch.equal(uniform[0, :, 0], torch.arange(125, dtype=torch.int32)) and int((uniform >= 0).sum()) == 1000
 
 
+def test_edge_tile_lists_cover_every_destination_once_within_their_caps():
+    """``runtime.edge_tile_lists`` (host lists of the LDS-tile edge kernel, round 6): every destination in exactly one tile of
+    its own XCD's range, tiles within the caps, ``slot -> source`` reproduces the CSR's source column, the packed
+    ``(first edge << 8 | degree)`` words match the row pointers, passes ordered by descending in-degree; a destination that
+    alone exceeds a cap makes the graph ineligible (``None``)."""
+    g = torch.Generator().manual_seed(3)
+    n_dst, n_src = 1000, 900
+    deg = torch.randint(0, 14, (n_dst,), generator=g)
+    deg[17] = 40
+    dst = torch.repeat_interleave(torch.arange(n_dst), deg)
+    src = (dst * n_src // n_dst + torch.randint(-20, 21, dst.shape, generator=g)).clamp_(0, n_src - 1)
+    plan = runtime.build_edge_plan(torch.stack([src, dst]), n_src, n_dst)
+    t = runtime.edge_tile_lists(plan.rowptr, plan.col, src_cap=48, edge_cap=160)
+    assert t is not None and t.hdr.shape == (t.n_tiles, 8) and t.dst.shape == (t.n_tiles, 32, 2) and t.xcd.shape == (9,)
+    rp, cl = plan.rowptr.long(), plan.col.long()
+    seen = torch.zeros(n_dst, dtype=torch.int64)
+    for x in range(8):
+        for ti in range(int(t.xcd[x]), int(t.xcd[x + 1])):
+            e0, ne, so, ns, slo, nd = t.hdr[ti, :6].tolist()
+            assert 1 <= nd <= 32 and 1 <= ns <= 48 and ne <= 160 and slo % 16 == 0
+            assert torch.equal(t.src[so:so + ns].long()[t.slot[slo:slo + ne].long()], cl[e0:e0 + ne])
+            degs = []
+            for node, pk in t.dst[ti].tolist():
+                if node < 0:
+                    continue
+                assert n_dst * x // 8 <= node < n_dst * (x + 1) // 8  # the tile belongs to its XCD's destination range
+                assert int(rp[node]) == e0 + (pk >> 8) and int(rp[node + 1] - rp[node]) == (pk & 255)
+                seen[node] += 1
+                degs.append(pk & 255)
+            assert len(degs) == nd and degs == sorted(degs, reverse=True)
+    assert bool((seen == 1).all())
+    assert int(t.hdr[:, 1].sum()) == plan.num_edges > 1.5 * t.src.shape[0]  # neighbours share sources: re-use inside a tile
+    assert runtime.edge_tile_lists(plan.rowptr, plan.col, src_cap=12, edge_cap=160) is None  # destination 17: 40 edges, > 12 sources ...
+    assert runtime.edge_tile_lists(plan.rowptr, plan.col, src_cap=48, edge_cap=32) is None   # ... alone beyond either cap
+
+
 def test_grad_sink_hands_out_the_stacked_gradient_without_a_copy():
     """``autograd.GradSink`` / ``_Unstack`` (training route of a processor): when the gradient of block i's weight IS slot i of
     the sink, the gradient of the stacked weight is the sink's buffer itself (no ``torch.stack``); anything else -- a missing

@@ -57,13 +57,21 @@ def main():
     out = torch.zeros(n, ld_out, dtype=torch.bfloat16, device=dev)
 
     sched = plan.schedule(torch.bfloat16, c) if os.environ.get("ANEMOI_AMD_EDGE_SCHED", "1") != "0" else None
+    tiles = None
+    if os.environ.get("ANEMOI_AMD_EDGE_TILES", "0") != "0":  # round 6: the LDS-tile kernel (caps: ANEMOI_AMD_EDGE_TILE_SRC / _EDGES)
+        tiles = plan.tiles(torch.bfloat16, c, h, up)
+        th = tiles.hdr.cpu()
+        print(f"tiles: {tiles.n_tiles} (caps {tiles.src_cap} sources / {tiles.edge_cap} edges), {float(th[:, 5].float().mean()):.1f} "
+              f"destinations, {float(th[:, 1].float().mean()):.0f} edges, {float(th[:, 3].float().mean()):.1f} distinct sources per "
+              f"tile: a staged row serves {float(th[:, 1].sum()) / float(th[:, 3].sum()):.2f} edges")
 
     def run():
         ops.gt_edge_attention_folded(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:4 * c], sq[:, :c], sq[:, 4 * c:],
-                                     attr, plan.rowptr, plan.col, h, up, out=out, ld_out=ld_out, sched=sched)
+                                     attr, plan.rowptr, plan.col, h, up, out=out, ld_out=ld_out, sched=sched, tiles=tiles)
 
     e = plan.col.shape[0]
-    report(a, run, out, 4 * n * c * 2 + e * 52 + (n + 1) * 4, f"set=proc order={a.order} col={a.col} n={n} E={e}")
+    report(a, run, out, 4 * n * c * 2 + e * 52 + (n + 1) * 4, f"set=proc order={a.order} col={a.col} n={n} E={e}"
+           + (f" tiles={tiles.src_cap}/{tiles.edge_cap}" if tiles is not None else ""))
 
 
 def mapper(a):
