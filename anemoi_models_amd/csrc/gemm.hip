@@ -15,6 +15,7 @@
 // one barrier per K-slab.  The LDS image is lane-linear (8 rows x 128 B per wave instruction), so the
 // bank swizzle is applied to the per-lane SOURCE address and undone on the fragment read
 // (chunk' = chunk ^ ((row >> 1) & 7)): conflict-free for both fragment shapes.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -28,16 +29,6 @@
 #endif
 #ifndef ANEMOI_LAB_W_AUX
 #define ANEMOI_LAB_W_AUX 0
-#endif
-// Lab switch (round 6): start the workgroups of a launch in ANEMOI_LAB_STAGGER_PHASES groups, group g delayed by
-// g x ANEMOI_LAB_STAGGER x 8128 cycles -- every tile of a launch takes the same time, so the 256 workgroups run in lockstep
-// and their epilogues store 128 KiB each AT ONCE (6.4 us per tile instead of the 3.7 us a CU's own store path takes:
-// profiles/r05_gemm_store_path.md); out of phase the bursts would interleave with other workgroups' K loops.  0 = off.
-#ifndef ANEMOI_LAB_STAGGER
-#define ANEMOI_LAB_STAGGER 0
-#endif
-#ifndef ANEMOI_LAB_STAGGER_PHASES
-#define ANEMOI_LAB_STAGGER_PHASES 2
 #endif
 
 namespace anemoi {
@@ -74,6 +65,12 @@ struct LnFold {
   // operand bases b * b_sx / b_sw / b_sy elements apart; b_tiles = 0: one problem
   int64_t b_tiles, b_sx, b_sw, b_sy;
   int b_count;
+  // staggered start of the four-wave kernel (round 6; set by its launcher): workgroup i of an XCD waits
+  // (i % stagger_phases) * stagger_unit x 1024 cycles before its first tile.  Every tile of a launch takes the same time, so the
+  // 256 persistent workgroups otherwise run in lockstep for the whole launch and their epilogues store 128 KiB each AT THE
+  // SAME TIME (6.4 us per tile against the 3.7 us a CU's own store path needs, profiles/r05_gemm_store_path.md) while
+  // nobody stages; out of phase one group's stores interleave with the others' K loops.  0 / 1 phases: off.
+  int stagger_phases, stagger_unit;
 };
 
 template <typename T, typename TO, int VEC>
@@ -382,6 +379,7 @@ __device__ __forceinline__ void tile_coords(int64_t t64, int nt_count, int64_t m
 // Operand rows beyond M / N are never loaded: the staging goes through buffer descriptors sized to the tile's
 // valid rows (out-of-range lanes of buffer_load ... lds deliver zeros).
 // =============================================================================================
+constexpr int STAGGER_PHASES = 4, STAGGER_UNIT = 8, STAGGER_MIN_ROUNDS = 2, STAGGER_MIN_K = 512;  // (launcher; measured r06)
 constexpr int W4_LDS = 2 * BIG_STAGE + 4096;        // 132 KiB: two slab buffers + the tile's bias, LN column sums, LN row statistics
 
 #define ANEMOI_MFMA_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
@@ -651,9 +649,8 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     else skinny_columns<8, EPI, ACT>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
   }
   if (!has_tiles) return;
-#if ANEMOI_LAB_STAGGER
-  for (int i = 0, n = (int)(bix % ANEMOI_LAB_STAGGER_PHASES) * ANEMOI_LAB_STAGGER; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
+  if (ln.stagger_phases > 1)
+    for (int i = 0, n = (int)(bix % ln.stagger_phases) * ln.stagger_unit; i < n; ++i) __builtin_amdgcn_s_sleep(16);
 #ifndef ANEMOI_LAB_TAIL_BEHIND_DMA
   set_tile(chunk_start + bix);
   stage_all(0, 0);
@@ -1222,7 +1219,21 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       const int64_t m_a = mt_a * BIG_M < M ? mt_a * BIG_M : M, tiles_a = problems * mt_a * nt;
       const int tail_a = mt_b == 0 ? w4_tail : 0;
       w4_blocks = tiles_a < max_blocks ? (tiles_a + 7) / 8 * 8 : max_blocks;
-      LAUNCH_W4_ACT(8, xb, rb, yb, ln, m_a, tiles_a, tail_a)
+      // Staggered start (LnFold::stagger_*): launches of >= min_rounds rounds of tiles with a K loop long enough for one
+      // group's stores to hide under the others' (K >= STAGGER_MIN_K; the K = 256 products measured no gain).  Phase g waits
+      // g x unit x 1024 cycles: what has to be pulled apart is the epilogues (~6 us each), whatever the tile's K.
+      // ANEMOI_AMD_GEMM_STAGGER="phases,unit,min rounds" overrides (phases 0: off; A/B runs).
+      static const struct Stagger { int phases, unit, min_rounds; } stagger = [] {
+        Stagger v{STAGGER_PHASES, STAGGER_UNIT, STAGGER_MIN_ROUNDS};
+        if (const char* e = getenv("ANEMOI_AMD_GEMM_STAGGER")) sscanf(e, "%d,%d,%d", &v.phases, &v.unit, &v.min_rounds);
+        return v;
+      }();
+      LnFold la = ln;
+      if (stagger.phases > 1 && tiles_a >= (int64_t)stagger.min_rounds * max_blocks && K >= STAGGER_MIN_K) {
+        la.stagger_phases = stagger.phases;
+        la.stagger_unit = stagger.unit;
+      }
+      LAUNCH_W4_ACT(8, xb, rb, yb, la, m_a, tiles_a, tail_a)
     }
     if (mt_b > 0) {
       const int64_t m_a = mt_a * BIG_M, m_b = M - m_a, tiles_b = mt_b * 2 * nt;  // m_b may end inside the last tile

@@ -74,7 +74,7 @@ def edge_attr_csr(a0, a1, perm, ld_out=None, one_col=-1):
     return out
 
 
-def gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, rowptr, col, num_heads, up, out=None, ld_out=None, lse=None, runs=None, sched=None):
+def gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, rowptr, col, num_heads, up, out=None, ld_out=None, lse=None, runs=None, sched=None, tiles=None):
     n_dst, c = q.shape
     d = c // num_heads
     dst = torch.repeat_interleave(torch.arange(n_dst), (rowptr[1:] - rowptr[:-1]).long())
