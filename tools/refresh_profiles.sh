@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 
 cd "$ROOT"
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_cfg3_bf16.json" 2> "$OUT/bench_cfg3_bf16.err"
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail > "$OUT/bench_cfg3_bf16_detail.txt" 2>&1
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --detail > "$OUT/bench_cfg3_bf16_detail.txt" 2>&1
 python3 bench.py --workload cfg1 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/bench_cfg1_bf16.json" 2>/dev/null
 python3 bench.py --workload cfg2 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/bench_cfg2_bf16.json" 2>/dev/null
 python3 bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_cfg3_fp32.json" 2>/dev/null
@@ -24,13 +24,13 @@ python3 bench.py --workload cfg2 --steps 20 --warmup 5 > "$OUT/bench_cfg2_bf16_c
 
 cd /tmp
 rm -rf /tmp/kt /tmp/pmcf /tmp/pmcw
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 "$ROOT/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > "$OUT/rocprof_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 "$ROOT/bench.py" --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > "$OUT/rocprof_bench.log" 2>&1
 cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null
 python3 "$ROOT/tools/summarize_trace.py" /tmp/kt > "$OUT/kernel_summary.txt" 2>&1
 
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcf -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcf -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmcf > "$OUT/pmc_fetch_size.txt" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcw -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcw -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmcw > "$OUT/pmc_write_size.txt" 2>&1
 # mesh-node self attention (Transformer processor): kernel trace + MFMA-busy counters of the attention kernel
 rm -rf /tmp/ktt /tmp/pmcm
