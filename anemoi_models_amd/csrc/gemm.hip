@@ -379,7 +379,7 @@ __device__ __forceinline__ void tile_coords(int64_t t64, int nt_count, int64_t m
 // Operand rows beyond M / N are never loaded: the staging goes through buffer descriptors sized to the tile's
 // valid rows (out-of-range lanes of buffer_load ... lds deliver zeros).
 // =============================================================================================
-constexpr int STAGGER_PHASES = 4, STAGGER_UNIT = 8, STAGGER_MIN_ROUNDS = 2, STAGGER_MIN_K = 512;  // (launcher; measured r06)
+constexpr int STAGGER_PHASES = 2, STAGGER_UNIT = 16, STAGGER_MIN_ROUNDS = 2, STAGGER_MIN_K = 512, STAGGER_PCT = 0;  // (launcher; measured r06)
 constexpr int W4_LDS = 2 * BIG_STAGE + 4096;        // 132 KiB: two slab buffers + the tile's bias, LN column sums, LN row statistics
 
 #define ANEMOI_MFMA_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
@@ -1222,16 +1222,24 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       // Staggered start (LnFold::stagger_*): launches of >= min_rounds rounds of tiles with a K loop long enough for one
       // group's stores to hide under the others' (K >= STAGGER_MIN_K; the K = 256 products measured no gain).  Phase g waits
       // g x unit x 1024 cycles: what has to be pulled apart is the epilogues (~6 us each), whatever the tile's K.
-      // ANEMOI_AMD_GEMM_STAGGER="phases,unit,min rounds" overrides (phases 0: off; A/B runs).
-      static const struct Stagger { int phases, unit, min_rounds; } stagger = [] {
-        Stagger v{STAGGER_PHASES, STAGGER_UNIT, STAGGER_MIN_ROUNDS};
-        if (const char* e = getenv("ANEMOI_AMD_GEMM_STAGGER")) sscanf(e, "%d,%d,%d", &v.phases, &v.unit, &v.min_rounds);
+      // ANEMOI_AMD_GEMM_STAGGER="phases,unit,min rounds[,percent of a tile's time per step]" overrides (phases 0: off; A/B runs).
+      static const struct Stagger { int phases, unit, min_rounds, pct; } stagger = [] {
+        Stagger v{STAGGER_PHASES, STAGGER_UNIT, STAGGER_MIN_ROUNDS, STAGGER_PCT};
+        if (const char* e = getenv("ANEMOI_AMD_GEMM_STAGGER")) {
+          v.pct = 0;
+          sscanf(e, "%d,%d,%d,%d", &v.phases, &v.unit, &v.min_rounds, &v.pct);
+        }
         return v;
       }();
       LnFold la = ln;
       if (stagger.phases > 1 && tiles_a >= (int64_t)stagger.min_rounds * max_blocks && K >= STAGGER_MIN_K) {
         la.stagger_phases = stagger.phases;
         la.stagger_unit = stagger.unit;
+        if (stagger.pct > 0) {  // the step between two phases as a percentage of ONE TILE's time (6.5 us + 1.44 us per slab, ~2.1 cycles / ns)
+          const double tile_cycles = (6.5 + (K / 64) * 1.44) * 2100.0;
+          la.stagger_unit = (int)(tile_cycles * stagger.pct / 100.0 / 1024.0 + 0.5);
+          if (la.stagger_unit < 1) la.stagger_unit = 1;
+        }
       }
       LAUNCH_W4_ACT(8, xb, rb, yb, la, m_a, tiles_a, tail_a)
     }

@@ -592,6 +592,41 @@ def test_gt_edge_attention_folded_tiles_is_the_plain_kernel_bit_for_bit(n_src, n
         assert torch.equal(run(tiles=tiles)[0], plain)  # reproducible
 
 
+def test_model_on_the_tile_edge_kernel_is_the_default_route_bit_for_bit(monkeypatch):
+    """``ANEMOI_AMD_EDGE_TILES=1`` (round 6): the mesh launches of the processor take the LDS-tile kernel -- through the
+    block-level entry point (``anemoi_gt_block_args.tile_*``) and through the op-by-op route (``ops.gt_edge_attention_folded
+    (tiles=...)``) -- and the whole model's output is BIT-IDENTICAL to the default route's (scheduled kernel): O96 -> ico-5,
+    512 channels (D = 32, four 128-channel slices), 4 blocks, bf16."""
+    from anemoi_models_amd.graphs.synthetic import build_graph
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    graph = build_graph("o96_ico5")
+    x = torch.randn(1, 2, 1, graph["data"].num_nodes, 12, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def run(tiles: str, block_abi: bool):
+        monkeypatch.setenv("ANEMOI_AMD_EDGE_TILES", tiles)
+        torch.manual_seed(3)
+        model, _ = _build(graph, 512, 4, heads=16)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if name.endswith("trainable"):
+                    p.normal_(0.0, 0.1)
+        model = model.to(DEV).eval()
+        model.processor.block_abi = block_abi
+        with torch.no_grad():
+            y = model(x)
+        return y, model, None
+
+    want, _, _ = run("0", True)
+    got, model, _ = run("1", True)
+    assert torch.equal(got, want)
+    got_ops, _, _ = run("1", False)  # (op-by-op: ops.gt_edge_attention_folded(tiles=...))
+    assert torch.equal(got_ops, want)
+    # the tile lists really were built for the mesh plan of that model (the switch is not a no-op)
+    fast = model.processor.__dict__.get("_abi_plan")
+    assert fast is not None and fast.ok and fast.keep[4] is not None and fast.keep[4].n_tiles > 100
+
+
 def test_edge_plan_on_device_is_bit_exact_with_cpu():
     from anemoi_models_amd import runtime
 
