@@ -379,7 +379,7 @@ __device__ __forceinline__ void tile_coords(int64_t t64, int nt_count, int64_t m
 // Operand rows beyond M / N are never loaded: the staging goes through buffer descriptors sized to the tile's
 // valid rows (out-of-range lanes of buffer_load ... lds deliver zeros).
 // =============================================================================================
-constexpr int STAGGER_PHASES = 2, STAGGER_UNIT = 16, STAGGER_MIN_ROUNDS = 2, STAGGER_MIN_K = 512, STAGGER_PCT = 0;  // (launcher; measured r06)
+constexpr int STAGGER_PHASES = 2, STAGGER_UNIT = 16, STAGGER_MIN_ROUNDS = 2, STAGGER_MIN_K = 512;  // (launcher; measured r06)
 constexpr int W4_LDS = 2 * BIG_STAGE + 4096;        // 132 KiB: two slab buffers + the tile's bias, LN column sums, LN row statistics
 
 #define ANEMOI_MFMA_A(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void linear_bf16_w4_kernel(const bf16_t* __res
     else skinny_columns<8, EPI, ACT>(xt, ldx, W, bias, rt, ldr, yt, ldy, m_tail, N, K, ACT, lt, lane, gw, tw);
   }
   if (!has_tiles) return;
-  if (ln.stagger_phases > 1)
+  if (ln.stagger_phases > 1)  // (phases by position inside the XCD; by XCD, or by both, measured the same: gpurun_out/r06_s24)
     for (int i = 0, n = (int)(bix % ln.stagger_phases) * ln.stagger_unit; i < n; ++i) __builtin_amdgcn_s_sleep(16);
 #ifndef ANEMOI_LAB_TAIL_BEHIND_DMA
   set_tile(chunk_start + bix);
@@ -1177,6 +1177,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
     // (a half-tile split chosen above competes with the single-launch candidates: its cost by the same model = whole rounds of
     //  256-row tiles + the rounds of half tiles at 0.75 of the slab cost + ~6 us for the second launch.  20 481 x 1024 x 4096,
     //  one rank of two: 256 + 128 half tiles = 177 against 158 for two rounds of 160-row tiles)
+    // Staggered start (LnFold::stagger_*); ANEMOI_AMD_GEMM_STAGGER="phases,unit,min rounds" overrides the shipped values
+    // (phases 0: off; A/B runs)
+    static const struct Stagger { int phases, unit, min_rounds; } stagger = [] {
+      Stagger v{STAGGER_PHASES, STAGGER_UNIT, STAGGER_MIN_ROUNDS};
+      if (const char* e = getenv("ANEMOI_AMD_GEMM_STAGGER")) sscanf(e, "%d,%d,%d", &v.phases, &v.unit, &v.min_rounds);
+      return v;
+    }();
     const bool split_chosen = mt_b > 0 && !dual && !gmul;
     if (!batched && !dual && !gmul && (mt_b == 0 || split_chosen) && mt * nt < 4 * max_blocks) {
       static const int forced_mh = [] {  // lab switch for A/B runs: ANEMOI_AMD_GEMM_MH=3|4|5|6|8
@@ -1208,6 +1215,7 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       if (single && best_mh != 8) {
         const int64_t tiles = (M + 32 * best_mh - 1) / (32 * best_mh) * nt;
         w4_blocks = tiles < max_blocks ? (tiles + 7) / 8 * 8 : max_blocks;
+        // (no stagger on these launches of one or two rounds: 1 ... 4 units measured 3.20 -> 3.20 ... 3.26 ms at config 2)
         if (best_mh == 6) { LAUNCH_W4_PLAIN(6, xb, rb, yb, ln, M, tiles, w4_tail) }
         else if (best_mh == 5) { LAUNCH_W4_PLAIN(5, xb, rb, yb, ln, M, tiles, w4_tail) }
         else if (best_mh == 3) { LAUNCH_W4_PLAIN(3, xb, rb, yb, ln, M, tiles, w4_tail) }
@@ -1219,27 +1227,13 @@ static int linear_bf16_256_launch(const void* x, int64_t ldx, const void* w, con
       const int64_t m_a = mt_a * BIG_M < M ? mt_a * BIG_M : M, tiles_a = problems * mt_a * nt;
       const int tail_a = mt_b == 0 ? w4_tail : 0;
       w4_blocks = tiles_a < max_blocks ? (tiles_a + 7) / 8 * 8 : max_blocks;
-      // Staggered start (LnFold::stagger_*): launches of >= min_rounds rounds of tiles with a K loop long enough for one
-      // group's stores to hide under the others' (K >= STAGGER_MIN_K; the K = 256 products measured no gain).  Phase g waits
-      // g x unit x 1024 cycles: what has to be pulled apart is the epilogues (~6 us each), whatever the tile's K.
-      // ANEMOI_AMD_GEMM_STAGGER="phases,unit,min rounds[,percent of a tile's time per step]" overrides (phases 0: off; A/B runs).
-      static const struct Stagger { int phases, unit, min_rounds, pct; } stagger = [] {
-        Stagger v{STAGGER_PHASES, STAGGER_UNIT, STAGGER_MIN_ROUNDS, STAGGER_PCT};
-        if (const char* e = getenv("ANEMOI_AMD_GEMM_STAGGER")) {
-          v.pct = 0;
-          sscanf(e, "%d,%d,%d,%d", &v.phases, &v.unit, &v.min_rounds, &v.pct);
-        }
-        return v;
-      }();
+      // Staggered start (LnFold::stagger_*): launches of >= min_rounds rounds of tiles with K >= STAGGER_MIN_K (the K = 256
+      // products measured no gain).  Phase g waits g x unit x 1024 cycles; a SMALL offset is what counts -- 2 x 8 ... 32 units,
+      // 3 x 12, 4 x 8 measured alike, a step of half a tile's time or 16 phases nothing.
       LnFold la = ln;
       if (stagger.phases > 1 && tiles_a >= (int64_t)stagger.min_rounds * max_blocks && K >= STAGGER_MIN_K) {
         la.stagger_phases = stagger.phases;
         la.stagger_unit = stagger.unit;
-        if (stagger.pct > 0) {  // the step between two phases as a percentage of ONE TILE's time (6.5 us + 1.44 us per slab, ~2.1 cycles / ns)
-          const double tile_cycles = (6.5 + (K / 64) * 1.44) * 2100.0;
-          la.stagger_unit = (int)(tile_cycles * stagger.pct / 100.0 / 1024.0 + 0.5);
-          if (la.stagger_unit < 1) la.stagger_unit = 1;
-        }
       }
       LAUNCH_W4_ACT(8, xb, rb, yb, la, m_a, tiles_a, tail_a)
     }
