@@ -225,3 +225,31 @@ def test_bench_secondary_block_on_the_gpu(monkeypatch):
         assert 0.0 < leg["roofline"]["frac"] < 1.0 and leg["roofline"]["bound"] == "mfma"
     assert 0.0 < out["cfg2"]["roofline_edge"]["frac"] < 1.0 and out["cfg2"]["roofline_edge"]["bound"] == "hbm"
     json.dumps(out)  # serialisable as it is
+
+
+def test_host_threads_follow_the_cgroup_cpu_quota(tmp_path, monkeypatch):
+    """``bench.host_threads`` (the oracle's thread count, ``cpu_baseline.cores``): the affinity mask, cut by the cgroup CPU
+    quota when there is one -- the GPU boxes of this pool show 256 logical CPUs under a quota of 16."""
+    import builtins
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    real_open = builtins.open
+
+    def fake(content):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(content)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert bench.host_threads() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert bench.host_threads() == 256
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert bench.host_threads() == 1

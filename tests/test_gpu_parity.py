@@ -708,6 +708,46 @@ def test_glue_kernels_on_a_row_list():
         ops.assemble_nodes(x.repeat(2, 1, 1, 1, 1), ll, tr, 2, torch.float32, rows=rows)
 
 
+def test_linear_staggered_start_changes_no_bit(tmp_path):
+    """Round 6: the persistent GEMM starts its workgroups in phases (``LnFold::stagger_*``, DESIGN 4.1; launches of >= 2 rounds
+    of 256-row tiles with K >= 512).  Which workgroup starts when changes no arithmetic: fresh processes with the stagger off
+    (``ANEMOI_AMD_GEMM_STAGGER=0,0,2``, read once per process), at its shipped setting and at an exaggerated one compute the
+    same products -- plain, GELU, residual + row statistics, LayerNorm fold, ragged rows -- bit for bit."""
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from anemoi_models_amd import ops\n"
+        "g = torch.Generator().manual_seed(33)\n"
+        "out = {}\n"
+        "for m, n, k in ((40962, 1024, 1024), (20481, 2048, 512), (8200, 4096, 1216)):\n"
+        "    x = torch.randn(m, k, generator=g).bfloat16().cuda()\n"
+        "    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16().cuda()\n"
+        "    b = torch.randn(n, generator=g).cuda()\n"
+        "    r = torch.randn(m, n, generator=g).bfloat16().cuda()\n"
+        "    stats = torch.stack([torch.rand(m, generator=g) + 0.5, torch.randn(m, generator=g) * 0.3], 1).contiguous().cuda()\n"
+        "    cs = torch.randn(n, generator=g).cuda()\n"
+        "    out[f'{m}x{n}x{k} plain'] = ops.linear(x, w, b).cpu()\n"
+        "    out[f'{m}x{n}x{k} gelu ln'] = ops.linear(x, w, b, act='GELU', ln=(stats, cs)).cpu()\n"
+        "    y = ops.linear(x, w, b, residual=r, stats_eps=1e-5)\n"
+        "    out[f'{m}x{n}x{k} res'] = y.cpu()\n"
+        "    out[f'{m}x{n}x{k} res stats'] = ops.row_stats(y, 1e-5).cpu()\n"
+        "torch.save(out, sys.argv[1])\n")
+    res = {}
+    for mode in ("0,0,2", "2,16,2", "4,40,1"):
+        path = str(tmp_path / f"out_{mode.replace(',', '_')}.pt")
+        subprocess.run([sys.executable, str(script), path], check=True, env=dict(os.environ, ANEMOI_AMD_GEMM_STAGGER=mode),
+                       timeout=600)
+        res[mode] = torch.load(path)
+    for mode in ("2,16,2", "4,40,1"):
+        for k in res["0,0,2"]:
+            assert torch.equal(res["0,0,2"][k], res[mode][k]), (mode, k)
+
+
 def test_glue_kernels_64_bit_index_instantiations(tmp_path):
     """The glue kernels pick 32-bit index arithmetic when the flat index fits 31 bits -- always, at the sizes a test can hold.
     ``ANEMOI_AMD_IDX64=1`` (read once per process) forces the 64-bit instantiations: a fresh process computes the same
