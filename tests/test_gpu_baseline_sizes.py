@@ -168,6 +168,33 @@ def test_config5_gnn_o96_512ch_16_blocks_bf16_vs_oracle(o96_gnn, monkeypatch):
     assert torch.isfinite(got).all() and err < BF16_BOUND
 
 
+@pytest.fixture(scope="module")
+def o96_tfm():
+    return _make("Transformer")
+
+
+def test_config2_size_transformer_processor_16_blocks_f32_and_bf16_vs_oracle(o96_tfm, monkeypatch):
+    """The Transformer-processor family at BASELINE config 2's size (O96 -> ico-5, 512 channels, 16 blocks of mesh-node
+    MultiHeadSelfAttention over all 10 242 nodes, 16 heads of 32; reference layers/attention.py:67-112, layers/block.py:99-105)
+    against ``oracle.model_forward(processor="Transformer")``: f32 (exact-f32 GEMMs, the f32 attention route) gated at 1e-3 per
+    output variable; bf16 (the MFMA flash attention, D = 32) bounded.  Round 6: until now this family was held to the oracle at
+    config 1's size only (golden vectors) and to an f64 formula per attention call at mesh size."""
+    model, x, want, _, _ = o96_tfm
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "fp32")
+    with torch.no_grad():
+        got = model(x)
+    err, err_v = rel_err(got, want), per_variable_rel_err(got, want)
+    print(f"config-2 size, 16 Transformer blocks, f32 vs CPU oracle: max rel {err:.3e}, per variable {err_v:.3e}")
+    assert got.dtype == torch.float32 and got.shape == want.shape
+    assert err < 1e-3 and err_v < 1e-3
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", "bf16")
+    with torch.no_grad():
+        got16 = model(x)
+    e16 = rel_err(got16, want)
+    print(f"config-2 size, 16 Transformer blocks, bf16 vs f32 CPU oracle: max rel {e16:.3e} (bound {BF16_BOUND})")
+    assert torch.isfinite(got16).all() and e16 < BF16_BOUND
+
+
 def test_rollout_2_steps_o96_vs_oracle(monkeypatch):
     """BASELINE config 4 semantics at O96 / 512 ch / 16 blocks: 2 autoregressive steps through
     ``AnemoiModelInterface.rollout`` (normaliser folded into the first / last kernel, ``anemoi_advance_input`` between the
