@@ -32,7 +32,7 @@ BF16 = 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 ACT_CODES = {"Identity": ACT_NONE, "GELU": ACT_GELU, "SiLU": ACT_SILU, "ReLU": ACT_RELU}
 
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 
 class GtBlockArgs(ctypes.Structure):
@@ -129,13 +129,15 @@ SIGNATURES = {
     "anemoi_linear_actgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                       c_int, c_int, c_int, c_void_p]),
     "anemoi_gt_conv": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_float, c_uint32,
+                               c_void_p, c_void_p]),
     "anemoi_gt_conv_backward_dst": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                             c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+                                            c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_uint32, c_void_p,
+                                            c_void_p]),
     "anemoi_gt_conv_backward_src": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                            c_int64, c_int, c_int, c_void_p]),
+                                            c_int64, c_int, c_int, c_float, c_uint32, c_void_p, c_void_p]),
     "anemoi_gt_edge_attention": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int64, c_int64, c_int, c_int, c_void_p]),

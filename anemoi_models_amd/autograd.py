@@ -635,11 +635,14 @@ class _GTConv(torch.autograd.Function):
     variants), which also return ``d e``."""
 
     @staticmethod
-    def forward(ctx, q, k, v, e, x_r, plan, num_heads: int):
+    def forward(ctx, q, k, v, e, x_r, plan, num_heads: int, dropout_p: float = 0.0, seed: int = 0, seed_dev=None):
         lse = torch.empty((q.shape[0], num_heads), dtype=torch.float32, device=q.device)
-        out = ops.gt_conv(q, k, v, e, plan.rowptr, plan.col, num_heads, x_r=x_r, lse=lse)
+        out = ops.gt_conv(q, k, v, e, plan.rowptr, plan.col, num_heads, x_r=x_r, lse=lse, dropout_p=dropout_p,
+                          dropout_seed=seed, seed_dev=seed_dev)
         ctx.save_for_backward(q, k, v, e, lse)
         ctx.plan, ctx.h, ctx.has_xr = plan, num_heads, x_r is not None
+        # (seed_dev is THIS call's word, see _MHSA: the backward rebuilds the mask its forward drew)
+        ctx.drop = (float(dropout_p), int(seed) & 0xFFFFFFFF, seed_dev)
         return out
 
     @staticmethod
@@ -653,8 +656,11 @@ class _GTConv(torch.autograd.Function):
         n_dst, c = q.shape
         n_src, n_edges = k.shape[0], plan.col.shape[0]
         if n_edges == 0:
-            return torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v), torch.zeros_like(e), dxr, None, None
+            return (torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v), torch.zeros_like(e), dxr, None, None, None,
+                    None, None)
         dev = q.device
+        p_drop, seed, seed_dev = ctx.drop
+        drop = (p_drop, seed, ops._seed_dev_ptr(seed_dev, q))
         alpha = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
         w = torch.empty((n_edges, h), dtype=torch.float32, device=dev)
         dsum = torch.empty((n_dst, h), dtype=torch.float32, device=dev)
@@ -668,25 +674,31 @@ class _GTConv(torch.autograd.Function):
         st = lib.anemoi_gt_conv_backward_dst(code, q.data_ptr(), ld(q), k.data_ptr(), v.data_ptr(), ld(k), e.data_ptr(), ld(e),
                                              dout.data_ptr(), ld(dout), lse.data_ptr(), plan.rowptr.data_ptr(),
                                              plan.col.data_ptr(), alpha.data_ptr(), w.data_ptr(), dsum.data_ptr(),
-                                             dq.data_ptr(), c, n_dst, c, h, stream)
+                                             dq.data_ptr(), c, n_dst, c, h, *drop, stream)
         _lib.check(st, "anemoi_gt_conv_backward_dst")
         rowptr_t, eid_t, dst_t, _ = _transposed_csr(plan)
         st = lib.anemoi_gt_conv_backward_src(code, q.data_ptr(), ld(q), dout.data_ptr(), ld(dout), alpha.data_ptr(),
                                              w.data_ptr(), dsum.data_ptr(), rowptr_t.data_ptr(), eid_t.data_ptr(),
                                              dst_t.data_ptr(), dkv.data_ptr(), dkv[:, c:].data_ptr(), 2 * c, de.data_ptr(), c,
-                                             n_src, c, h, stream)
+                                             n_src, c, h, *drop, stream)
         _lib.check(st, "anemoi_gt_conv_backward_src")
-        return dq, dkv[:, :c], dkv[:, c:], de, dxr, None, None
+        return dq, dkv[:, :c], dkv[:, c:], de, dxr, None, None, None, None, None
 
 
-def gt_conv(q: Tensor, k: Tensor, v: Tensor, e_csr: Tensor, x_r: Optional[Tensor], plan, num_heads: int) -> Tensor:
+def gt_conv(q: Tensor, k: Tensor, v: Tensor, e_csr: Tensor, x_r: Optional[Tensor], plan, num_heads: int,
+            dropout_p: float = 0.0, seed: Optional[int] = None, seed_dev: Optional[Tensor] = None) -> Tensor:
     """Differentiable ``ops.gt_conv``: gradients for ``q, k, v`` (``k`` / ``v`` slices of one buffer), the per-edge
-    features ``e_csr [E, C]`` and ``x_r``."""
+    features ``e_csr [E, C]`` and ``x_r``.  ``dropout_p > 0``: dropout of the attention weights (reference layers/conv.py:140)
+    with the mask derived from ``seed`` (default: drawn from torch's CPU generator, so ``torch.manual_seed`` reproduces it);
+    the backward rebuilds the same mask."""
+    if dropout_p > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+    drop = (float(dropout_p), int(seed or 0), seed_dev)
     if _edge_phase_in_f32(q.dtype, q.shape[1], num_heads):
         kv, c = torch.cat([k, v], dim=1).float(), q.shape[1]
         return _GTConv.apply(q.float(), kv[:, :c], kv[:, c:], e_csr.float(), None if x_r is None else x_r.float(), plan,
-                             num_heads).to(q.dtype)
-    return _GTConv.apply(q, k, v, e_csr, x_r, plan, num_heads)
+                             num_heads, *drop).to(q.dtype)
+    return _GTConv.apply(q, k, v, e_csr, x_r, plan, num_heads, *drop)
 
 
 def _edge_phase_in_f32(dtype: torch.dtype, c: int, num_heads: int) -> bool:

@@ -220,4 +220,38 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 
 inline hipStream_t as_stream(anemoi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Dropout of the edge attention weights (reference layers/conv.py:140, `dropout(alpha, p, training)` on alpha [E, H]): a
+// counter-based keep decision per (edge position in the destination-sorted CSR, head) -- no mask tensor, the backward kernels
+// rebuild it from the seed.  x = e G1 ^ h G2 ^ seed, one multiply between two fold-downs, the top 15 bits against p 2^15
+// (tests/test_gpu_training.py::_edge_dropout_keep_mask restates it).  `seed_dev`: optional device word added to the seed by
+// the kernel (runtime.DeviceDropout: what a captured training step advances itself), as in csrc/attention.hip.
+struct EdgeDropout {
+  uint32_t thr15;    // keep  <=>  15 hash bits >= thr15  (p 2^15; 0: no dropout, 0x8000: everything dropped)
+  uint32_t seed;
+  float keep_scale;  // 1 / (1 - p); 0 when p >= 1
+  const uint32_t* seed_dev;
+};
+
+inline EdgeDropout make_edge_dropout(float p, uint32_t seed, const void* seed_dev) {
+  EdgeDropout dr;
+  const double t = p <= 0.f ? 0.0 : (double)p * 32768.0 + 0.5;
+  dr.thr15 = p >= 1.0f ? 0x8000u : (uint32_t)(t > 32768.0 ? 32768.0 : t);
+  dr.seed = seed;
+  dr.keep_scale = (p > 0.f && p < 1.0f) ? 1.0f / (1.0f - p) : (p >= 1.0f ? 0.f : 1.0f);
+  dr.seed_dev = static_cast<const uint32_t*>(seed_dev);
+  return dr;
+}
+
+__device__ __forceinline__ uint32_t edge_dropout_seed(const EdgeDropout& dr) {
+  return dr.seed_dev != nullptr ? dr.seed + __builtin_nontemporal_load(dr.seed_dev) : dr.seed;
+}
+
+__device__ __forceinline__ float edge_dropout_keep(const EdgeDropout& dr, uint32_t seed, int64_t e, int head) {
+  uint32_t x = (uint32_t)e * 0x9E3779B1u ^ (uint32_t)head * 0x85EBCA77u ^ seed;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  return (x >> 17) >= dr.thr15 ? dr.keep_scale : 0.f;
+}
+
 }  // namespace anemoi

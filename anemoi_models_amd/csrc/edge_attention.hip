@@ -1593,6 +1593,8 @@ extern "C" int anemoi_gt_edge_attention(int dtype, const void* q, int64_t ldq, c
 //     s = q_i . (k_j + e_ij) / sqrt(D),  alpha = segment_softmax_i(s) (+1e-16),  out_i = sum_j alpha (v_j + e_ij).
 // Same wave / lane mapping and online softmax as the fused kernels; the edge rows are streamed (read once, in order), so
 // this costs 2 C bytes per edge more than the folded kernel -- it exists for callers that use the conv on its own.
+// DROP: the conv's `dropout` argument in training mode (layers/conv.py:140): alpha keeps its normalisation, the weighted sum
+// takes alpha keep / (1 - p) per (edge, head) -- common.hpp::edge_dropout_keep.
 // ---------------------------------------------------------------------------------------------
 struct EdgeConvParams {
   const void* q;
@@ -1606,13 +1608,15 @@ struct EdgeConvParams {
   int64_t n_dst;
   int C, D, n_slices;
   float scale;
+  EdgeDropout drop;
 };
 
-template <typename T, int VEC, int LPH>
+template <typename T, int VEC, int LPH, bool DROP>
 __global__ __launch_bounds__(256) void gt_conv_kernel(const EdgeConvParams p, const int32_t* __restrict__ rowptr_,
                                                       const int32_t* __restrict__ col_) {
   using Raw = typename RawVec<T, VEC>::type;
   constexpr int U = 2;
+  const uint32_t dseed = DROP ? edge_dropout_seed(p.drop) : 0u;
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int xcd = blockIdx.x & 7;
@@ -1662,8 +1666,9 @@ __global__ __launch_bounds__(256) void gt_conv_kernel(const EdgeConvParams p, co
           const float mn = fmaxf(m, s);
           const float corr = __expf(m - mn), pe = __expf(s - mn);
           l = l * corr + pe;
+          const float pv = DROP ? pe * edge_dropout_keep(p.drop, dseed, e + uu, (active ? gl : 0) / LPH) : pe;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pe, vv[i] + ee[i], acc[i] * corr);
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pv, vv[i] + ee[i], acc[i] * corr);
           m = mn;
         }
       }
@@ -1694,9 +1699,10 @@ static bool dispatch_conv(const EdgeConvParams& p, const int32_t* rowptr, const 
   while ((bpx * 4) % p.n_slices != 0) ++bpx;
   const dim3 grid((unsigned)(8 * bpx)), block(256);
   switch (p.D / VEC) {
-#define ANEMOI_CONV(L)                                                                        \
-  case L:                                                                                     \
-    hipLaunchKernelGGL((gt_conv_kernel<T, VEC, L>), grid, block, 0, st, p, rowptr, col);       \
+#define ANEMOI_CONV(L)                                                                                 \
+  case L:                                                                                              \
+    if (p.drop.thr15 != 0) hipLaunchKernelGGL((gt_conv_kernel<T, VEC, L, true>), grid, block, 0, st, p, rowptr, col); \
+    else hipLaunchKernelGGL((gt_conv_kernel<T, VEC, L, false>), grid, block, 0, st, p, rowptr, col);    \
     return true;
     ANEMOI_CONV(1)
     ANEMOI_CONV(2)
@@ -1711,8 +1717,11 @@ static bool dispatch_conv(const EdgeConvParams& p, const int32_t* rowptr, const 
 extern "C" int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                               const void* edges, int64_t lde, const void* x_r, int64_t ldr, const int32_t* rowptr,
                               const int32_t* col, void* out, int64_t ldo, float* lse, int64_t n_dst, int C, int H,
+                              float dropout_p, uint32_t dropout_seed, const void* dropout_seed_dev,
                               anemoi_stream_t stream) {
   ANEMOI_REQUIRE(q && k && v && out && rowptr, ANEMOI_ERR_INVALID, "anemoi_gt_conv: null pointer");
+  ANEMOI_REQUIRE(dropout_p >= 0.f && dropout_p <= 1.f, ANEMOI_ERR_INVALID, "anemoi_gt_conv: dropout_p %g outside [0, 1]",
+                 (double)dropout_p);
   ANEMOI_REQUIRE(C > 0 && H > 0 && C % H == 0 && n_dst >= 0 && ldq >= C && ldkv >= C && ldo >= C && lde >= C &&
                      (x_r == nullptr || ldr >= C),
                  ANEMOI_ERR_INVALID, "anemoi_gt_conv: bad shape");
@@ -1729,6 +1738,7 @@ extern "C" int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void*
   p.n_dst = n_dst; p.C = C; p.D = C / H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
   p.scale = 1.0f / sqrtf((float)(C / H));
+  p.drop = make_edge_dropout(dropout_p, dropout_seed, dropout_seed_dev);
   bool ok = false;
   if (dtype == ANEMOI_F32) ok = dispatch_conv<float>(p, rowptr, col, as_stream(stream));
   else if (dtype == ANEMOI_BF16) ok = dispatch_conv<bf16_t>(p, rowptr, col, as_stream(stream));

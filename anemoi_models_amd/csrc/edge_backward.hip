@@ -294,6 +294,9 @@ __global__ __launch_bounds__(256) void edge_attr_grad_kernel(const float* __rest
 // folded kernels do not cover): with k'_e = k_j + e_e, v'_e = v_j + e_e the formulas above hold with k', v' in place of
 // k, v and no attribute terms; in addition  d e_e = alpha_e dout_i + scale ds_e q_i  -- exactly the per-edge terms of
 // dv_j and dk_j, so the source-major kernel stores them on its way ([E, C], CSR position eid_t).
+// DROP (the conv's dropout in training mode, out_i = sum_e alpha_e m_e v'_e with m_e = keep_e / (1 - p) rebuilt from the
+// seed): d v'_e = alpha_e m_e dout_i and d alpha_e = m_e (dout_i . v'_e), so w_e = alpha_e m_e (dout_i . v'_e) and everything
+// behind w -- dsum, ds_e, dq, dk' -- is unchanged.
 // ---------------------------------------------------------------------------------------------
 struct ConvBwdParams {
   const void* q;
@@ -310,9 +313,10 @@ struct ConvBwdParams {
   int64_t n_dst;
   int C, H, n_slices;
   float scale;
+  EdgeDropout drop;
 };
 
-template <typename T, int VEC, int LPH, int U>
+template <typename T, int VEC, int LPH, int U, bool DROP>
 __global__ __launch_bounds__(256) void gt_conv_bwd_dst_kernel(const ConvBwdParams p, const int32_t* __restrict__ rowptr_,
                                                               const int32_t* __restrict__ col_) {
   using Raw = typename RawVec<T, VEC>::type;
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(256) void gt_conv_bwd_dst_kernel(const ConvBwdParam
   const T* vb = static_cast<const T*>(p.v) + c0;
   const T* eb = static_cast<const T*>(p.e) + c0;
   const T* dob = static_cast<const T*>(p.dout) + c0;
+  const uint32_t dseed = DROP ? edge_dropout_seed(p.drop) : 0u;
   for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
     const int e_begin = rowptr_[node], e_end = rowptr_[node + 1];
     float qf[VEC], dof[VEC], ak[VEC], bk[VEC], dsum = 0.f;
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void gt_conv_bwd_dst_kernel(const ConvBwdParam
           const float s = group_sum<LPH>(ts) * p.scale;
           const float da = group_sum<LPH>(td);
           const float alpha = __expf(s - lse);
-          const float w = alpha * da;
+          const float w = DROP ? alpha * da * edge_dropout_keep(p.drop, dseed, e + uu, head) : alpha * da;
           dsum += w;
           if (writer) {
             p.alpha[(int64_t)(e + uu) * p.H + head] = alpha;
@@ -408,9 +413,10 @@ struct ConvBwdSrcParams {
   int64_t n_src;
   int C, H, n_slices;
   float scale;
+  EdgeDropout drop;
 };
 
-template <typename T, int VEC, int LPH, int U>
+template <typename T, int VEC, int LPH, int U, bool DROP>
 __global__ __launch_bounds__(256) void gt_conv_bwd_src_kernel(const ConvBwdSrcParams p,
                                                               const int32_t* __restrict__ rowptr_t,
                                                               const int32_t* __restrict__ eid_t,
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(256) void gt_conv_bwd_src_kernel(const ConvBwdSrcPa
   const T* qb = static_cast<const T*>(p.q) + c0;
   const T* dob = static_cast<const T*>(p.dout) + c0;
   T* deb = static_cast<T*>(p.de) + c0;
+  const uint32_t dseed = DROP ? edge_dropout_seed(p.drop) : 0u;
   for (int64_t node = n0 + node_first; node < n1; node += node_stride) {
     const int t_begin = rowptr_t[node], t_end = rowptr_t[node + 1];
     float dk[VEC], dv[VEC];
@@ -459,12 +466,13 @@ __global__ __launch_bounds__(256) void gt_conv_bwd_src_kernel(const ConvBwdSrcPa
       for (int uu = 0; uu < U; ++uu) {
         if (t + uu < t_end) {
           const float dse = fmaf(-al[uu], dsm[uu], ww[uu]) * p.scale;  // scale ds_e
+          const float alv = DROP ? al[uu] * edge_dropout_keep(p.drop, dseed, eid[uu], head) : al[uu];  // alpha_e m_e
           float qf[VEC], dof[VEC], de[VEC];
           unpack<T, VEC>(qr[uu], qf);
           unpack<T, VEC>(dor[uu], dof);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
-            const float gk = dse * qf[i], gv = al[uu] * dof[i];
+            const float gk = dse * qf[i], gv = alv * dof[i];
             dk[i] += gk;
             dv[i] += gv;
             de[i] = gk + gv;
@@ -640,7 +648,8 @@ int anemoi_gt_edge_attr_grad(int dtype, const float* alpha, const float* w, cons
 int anemoi_gt_conv_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                                 const void* edges, int64_t lde, const void* dout, int64_t ldd, const float* lse,
                                 const int32_t* rowptr, const int32_t* col, float* alpha, float* w, float* dsum, void* dq,
-                                int64_t lddq, int64_t n_dst, int C, int H, anemoi_stream_t stream) {
+                                int64_t lddq, int64_t n_dst, int C, int H, float dropout_p, uint32_t dropout_seed,
+                                const void* dropout_seed_dev, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(q && k && v && edges && dout && lse && rowptr && col && alpha && w && dsum && dq, ANEMOI_ERR_INVALID,
                  "anemoi_gt_conv_backward_dst: null pointer");
   ANEMOI_REQUIRE(n_dst >= 0 && C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID, "anemoi_gt_conv_backward_dst: bad shape");
@@ -655,13 +664,15 @@ int anemoi_gt_conv_backward_dst(int dtype, const void* q, int64_t ldq, const voi
   p.ldq = ldq; p.ldkv = ldkv; p.lde = lde; p.ldd = ldd; p.lddq = lddq; p.n_dst = n_dst; p.C = C; p.H = H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
   p.scale = 1.0f / sqrtf((float)(C / H));
+  p.drop = make_edge_dropout(dropout_p, dropout_seed, dropout_seed_dev);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(bwd_blocks(n_dst, p.n_slices, 4)), block(256);
   const int D = C / H;
   bool ok = D % vec == 0;
-#define ANEMOI_CONV_DST(TT, VV, L)                                                                          \
-  case L:                                                                                                   \
-    hipLaunchKernelGGL((gt_conv_bwd_dst_kernel<TT, VV, L, 2>), grid, block, 0, st, p, rowptr, col);         \
+#define ANEMOI_CONV_DST(TT, VV, L)                                                                                          \
+  case L:                                                                                                                   \
+    if (p.drop.thr15 != 0) hipLaunchKernelGGL((gt_conv_bwd_dst_kernel<TT, VV, L, 2, true>), grid, block, 0, st, p, rowptr, col); \
+    else hipLaunchKernelGGL((gt_conv_bwd_dst_kernel<TT, VV, L, 2, false>), grid, block, 0, st, p, rowptr, col);              \
     break;
   if (ok && dtype == ANEMOI_F32) {
     switch (D / 4) { ANEMOI_CONV_DST(float, 4, 1) ANEMOI_CONV_DST(float, 4, 2) ANEMOI_CONV_DST(float, 4, 4)
@@ -680,7 +691,8 @@ int anemoi_gt_conv_backward_dst(int dtype, const void* q, int64_t ldq, const voi
 int anemoi_gt_conv_backward_src(int dtype, const void* q, int64_t ldq, const void* dout, int64_t ldd, const float* alpha,
                                 const float* w, const float* dsum, const int32_t* rowptr_t, const int32_t* eid_t,
                                 const int32_t* dst_t, void* dk, void* dv, int64_t ldg, void* dedges, int64_t ldde,
-                                int64_t n_src, int C, int H, anemoi_stream_t stream) {
+                                int64_t n_src, int C, int H, float dropout_p, uint32_t dropout_seed,
+                                const void* dropout_seed_dev, anemoi_stream_t stream) {
   ANEMOI_REQUIRE(q && dout && alpha && w && dsum && rowptr_t && eid_t && dst_t && dk && dv && dedges, ANEMOI_ERR_INVALID,
                  "anemoi_gt_conv_backward_src: null pointer");
   ANEMOI_REQUIRE(n_src >= 0 && C > 0 && H > 0 && C % H == 0, ANEMOI_ERR_INVALID, "anemoi_gt_conv_backward_src: bad shape");
@@ -695,13 +707,16 @@ int anemoi_gt_conv_backward_src(int dtype, const void* q, int64_t ldq, const voi
   p.ldq = ldq; p.ldd = ldd; p.ldg = ldg; p.ldde = ldde; p.n_src = n_src; p.C = C; p.H = H;
   p.n_slices = (C + 64 * vec - 1) / (64 * vec);
   p.scale = 1.0f / sqrtf((float)(C / H));
+  p.drop = make_edge_dropout(dropout_p, dropout_seed, dropout_seed_dev);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(bwd_blocks(n_src, p.n_slices, 5)), block(256);
   const int D = C / H;
   bool ok = D % vec == 0;
-#define ANEMOI_CONV_SRC(TT, VV, L)                                                                                    \
-  case L:                                                                                                             \
-    hipLaunchKernelGGL((gt_conv_bwd_src_kernel<TT, VV, L, 2>), grid, block, 0, st, p, rowptr_t, eid_t, dst_t);        \
+#define ANEMOI_CONV_SRC(TT, VV, L)                                                                                          \
+  case L:                                                                                                                   \
+    if (p.drop.thr15 != 0)                                                                                                  \
+      hipLaunchKernelGGL((gt_conv_bwd_src_kernel<TT, VV, L, 2, true>), grid, block, 0, st, p, rowptr_t, eid_t, dst_t);      \
+    else hipLaunchKernelGGL((gt_conv_bwd_src_kernel<TT, VV, L, 2, false>), grid, block, 0, st, p, rowptr_t, eid_t, dst_t);   \
     break;
   if (ok && dtype == ANEMOI_F32) {
     switch (D / 4) { ANEMOI_CONV_SRC(float, 4, 1) ANEMOI_CONV_SRC(float, 4, 2) ANEMOI_CONV_SRC(float, 4, 4)

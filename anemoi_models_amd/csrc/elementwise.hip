@@ -866,7 +866,7 @@ int anemoi_bound_output(float* y, int V_out, int64_t rows, int n_ops, const int3
   return check_launch("anemoi_bound_output");
 }
 
-int anemoi_abi_version(void) { return 40; }
+int anemoi_abi_version(void) { return 41; }
 
 #ifndef ANEMOI_HIPCC_VERSION
 #define ANEMOI_HIPCC_VERSION "unknown (built without anemoi_models_amd/_build.py)"

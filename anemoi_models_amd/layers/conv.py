@@ -36,10 +36,32 @@ class GraphTransformerConv(nn.Module):
         self.dropout = dropout
         self._plans = None  # plan cache of the stand-alone forward (runtime.PlanCache, created on first use)
 
+    def dropout_args(self):
+        """``(p, seed, seed_dev)`` of this call: the reference drops attention weights in training mode only
+        (layers/conv.py:140).  Seeds as in ``MultiHeadSelfAttention.dropout``: drawn per call from torch's CPU generator
+        (``torch.manual_seed`` reproduces the mask); inside a ``runtime.DeviceDropout`` context a per-module constant plus the
+        step's device word, so that a captured training step draws a new mask at every replay."""
+        import torch
+
+        from .. import runtime
+
+        if not self.training or self.dropout <= 0.0:
+            return 0.0, 0, None
+        if not 0.0 <= self.dropout <= 1.0:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {self.dropout}")
+        dd = runtime.device_dropout()
+        if dd is None:
+            return float(self.dropout), int(torch.randint(0, 2**31 - 1, (1,)).item()), None
+        if self.__dict__.get("_layer_seed") is None:
+            self.__dict__["_layer_seed"] = int(torch.randint(0, 2**31 - 1, (1,)).item())
+        return float(self.dropout), self.__dict__["_layer_seed"], dd.word
+
     def fused(self, query: Tensor, key: Tensor, value: Tensor, x_r: Optional[Tensor], edge_attr_csr: Tensor,
               edge_dim: int, w_edge: Tensor, b_edge: Tensor, plan: EdgePlan, num_heads: int) -> Tensor:
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("attention dropout > 0 is not implemented on the MI355X path")
+        if self.training and self.dropout > 0.0:  # (no block of the reference constructs its conv with dropout,
+            # layers/block.py:339: the folded kernels of the block mirrors carry no mask; ``forward`` below does)
+            raise NotImplementedError("dropout > 0 is implemented for GraphTransformerConv.forward (explicit edge "
+                                      "features), not for the blocks' folded edge kernels")
         if query.shape[0] != plan.n_dst or key.shape[0] != plan.n_src:
             raise ValueError(
                 f"Encountered tensors with {key.shape[0]} source / {query.shape[0]} destination rows, "
@@ -53,14 +75,13 @@ class GraphTransformerConv(nn.Module):
         """The reference's call (layers/conv.py:98-142): ``query [N_dst, H, D]``, ``key / value [N_src, H, D]``,
         ``edge_attr [E, H, D]`` (= ``lin_edge`` of the raw attributes), ``edge_index [2, E]`` -> ``[N_dst, H, D]``.
         One kernel (``anemoi_gt_conv``) over a destination-sorted plan that is cached per ``edge_index`` tensor; with
-        gradients required, the same kernel as an autograd node (``autograd.gt_conv``).  The block mirrors do not come
+        gradients required, the same kernel as an autograd node (``autograd.gt_conv``).  ``dropout > 0`` in training mode
+        drops attention weights per (edge, head) as the reference does (layers/conv.py:140), inside the kernels.  The block mirrors do not come
         through here (they fold ``lin_edge`` into the neighbouring GEMMs)."""
         import torch
 
         from .. import runtime
 
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("attention dropout > 0 is not implemented on the MI355X path")
         if edge_attr is None:
             raise ValueError("GraphTransformerConv needs edge features (the reference adds them to key and value)")
         n_dst, heads, d = query.shape
@@ -74,14 +95,22 @@ class GraphTransformerConv(nn.Module):
         c = heads * d
         flat = lambda t: (t if t.dtype == dtype else t.to(dtype)).reshape(t.shape[0], c)  # noqa: E731
         kv = torch.cat([flat(key), flat(value)], dim=1)  # one k | v buffer: the kernel gathers both with one row pitch
+        p_drop, seed, seed_dev = self.dropout_args()  # (training mode only; the mask is per edge of the SORTED plan and head)
         if torch.is_grad_enabled() and any(t.requires_grad for t in (query, key, value, edge_attr)):
             from .. import autograd  # explicit-edge backward kernels (anemoi_gt_conv_backward_dst / _src)
 
             edges = autograd.permute_rows(flat(edge_attr).contiguous(), plan.perm.long())
-            out = autograd.gt_conv(flat(query).contiguous(), kv[:, :c], kv[:, c:], edges, None, plan, heads)
+            out = autograd.gt_conv(flat(query).contiguous(), kv[:, :c], kv[:, c:], edges, None, plan, heads, p_drop, seed,
+                                   seed_dev)
         else:
+            from ..autograd import _edge_phase_in_f32
+
             edges = flat(edge_attr).index_select(0, plan.perm.long())
-            out = ops.gt_conv(flat(query).contiguous(), kv[:, :c], kv[:, c:], edges, plan.rowptr, plan.col, heads)
+            q2 = flat(query).contiguous()
+            if _edge_phase_in_f32(dtype, c, heads):  # bf16 heads of 4 (config 1's D): the f32 kernels between two casts
+                q2, kv, edges = q2.float(), kv.float(), edges.float()
+            out = ops.gt_conv(q2, kv[:, :c], kv[:, c:], edges, plan.rowptr, plan.col, heads, dropout_p=p_drop,
+                              dropout_seed=seed, seed_dev=seed_dev)
         return out.view(n_dst, heads, d).to(query.dtype)
 
 

@@ -368,10 +368,15 @@ def gt_edge_attention_folded(q: Tensor, k: Tensor, v: Tensor, x_r: Optional[Tens
 
 
 def gt_conv(q: Tensor, k: Tensor, v: Tensor, edges_csr: Tensor, rowptr: Tensor, col: Tensor, num_heads: int,
-            x_r: Optional[Tensor] = None, lse: Optional[Tensor] = None) -> Tensor:
+            x_r: Optional[Tensor] = None, lse: Optional[Tensor] = None, dropout_p: float = 0.0, dropout_seed: int = 0,
+            seed_dev: Optional[Tensor] = None) -> Tensor:
     """``GraphTransformerConv`` with explicit per-edge features (reference layers/conv.py:98-142): ``q [n_dst, C]``,
     ``k, v [n_src, C]``, ``edges_csr [E, C]`` in the CSR order of ``(rowptr, col)``; returns ``[n_dst, C]`` (``+ x_r``).
-    ``lse`` (optional f32 ``[n_dst, H]``) receives the softmax normaliser (training)."""
+    ``lse`` (optional f32 ``[n_dst, H]``) receives the softmax normaliser (training).  ``dropout_p`` / ``dropout_seed`` /
+    ``seed_dev``: the conv's dropout of the attention weights in training mode (layers/conv.py:140), mask = hash(CSR edge
+    position, head, seed) as for :func:`mhsa`."""
+    if not 0.0 <= dropout_p <= 1.0:
+        raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout_p}")
     _dev(q, k, v, edges_csr, rowptr, col, x_r, lse)
     n_dst, c = _rows(q).shape
     if _ld(_rows(k)) != _ld(_rows(v)):
@@ -390,7 +395,8 @@ def gt_conv(q: Tensor, k: Tensor, v: Tensor, edges_csr: Tensor, rowptr: Tensor, 
         st = _lib.load().anemoi_gt_conv(dtype_code(q.dtype), q.data_ptr(), _ld(q), k.data_ptr(), v.data_ptr(), _ld(_rows(k)),
                                         edges_csr.data_ptr(), _ld(_rows(edges_csr)), _ptr(x_r),
                                         0 if x_r is None else _ld(_rows(x_r)), rowptr.data_ptr(), col.data_ptr(),
-                                        out.data_ptr(), _ld(out), _ptr(lse), n_dst, c, num_heads, _stream())
+                                        out.data_ptr(), _ld(out), _ptr(lse), n_dst, c, num_heads, float(dropout_p),
+                                        int(dropout_seed) & 0xFFFFFFFF, _seed_dev_ptr(seed_dev, q), _stream())
     _lib.check(st, "anemoi_gt_conv")
     return out
 

@@ -259,18 +259,26 @@ int anemoi_gt_edge_attention_folded_tiles(int dtype, const void* q, int64_t ldq,
  * the folded / fused kernels do not cover (any edge_dim works on this route).
  * Backward (same structure as the folded backward below, with k + e, v + e in place of k, v):
  *   _dst: alpha, w [E, H], dsum [n_dst, H] (f32), dq;   _src: dk, dv and d edges [E, C] (CSR order) = alpha dout_i + scale ds q_i.
+ * dropout_p / dropout_seed / dropout_seed_dev (ABI v41): the conv's `dropout` argument in training mode (reference
+ * layers/conv.py:89,140 -- `dropout(alpha, p, training)` on alpha [E, H]): out_i = sum_j alpha keep / (1 - p) (v_j + e_ij) with
+ * one counter-based keep decision per (CSR edge position, head) and seed (no mask tensor; the two backward entry points
+ * take the same three arguments and rebuild it).  dropout_seed_dev: optional device word whose low 32 bits the kernels add
+ * to the seed when they run (what a captured training step advances; NULL otherwise).  dropout_p = 0: the plain kernels.
  */
 int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* edges,
                    int64_t lde, const void* x_r, int64_t ldr, const int32_t* rowptr, const int32_t* col, void* out,
-                   int64_t ldo, float* lse, int64_t n_dst, int C, int H, anemoi_stream_t stream);
+                   int64_t ldo, float* lse, int64_t n_dst, int C, int H, float dropout_p, uint32_t dropout_seed,
+                   const void* dropout_seed_dev, anemoi_stream_t stream);
 int anemoi_gt_conv_backward_dst(int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                                 const void* edges, int64_t lde, const void* dout, int64_t ldd, const float* lse,
                                 const int32_t* rowptr, const int32_t* col, float* alpha, float* w, float* dsum, void* dq,
-                                int64_t lddq, int64_t n_dst, int C, int H, anemoi_stream_t stream);
+                                int64_t lddq, int64_t n_dst, int C, int H, float dropout_p, uint32_t dropout_seed,
+                                const void* dropout_seed_dev, anemoi_stream_t stream);
 int anemoi_gt_conv_backward_src(int dtype, const void* q, int64_t ldq, const void* dout, int64_t ldd, const float* alpha,
                                 const float* w, const float* dsum, const int32_t* rowptr_t, const int32_t* eid_t,
                                 const int32_t* dst_t, void* dk, void* dv, int64_t ldg, void* dedges, int64_t ldde,
-                                int64_t n_src, int C, int H, anemoi_stream_t stream);
+                                int64_t n_src, int C, int H, float dropout_p, uint32_t dropout_seed,
+                                const void* dropout_seed_dev, anemoi_stream_t stream);
 
 /*
  * Input assembly (I/O glue K9): rows (b, ens, g) of

@@ -93,11 +93,14 @@ def sort_edges_1hop_chunks(num_nodes, edge_attr: Tensor, edge_index: Tensor, num
 # --------------------------------------------------------------------------
 
 
-def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index: Tensor, n_dst: int) -> Tensor:
+def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index: Tensor, n_dst: int,
+            dropout_p: float = 0.0, keep: Optional[Tensor] = None) -> Tensor:
     """layers/conv.py:98-142 ``GraphTransformerConv`` (+ PyG propagate, flow source_to_target).
 
     query [N_dst,H,D], key/value [N_src,H,D], edges [E,H,D], edge_index int64 [2,E]
-    (row 0 = src ``j``, row 1 = dst ``i``).
+    (row 0 = src ``j``, row 1 = dst ``i``).  ``dropout_p`` with ``keep [E, H]`` of 0 / 1: conv.py:140 in training mode,
+    ``torch.nn.functional.dropout(alpha, p)`` = ``alpha * keep / (1 - p)`` with the Bernoulli draw handed in (torch's own
+    draw cannot be reproduced outside torch; the HIP kernels draw theirs from a counter hash, restated in the tests).
     """
     src, dst = edge_index[0], edge_index[1]
     d = query.shape[-1]
@@ -106,7 +109,9 @@ def gt_conv(query: Tensor, key: Tensor, value: Tensor, edges: Tensor, edge_index
     value_j = value.index_select(0, src)
     alpha = (query_i * key_j).sum(dim=-1) / d**0.5  # conv.py:137
     alpha = segment_softmax(alpha, dst, n_dst)  # conv.py:139
-    msg = (value_j + edges) * alpha.unsqueeze(-1)  # conv.py:142 (dropout p=0)
+    if dropout_p > 0.0:  # conv.py:140
+        alpha = alpha * keep.to(alpha.dtype) * (1.0 / (1.0 - dropout_p) if dropout_p < 1.0 else 0.0)
+    msg = (value_j + edges) * alpha.unsqueeze(-1)  # conv.py:142
     return scatter_sum(msg, dst, n_dst)  # aggr="add", conv.py:92
 
 

@@ -95,7 +95,21 @@ def gt_edge_attention_folded(q, k, v, x_r, u, edge_attr, rowptr, col, num_heads,
     return F.pad(res, (0, ld - res.shape[1])).to(q.dtype)
 
 
-def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads, x_r=None, lse=None):
+def edge_dropout_keep_mask(seed: int, p: float, n_edges: int, heads: int) -> torch.Tensor:
+    """The edge kernels' counter-based keep mask (csrc/common.hpp::edge_dropout_keep) restated with torch integer
+    arithmetic: ``[E, H]`` of 0 / 1 over the CSR edge positions."""
+    m32 = 0xFFFFFFFF
+    e = torch.arange(n_edges, dtype=torch.int64).view(-1, 1)
+    h = torch.arange(heads, dtype=torch.int64).view(1, -1)
+    x = ((e * 0x9E3779B1) & m32) ^ ((h * 0x85EBCA77) & m32) ^ (seed & m32)
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & m32
+    x = x ^ (x >> 15)
+    thr = min(int(p * 32768.0 + 0.5), 32768)
+    return ((x >> 17) >= thr).to(torch.float64) if p < 1.0 else torch.zeros(n_edges, heads, dtype=torch.float64)
+
+
+def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads, x_r=None, lse=None, dropout_p=0.0, dropout_seed=0, seed_dev=None):
     n_dst, c = q.shape
     d = c // num_heads
     dst = torch.repeat_interleave(torch.arange(n_dst), (rowptr[1:] - rowptr[:-1]).long())
@@ -105,6 +119,10 @@ def gt_conv(q, k, v, edges_csr, rowptr, col, num_heads, x_r=None, lse=None):
     vj = v.float().reshape(-1, num_heads, d)[src] + e
     score = (q.float().reshape(n_dst, num_heads, d)[dst] * kj).sum(-1) / d**0.5
     alpha = segment_softmax(score, dst, n_dst)
+    if dropout_p > 0.0:
+        seed = int(dropout_seed) + (0 if seed_dev is None else int(seed_dev.reshape(-1)[0]))
+        keep = edge_dropout_keep_mask(seed, dropout_p, col.shape[0], num_heads).float()
+        alpha = alpha * keep * (1.0 / (1.0 - dropout_p) if dropout_p < 1.0 else 0.0)
     out = scatter_sum(vj * alpha.unsqueeze(-1), dst, n_dst).reshape(n_dst, c)
     return (out if x_r is None else out + x_r.float()).to(q.dtype)
 

@@ -143,8 +143,18 @@ def test_config2_bf16_anchored_to_the_oracle_under_bf16_autocast(o96_gt, monkeyp
     hip_out, hip_lat = rel_err(got, want32), rel_err(latent, st32["x_latent"])
     print(f"config 2, bf16 vs the f32 oracle -- prediction: HIP {hip_out:.3e}, oracle under bf16 autocast {ref_out:.3e}; "
           f"encoder latent: HIP {hip_lat:.3e}, oracle under bf16 autocast {ref_lat:.3e}")
-    assert hip_out <= 1.5 * ref_out, (hip_out, ref_out)
-    assert hip_lat <= 1.5 * ref_lat, (hip_lat, ref_lat)
+    if not (hip_out <= 1.5 * ref_out and hip_lat <= 1.5 * ref_lat):
+        # one whole-suite run of round 6 measured 1.21e-2 here where every other run of the same library measures 6.50e-3
+        # (DESIGN section 2): say whether the SAME model gives the same bits when asked again -- a persistent state or a
+        # single forward that went wrong
+        again = [bench.device_forward_with_latent(model, x) for _ in range(3)]
+        lat32 = st32["x_latent"]
+        pytest.fail(f"prediction {hip_out:.4e} (oracle under autocast {ref_out:.4e}), latent {hip_lat:.4e} ({ref_lat:.4e}); "
+                    f"three more forwards of the same model: latent "
+                    f"{[round(rel_err(l, lat32), 6) for _, l in again]}, bit-equal to the failing one "
+                    f"{[bool(torch.equal(l, latent) and torch.equal(y, got)) for y, l in again]}; latent elements that "
+                    f"moved against the first of them: {int((again[0][1] != latent).sum())} in "
+                    f"{int((again[0][1] != latent).any(1).sum())} rows")
 
 
 def test_config5_gnn_o96_512ch_16_blocks_f32_vs_oracle(o96_gnn, monkeypatch):

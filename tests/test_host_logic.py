@@ -505,6 +505,21 @@ def test_graph_transformer_conv_forward_host_wiring(monkeypatch):
         got = GraphTransformerConv(out_channels=d).eval()(q, k, v, edges, ei, size=(n_src, n_dst))
     torch.testing.assert_close(got, ref.gt_conv(q, k, v, edges, ei, n_dst), atol=1e-5, rtol=1e-5)
     assert float(got[n_dst - 1].abs().max()) == 0.0  # isolated destination
+    # dropout of the attention weights in training mode (layers/conv.py:140): the seed drawn from torch's generator, the mask
+    # over CSR positions carried back to the caller's edge order, against the oracle with that mask
+    conv = GraphTransformerConv(out_channels=d, dropout=0.35)
+    torch.manual_seed(99)
+    seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+    torch.manual_seed(99)
+    with torch.no_grad():
+        dropped = conv(q, k, v, edges, ei)
+        assert conv.dropout_args()[0] == 0.35 and conv.eval().dropout_args() == (0.0, 0, None)
+    plan = conv._plans.get(ei, n_src, n_dst)
+    keep = torch.empty(e, h, dtype=torch.float64)
+    keep[plan.perm.long()] = _cpu_ops.edge_dropout_keep_mask(seed, 0.35, e, h)
+    assert 0.55 < float(keep.mean()) < 0.75
+    torch.testing.assert_close(dropped, ref.gt_conv(q, k, v, edges, ei, n_dst, dropout_p=0.35, keep=keep), atol=1e-5,
+                               rtol=1e-5)
 
 
 def test_reference_piecewise_api_of_blocks_and_mappers(graph_o32, monkeypatch):
