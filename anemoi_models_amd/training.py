@@ -515,6 +515,12 @@ def model_forward(model, x: Tensor) -> Tensor:
         x_hidden = x_hidden.to(dtype)
 
         def run_mapper(mapper, a, c, src_map, dst_map):
+            if inv is None and augmented:
+                # (a processor that keeps the external mesh order -- the Transformer -- between GraphTransformer mappers: the
+                #  grid rows are ``[features | 1 | 0-pad]`` here too, which the mappers' module-level call cannot be told)
+                with mapper._offloaded():
+                    y = gt_mapper(mapper, a, c, rows, None, None, augmented=True)
+                return (a, y) if hasattr(mapper, "emb_nodes_src") else y
             if inv is None:
                 return mapper((a, c), rows, shapes)
             if isinstance(mapper, GraphTransformerBaseMapper):
