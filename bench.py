@@ -182,10 +182,47 @@ def reference_linear_flops(model) -> float:
     return total
 
 
-def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic_ok: bool = True):
-    """One instrumented forward: HIP events around every kernel launch, on the launch stream."""
+_SLEEP_TICKS_PER_MS = None
+
+
+def hold_stream(ms: float) -> None:
+    """Park the launch stream for about ``ms`` milliseconds (a spin kernel), so that what the host enqueues next is queued
+    AHEAD of the GPU.  The instrumented forward records two events per launch; on the small configurations (config 2: ~200
+    launches of 10 - 40 us) the host cannot keep up with that, the stream runs dry between launches and every event pair
+    then brackets the kernel PLUS the wait for its submission -- 3.0 - 4.5 ms of "Linear time" inside a 2.96 ms step, box
+    by box, where rocprofv3 measures 2.61.  Behind a parked stream the events bracket back-to-back kernels, as the
+    profiler's timestamps do (2.71 ms)."""
+    global _SLEEP_TICKS_PER_MS
+    sleep = getattr(torch.cuda, "_sleep", None)
+    if sleep is None:
+        return
+    if _SLEEP_TICKS_PER_MS is None:  # what one tick of the spin kernel's clock is worth on this box
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        sleep(1_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        _SLEEP_TICKS_PER_MS = 1_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    sleep(int(ms * _SLEEP_TICKS_PER_MS))
+
+
+HOLD_BELOW_MS, HOLD_MS = 10.0, 8.0  # steps shorter than HOLD_BELOW_MS: the instrumented forward is enqueued behind an 8-ms hold
+
+
+def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic_ok: bool = True, step_ms: float = 1e9):
+    """One instrumented forward: HIP events around every kernel launch, on the launch stream.  Where a step is short enough
+    for the host's submission rate to show in the event pairs (``step_ms < HOLD_BELOW_MS``: configs 1, 2, 5, a rank of a
+    partition) the forward is enqueued behind a parked stream (:func:`hold_stream`); the long steps are GPU-bound without it,
+    and a GPU that idled through a hold starts them at a lower clock (config 3: Linear 31.0 ms behind a 25-ms hold, 30.3
+    without, 30.4 by rocprofv3; `gpurun_out/r06_s44`)."""
     from anemoi_models_amd import ops
 
+    torch.cuda.synchronize()
+    hold = os.environ.get("ANEMOI_AMD_BENCH_HOLD_MS")
+    hold = float(hold) if hold is not None else (HOLD_MS if step_ms < HOLD_BELOW_MS else 0.0)
+    if hold > 0:
+        hold_stream(hold)
     ops.PROFILE = []
     with torch.no_grad():
         model(x, group) if group is not None else model(x)
@@ -465,7 +502,7 @@ def secondary_leg(workload: str, processor: str, device, dtype_name: str, graph=
     ms = (time.perf_counter() - t0) / steps * 1e3
     if not bool(torch.isfinite(y).all()):
         raise RuntimeError("non-finite output")
-    extra = profile_pass(model, x, None, dtype_name, traffic_ok=False)
+    extra = profile_pass(model, x, None, dtype_name, traffic_ok=False, step_ms=ms)
     keep = ("frac", "achieved", "unit", "bound", "avg_launch_ms", "launches", "frac_executed")
     out = {"workload": WORKLOADS[workload][4].replace("GT blocks", f"{processor} blocks") if processor != "GraphTransformer"
            else WORKLOADS[workload][4], "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
@@ -765,7 +802,7 @@ def _run(stage, args) -> int:
     ms_per_step = elapsed / args.steps * 1e3
     value = n_mesh * layers * args.rollout / (elapsed / args.steps)
     extra = profile_pass(model, x, group, args.dtype, args.detail and rank == 0,
-                         traffic_ok=args.workload == "cfg3" and args.processor == "GraphTransformer")
+                         traffic_ok=args.workload == "cfg3" and args.processor == "GraphTransformer", step_ms=ms_per_step)
 
     if rank == 0:
         line = {
