@@ -349,7 +349,9 @@ class GraphTransformerProcessor(GraphEdgeMixin, BaseProcessor):
             params = self.__dict__["_abi_params"] = [p for p in self.parameters()]
         # any in-place change of a parameter (optimiser step, load_state_dict, .normal_()) bumps its version counter
         sig = (sum(p._version for p in params), params[0].data_ptr(), x.shape[0], str(x.device), ea.data_ptr(), id(plan),
-               os.environ.get("ANEMOI_AMD_EDGE_TILES"), os.environ.get("ANEMOI_AMD_EDGE_SCHED"))  # (A/B switches of the edge kernel)
+               os.environ.get("ANEMOI_AMD_EDGE_TILES"), os.environ.get("ANEMOI_AMD_EDGE_SCHED"),  # (A/B switches of the edge
+               os.environ.get("ANEMOI_AMD_LN_FOLD"))  # kernel; the fold the plan's operands are built for: a model that ran
+        # with the fold and is then asked without it kept the folded blocks between unfolded mappers until round 6)
         fast = self.__dict__.get("_abi_plan")
         if fast is None or fast.sig != sig:
             fast = self.__dict__["_abi_plan"] = _BlockAbiPlan.build(self, x, ea, plan, sig)
