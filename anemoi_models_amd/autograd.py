@@ -694,11 +694,40 @@ def gt_conv(q: Tensor, k: Tensor, v: Tensor, e_csr: Tensor, x_r: Optional[Tensor
     if dropout_p > 0.0 and seed is None:
         seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
     drop = (float(dropout_p), int(seed or 0), seed_dev)
-    if _edge_phase_in_f32(q.dtype, q.shape[1], num_heads):
-        kv, c = torch.cat([k, v], dim=1).float(), q.shape[1]
-        return _GTConv.apply(q.float(), kv[:, :c], kv[:, c:], e_csr.float(), None if x_r is None else x_r.float(), plan,
-                             num_heads, *drop).to(q.dtype)
-    return _GTConv.apply(q, k, v, e_csr, x_r, plan, num_heads, *drop)
+    out_dtype, c = q.dtype, q.shape[1]
+    if _edge_phase_in_f32(q.dtype, c, num_heads):
+        kv = torch.cat([k, v], dim=1).float()
+        q, k, v, e_csr, x_r = q.float(), kv[:, :c], kv[:, c:], e_csr.float(), None if x_r is None else x_r.float()
+    d = c // num_heads
+    d_pad = conv_head_size(d, q.dtype)
+    if d_pad != d:
+        # A head size the kernels' lane groups do not come in (they reduce over 1, 2, 4, 8 or 16 lanes of 16 bytes: D = 12, or
+        # D = 5 as the reference's tests like them): every head zero-padded to the next size that does.  Zero columns add
+        # nothing to q . (k + e) and produce zero output columns (dropped below); the kernels scale by 1 / sqrt(their D), so q
+        # carries sqrt(D_pad / D).  Plain torch ops around the same autograd node: the gradients of the real columns are
+        # exact, those of the padding are discarded by the slice.
+        def pad(t):
+            return torch.nn.functional.pad(t.reshape(t.shape[0], num_heads, d), (0, d_pad - d)).reshape(t.shape[0], -1)
+
+        kvp = torch.cat([pad(k), pad(v)], dim=1)
+        cp = num_heads * d_pad
+        out = _GTConv.apply(pad(q) * (d_pad / d) ** 0.5, kvp[:, :cp], kvp[:, cp:], pad(e_csr),
+                            None if x_r is None else pad(x_r), plan, num_heads, *drop)
+        out = out.reshape(out.shape[0], num_heads, d_pad)[:, :, :d].reshape(out.shape[0], c)
+    else:
+        out = _GTConv.apply(q, k, v, e_csr, x_r, plan, num_heads, *drop)
+    return out if out.dtype == out_dtype else out.to(out_dtype)
+
+
+def conv_head_size(d: int, dtype: torch.dtype) -> int:
+    """The head size the explicit-edge conv kernels run ``d`` at: lanes of 16 bytes (4 f32 / 8 bf16 channels) in groups of
+    1, 2, 4, 8 or 16 per head -- ``d`` itself where it is such a size."""
+    vec = 16 // torch.empty((), dtype=dtype).element_size()
+    lanes = max(1, -(-d // vec))
+    lanes = 1 << (lanes - 1).bit_length()
+    if lanes > 16:
+        raise NotImplementedError(f"GraphTransformerConv: head size {d} beyond {16 * vec} channels per head")
+    return vec * lanes
 
 
 def _edge_phase_in_f32(dtype: torch.dtype, c: int, num_heads: int) -> bool:

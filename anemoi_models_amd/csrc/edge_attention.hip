@@ -1743,8 +1743,9 @@ extern "C" int anemoi_gt_conv(int dtype, const void* q, int64_t ldq, const void*
   if (dtype == ANEMOI_F32) ok = dispatch_conv<float>(p, rowptr, col, as_stream(stream));
   else if (dtype == ANEMOI_BF16) ok = dispatch_conv<bf16_t>(p, rowptr, col, as_stream(stream));
   else return fail(ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv: dtype %d", dtype);
-  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED, "anemoi_gt_conv: head size %d needs a multiple of %d channels (<= %d)", C / H, vec,
-                 16 * vec);
+  ANEMOI_REQUIRE(ok, ANEMOI_ERR_UNSUPPORTED,
+                 "anemoi_gt_conv: head size %d is not 1, 2, 4, 8 or 16 lanes of %d channels (the host side zero-pads heads)",
+                 C / H, vec);
   return check_launch("anemoi_gt_conv");
 }
 

@@ -96,21 +96,16 @@ class GraphTransformerConv(nn.Module):
         flat = lambda t: (t if t.dtype == dtype else t.to(dtype)).reshape(t.shape[0], c)  # noqa: E731
         kv = torch.cat([flat(key), flat(value)], dim=1)  # one k | v buffer: the kernel gathers both with one row pitch
         p_drop, seed, seed_dev = self.dropout_args()  # (training mode only; the mask is per edge of the SORTED plan and head)
+        from .. import autograd  # explicit-edge kernels (anemoi_gt_conv, anemoi_gt_conv_backward_dst / _src) as one autograd node
+
         if torch.is_grad_enabled() and any(t.requires_grad for t in (query, key, value, edge_attr)):
-            from .. import autograd  # explicit-edge backward kernels (anemoi_gt_conv_backward_dst / _src)
-
             edges = autograd.permute_rows(flat(edge_attr).contiguous(), plan.perm.long())
-            out = autograd.gt_conv(flat(query).contiguous(), kv[:, :c], kv[:, c:], edges, None, plan, heads, p_drop, seed,
-                                   seed_dev)
         else:
-            from ..autograd import _edge_phase_in_f32
-
             edges = flat(edge_attr).index_select(0, plan.perm.long())
-            q2 = flat(query).contiguous()
-            if _edge_phase_in_f32(dtype, c, heads):  # bf16 heads of 4 (config 1's D): the f32 kernels between two casts
-                q2, kv, edges = q2.float(), kv.float(), edges.float()
-            out = ops.gt_conv(q2, kv[:, :c], kv[:, c:], edges, plan.rowptr, plan.col, heads, dropout_p=p_drop,
-                              dropout_seed=seed, seed_dev=seed_dev)
+        # (bf16 heads of 4 -- config 1's D -- run on the f32 kernels between two casts, head sizes outside the kernels' lane
+        #  groups zero-padded: autograd.gt_conv)
+        out = autograd.gt_conv(flat(query).contiguous(), kv[:, :c], kv[:, c:], edges, None, plan, heads, p_drop, seed,
+                               seed_dev)
         return out.view(n_dst, heads, d).to(query.dtype)
 
 

@@ -153,10 +153,14 @@ def _edge_case(n_src, n_dst, e, c, h, edge_dim, seed):
 @pytest.mark.parametrize("dtype,n_src,n_dst,e,c,h", [
     (torch.float32, 180, 90, 500, 64, 16), (torch.float32, 300, 200, 2000, 512, 16), (torch.bfloat16, 120, 100, 900, 1024, 16),
     (torch.bfloat16, 150, 150, 700, 128, 16), (torch.float32, 20, 10, 0, 64, 16),
+    # head sizes outside the kernels' lane groups (zero-padded heads, autograd.gt_conv): D = 12, D = 5, D = 20, f32 and bf16
+    (torch.float32, 90, 70, 400, 96, 8), (torch.float32, 50, 40, 300, 35, 7), (torch.bfloat16, 90, 70, 400, 96, 8),
+    (torch.bfloat16, 50, 40, 300, 20, 4), (torch.float32, 60, 60, 500, 40, 2),
 ])
 def test_graph_transformer_conv_module_forward(dtype, n_src, n_dst, e, c, h):
     """GraphTransformerConv.forward as the reference calls it (layers/conv.py:98-142: q / k / v [N, H, D], projected edge
-    features [E, H, D], edge_index) on anemoi_gt_conv vs oracle.gt_conv -- isolated and high in-degree destinations."""
+    features [E, H, D], edge_index) on anemoi_gt_conv vs oracle.gt_conv -- isolated and high in-degree destinations, any
+    head size up to 64 channels (the reference's conv takes any ``out_channels``)."""
     from anemoi_models_amd.layers.conv import GraphTransformerConv
 
     g = torch.Generator().manual_seed(n_src + e)
@@ -194,6 +198,7 @@ def test_graph_transformer_conv_module_forward(dtype, n_src, n_dst, e, c, h):
     (torch.float32, 180, 90, 500, 64, 16, 0.3), (torch.float32, 300, 200, 2000, 512, 16, 0.1),
     (torch.bfloat16, 120, 100, 900, 1024, 16, 0.25), (torch.bfloat16, 150, 150, 700, 128, 16, 0.5),
     (torch.float32, 64, 50, 300, 256, 16, 1.0), (torch.bfloat16, 180, 90, 500, 64, 16, 0.2),  # (last: D = 4, f32 edge phase)
+    (torch.float32, 90, 70, 400, 96, 8, 0.3), (torch.bfloat16, 60, 50, 300, 20, 4, 0.4),  # D = 12 / D = 5: zero-padded heads
 ])
 def test_graph_transformer_conv_module_dropout_in_training_mode(dtype, n_src, n_dst, e, c, h, p):
     """``GraphTransformerConv(out_channels, dropout=p)`` in training mode (reference layers/conv.py:89,140:

@@ -258,7 +258,92 @@ def fuzz_weight_grad():
     print(f"weight_grad (TN kernel): {bad} bad of {n_cases // 2}", flush=True)
 
 
+def fuzz_conv_dropout():
+    """anemoi_gt_conv and its two backward kernels with the conv's dropout (ABI v41): random graphs (isolated destinations,
+    hubs), head sizes, probabilities; output and all four input gradients against torch autograd in f64 with the same mask."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from _cpu_ops import edge_dropout_keep_mask
+    from anemoi_models_amd import autograd
+
+    bad = 0
+    for case in range(n_cases // 2):
+        dtype = torch.bfloat16 if rng.random() < 0.6 else torch.float32
+        h = rng.choice([1, 2, 4, 8, 16])
+        d = rng.choice([4, 5, 8, 12, 16, 20, 24, 32, 48, 64])  # (sizes outside the kernels' lane groups: zero-padded heads)
+        c = h * d
+        n_src, n_dst, e = rng.randint(1, 400), rng.randint(2, 400), rng.randint(0, 3000)
+        p = rng.choice([0.0, 0.1, 0.5, rng.random() * 0.95])
+        seed_c = rng.randint(0, 2**31 - 1)
+        g = torch.Generator().manual_seed(seed * 100003 + case)
+        ei = torch.stack([torch.randint(0, n_src, (e,), generator=g), torch.randint(0, n_dst - 1, (e,), generator=g)])
+        if e > 60:
+            ei[1, :50] = 0  # a hub
+        plan = runtime.PlanCache().get(ei.to(dev), n_src, n_dst)
+        q = torch.randn(n_dst, c, generator=g).to(dtype)
+        kv = torch.randn(n_src, 2 * c, generator=g).to(dtype)
+        ed = torch.randn(e, c, generator=g).to(dtype)  # CSR order
+        w = torch.randn(n_dst, c, generator=g)
+        perm = plan.perm.long().cpu()
+        src, dst = ei[0][perm], ei[1][perm]  # the plan's (destination-sorted) order
+        keep = edge_dropout_keep_mask(seed_c, p, e, h)
+        refs = [t.double().requires_grad_() for t in (q, kv, ed)]
+        qr, kvr, er = refs
+        kj = kvr[:, :c].reshape(n_src, h, d)[src] + er.reshape(e, h, d)
+        vj = kvr[:, c:].reshape(n_src, h, d)[src] + er.reshape(e, h, d)
+        sc = (qr.reshape(n_dst, h, d)[dst] * kj).sum(-1) / d**0.5
+        mx = torch.full((n_dst, h), float("-inf"), dtype=torch.float64).scatter_reduce(0, dst[:, None].expand(-1, h), sc.detach(), "amax")
+        ex = torch.exp(sc - mx[dst])
+        den = torch.zeros(n_dst, h, dtype=torch.float64).index_add(0, dst, ex) + 1e-16
+        alpha = ex / den[dst] * keep * (1.0 / (1.0 - p))
+        want = torch.zeros(n_dst, h, d, dtype=torch.float64).index_add(0, dst, vj * alpha[..., None]).reshape(n_dst, c)
+        (want * w.double()).sum().backward()
+        leaves = [t.to(dev).requires_grad_() for t in (q, kv, ed)]
+        out = autograd.gt_conv(leaves[0], leaves[1][:, :c], leaves[1][:, c:], leaves[2], None, plan, h, p, seed_c)
+        (out.float() * w.to(dev)).sum().backward()
+        tol_o, tol_g = (1e-5, 2e-4) if dtype == torch.float32 else (2e-2, 5e-2)
+        # (a gradient that is zero in exact arithmetic -- dq when no destination has two edges: ds = w - alpha dsum = 0 -- is
+        #  held against the scale of the step's gradients, not against its own rounding noise)
+        g_scale = max(float(b.grad.abs().max()) for b in refs) if e > 0 else 1.0
+        errs = [rel(out.detach().cpu(), want.detach())] + [
+            float((a.grad.cpu().double() - b.grad).abs().max() / max(float(b.grad.abs().max()), 1e-3 * g_scale, 1e-6))
+            if e > 0 else 0.0 for a, b in zip(leaves, refs)]
+        if errs[0] > tol_o or max(errs[1:]) > tol_g or not torch.isfinite(out).all():
+            bad += 1
+            print(f"  conv dropout case {case}: {dtype} n_src={n_src} n_dst={n_dst} e={e} h={h} d={d} p={p:.3f}: "
+                  f"out {errs[0]:.2e}, dq {errs[1]:.2e}, dkv {errs[2]:.2e}, de {errs[3]:.2e}", flush=True)
+    print(f"gt_conv with dropout, forward + backward: {bad} bad of {n_cases // 2}", flush=True)
+
+
+def fuzz_mhsa():
+    """anemoi_mhsa at random sequence lengths around the tile borders (512-query blocks, 32-key tiles, the key-split tail
+    rows), batch sizes, head counts, windows: forward against softmax(Q K^T / sqrt(D)) V in f64."""
+    bad = 0
+    for case in range(n_cases // 3):
+        d = rng.choice([64, 64, 32, 16, 8, 48])
+        dtype = torch.bfloat16 if (d in (64, 32) or rng.random() < 0.5) else torch.float32
+        h, b = rng.choice([1, 2, 4]), rng.choice([1, 1, 2])
+        s_len = rng.choice([rng.randint(1, 200), 512 * rng.randint(1, 4) + rng.choice([-1, 0, 1, 2, 33]), rng.randint(200, 2600)])
+        window = rng.choice([-1, -1, rng.randint(0, 300)])
+        c = h * d
+        g = torch.Generator().manual_seed(seed * 100003 + case)
+        qkv = (torch.randn(b * s_len, 3 * c, generator=g) * 0.7).to(dtype)
+        q, k, v = (t.double().reshape(b, s_len, h, d).permute(0, 2, 1, 3) for t in qkv.split(c, dim=1))
+        sc = q @ k.transpose(-1, -2) / d**0.5
+        if window >= 0:
+            i = torch.arange(s_len)
+            sc = sc.masked_fill((i[:, None] - i[None, :]).abs() > window, float("-inf"))
+        want = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(b * s_len, c)
+        got = ops.mhsa(qkv.to(dev), b, h, window)
+        err = rel(got.cpu(), want)
+        if err > (2e-5 if dtype == torch.float32 else 2e-2) or not torch.isfinite(got).all():
+            bad += 1
+            print(f"  mhsa case {case}: {dtype} b={b} s={s_len} h={h} d={d} window={window}: {err:.2e}", flush=True)
+    print(f"mhsa forward: {bad} bad of {n_cases // 3}", flush=True)
+
+
 fuzz_linear()
+fuzz_conv_dropout()
+fuzz_mhsa()
 fuzz_edge_attention()
 fuzz_edge_scheduled()
 fuzz_edge_groups()
