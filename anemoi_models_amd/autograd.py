@@ -873,6 +873,21 @@ def _lin_edge_fold(sd: dict, prefix: str, c: int, h: int, up: int, device):
 FOLD_MAX_UP = 16  # widest per-head edge representation of the folded edge kernels (edge_dim + 1 rounded up to 4)
 
 
+def folded_edge_route(dtype: torch.dtype, c: int, num_heads: int, up: int) -> bool:
+    """Do the differentiable blocks take the FOLDED edge kernels at this shape?  They exist for a per-head edge width up to
+    ``FOLD_MAX_UP``, head sizes of 1, 2, 4, 8 or 16 lanes of 16 bytes (in the dtype the edge phase runs in: bf16 heads of 4
+    run it in f32) and a packed ``u`` / ``t`` width ``H * up`` that keeps the rows 16-byte aligned (one bf16 head with 3 or 11
+    edge attributes does not).  Everything else -- many edge attributes, head sizes like 12 / 20 / 48 / 96, a single bf16
+    head -- runs ``lin_edge`` as a GEMM and the conv on explicit per-edge features (``gt_conv``: any head size, zero-padded).
+    Round 6: until then only ``up`` decided, and the other shapes raised from the kernel's dispatch in training mode."""
+    if up > FOLD_MAX_UP or c % num_heads != 0:
+        return False
+    edge_dtype = torch.float32 if _edge_phase_in_f32(dtype, c, num_heads) else dtype
+    vec = 16 // torch.empty((), dtype=edge_dtype).element_size()
+    d = c // num_heads
+    return d % vec == 0 and (d // vec) in (1, 2, 4, 8, 16) and (num_heads * up) % vec == 0
+
+
 class GTBlockWeights:
     """The operands of ONE processor block out of :func:`gt_processor_weights`: f32 ``w_in`` / ``b_in`` / ``w_p`` (results
     of the batched fold algebra -- autograd carries their gradients back to every block's parameters in one batched
@@ -954,7 +969,7 @@ def gt_processor_weights(sds: list, prefix: str, c: int, h: int, up: int, dtype:
     count = len(sds)
     km = ops.k_multiple(dtype)
     if (os.environ.get("ANEMOI_AMD_TRAIN_BATCHED_PARAMS", "1") == "0" or dtype != torch.bfloat16 or count < 2
-            or up > FOLD_MAX_UP or c % km != 0 or (h * up) % km != 0):
+            or not folded_edge_route(dtype, c, h, up) or c % km != 0 or (h * up) % km != 0):
         return None
     names = ("lin_self", "lin_query", "lin_key", "lin_value", "lin_edge", "projection", "node_dst_mlp.1", "node_dst_mlp.3")
     key = lambda sd, n, part: sd.get(f"{prefix}.{n}.{part}")  # noqa: E731
@@ -1033,7 +1048,7 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
         else:
             att = _GTEdgeAttentionSelf.apply(sq, edge_attr_csr, plan, h, up)
         return _gt_tail(att, x, sd, prefix, None, act, eps, prepared)
-    if up > FOLD_MAX_UP:  # many edge attributes: lin_edge as a GEMM, the conv on explicit per-edge features
+    if not folded_edge_route(x.dtype, c, h, up):  # lin_edge as a GEMM, the conv on explicit per-edge features
         xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
         sq = linear(xh, torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight")], 0),
                     torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias")], 0))
@@ -1069,9 +1084,10 @@ def gt_mapper_block(x_src: Optional[Tensor], x_dst: Tensor, sd: dict, prefix: st
         kv = kv_fn(w_kv, b_kv, g("layer_norm1.weight"), g("layer_norm1.bias"))
     else:
         kv = linear(layer_norm(x_src, g("layer_norm1.weight"), g("layer_norm1.bias"), eps), w_kv, b_kv)
-    if sq_fn is None or up > FOLD_MAX_UP:
+    folded = folded_edge_route(x_dst.dtype, c, h, up)
+    if sq_fn is None or not folded:
         xd, x_dst = layer_norm_skip(x_dst, g("layer_norm2.weight"), g("layer_norm2.bias"), eps)
-    if up > FOLD_MAX_UP:  # see gt_processor_block
+    if not folded:  # see gt_processor_block
         sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight")], 0),
                     torch.cat([g("lin_self.bias"), g("lin_query.bias")], 0))
         att = gt_conv(sq[:, c:], kv[:, :c], kv[:, c:], _explicit_edge_features(sd, prefix, edge_attr_csr, x_dst.dtype),
@@ -1148,10 +1164,8 @@ def model_forward(sd: dict, graph: dict, x: Tensor, *, num_heads: int, num_layer
         raise NotImplementedError("autograd.model_forward: an ensemble dimension > 1 only with batch size 1 (the "
                                   "reference repeats the node attributes per batch element only)")
     bs = b * ens  # rows are ordered (batch, ensemble, grid) as in the reference's rearrange (:173-177)
-    head_dim = sd["processor.proc.0.blocks.0.lin_query.weight"].shape[0] // num_heads
-    if head_dim % 4 != 0:
-        raise NotImplementedError(f"autograd.model_forward: head size {head_dim} must be a multiple of 4 "
-                                  "(the folded edge kernels own whole 16-byte channel groups per lane)")
+    # (any head size: the blocks take the folded edge kernels where they exist for it, else the conv on explicit edge features
+    #  with zero-padded heads -- folded_edge_route)
 
     def node_attrs(name):
         parts = [sd[f"node_attributes.latlons_{name}"]]

@@ -745,6 +745,14 @@ class GraphConvBaseBlock(BaseBlock, ABC):
     def forward(self, x, edge_attr: Tensor, edge_index: Tensor, shapes: tuple, model_comm_group=None, size=None):
         """``(new nodes, new edge state)`` -- reference layers/block.py:157-167."""
 
+    @staticmethod
+    def _check_width(width: int, dtype) -> None:
+        """The node / edge width splits the first edge-MLP Linear into column blocks that are GEMM operands of their own
+        (K = width): it has to be a whole number of the GEMM's K slabs, as the graph-transformer blocks' hidden width."""
+        mult = ops.k_multiple(dtype)
+        if width % mult != 0:
+            raise NotImplementedError(f"hidden width {width} must be a multiple of {mult} for {dtype} on the MI355X path")
+
 
 class GraphConvProcessorBlock(GraphConvBaseBlock):
     """Edge-MLP message passing on one node set (reference layers/block.py:170-223, layers/conv.py:27-76)."""
@@ -756,6 +764,7 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
         from their owners by one all-to-all-v (C values per halo node) while the edge-side GEMM runs."""
         dtype = x.dtype
         c = x.shape[1]
+        self._check_width(c, dtype)
         edge_mlp, node_mlp = self.conv.edge_mlp.native(), self.node_mlp.native()
         lin1 = edge_mlp.steps[0][1]
         act1 = edge_mlp.steps[0][2]
@@ -824,6 +833,7 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         and edge GEMMs run."""
         dtype = x_dst.dtype
         c = x_dst.shape[1]
+        self._check_width(c, dtype)
         edge_mlp, node_mlp = self.conv.edge_mlp.native(), self.node_mlp.native()
         lin1, act1 = edge_mlp.steps[0][1], edge_mlp.steps[0][2]
         w_dst = self._packed.get(("w1_dst", dtype), [lin1.weight], lambda: runtime.pack_weight([lin1.weight[:, :c]], dtype))
