@@ -37,6 +37,8 @@ for case in cases:
             idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
             cfg = model_config(proc, channels, 4, heads, multistep=multistep, trainable=trainable, proc_chunks=chunks,
                                window_size=64, mappers=maps)
+            if os.environ.get("SWEEP_MAPPER_CHUNKS"):  # (the mappers' own num_chunks: row chunks of their node MLPs)
+                cfg["model"]["encoder"]["num_chunks"] = cfg["model"]["decoder"]["num_chunks"] = int(os.environ["SWEEP_MAPPER_CHUNKS"])
             model = AnemoiModelEncProcDec(model_config=cfg, data_indices=idx, graph_data=graph).to(dev).train(train)
             for m in model.modules():
                 if hasattr(m, "dropout_p"):
