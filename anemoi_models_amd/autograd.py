@@ -707,13 +707,13 @@ def gt_conv(q: Tensor, k: Tensor, v: Tensor, e_csr: Tensor, x_r: Optional[Tensor
         # carries sqrt(D_pad / D).  Plain torch ops around the same autograd node: the gradients of the real columns are
         # exact, those of the padding are discarded by the slice.
         def pad(t):
-            return torch.nn.functional.pad(t.reshape(t.shape[0], num_heads, d), (0, d_pad - d)).reshape(t.shape[0], -1)
+            return torch.nn.functional.pad(t.reshape(t.shape[0], num_heads, d), (0, d_pad - d)).reshape(t.shape[0], num_heads * d_pad)
 
         kvp = torch.cat([pad(k), pad(v)], dim=1)
         cp = num_heads * d_pad
         out = _GTConv.apply(pad(q) * (d_pad / d) ** 0.5, kvp[:, :cp], kvp[:, cp:], pad(e_csr),
                             None if x_r is None else pad(x_r), plan, num_heads, *drop)
-        out = out.reshape(out.shape[0], num_heads, d_pad)[:, :, :d].reshape(out.shape[0], c)
+        out = out.reshape(out.shape[0], num_heads, d_pad)[:, :, :d].reshape(out.shape[0], c).contiguous()  # (D = 1: a strided view)
     else:
         out = _GTConv.apply(q, k, v, e_csr, x_r, plan, num_heads, *drop)
     return out if out.dtype == out_dtype else out.to(out_dtype)
@@ -1052,8 +1052,11 @@ def gt_processor_block(x: Tensor, sd: dict, prefix: str, edge_attr_csr: Tensor, 
         xh = layer_norm(x, g("layer_norm1.weight"), g("layer_norm1.bias"), eps)
         sq = linear(xh, torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight")], 0),
                     torch.cat([g("lin_self.bias"), g("lin_query.bias"), g("lin_key.bias"), g("lin_value.bias")], 0))
-        att = gt_conv(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:], _explicit_edge_features(sd, prefix, edge_attr_csr, x.dtype),
-                      sq[:, :c], plan, h)
+        if plan.col.shape[0] == 0:  # an edge set without edges: the conv's sums are empty, x_r passes through
+            att = sq[:, :c].contiguous()
+        else:
+            att = gt_conv(sq[:, c:2 * c], sq[:, 2 * c:3 * c], sq[:, 3 * c:],
+                          _explicit_edge_features(sd, prefix, edge_attr_csr, x.dtype), sq[:, :c], plan, h)
         return _gt_tail(att, x, sd, prefix, None, act, eps)
     w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x.device)
     w_in = torch.cat([g("lin_self.weight"), g("lin_query.weight"), g("lin_key.weight"), g("lin_value.weight"), w_u], 0)
@@ -1090,8 +1093,11 @@ def gt_mapper_block(x_src: Optional[Tensor], x_dst: Tensor, sd: dict, prefix: st
     if not folded:  # see gt_processor_block
         sq = linear(xd, torch.cat([g("lin_self.weight"), g("lin_query.weight")], 0),
                     torch.cat([g("lin_self.bias"), g("lin_query.bias")], 0))
-        att = gt_conv(sq[:, c:], kv[:, :c], kv[:, c:], _explicit_edge_features(sd, prefix, edge_attr_csr, x_dst.dtype),
-                      sq[:, :c], plan, h)
+        if plan.col.shape[0] == 0:  # (see gt_processor_block)
+            att = sq[:, :c].contiguous()
+        else:
+            att = gt_conv(sq[:, c:], kv[:, :c], kv[:, c:], _explicit_edge_features(sd, prefix, edge_attr_csr, x_dst.dtype),
+                          sq[:, :c], plan, h)
         return _gt_tail(att, x_dst, sd, prefix, None, act, eps)
     w_u, b_u, w_t = _lin_edge_fold(sd, prefix, c, h, up, x_dst.device)
     w_sq = torch.cat([g("lin_self.weight"), g("lin_query.weight"), w_u], 0)

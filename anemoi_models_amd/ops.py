@@ -187,6 +187,8 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: str = "I
         out = torch.empty((x.shape[0], n), dtype=out_dtype or x.dtype, device=x.device)
     if act not in _lib.ACT_CODES:
         raise RuntimeError(f"activation {act} is not supported by the fused Linear kernel")
+    if x.shape[0] == 0:  # (an edge set without edges, an empty shard: torch hands out null pointers for empty tensors)
+        return out
     alg = (x.shape[0] * k + n * k) * x.element_size() + x.shape[0] * n * (out.element_size() + (
         0 if residual is None else residual.element_size()))
     fuse_stats = stats_eps is not None and act == "Identity" and out.dtype == x.dtype and _rows(out).shape[1] == n
@@ -662,6 +664,8 @@ def convert_pad(src: Tensor, dtype: torch.dtype, ld_out: Optional[int] = None) -
     rows, cols = src.shape
     ld = cols if ld_out is None else ld_out
     out = torch.empty((rows, ld), dtype=dtype, device=src.device)
+    if rows == 0:  # (an edge set without edges: torch hands out a null pointer for the empty tensor)
+        return out
     st = _lib.load().anemoi_convert_pad(dtype_code(src.dtype), src.data_ptr(), _ld(src), dtype_code(dtype),
                                         out.data_ptr(), ld, rows, cols, _stream())
     _lib.check(st, "anemoi_convert_pad")

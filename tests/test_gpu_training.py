@@ -909,6 +909,53 @@ def test_blocks_outside_the_folded_edge_kernels_train_through_the_explicit_conv(
     _compare_block_grads(blk, rsd, tol=tol)
 
 
+@pytest.mark.parametrize("mode,c,h,edge_dim", [("fp32", 64, 16, 3), ("bf16", 128, 16, 11), ("fp32", 96, 8, 11), ("bf16", 192, 4, 3),
+                                               ("fp32", 128, 16, 23), ("fp32", 32, 32, 4)])
+def test_blocks_train_on_an_edge_set_without_edges(mode, c, h, edge_dim, monkeypatch):
+    """E = 0 (PyG's propagate takes an empty edge_index; the op fuzzer found the differentiable blocks' explicit-conv route
+    raising on it in round 6 -- empty GEMM operands, an ambiguous reshape): processor and mapper block, folded and explicit
+    routes, head size 1 included: the output is the oracle's, the backward runs and every gradient it returns is the oracle's."""
+    from anemoi_models_amd.layers.block import GraphTransformerMapperBlock, GraphTransformerProcessorBlock
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", mode)
+    tol = 2e-3 if mode == "fp32" else 8e-2
+    g = torch.Generator().manual_seed(c + h)
+    n, n_src = 70, 45
+    ei = torch.zeros(2, 0, dtype=torch.int64)
+    ea0 = torch.zeros(0, edge_dim)
+    torch.manual_seed(3)
+    for mapper in (False, True):
+        if mapper:
+            blk = GraphTransformerMapperBlock(c, 2 * c, c, edge_dim=edge_dim, num_heads=h)
+            xs0, xd0 = torch.randn(n_src, c, generator=g), torch.randn(n, c, generator=g)
+            rsd = {"x." + k: v.detach().double().requires_grad_() for k, v in blk.named_parameters()}
+            ins_r = [xs0.double().requires_grad_(), xd0.double().requires_grad_()]
+            want = ref.gt_mapper_block(rsd, "x", ins_r[0], ins_r[1], ea0.double(), ei, h)
+            blk = blk.to(DEV)
+            ins = [t.to(DEV).requires_grad_() for t in (xs0, xd0)]
+            (_, y), _ = blk((ins[0], ins[1]), ea0.to(DEV), ei.to(DEV), None, 1, size=(n_src, n))
+        else:
+            blk = GraphTransformerProcessorBlock(c, 2 * c, c, edge_dim=edge_dim, num_heads=h)
+            x0 = torch.randn(n, c, generator=g)
+            rsd = {"x." + k: v.detach().double().requires_grad_() for k, v in blk.named_parameters()}
+            ins_r = [x0.double().requires_grad_()]
+            want = ref.gt_processor_block(rsd, "x", ins_r[0], ea0.double(), ei, h)
+            blk = blk.to(DEV)
+            ins = [x0.to(DEV).requires_grad_()]
+            y, _ = blk(ins[0], ea0.to(DEV), ei.to(DEV), None, 1)
+        assert rel_err(y.detach(), want.detach()) < tol
+        want.sum().backward()
+        y.float().sum().backward()
+        assert rel_err(ins[-1].grad, ins_r[-1].grad) < tol  # the destination rows' gradient
+        scale = max(float(v.grad.abs().max()) for v in rsd.values() if v.grad is not None)
+        for k, p in blk.named_parameters():
+            want_g = rsd["x." + k].grad
+            if p.grad is None:  # nothing reached this parameter: the oracle's gradient is zero (keys / values / lin_edge)
+                assert want_g is None or float(want_g.abs().max()) <= 1e-12 * scale, k
+            else:
+                assert float((p.grad.cpu() - want_g.float()).abs().max()) <= tol * max(float(want_g.abs().max()), 0.02 * scale), k
+
+
 @pytest.mark.parametrize("pair", [False, True])
 def test_graph_conv_module_forward_and_backward(golden_blocks, pair):
     """``GraphConv.forward`` on its own (reference layers/conv.py:62-76): ``edges_new = edge_mlp(cat[x_i, x_j, e]) + e``
