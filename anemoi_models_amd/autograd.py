@@ -1133,6 +1133,8 @@ class _PermuteRows(torch.autograd.Function):
 
 def permute_rows(x: Tensor, perm: Tensor) -> Tensor:
     """Differentiable ``x[perm]`` for a row permutation ``perm`` (int64)."""
+    if x.shape[0] == 0 and perm.numel() == 0:  # (an edge set without edges)
+        return x
     return _PermuteRows.apply(x, perm)
 
 

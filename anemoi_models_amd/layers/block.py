@@ -770,6 +770,10 @@ class GraphConvProcessorBlock(GraphConvBaseBlock):
         act1 = edge_mlp.steps[0][2]
         if lin1.in_features != 3 * c or e_csr.shape[1] != c:
             raise ValueError(f"GNN block expects node / edge width {lin1.in_features // 3}, got {c} / {e_csr.shape[1]}")
+        if e_csr.shape[0] == 0 and halo is None:  # an edge set without edges: empty new state, zero sums, nothing launched on it
+            xcat = torch.zeros((x.shape[0], 2 * c), dtype=dtype, device=x.device)
+            xcat[:, :c].copy_(x)
+            return node_mlp(xcat, residual=x), e_csr
         # W1 [x_i | x_j | e] = (W1a x)_i + (W1b x)_j + W1c e : node part as ONE [N, 2C] GEMM, edge part as [E, C] GEMM
         w_nodes = self._packed.get(("w1_nodes", dtype), [lin1.weight],
                                    lambda: runtime.pack_weight([lin1.weight[:, :c], lin1.weight[:, c:2 * c]], dtype))
@@ -836,6 +840,15 @@ class GraphConvMapperBlock(GraphConvBaseBlock):
         self._check_width(c, dtype)
         edge_mlp, node_mlp = self.conv.edge_mlp.native(), self.node_mlp.native()
         lin1, act1 = edge_mlp.steps[0][1], edge_mlp.steps[0][2]
+        if e_csr.shape[0] == 0 and halo is None:  # (see GraphConvProcessorBlock.native)
+            def lone(x, second):  # node_mlp(cat[x, second]) + x
+                xcat = torch.zeros((x.shape[0], 2 * c), dtype=dtype, device=x.device)
+                xcat[:, :c].copy_(x)
+                if second is not None:
+                    xcat[:, c:].copy_(second)
+                return node_mlp(xcat, residual=x)
+
+            return (lone(x_src, x_src) if self.update_src_nodes else x_src, lone(x_dst, None)), e_csr
         w_dst = self._packed.get(("w1_dst", dtype), [lin1.weight], lambda: runtime.pack_weight([lin1.weight[:, :c]], dtype))
         w_src = self._packed.get(("w1_src", dtype), [lin1.weight],
                                  lambda: runtime.pack_weight([lin1.weight[:, c:2 * c]], dtype))

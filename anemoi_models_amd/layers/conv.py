@@ -10,6 +10,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import torch
 from torch import Tensor
 from torch import nn
 
@@ -67,8 +68,21 @@ class GraphTransformerConv(nn.Module):
                 f"Encountered tensors with {key.shape[0]} source / {query.shape[0]} destination rows, "
                 f"but expected {plan.n_src} / {plan.n_dst}"
             )
-        return ops.gt_edge_attention(query, key, value, x_r, edge_attr_csr, edge_dim, w_edge, b_edge, plan.rowptr,
-                                     plan.col, num_heads)
+        try:
+            return ops.gt_edge_attention(query, key, value, x_r, edge_attr_csr, edge_dim, w_edge, b_edge, plan.rowptr,
+                                         plan.col, num_heads)
+        except NotImplementedError:
+            if query.shape[1] // num_heads <= 64:
+                raise
+        # heads beyond the generic kernel's 64 channels that the fast kernels do not take either (bf16 heads of 80 / 96 / 112;
+        # heads of 128 with more edge attributes than the fast kernels carry): lin_edge as a GEMM, the conv on explicit edge
+        # features with zero-padded heads -- the route the differentiable blocks take for such shapes
+        # (autograd.folded_edge_route)
+        from .. import autograd
+
+        with torch.no_grad():
+            e = autograd.linear(edge_attr_csr[:, :edge_dim].to(query.dtype), w_edge, b_edge)
+            return autograd.gt_conv(query, key, value, e, x_r, plan, num_heads)
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, edge_attr: Tensor, edge_index: Tensor,
                 size=None) -> Tensor:
@@ -143,7 +157,6 @@ class GraphConv(nn.Module):
         grad = training.wants_grad(self, x_src, x_dst, edge_attr)
         with torch.enable_grad() if grad else torch.no_grad():
             e_csr, inv = training._csr_round_trip(plan, edge_attr, dtype)
-            e_new = training._gnn_edge_update(self.edge_mlp, training._cast(x_dst, dtype), training._cast(x_src, dtype),
-                                              e_csr, plan)
-            out = autograd.segment_sum(e_new, plan)
+            e_new, out = training.gnn_message_pass(self.edge_mlp, training._cast(x_dst, dtype), training._cast(x_src, dtype),
+                                                   e_csr, plan)
             return out, autograd.permute_rows(e_new, inv)

@@ -277,17 +277,24 @@ def _gnn_edge_update(conv_mlp, x_dst: Tensor, x_src: Tensor, e_csr: Tensor, plan
     return sequential(nn.Sequential(*rest), h, residual=e_csr)
 
 
+def gnn_message_pass(conv_mlp, x_dst: Tensor, x_src: Tensor, e_csr: Tensor, plan):
+    """``(new edge state, its sum over the destinations)`` of ``GraphConv`` (reference layers/conv.py:62-76).  An edge set
+    without edges (PyG's propagate takes one) has an empty new state and zero sums: nothing is launched on empty operands."""
+    if e_csr.shape[0] == 0:
+        return e_csr, x_dst.new_zeros(x_dst.shape)
+    e_new = _gnn_edge_update(conv_mlp, x_dst, x_src, e_csr, plan)
+    return e_new, autograd.segment_sum(e_new, plan)
+
+
 def gnn_processor_block_csr(block, x: Tensor, e_csr: Tensor, plan):
     """``GraphConvProcessorBlock`` (reference layers/block.py:193-223) on an edge state kept in CSR order."""
-    e_new = _gnn_edge_update(block.conv.edge_mlp, x, x, e_csr, plan)
-    agg = autograd.segment_sum(e_new, plan)
+    e_new, agg = gnn_message_pass(block.conv.edge_mlp, x, x, e_csr, plan)
     return mlp(block.node_mlp, torch.cat([x, agg], dim=1), residual=x), e_new
 
 
 def gnn_mapper_block_csr(block, x_src: Tensor, x_dst: Tensor, e_csr: Tensor, plan):
     """``GraphConvMapperBlock`` (reference layers/block.py:226-286)."""
-    e_new = _gnn_edge_update(block.conv.edge_mlp, x_dst, x_src, e_csr, plan)
-    agg = autograd.segment_sum(e_new, plan)
+    e_new, agg = gnn_message_pass(block.conv.edge_mlp, x_dst, x_src, e_csr, plan)
     new_dst = mlp(block.node_mlp, torch.cat([x_dst, agg], dim=1), residual=x_dst)
     new_src = mlp(block.node_mlp, torch.cat([x_src, x_src], dim=1), residual=x_src) if block.update_src_nodes else x_src
     return (new_src, new_dst), e_new
@@ -295,6 +302,8 @@ def gnn_mapper_block_csr(block, x_src: Tensor, x_dst: Tensor, e_csr: Tensor, pla
 
 def _csr_round_trip(plan, edge_attr: Tensor, dtype):
     perm = plan.perm.long()
+    if perm.numel() == 0:
+        return _cast(edge_attr, dtype), perm
     inv = torch.empty_like(perm)
     inv[perm] = torch.arange(perm.shape[0], device=perm.device)
     return autograd.permute_rows(_cast(edge_attr, dtype), perm), inv

@@ -956,6 +956,64 @@ def test_blocks_train_on_an_edge_set_without_edges(mode, c, h, edge_dim, monkeyp
                 assert float((p.grad.cpu() - want_g.float()).abs().max()) <= tol * max(float(want_g.abs().max()), 0.02 * scale), k
 
 
+@pytest.mark.parametrize("mode,c,h,edge_dim", [("bf16", 192, 2, 4), ("bf16", 128, 1, 23), ("bf16", 256, 2, 23), ("fp32", 96, 8, 11)])
+def test_graph_transformer_block_inference_at_heads_the_edge_kernels_do_not_take(mode, c, h, edge_dim, monkeypatch):
+    """The INFERENCE route of a block at head sizes beyond the generic edge kernel's 64 channels that the fast kernels do not
+    take either (bf16 heads of 96; heads of 128 with 23 edge attributes) used to raise from the kernel dispatch (found by the
+    block fuzzer in round 6); it now runs lin_edge as a GEMM and the conv on explicit edge features, as the training route
+    does.  Against the oracle; the last case (heads of 12, the generic kernel) is the control."""
+    from anemoi_models_amd.layers.block import GraphTransformerProcessorBlock
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", mode)
+    g = torch.Generator().manual_seed(c + edge_dim)
+    n, e = 150, 1800
+    torch.manual_seed(2)
+    blk = GraphTransformerProcessorBlock(c, 2 * c, c, edge_dim=edge_dim, num_heads=h)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n - 1, (e,), generator=g)])
+    x0, ea0 = torch.randn(n, c, generator=g), torch.randn(e, edge_dim, generator=g)
+    sd = {"x." + k: v.detach().double() for k, v in blk.named_parameters()}
+    want = ref.gt_processor_block(sd, "x", x0.double(), ea0.double(), ei, h)
+    blk = blk.to(DEV).eval()
+    with torch.no_grad():
+        y, _ = blk(x0.to(DEV), ea0.to(DEV), ei.to(DEV), None, 1)
+    assert rel_err(y, want) < (2e-3 if mode == "fp32" else 8e-2)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("train", [False, True])
+def test_gnn_blocks_on_an_edge_set_without_edges(mode, train, monkeypatch):
+    """GraphConvProcessorBlock / GraphConvMapperBlock with E = 0 (reference layers/block.py:193-286 through PyG's propagate on
+    an empty edge_index): empty new edge state, the node MLP sees zero sums.  Inference and training route against the oracle
+    (both raised on the empty operands until the block fuzzer of round 6)."""
+    from anemoi_models_amd.layers.block import GraphConvMapperBlock, GraphConvProcessorBlock
+
+    monkeypatch.setenv("ANEMOI_AMD_DTYPE", mode)
+    tol = 2e-3 if mode == "fp32" else 8e-2
+    c, n, n_src = 128, 60, 45
+    g = torch.Generator().manual_seed(8)
+    ei, ea0 = torch.zeros(2, 0, dtype=torch.int64), torch.zeros(0, c)
+    torch.manual_seed(4)
+    x0, xs0 = torch.randn(n, c, generator=g), torch.randn(n_src, c, generator=g)
+    for blk, is_mapper in ((GraphConvProcessorBlock(c, c), False), (GraphConvMapperBlock(c, c, update_src_nodes=True), True)):
+        sd = {"x." + k: v.detach().double() for k, v in blk.named_parameters()}
+        if is_mapper:
+            (ws, wd), we = ref.gnn_mapper_block(sd, "x", xs0.double(), x0.double(), ea0.double(), ei, True)
+        else:
+            wd, we = ref.gnn_processor_block(sd, "x", x0.double(), ea0.double(), ei)
+        blk = blk.to(DEV).train(train)
+        xd, xs = x0.to(DEV).requires_grad_(train), xs0.to(DEV).requires_grad_(train)
+        with torch.enable_grad() if train else torch.no_grad():
+            if is_mapper:
+                (ys, yd), ye = blk((xs, xd), ea0.to(DEV), ei.to(DEV), (None, None, None), size=(n_src, n))
+                assert rel_err(ys.detach(), ws) < tol
+            else:
+                yd, ye = blk(xd, ea0.to(DEV), ei.to(DEV), (None, None, None))
+            assert rel_err(yd.detach(), wd) < tol and ye.shape == we.shape == (0, c)
+            if train:
+                yd.float().sum().backward()
+                assert xd.grad is not None and bool(torch.isfinite(xd.grad).all())
+
+
 @pytest.mark.parametrize("pair", [False, True])
 def test_graph_conv_module_forward_and_backward(golden_blocks, pair):
     """``GraphConv.forward`` on its own (reference layers/conv.py:62-76): ``edges_new = edge_mlp(cat[x_i, x_j, e]) + e``
