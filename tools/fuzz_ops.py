@@ -513,13 +513,83 @@ def fuzz_gnn_and_transformer_blocks():
     print(f"GNN / Transformer blocks, forward + backward against the oracle's autograd: {bad} bad of {n_run}", flush=True)
 
 
-fuzz_linear()
-fuzz_gt_blocks_training()
-fuzz_gnn_and_transformer_blocks()
-fuzz_conv_dropout()
-fuzz_mhsa()
-fuzz_edge_attention()
-fuzz_edge_scheduled()
-fuzz_edge_groups()
-fuzz_rows()
-fuzz_weight_grad()
+def fuzz_models():
+    """AnemoiModelEncProcDec, whole forward (and backward for half of the cases) against the oracle: random processor / mapper
+    families, widths, heads, batch sizes, multistep inputs, variable counts, trainable sizes, chunkings on the O32 graph."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.models import AnemoiModelEncProcDec
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+    from oracle import reference_path as ref
+    from test_oracle_golden import graph_tensors
+
+    graph = build_graph("o32_ico2")
+    gt = graph_tensors(graph)
+    n_grid = graph["data"].num_nodes
+    bad, n_run = 0, max(n_cases // 12, 4)
+    for case in range(n_run):
+        bf16 = rng.random() < 0.5
+        os.environ["ANEMOI_AMD_DTYPE"] = "bf16" if bf16 else "fp32"
+        proc = rng.choice(["GraphTransformer", "GNN", "Transformer"])
+        maps = rng.choice(["GraphTransformer", "GraphTransformer", "GNN"])
+        channels, heads = rng.choice([(64, 16), (128, 8), (64, 4), (128, 16), (192, 16)])
+        b, multistep = rng.choice([(1, 2), (2, 2), (1, 1), (3, 1), (1, 3)])
+        n_prog, n_forc, n_diag = rng.choice([(10, 2, 1), (5, 0, 0), (1, 0, 3), (26, 6, 1), (7, 3, 2)])
+        trainable, layers, chunks = rng.choice([8, 8, 0, 3]), rng.choice([2, 4]), rng.choice([1, 2])
+        train = rng.random() < 0.5
+        what = f"model {proc} / {maps} mappers C={channels} H={heads} B={b} T={multistep} vars={n_prog}+{n_forc}+{n_diag} " \
+               f"trainable={trainable} layers={layers} chunks={chunks} {'bf16' if bf16 else 'f32'} {'train' if train else 'eval'}"
+        try:
+            torch.manual_seed(seed * 11 + case)
+            idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
+            cfg = model_config(proc, channels, layers, heads, multistep=multistep, trainable=trainable, proc_chunks=chunks,
+                               window_size=512, mappers=maps)
+            model = AnemoiModelEncProcDec(model_config=cfg, data_indices=idx, graph_data=graph)
+            with torch.no_grad():
+                for name, p in model.named_parameters():
+                    if name.endswith("trainable"):
+                        p.normal_(0.0, 0.1)
+            for m in model.modules():
+                if hasattr(m, "dropout_p"):
+                    m.dropout_p = 0.0
+            x0 = torch.randn(b, multistep, 1, n_grid, idx.num_input, generator=torch.Generator().manual_seed(case))
+            sd = {k: (v.detach().double().requires_grad_() if v.is_floating_point() else v.detach())
+                  for k, v in model.state_dict(keep_vars=True).items()}
+            kw = dict(num_heads=heads, num_layers=layers, num_chunks=chunks, prognostic_in=list(range(n_prog)),
+                      prognostic_out=list(range(n_prog)), processor=proc, mappers=maps)
+            gt64 = {k: (v.double() if v.is_floating_point() else v) for k, v in gt.items()}
+            want = ref.model_forward(sd, gt64, x0.double(), **kw)
+            model = model.to(dev).train(train)
+            tol_o, tol_g = (5e-2, 1e-1) if bf16 else (2e-4, 5e-3)
+            with torch.enable_grad() if train else torch.no_grad():
+                y = model(x0.to(dev))
+            err = rel(y.detach().cpu(), want.detach())
+            worst, worst_k = 0.0, ""
+            if train:
+                w = torch.randn(want.shape, generator=torch.Generator().manual_seed(2))
+                (want * w.double()).sum().backward()
+                (y.float() * w.to(dev)).sum().backward()
+                grads = {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
+                g_scale = max(float(g_.abs().max()) for g_ in grads.values())
+                for k, p in model.named_parameters():
+                    if k not in grads or float(grads[k].abs().max()) <= 1e-9 * g_scale:
+                        continue
+                    e_k = float("inf") if p.grad is None else float(
+                        (p.grad.cpu().double() - grads[k]).abs().max() / max(float(grads[k].abs().max()), 2e-2 * g_scale))
+                    if e_k > worst:
+                        worst, worst_k = e_k, k
+            if err > tol_o or worst > tol_g or not torch.isfinite(y).all():
+                bad += 1
+                print(f"  {what}: out {err:.2e}, worst gradient {worst:.2e} ({worst_k})", flush=True)
+        except Exception as exc:  # noqa: BLE001
+            bad += 1
+            print(f"  {what}: {type(exc).__name__}: {str(exc).splitlines()[0][:160]}", flush=True)
+    os.environ.pop("ANEMOI_AMD_DTYPE", None)
+    print(f"whole models against the oracle (forward; backward for the training cases): {bad} bad of {n_run}", flush=True)
+
+
+ONLY = os.environ.get("FUZZ_ONLY")  # e.g. FUZZ_ONLY=models: one fuzzer alone
+for fn in (fuzz_linear, fuzz_models, fuzz_gt_blocks_training, fuzz_gnn_and_transformer_blocks, fuzz_conv_dropout, fuzz_mhsa, fuzz_edge_attention, fuzz_edge_scheduled, fuzz_edge_groups, fuzz_rows, fuzz_weight_grad):
+    if ONLY is None or ONLY in fn.__name__:
+        fn()
