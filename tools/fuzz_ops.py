@@ -589,7 +589,56 @@ def fuzz_models():
     print(f"whole models against the oracle (forward; backward for the training cases): {bad} bad of {n_run}", flush=True)
 
 
+def fuzz_mhsa_backward():
+    """autograd.mhsa forward + backward (the MFMA dK/dV and dQ kernels at D = 64 / 32 in bf16, the VALU kernels elsewhere) at
+    random sequence lengths around the tile borders, batch sizes, windows, with and without dropout (mask restated from the
+    kernels' hash): output and d qkv against torch autograd in f64."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from anemoi_models_amd import autograd
+    from test_gpu_training import _dropout_keep_mask
+
+    bad, n_run = 0, n_cases // 4
+    for case in range(n_run):
+        d = rng.choice([64, 64, 32, 32, 16, 8, 48, 5])
+        dtype = torch.bfloat16 if (d in (64, 32) or rng.random() < 0.4) else torch.float32
+        h, b = rng.choice([1, 2, 4]), rng.choice([1, 1, 2])
+        s_len = rng.choice([rng.randint(1, 130), 32 * rng.randint(1, 40) + rng.choice([-1, 0, 1]), 512 * rng.randint(1, 3) + rng.choice([0, 2]),
+                            rng.randint(130, 1500)])
+        window = rng.choice([-1, -1, rng.randint(0, 200)])
+        p = rng.choice([0.0, 0.0, 0.1, 0.35])
+        seed_c = rng.randint(1, 2**31 - 1)
+        c = h * d
+        g = torch.Generator().manual_seed(seed * 100003 + case)
+        qkv = (torch.randn(b * s_len, 3 * c, generator=g) * 0.7).to(dtype)
+        dout = torch.randn(b * s_len, c, generator=g).to(dtype)
+        ref_in = qkv.double().requires_grad_()
+        q, k, v = (t.reshape(b, s_len, h, d).permute(0, 2, 1, 3) for t in ref_in.split(c, dim=1))
+        sc = q @ k.transpose(-1, -2) / d**0.5
+        if window >= 0:
+            i = torch.arange(s_len)
+            sc = sc.masked_fill((i[:, None] - i[None, :]).abs() > window, float("-inf"))
+        prob = torch.softmax(sc, -1)
+        if p > 0:
+            prob = prob * _dropout_keep_mask(seed_c, p, b, h, s_len) * (1.0 / (1.0 - p))
+        want = (prob @ v).permute(0, 2, 1, 3).reshape(b * s_len, c)
+        want.backward(dout.double())
+        what = f"mhsa backward case {case}: {dtype} b={b} s={s_len} h={h} d={d} window={window} p={p}"
+        try:
+            x = qkv.to(dev).requires_grad_()
+            got = autograd.mhsa(x, b, h, window, p, seed_c)
+            got.backward(dout.to(dev))
+            e_o = rel(got.detach().cpu(), want.detach())
+            e_g = float((x.grad.cpu().double() - ref_in.grad).abs().max() / ref_in.grad.abs().max().clamp_min(1e-9))
+            if e_o > (2e-5 if dtype == torch.float32 else 2e-2) or e_g > (2e-4 if dtype == torch.float32 else 3e-2):
+                bad += 1
+                print(f"  {what}: out {e_o:.2e}, d qkv {e_g:.2e}", flush=True)
+        except Exception as exc:  # noqa: BLE001
+            bad += 1
+            print(f"  {what}: {type(exc).__name__}: {str(exc).splitlines()[0][:160]}", flush=True)
+    print(f"mhsa forward + backward (with dropout): {bad} bad of {n_run}", flush=True)
+
+
 ONLY = os.environ.get("FUZZ_ONLY")  # e.g. FUZZ_ONLY=models: one fuzzer alone
-for fn in (fuzz_linear, fuzz_models, fuzz_gt_blocks_training, fuzz_gnn_and_transformer_blocks, fuzz_conv_dropout, fuzz_mhsa, fuzz_edge_attention, fuzz_edge_scheduled, fuzz_edge_groups, fuzz_rows, fuzz_weight_grad):
+for fn in (fuzz_linear, fuzz_models, fuzz_gt_blocks_training, fuzz_gnn_and_transformer_blocks, fuzz_conv_dropout, fuzz_mhsa, fuzz_mhsa_backward, fuzz_edge_attention, fuzz_edge_scheduled, fuzz_edge_groups, fuzz_rows, fuzz_weight_grad):
     if ONLY is None or ONLY in fn.__name__:
         fn()
