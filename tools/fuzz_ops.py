@@ -589,6 +589,85 @@ def fuzz_models():
     print(f"whole models against the oracle (forward; backward for the training cases): {bad} bad of {n_run}", flush=True)
 
 
+def fuzz_interface():
+    """AnemoiModelInterface.predict_step (normalise -> model -> de-normalise; the second call rides on the fused input /
+    output kernels) over random normaliser methods and statistics, families, batch sizes, multistep inputs, f32 / bf16, against
+    the oracle's predict_step on the interface's own state dict."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import numpy as np
+
+    from anemoi_models_amd.graphs.synthetic import build_graph
+    from anemoi_models_amd.interface import AnemoiModelInterface
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import model_config
+    from oracle import reference_path as ref
+    from test_oracle_golden import graph_tensors
+
+    graph = build_graph("o32_ico2")
+    gt = {k: (v.double() if v.is_floating_point() else v) for k, v in graph_tensors(graph).items()}
+    n_grid = graph["data"].num_nodes
+    bad, n_run = 0, max(n_cases // 12, 4)
+    for case in range(n_run):
+        bf16 = rng.random() < 0.5
+        os.environ["ANEMOI_AMD_DTYPE"] = "bf16" if bf16 else "fp32"
+        proc = rng.choice(["GraphTransformer", "GNN", "Transformer"])
+        maps = rng.choice(["GraphTransformer", "GraphTransformer", "GNN"])
+        n_prog, n_forc, n_diag = rng.choice([(10, 2, 1), (5, 1, 0), (3, 0, 2), (12, 4, 1)])
+        b, multistep, layers = rng.choice([1, 2, 3]), rng.choice([1, 2, 3]), 2
+        what = f"interface {proc} / {maps} mappers vars={n_prog}+{n_forc}+{n_diag} B={b} T={multistep} {'bf16' if bf16 else 'f32'}"
+        try:
+            torch.manual_seed(seed * 13 + case)
+            idx = SimpleDataIndices(n_prognostic=n_prog, n_forcing=n_forc, n_diagnostic=n_diag)
+            names = sorted(idx.name_to_index, key=idx.name_to_index.get)
+            pool = [n for n in names]
+            rng.shuffle(pool)
+            methods = {"default": rng.choice(["mean-std", "mean-std", "min-max", "none"])}
+            for m in ("min-max", "max", "std", "none"):
+                take = [pool.pop() for _ in range(min(len(pool), rng.randint(0, 2)))]
+                if take:
+                    methods[m] = take
+            cfg = model_config(proc, 64, layers, 16, multistep=multistep, proc_chunks=1, mappers=maps)
+            cfg["data"] = {"forcing": [n for n in names if n.startswith("forc")], "diagnostic": [n for n in names if n.startswith("diag")],
+                           "processors": {"normalizer": {"_target_": "anemoi.models.preprocessing.normalizer.InputNormalizer",
+                                                         "config": methods}}}
+            cfg["model"]["model"] = {"_target_": "anemoi.models.models.encoder_processor_decoder.AnemoiModelEncProcDec"}
+            cfg = type(cfg)(cfg)
+            nv = len(names)
+            gs = np.random.default_rng(seed * 17 + case)
+            mean, sd_ = gs.normal(0, 5, nv), gs.uniform(0.5, 4.0, nv)
+            mean, sd_ = mean.astype(np.float32), sd_.astype(np.float32)
+            stats = {"mean": mean, "stdev": sd_, "minimum": (mean - 3 * sd_ - gs.uniform(0, 1, nv)).astype(np.float32),
+                     "maximum": (np.abs(mean) + 3 * sd_ + 1.0).astype(np.float32)}
+            iface = AnemoiModelInterface(config=cfg, graph_data=graph, statistics=stats, data_indices=idx, metadata={})
+            for m in iface.modules():
+                if hasattr(m, "dropout_p"):
+                    m.dropout_p = 0.0
+            in_idx = idx.data.input.full.long()
+            z = torch.randn((b, multistep, n_grid, n_prog + n_forc), generator=torch.Generator().manual_seed(case))
+            batch = z * torch.from_numpy(sd_).float()[in_idx] + torch.from_numpy(mean).float()[in_idx]
+            with torch.no_grad():
+                for name, p_ in iface.named_parameters():
+                    if name.endswith("trainable"):
+                        p_.normal_(0.0, 0.1)
+            sd = {k: (v.detach().double() if v.is_floating_point() else v.detach()) for k, v in iface.state_dict().items()}
+            want = ref.predict_step(sd, gt, batch.double(), multi_step=multistep, num_heads=16, num_layers=layers, num_chunks=1,
+                                    prognostic_in=list(range(n_prog)), prognostic_out=list(range(n_prog)), processor=proc,
+                                    mappers=maps)
+            iface = iface.to(dev).eval()
+            y1 = iface.predict_step(batch.to(dev))
+            y2 = iface.predict_step(batch.to(dev))
+            e12 = rel(y2.cpu(), y1.cpu())
+            e_o = rel(y2.cpu(), want)
+            if e_o > (5e-2 if bf16 else 5e-4) or e12 > (5e-2 if bf16 else 1e-4) or not torch.isfinite(y2).all():
+                bad += 1
+                print(f"  {what} methods={methods}: vs oracle {e_o:.2e}, second call vs first {e12:.2e}", flush=True)
+        except Exception as exc:  # noqa: BLE001
+            bad += 1
+            print(f"  {what}: {type(exc).__name__}: {str(exc).splitlines()[0][:200]}", flush=True)
+    os.environ.pop("ANEMOI_AMD_DTYPE", None)
+    print(f"interface predict_step against the oracle: {bad} bad of {n_run}", flush=True)
+
+
 def fuzz_mhsa_backward():
     """autograd.mhsa forward + backward (the MFMA dK/dV and dQ kernels at D = 64 / 32 in bf16, the VALU kernels elsewhere) at
     random sequence lengths around the tile borders, batch sizes, windows, with and without dropout (mask restated from the
@@ -639,6 +718,6 @@ def fuzz_mhsa_backward():
 
 
 ONLY = os.environ.get("FUZZ_ONLY")  # e.g. FUZZ_ONLY=models: one fuzzer alone
-for fn in (fuzz_linear, fuzz_models, fuzz_gt_blocks_training, fuzz_gnn_and_transformer_blocks, fuzz_conv_dropout, fuzz_mhsa, fuzz_mhsa_backward, fuzz_edge_attention, fuzz_edge_scheduled, fuzz_edge_groups, fuzz_rows, fuzz_weight_grad):
+for fn in (fuzz_linear, fuzz_models, fuzz_interface, fuzz_gt_blocks_training, fuzz_gnn_and_transformer_blocks, fuzz_conv_dropout, fuzz_mhsa, fuzz_mhsa_backward, fuzz_edge_attention, fuzz_edge_scheduled, fuzz_edge_groups, fuzz_rows, fuzz_weight_grad):
     if ONLY is None or ONLY in fn.__name__:
         fn()
