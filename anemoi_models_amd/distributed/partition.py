@@ -554,6 +554,8 @@ def sharded_training_forward(model, x: Tensor, group) -> Tensor:
     enc, proc, dec = model.encoder, model.processor, model.decoder
     heads = proc.proc[0].blocks[0].num_heads if gt_proc else (enc.proc.num_heads if gt_maps else 1)
     if tfm_proc and proc.proc[0].blocks[0].attention.num_heads % sp.world != 0:
+        # (as the reference: its _headsalltoall / _seqalltoall size every receive buffer like the rank's own piece,
+        #  distributed/transformer.py:41-52,77 -- equal head shares; the inference route's HeadExchange takes uneven ones)
         raise NotImplementedError("node-partitioned training of the Transformer processor needs heads divisible by the group size")
     if gt_proc or gt_maps:
         training._check_heads(model.num_channels, heads, dtype)

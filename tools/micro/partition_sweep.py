@@ -19,6 +19,11 @@ CASES = [
     (5, "o48_ico3", 128, 2, 8, "bf16", "GraphTransformer", True), (4, "o32_ico2", 64, 2, 16, "fp32", "GNN_all", True),
     (3, "o32_ico2", 128, 2, 4, "fp32", "Transformer", True), (6, "o48_ico3", 192, 2, 16, "bf16", "GraphTransformer", False),
 ]
+if len(sys.argv) > 1:  # python tools/micro/partition_sweep.py 3,o32_ico2,128,2,4,fp32,Transformer,train ...
+    CASES = []
+    for a in sys.argv[1:]:
+        w, gname, c, l_, h, dt, fam, tr = a.split(",")
+        CASES.append((int(w), gname, int(c), int(l_), int(h), dt, fam, tr == "train"))
 bad = 0
 for n, (world, graph, channels, layers, heads, dtype, family, train) in enumerate(CASES):
     port = 29900 + (os.getpid() + n) % 90
