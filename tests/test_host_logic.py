@@ -950,3 +950,32 @@ def test_no_mfma_result_is_touched_before_its_wait_states_in_the_built_kernels()
         assert not found, f"{name}.hip: {len(found)} wide buffer stores whose data is overwritten too early, first: {found[0]}"
     if seen == 0:
         pytest.skip("no device listing in anemoi_models_amd/lib/obj (run __graft_entry__.build() from source)")
+
+
+def test_folded_edge_route_and_conv_head_size():
+    """Which edge route the differentiable GraphTransformer blocks take per shape (``autograd.folded_edge_route``) and the head
+    size the explicit-edge conv kernels run a head at (``autograd.conv_head_size``): pure host logic behind the shapes the
+    round-6 sweeps found refused."""
+    import torch
+
+    from anemoi_models_amd import autograd
+
+    f32, bf16 = torch.float32, torch.bfloat16
+    # the benchmark shapes stay on the folded kernels
+    assert autograd.folded_edge_route(bf16, 1024, 16, 12) and autograd.folded_edge_route(bf16, 512, 16, 12)
+    assert autograd.folded_edge_route(f32, 64, 16, 4) and autograd.folded_edge_route(bf16, 64, 16, 4)  # D = 4: f32 edge phase
+    assert not autograd.folded_edge_route(bf16, 128, 8, 40)        # more edge attributes than the folded kernels carry
+    assert not autograd.folded_edge_route(f32, 96, 8, 12)          # heads of 12: three f32 lanes
+    assert not autograd.folded_edge_route(bf16, 192, 16, 12)       # heads of 12 in bf16: f32 edge phase, still three lanes
+    assert not autograd.folded_edge_route(bf16, 192, 4, 4)         # heads of 48: six bf16 lanes
+    assert not autograd.folded_edge_route(f32, 160, 16, 12)        # heads of 10: not a multiple of 4
+    assert not autograd.folded_edge_route(bf16, 64, 1, 4)          # one bf16 head: H * up = 4 breaks the 16-byte row pitch
+    assert autograd.folded_edge_route(bf16, 64, 1, 8) and autograd.folded_edge_route(f32, 64, 1, 4)
+    assert not autograd.folded_edge_route(f32, 64, 3, 4)           # channels that do not split into the heads
+    for d, dtype, want in ((4, f32, 4), (5, f32, 8), (12, f32, 16), (20, f32, 32), (48, f32, 64), (64, f32, 64), (1, f32, 4),
+                           (8, bf16, 8), (5, bf16, 8), (12, bf16, 16), (48, bf16, 64), (96, bf16, 128), (128, bf16, 128)):
+        assert autograd.conv_head_size(d, dtype) == want, (d, dtype)
+    for d, dtype in ((65, f32), (129, bf16)):
+        with pytest.raises(NotImplementedError):
+            autograd.conv_head_size(d, dtype)
+
