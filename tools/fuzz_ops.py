@@ -589,6 +589,76 @@ def fuzz_models():
     print(f"whole models against the oracle (forward; backward for the training cases): {bad} bad of {n_run}", flush=True)
 
 
+def fuzz_hierarchical():
+    """AnemoiModelEncProcDecHierarchical against oracle.hierarchical_forward: 2 / 3 hidden levels, level processing on / off,
+    widths, heads, batch sizes, multistep inputs, f32 / bf16; forward, and backward for half of the cases."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from anemoi_models_amd.graphs.synthetic import build_hierarchical_graph
+    from anemoi_models_amd.models import AnemoiModelEncProcDecHierarchical
+    from anemoi_models_amd.utils.indices import SimpleDataIndices
+    from anemoi_models_amd.utils.presets import hierarchical_model_config
+    from oracle import reference_path as ref
+    from test_oracle_golden import hier_graph_tensors
+
+    graphs = {2: build_hierarchical_graph("o32", (2, 1)), 3: build_hierarchical_graph("o32", (3, 2, 1))}
+    bad, n_run = 0, max(n_cases // 12, 4)
+    for case in range(n_run):
+        bf16 = rng.random() < 0.5
+        os.environ["ANEMOI_AMD_DTYPE"] = "bf16" if bf16 else "fp32"
+        levels, level_process = rng.choice([2, 3]), rng.random() < 0.7
+        channels, heads = rng.choice([(64, 16), (64, 4), (128, 8)])
+        b, multistep, level_layers, trainable = rng.choice([1, 2]), rng.choice([1, 2, 3]), rng.choice([1, 2]), rng.choice([8, 0, 3])
+        train = rng.random() < 0.5
+        hidden = [f"hidden_{i + 1}" for i in range(levels)]
+        graph = graphs[levels]
+        what = f"hierarchical levels={levels} level_process={level_process} C={channels} H={heads} B={b} T={multistep} " \
+               f"layers={level_layers} trainable={trainable} {'bf16' if bf16 else 'f32'} {'train' if train else 'eval'}"
+        try:
+            torch.manual_seed(seed * 19 + case)
+            idx = SimpleDataIndices(n_prognostic=10, n_forcing=2, n_diagnostic=1)
+            cfg = hierarchical_model_config(channels, heads, hidden=hidden, level_layers=level_layers, level_process=level_process,
+                                            multistep=multistep, trainable=trainable)
+            model = AnemoiModelEncProcDecHierarchical(model_config=cfg, data_indices=idx, graph_data=graph)
+            with torch.no_grad():
+                for name, p in model.named_parameters():
+                    if name.endswith("trainable"):
+                        p.normal_(0.0, 0.1)
+            x0 = torch.randn(b, multistep, 1, graph["data"].num_nodes, idx.num_input, generator=torch.Generator().manual_seed(case))
+            sd = {k: (v.detach().double().requires_grad_() if v.is_floating_point() else v.detach())
+                  for k, v in model.state_dict(keep_vars=True).items()}
+            gt = {k: (v.double() if v.is_floating_point() else v) for k, v in hier_graph_tensors(graph, hidden).items()}
+            want = ref.hierarchical_forward(sd, gt, x0.double(), hidden=hidden, num_heads=heads, level_layers=level_layers,
+                                            prognostic_in=list(range(10)), prognostic_out=list(range(10)),
+                                            level_process=level_process)
+            model = model.to(dev).train(train)
+            with torch.enable_grad() if train else torch.no_grad():
+                y = model(x0.to(dev))
+            err = rel(y.detach().cpu(), want.detach())
+            worst, worst_k = 0.0, ""
+            if train:
+                w = torch.randn(want.shape, generator=torch.Generator().manual_seed(2))
+                (want * w.double()).sum().backward()
+                (y.float() * w.to(dev)).sum().backward()
+                grads = {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
+                g_scale = max(float(g_.abs().max()) for g_ in grads.values())
+                for k, p in model.named_parameters():
+                    if k not in grads or float(grads[k].abs().max()) <= 1e-9 * g_scale:
+                        continue
+                    e_k = float("inf") if p.grad is None else float(
+                        (p.grad.cpu().double() - grads[k]).abs().max() / max(float(grads[k].abs().max()), 2e-2 * g_scale))
+                    if e_k > worst:
+                        worst, worst_k = e_k, k
+            tol_o, tol_g = (5e-2, 1e-1) if bf16 else (2e-4, 5e-3)
+            if err > tol_o or worst > tol_g or not torch.isfinite(y).all():
+                bad += 1
+                print(f"  {what}: out {err:.2e}, worst gradient {worst:.2e} ({worst_k})", flush=True)
+        except Exception as exc:  # noqa: BLE001
+            bad += 1
+            print(f"  {what}: {type(exc).__name__}: {str(exc).splitlines()[0][:200]}", flush=True)
+    os.environ.pop("ANEMOI_AMD_DTYPE", None)
+    print(f"hierarchical models against the oracle (forward; backward for the training cases): {bad} bad of {n_run}", flush=True)
+
+
 def fuzz_interface():
     """AnemoiModelInterface.predict_step (normalise -> model -> de-normalise; the second call rides on the fused input /
     output kernels) over random normaliser methods and statistics, families, batch sizes, multistep inputs, f32 / bf16, against
@@ -718,6 +788,6 @@ def fuzz_mhsa_backward():
 
 
 ONLY = os.environ.get("FUZZ_ONLY")  # e.g. FUZZ_ONLY=models: one fuzzer alone
-for fn in (fuzz_linear, fuzz_models, fuzz_interface, fuzz_gt_blocks_training, fuzz_gnn_and_transformer_blocks, fuzz_conv_dropout, fuzz_mhsa, fuzz_mhsa_backward, fuzz_edge_attention, fuzz_edge_scheduled, fuzz_edge_groups, fuzz_rows, fuzz_weight_grad):
+for fn in (fuzz_linear, fuzz_models, fuzz_hierarchical, fuzz_interface, fuzz_gt_blocks_training, fuzz_gnn_and_transformer_blocks, fuzz_conv_dropout, fuzz_mhsa, fuzz_mhsa_backward, fuzz_edge_attention, fuzz_edge_scheduled, fuzz_edge_groups, fuzz_rows, fuzz_weight_grad):
     if ONLY is None or ONLY in fn.__name__:
         fn()
