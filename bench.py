@@ -207,7 +207,7 @@ def hold_stream(ms: float) -> None:
     sleep(int(ms * _SLEEP_TICKS_PER_MS))
 
 
-HOLD_BELOW_MS, HOLD_MS = 10.0, 8.0  # steps shorter than HOLD_BELOW_MS: the instrumented forward is enqueued behind an 8-ms hold
+HOLD_BELOW_MS, HOLD_MS = 10.0, 8.0  # steps shorter than HOLD_BELOW_MS: the instrumented forward is enqueued behind a hold of >= 8 ms
 
 
 def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic_ok: bool = True, step_ms: float = 1e9):
@@ -218,15 +218,28 @@ def profile_pass(model, x, group, dtype_name: str, detail: bool = False, traffic
     without, 30.4 by rocprofv3; `gpurun_out/r06_s44`)."""
     from anemoi_models_amd import ops
 
+    def instrumented():
+        ops.PROFILE = []
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            model(x, group) if group is not None else model(x)
+        host_ms = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        return host_ms
+
     torch.cuda.synchronize()
     hold = os.environ.get("ANEMOI_AMD_BENCH_HOLD_MS")
-    hold = float(hold) if hold is not None else (HOLD_MS if step_ms < HOLD_BELOW_MS else 0.0)
+    if hold is not None:
+        hold = float(hold)
+    elif step_ms < HOLD_BELOW_MS:
+        # long enough for the host to enqueue the WHOLE instrumented forward: a rehearsal says how long that takes on this
+        # box (4 - 9 ms at config 2, box by box: a fixed 8 ms was not always enough)
+        hold = min(40.0, max(HOLD_MS, 1.5 * instrumented() + 2.0))
+    else:
+        hold = 0.0
     if hold > 0:
         hold_stream(hold)
-    ops.PROFILE = []
-    with torch.no_grad():
-        model(x, group) if group is not None else model(x)
-    torch.cuda.synchronize()
+    instrumented()
     records, ops.PROFILE = ops.PROFILE, None
     if detail:
         detail_table(records, dtype_name)
